@@ -1,0 +1,139 @@
+/*
+ * sparse_linear_hip.h — C ABI of the MI355X (gfx950) backend for the
+ * SpMV / SpGEMM / sparse-add / transpose / compress hot path under
+ * ttuegel/sparse-linear's Data.Matrix.Sparse.
+ *
+ * There is no existing FFI for these operations in the reference (they are
+ * pure Haskell); the reference's designated seam is
+ *   withConstMatrix :: Matrix v a -> (CInt -> CInt -> Ptr CInt -> Ptr CInt -> Ptr a -> IO b) -> IO b
+ *       (sparse-linear/src/Data/Matrix/Sparse/Foreign.hs:24-41)   inputs
+ *   fromForeign :: Bool -> CInt -> CInt -> Ptr CInt -> Ptr CInt -> Ptr a -> IO (Matrix v a)
+ *       (Foreign.hs:43-88)                                           outputs
+ * so every matrix crosses this ABI as that 5-tuple
+ *   (int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax):
+ * CSC, 0-based, int32, Ap[ncols] = nnz, row indices strictly ascending inside
+ * a column, borrowed only for the duration of the call.  The LU / solve step
+ * keeps its existing link-time ABI: see umfpack_hip.h.
+ *
+ * Conventions (those of the reference's UMFPACK binding,
+ * suitesparse/src/Numeric/LinearAlgebra/Umfpack.hs:60-102):
+ *   - every function returns an int status: 0 OK, < 0 fatal (the Haskell
+ *     wrapper throws), > 0 warning;
+ *   - handles are allocated by the callee and written through a void**; the
+ *     free function takes that void**, releases everything and nulls it, and
+ *     may be called from any thread (GHC finalizer thread);
+ *   - output matrices of unknown size are returned as malloc()'d arrays so
+ *     that `fromForeign False` can adopt them (it frees with C free(),
+ *     Foreign.hs:54-55); spl_free is free().
+ *   - all entry points are thread-safe; a handle may be used from several
+ *     threads for read-only operations (spmv) concurrently.
+ *
+ * No torch / HIP types appear in any signature; `stream` arguments are an
+ * opaque hipStream_t passed as void* (NULL = the default stream).
+ */
+#ifndef SPARSE_LINEAR_HIP_H
+#define SPARSE_LINEAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (UMFPACK's numbering where one exists) ------------------- */
+#define SPL_OK 0
+#define SPL_WARNING_singular_matrix 1
+#define SPL_ERROR_out_of_memory (-1)
+#define SPL_ERROR_invalid_handle (-3)
+#define SPL_ERROR_argument_missing (-5)
+#define SPL_ERROR_n_nonpositive (-6)
+#define SPL_ERROR_invalid_matrix (-8)   /* pointers not monotone / index out of range */
+#define SPL_ERROR_dimension_mismatch (-20) /* the reference's errorWithStackTrace sites */
+#define SPL_ERROR_index_out_of_bounds (-21) /* compress: Sparse.hs:196-212 */
+#define SPL_ERROR_index_overflow (-22)  /* result does not fit int32 at the seam */
+#define SPL_ERROR_device (-30)          /* HIP runtime failure, no GPU, wrong arch */
+#define SPL_ERROR_internal (-911)
+
+/* human-readable name of a status code (static string) */
+const char *spl_status_string(int status);
+/* number of visible HIP devices (0 if none); never fails */
+int spl_device_count(void);
+/* last HIP error text seen by this thread ("" if none) */
+const char *spl_last_error(void);
+void spl_free(void *p);
+
+/* ---- one-shot operations on borrowed host CSC 5-tuples ---------------------- */
+
+/* axpy_ (Sparse.hs:433-453):  y <- A x + y.  xlen must equal ncols and ylen
+ * nrows, else SPL_ERROR_dimension_mismatch (the reference's two guards). */
+int spl_gaxpy(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax,
+              int xlen, const double *x, int ylen, double *y);
+
+/* mulV (Sparse.hs:464-471):  y = A x  (y need not be initialised). */
+int spl_mulv(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax,
+             int xlen, const double *x, double *y);
+
+/* y <- A^T x + y : a pure gather on the CSC arrays. */
+int spl_gaxpy_t(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax,
+                int xlen, const double *x, int ylen, double *y);
+
+/* mulM (Sparse.hs:473-498): C = A B with B dense brows x bcols, row-major
+ * (hmatrix's default order); C is nrows x bcols row-major. */
+int spl_mulm(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax,
+             int brows, int bcols, const double *B, double *C);
+
+/* transpose (Sparse.hs:301-329): CSC(A) -> CSC(A^T) == CSR(A).  Caller
+ * allocates Tp[nrows+1], Ti[nnz], Tx[nnz]. */
+int spl_transpose(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax,
+                  int *Tp, int *Ti, double *Tx);
+
+/* ---- device-resident matrix handles ------------------------------------------ */
+
+/* Upload the CSC 5-tuple once and build the row-major (CSR) image the SpMV
+ * kernels read.  The inputs may be freed as soon as the call returns. */
+int spl_matrix_create(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax,
+                      void **H);
+/* Same, but keep only the rows of the part-th of nparts nnz-balanced
+ * contiguous row blocks (1-D row partition). */
+int spl_matrix_create_rowblock(int nrows, int ncols, const int *Ap, const int *Ai,
+                               const double *Ax, int part, int nparts, void **H);
+/* Build from CSR arrays directly (== the CSC arrays of A^T). Rows [row0,row0+nrows_local)
+ * of a matrix with nrows_global rows. */
+int spl_matrix_create_csr(int64_t nrows_global, int64_t ncols, int64_t row0, int64_t nrows_local,
+                          const int *rowptr, const int *colidx, const double *val, void **H);
+/* Synthetic workloads generated on the device (include/spl_synth.h):
+ * kind 0 random(n,K), 1 banded(n), 2 poisson2d(m) [n=m*m], 3 poisson3d(m) [n=m^3].
+ * Generates rows [row0,row1) only. */
+int spl_matrix_create_synthetic(int kind, int64_t n_or_m, int K, uint64_t seed, int64_t row0,
+                                int64_t row1, void **H);
+void spl_matrix_free(void **H);
+
+/* info[0..5] = nrows_global, ncols, row0, nrows_local, nnz_local, device */
+int spl_matrix_info(void *H, int64_t info[6]);
+/* copy the device CSR image back: rowptr[nrows_local+1] (relative to the block,
+ * rowptr[0]=0), colidx[nnz_local], val[nnz_local] */
+int spl_matrix_export_csr(void *H, int64_t *rowptr, int *colidx, double *val);
+/* transpose the block on the device (Sparse.hs:301-329) and copy out its
+ * column-major image: colptr[ncols+1], rowidx[nnz_local] (LOCAL row ids, ascending
+ * inside a column), val[nnz_local] — i.e. the reference's own CSC Matrix fields */
+int spl_matrix_export_csc(void *H, int64_t *colptr, int *rowidx, double *val);
+
+/* y = A x  /  y <- A x + y  with HOST vectors (upload, run, download) */
+int spl_matrix_mulv(void *H, int xlen, const double *x, double *y);
+int spl_matrix_gaxpy(void *H, int xlen, const double *x, int ylen, double *y);
+
+/* Device-resident SpMV: d_x (ncols doubles) and d_y (nrows_local doubles) are
+ * DEVICE pointers; the kernel is enqueued on `stream` and the call returns
+ * without synchronising.  accumulate != 0: y <- A x + y. */
+int spl_matrix_spmv_dev(void *H, const double *d_x, double *d_y, int accumulate, void *stream);
+/* select a kernel variant for spl_matrix_spmv_dev (tuning / ablation only):
+ * 0 = default.  Returns SPL_ERROR_argument_missing for an unknown variant. */
+int spl_matrix_set_variant(void *H, int variant);
+
+/* fill a device vector with the synthetic entries j in [j0,j1) */
+int spl_vector_synthetic_dev(uint64_t seed, int64_t j0, int64_t j1, double *d_x, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARSE_LINEAR_HIP_H */

@@ -1,0 +1,520 @@
+// abi.hip — the extern "C" surface declared in include/sparse_linear_hip.h.
+// Host-side marshalling only; every numerical step runs in a HIP kernel.
+#include <stdio.h>
+#include <vector>
+
+#include "common.hpp"
+
+namespace spl {
+
+static thread_local char g_last_error[512] = "";
+
+void set_last_error(const char *where, hipError_t e) {
+  snprintf(g_last_error, sizeof(g_last_error), "%s: %s", where, hipGetErrorString(e));
+}
+void set_last_error_text(const char *text) { snprintf(g_last_error, sizeof(g_last_error), "%s", text); }
+
+namespace {
+
+// run f(), mapping C++ failures to status codes
+template <typename F>
+int guarded(F &&f) {
+  try {
+    return f();
+  } catch (const DeviceError &e) {
+    return e.status;
+  } catch (const std::bad_alloc &) {
+    return SPL_ERROR_out_of_memory;
+  } catch (...) {
+    return SPL_ERROR_internal;
+  }
+}
+
+int current_device() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_last_error_text("no HIP device visible");
+    throw DeviceError{SPL_ERROR_device};
+  }
+  int dev = 0;
+  SPL_HIP(hipGetDevice(&dev));
+  return dev;
+}
+
+template <typename T>
+void upload(DBuf<T> &dst, const T *src, size_t n, hipStream_t s) {
+  dst.alloc(n);
+  if (n) SPL_HIP(hipMemcpyAsync(dst.get(), src, n * sizeof(T), hipMemcpyHostToDevice, s));
+}
+
+int check_tuple(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax) {
+  if (nrows < 0 || ncols < 0) return SPL_ERROR_n_nonpositive;
+  if (!Ap) return SPL_ERROR_argument_missing;
+  const int nnz = Ap[ncols];
+  if (nnz < 0) return SPL_ERROR_invalid_matrix;
+  if (nnz > 0 && (!Ai || !Ax)) return SPL_ERROR_argument_missing;
+  return SPL_OK;
+}
+
+// Build the row-major image of a CSC 5-tuple on the current device.
+// out receives rows [row0,row1) chosen as the part-th of nparts nnz-balanced blocks.
+int build_from_csc(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax, int part,
+                   int nparts, Matrix **out) {
+  int st = check_tuple(nrows, ncols, Ap, Ai, Ax);
+  if (st != SPL_OK) return st;
+  if (nparts < 1 || part < 0 || part >= nparts) return SPL_ERROR_argument_missing;
+  const int64_t nnz = Ap[ncols];
+  const int dev = current_device();
+  hipStream_t s = nullptr;
+
+  DBuf<int> dAp, dAi;
+  DBuf<double> dAx;
+  upload(dAp, Ap, (size_t)ncols + 1, s);
+  upload(dAi, Ai, (size_t)nnz, s);
+  upload(dAx, Ax, (size_t)nnz, s);
+  st = validate_compressed(dAp.get(), dAi.get(), ncols, nrows, nnz, s);
+  if (st != SPL_OK) return st;
+
+  Matrix *full = new Matrix();
+  full->device = dev;
+  full->nrows_global = nrows;
+  full->ncols = ncols;
+  full->row0 = 0;
+  full->nrows_local = nrows;
+  full->nnz = nnz;
+  try {
+    full->rowptr64.alloc((size_t)nrows + 1);
+    full->colidx.alloc((size_t)nnz);
+    full->val.alloc((size_t)nnz);
+    transpose_compressed(dAp.get(), dAi.get(), dAx.get(), ncols, nrows, nnz, full->rowptr64.get(),
+                         full->colidx.get(), full->val.get(), s);
+    if (nparts == 1) {
+      finalize_matrix(full, s);
+      *out = full;
+      return SPL_OK;
+    }
+    // nnz-balanced contiguous row blocks: block p starts at the first row whose
+    // pointer is >= nnz*p/nparts (identical on every rank: same input, same rule)
+    std::vector<int64_t> hptr((size_t)nrows + 1);
+    SPL_HIP(hipMemcpy(hptr.data(), full->rowptr64.get(), ((size_t)nrows + 1) * sizeof(int64_t),
+                      hipMemcpyDeviceToHost));
+    auto boundary = [&](int p) -> int64_t {
+      if (p <= 0) return 0;
+      if (p >= nparts) return nrows;
+      const int64_t target = (int64_t)(((__int128)nnz * p) / nparts);
+      int64_t lo = 0, hi = nrows;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) / 2;
+        if (hptr[(size_t)mid] < target) lo = mid + 1; else hi = mid;
+      }
+      return lo;
+    };
+    const int64_t r0 = boundary(part), r1 = boundary(part + 1);
+    Matrix *blk = new Matrix();
+    blk->device = dev;
+    blk->nrows_global = nrows;
+    blk->ncols = ncols;
+    blk->row0 = r0;
+    blk->nrows_local = r1 - r0;
+    const int64_t k0 = hptr[(size_t)r0], k1 = hptr[(size_t)r1];
+    blk->nnz = k1 - k0;
+    try {
+      std::vector<int64_t> rel((size_t)(r1 - r0) + 1);
+      for (int64_t i = 0; i <= r1 - r0; ++i) rel[(size_t)i] = hptr[(size_t)(r0 + i)] - k0;
+      upload(blk->rowptr64, rel.data(), rel.size(), s);
+      blk->colidx.alloc((size_t)blk->nnz);
+      blk->val.alloc((size_t)blk->nnz);
+      if (blk->nnz) {
+        SPL_HIP(hipMemcpyAsync(blk->colidx.get(), full->colidx.get() + k0, (size_t)blk->nnz * sizeof(int),
+                               hipMemcpyDeviceToDevice, s));
+        SPL_HIP(hipMemcpyAsync(blk->val.get(), full->val.get() + k0, (size_t)blk->nnz * sizeof(double),
+                               hipMemcpyDeviceToDevice, s));
+      }
+      SPL_HIP(hipStreamSynchronize(s));
+      finalize_matrix(blk, s);
+    } catch (...) {
+      delete blk;
+      throw;
+    }
+    delete full;
+    *out = blk;
+    return SPL_OK;
+  } catch (...) {
+    delete full;
+    throw;
+  }
+}
+
+// y (host) = A x (host) [+ y]
+int host_spmv(Matrix *m, int xlen, const double *x, int ylen, double *y, int accumulate) {
+  if ((int64_t)xlen != m->ncols) return SPL_ERROR_dimension_mismatch;     // Sparse.hs:438-441
+  if ((int64_t)ylen != m->nrows_local) return SPL_ERROR_dimension_mismatch;  // Sparse.hs:442-445
+  if ((xlen > 0 && !x) || (ylen > 0 && !y)) return SPL_ERROR_argument_missing;
+  DeviceGuard g(m->device);
+  hipStream_t s = nullptr;
+  DBuf<double> dx, dy;
+  upload(dx, x, (size_t)xlen, s);
+  if (accumulate) upload(dy, y, (size_t)ylen, s); else dy.alloc((size_t)ylen);
+  int st = launch_spmv(m, dx.get(), dy.get(), accumulate, s);
+  if (st != SPL_OK) return st;
+  if (ylen) SPL_HIP(hipMemcpyAsync(y, dy.get(), (size_t)ylen * sizeof(double), hipMemcpyDeviceToHost, s));
+  SPL_HIP(hipStreamSynchronize(s));
+  return SPL_OK;
+}
+
+__global__ __launch_bounds__(256) void transpose_dense_kernel(const double *__restrict__ in,
+                                                              double *__restrict__ out, int64_t rows,
+                                                              int64_t cols) {
+  // out[c*rows + r] = in[r*cols + c]
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = rows * cols, stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int64_t r = i / cols, c = i % cols;
+    out[c * rows + r] = in[i];
+  }
+}
+
+}  // namespace
+}  // namespace spl
+
+using namespace spl;
+
+extern "C" {
+
+const char *spl_status_string(int status) {
+  switch (status) {
+    case SPL_OK: return "OK";
+    case SPL_WARNING_singular_matrix: return "warning: singular matrix";
+    case SPL_ERROR_out_of_memory: return "out of memory";
+    case SPL_ERROR_invalid_handle: return "invalid handle";
+    case SPL_ERROR_argument_missing: return "argument missing or invalid";
+    case SPL_ERROR_n_nonpositive: return "negative dimension";
+    case SPL_ERROR_invalid_matrix: return "invalid matrix (pointers not monotone or index out of range)";
+    case SPL_ERROR_dimension_mismatch: return "dimension mismatch";
+    case SPL_ERROR_index_out_of_bounds: return "index out of bounds";
+    case SPL_ERROR_index_overflow: return "result does not fit 32-bit indices";
+    case SPL_ERROR_device: return "HIP device error";
+    case SPL_ERROR_internal: return "internal error";
+    default: return "unknown status";
+  }
+}
+
+int spl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *spl_last_error(void) { return g_last_error; }
+
+void spl_free(void *p) { free(p); }
+
+int spl_matrix_create(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax, void **H) {
+  return spl_matrix_create_rowblock(nrows, ncols, Ap, Ai, Ax, 0, 1, H);
+}
+
+int spl_matrix_create_rowblock(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax,
+                               int part, int nparts, void **H) {
+  if (!H) return SPL_ERROR_argument_missing;
+  *H = nullptr;
+  return guarded([&]() -> int {
+    Matrix *m = nullptr;
+    int st = build_from_csc(nrows, ncols, Ap, Ai, Ax, part, nparts, &m);
+    if (st == SPL_OK) *H = m;
+    return st;
+  });
+}
+
+int spl_matrix_create_csr(int64_t nrows_global, int64_t ncols, int64_t row0, int64_t nrows_local,
+                          const int *rowptr, const int *colidx, const double *val, void **H) {
+  if (!H) return SPL_ERROR_argument_missing;
+  *H = nullptr;
+  if (nrows_global < 0 || ncols < 0 || nrows_local < 0 || row0 < 0) return SPL_ERROR_n_nonpositive;
+  if (row0 + nrows_local > nrows_global || ncols > 0x7fffffffLL) return SPL_ERROR_argument_missing;
+  if (!rowptr) return SPL_ERROR_argument_missing;
+  const int64_t nnz = rowptr[nrows_local];
+  if (nnz < 0) return SPL_ERROR_invalid_matrix;
+  if (nnz > 0 && (!colidx || !val)) return SPL_ERROR_argument_missing;
+  return guarded([&]() -> int {
+    const int dev = current_device();
+    hipStream_t s = nullptr;
+    Matrix *m = new Matrix();
+    try {
+      m->device = dev;
+      m->nrows_global = nrows_global;
+      m->ncols = ncols;
+      m->row0 = row0;
+      m->nrows_local = nrows_local;
+      m->nnz = nnz;
+      DBuf<int> dptr;
+      upload(dptr, rowptr, (size_t)nrows_local + 1, s);
+      upload(m->colidx, colidx, (size_t)nnz, s);
+      upload(m->val, val, (size_t)nnz, s);
+      int st = validate_compressed(dptr.get(), m->colidx.get(), nrows_local, ncols, nnz, s);
+      if (st != SPL_OK) { delete m; return st; }
+      m->rowptr64.alloc((size_t)nrows_local + 1);
+      widen_i32_to_i64(dptr.get(), m->rowptr64.get(), nrows_local + 1, s);
+      finalize_matrix(m, s);
+    } catch (...) {
+      delete m;
+      throw;
+    }
+    *H = m;
+    return SPL_OK;
+  });
+}
+
+int spl_matrix_create_synthetic(int kind, int64_t n_or_m, int K, uint64_t seed, int64_t row0,
+                                int64_t row1, void **H) {
+  if (!H) return SPL_ERROR_argument_missing;
+  *H = nullptr;
+  if (kind < 0 || kind > 3 || n_or_m <= 0) return SPL_ERROR_argument_missing;
+  if (kind == 0 && (K < 1 || K > 64)) return SPL_ERROR_argument_missing;
+  int64_t n = n_or_m;
+  if (kind == 2) n = n_or_m * n_or_m;
+  if (kind == 3) n = n_or_m * n_or_m * n_or_m;
+  if (n > 0x7fffffffLL) return SPL_ERROR_index_overflow;
+  if (row0 < 0 || row1 < row0 || row1 > n) return SPL_ERROR_argument_missing;
+  return guarded([&]() -> int {
+    const int dev = current_device();
+    Matrix *m = new Matrix();
+    try {
+      m->device = dev;
+      m->nrows_global = n;
+      m->ncols = n;
+      m->row0 = row0;
+      m->nrows_local = row1 - row0;
+      generate_synthetic(m, kind, n_or_m, K, seed, nullptr);
+      finalize_matrix(m, nullptr);
+    } catch (...) {
+      delete m;
+      throw;
+    }
+    *H = m;
+    return SPL_OK;
+  });
+}
+
+void spl_matrix_free(void **H) {
+  if (!H || !*H) return;
+  Matrix *m = as_matrix(*H);
+  *H = nullptr;
+  if (!m) return;
+  int prev = -1;
+  const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+  (void)hipSetDevice(m->device);  // may run on a finalizer thread with another current device
+  m->magic = 0;
+  delete m;
+  if (have_prev) (void)hipSetDevice(prev);
+}
+
+int spl_matrix_info(void *H, int64_t info[6]) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  if (!info) return SPL_ERROR_argument_missing;
+  info[0] = m->nrows_global;
+  info[1] = m->ncols;
+  info[2] = m->row0;
+  info[3] = m->nrows_local;
+  info[4] = m->nnz;
+  info[5] = m->device;
+  return SPL_OK;
+}
+
+int spl_matrix_export_csr(void *H, int64_t *rowptr, int *colidx, double *val) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  if (!rowptr || (m->nnz > 0 && (!colidx || !val))) return SPL_ERROR_argument_missing;
+  return guarded([&]() -> int {
+    DeviceGuard g(m->device);
+    SPL_HIP(hipMemcpy(rowptr, m->rowptr64.get(), ((size_t)m->nrows_local + 1) * sizeof(int64_t),
+                      hipMemcpyDeviceToHost));
+    if (m->nnz) {
+      SPL_HIP(hipMemcpy(colidx, m->colidx.get(), (size_t)m->nnz * sizeof(int), hipMemcpyDeviceToHost));
+      SPL_HIP(hipMemcpy(val, m->val.get(), (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return SPL_OK;
+  });
+}
+
+int spl_matrix_export_csc(void *H, int64_t *colptr, int *rowidx, double *val) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  if (!colptr || (m->nnz > 0 && (!rowidx || !val))) return SPL_ERROR_argument_missing;
+  if (!m->rowptr.get()) return SPL_ERROR_index_overflow;
+  return guarded([&]() -> int {
+    DeviceGuard g(m->device);
+    hipStream_t s = nullptr;
+    DBuf<int64_t> dcp((size_t)m->ncols + 1);
+    DBuf<int> dri((size_t)m->nnz);
+    DBuf<double> dv((size_t)m->nnz);
+    transpose_compressed(m->rowptr.get(), m->colidx.get(), m->val.get(), m->nrows_local, m->ncols, m->nnz,
+                         dcp.get(), dri.get(), dv.get(), s);
+    SPL_HIP(hipMemcpy(colptr, dcp.get(), ((size_t)m->ncols + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (m->nnz) {
+      SPL_HIP(hipMemcpy(rowidx, dri.get(), (size_t)m->nnz * sizeof(int), hipMemcpyDeviceToHost));
+      SPL_HIP(hipMemcpy(val, dv.get(), (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return SPL_OK;
+  });
+}
+
+int spl_matrix_mulv(void *H, int xlen, const double *x, double *y) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  return guarded([&]() -> int { return host_spmv(m, xlen, x, (int)m->nrows_local, y, 0); });
+}
+
+int spl_matrix_gaxpy(void *H, int xlen, const double *x, int ylen, double *y) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  return guarded([&]() -> int { return host_spmv(m, xlen, x, ylen, y, 1); });
+}
+
+int spl_matrix_spmv_dev(void *H, const double *d_x, double *d_y, int accumulate, void *stream) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  if ((m->ncols > 0 && !d_x) || (m->nrows_local > 0 && !d_y)) return SPL_ERROR_argument_missing;
+  return guarded([&]() -> int {
+    DeviceGuard g(m->device);
+    return launch_spmv(m, d_x, d_y, accumulate, as_stream(stream));
+  });
+}
+
+int spl_matrix_set_variant(void *H, int variant) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  if (variant < 0 || variant >= kNumSpmvVariants) return SPL_ERROR_argument_missing;
+  m->variant = variant;
+  return SPL_OK;
+}
+
+int spl_vector_synthetic_dev(uint64_t seed, int64_t j0, int64_t j1, double *d_x, void *stream) {
+  if (j1 < j0) return SPL_ERROR_argument_missing;
+  if (j1 > j0 && !d_x) return SPL_ERROR_argument_missing;
+  return guarded([&]() -> int {
+    (void)current_device();
+    generate_vector(seed, j0, j1, d_x, as_stream(stream));
+    return SPL_OK;
+  });
+}
+
+// ---- one-shot operations ------------------------------------------------------------------
+
+int spl_gaxpy(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax, int xlen,
+              const double *x, int ylen, double *y) {
+  // the reference checks dimensions before touching anything (Sparse.hs:438-445)
+  if (nrows >= 0 && ncols >= 0 && (xlen != ncols || ylen != nrows)) return SPL_ERROR_dimension_mismatch;
+  return guarded([&]() -> int {
+    Matrix *m = nullptr;
+    int st = build_from_csc(nrows, ncols, Ap, Ai, Ax, 0, 1, &m);
+    if (st != SPL_OK) return st;
+    try {
+      st = host_spmv(m, xlen, x, ylen, y, 1);
+    } catch (...) {
+      delete m;
+      throw;
+    }
+    delete m;
+    return st;
+  });
+}
+
+int spl_mulv(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax, int xlen,
+             const double *x, double *y) {
+  if (nrows >= 0 && ncols >= 0 && xlen != ncols) return SPL_ERROR_dimension_mismatch;
+  return guarded([&]() -> int {
+    Matrix *m = nullptr;
+    int st = build_from_csc(nrows, ncols, Ap, Ai, Ax, 0, 1, &m);
+    if (st != SPL_OK) return st;
+    try {
+      st = host_spmv(m, xlen, x, nrows, y, 0);
+    } catch (...) {
+      delete m;
+      throw;
+    }
+    delete m;
+    return st;
+  });
+}
+
+int spl_gaxpy_t(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax, int xlen,
+                const double *x, int ylen, double *y) {
+  if (nrows >= 0 && ncols >= 0 && (xlen != nrows || ylen != ncols)) return SPL_ERROR_dimension_mismatch;
+  int st = check_tuple(nrows, ncols, Ap, Ai, Ax);
+  if (st != SPL_OK) return st;
+  // the CSC arrays of A are the CSR arrays of A^T: no conversion at all
+  void *h = nullptr;
+  st = spl_matrix_create_csr(ncols, nrows, 0, ncols, Ap, Ai, Ax, &h);
+  if (st != SPL_OK) return st;
+  st = spl_matrix_gaxpy(h, xlen, x, ylen, y);
+  spl_matrix_free(&h);
+  return st;
+}
+
+int spl_mulm(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax, int brows, int bcols,
+             const double *B, double *C) {
+  if (nrows >= 0 && ncols >= 0 && ncols != brows) return SPL_ERROR_dimension_mismatch;  // Sparse.hs:478
+  if (bcols < 0) return SPL_ERROR_n_nonpositive;
+  if ((int64_t)brows * bcols > 0 && !B) return SPL_ERROR_argument_missing;
+  if ((int64_t)nrows * bcols > 0 && !C) return SPL_ERROR_argument_missing;
+  return guarded([&]() -> int {
+    Matrix *m = nullptr;
+    int st = build_from_csc(nrows, ncols, Ap, Ai, Ax, 0, 1, &m);
+    if (st != SPL_OK) return st;
+    try {
+      hipStream_t s = nullptr;
+      const size_t nb = (size_t)brows * bcols, nc = (size_t)nrows * bcols;
+      DBuf<double> dB, dBt(nb), dCt(nc), dC(nc);
+      upload(dB, B, nb, s);
+      if (nb) hipLaunchKernelGGL(transpose_dense_kernel, dim3(1024), dim3(256), 0, s, dB.get(), dBt.get(),
+                                 (int64_t)brows, (int64_t)bcols);
+      for (int j = 0; j < bcols && st == SPL_OK; ++j)  // one axpy_ per column (Sparse.hs:482-488)
+        st = launch_spmv(m, dBt.get() + (size_t)j * brows, dCt.get() + (size_t)j * nrows, 0, s);
+      if (st == SPL_OK && nc) {
+        hipLaunchKernelGGL(transpose_dense_kernel, dim3(1024), dim3(256), 0, s, dCt.get(), dC.get(),
+                           (int64_t)bcols, (int64_t)nrows);
+        SPL_HIP(hipMemcpyAsync(C, dC.get(), nc * sizeof(double), hipMemcpyDeviceToHost, s));
+      }
+      SPL_HIP(hipStreamSynchronize(s));
+    } catch (...) {
+      delete m;
+      throw;
+    }
+    delete m;
+    return st;
+  });
+}
+
+int spl_transpose(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax, int *Tp, int *Ti,
+                  double *Tx) {
+  int st = check_tuple(nrows, ncols, Ap, Ai, Ax);
+  if (st != SPL_OK) return st;
+  if (!Tp) return SPL_ERROR_argument_missing;
+  const int64_t nnz = Ap[ncols];
+  if (nnz > 0 && (!Ti || !Tx)) return SPL_ERROR_argument_missing;
+  return guarded([&]() -> int {
+    (void)current_device();
+    hipStream_t s = nullptr;
+    DBuf<int> dAp, dAi, dTi((size_t)nnz), dTp((size_t)nrows + 1);
+    DBuf<double> dAx, dTx((size_t)nnz);
+    DBuf<int64_t> dTp64((size_t)nrows + 1);
+    upload(dAp, Ap, (size_t)ncols + 1, s);
+    upload(dAi, Ai, (size_t)nnz, s);
+    upload(dAx, Ax, (size_t)nnz, s);
+    int v = validate_compressed(dAp.get(), dAi.get(), ncols, nrows, nnz, s);
+    if (v != SPL_OK) return v;
+    transpose_compressed(dAp.get(), dAi.get(), dAx.get(), ncols, nrows, nnz, dTp64.get(), dTi.get(),
+                         dTx.get(), s);
+    narrow_i64_to_i32(dTp64.get(), dTp.get(), (int64_t)nrows + 1, s);
+    SPL_HIP(hipMemcpyAsync(Tp, dTp.get(), ((size_t)nrows + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (nnz) {
+      SPL_HIP(hipMemcpyAsync(Ti, dTi.get(), (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+      SPL_HIP(hipMemcpyAsync(Tx, dTx.get(), (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    SPL_HIP(hipStreamSynchronize(s));
+    return SPL_OK;
+  });
+}
+
+}  // extern "C"

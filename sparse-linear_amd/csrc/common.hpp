@@ -1,0 +1,130 @@
+// common.hpp — shared host-side plumbing of the gfx950 backend.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+
+#include "../../include/sparse_linear_hip.h"
+
+namespace spl {
+
+// thread-local text of the last HIP failure, returned by spl_last_error()
+void set_last_error(const char *where, hipError_t e);
+void set_last_error_text(const char *text);
+
+struct DeviceError {
+  int status;
+};
+
+#define SPL_HIP(expr)                                                        \
+  do {                                                                       \
+    hipError_t e_ = (expr);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      ::spl::set_last_error(#expr, e_);                                      \
+      throw ::spl::DeviceError{e_ == hipErrorOutOfMemory ? SPL_ERROR_out_of_memory \
+                                                         : SPL_ERROR_device}; \
+    }                                                                        \
+  } while (0)
+
+// RAII device buffer (hipMalloc / hipFree), movable
+template <typename T>
+struct DBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DBuf() = default;
+  explicit DBuf(size_t count) { alloc(count); }
+  DBuf(const DBuf &) = delete;
+  DBuf &operator=(const DBuf &) = delete;
+  DBuf(DBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DBuf &operator=(DBuf &&o) noexcept {
+    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~DBuf() { release(); }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    // +64 B slack: vector loads of the streaming kernels may read (never use) a
+    // few elements past the logical end
+    SPL_HIP(hipMalloc(reinterpret_cast<void **>(&p), (count ? count : 1) * sizeof(T) + 64));
+  }
+  void release() {
+    if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+  }
+  T *get() const { return p; }
+};
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// sets the device for the current thread and restores the previous one on exit
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  explicit DeviceGuard(int dev) {
+    SPL_HIP(hipGetDevice(&prev));
+    if (prev != dev) { SPL_HIP(hipSetDevice(dev)); changed = true; }
+  }
+  ~DeviceGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+};
+
+constexpr uint32_t kMatrixMagic = 0x53504C4Du;  // "SPLM"
+
+// A device-resident block of rows [row0, row0+nrows_local) of a sparse matrix
+// with nrows_global x ncols entries, stored row-major (CSR, int32 column
+// indices, int64 row pointers relative to the block).
+struct Matrix {
+  uint32_t magic = kMatrixMagic;
+  int device = 0;
+  int64_t nrows_global = 0, ncols = 0, row0 = 0, nrows_local = 0, nnz = 0;
+  DBuf<int64_t> rowptr64;  // nrows_local+1, always present
+  DBuf<int> rowptr;        // nrows_local+1, present iff nnz < 2^31
+  DBuf<int> colidx;        // nnz
+  DBuf<double> val;        // nnz
+  int variant = 0;
+  int64_t max_row_len = 0;
+};
+
+inline Matrix *as_matrix(void *h) {
+  Matrix *m = static_cast<Matrix *>(h);
+  return (m && m->magic == kMatrixMagic) ? m : nullptr;
+}
+
+// ---- device primitives (scan.hip) -------------------------------------------------
+// exclusive prefix sum of n counts; out has n+1 entries (out[n] = total).
+void exclusive_scan_i32_to_i64(const int *d_in, int64_t *d_out, int64_t n, hipStream_t s);
+void exclusive_scan_i64(const int64_t *d_in, int64_t *d_out, int64_t n, hipStream_t s);
+void narrow_i64_to_i32(const int64_t *d_in, int *d_out, int64_t n, hipStream_t s);
+void widen_i32_to_i64(const int *d_in, int64_t *d_out, int64_t n, hipStream_t s);
+
+// ---- CSR image construction (convert.hip) ------------------------------------------
+// validate a CSC/CSR pointer+index pair on the device: ptr[0]==0, monotone,
+// ptr[nmajor]==nnz, 0 <= idx < nminor.  Returns SPL_OK or SPL_ERROR_invalid_matrix.
+int validate_compressed(const int *d_ptr, const int *d_idx, int64_t nmajor, int64_t nminor,
+                        int64_t nnz, hipStream_t s);
+// Order-preserving transpose of compressed arrays (nmajor slices over nminor
+// indices): out_ptr64[nminor+1], out_idx[nnz], out_val[nnz]; inside each new
+// slice the old major index ascends (Sparse.hs:301-329).
+void transpose_compressed(const int *d_ptr, const int *d_idx, const double *d_val, int64_t nmajor,
+                          int64_t nminor, int64_t nnz, int64_t *out_ptr64, int *out_idx,
+                          double *out_val, hipStream_t s);
+// sort every segment [ptr[i], ptr[i+1]) of (key, val) pairs by key ascending
+void segmented_sort_pairs(const int64_t *d_ptr64, int64_t nseg, int *d_key, double *d_val,
+                          hipStream_t s);
+// finish a Matrix whose rowptr64/colidx/val are filled: int32 pointers, stats
+void finalize_matrix(Matrix *m, hipStream_t s);
+
+// ---- synthetic generators (generate.hip) --------------------------------------------
+void generate_synthetic(Matrix *m, int kind, int64_t n_or_m, int K, uint64_t seed, hipStream_t s);
+void generate_vector(uint64_t seed, int64_t j0, int64_t j1, double *d_x, hipStream_t s);
+
+// ---- SpMV (spmv.hip) --------------------------------------------------------------------
+// y = A x (accumulate == 0) or y <- A x + y, rows of the block; enqueued on s
+int launch_spmv(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s);
+constexpr int kNumSpmvVariants = 8;
+
+}  // namespace spl

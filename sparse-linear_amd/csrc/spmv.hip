@@ -1,0 +1,228 @@
+// spmv.hip — fp64 CSR SpMV for gfx950 (MI355X).
+//
+// Reference semantics: axpy_ / mulV, sparse-linear/src/Data/Matrix/Sparse.hs:433-471.
+// The reference walks CSC columns and scatters `y[r] = a*x[c] + y[r]`; per output
+// row that is the fold  acc <- a*x[c] + acc  over the row's entries in ascending
+// column order starting from y0[r] (0 for mulV).  The kernels below read the
+// row-major (CSR) image — bit for bit the CSC arrays of A^T — and keep exactly
+// that per-row order and the separately rounded multiply and add (this file is
+// compiled with -ffp-contract=off), so results are bit-identical to the
+// reference order for every row shorter than one LDS chunk.
+//
+// Kernel `spmv_stream` ("CSR-stream"): HBM-bound by design.
+//   * one wavefront owns 64 consecutive rows; its nnz range [S,E) is contiguous,
+//     so colidx/val are read as fully coalesced 8/16-byte-per-lane streams
+//     (non-temporal: each matrix byte is used once and must not evict x);
+//   * products a*x[c] are staged in a wavefront-private LDS chunk (no
+//     workgroup barrier anywhere: LDS operations of one wavefront complete in
+//     issue order);
+//   * lane l then folds the products of row l sequentially out of LDS — the
+//     segmented reduction — and stores y[r] once;
+//   * a chunk that lies entirely inside ONE long row is reduced by the whole
+//     wavefront with shuffles instead;
+//   * blockIdx is remapped so that each XCD (blocks b, b+8, ... share one)
+//     walks a contiguous range of rows: neighbouring row blocks of banded /
+//     stencil matrices then share their x lines in one XCD's L2.
+//
+// Algorithmic bytes per launch:
+//   12*nnz + 4*(nrows+1) + 8*ncols + 8*nrows.
+#include "common.hpp"
+
+namespace spl {
+
+namespace {
+
+typedef int int2v __attribute__((ext_vector_type(2)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef double double2v __attribute__((ext_vector_type(2)));
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kRowsPerBlock = kWavesPerBlock * 64;
+
+template <bool NT, typename T>
+__device__ inline T stream_load(const T *p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// EPL: elements per lane per pass (chunk = 64*EPL products in LDS per wavefront)
+// VW : elements per vector load (1, 2 or 4)
+template <int EPL, int VW, bool NT, typename PtrT>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void spmv_stream(
+    int64_t nrows, int64_t nblocks, const PtrT *__restrict__ rowptr, const int *__restrict__ colidx,
+    const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
+    int accumulate) {
+  constexpr int CH = 64 * EPL;
+  constexpr int NV = EPL / VW;
+  __shared__ double prod_all[kWavesPerBlock][CH];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  // XCD-aware remap: blocks with equal (blockIdx % 8) share an XCD and get a
+  // contiguous range of row blocks (speed only; any placement is correct).
+  const int64_t per_xcd = gridDim.x >> 3;
+  const int64_t rb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (rb >= nblocks) return;
+  const int64_t r0 = rb * kRowsPerBlock + (int64_t)wave * 64;
+  if (r0 >= nrows) return;
+  double *prod = prod_all[wave];
+
+  const int64_t r = r0 + lane;
+  const bool valid = r < nrows;
+  const int64_t rc = valid ? r : nrows - 1;
+  PtrT my_s = rowptr[rc];
+  PtrT my_e = rowptr[rc + 1];
+  const int nvalid = (nrows - r0) < 64 ? (int)(nrows - r0) : 64;
+  const PtrT S = __shfl(my_s, 0, 64);
+  const PtrT E = __shfl(my_e, nvalid - 1, 64);
+  if (!valid) { my_s = E; my_e = E; }
+
+  double acc = (accumulate && valid) ? y[r] : 0.0;
+
+  for (PtrT b0 = S & ~(PtrT)(VW - 1); b0 < E; b0 += CH) {
+    // ---- stream the chunk: coalesced vector loads, gather x, products to LDS
+    int c[EPL];
+    double a[EPL];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const PtrT k = b0 + (PtrT)((i * 64 + lane) * VW);
+      if (k < E) {
+        if (VW == 1) {
+          c[i] = stream_load<NT>(colidx + k);
+          a[i] = stream_load<NT>(val + k);
+        } else if (VW == 2) {
+          const int2v cv = stream_load<NT>(reinterpret_cast<const int2v *>(colidx + k));
+          const double2v av = stream_load<NT>(reinterpret_cast<const double2v *>(val + k));
+          c[2 * i] = cv.x; c[2 * i + 1] = cv.y;
+          a[2 * i] = av.x; a[2 * i + 1] = av.y;
+        } else {
+          const int4v cv = stream_load<NT>(reinterpret_cast<const int4v *>(colidx + k));
+          const double2v a0 = stream_load<NT>(reinterpret_cast<const double2v *>(val + k));
+          const double2v a1 = stream_load<NT>(reinterpret_cast<const double2v *>(val + k + 2));
+          c[4 * i] = cv.x; c[4 * i + 1] = cv.y; c[4 * i + 2] = cv.z; c[4 * i + 3] = cv.w;
+          a[4 * i] = a0.x; a[4 * i + 1] = a0.y; a[4 * i + 2] = a1.x; a[4 * i + 3] = a1.y;
+        }
+#pragma unroll
+        for (int j = 0; j < VW; ++j)  // tail of the last vector: never gather with a foreign index
+          if (k + j >= E) { c[VW * i + j] = 0; a[VW * i + j] = 0.0; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < VW; ++j) { c[VW * i + j] = 0; a[VW * i + j] = 0.0; }
+      }
+    }
+    double p[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) p[e] = a[e] * x[c[e]];
+
+    // ---- one long row covers the whole chunk: wavefront-wide reduction
+    const bool covers = (my_s <= b0) && (my_e >= b0 + CH);
+    const unsigned long long cover_mask = __ballot(covers);
+    if (cover_mask != 0ull) {
+      double part = 0.0;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) part += p[e];
+      part = wave_sum(part);
+      if (covers) acc = part + acc;
+      continue;
+    }
+
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int off = (i * 64 + lane) * VW;
+      if (VW == 1) {
+        prod[off] = p[i];
+      } else if (VW == 2) {
+        double2v pv; pv.x = p[2 * i]; pv.y = p[2 * i + 1];
+        *reinterpret_cast<double2v *>(prod + off) = pv;
+      } else {
+        double2v p0, p1;
+        p0.x = p[4 * i]; p0.y = p[4 * i + 1]; p1.x = p[4 * i + 2]; p1.y = p[4 * i + 3];
+        *reinterpret_cast<double2v *>(prod + off) = p0;
+        *reinterpret_cast<double2v *>(prod + off + 2) = p1;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- segmented reduction: lane folds its row's slice of the chunk in order
+    const PtrT lo = (my_s > b0 ? my_s : b0) - b0;
+    const PtrT hi = (my_e < b0 + CH ? my_e : b0 + CH) - b0;
+    for (PtrT t = lo; t < hi; ++t) acc = prod[t] + acc;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (valid) y[r] = acc;
+}
+
+// Classic sub-wavefront CSR kernel (G lanes per row, shuffle reduction): kept as
+// the ablation baseline for the streaming kernel.  Summation order differs from
+// the reference order (tolerance-checked only).
+template <int G>
+__global__ __launch_bounds__(256) void spmv_subwave(int64_t nrows, const int *__restrict__ rowptr,
+                                                    const int *__restrict__ colidx,
+                                                    const double *__restrict__ val,
+                                                    const double *__restrict__ x,
+                                                    double *__restrict__ y, int accumulate) {
+  const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const int gl = threadIdx.x & (G - 1);
+  const bool valid = gid < nrows;
+  const int64_t r = valid ? gid : nrows - 1;
+  const int s = rowptr[r], e = valid ? rowptr[r + 1] : s;
+  double acc = 0.0;
+  for (int k = s + gl; k < e; k += G) acc += val[k] * x[colidx[k]];
+#pragma unroll
+  for (int d = G >> 1; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if (valid && gl == 0) y[r] = accumulate ? acc + y[r] : acc;
+}
+
+template <int EPL, int VW, bool NT>
+int launch_stream(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s) {
+  const int64_t nblocks = (m->nrows_local + kRowsPerBlock - 1) / kRowsPerBlock;
+  const int64_t grid = ((nblocks + 7) / 8) * 8;
+  if (grid > 0x7fffffffLL) return SPL_ERROR_internal;
+  if (m->rowptr.get()) {
+    hipLaunchKernelGGL((spmv_stream<EPL, VW, NT, int>), dim3((unsigned)grid), dim3(kWavesPerBlock * 64),
+                       0, s, m->nrows_local, nblocks, m->rowptr.get(), m->colidx.get(), m->val.get(),
+                       d_x, d_y, accumulate);
+  } else {
+    hipLaunchKernelGGL((spmv_stream<EPL, VW, NT, int64_t>), dim3((unsigned)grid),
+                       dim3(kWavesPerBlock * 64), 0, s, m->nrows_local, nblocks, m->rowptr64.get(),
+                       m->colidx.get(), m->val.get(), d_x, d_y, accumulate);
+  }
+  return SPL_OK;
+}
+
+}  // namespace
+
+int launch_spmv(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s) {
+  if (m->nrows_local == 0) return SPL_OK;
+  int st = SPL_OK;
+  switch (m->variant) {
+    case 0:
+    case 1: st = launch_stream<8, 2, true>(m, d_x, d_y, accumulate, s); break;
+    case 2: st = launch_stream<8, 4, true>(m, d_x, d_y, accumulate, s); break;
+    case 3: st = launch_stream<4, 2, true>(m, d_x, d_y, accumulate, s); break;
+    case 4: st = launch_stream<16, 4, true>(m, d_x, d_y, accumulate, s); break;
+    case 5: st = launch_stream<8, 1, true>(m, d_x, d_y, accumulate, s); break;
+    case 6: st = launch_stream<8, 2, false>(m, d_x, d_y, accumulate, s); break;
+    case 7: {
+      if (!m->rowptr.get()) return SPL_ERROR_index_overflow;
+      const int64_t threads = m->nrows_local * 16;
+      const int64_t grid = (threads + 255) / 256;
+      hipLaunchKernelGGL((spmv_subwave<16>), dim3((unsigned)grid), dim3(256), 0, s, m->nrows_local,
+                         m->rowptr.get(), m->colidx.get(), m->val.get(), d_x, d_y, accumulate);
+      break;
+    }
+    default: return SPL_ERROR_argument_missing;
+  }
+  if (st != SPL_OK) return st;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_last_error("spmv launch", e); return SPL_ERROR_device; }
+  return SPL_OK;
+}
+
+}  // namespace spl

@@ -1,0 +1,548 @@
+"""Host-side mirror of ``Data.Matrix.Sparse`` (sparse-linear/src/Data/Matrix/Sparse.hs).
+
+Same names, argument order, meaning and error behaviour as the reference's
+export list (Sparse.hs:13-30), so code and tests written against the Haskell
+API read the same here.  ``Matrix`` is the reference's CSC record
+(Sparse.hs:67-76) with 64-bit ``pointers`` / ``indices`` and fp64 ``values``.
+
+Everything on the hot path — ``mulV``, ``axpy``, ``axpy_``, ``mulM``, ``mm`` /
+``*``, ``lin`` / ``+`` / ``-``, ``transpose``, ``compress`` / ``fromTriples`` —
+crosses the C ABI (include/sparse_linear_hip.h) into the gfx950 kernels, with
+the int64 -> int32 narrowing of ``withConstMatrix`` (Foreign.hs:39-41) at the
+seam.  There is no CPU implementation of those operations in this package: if
+the shared library or a GPU is missing they raise.
+
+The purely structural combinators (``hcat``, ``vcat``, ``fromBlocks*``,
+``kronecker``, ``diag``, ``ident``, ``zeros``, ``takeDiag``, ``pack`` …) only
+rearrange index arrays; they are host-side numpy here (SURVEY.md §8f rank 4
+lists their device versions as "next").
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import (SPL_ERROR_dimension_mismatch, SPL_ERROR_index_out_of_bounds, as_f64, as_i32, check,
+                   lib, p_f64, p_i32)
+
+I64 = np.int64
+F64 = np.float64
+
+
+class SparseError(ValueError):
+    """The reference's ``errorWithStackTrace`` / ``error`` call sites."""
+
+
+def _oops(fn, msg):
+    raise SparseError("%s: %s" % (fn, msg))
+
+
+class Matrix(object):
+    """Matrix in compressed sparse column (CSC) format (Sparse.hs:67-76)."""
+
+    __slots__ = ("ncols", "nrows", "pointers", "indices", "values", "_handle", "__weakref__")
+
+    def __init__(self, ncols, nrows, pointers, indices, values):
+        self.ncols = int(ncols)
+        self.nrows = int(nrows)
+        self.pointers = np.ascontiguousarray(pointers, dtype=I64)
+        self.indices = np.ascontiguousarray(indices, dtype=I64)
+        self.values = np.ascontiguousarray(values, dtype=F64)
+        self._handle = None
+
+    # deriving Eq (Sparse.hs:78): structural equality, explicit zeros included
+    def __eq__(self, other):
+        if not isinstance(other, Matrix):
+            return NotImplemented
+        return (self.ncols == other.ncols and self.nrows == other.nrows
+                and np.array_equal(self.pointers, other.pointers)
+                and np.array_equal(self.indices, other.indices)
+                and np.array_equal(self.values, other.values))
+
+    def __ne__(self, other):
+        r = self.__eq__(other)
+        return r if r is NotImplemented else not r
+
+    __hash__ = None
+
+    def __repr__(self):
+        return "Matrix {ncols = %d, nrows = %d, pointers = %s, indices = %s, values = %s}" % (
+            self.ncols, self.nrows, self.pointers.tolist(), self.indices.tolist(), self.values.tolist())
+
+    # instance Num (Sparse.hs:100-113)
+    def __add__(self, other):
+        return lin(1.0, self, 1.0, other)  # glin 0 (+) a (+) b
+
+    def __sub__(self, other):
+        return lin(1.0, self, -1.0, other)  # glin 0 (+) a (-) b
+
+    def __mul__(self, other):
+        return mm(self, other)
+
+    def __neg__(self):
+        return cmap(np.negative, self)
+
+    def __abs__(self):
+        return cmap(np.abs, self)
+
+    def signum(self):
+        return cmap(np.sign, self)
+
+    # -- FFI seam -----------------------------------------------------------------------
+    def _tuple32(self):
+        """withConstMatrix's marshalling (Foreign.hs:24-41): fresh int32 copies."""
+        return (self.nrows, self.ncols, as_i32(self.pointers), as_i32(self.indices), as_f64(self.values))
+
+    def device_handle(self):
+        """Upload once, reuse for every later SpMV (handle API)."""
+        if self._handle is None:
+            self._handle = DeviceMatrix.from_csc(self)
+        return self._handle
+
+
+class DeviceMatrix(object):
+    """Owner of a ``void *H`` from ``spl_matrix_create*`` (UMFPACK-style handle:
+    callee-allocated, freed through ``void **``; Umfpack.hs:63-65)."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+        self._finalizer = weakref.finalize(self, DeviceMatrix._free, self._h)
+
+    @staticmethod
+    def _free(h):
+        try:
+            lib().spl_matrix_free(C.byref(h))
+        except Exception:  # interpreter shutdown
+            pass
+
+    def free(self):
+        self._finalizer()
+
+    @property
+    def handle(self):
+        if not self._h.value:
+            raise _ffi.SparseLinearError("DeviceMatrix", _ffi.SPL_ERROR_invalid_handle)
+        return self._h
+
+    @classmethod
+    def from_csc(cls, mat, part=0, nparts=1):
+        _ffi.require_gpu()
+        nr, nc, ap, ai, ax = mat._tuple32()
+        h = C.c_void_p()
+        check("spl_matrix_create_rowblock",
+              lib().spl_matrix_create_rowblock(nr, nc, p_i32(ap), p_i32(ai), p_f64(ax), part, nparts,
+                                               C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_csr(cls, nrows_global, ncols, rowptr, colidx, val, row0=0):
+        _ffi.require_gpu()
+        rp, ci, v = as_i32(rowptr), as_i32(colidx), as_f64(val)
+        h = C.c_void_p()
+        check("spl_matrix_create_csr",
+              lib().spl_matrix_create_csr(nrows_global, ncols, row0, len(rp) - 1, p_i32(rp), p_i32(ci),
+                                          p_f64(v), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def synthetic(cls, kind, n_or_m, K=20, seed=0x5EED, row0=0, row1=None):
+        """kind: 'random' | 'banded' | 'poisson2d' | 'poisson3d' (include/spl_synth.h)."""
+        _ffi.require_gpu()
+        kinds = {"random": 0, "banded": 1, "poisson2d": 2, "poisson3d": 3}
+        k = kinds[kind]
+        n = n_or_m ** 2 if k == 2 else n_or_m ** 3 if k == 3 else n_or_m
+        row1 = n if row1 is None else row1
+        h = C.c_void_p()
+        check("spl_matrix_create_synthetic",
+              lib().spl_matrix_create_synthetic(k, n_or_m, K, seed, row0, row1, C.byref(h)))
+        return cls(h.value)
+
+    def info(self):
+        buf = (C.c_int64 * 6)()
+        check("spl_matrix_info", lib().spl_matrix_info(self.handle, buf))
+        keys = ("nrows_global", "ncols", "row0", "nrows_local", "nnz", "device")
+        return dict(zip(keys, [int(v) for v in buf]))
+
+    def export_csr(self):
+        inf = self.info()
+        rp = np.zeros(inf["nrows_local"] + 1, dtype=I64)
+        ci = np.zeros(max(inf["nnz"], 1), dtype=np.int32)
+        v = np.zeros(max(inf["nnz"], 1), dtype=F64)
+        check("spl_matrix_export_csr", lib().spl_matrix_export_csr(self.handle, _ffi.p_i64(rp), p_i32(ci), p_f64(v)))
+        return rp, ci[:inf["nnz"]], v[:inf["nnz"]]
+
+    def export_csc(self):
+        """the block as the reference's CSC fields (device transpose, Sparse.hs:301-329)"""
+        inf = self.info()
+        cp = np.zeros(inf["ncols"] + 1, dtype=I64)
+        ri = np.zeros(max(inf["nnz"], 1), dtype=np.int32)
+        v = np.zeros(max(inf["nnz"], 1), dtype=F64)
+        check("spl_matrix_export_csc", lib().spl_matrix_export_csc(self.handle, _ffi.p_i64(cp), p_i32(ri), p_f64(v)))
+        return cp, ri[:inf["nnz"]], v[:inf["nnz"]]
+
+    def set_variant(self, variant):
+        check("spl_matrix_set_variant", lib().spl_matrix_set_variant(self.handle, int(variant)))
+
+    def mulv(self, x):
+        x = as_f64(x)
+        y = np.zeros(self.info()["nrows_local"], dtype=F64)
+        st = lib().spl_matrix_mulv(self.handle, len(x), p_f64(x), p_f64(y))
+        if st == SPL_ERROR_dimension_mismatch:
+            _oops("axpy_", "column dimension does not match operand dimension %d" % len(x))
+        check("spl_matrix_mulv", st)
+        return y
+
+    def gaxpy(self, x, y):
+        x = as_f64(x)
+        assert y.dtype == F64 and y.flags.c_contiguous
+        st = lib().spl_matrix_gaxpy(self.handle, len(x), p_f64(x), len(y), p_f64(y))
+        if st == SPL_ERROR_dimension_mismatch:
+            _oops("axpy_", "dimension does not match operand dimension")
+        check("spl_matrix_gaxpy", st)
+        return y
+
+    def spmv_dev(self, x_ptr, y_ptr, accumulate=False, stream=0):
+        """device pointers (ints); enqueues on `stream` (a hipStream_t as int), no sync"""
+        check("spl_matrix_spmv_dev",
+              lib().spl_matrix_spmv_dev(self.handle, C.c_void_p(x_ptr), C.c_void_p(y_ptr),
+                                        1 if accumulate else 0, C.c_void_p(stream)))
+
+
+# ---- accessors ------------------------------------------------------------------------------
+
+def nonZero(mat):
+    return int(mat.pointers[-1])  # Sparse.hs:115-117
+
+
+def cmap(f, mat):
+    return Matrix(mat.ncols, mat.nrows, mat.pointers, mat.indices, f(mat.values))  # :119-121
+
+
+def scale(x, mat):
+    return cmap(lambda v: v * x, mat)  # :123-125
+
+
+def slice(mat, c):  # noqa: A001 - the reference's name
+    """(indices, values) of column c as a sparse vector of length nrows (Sparse.hs:175-182)."""
+    if c >= mat.ncols:
+        _oops("slice", "column out of range")
+    s, e = int(mat.pointers[c]), int(mat.pointers[c + 1])
+    return mat.nrows, mat.indices[s:e], mat.values[s:e]
+
+
+def toColumns(mat):
+    return [slice(mat, c) for c in range(mat.ncols)]  # :381-383
+
+
+# ---- construction on the device ---------------------------------------------------------------
+
+def compress(nrows, ncols, rows, cols, vals):
+    """COO -> CSC, duplicates summed, explicit zeros kept (Sparse.hs:184-255)."""
+    rows = np.asarray(rows)
+    cols = np.asarray(cols)
+    vals = np.asarray(vals, dtype=F64)
+    if len(rows) != len(cols):
+        _oops("compress", "row and column array lengths differ")
+    if len(rows) != len(vals):
+        _oops("compress", "row and value array lengths differ")
+    _ffi.require_gpu()
+    r32, c32 = _checked_i32(rows, nrows, "row"), _checked_i32(cols, ncols, "column")
+    ap = np.zeros(ncols + 1, dtype=np.int32)
+    ai, ax, bad = C.c_void_p(), C.c_void_p(), C.c_int64(-1)
+    st = lib().spl_compress(nrows, ncols, len(r32), p_i32(r32), p_i32(c32), p_f64(as_f64(vals)), p_i32(ap),
+                            C.byref(ai), C.byref(ax), C.byref(bad))
+    if st == SPL_ERROR_index_out_of_bounds:
+        k = bad.value
+        if not (0 <= rows[k] < nrows):
+            _oops("compress", "row index out of bounds (0,%d) at %d" % (nrows, k))
+        _oops("compress", "column index out of bounds (0,%d) at %d" % (ncols, k))
+    check("spl_compress", st)
+    nz = int(ap[ncols])
+    return Matrix(ncols, nrows, ap.astype(I64), _ffi.take_malloced(ai, nz, C.c_int, I64),
+                  _ffi.take_malloced(ax, nz, C.c_double, F64))
+
+
+def _checked_i32(a, bound, what):
+    """int64 -> int32 narrowing that keeps out-of-range values out of range"""
+    a = np.asarray(a, dtype=I64)
+    lim = np.iinfo(np.int32)
+    return np.ascontiguousarray(np.where((a < lim.min) | (a > lim.max), -1, a), dtype=np.int32)
+
+
+def fromTriples(nr, nc, triples):
+    triples = list(triples)
+    rows = [t[0] for t in triples]
+    cols = [t[1] for t in triples]
+    vals = [t[2] for t in triples]
+    return compress(nr, nc, rows, cols, vals)  # Sparse.hs:357-363
+
+
+def transpose(mat):
+    """Counting-sort transpose (Sparse.hs:301-329); also the CSC -> CSR converter."""
+    _ffi.require_gpu()
+    nr, nc, ap, ai, ax = mat._tuple32()
+    nz = int(ap[nc])
+    tp = np.zeros(nr + 1, dtype=np.int32)
+    ti = np.zeros(max(nz, 1), dtype=np.int32)
+    tx = np.zeros(max(nz, 1), dtype=F64)
+    check("spl_transpose", lib().spl_transpose(nr, nc, p_i32(ap), p_i32(ai), p_f64(ax), p_i32(tp), p_i32(ti),
+                                              p_f64(tx)))
+    return Matrix(nr, nc, tp.astype(I64), ti[:nz].astype(I64), tx[:nz])
+
+
+def ctrans(mat):
+    return transpose(mat)  # conj is the identity on Double (Sparse.hs:371-375)
+
+
+def hermitian(mat):
+    return ctrans(mat) == mat  # :377-379
+
+
+# ---- SpMV ---------------------------------------------------------------------------------------
+
+def axpy_(mat, xs, ys):
+    """in place ys <- A xs + ys (Sparse.hs:433-453); ys is a float64 numpy array."""
+    if len(xs) != mat.ncols:
+        _oops("axpy_", "column dimension %d does not match operand dimension %d" % (mat.ncols, len(xs)))
+    if len(ys) != mat.nrows:
+        _oops("axpy_", "row dimension %d does not match result dimension %d" % (mat.nrows, len(ys)))
+    if not (isinstance(ys, np.ndarray) and ys.dtype == F64 and ys.flags.c_contiguous):
+        raise TypeError("axpy_: ys must be a contiguous float64 array (it is updated in place)")
+    mat.device_handle().gaxpy(xs, ys)
+
+
+def axpy(mat, x, y):
+    y = np.array(y, dtype=F64)  # U.thaw _y (Sparse.hs:459)
+    axpy_(mat, np.asarray(x, dtype=F64), y)
+    return y
+
+
+def mulV(mat, x):
+    x = np.asarray(x, dtype=F64)
+    if len(x) != mat.ncols:
+        _oops("axpy_", "column dimension %d does not match operand dimension %d" % (mat.ncols, len(x)))
+    return mat.device_handle().mulv(x)  # Sparse.hs:464-471
+
+
+def mulVT(mat, x):
+    """A^T x — a gather on the CSC arrays themselves."""
+    _ffi.require_gpu()
+    x = as_f64(x)
+    nr, nc, ap, ai, ax = mat._tuple32()
+    y = np.zeros(nc, dtype=F64)
+    st = lib().spl_gaxpy_t(nr, nc, p_i32(ap), p_i32(ai), p_f64(ax), len(x), p_f64(x), nc, p_f64(y))
+    if st == SPL_ERROR_dimension_mismatch:
+        _oops("axpy_", "row dimension %d does not match operand dimension %d" % (nr, len(x)))
+    check("spl_gaxpy_t", st)
+    return y
+
+
+def mulM(matA, matB):
+    """sparse x dense (Sparse.hs:473-498); matB is a 2-D array (rows x cols)."""
+    B = np.ascontiguousarray(matB, dtype=F64)
+    if matA.ncols != B.shape[0]:
+        _oops("mulM", "inner dimension mismatch")
+    _ffi.require_gpu()
+    nr, nc, ap, ai, ax = matA._tuple32()
+    out = np.zeros((nr, B.shape[1]), dtype=F64)
+    check("spl_mulm", lib().spl_mulm(nr, nc, p_i32(ap), p_i32(ai), p_f64(ax), B.shape[0], B.shape[1],
+                                    p_f64(B), p_f64(out)))
+    return out
+
+
+# ---- SpGEMM / sparse add ---------------------------------------------------------------------------
+
+def _take_matrix(where, st, nr, nc, cp, ci, cx):
+    check(where, st)
+    ncols = nc.value
+    ptrs = _ffi.take_malloced(cp, ncols + 1, C.c_int, I64)
+    nz = int(ptrs[ncols])
+    return Matrix(ncols, nr.value, ptrs, _ffi.take_malloced(ci, nz, C.c_int, I64),
+                  _ffi.take_malloced(cx, nz, C.c_double, F64))
+
+
+def mm(matA, matB):
+    """C = A B (Sparse.hs:691-702): union pattern, cancellation keeps a stored 0."""
+    if matA.ncols != matB.nrows:
+        _oops("mm", "inner dimension mismatch")
+    _ffi.require_gpu()
+    a, b = matA._tuple32(), matB._tuple32()
+    nr, nc = C.c_int(), C.c_int()
+    cp, ci, cx = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    st = lib().spl_spgemm(a[0], a[1], p_i32(a[2]), p_i32(a[3]), p_f64(a[4]), b[0], b[1], p_i32(b[2]),
+                          p_i32(b[3]), p_f64(b[4]), C.byref(nr), C.byref(nc), C.byref(cp), C.byref(ci),
+                          C.byref(cx))
+    return _take_matrix("spl_spgemm", st, nr, nc, cp, ci, cx)
+
+
+def lin(alpha, matA, beta, matB):
+    """alpha A + beta B (Sparse.hs:426-431 over glin :401-424)."""
+    if matA.nrows != matB.nrows:
+        _oops("glin", "row number mismatch")
+    if matA.ncols != matB.ncols:
+        _oops("glin", "column number mismatch")
+    _ffi.require_gpu()
+    a, b = matA._tuple32(), matB._tuple32()
+    nr, nc = C.c_int(), C.c_int()
+    cp, ci, cx = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    st = lib().spl_lin(float(alpha), a[0], a[1], p_i32(a[2]), p_i32(a[3]), p_f64(a[4]), float(beta), b[0],
+                       b[1], p_i32(b[2]), p_i32(b[3]), p_f64(b[4]), C.byref(nr), C.byref(nc), C.byref(cp),
+                       C.byref(ci), C.byref(cx))
+    return _take_matrix("spl_lin", st, nr, nc, cp, ci, cx)
+
+
+# ---- structural combinators (host-side index plumbing) -----------------------------------------------
+
+def _lengths(mat):
+    return np.diff(mat.pointers)
+
+
+def diag(values):
+    values = np.asarray(values, dtype=F64)
+    n = len(values)
+    return Matrix(n, n, np.arange(n + 1, dtype=I64), np.arange(n, dtype=I64), values)  # :650-657
+
+
+def ident(n):
+    return diag(np.ones(n, dtype=F64))  # :667-669
+
+
+def zeros(nrows, ncols):
+    return Matrix(ncols, nrows, np.zeros(ncols + 1, dtype=I64), np.zeros(0, dtype=I64),
+                  np.zeros(0, dtype=F64))  # :671-677
+
+
+def takeDiag(mat):
+    out = np.zeros(min(mat.nrows, mat.ncols), dtype=F64)  # :636-648
+    for c in range(len(out)):
+        _, ix, xs = slice(mat, c)
+        hit = np.nonzero(ix == c)[0]
+        if len(hit):
+            out[c] = xs[hit[0]]
+    return out
+
+
+def hcat(mats):
+    mats = list(mats)
+    if not mats:
+        _oops("hcat", "empty list")
+    if any(m.nrows != mats[0].nrows for m in mats):
+        _oops("hcat", "nrows mismatch")
+    lens = np.concatenate([_lengths(m) for m in mats])
+    ptrs = np.concatenate([[0], np.cumsum(lens)]).astype(I64)
+    return Matrix(sum(m.ncols for m in mats), mats[0].nrows, ptrs, np.concatenate([m.indices for m in mats]),
+                  np.concatenate([m.values for m in mats]))  # :504-522
+
+
+def hjoin(a, b):
+    return hcat([a, b])
+
+
+def vcat(mats):
+    mats = list(mats)
+    if not mats:
+        _oops("vcat", "empty list")
+    ncols = mats[0].ncols
+    if any(m.ncols != ncols for m in mats):
+        _oops("vcat", "ncols mismatch")
+    ptrs = np.sum([m.pointers for m in mats], axis=0).astype(I64)  # :545
+    nz = int(ptrs[-1])
+    idx = np.zeros(nz, dtype=I64)
+    val = np.zeros(nz, dtype=F64)
+    offs = np.concatenate([[0], np.cumsum([m.nrows for m in mats])])
+    cursor = ptrs[:-1].copy()
+    for m, off in zip(mats, offs):  # column c: blocks stacked in list order (:551-559)
+        ln = _lengths(m)
+        if int(m.pointers[-1]) == 0:
+            continue
+        dst = np.repeat(cursor - m.pointers[:-1], ln) + np.arange(int(m.pointers[-1]))
+        idx[dst] = m.indices + off
+        val[dst] = m.values
+        cursor = cursor + ln
+    return Matrix(ncols, int(offs[-1]), ptrs, idx, val)
+
+
+def vjoin(a, b):
+    return vcat([a, b])
+
+
+def fromBlocks(blocks):
+    """[[Maybe Matrix]] -> Matrix, None = zero block (Sparse.hs:563-587)."""
+    rows = [list(r) for r in blocks]
+    ncb = max(len(r) for r in rows)
+    cols = [[r[c] for r in rows if c < len(r)] for c in range(ncb)]
+
+    def spec(groups, attr, what):
+        out = []
+        for g in groups:
+            ds = [getattr(m, attr) for m in g if m is not None]
+            if not ds:
+                _oops("fromBlocks", "underspecified " + what)
+            if any(d != ds[0] for d in ds):
+                _oops("fromBlocks", "incompatible " + what)
+            out.append(ds[0])
+        return out
+
+    heights = spec(rows, "nrows", "heights")
+    widths = spec(cols, "ncols", "widths")
+    return vcat([hcat([m if m is not None else zeros(heights[r], widths[c]) for c, m in enumerate(row)])
+                 for r, row in enumerate(rows)])
+
+
+def fromBlocksDiag(blocks):
+    """blocks given by (super-)diagonals (Sparse.hs:589-597)."""
+    blocks = [list(b) for b in blocks]
+    n = len(blocks)
+    trans = [[b[i] for b in blocks if i < len(b)] for i in range(max(len(b) for b in blocks))]
+    out = []
+    for k, as_ in enumerate(trans):
+        as_ = as_ + [None] * (n - len(as_))
+        cut = len(as_) - k
+        out.append(as_[cut:] + as_[:cut])
+    return fromBlocks(out)
+
+
+def blockDiag(mats):
+    mats = list(mats)
+    n = len(mats)
+    return fromBlocksDiag([list(mats)] + [[None] * n for _ in range(n - 1)])  # :659-665
+
+
+def kronecker(matA, matB):
+    """Kronecker product (Sparse.hs:599-634)."""
+    lA, lB = _lengths(matA), _lengths(matB)
+    ptrs = np.concatenate([[0], np.cumsum(np.outer(lA, lB).ravel())]).astype(I64)
+    idx_parts, val_parts = [], []
+    for na in range(matA.ncols):
+        _, ia, xa = slice(matA, na)
+        for nb in range(matB.ncols):
+            _, ib, xb = slice(matB, nb)
+            idx_parts.append((ia[:, None] * matB.nrows + ib[None, :]).ravel())
+            val_parts.append((xa[:, None] * xb[None, :]).ravel())
+    idx = np.concatenate(idx_parts) if idx_parts else np.zeros(0, dtype=I64)
+    val = np.concatenate(val_parts) if val_parts else np.zeros(0, dtype=F64)
+    return Matrix(matA.ncols * matB.ncols, matA.nrows * matB.nrows, ptrs, idx, val)
+
+
+def pack(mat):
+    """dense copy (Sparse.hs:679-689)"""
+    out = np.zeros((mat.nrows, mat.ncols), dtype=F64)
+    cols = np.repeat(np.arange(mat.ncols), _lengths(mat))
+    out[mat.indices, cols] = mat.values
+    return out
+
+
+def outer(sliceC, sliceR):
+    """outer product of a sparse column and a sparse row vector (Sparse.hs:331-355);
+    both given as (length, indices, values).  Mirrors the reference's naming,
+    in which `sliceC` supplies the column dimension."""
+    ncols, indicesC, valuesC = sliceC
+    nrows, indicesR, valuesR = sliceR
+    lenR = len(valuesR)
+    lens = np.zeros(ncols + 1, dtype=I64)
+    lens[np.asarray(indicesC, dtype=I64)] = lenR
+    ptrs = np.concatenate([[0], np.cumsum(lens)]).astype(I64)
+    idx = np.tile(np.asarray(indicesR, dtype=I64), len(valuesC))
+    val = (np.asarray(valuesC, dtype=F64)[:, None] * np.asarray(valuesR, dtype=F64)[None, :]).ravel()
+    return Matrix(ncols, nrows, ptrs[:ncols + 1], idx, val)
