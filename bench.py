@@ -85,16 +85,16 @@ def main():
     x = torch.empty(n, dtype=torch.float64, device="cuda")
     ffi.check("spl_vector_synthetic_dev",
               ffi.lib().spl_vector_synthetic_dev(0xBEEF, 0, n, x.data_ptr(), stream.cuda_stream))
-    y_full = torch.zeros(n, dtype=torch.float64, device="cuda")
-    y_local = y_full[r0:r1] if N == 1 else torch.zeros(r1 - r0, dtype=torch.float64, device="cuda")
+    dist_mod = sys.modules["sparse_linear_amd.dist"]
+    op = dist_mod.RowBlockSpMV(n, dist_mod.equal_row_bounds(n, N), rank, N,
+                               dist_mod.hip_local_spmv(H, lambda: stream.cuda_stream), "cuda")
+    y_local, y_full = op.y_local, op.y_full
 
     def spmv():
-        H.spmv_dev(x.data_ptr(), y_local.data_ptr(), accumulate=False, stream=stream.cuda_stream)
+        op.local_spmv(x, y_local)
 
     def step():
-        spmv()
-        if N > 1:
-            dist.all_gather_into_tensor(y_full, y_local)
+        op.step(x)  # local CSR-stream kernel, then (N > 1) the RCCL all-gather of y
 
     def barrier():
         if N > 1:

@@ -82,10 +82,29 @@ int spl_gaxpy_t(int nrows, int ncols, const int *Ap, const int *Ai, const double
 int spl_mulm(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax,
              int brows, int bcols, const double *B, double *C);
 
+/* mm / (*) (Sparse.hs:691-702): C = A B.  Union pattern (cancellation keeps a
+ * stored zero), row indices ascending, Cp = exclusive prefix sum.  Outputs are
+ * malloc()'d.  SPL_ERROR_index_overflow if nnz(C) >= 2^31 (use the handle API). */
+int spl_spgemm(int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Ax,
+               int nrowsB, int ncolsB, const int *Bp, const int *Bi, const double *Bx,
+               int *nrowsC, int *ncolsC, int **Cp, int **Ci, double **Cx);
+
+/* lin (Sparse.hs:426-431):  C = alpha A + beta B, union pattern. malloc()'d outputs. */
+int spl_lin(double alpha, int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Ax,
+            double beta, int nrowsB, int ncolsB, const int *Bp, const int *Bi, const double *Bx,
+            int *nrowsC, int *ncolsC, int **Cp, int **Ci, double **Cx);
+
 /* transpose (Sparse.hs:301-329): CSC(A) -> CSC(A^T) == CSR(A).  Caller
  * allocates Tp[nrows+1], Ti[nnz], Tx[nnz]. */
 int spl_transpose(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax,
                   int *Tp, int *Ti, double *Tx);
+
+/* compress / fromTriples (Sparse.hs:184-255): COO -> CSC, duplicates summed,
+ * explicit zeros kept.  Ap[ncols+1] caller-allocated; *Ai,*Ax malloc()'d with
+ * Ap[ncols] entries.  On SPL_ERROR_index_out_of_bounds *bad is the first
+ * offending position (rows checked first, then columns). */
+int spl_compress(int nrows, int ncols, int64_t nnz, const int *rows, const int *cols,
+                 const double *vals, int *Ap, int **Ai, double **Ax, int64_t *bad);
 
 /* ---- device-resident matrix handles ------------------------------------------ */
 

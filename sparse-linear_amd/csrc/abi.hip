@@ -518,3 +518,162 @@ int spl_transpose(int nrows, int ncols, const int *Ap, const int *Ai, const doub
 }
 
 }  // extern "C"
+
+// ---- assembly / SpGEMM one-shots ------------------------------------------------------------
+
+namespace {
+
+struct DeviceCsc {
+  DBuf<int> p, i;
+  DBuf<double> x;
+  int64_t nnz = 0;
+};
+
+// upload + validate a CSC 5-tuple; sort its columns if a caller violated the
+// ascending-row invariant (the reference's SPA does not care about input order)
+int upload_csc(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax, DeviceCsc &d,
+               hipStream_t s) {
+  int st = check_tuple(nrows, ncols, Ap, Ai, Ax);
+  if (st != SPL_OK) return st;
+  d.nnz = Ap[ncols];
+  upload(d.p, Ap, (size_t)ncols + 1, s);
+  upload(d.i, Ai, (size_t)d.nnz, s);
+  upload(d.x, Ax, (size_t)d.nnz, s);
+  st = validate_compressed(d.p.get(), d.i.get(), ncols, nrows, d.nnz, s);
+  if (st != SPL_OK) return st;
+  if (!columns_sorted(d.p.get(), d.i.get(), ncols, s)) {
+    DBuf<int64_t> p64((size_t)ncols + 1);
+    widen_i32_to_i64(d.p.get(), p64.get(), (int64_t)ncols + 1, s);
+    segmented_sort_pairs(p64.get(), ncols, d.i.get(), d.x.get(), s);
+    SPL_HIP(hipStreamSynchronize(s));
+  }
+  return SPL_OK;
+}
+
+// copy a device result into malloc()'d host arrays (adoptable by `fromForeign False`)
+int download_result(int64_t ncols, int64_t nnz, const int64_t *dCp64, const int *dCi, const double *dCx,
+                    int **Cp, int **Ci, double **Cx, hipStream_t s) {
+  if (nnz >= 0x7fffffffLL) return SPL_ERROR_index_overflow;
+  int *hp = (int *)malloc(((size_t)ncols + 1) * sizeof(int));
+  int *hi = (int *)malloc((size_t)(nnz ? nnz : 1) * sizeof(int));
+  double *hx = (double *)malloc((size_t)(nnz ? nnz : 1) * sizeof(double));
+  if (!hp || !hi || !hx) { free(hp); free(hi); free(hx); return SPL_ERROR_out_of_memory; }
+  try {
+    DBuf<int> dCp32((size_t)ncols + 1);
+    narrow_i64_to_i32(dCp64, dCp32.get(), ncols + 1, s);
+    SPL_HIP(hipMemcpyAsync(hp, dCp32.get(), ((size_t)ncols + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (nnz) {
+      SPL_HIP(hipMemcpyAsync(hi, dCi, (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+      SPL_HIP(hipMemcpyAsync(hx, dCx, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    SPL_HIP(hipStreamSynchronize(s));
+  } catch (...) {
+    free(hp); free(hi); free(hx);
+    throw;
+  }
+  *Cp = hp; *Ci = hi; *Cx = hx;
+  return SPL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spl_spgemm(int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Ax, int nrowsB,
+               int ncolsB, const int *Bp, const int *Bi, const double *Bx, int *nrowsC, int *ncolsC,
+               int **Cp, int **Ci, double **Cx) {
+  if (!nrowsC || !ncolsC || !Cp || !Ci || !Cx) return SPL_ERROR_argument_missing;
+  *Cp = nullptr; *Ci = nullptr; *Cx = nullptr;
+  if (nrowsA >= 0 && ncolsA >= 0 && nrowsB >= 0 && ncolsB >= 0 && ncolsA != nrowsB)
+    return SPL_ERROR_dimension_mismatch;  // Sparse.hs:694
+  return guarded([&]() -> int {
+    (void)current_device();
+    hipStream_t s = nullptr;
+    DeviceCsc A, B;
+    int st = upload_csc(nrowsA, ncolsA, Ap, Ai, Ax, A, s);
+    if (st != SPL_OK) return st;
+    st = upload_csc(nrowsB, ncolsB, Bp, Bi, Bx, B, s);
+    if (st != SPL_OK) return st;
+    DBuf<int64_t> dCp;
+    DBuf<int> dCi;
+    DBuf<double> dCx;
+    int64_t nnzC = 0;
+    spgemm_device(nrowsA, ncolsA, A.p.get(), A.i.get(), A.x.get(), ncolsB, B.p.get(), B.i.get(), B.x.get(),
+                  dCp, dCi, dCx, &nnzC, nullptr, s);
+    st = download_result(ncolsB, nnzC, dCp.get(), dCi.get(), dCx.get(), Cp, Ci, Cx, s);
+    if (st != SPL_OK) return st;
+    *nrowsC = nrowsA;
+    *ncolsC = ncolsB;
+    return SPL_OK;
+  });
+}
+
+int spl_lin(double alpha, int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Ax,
+            double beta, int nrowsB, int ncolsB, const int *Bp, const int *Bi, const double *Bx,
+            int *nrowsC, int *ncolsC, int **Cp, int **Ci, double **Cx) {
+  if (!nrowsC || !ncolsC || !Cp || !Ci || !Cx) return SPL_ERROR_argument_missing;
+  *Cp = nullptr; *Ci = nullptr; *Cx = nullptr;
+  if (nrowsA >= 0 && ncolsA >= 0 && nrowsB >= 0 && ncolsB >= 0 && (nrowsA != nrowsB || ncolsA != ncolsB))
+    return SPL_ERROR_dimension_mismatch;  // Sparse.hs:408-409
+  return guarded([&]() -> int {
+    (void)current_device();
+    hipStream_t s = nullptr;
+    DeviceCsc A, B;
+    int st = upload_csc(nrowsA, ncolsA, Ap, Ai, Ax, A, s);
+    if (st != SPL_OK) return st;
+    st = upload_csc(nrowsB, ncolsB, Bp, Bi, Bx, B, s);
+    if (st != SPL_OK) return st;
+    DBuf<int64_t> dCp;
+    DBuf<int> dCi;
+    DBuf<double> dCx;
+    int64_t nnzC = 0;
+    lin_device(alpha, A.p.get(), A.i.get(), A.x.get(), beta, B.p.get(), B.i.get(), B.x.get(), ncolsA, dCp,
+               dCi, dCx, &nnzC, s);
+    st = download_result(ncolsA, nnzC, dCp.get(), dCi.get(), dCx.get(), Cp, Ci, Cx, s);
+    if (st != SPL_OK) return st;
+    *nrowsC = nrowsA;
+    *ncolsC = ncolsA;
+    return SPL_OK;
+  });
+}
+
+int spl_compress(int nrows, int ncols, int64_t nnz, const int *rows, const int *cols, const double *vals,
+                 int *Ap, int **Ai, double **Ax, int64_t *bad) {
+  if (!Ap || !Ai || !Ax) return SPL_ERROR_argument_missing;
+  *Ai = nullptr; *Ax = nullptr;
+  if (nrows < 0 || ncols < 0 || nnz < 0) return SPL_ERROR_n_nonpositive;
+  if (nnz >= 0x7fffffffLL) return SPL_ERROR_index_overflow;
+  if (nnz > 0 && (!rows || !cols || !vals)) return SPL_ERROR_argument_missing;
+  return guarded([&]() -> int {
+    (void)current_device();
+    hipStream_t s = nullptr;
+    DBuf<int> dr, dc, dptr((size_t)ncols + 1), oidx;
+    DBuf<double> dv, oval;
+    upload(dr, rows, (size_t)nnz, s);
+    upload(dc, cols, (size_t)nnz, s);
+    upload(dv, vals, (size_t)nnz, s);
+    int64_t nz = 0;
+    int st = compress_device(nrows, ncols, nnz, dr.get(), dc.get(), dv.get(), dptr.get(), oidx, oval, &nz,
+                             bad, s);
+    if (st != SPL_OK) return st;
+    int *hi = (int *)malloc((size_t)(nz ? nz : 1) * sizeof(int));
+    double *hx = (double *)malloc((size_t)(nz ? nz : 1) * sizeof(double));
+    if (!hi || !hx) { free(hi); free(hx); return SPL_ERROR_out_of_memory; }
+    try {
+      SPL_HIP(hipMemcpyAsync(Ap, dptr.get(), ((size_t)ncols + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+      if (nz) {
+        SPL_HIP(hipMemcpyAsync(hi, oidx.get(), (size_t)nz * sizeof(int), hipMemcpyDeviceToHost, s));
+        SPL_HIP(hipMemcpyAsync(hx, oval.get(), (size_t)nz * sizeof(double), hipMemcpyDeviceToHost, s));
+      }
+      SPL_HIP(hipStreamSynchronize(s));
+    } catch (...) {
+      free(hi); free(hx);
+      throw;
+    }
+    *Ai = hi;
+    *Ax = hx;
+    return SPL_OK;
+  });
+}
+
+}  // extern "C"

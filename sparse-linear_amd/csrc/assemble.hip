@@ -1,0 +1,247 @@
+// assemble.hip — COO -> CSC (`compress`, Sparse.hs:184-255) and the sparse linear
+// combination alpha*A + beta*B (`lin` over `glin`, Sparse.hs:401-431) in HBM.
+//
+// compress: bounds check (rows first, then columns: Sparse.hs:196-212), bucket by
+// column (histogram + scan + cursor scatter), sort every column by the 64-bit key
+// (row << 32 | input position) — i.e. by row, ties in input order, the order in
+// which the oracle's stable sorts leave duplicates — then sum each run of equal
+// rows left to right into its first entry (dedupInPlace, Sparse.hs:257-280) and
+// compact.  Explicit zeros are kept.
+//
+// lin: both operands are valid Matrix values, so their columns are strictly
+// ascending; the union pattern of a column is a two-pointer merge.  Values are
+// evaluated exactly as the reference's SPA does: (0 + alpha*a) + beta*b, each
+// operation separately rounded (-ffp-contract=off).
+#include "common.hpp"
+
+namespace spl {
+
+namespace {
+
+inline unsigned blocks_for(int64_t n, int per_block, int64_t cap = 1 << 20) {
+  int64_t b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
+__global__ __launch_bounds__(256) void bounds_kernel(const int *__restrict__ idx, int64_t nnz, int bound,
+                                                     unsigned long long *__restrict__ first_bad) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long bad = ~0ull;
+  for (; i < nnz; i += stride) {
+    const int v = idx[i];
+    if ((v < 0 || v >= bound) && (unsigned long long)i < bad) bad = (unsigned long long)i;
+  }
+  if (bad != ~0ull) atomicMin(first_bad, bad);
+}
+
+__global__ __launch_bounds__(256) void count_kernel(const int *__restrict__ idx, int64_t nnz,
+                                                    int *__restrict__ counts) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) atomicAdd(&counts[idx[i]], 1);
+}
+
+__global__ __launch_bounds__(256) void coo_bucket_kernel(const int *__restrict__ rows,
+                                                         const int *__restrict__ cols,
+                                                         const double *__restrict__ vals, int64_t nnz,
+                                                         const int64_t *__restrict__ colptr,
+                                                         int *__restrict__ cursor, int64_t *__restrict__ key,
+                                                         double *__restrict__ val) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) {
+    const int c = cols[i];
+    const int64_t pos = colptr[c] + (int64_t)atomicAdd(&cursor[c], 1);
+    key[pos] = ((int64_t)rows[i] << 32) | i;  // nnz < 2^31: the position fits the low word
+    val[pos] = vals[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void mark_col_starts_kernel(const int64_t *__restrict__ colptr,
+                                                              int64_t ncols, int *__restrict__ head) {
+  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; c < ncols; c += stride)
+    if (colptr[c] < colptr[c + 1]) head[colptr[c]] = 1;
+}
+
+__global__ __launch_bounds__(256) void mark_row_changes_kernel(const int64_t *__restrict__ key, int64_t nnz,
+                                                               int *__restrict__ head) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride)
+    if (i == 0 || (key[i] >> 32) != (key[i - 1] >> 32)) head[i] = 1;
+}
+
+// every run head sums its run left to right and writes the compacted entry
+__global__ __launch_bounds__(256) void dedup_sum_kernel(const int64_t *__restrict__ key,
+                                                        const double *__restrict__ val,
+                                                        const int *__restrict__ head,
+                                                        const int64_t *__restrict__ outpos, int64_t nnz,
+                                                        int *__restrict__ out_idx,
+                                                        double *__restrict__ out_val) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nnz; i += stride) {
+    if (!head[i]) continue;
+    double acc = val[i];
+    for (int64_t q = i + 1; q < nnz && !head[q]; ++q) acc = acc + val[q];  // x' + x, Sparse.hs:272-273
+    const int64_t o = outpos[i];
+    out_idx[o] = (int)(key[i] >> 32);
+    out_val[o] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void remap_ptr_kernel(const int64_t *__restrict__ colptr,
+                                                        const int64_t *__restrict__ outpos, int64_t ncols,
+                                                        int64_t nnz, int *__restrict__ newptr) {
+  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; c <= ncols; c += stride) newptr[c] = (int)outpos[colptr[c]];  // outpos has nnz+1 entries
+}
+
+// ---- lin ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sorted_check_kernel(const int *__restrict__ ptr,
+                                                           const int *__restrict__ idx, int64_t ncols,
+                                                           int *__restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= ncols) return;
+  bool bad = false;
+  for (int k = ptr[c] + 1 + lane; k < ptr[c + 1]; k += 64) bad |= !(idx[k - 1] < idx[k]);
+  if (bad) atomicOr(flag, 1);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void lin_merge_kernel(
+    double alpha, const int *__restrict__ Ap, const int *__restrict__ Ai, const double *__restrict__ Ax,
+    double beta, const int *__restrict__ Bp, const int *__restrict__ Bi, const double *__restrict__ Bx,
+    int64_t ncols, int *__restrict__ counts, const int64_t *__restrict__ Cp, int *__restrict__ Ci,
+    double *__restrict__ Cx) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  int a = Ap[c], b = Bp[c];
+  const int ae = Ap[c + 1], be = Bp[c + 1];
+  int64_t o = FILL ? Cp[c] : 0;
+  int n = 0;
+  while (a < ae || b < be) {
+    const int ra = a < ae ? Ai[a] : 0x7fffffff;
+    const int rb = b < be ? Bi[b] : 0x7fffffff;
+    if (FILL) {
+      double w = 0.0;                       // SG.reset 0
+      if (ra <= rb) w = w + alpha * Ax[a];  // fA: \r a -> r + alpha * a
+      if (rb <= ra) w = w + beta * Bx[b];   // fB: \r b -> r + beta * b
+      Ci[o] = ra < rb ? ra : rb;
+      Cx[o] = w;
+      ++o;
+    }
+    ++n;
+    if (ra <= rb) ++a;
+    if (rb <= ra) ++b;
+  }
+  if (!FILL) counts[c] = n;
+}
+
+}  // namespace
+
+// COO (device arrays) -> CSC.  Returns SPL_OK / SPL_ERROR_index_out_of_bounds.
+// Outputs: d_newptr[ncols+1] (int32), out_idx/out_val allocated with nnz_out entries.
+int compress_device(int nrows, int ncols, int64_t nnz, const int *d_rows, const int *d_cols,
+                    const double *d_vals, int *d_newptr, DBuf<int> &out_idx, DBuf<double> &out_val,
+                    int64_t *nnz_out, int64_t *bad, hipStream_t s) {
+  *nnz_out = 0;
+  if (nnz == 0) {
+    SPL_HIP(hipMemsetAsync(d_newptr, 0, ((size_t)ncols + 1) * sizeof(int), s));
+    out_idx.alloc(0);
+    out_val.alloc(0);
+    SPL_HIP(hipStreamSynchronize(s));
+    return SPL_OK;
+  }
+  DBuf<unsigned long long> first_bad(1);
+  for (int pass = 0; pass < 2; ++pass) {  // rows, then columns (Sparse.hs:196-212)
+    SPL_HIP(hipMemsetAsync(first_bad.get(), 0xff, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(bounds_kernel, dim3(blocks_for(nnz, 256, 8192)), dim3(256), 0, s,
+                       pass == 0 ? d_rows : d_cols, nnz, pass == 0 ? nrows : ncols, first_bad.get());
+    unsigned long long h = 0;
+    SPL_HIP(hipMemcpyAsync(&h, first_bad.get(), sizeof(h), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipStreamSynchronize(s));
+    if (h != ~0ull) {
+      if (bad) *bad = (int64_t)h;
+      return SPL_ERROR_index_out_of_bounds;
+    }
+  }
+  DBuf<int> counts((size_t)ncols);
+  DBuf<int64_t> colptr((size_t)ncols + 1);
+  SPL_HIP(hipMemsetAsync(counts.get(), 0, (size_t)(ncols ? ncols : 1) * sizeof(int), s));
+  hipLaunchKernelGGL(count_kernel, dim3(blocks_for(nnz, 256, 16384)), dim3(256), 0, s, d_cols, nnz,
+                     counts.get());
+  exclusive_scan_i32_to_i64(counts.get(), colptr.get(), ncols, s);
+  SPL_HIP(hipMemsetAsync(counts.get(), 0, (size_t)(ncols ? ncols : 1) * sizeof(int), s));
+  DBuf<int64_t> key((size_t)nnz);
+  DBuf<double> val((size_t)nnz);
+  hipLaunchKernelGGL(coo_bucket_kernel, dim3(blocks_for(nnz, 256, 16384)), dim3(256), 0, s, d_rows, d_cols,
+                     d_vals, nnz, colptr.get(), counts.get(), key.get(), val.get());
+  segmented_sort_pairs64(colptr.get(), ncols, key.get(), val.get(), s);
+  // run heads: first entry of a column, or a row change
+  DBuf<int> head((size_t)nnz);
+  DBuf<int64_t> outpos((size_t)nnz + 1);
+  SPL_HIP(hipMemsetAsync(head.get(), 0, (size_t)nnz * sizeof(int), s));
+  hipLaunchKernelGGL(mark_col_starts_kernel, dim3(blocks_for(ncols, 256, 8192)), dim3(256), 0, s,
+                     colptr.get(), (int64_t)ncols, head.get());
+  hipLaunchKernelGGL(mark_row_changes_kernel, dim3(blocks_for(nnz, 256, 16384)), dim3(256), 0, s, key.get(),
+                     nnz, head.get());
+  exclusive_scan_i32_to_i64(head.get(), outpos.get(), nnz, s);
+  int64_t nz = 0;
+  SPL_HIP(hipMemcpyAsync(&nz, outpos.get() + nnz, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  SPL_HIP(hipStreamSynchronize(s));
+  out_idx.alloc((size_t)nz);
+  out_val.alloc((size_t)nz);
+  hipLaunchKernelGGL(dedup_sum_kernel, dim3(blocks_for(nnz, 256, 16384)), dim3(256), 0, s, key.get(),
+                     val.get(), head.get(), outpos.get(), nnz, out_idx.get(), out_val.get());
+  hipLaunchKernelGGL(remap_ptr_kernel, dim3(blocks_for(ncols + 1, 256, 8192)), dim3(256), 0, s, colptr.get(),
+                     outpos.get(), (int64_t)ncols, nnz, d_newptr);
+  SPL_HIP(hipStreamSynchronize(s));
+  *nnz_out = nz;
+  return SPL_OK;
+}
+
+// columns strictly ascending?  (valid Matrix invariant, tests/Test/LinearAlgebra.hs:57-58)
+bool columns_sorted(const int *d_ptr, const int *d_idx, int64_t ncols, hipStream_t s) {
+  if (ncols == 0) return true;
+  DBuf<int> flag(1);
+  SPL_HIP(hipMemsetAsync(flag.get(), 0, sizeof(int), s));
+  hipLaunchKernelGGL(sorted_check_kernel, dim3(blocks_for(ncols, 4)), dim3(256), 0, s, d_ptr, d_idx, ncols,
+                     flag.get());
+  int h = 0;
+  SPL_HIP(hipMemcpyAsync(&h, flag.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+  SPL_HIP(hipStreamSynchronize(s));
+  return h == 0;
+}
+
+// C = alpha A + beta B on device CSC arrays with sorted columns.
+void lin_device(double alpha, const int *Ap, const int *Ai, const double *Ax, double beta, const int *Bp,
+                const int *Bi, const double *Bx, int64_t ncols, DBuf<int64_t> &Cp, DBuf<int> &Ci,
+                DBuf<double> &Cx, int64_t *nnzC, hipStream_t s) {
+  Cp.alloc((size_t)ncols + 1);
+  DBuf<int> counts((size_t)ncols);
+  const unsigned grid = blocks_for(ncols, 256);
+  if (ncols > 0)
+    hipLaunchKernelGGL(lin_merge_kernel<false>, dim3(grid), dim3(256), 0, s, alpha, Ap, Ai, Ax, beta, Bp, Bi,
+                       Bx, ncols, counts.get(), (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
+  exclusive_scan_i32_to_i64(counts.get(), Cp.get(), ncols, s);
+  int64_t nz = 0;
+  SPL_HIP(hipMemcpyAsync(&nz, Cp.get() + ncols, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  SPL_HIP(hipStreamSynchronize(s));
+  Ci.alloc((size_t)nz);
+  Cx.alloc((size_t)nz);
+  if (ncols > 0 && nz > 0)
+    hipLaunchKernelGGL(lin_merge_kernel<true>, dim3(grid), dim3(256), 0, s, alpha, Ap, Ai, Ax, beta, Bp, Bi,
+                       Bx, ncols, (int *)nullptr, Cp.get(), Ci.get(), Cx.get());
+  SPL_HIP(hipStreamSynchronize(s));
+  *nnzC = nz;
+}
+
+}  // namespace spl

@@ -115,8 +115,27 @@ void transpose_compressed(const int *d_ptr, const int *d_idx, const double *d_va
 // sort every segment [ptr[i], ptr[i+1]) of (key, val) pairs by key ascending
 void segmented_sort_pairs(const int64_t *d_ptr64, int64_t nseg, int *d_key, double *d_val,
                           hipStream_t s);
+// same, but segments longer than max_len are left untouched (already sorted)
+void segmented_sort_pairs_capped(const int64_t *d_ptr64, int64_t nseg, int *d_key, double *d_val,
+                                 int64_t max_len, hipStream_t s);
+void segmented_sort_pairs64(const int64_t *d_ptr64, int64_t nseg, int64_t *d_key, double *d_val,
+                            hipStream_t s);
 // finish a Matrix whose rowptr64/colidx/val are filled: int32 pointers, stats
 void finalize_matrix(Matrix *m, hipStream_t s);
+
+// ---- assembly (assemble.hip) ------------------------------------------------------------
+int compress_device(int nrows, int ncols, int64_t nnz, const int *d_rows, const int *d_cols,
+                    const double *d_vals, int *d_newptr, DBuf<int> &out_idx, DBuf<double> &out_val,
+                    int64_t *nnz_out, int64_t *bad, hipStream_t s);
+bool columns_sorted(const int *d_ptr, const int *d_idx, int64_t ncols, hipStream_t s);
+void lin_device(double alpha, const int *Ap, const int *Ai, const double *Ax, double beta, const int *Bp,
+                const int *Bi, const double *Bx, int64_t ncols, DBuf<int64_t> &Cp, DBuf<int> &Ci,
+                DBuf<double> &Cx, int64_t *nnzC, hipStream_t s);
+
+// ---- SpGEMM (spgemm.hip) ------------------------------------------------------------------
+void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai, const double *Ax,
+                   int64_t ncolsB, const int *Bp, const int *Bi, const double *Bx, DBuf<int64_t> &Cp,
+                   DBuf<int> &Ci, DBuf<double> &Cx, int64_t *nnzC, int64_t *products, hipStream_t s);
 
 // ---- synthetic generators (generate.hip) --------------------------------------------
 void generate_synthetic(Matrix *m, int kind, int64_t n_or_m, int K, uint64_t seed, hipStream_t s);

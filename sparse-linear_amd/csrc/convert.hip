@@ -68,17 +68,25 @@ __global__ __launch_bounds__(256) void transpose_fill_kernel(
 // i with i ^ (k-1) ("flip"), later substages i with i ^ j.  Positions >= len act
 // as +inf, so a pair whose upper index is >= len is simply skipped.
 
+template <typename K>
+__device__ inline K key_max();
+template <>
+__device__ inline int key_max<int>() { return 0x7fffffff; }
+template <>
+__device__ inline int64_t key_max<int64_t>() { return 0x7fffffffffffffffLL; }
+
 // len <= 64: one wavefront, registers + shuffles
-__device__ inline void wave_sort_segment(int *key, double *val, int64_t base, int len) {
+template <typename K>
+__device__ inline void wave_sort_segment(K *key, double *val, int64_t base, int len) {
   const int lane = threadIdx.x & 63;
-  int k = lane < len ? key[base + lane] : 0x7fffffff;
+  K k = lane < len ? key[base + lane] : key_max<K>();
   double v = lane < len ? val[base + lane] : 0.0;
   int n2 = 2;
   while (n2 < len) n2 <<= 1;
   for (int size = 2; size <= n2; size <<= 1) {
     {
       const int partner = lane ^ (size - 1);
-      const int pk = __shfl(k, partner, 64);
+      const K pk = __shfl(k, partner, 64);
       const double pv = __shfl(v, partner, 64);
       const bool lower = lane < partner;
       const bool take = lower ? (pk < k) : (pk > k);
@@ -86,7 +94,7 @@ __device__ inline void wave_sort_segment(int *key, double *val, int64_t base, in
     }
     for (int j = size >> 2; j > 0; j >>= 1) {
       const int partner = lane ^ j;
-      const int pk = __shfl(k, partner, 64);
+      const K pk = __shfl(k, partner, 64);
       const double pv = __shfl(v, partner, 64);
       const bool lower = lane < partner;
       const bool take = lower ? (pk < k) : (pk > k);
@@ -96,11 +104,12 @@ __device__ inline void wave_sort_segment(int *key, double *val, int64_t base, in
   if (lane < len) { key[base + lane] = k; val[base + lane] = v; }
 }
 
+template <typename K>
 __global__ __launch_bounds__(256) void segsort_small_kernel(const int64_t *__restrict__ ptr,
-                                                            int64_t nseg, int *__restrict__ key,
+                                                            int64_t nseg, K *__restrict__ key,
                                                             double *__restrict__ val,
                                                             int64_t *__restrict__ big_list,
-                                                            int *__restrict__ big_count) {
+                                                            int *__restrict__ big_count, int64_t max_len) {
   const int lane = threadIdx.x & 63;
   const int64_t seg = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (seg >= nseg) return;
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(256) void segsort_small_kernel(const int64_t *__res
   if (len <= 1) return;
   if (len <= 64) {
     wave_sort_segment(key, val, s, (int)len);
-  } else if (lane == 0) {
+  } else if (lane == 0 && len <= max_len) {
     big_list[atomicAdd(big_count, 1)] = seg;
   }
 }
@@ -117,11 +126,12 @@ __global__ __launch_bounds__(256) void segsort_small_kernel(const int64_t *__res
 constexpr int kSortLdsCap = 4096;
 
 // len > 64: one workgroup per listed segment; LDS when it fits, global otherwise
+template <typename K>
 __global__ __launch_bounds__(256) void segsort_big_kernel(const int64_t *__restrict__ ptr,
                                                           const int64_t *__restrict__ big_list,
-                                                          int *__restrict__ key,
+                                                          K *__restrict__ key,
                                                           double *__restrict__ val) {
-  __shared__ int skey[kSortLdsCap];
+  __shared__ K skey[kSortLdsCap];
   __shared__ double sval[kSortLdsCap];
   const int64_t seg = big_list[blockIdx.x];
   const int64_t s = ptr[seg];
@@ -142,13 +152,13 @@ __global__ __launch_bounds__(256) void segsort_big_kernel(const int64_t *__restr
         const int64_t hi = flip ? (lo ^ (size - 1)) : (lo | j);
         if (hi < len) {
           if (in_lds) {
-            const int a = skey[lo], b = skey[hi];
+            const K a = skey[lo], b = skey[hi];
             if (b < a) {
               skey[lo] = b; skey[hi] = a;
               const double va = sval[lo]; sval[lo] = sval[hi]; sval[hi] = va;
             }
           } else {
-            const int a = key[s + lo], b = key[s + hi];
+            const K a = key[s + lo], b = key[s + hi];
             if (b < a) {
               key[s + lo] = b; key[s + hi] = a;
               const double va = val[s + lo]; val[s + lo] = val[s + hi]; val[s + hi] = va;
@@ -204,22 +214,36 @@ int validate_compressed(const int *d_ptr, const int *d_idx, int64_t nmajor, int6
   return h ? SPL_ERROR_invalid_matrix : SPL_OK;
 }
 
-void segmented_sort_pairs(const int64_t *d_ptr64, int64_t nseg, int *d_key, double *d_val,
-                          hipStream_t s) {
+template <typename K>
+static void segmented_sort_impl(const int64_t *d_ptr64, int64_t nseg, K *d_key, double *d_val,
+                                hipStream_t s, int64_t max_len = 0x7fffffffffffffffLL) {
   if (nseg <= 0) return;
   DBuf<int64_t> big_list((size_t)nseg);
   DBuf<int> big_count(1);
   SPL_HIP(hipMemsetAsync(big_count.get(), 0, sizeof(int), s));
-  hipLaunchKernelGGL(segsort_small_kernel, dim3(blocks_for(nseg, 4)), dim3(256), 0, s, d_ptr64, nseg,
-                     d_key, d_val, big_list.get(), big_count.get());
+  hipLaunchKernelGGL(segsort_small_kernel<K>, dim3(blocks_for(nseg, 4)), dim3(256), 0, s, d_ptr64, nseg,
+                     d_key, d_val, big_list.get(), big_count.get(), max_len);
   int nbig = 0;
   SPL_HIP(hipMemcpyAsync(&nbig, big_count.get(), sizeof(int), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
   if (nbig > 0) {
-    hipLaunchKernelGGL(segsort_big_kernel, dim3((unsigned)nbig), dim3(256), 0, s, d_ptr64,
+    hipLaunchKernelGGL(segsort_big_kernel<K>, dim3((unsigned)nbig), dim3(256), 0, s, d_ptr64,
                        big_list.get(), d_key, d_val);
     SPL_HIP(hipStreamSynchronize(s));
   }
+}
+
+void segmented_sort_pairs(const int64_t *d_ptr64, int64_t nseg, int *d_key, double *d_val,
+                          hipStream_t s) {
+  segmented_sort_impl<int>(d_ptr64, nseg, d_key, d_val, s);
+}
+void segmented_sort_pairs_capped(const int64_t *d_ptr64, int64_t nseg, int *d_key, double *d_val,
+                                 int64_t max_len, hipStream_t s) {
+  segmented_sort_impl<int>(d_ptr64, nseg, d_key, d_val, s, max_len);
+}
+void segmented_sort_pairs64(const int64_t *d_ptr64, int64_t nseg, int64_t *d_key, double *d_val,
+                            hipStream_t s) {
+  segmented_sort_impl<int64_t>(d_ptr64, nseg, d_key, d_val, s);
 }
 
 void transpose_compressed(const int *d_ptr, const int *d_idx, const double *d_val, int64_t nmajor,

@@ -1,0 +1,80 @@
+"""SpGEMM (mm, Sparse.hs:691-702) on the HIP path: structure bit-exact, values bit-exact
+(the kernels keep the reference's ascending-k accumulation order), every size bin."""
+import numpy as np
+import pytest
+
+from helpers import csc_tuple_to_scipy, mat_to_tuple, tuple_to_mat, tuples_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_csc(O, rng, nr, nc, k, ints=False):
+    v = rng.integers(-4, 5, k).astype(float) if ints else rng.uniform(0.5, 1.5, k)
+    return O.compress(nr, nc, rng.integers(0, nr, k), rng.integers(0, nc, k), v)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (40, 30, 50, 300), (300, 300, 300, 3000),
+                                   (2000, 1500, 1800, 30000), (200, 5000, 100, 8000)])
+def test_mm_matches_oracle_bitwise(gpu, pkg, O, shape):
+    rng = np.random.default_rng(sum(shape))
+    m, n, p, k = shape
+    A, B = rand_csc(O, rng, m, n, k), rand_csc(O, rng, n, p, k)
+    C = pkg.mm(tuple_to_mat(pkg, A), tuple_to_mat(pkg, B))
+    Co = O.mm(A, B)
+    assert tuples_equal(mat_to_tuple(C), Co)
+    assert O.check_matrix(mat_to_tuple(C)) == 0
+
+
+def test_mm_all_bins(gpu, pkg, O):
+    """columns of B engineered so that every accumulator bin is used: a few products (LDS
+    table per wavefront), a few thousand (LDS table per workgroup), tens of thousands
+    (dense accumulator in HBM)"""
+    rng = np.random.default_rng(9)
+    n = 6000
+    # A: ~40 per column, plus three dense-ish columns
+    rows = [rng.integers(0, n, 40 * n)]
+    cols = [np.repeat(np.arange(n), 40)]
+    for c in (7, 1000, 4242):
+        rows.append(rng.choice(n, 3000, replace=False))
+        cols.append(np.full(3000, c))
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    A = O.compress(n, n, rows, cols, rng.uniform(0.5, 1.5, len(rows)))
+    # B: column 0 empty, column 1 tiny, column 2 medium (~60 entries -> ~2400 products),
+    # column 3 heavy (hits the dense columns of A), the rest ~3 entries
+    brow = [rng.integers(0, n, 3 * n), np.array([5]), rng.choice(n, 60, replace=False),
+            np.concatenate([[7, 1000, 4242], rng.choice(n, 300, replace=False)])]
+    bcol = [rng.integers(4, n, 3 * n), np.array([1]), np.full(60, 2), np.full(303, 3)]
+    brow, bcol = np.concatenate(brow), np.concatenate(bcol)
+    B = O.compress(n, n, brow, bcol, rng.uniform(0.5, 1.5, len(brow)))
+    C = pkg.mm(tuple_to_mat(pkg, A), tuple_to_mat(pkg, B))
+    Co = O.mm(A, B)
+    assert np.array_equal(C.pointers, Co[2]) and np.array_equal(C.indices, Co[3])
+    assert np.array_equal(C.values, Co[4])
+    lens = np.diff(Co[2])
+    assert lens[0] == 0 and lens[3] > 4096 and 256 < lens[2] <= 4096
+
+
+def test_mm_vs_scipy_independent(gpu, pkg, O):
+    rng = np.random.default_rng(21)
+    A, B = rand_csc(O, rng, 400, 300, 5000, ints=True), rand_csc(O, rng, 300, 500, 5000, ints=True)
+    C = pkg.mm(tuple_to_mat(pkg, A), tuple_to_mat(pkg, B))
+    ref = (csc_tuple_to_scipy(A) @ csc_tuple_to_scipy(B)).toarray()
+    assert np.array_equal(pkg.pack(C), ref)
+
+
+def test_mm_A_times_A_random_generator(gpu, pkg, O):
+    """A*A on a synthetic random matrix (the C4 shape in miniature)"""
+    n = 20000
+    rp, ci, v = O.gen_random_csr(n, 16)
+    A = O.csr_to_csc_tuple(n, n, rp, ci, v)
+    M = tuple_to_mat(pkg, A)
+    C = M * M
+    assert tuples_equal(mat_to_tuple(C), O.mm(A, A))
+
+
+def test_mm_unsorted_input_columns(gpu, pkg, O):
+    """fromForeign-style inputs with unsorted columns are tolerated (sorted on upload)"""
+    A = pkg.Matrix(2, 3, [0, 2, 3], [2, 0, 1], [1.0, 2.0, 3.0])  # column 0 has rows (2, 0)
+    As = pkg.Matrix(2, 3, [0, 2, 3], [0, 2, 1], [2.0, 1.0, 3.0])
+    B = pkg.ident(2)
+    assert A * B == As
