@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--draws", type=int, default=20)
     ap.add_argument("--matrix", default="random", choices=["random", "banded"])
     ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (ablation)")
+    ap.add_argument("--blocked", default="", help="force the column-blocked image: rows_per_panel,cols_log2[,unroll]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
     args = ap.parse_args()
@@ -79,7 +80,13 @@ def main():
 
     # ---- inputs resident in HBM before anything is timed
     H = pkg.DeviceMatrix.synthetic(args.matrix, n, args.draws, seed=0x5EED, row0=r0, row1=r1)
-    H.set_variant(args.variant)
+    if args.blocked:
+        H.build_blocked(*[int(t) for t in args.blocked.split(",")])
+        H.set_variant(8)
+    elif args.variant:
+        H.set_variant(args.variant)
+    else:
+        H.optimize()  # one-time analysis (not timed): picks CSR-stream or the column-blocked image
     info = H.info()
     stream = torch.cuda.current_stream()
     x = torch.empty(n, dtype=torch.float64, device="cuda")
@@ -148,7 +155,7 @@ def main():
                                % (args.matrix, n, n, args.draws, nnz_total,
                                   "" if N == 1 else ", %d row blocks + RCCL all-gather of y" % N),
                    "algorithmic_bytes": B_total, "hbm_frac_of_%dx8TBps" % N: round(value / (N * HBM_PEAK_GBPS), 4),
-                   "variant": args.variant},
+                   "variant": args.variant, "blocked": args.blocked or "auto"},
         "roofline": roofline,
     }
 

@@ -149,6 +149,16 @@ int spl_matrix_spmv_dev(void *H, const double *d_x, double *d_y, int accumulate,
  * 0 = default.  Returns SPL_ERROR_argument_missing for an unknown variant. */
 int spl_matrix_set_variant(void *H, int variant);
 
+/* Analyse the matrix once (like umfpack_*_symbolic) and, if its columns have no
+ * locality and x exceeds the L2s, build the column-blocked image that variant 0
+ * then uses (csrc/spmv_blocked.hip).  Results are bit-identical either way. */
+int spl_matrix_optimize(void *H);
+/* build that image with an explicit shape (tuning / ablation): panels of rows_per_panel rows,
+ * column blocks of 2^cols_log2 columns (rows_per_panel << cols_log2 must fit 31 bits);
+ * 0,0 = choose.  unroll: 0 default, {4,8,10,12} 64-entry chunks per register set of the
+ * lockstep kernel; negative {-1,-2,-4,-8} selects the free-running baseline kernel. */
+int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unroll);
+
 /* fill a device vector with the synthetic entries j in [j0,j1) */
 int spl_vector_synthetic_dev(uint64_t seed, int64_t j0, int64_t j1, double *d_x, void *stream);
 

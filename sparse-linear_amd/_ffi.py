@@ -101,6 +101,8 @@ def _declare(L):
         "spl_matrix_gaxpy": [C.c_void_p, i, c_dbl_p, i, c_dbl_p],
         "spl_matrix_spmv_dev": [C.c_void_p, C.c_void_p, C.c_void_p, i, C.c_void_p],
         "spl_matrix_set_variant": [C.c_void_p, i],
+        "spl_matrix_optimize": [C.c_void_p],
+        "spl_matrix_build_blocked": [C.c_void_p, i, i, i],
         "spl_vector_synthetic_dev": [u64, i64, i64, C.c_void_p, C.c_void_p],
     }
     for name, args in sigs.items():

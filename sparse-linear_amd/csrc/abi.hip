@@ -385,8 +385,49 @@ int spl_matrix_set_variant(void *H, int variant) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;
   if (variant < 0 || variant >= kNumSpmvVariants) return SPL_ERROR_argument_missing;
+  if (variant == 8 && !m->blocked) {
+    int st = spl_matrix_build_blocked(H, 0, 0, 0);
+    if (st != SPL_OK) return st;
+  }
   m->variant = variant;
   return SPL_OK;
+}
+
+int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unroll) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  int waves = 16;
+  if (rows_per_panel == 0 && cols_log2 == 0) {
+    choose_blocking(m, &rows_per_panel, &cols_log2, &waves);
+    if (rows_per_panel == 0) { rows_per_panel = 1024; cols_log2 = 18; }  // explicit request: default shape
+  }
+  if (const char *ev = getenv("SPL_BLOCKED_LOCKSTEP")) waves = atoi(ev);
+  if (waves != 0 && waves != 8) waves = 16;
+  if (rows_per_panel < 1 || rows_per_panel > 20480 || cols_log2 < 4 || cols_log2 > 26 ||
+      ((int64_t)rows_per_panel << cols_log2) > 0x7fffffffLL)
+    return SPL_ERROR_argument_missing;
+  // the lockstep workgroup keeps `waves` panels in one CU's LDS (160 KiB)
+  while (waves > 0 && (size_t)waves * (size_t)rows_per_panel * sizeof(double) > 160 * 1024)
+    waves = waves == 16 ? 8 : 0;
+  if (waves == 0 && (size_t)4 * (size_t)rows_per_panel * sizeof(double) > 160 * 1024)
+    return SPL_ERROR_argument_missing;
+  return guarded([&]() -> int {
+    DeviceGuard g(m->device);
+    build_blocked_image(m, rows_per_panel, cols_log2, nullptr);
+    m->blocked_unroll = unroll;
+    m->blocked->lockstep_waves = waves;
+    if (const char *ev = getenv("SPL_BLOCKED_FOLD")) m->blocked->fold = atoi(ev) ? 1 : 0;
+    return SPL_OK;
+  });
+}
+
+int spl_matrix_optimize(void *H) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  int R = 0, w = 0, waves = 16;
+  choose_blocking(m, &R, &w, &waves);
+  if (R == 0) return SPL_OK;  // the CSR-stream kernel is already the right one
+  return spl_matrix_build_blocked(H, R, w, 0);
 }
 
 int spl_vector_synthetic_dev(uint64_t seed, int64_t j0, int64_t j1, double *d_x, void *stream) {

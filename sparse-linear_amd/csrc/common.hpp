@@ -74,6 +74,18 @@ struct DeviceGuard {
 
 constexpr uint32_t kMatrixMagic = 0x53504C4Du;  // "SPLM"
 
+// column-blocked image of a row block (spmv_blocked.hip)
+struct BlockedImage {
+  int R = 0, w = 0;               // panel = R rows (R << w must fit 31 bits), column block = 2^w columns
+  int64_t npanels = 0, ncb = 0;
+  DBuf<int64_t> segptr;           // npanels*ncb + 1
+  DBuf<int> key;                  // nnz: (local_row << w) | local_col
+  DBuf<double> val;               // nnz
+  DBuf<unsigned> arrive;          // rendezvous counter of the persistent kernel
+  int fold = 1;                   // 1: ds_add_f64 fold, 0: shuffle fold (both reference order)
+  int lockstep_waves = 16;        // wavefronts (= panels) per lockstep workgroup: 16 or 8; 0 = ablation kernel
+};
+
 // A device-resident block of rows [row0, row0+nrows_local) of a sparse matrix
 // with nrows_global x ncols entries, stored row-major (CSR, int32 column
 // indices, int64 row pointers relative to the block).
@@ -87,6 +99,13 @@ struct Matrix {
   DBuf<double> val;        // nnz
   int variant = 0;
   int64_t max_row_len = 0;
+  double new_line_fraction = 0.0;  // share of entries whose x line the previous row did not touch
+  BlockedImage *blocked = nullptr;  // built on demand (spl_matrix_build_blocked / auto)
+  int blocked_unroll = 0;  // 0 = default; < 0 selects the ablation kernel
+  Matrix() = default;
+  Matrix(const Matrix &) = delete;
+  Matrix &operator=(const Matrix &) = delete;
+  ~Matrix() { delete blocked; }
 };
 
 inline Matrix *as_matrix(void *h) {
@@ -144,6 +163,11 @@ void generate_vector(uint64_t seed, int64_t j0, int64_t j1, double *d_x, hipStre
 // ---- SpMV (spmv.hip) --------------------------------------------------------------------
 // y = A x (accumulate == 0) or y <- A x + y, rows of the block; enqueued on s
 int launch_spmv(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s);
-constexpr int kNumSpmvVariants = 8;
+constexpr int kNumSpmvVariants = 12;  // 0 auto, 1-6 CSR-stream shapes, 7 sub-wavefront, 8 column-blocked
+void build_blocked_image(Matrix *m, int rows_per_panel, int w, hipStream_t s);
+int launch_spmv_blocked(const Matrix *m, const double *d_x, double *d_y, int accumulate, int unroll,
+                        hipStream_t s);
+// choose the blocked image's shape for this matrix (0,0 = blocking would not help)
+void choose_blocking(const Matrix *m, int *rows_per_panel, int *w, int *waves);
 
 }  // namespace spl

@@ -191,6 +191,33 @@ __global__ __launch_bounds__(256) void max_len_kernel(const int64_t *__restrict_
   if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
 }
 
+// share of entries whose 128-byte x line (16 doubles) is not touched by the previous row:
+// ~1 for uniformly random columns, ~1/16 for banded / stencil rows
+__global__ __launch_bounds__(256) void new_line_kernel(const int64_t *__restrict__ ptr,
+                                                       const int *__restrict__ col, int64_t nrows,
+                                                       int64_t stride_rows,
+                                                       unsigned long long *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = 1 + i * stride_rows;
+  unsigned long long fresh = 0, total = 0;
+  if (r < nrows) {
+    const int64_t ps = ptr[r - 1], pe = ptr[r], ce = ptr[r + 1];
+    int64_t q = ps;
+    for (int64_t k = pe; k < ce; ++k) {
+      const int line = col[k] >> 4;
+      while (q < pe && (col[q] >> 4) < line) ++q;
+      fresh += !(q < pe && (col[q] >> 4) == line);
+      ++total;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    fresh += __shfl_xor(fresh, d, 64);
+    total += __shfl_xor(total, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && total) { atomicAdd(&out[0], fresh); atomicAdd(&out[1], total); }
+}
+
 }  // namespace
 
 int validate_compressed(const int *d_ptr, const int *d_idx, int64_t nmajor, int64_t nminor,
@@ -283,6 +310,20 @@ void finalize_matrix(Matrix *m, hipStream_t s) {
   SPL_HIP(hipMemcpyAsync(&h, mx.get(), sizeof(h), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
   m->max_row_len = (int64_t)h;
+  // sample about 64k rows for the locality estimate that steers choose_blocking()
+  m->new_line_fraction = 0.0;
+  if (nl > 1 && m->nnz > 0) {
+    DBuf<unsigned long long> acc(2);
+    SPL_HIP(hipMemsetAsync(acc.get(), 0, 2 * sizeof(unsigned long long), s));
+    const int64_t stride = nl / 65536 > 0 ? nl / 65536 : 1;
+    const int64_t samples = (nl - 1 + stride - 1) / stride;
+    hipLaunchKernelGGL(new_line_kernel, dim3(blocks_for(samples, 256)), dim3(256), 0, s, m->rowptr64.get(),
+                       m->colidx.get(), nl, stride, acc.get());
+    unsigned long long ha[2] = {0, 0};
+    SPL_HIP(hipMemcpyAsync(ha, acc.get(), sizeof(ha), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipStreamSynchronize(s));
+    if (ha[1]) m->new_line_fraction = (double)ha[0] / (double)ha[1];
+  }
 }
 
 }  // namespace spl

@@ -45,6 +45,16 @@ __device__ inline T stream_load(const T *p) {
   return *p;
 }
 
+// flavours of the x gather (ablation): 0 plain, 1 non-temporal, 2 agent-scope (sc1, bypasses
+// the CU's L1), 3 system-scope (sc0 sc1)
+template <int GF>
+__device__ inline double gather_load(const double *p) {
+  if (GF == 1) return __builtin_nontemporal_load(p);
+  if (GF == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (GF == 3) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return *p;
+}
+
 __device__ inline double wave_sum(double v) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -53,7 +63,7 @@ __device__ inline double wave_sum(double v) {
 
 // EPL: elements per lane per pass (chunk = 64*EPL products in LDS per wavefront)
 // VW : elements per vector load (1, 2 or 4)
-template <int EPL, int VW, bool NT, typename PtrT>
+template <int EPL, int VW, bool NT, typename PtrT, int GF = 0>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void spmv_stream(
     int64_t nrows, int64_t nblocks, const PtrT *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmv_stream(
     }
     double p[EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) p[e] = a[e] * x[c[e]];
+    for (int e = 0; e < EPL; ++e) p[e] = a[e] * gather_load<GF>(x + c[e]);
 
     // ---- one long row covers the whole chunk: wavefront-wide reduction
     const bool covers = (my_s <= b0) && (my_e >= b0 + CH);
@@ -179,17 +189,17 @@ __global__ __launch_bounds__(256) void spmv_subwave(int64_t nrows, const int *__
   if (valid && gl == 0) y[r] = accumulate ? acc + y[r] : acc;
 }
 
-template <int EPL, int VW, bool NT>
+template <int EPL, int VW, bool NT, int GF = 0>
 int launch_stream(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s) {
   const int64_t nblocks = (m->nrows_local + kRowsPerBlock - 1) / kRowsPerBlock;
   const int64_t grid = ((nblocks + 7) / 8) * 8;
   if (grid > 0x7fffffffLL) return SPL_ERROR_internal;
   if (m->rowptr.get()) {
-    hipLaunchKernelGGL((spmv_stream<EPL, VW, NT, int>), dim3((unsigned)grid), dim3(kWavesPerBlock * 64),
+    hipLaunchKernelGGL((spmv_stream<EPL, VW, NT, int, GF>), dim3((unsigned)grid), dim3(kWavesPerBlock * 64),
                        0, s, m->nrows_local, nblocks, m->rowptr.get(), m->colidx.get(), m->val.get(),
                        d_x, d_y, accumulate);
   } else {
-    hipLaunchKernelGGL((spmv_stream<EPL, VW, NT, int64_t>), dim3((unsigned)grid),
+    hipLaunchKernelGGL((spmv_stream<EPL, VW, NT, int64_t, GF>), dim3((unsigned)grid),
                        dim3(kWavesPerBlock * 64), 0, s, m->nrows_local, nblocks, m->rowptr64.get(),
                        m->colidx.get(), m->val.get(), d_x, d_y, accumulate);
   }
@@ -201,6 +211,10 @@ int launch_stream(const Matrix *m, const double *d_x, double *d_y, int accumulat
 int launch_spmv(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s) {
   if (m->nrows_local == 0) return SPL_OK;
   int st = SPL_OK;
+  if (m->variant == 8 || (m->variant == 0 && m->blocked)) {
+    if (!m->blocked) return SPL_ERROR_argument_missing;
+    return launch_spmv_blocked(m, d_x, d_y, accumulate, m->blocked_unroll, s);
+  }
   switch (m->variant) {
     case 0:
     case 1: st = launch_stream<8, 2, true>(m, d_x, d_y, accumulate, s); break;
@@ -209,6 +223,9 @@ int launch_spmv(const Matrix *m, const double *d_x, double *d_y, int accumulate,
     case 4: st = launch_stream<16, 4, true>(m, d_x, d_y, accumulate, s); break;
     case 5: st = launch_stream<8, 1, true>(m, d_x, d_y, accumulate, s); break;
     case 6: st = launch_stream<8, 2, false>(m, d_x, d_y, accumulate, s); break;
+    case 9: st = launch_stream<8, 2, true, 1>(m, d_x, d_y, accumulate, s); break;
+    case 10: st = launch_stream<8, 2, true, 2>(m, d_x, d_y, accumulate, s); break;
+    case 11: st = launch_stream<8, 2, true, 3>(m, d_x, d_y, accumulate, s); break;
     case 7: {
       if (!m->rowptr.get()) return SPL_ERROR_index_overflow;
       const int64_t threads = m->nrows_local * 16;
@@ -223,6 +240,34 @@ int launch_spmv(const Matrix *m, const double *d_x, double *d_y, int accumulate,
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_last_error("spmv launch", e); return SPL_ERROR_device; }
   return SPL_OK;
+}
+
+// Blocking pays when x does not fit the L2s and neighbouring rows do not share x lines
+// (measured: random 1e7 gathers move 10x the algorithmic bytes; banded rows reuse lines).
+// Shape: 16 panels per CU fill its LDS; the panel height is chosen so that the generations of
+// the persistent grid are full (n = 1e7 on 256 CUs: 2 generations of 4096 panels of 1221 rows).
+void choose_blocking(const Matrix *m, int *rows_per_panel, int *w, int *waves) {
+  *rows_per_panel = 0;
+  *w = 0;
+  *waves = 16;
+  const int64_t x_bytes = m->ncols * 8;
+  if (x_bytes <= (32LL << 20)) return;       // x fits the aggregate L2: gathers already hit
+  if (m->new_line_fraction < 0.5) return;    // rows reuse their neighbours' lines (banded, stencil)
+  if (m->nnz < 4 * m->nrows_local) return;   // too sparse for 64-entry chunks per segment
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device);
+  const int64_t slots = (int64_t)cus * 16;
+  const int64_t rmax = (160 * 1024 / 8) / 16;  // 1280 rows of y per wavefront
+  const int64_t ngen = (m->nrows_local + slots * rmax - 1) / (slots * rmax);
+  int64_t R = (m->nrows_local + ngen * slots - 1) / (ngen * slots);
+  if (R < 64) R = 64;
+  *rows_per_panel = (int)R;
+  // column block: 2 MiB of x unless segments would outgrow the 10-chunk register pipeline
+  const double avg = (double)m->nnz / (double)(m->nrows_local > 0 ? m->nrows_local : 1);
+  // (a segment longer than the register pipeline just takes the un-pipelined tail loop)
+  int ww = 18;
+  while (ww > 14 && avg * (double)R / (double)((m->ncols >> ww) + 1) > 1100.0) --ww;
+  *w = ww;
 }
 
 }  // namespace spl

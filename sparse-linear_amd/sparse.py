@@ -98,6 +98,7 @@ class Matrix(object):
         """Upload once, reuse for every later SpMV (handle API)."""
         if self._handle is None:
             self._handle = DeviceMatrix.from_csc(self)
+            self._handle.optimize()  # one-time analysis, like umfpack_*_symbolic
         return self._handle
 
 
@@ -183,6 +184,14 @@ class DeviceMatrix(object):
 
     def set_variant(self, variant):
         check("spl_matrix_set_variant", lib().spl_matrix_set_variant(self.handle, int(variant)))
+
+    def optimize(self):
+        """one-time analysis; may build the column-blocked image (csrc/spmv_blocked.hip)"""
+        check("spl_matrix_optimize", lib().spl_matrix_optimize(self.handle))
+
+    def build_blocked(self, rows_per_panel=0, cols_log2=0, unroll=0):
+        check("spl_matrix_build_blocked",
+              lib().spl_matrix_build_blocked(self.handle, rows_per_panel, cols_log2, unroll))
 
     def mulv(self, x):
         x = as_f64(x)
