@@ -142,9 +142,17 @@ def main():
     torch.cuda.synchronize()
     kern_ms = ev0.elapsed_time(ev1) / args.steps
     achieved = B_local / (kern_ms * 1e-3) / 1e9
+    info = H.info()
+    kernel = "spmv_blocked_lockstep" if info["blocked_rows"] else "spmv_stream"
+    traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (N = 1, default sizes only)
+    tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if N == 1 and n == 10_000_000 and args.draws == 20 and os.path.exists(tfile):
+        traffic = json.load(open(tfile)).get("%s:%s" % (args.matrix, kernel))
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                "kernel": "spmv_stream", "kernel_ms": round(kern_ms, 4), "bytes_per_launch": B_local}
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "kernel": kernel, "kernel_ms": round(kern_ms, 4), "bytes_per_launch": B_local}
+    if info["blocked_rows"]:
+        roofline["image"] = "column-blocked: %d rows/panel, 2^%d columns/block" % (info["blocked_rows"], info["blocked_cols_log2"])
 
     out = {
         "metric": "fp64 CSR SpMV effective GB/s", "value": round(value, 1), "unit": "GB/s",

@@ -127,8 +127,9 @@ int spl_matrix_create_synthetic(int kind, int64_t n_or_m, int K, uint64_t seed, 
                                 int64_t row1, void **H);
 void spl_matrix_free(void **H);
 
-/* info[0..5] = nrows_global, ncols, row0, nrows_local, nnz_local, device */
-int spl_matrix_info(void *H, int64_t info[6]);
+/* info[0..7] = nrows_global, ncols, row0, nrows_local, nnz_local, device,
+ * rows per panel of the column-blocked image (0 = CSR-stream kernel in use), its cols_log2 */
+int spl_matrix_info(void *H, int64_t info[8]);
 /* copy the device CSR image back: rowptr[nrows_local+1] (relative to the block,
  * rowptr[0]=0), colidx[nnz_local], val[nnz_local] */
 int spl_matrix_export_csr(void *H, int64_t *rowptr, int *colidx, double *val);

@@ -308,7 +308,7 @@ void spl_matrix_free(void **H) {
   if (have_prev) (void)hipSetDevice(prev);
 }
 
-int spl_matrix_info(void *H, int64_t info[6]) {
+int spl_matrix_info(void *H, int64_t info[8]) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;
   if (!info) return SPL_ERROR_argument_missing;
@@ -318,6 +318,9 @@ int spl_matrix_info(void *H, int64_t info[6]) {
   info[3] = m->nrows_local;
   info[4] = m->nnz;
   info[5] = m->device;
+  const bool blocked = m->blocked && (m->variant == 0 || m->variant == 8);
+  info[6] = blocked ? m->blocked->R : 0;
+  info[7] = blocked ? m->blocked->w : 0;
   return SPL_OK;
 }
 

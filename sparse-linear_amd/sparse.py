@@ -160,9 +160,9 @@ class DeviceMatrix(object):
         return cls(h.value)
 
     def info(self):
-        buf = (C.c_int64 * 6)()
+        buf = (C.c_int64 * 8)()
         check("spl_matrix_info", lib().spl_matrix_info(self.handle, buf))
-        keys = ("nrows_global", "ncols", "row0", "nrows_local", "nnz", "device")
+        keys = ("nrows_global", "ncols", "row0", "nrows_local", "nnz", "device", "blocked_rows", "blocked_cols_log2")
         return dict(zip(keys, [int(v) for v in buf]))
 
     def export_csr(self):
