@@ -1,0 +1,67 @@
+/*
+ * umfpack_hip.h — the link-time ABI of the LU / solve step, served by the MI355X backend.
+ *
+ * These are exactly the real-valued symbols that the reference imports from SuiteSparse
+ * UMFPACK (suitesparse/src/Numeric/LinearAlgebra/Umfpack/Internal.hs:137-148):
+ *     umfpack_di_symbolic   (called by `analyze`,      Umfpack.hs:64)
+ *     umfpack_di_numeric    (called by `factor`,       Umfpack.hs:78)
+ *     umfpack_di_solve      (called by `linearSolve_`, Umfpack.hs:99)
+ *     umfpack_di_free_symbolic / umfpack_di_free_numeric   (ForeignPtr finalizers, :65,79)
+ *     umfpack_di_report_status                              (:66,80,100)
+ * with the argument lists of the Haskell type synonyms UmfpackSymbolic / UmfpackNumeric /
+ * UmfpackSolve / UmfpackReport (Internal.hs:26-59).  Linking the reference's `suitesparse`
+ * package against libsparse_linear_hip.so instead of libumfpack routes `analyze`, `factor`,
+ * `linearSolve_`, `linearSolve` and `(<\>)` to the GPU with no Haskell change.
+ *
+ * Conventions honoured: CSC, 0-based, int32, borrowed for the call only;
+ * Control and Info may be NULL (the reference always passes NULL => UMFPACK defaults, which
+ * include up to 2 steps of iterative refinement in solve); Symbolic/Numeric are opaque,
+ * callee-allocated, written through void**; the free functions take that void**, are
+ * idempotent and may run on any thread; status: 0 OK, 1 singular-matrix warning, < 0 error;
+ * only sys = 0 (A x = b) and sys = 1 (A^T x = b; UMFPACK_At) are ever passed (Umfpack.hs:95-97).
+ *
+ * Algorithm (round 1): a reverse-Cuthill-McKee profile ordering on the host (symbolic), then
+ * LU with partial pivoting of the permuted matrix in LAPACK band storage entirely on the GPU
+ * (numeric), banded forward/back substitution and SpMV-based iterative refinement on the GPU
+ * (solve).  Square matrices only (the reference's linearSolve_ assumes square, Umfpack.hs:93).
+ * The complex (`zi`) entry points are not built yet.
+ */
+#ifndef UMFPACK_HIP_H
+#define UMFPACK_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UMFPACK_OK 0
+#define UMFPACK_WARNING_singular_matrix 1
+#define UMFPACK_ERROR_out_of_memory (-1)
+#define UMFPACK_ERROR_invalid_Numeric_object (-3)
+#define UMFPACK_ERROR_invalid_Symbolic_object (-4)
+#define UMFPACK_ERROR_argument_missing (-5)
+#define UMFPACK_ERROR_n_nonpositive (-6)
+#define UMFPACK_ERROR_invalid_matrix (-8)
+#define UMFPACK_ERROR_different_pattern (-11)
+#define UMFPACK_ERROR_invalid_system (-13)
+#define UMFPACK_ERROR_internal_error (-911)
+
+#define UMFPACK_A 0   /* A x = b   */
+#define UMFPACK_At 1  /* A' x = b  */
+
+int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], const double Ax[],
+                        void **Symbolic, const double Control[], double Info[]);
+
+int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *Symbolic,
+                       void **Numeric, const double Control[], double Info[]);
+
+int umfpack_di_solve(int sys, const int Ap[], const int Ai[], const double Ax[], double X[],
+                     const double B[], void *Numeric, const double Control[], double Info[]);
+
+void umfpack_di_free_symbolic(void **Symbolic);
+void umfpack_di_free_numeric(void **Numeric);
+void umfpack_di_report_status(const double Control[], int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMFPACK_HIP_H */

@@ -18,3 +18,4 @@ from .sparse import *  # noqa: F401,F403
 from .sparse import DeviceMatrix, Matrix, SparseError  # noqa: F401
 from .foreign import fromForeign, withConstMatrix  # noqa: F401
 from . import dist  # noqa: F401
+from . import umfpack  # noqa: F401

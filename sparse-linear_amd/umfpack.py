@@ -1,0 +1,123 @@
+"""Mirror of ``Numeric.LinearAlgebra.Umfpack`` (suitesparse/src/Numeric/LinearAlgebra/Umfpack.hs).
+
+Same interface as the reference: the simple ``linearSolve`` / ``solve`` (``<\\>``) and the
+advanced ``analyze`` / ``factor`` / ``linearSolve_`` with ``UmfpackNormal`` / ``UmfpackTrans``,
+over the same six ``umfpack_di_*`` C symbols (include/umfpack_hip.h) that the reference
+imports (Umfpack/Internal.hs:137-148).  Handles are owned like the reference's ForeignPtrs:
+the free function is the finalizer and receives a ``void**``.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import as_f64, lib, p_f64, p_i32
+
+UmfpackNormal = 0  # sys = UMFPACK_A   (Umfpack.hs:95-97)
+UmfpackTrans = 1   # sys = UMFPACK_At
+
+
+class UmfpackError(RuntimeError):
+    """negative status: the reference calls errorWithStackTrace (Umfpack.hs:67,81,101)"""
+
+
+def _declare():
+    L = lib()
+    if getattr(L, "_umf_declared", False):
+        return L
+    i, vp, ip, dp = C.c_int, C.c_void_p, _ffi.c_int_p, _ffi.c_dbl_p
+    L.umfpack_di_symbolic.restype = i
+    L.umfpack_di_symbolic.argtypes = [i, i, ip, ip, dp, C.POINTER(vp), dp, dp]
+    L.umfpack_di_numeric.restype = i
+    L.umfpack_di_numeric.argtypes = [ip, ip, dp, vp, C.POINTER(vp), dp, dp]
+    L.umfpack_di_solve.restype = i
+    L.umfpack_di_solve.argtypes = [i, ip, ip, dp, dp, dp, vp, dp, dp]
+    L.umfpack_di_free_symbolic.restype = None
+    L.umfpack_di_free_symbolic.argtypes = [C.POINTER(vp)]
+    L.umfpack_di_free_numeric.restype = None
+    L.umfpack_di_free_numeric.argtypes = [C.POINTER(vp)]
+    L.umfpack_di_report_status.restype = None
+    L.umfpack_di_report_status.argtypes = [dp, i]
+    L._umf_declared = True
+    return L
+
+
+def _report(where, status):
+    L = _declare()
+    L.umfpack_di_report_status(None, status)  # umfpack_report_status mat nullPtr _stat
+    if status < 0:
+        raise UmfpackError("%s failed (status %d)" % (where, status))
+    return status
+
+
+class _Handle(object):
+    def __init__(self, value, free_name):
+        self._h = C.c_void_p(value)
+        self._finalizer = weakref.finalize(self, _Handle._free, self._h, free_name)
+
+    @staticmethod
+    def _free(h, free_name):
+        try:
+            getattr(lib(), free_name)(C.byref(h))
+        except Exception:
+            pass
+
+    @property
+    def value(self):
+        return self._h
+
+
+class Analysis(_Handle):
+    """newtype Analysis a = Analysis { fsym :: ForeignPtr (Symbolic a) } (Umfpack.hs:56)"""
+
+
+class Factors(_Handle):
+    """newtype Factors a = Factors { fnum :: ForeignPtr (Numeric a) } (Umfpack.hs:58)"""
+    status = 0
+
+
+def analyze(mat):
+    """symbolic analysis (Umfpack.hs:60-69)"""
+    L = _declare()
+    nr, nc, ap, ai, ax = mat._tuple32()
+    sym = C.c_void_p()
+    st = L.umfpack_di_symbolic(nr, nc, p_i32(ap), p_i32(ai), p_f64(ax), C.byref(sym), None, None)
+    a = Analysis(sym.value, "umfpack_di_free_symbolic")
+    _report("analyze: umfpack_symbolic", st)
+    return a
+
+
+def factor(mat, analysis):
+    """numeric factorisation (Umfpack.hs:71-83); needs a GPU"""
+    L = _declare()
+    _ffi.require_gpu()
+    nr, nc, ap, ai, ax = mat._tuple32()
+    num = C.c_void_p()
+    st = L.umfpack_di_numeric(p_i32(ap), p_i32(ai), p_f64(ax), analysis.value, C.byref(num), None, None)
+    f = Factors(num.value, "umfpack_di_free_numeric")
+    f.status = _report("factor: umfpack_numeric", st)
+    return f
+
+
+def linearSolve_(fact, mode, mat, b):
+    """solve with existing factors (Umfpack.hs:87-102); returns the solution vector"""
+    L = _declare()
+    nr, nc, ap, ai, ax = mat._tuple32()
+    b = as_f64(b)
+    soln = np.zeros(mat.ncols, dtype=np.float64)  # MV.replicate ncols 0 (:93)
+    st = L.umfpack_di_solve(int(mode), p_i32(ap), p_i32(ai), p_f64(ax), p_f64(soln), p_f64(b), fact.value,
+                            None, None)
+    _report("linearSolve_: umfpack_solve", st)
+    return soln
+
+
+def linearSolve(mat, bs):
+    """factor once, solve for every right-hand side (Umfpack.hs:38-46)"""
+    fact = factor(mat, analyze(mat))
+    return [linearSolve_(fact, UmfpackNormal, mat, b) for b in bs]
+
+
+def solve(mat, b):
+    """the reference's (<\\>) (Umfpack.hs:48-50)"""
+    return linearSolve(mat, [b])[0]

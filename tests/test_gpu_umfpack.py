@@ -1,0 +1,128 @@
+"""The umfpack_di_* ABI on the GPU (suitesparse/src/Numeric/LinearAlgebra/Umfpack.hs).
+The reference pins exactly one thing: `ident <\\> v == v` (suitesparse/tests/test-umfpack.hs:16-19,
+exact equality).  Everything else is checked on the solution: manufactured solutions, residuals,
+the CPU oracle and scipy (UMFPACK's pivot order is an un-pinned implementation detail)."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from helpers import csc_tuple_to_scipy, mat_to_tuple, tuple_to_mat
+
+pytestmark = pytest.mark.gpu
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+@given(st.lists(st.floats(-1e6, 1e6, allow_nan=False), min_size=1, max_size=60))
+def test_ident_solve_exact(gpu, pkg, v):
+    v = np.array(v)
+    assert np.array_equal(pkg.umfpack.solve(pkg.ident(len(v)), v), v)  # prop_linSolveId
+
+
+def test_feast_fixture_matrix(gpu, pkg, O):
+    A = pkg.fromTriples(2, 2, [(0, 0, 2), (0, 1, -1), (1, 0, -1), (1, 1, 2)])
+    x = pkg.umfpack.solve(A, np.array([1.0, 0.0]))
+    assert O.count_not_close(x, np.array([2.0 / 3.0, 1.0 / 3.0])) == 0
+
+
+@pytest.mark.parametrize("m", [5, 30, 100])
+def test_poisson2d_manufactured(gpu, pkg, O, m):
+    n = m * m
+    rp, ci, v = O.gen_poisson2d_csr(m)
+    A = pkg.Matrix(n, n, rp, ci, v)
+    xs = O.gen_vector(n)
+    b = O.mulV(mat_to_tuple(A), xs)
+    fact = pkg.umfpack.factor(A, pkg.umfpack.analyze(A))
+    x = pkg.umfpack.linearSolve_(fact, pkg.umfpack.UmfpackNormal, A, b)
+    assert O.count_not_close(x, xs, 1e-10) == 0
+    xt = pkg.umfpack.linearSolve_(fact, pkg.umfpack.UmfpackTrans, A, b)  # symmetric: same answer
+    assert O.count_not_close(xt, xs, 1e-10) == 0
+    xo, _ = O.linear_solve(mat_to_tuple(A), b)
+    assert O.count_not_close(x, xo, 1e-10) == 0
+
+
+def test_poisson3d_wide_band_path(gpu, pkg, O):
+    """m = 14: band half-width 196 -> the one-kernel-pair-per-column path"""
+    m = 14
+    n = m ** 3
+    rp, ci, v = O.gen_poisson3d_csr(m)
+    A = pkg.Matrix(n, n, rp, ci, v)
+    xs = O.gen_vector(n)
+    b = O.mulV(mat_to_tuple(A), xs)
+    x = pkg.umfpack.solve(A, b)
+    assert O.count_not_close(x, xs, 1e-10) == 0
+
+
+def test_unsymmetric_needs_pivoting(gpu, pkg, O):
+    """zero diagonal + unsymmetric values: partial pivoting inside the band is required"""
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(5)
+    n = 400
+    k = 2400
+    rows = np.concatenate([rng.integers(0, n, k), (np.arange(n) + 1) % n])
+    cols = np.concatenate([rng.integers(0, n, k), np.arange(n)])
+    vals = np.concatenate([rng.normal(size=k), np.full(n, 7.0)])
+    A = O.compress(n, n, rows, cols, vals)
+    keep = A[3] != np.repeat(np.arange(n), np.diff(A[2]))  # drop the diagonal entirely
+    # rebuild without diagonal entries
+    cols_e = np.repeat(np.arange(n), np.diff(A[2]))[keep]
+    A = O.compress(n, n, A[3][keep], cols_e, A[4][keep])
+    M = tuple_to_mat(pkg, A)
+    S = csc_tuple_to_scipy(A)
+    xs = rng.uniform(0.5, 1.5, n)
+    for mode, op in ((pkg.umfpack.UmfpackNormal, S), (pkg.umfpack.UmfpackTrans, S.T.tocsc())):
+        b = op @ xs
+        fact = pkg.umfpack.factor(M, pkg.umfpack.analyze(M))
+        x = pkg.umfpack.linearSolve_(fact, mode, M, b)
+        r = np.max(np.abs(op @ x - b)) / (np.max(np.abs(b)) + np.max(np.abs(x)))
+        assert r < 1e-12
+        ref = spla.spsolve(op.tocsc(), b)
+        assert np.max(np.abs(x - ref)) / np.max(np.abs(ref)) < 1e-8
+
+
+def test_same_analysis_many_factorisations_many_rhs(gpu, pkg, O):
+    """the FEAST usage pattern (Feast.hs:210-218): one analyze, several same-pattern factors,
+    several right-hand sides each"""
+    m = 20
+    n = m * m
+    rp, ci, v = O.gen_poisson2d_csr(m)
+    A = pkg.Matrix(n, n, rp, ci, v)
+    an = pkg.umfpack.analyze(A)
+    for shift in (0.0, 1.5, -0.25):
+        As = pkg.Matrix(n, n, rp, ci, np.where(v == 4.0, v + shift, v))
+        fact = pkg.umfpack.factor(As, an)
+        for seed in (1, 2, 3):
+            xs = O.gen_vector(n, seed=seed)
+            b = O.mulV(mat_to_tuple(As), xs)
+            assert O.count_not_close(pkg.umfpack.linearSolve_(fact, 0, As, b), xs, 1e-10) == 0
+    xs = [O.gen_vector(n, seed=s) for s in (7, 8)]
+    bs = [O.mulV(mat_to_tuple(A), x) for x in xs]
+    for x, xo in zip(pkg.umfpack.linearSolve(A, bs), xs):
+        assert O.count_not_close(x, xo, 1e-10) == 0
+
+
+def test_status_codes(gpu, pkg):
+    import ctypes as C
+    L = pkg.umfpack._declare()
+    # singular: positive warning, not an exception (Umfpack.hs:101 throws only on < 0)
+    S = pkg.fromTriples(2, 2, [(0, 0, 1.0), (1, 0, 1.0)])
+    f = pkg.umfpack.factor(S, pkg.umfpack.analyze(S))
+    assert f.status == 1
+    # different pattern
+    A = pkg.ident(3)
+    an = pkg.umfpack.analyze(A)
+    B = pkg.fromTriples(3, 3, [(0, 0, 1.0), (1, 1, 1.0), (2, 2, 1.0), (0, 2, 1.0)])
+    with pytest.raises(pkg.umfpack.UmfpackError):
+        pkg.umfpack.factor(B, an)
+    # non-square, bad handles
+    R = pkg.zeros(2, 3)
+    with pytest.raises(pkg.umfpack.UmfpackError):
+        pkg.umfpack.analyze(R)
+    x = np.zeros(3)
+    ap = (C.c_int * 4)(0, 1, 2, 3)
+    ai = (C.c_int * 3)(0, 1, 2)
+    ax = (C.c_double * 3)(1, 1, 1)
+    assert L.umfpack_di_solve(0, ap, ai, ax, pkg._ffi.p_f64(x), pkg._ffi.p_f64(x), None, None, None) == -3
+    h = C.c_void_p()
+    L.umfpack_di_free_numeric(C.byref(h))  # NULL: no-op
+    L.umfpack_di_free_symbolic(C.byref(h))
