@@ -125,6 +125,14 @@ int spl_matrix_create_csr(int64_t nrows_global, int64_t ncols, int64_t row0, int
  * Generates rows [row0,row1) only. */
 int spl_matrix_create_synthetic(int kind, int64_t n_or_m, int K, uint64_t seed, int64_t row0,
                                 int64_t row1, void **H);
+/* R-MAT graph of 2^scale vertices and edge_factor * 2^scale edges with quadrant
+ * probabilities (a, b, c, 1-a-b-c); duplicate edges summed (compress semantics). */
+int spl_matrix_create_rmat(int scale, int edge_factor, double a, double b, double c, uint64_t seed,
+                           void **H);
+/* C = A * B on device-resident operands (mm, Sparse.hs:691-702); C gets 64-bit row
+ * pointers, so nnz(C) >= 2^31 is fine.  *products (may be NULL) receives the number of
+ * intermediate products. */
+int spl_matrix_spgemm(void *HA, void *HB, void **HC, int64_t *products);
 void spl_matrix_free(void **H);
 
 /* info[0..7] = nrows_global, ncols, row0, nrows_local, nnz_local, device,

@@ -295,6 +295,85 @@ int spl_matrix_create_synthetic(int kind, int64_t n_or_m, int K, uint64_t seed, 
   });
 }
 
+int spl_matrix_create_rmat(int scale, int edge_factor, double a, double b, double c, uint64_t seed,
+                           void **H) {
+  if (!H) return SPL_ERROR_argument_missing;
+  *H = nullptr;
+  if (scale < 1 || scale > 30 || edge_factor < 1 || a < 0 || b < 0 || c < 0 || a + b + c > 1.0)
+    return SPL_ERROR_argument_missing;
+  const int64_t n = 1LL << scale;
+  const int64_t nedges = n * edge_factor;
+  if (nedges >= 0x7fffffffLL) return SPL_ERROR_index_overflow;
+  return guarded([&]() -> int {
+    const int dev = current_device();
+    hipStream_t s = nullptr;
+    auto thr = [](double p) -> uint32_t {
+      const double v = p * 4294967296.0;
+      return v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v;
+    };
+    DBuf<int> dr((size_t)nedges), dc((size_t)nedges), dptr((size_t)n + 1), oidx;
+    DBuf<double> dv((size_t)nedges), oval;
+    generate_rmat_coo(seed, scale, thr(a), thr(a + b), thr(a + b + c), nedges, dr.get(), dc.get(), dv.get(), s);
+    // row-major image: compress with the roles of rows and columns exchanged
+    int64_t nz = 0, bad = -1;
+    int st = compress_device((int)n, (int)n, nedges, dc.get(), dr.get(), dv.get(), dptr.get(), oidx, oval, &nz,
+                             &bad, s);
+    if (st != SPL_OK) return st;
+    Matrix *m = new Matrix();
+    try {
+      m->device = dev;
+      m->nrows_global = n;
+      m->ncols = n;
+      m->row0 = 0;
+      m->nrows_local = n;
+      m->nnz = nz;
+      m->rowptr64.alloc((size_t)n + 1);
+      widen_i32_to_i64(dptr.get(), m->rowptr64.get(), n + 1, s);
+      m->colidx = std::move(oidx);
+      m->val = std::move(oval);
+      finalize_matrix(m, s);
+    } catch (...) {
+      delete m;
+      throw;
+    }
+    *H = m;
+    return SPL_OK;
+  });
+}
+
+int spl_matrix_spgemm(void *HA, void *HB, void **HC, int64_t *products) {
+  Matrix *A = as_matrix(HA), *B = as_matrix(HB);
+  if (!A || !B) return SPL_ERROR_invalid_handle;
+  if (!HC) return SPL_ERROR_argument_missing;
+  *HC = nullptr;
+  if (A->ncols != B->nrows_global || B->row0 != 0 || B->nrows_local != B->nrows_global)
+    return SPL_ERROR_dimension_mismatch;  // Sparse.hs:694 (B must be whole; A may be a row block)
+  if (!A->rowptr.get() || !B->rowptr.get()) return SPL_ERROR_index_overflow;
+  return guarded([&]() -> int {
+    DeviceGuard g(A->device);
+    hipStream_t s = nullptr;
+    Matrix *C = new Matrix();
+    try {
+      C->device = A->device;
+      C->nrows_global = A->nrows_global;
+      C->ncols = B->ncols;
+      C->row0 = A->row0;
+      C->nrows_local = A->nrows_local;
+      // rows of A*B = columns of (A*B)^T = B^T * A^T: the CSR arrays of B and A are the CSC
+      // arrays of B^T and A^T, so the column-wise kernel runs on them unchanged
+      spgemm_device(B->ncols, B->nrows_global, B->rowptr.get(), B->colidx.get(), B->val.get(), A->nrows_local,
+                    A->rowptr.get(), A->colidx.get(), A->val.get(), C->rowptr64, C->colidx, C->val, &C->nnz,
+                    products, s);
+      finalize_matrix(C, s);
+    } catch (...) {
+      delete C;
+      throw;
+    }
+    *HC = C;
+    return SPL_OK;
+  });
+}
+
 void spl_matrix_free(void **H) {
   if (!H || !*H) return;
   Matrix *m = as_matrix(*H);

@@ -158,6 +158,8 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
 
 // ---- synthetic generators (generate.hip) --------------------------------------------
 void generate_synthetic(Matrix *m, int kind, int64_t n_or_m, int K, uint64_t seed, hipStream_t s);
+void generate_rmat_coo(uint64_t seed, int scale, uint32_t ta, uint32_t tb, uint32_t tc, int64_t nedges,
+                       int *d_rows, int *d_cols, double *d_vals, hipStream_t s);
 void generate_vector(uint64_t seed, int64_t j0, int64_t j1, double *d_x, hipStream_t s);
 
 // ---- SpMV (spmv.hip) --------------------------------------------------------------------

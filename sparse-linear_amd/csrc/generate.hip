@@ -122,7 +122,31 @@ __global__ __launch_bounds__(256) void gen_vector_kernel(uint64_t seed, int64_t 
   for (; i < count; i += stride) x[i] = spl_vector_entry(seed, (uint64_t)(j0 + i));
 }
 
+__global__ __launch_bounds__(256) void gen_rmat_kernel(uint64_t seed, int scale, uint32_t ta, uint32_t tb,
+                                                       uint32_t tc, int64_t nedges, int *__restrict__ rows,
+                                                       int *__restrict__ cols, double *__restrict__ vals) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; e < nedges; e += stride) {
+    uint64_t r, c;
+    spl_rmat_edge(seed, (uint64_t)e, scale, ta, tb, tc, &r, &c);
+    rows[e] = (int)r;
+    cols[e] = (int)c;
+    vals[e] = spl_uniform_value(spl_hash(seed ^ SPL_VAL_SALT, (uint64_t)e, 63));
+  }
+}
+
 }  // namespace
+
+void generate_rmat_coo(uint64_t seed, int scale, uint32_t ta, uint32_t tb, uint32_t tc, int64_t nedges,
+                       int *d_rows, int *d_cols, double *d_vals, hipStream_t s) {
+  if (nedges <= 0) return;
+  int64_t b = (nedges + 255) / 256;
+  if (b > 16384) b = 16384;
+  hipLaunchKernelGGL(gen_rmat_kernel, dim3((unsigned)b), dim3(256), 0, s, seed, scale, ta, tb, tc, nedges,
+                     d_rows, d_cols, d_vals);
+  SPL_HIP(hipGetLastError());
+}
 
 void generate_synthetic(Matrix *mat, int kind, int64_t n_or_m, int K, uint64_t seed, hipStream_t s) {
   GenParams g;

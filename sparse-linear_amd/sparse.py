@@ -159,6 +159,21 @@ class DeviceMatrix(object):
               lib().spl_matrix_create_synthetic(k, n_or_m, K, seed, row0, row1, C.byref(h)))
         return cls(h.value)
 
+    @classmethod
+    def rmat(cls, scale, edge_factor=32, abc=(0.25, 0.25, 0.25), seed=0x5EED):
+        _ffi.require_gpu()
+        h = C.c_void_p()
+        check("spl_matrix_create_rmat",
+              lib().spl_matrix_create_rmat(scale, edge_factor, abc[0], abc[1], abc[2], seed, C.byref(h)))
+        return cls(h.value)
+
+    def spgemm(self, other):
+        """device-resident C = self * other; returns (DeviceMatrix C, number of products)"""
+        h = C.c_void_p()
+        prod = C.c_int64(0)
+        check("spl_matrix_spgemm", lib().spl_matrix_spgemm(self.handle, other.handle, C.byref(h), C.byref(prod)))
+        return DeviceMatrix(h.value), int(prod.value)
+
     def info(self):
         buf = (C.c_int64 * 8)()
         check("spl_matrix_info", lib().spl_matrix_info(self.handle, buf))

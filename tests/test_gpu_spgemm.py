@@ -78,3 +78,23 @@ def test_mm_unsorted_input_columns(gpu, pkg, O):
     As = pkg.Matrix(2, 3, [0, 2, 3], [0, 2, 1], [2.0, 1.0, 3.0])
     B = pkg.ident(2)
     assert A * B == As
+
+
+def test_device_resident_spgemm_rmat(gpu, pkg, O):
+    """handle-based A*A on a device-generated R-MAT graph (C4 in miniature), all three
+    quadrant settings of SURVEY.md §8d; the generator, compress and SpGEMM all run in HBM"""
+    for scale, ef, abc in ((10, 8, (0.25, 0.25, 0.25)), (12, 16, (0.45, 0.22, 0.22)), (11, 32, (0.57, 0.19, 0.19))):
+        n = 1 << scale
+        H = pkg.DeviceMatrix.rmat(scale, ef, abc)
+        rp, ci, v = H.export_csr()
+        r, c, vals = O.gen_rmat_coo(scale, n * ef, abc)
+        A_csc = O.compress(n, n, r, c, vals)
+        A_csr = O.transpose(A_csc)  # CSR(A) = CSC(A^T)
+        assert np.array_equal(rp, A_csr[2]) and np.array_equal(ci, A_csr[3]) and np.array_equal(v, A_csr[4])
+        HC, products = H.spgemm(H)
+        crp, cci, cv = HC.export_csr()
+        Co = O.mm(A_csc, A_csc)
+        Ct = O.transpose(Co)
+        assert np.array_equal(crp, Ct[2]) and np.array_equal(cci, Ct[3]) and np.array_equal(cv, Ct[4])
+        lens = np.diff(A_csc[2])
+        assert products == int(np.sum(lens[A_csc[3]]))  # sum over entries (k, j) of |A[:,k]|

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Config C5 ladder: sparse LU factor + solve of the 3-D 7-point Poisson matrix on an m^3 grid
+through the umfpack_di_* ABI on one MI355X, next to a CPU baseline.  No libumfpack exists in
+this pipeline, so the CPU baseline is scipy's SuperLU (`splu`), labelled as a stand-in
+(BASELINE.md §4).  b = A x* for the synthetic x*; checks |x - x*| and the scaled residual."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", default="16,24,32")
+    ap.add_argument("--cpu-max", type=int, default=32, help="largest m for the SuperLU stand-in")
+    args = ap.parse_args()
+    import numpy as np
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    import torch
+    from __graft_entry__ import load_package
+    from oracle import oracle as O
+    pkg = load_package()
+    torch.cuda.set_device(0)
+    U = pkg.umfpack
+    for m in [int(t) for t in args.grid.split(",")]:
+        n = m ** 3
+        rp, ci, v = O.gen_poisson3d_csr(m)
+        A = pkg.Matrix(n, n, rp, ci, v)  # symmetric: CSR arrays == CSC arrays
+        xs = O.gen_vector(n)
+        S = sp.csc_matrix((v, ci, rp), shape=(n, n))
+        b = S @ xs
+        t0 = time.perf_counter(); an = U.analyze(A); t1 = time.perf_counter()
+        fa = U.factor(A, an); torch.cuda.synchronize(); t2 = time.perf_counter()
+        x = U.linearSolve_(fa, U.UmfpackNormal, A, b); torch.cuda.synchronize(); t3 = time.perf_counter()
+        err = float(np.max(np.abs(x - xs) / np.abs(xs)))
+        res = float(np.max(np.abs(S @ x - b)) / (np.max(np.abs(b)) + 6 * np.max(np.abs(x))))
+        out = {"metric": "sparse LU factor+solve seconds", "m": m, "n": n, "nnz": int(rp[-1]),
+               "gpu": {"analyze_s": round(t1 - t0, 3), "factor_s": round(t2 - t1, 3), "solve_s": round(t3 - t2, 3),
+                       "total_s": round(t3 - t0, 3)},
+               "max_rel_err_vs_manufactured": err, "scaled_residual": res, "within_1e-10": bool(err < 1e-10)}
+        if m <= args.cpu_max:
+            t = time.perf_counter(); lu = spla.splu(S); tf = time.perf_counter() - t
+            t = time.perf_counter(); xc = lu.solve(b); ts = time.perf_counter() - t
+            out["cpu_baseline"] = {"kind": "stand-in: scipy SuperLU splu (no libumfpack in this pipeline)", "cores": 1,
+                                   "factor_s": round(tf, 3), "solve_s": round(ts, 3),
+                                   "fill_nnz": int(lu.L.nnz + lu.U.nnz),
+                                   "max_rel_err": float(np.max(np.abs(xc - xs) / np.abs(xs)))}
+        print(json.dumps(out), flush=True)
+        del fa, an
+
+
+if __name__ == "__main__":
+    main()
