@@ -496,9 +496,18 @@ int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unr
   return guarded([&]() -> int {
     DeviceGuard g(m->device);
     build_blocked_image(m, rows_per_panel, cols_log2, nullptr);
+    if (unroll == 0) {
+      // register pipeline depth: the smallest of {4,8,10,12} chunks that covers 1.25x the mean
+      // segment (a deeper pipeline only streams entries of the next segment it cannot use yet)
+      const double seg = (double)m->nnz / (double)(m->blocked->npanels * m->blocked->ncb > 0
+                                                       ? m->blocked->npanels * m->blocked->ncb : 1);
+      const double want = 1.25 * seg / 64.0;
+      unroll = want <= 4 ? 4 : want <= 8 ? 8 : want <= 10 ? 10 : 12;
+    }
     m->blocked_unroll = unroll;
     m->blocked->lockstep_waves = waves;
     if (const char *ev = getenv("SPL_BLOCKED_FOLD")) m->blocked->fold = atoi(ev) ? 1 : 0;
+    if (const char *ev = getenv("SPL_BLOCKED_WARM")) m->blocked->warm = atoi(ev) ? 1 : 0;
     return SPL_OK;
   });
 }
