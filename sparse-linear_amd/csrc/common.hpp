@@ -82,7 +82,6 @@ struct BlockedImage {
   DBuf<int> key;                  // nnz: (local_row << w) | local_col
   DBuf<double> val;               // nnz
   DBuf<unsigned> arrive;          // rendezvous counter of the persistent kernel
-  int warm = 0;                   // 1: lockstep kernel warms the next x block in L2
   int fold = 1;                   // 1: ds_add_f64 fold, 0: shuffle fold (both reference order)
   int lockstep_waves = 16;        // wavefronts (= panels) per lockstep workgroup: 16 or 8; 0 = ablation kernel
 };

@@ -5,32 +5,35 @@
 //   * column j of C has the UNION pattern of { A[:,k] : B[k,j] stored }; numerical
 //     cancellation keeps a stored zero (the mask is set regardless of the value);
 //   * row indices ascend inside a column; pointers are the exclusive prefix sum;
-//   * C[i,j] = fold (\acc k -> acc + A[i,k]*B[k,j]) 0 over k ascending, each
-//     multiply and add separately rounded — the kernels below walk k SEQUENTIALLY
-//     per output column and parallelise over the (distinct) rows of A[:,k], so a
-//     given accumulator receives its contributions in ascending-k order: values
-//     are bit-identical to the reference order, not merely within tolerance.
+//   * C[i,j] = fold (\acc k -> acc + A[i,k]*B[k,j]) 0 over k ascending, each multiply and
+//     add separately rounded.  Every path below delivers the contributions of one output
+//     entry in ascending-k order, so VALUES are bit-identical to the reference order.
 //
-// MI355X design: the reference's O(nrows) dense accumulator per column is replaced
-// by an accumulator sized to the column's work.  Columns are binned by their
-// number of intermediate products (an upper bound of their nnz):
-//   bin S  (<= 256 products)  one wavefront per column, 512-slot hash table in LDS
-//   bin M  (<= 4096 products) one workgroup per column, 8192-slot hash table in LDS
-//   bin L  (more)             one workgroup per column, dense accumulator in HBM from
-//                             a small pool (the reference's own data structure, but only
-//                             for the heavy columns), gathered in row order
-// Two passes (symbolic count, exclusive scan to 64-bit pointers, numeric fill),
-// then a segment sort by row index of the hash-table columns.  HBM-bound /
-// latency-bound integer + fp64 work; no MFMA (no dense contraction).
+// MI355X design (expand - sort - compress in LDS): the reference's O(nrows) dense
+// accumulator per column is replaced by work proportional to the column's number of
+// intermediate products P_j (an upper bound of its nnz), by which columns are binned:
+//   bin S  P <= 256    one wavefront per column   (4 columns per workgroup, no barrier)
+//   bin M  P <= 2048   one workgroup per column, 3 workgroups per CU
+//   bin X  P <= 4096   one workgroup per column, 1 workgroup per CU
+//   bin L  more        one workgroup per column, dense accumulator in HBM from a small pool
+//                      (the reference's own data structure, only for the heavy columns)
+// ESC step for bins S/M/X: (1) the column's B entries and the extents of the A columns they
+// select are staged in LDS and prefix-summed, so product t of the column is found by a binary
+// search — ALL products of the column are gathered from HBM at once (no dependent chain per
+// k); (2) (row, t) keys and a*b values are bitonic-sorted in LDS (t = position in k-then-row
+// order breaks ties, which keeps equal rows in ascending-k order); (3) each run of equal rows
+// is summed left to right by its first element and written, already in ascending row order.
+// Two passes (symbolic: 32-bit keys, count distinct; 64-bit exclusive scan; numeric).
+// HBM/latency-bound integer + fp64 work; no MFMA (no dense contraction).
 #include "common.hpp"
 
 namespace spl {
 
 namespace {
 
-constexpr int kEmpty = -1;
-constexpr int kSmallProducts = 256, kSmallTable = 512;
-constexpr int kMediumProducts = 4096, kMediumTable = 8192;
+constexpr int kSmallProducts = 256;
+constexpr int kMediumProducts = 2048, kMediumB = 1024;
+constexpr int kLargeProducts = 4096, kLargeB = 2048;
 constexpr int kMaxPool = 512;
 
 inline unsigned blocks_for(int64_t n, int per_block) {
@@ -44,10 +47,20 @@ struct Csc {
   const double *x;
 };
 
+// bins: 0 empty, 1 S, 2 M, 3 X, 4 L
+__device__ inline int bin_of(int64_t np, int nb) {
+  if (np == 0) return 0;
+  if (np <= kSmallProducts) return 1;
+  if (np <= kMediumProducts && nb <= kMediumB) return 2;
+  if (np <= kLargeProducts && nb <= kLargeB) return 3;
+  return 4;
+}
+
 __global__ __launch_bounds__(256) void products_kernel(Csc A, Csc B, int64_t ncolsB,
                                                        int64_t *__restrict__ nprod,
                                                        int64_t *__restrict__ medium_list,
-                                                       int64_t *__restrict__ large_list,
+                                                       int64_t *__restrict__ xlarge_list,
+                                                       int64_t *__restrict__ dense_list,
                                                        int *__restrict__ list_counts) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= ncolsB) return;
@@ -57,35 +70,177 @@ __global__ __launch_bounds__(256) void products_kernel(Csc A, Csc B, int64_t nco
     n += A.p[k + 1] - A.p[k];
   }
   nprod[j] = n;
-  if (n > kMediumProducts) large_list[atomicAdd(&list_counts[1], 1)] = j;
-  else if (n > kSmallProducts) medium_list[atomicAdd(&list_counts[0], 1)] = j;
+  const int bin = bin_of(n, B.p[j + 1] - B.p[j]);
+  if (bin == 2) medium_list[atomicAdd(&list_counts[0], 1)] = j;
+  else if (bin == 3) xlarge_list[atomicAdd(&list_counts[1], 1)] = j;
+  else if (bin == 4) dense_list[atomicAdd(&list_counts[2], 1)] = j;
 }
 
-template <int TABLE>
-__device__ inline int hash_slot(int row) {
-  return (int)(((unsigned)row * 0x9E3779B1u) >> 7) & (TABLE - 1);
+template <int NT>
+__device__ inline void group_sync() {
+  if (NT == 64) __builtin_amdgcn_wave_barrier();  // LDS operations of one wavefront are in order
+  else __syncthreads();
 }
 
-// insert `row`, return its slot (linear probing; the table never fills: TABLE >= 2*products)
-template <int TABLE>
-__device__ inline int hash_insert(int *keys, int row) {
-  int slot = hash_slot<TABLE>(row);
-  while (true) {
-    const int old = atomicCAS(&keys[slot], kEmpty, row);
-    if (old == kEmpty || old == row) return slot;
-    slot = (slot + 1) & (TABLE - 1);
+// LDS footprint of one group (NT threads cooperating on one column)
+template <int CAP, int NBCAP, bool NUMERIC>
+struct EscLds {
+  static constexpr size_t key_bytes = NUMERIC ? CAP * sizeof(int64_t) : CAP * sizeof(int);
+  static constexpr size_t val_bytes = NUMERIC ? CAP * sizeof(double) : 0;
+  static constexpr size_t kb_bytes = NUMERIC ? NBCAP * sizeof(double) : 0;
+  static constexpr size_t start_bytes = NBCAP * sizeof(int);
+  static constexpr size_t off_bytes = (NBCAP + 8) * sizeof(int);
+  static constexpr size_t scratch_bytes = 16 * sizeof(int);
+  static constexpr size_t total = key_bytes + val_bytes + kb_bytes + start_bytes + off_bytes + scratch_bytes;
+};
+
+// expand - sort - compress for ONE column j with np products and nb entries in B[:,j];
+// `tid` in [0, NT) is the thread's index inside the group, `lds` the group's LDS region.
+template <int NT, int CAP, int NBCAP, bool NUMERIC>
+__device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np, unsigned char *lds, int tid,
+                                  int *__restrict__ counts, const int64_t *__restrict__ Cp,
+                                  int *__restrict__ Ci, double *__restrict__ Cx) {
+  typedef EscLds<CAP, NBCAP, NUMERIC> L;
+  int64_t *key64 = reinterpret_cast<int64_t *>(lds);
+  int *key32 = reinterpret_cast<int *>(lds);
+  double *vals = reinterpret_cast<double *>(lds + L::key_bytes);
+  double *kb = reinterpret_cast<double *>(lds + L::key_bytes + L::val_bytes);
+  int *kstart = reinterpret_cast<int *>(lds + L::key_bytes + L::val_bytes + L::kb_bytes);
+  int *koff = reinterpret_cast<int *>(lds + L::key_bytes + L::val_bytes + L::kb_bytes + L::start_bytes);
+  int *scratch = koff + NBCAP + 8;
+  const int lane = tid & 63;
+  const int qs = B.p[j];
+  const int nb = B.p[j + 1] - qs;
+
+  // (1) stage the column of B and the extents of the selected columns of A
+  for (int q = tid; q < nb; q += NT) {
+    const int k = B.i[qs + q];
+    const int s = A.p[k];
+    kstart[q] = s;
+    koff[q] = A.p[k + 1] - s;
+    if (NUMERIC) kb[q] = B.x[qs + q];
   }
+  group_sync<NT>();
+  // exclusive prefix sum of the extents: per-thread chunk, then a serial pass over the NT chunk sums
+  {
+    const int chunk = (nb + NT - 1) / NT;
+    const int lo = tid * chunk, hi = min(nb, lo + chunk);
+    int sum = 0;
+    for (int q = lo; q < hi; ++q) sum += koff[q];
+    // wave-level inclusive scan of the chunk sums, then across waves through scratch
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (NT > 64) {
+      if (lane == 63) scratch[tid >> 6] = incl;
+      __syncthreads();
+      int woff = 0;
+      for (int wv = 0; wv < (tid >> 6); ++wv) woff += scratch[wv];
+      incl += woff;
+      __syncthreads();
+    }
+    int run = incl - sum;
+    for (int q = lo; q < hi; ++q) {
+      const int l = koff[q];
+      koff[q] = run;
+      run += l;
+    }
+    if (tid == NT - 1) koff[nb] = run;  // == np
+  }
+  group_sync<NT>();
+
+  // (2) expand: every product of the column is fetched independently
+  for (int t = tid; t < np; t += NT) {
+    int lo = 0, hi = nb - 1;  // largest q with koff[q] <= t
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (koff[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    const int p = kstart[lo] + (t - koff[lo]);
+    const int row = A.i[p];
+    if (NUMERIC) {
+      key64[t] = ((int64_t)row << 32) | (int64_t)t;  // ties: ascending t = ascending k
+      vals[t] = A.x[p] * kb[lo];                     // a * b
+    } else {
+      key32[t] = row;
+    }
+  }
+  group_sync<NT>();
+
+  // (3) bitonic sort, ascending-only network; pairs whose upper index is >= np are skipped
+  int n2 = 2;
+  while (n2 < np) n2 <<= 1;
+  for (int size = 2; size <= n2; size <<= 1) {
+    for (int jj = size >> 1; jj > 0; jj >>= 1) {
+      const bool flip = (jj == (size >> 1));
+      for (int t = tid; t < (n2 >> 1); t += NT) {
+        const int lo = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+        const int hi = flip ? (lo ^ (size - 1)) : (lo | jj);
+        if (hi < np) {
+          if (NUMERIC) {
+            const int64_t ka = key64[lo], kb2 = key64[hi];
+            if (kb2 < ka) {
+              key64[lo] = kb2; key64[hi] = ka;
+              const double va = vals[lo]; vals[lo] = vals[hi]; vals[hi] = va;
+            }
+          } else {
+            const int ka = key32[lo], kb2 = key32[hi];
+            if (kb2 < ka) { key32[lo] = kb2; key32[hi] = ka; }
+          }
+        }
+      }
+      group_sync<NT>();
+    }
+  }
+
+  // (4) compress: run heads in ascending row order; numeric heads fold their run left to right
+  const int64_t base = NUMERIC ? Cp[j] : 0;
+  int running = 0;
+  for (int t0 = 0; t0 < np; t0 += NT) {
+    const int t = t0 + tid;
+    int row = 0;
+    bool head = false;
+    if (t < np) {
+      row = NUMERIC ? (int)(key64[t] >> 32) : key32[t];
+      const int prev = t > 0 ? (NUMERIC ? (int)(key64[t - 1] >> 32) : key32[t - 1]) : -1;
+      head = (t == 0) || (row != prev);
+    }
+    const unsigned long long m = __ballot(head);
+    int off = running + __popcll(m & ((1ull << lane) - 1ull));
+    int total = __popcll(m);
+    if (NT > 64) {
+      if (lane == 0) scratch[tid >> 6] = total;
+      __syncthreads();
+      total = 0;
+      for (int wv = 0; wv < NT / 64; ++wv) {
+        if (wv < (tid >> 6)) off += scratch[wv];
+        total += scratch[wv];
+      }
+      __syncthreads();
+    }
+    if (NUMERIC && head) {
+      double acc = 0.0;  // SG.reset 0
+      for (int u = t; u < np && (int)(key64[u] >> 32) == row; ++u) acc = acc + vals[u];  // c + a * b
+      Ci[base + off] = row;
+      Cx[base + off] = acc;
+    }
+    running += total;
+  }
+  if (!NUMERIC && tid == 0) counts[j] = running;
 }
 
-// bin S: one wavefront per column of B
+// bin S: one wavefront per column of B, four columns per workgroup
 template <bool NUMERIC>
 __global__ __launch_bounds__(256) void spgemm_wave_kernel(Csc A, Csc B, int64_t ncolsB,
                                                           const int64_t *__restrict__ nprod,
                                                           int *__restrict__ counts,
                                                           const int64_t *__restrict__ Cp,
                                                           int *__restrict__ Ci, double *__restrict__ Cx) {
-  __shared__ int keys_all[4][kSmallTable];
-  __shared__ double vals_all[NUMERIC ? 4 : 1][NUMERIC ? kSmallTable : 1];
+  typedef EscLds<kSmallProducts, kSmallProducts, NUMERIC> L;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_all[4][(L::total + 15) / 16 * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t j = (int64_t)blockIdx.x * 4 + wave;
   if (j >= ncolsB) return;
@@ -95,92 +250,20 @@ __global__ __launch_bounds__(256) void spgemm_wave_kernel(Csc A, Csc B, int64_t 
     if (!NUMERIC && lane == 0) counts[j] = 0;
     return;
   }
-  int *keys = keys_all[wave];
-  double *vals = vals_all[NUMERIC ? wave : 0];
-  for (int t = lane; t < kSmallTable; t += 64) {
-    keys[t] = kEmpty;
-    if (NUMERIC) vals[t] = 0.0;  // SG.reset 0
-  }
-  __builtin_amdgcn_wave_barrier();
-  const int qs = B.p[j], qe = B.p[j + 1];
-  for (int q = qs; q < qe; ++q) {  // k ascending: the reference's iforM_ colB
-    const int k = B.i[q];
-    const double b = NUMERIC ? B.x[q] : 0.0;
-    const int ps = A.p[k], pe = A.p[k + 1];
-    for (int p = ps + lane; p < pe; p += 64) {
-      const int slot = hash_insert<kSmallTable>(keys, A.i[p]);
-      if (NUMERIC) vals[slot] = vals[slot] + A.x[p] * b;  // \c a -> c + a * b
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  // extraction in slot order; rows are sorted afterwards
-  int64_t base = NUMERIC ? Cp[j] : 0;
-  int total = 0;
-  for (int t0 = 0; t0 < kSmallTable; t0 += 64) {
-    const int key = keys[t0 + lane];
-    const bool used = key != kEmpty;
-    const unsigned long long m = __ballot(used);
-    if (NUMERIC && used) {
-      const int off = __popcll(m & ((1ull << lane) - 1ull));
-      Ci[base + total + off] = key;
-      Cx[base + total + off] = vals[t0 + lane];
-    }
-    total += __popcll(m);
-  }
-  if (!NUMERIC && lane == 0) counts[j] = total;
+  esc_column<64, kSmallProducts, kSmallProducts, NUMERIC>(A, B, j, (int)np, lds_all[wave], lane, counts, Cp, Ci,
+                                                         Cx);
 }
 
-// bin M: one workgroup per listed column
-template <bool NUMERIC>
-__global__ __launch_bounds__(256) void spgemm_block_kernel(Csc A, Csc B,
-                                                           const int64_t *__restrict__ list,
+// bins M and X: one workgroup per listed column
+template <int CAP, int NBCAP, bool NUMERIC>
+__global__ __launch_bounds__(256) void spgemm_block_kernel(Csc A, Csc B, const int64_t *__restrict__ list,
+                                                           const int64_t *__restrict__ nprod,
                                                            int *__restrict__ counts,
                                                            const int64_t *__restrict__ Cp,
                                                            int *__restrict__ Ci, double *__restrict__ Cx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int *keys = reinterpret_cast<int *>(smem);
-  double *vals = reinterpret_cast<double *>(smem + kMediumTable * sizeof(int));
-  __shared__ int wave_counts[4];
-  __shared__ int running;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t j = list[blockIdx.x];
-  for (int t = threadIdx.x; t < kMediumTable; t += 256) {
-    keys[t] = kEmpty;
-    if (NUMERIC) vals[t] = 0.0;
-  }
-  if (threadIdx.x == 0) running = 0;
-  __syncthreads();
-  const int qs = B.p[j], qe = B.p[j + 1];
-  for (int q = qs; q < qe; ++q) {
-    const int k = B.i[q];
-    const double b = NUMERIC ? B.x[q] : 0.0;
-    const int ps = A.p[k], pe = A.p[k + 1];
-    for (int p = ps + (int)threadIdx.x; p < pe; p += 256) {
-      const int slot = hash_insert<kMediumTable>(keys, A.i[p]);
-      if (NUMERIC) vals[slot] = vals[slot] + A.x[p] * b;
-    }
-    if (NUMERIC) __syncthreads();  // next k may hit the same accumulator from another wavefront
-  }
-  __syncthreads();
-  const int64_t base = NUMERIC ? Cp[j] : 0;
-  for (int t0 = 0; t0 < kMediumTable; t0 += 256) {
-    const int key = keys[t0 + threadIdx.x];
-    const bool used = key != kEmpty;
-    const unsigned long long m = __ballot(used);
-    if (lane == 0) wave_counts[wave] = __popcll(m);
-    __syncthreads();
-    int off = running;
-    for (int w = 0; w < wave; ++w) off += wave_counts[w];
-    if (NUMERIC && used) {
-      off += __popcll(m & ((1ull << lane) - 1ull));
-      Ci[base + off] = key;
-      Cx[base + off] = vals[t0 + threadIdx.x];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) running += wave_counts[0] + wave_counts[1] + wave_counts[2] + wave_counts[3];
-    __syncthreads();
-  }
-  if (!NUMERIC && threadIdx.x == 0) counts[j] = running;
+  esc_column<256, CAP, NBCAP, NUMERIC>(A, B, j, (int)nprod[j], smem, (int)threadIdx.x, counts, Cp, Ci, Cx);
 }
 
 // bin L: persistent workgroups, each owning one dense accumulator of the pool
@@ -258,36 +341,40 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     SPL_HIP(hipStreamSynchronize(s));
     return;
   }
-  DBuf<int64_t> nprod((size_t)ncolsB), medium_list((size_t)ncolsB), large_list((size_t)ncolsB);
-  DBuf<int> list_counts(2), counts((size_t)ncolsB);
-  SPL_HIP(hipMemsetAsync(list_counts.get(), 0, 2 * sizeof(int), s));
-  hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 256)), dim3(256), 0, s, A, B, ncolsB,
-                     nprod.get(), medium_list.get(), large_list.get(), list_counts.get());
-  int hc[2] = {0, 0};
-  SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  DBuf<int64_t> nprod((size_t)ncolsB), medium_list((size_t)ncolsB), xlarge_list((size_t)ncolsB),
+      dense_list((size_t)ncolsB);
+  DBuf<int> list_counts(3), counts((size_t)ncolsB);
+  SPL_HIP(hipMemsetAsync(list_counts.get(), 0, 3 * sizeof(int), s));
+  hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 256)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
+                     medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get());
+  int hc[3] = {0, 0, 0};
+  SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 3 * sizeof(int), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
-  const int nmedium = hc[0], nlarge = hc[1];
+  const int nmedium = hc[0], nxlarge = hc[1], ndense = hc[2];
   if (products) {
     DBuf<int64_t> pscan((size_t)ncolsB + 1);
     exclusive_scan_i64(nprod.get(), pscan.get(), ncolsB, s);
     SPL_HIP(hipMemcpy(products, pscan.get() + ncolsB, sizeof(int64_t), hipMemcpyDeviceToHost));
   }
-  const size_t medium_lds_sym = kMediumTable * sizeof(int);
-  const size_t medium_lds_num = kMediumTable * (sizeof(int) + sizeof(double));
+  typedef EscLds<kMediumProducts, kMediumB, false> LMs;
+  typedef EscLds<kMediumProducts, kMediumB, true> LMn;
+  typedef EscLds<kLargeProducts, kLargeB, false> LXs;
+  typedef EscLds<kLargeProducts, kLargeB, true> LXn;
   static bool attr_set = false;
   if (!attr_set) {
-    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spgemm_block_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)medium_lds_num));
+    SPL_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void *>(&spgemm_block_kernel<kLargeProducts, kLargeB, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LXn::total));
     attr_set = true;
   }
-  int pool = nlarge < kMaxPool ? nlarge : kMaxPool;
+  int pool = ndense < kMaxPool ? ndense : kMaxPool;
   {  // keep the accumulator pool under ~8 GB
     const int64_t cap = (int64_t)8e9 / (9 * (nrowsA > 0 ? nrowsA : 1));
     if (pool > cap) pool = (int)(cap < 1 ? 1 : cap);
   }
   DBuf<unsigned char> pool_flags;
   DBuf<double> pool_vals;
-  if (nlarge > 0) {
+  if (ndense > 0) {
     pool_flags.alloc((size_t)pool * (size_t)nrowsA);
     pool_vals.alloc((size_t)pool * (size_t)nrowsA);
     SPL_HIP(hipMemsetAsync(pool_flags.get(), 0, (size_t)pool * (size_t)nrowsA, s));
@@ -298,12 +385,16 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   hipLaunchKernelGGL(spgemm_wave_kernel<false>, dim3(blocks_for(ncolsB, 4)), dim3(256), 0, s, A, B, ncolsB,
                      nprod.get(), counts.get(), (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
   if (nmedium > 0)
-    hipLaunchKernelGGL(spgemm_block_kernel<false>, dim3((unsigned)nmedium), dim3(256), medium_lds_sym, s, A, B,
-                       medium_list.get(), counts.get(), (const int64_t *)nullptr, (int *)nullptr,
-                       (double *)nullptr);
-  if (nlarge > 0)
+    hipLaunchKernelGGL((spgemm_block_kernel<kMediumProducts, kMediumB, false>), dim3((unsigned)nmedium), dim3(256),
+                       LMs::total, s, A, B, medium_list.get(), nprod.get(), counts.get(),
+                       (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
+  if (nxlarge > 0)
+    hipLaunchKernelGGL((spgemm_block_kernel<kLargeProducts, kLargeB, false>), dim3((unsigned)nxlarge), dim3(256),
+                       LXs::total, s, A, B, xlarge_list.get(), nprod.get(), counts.get(),
+                       (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
+  if (ndense > 0)
     hipLaunchKernelGGL(spgemm_dense_kernel<false>, dim3((unsigned)pool), dim3(256), 0, s, A, B, nrowsA,
-                       large_list.get(), nlarge, pool_flags.get(), (double *)nullptr, counts.get(),
+                       dense_list.get(), ndense, pool_flags.get(), (double *)nullptr, counts.get(),
                        (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
   exclusive_scan_i32_to_i64(counts.get(), Cp.get(), ncolsB, s);
   int64_t nz = 0;
@@ -314,20 +405,22 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   *nnzC = nz;
   if (nz == 0) return;
 
-  // ---- numeric
+  // ---- numeric: every path writes its column already sorted by row
   hipLaunchKernelGGL(spgemm_wave_kernel<true>, dim3(blocks_for(ncolsB, 4)), dim3(256), 0, s, A, B, ncolsB,
                      nprod.get(), (int *)nullptr, Cp.get(), Ci.get(), Cx.get());
   if (nmedium > 0)
-    hipLaunchKernelGGL(spgemm_block_kernel<true>, dim3((unsigned)nmedium), dim3(256), medium_lds_num, s, A, B,
-                       medium_list.get(), (int *)nullptr, Cp.get(), Ci.get(), Cx.get());
-  if (nlarge > 0)
+    hipLaunchKernelGGL((spgemm_block_kernel<kMediumProducts, kMediumB, true>), dim3((unsigned)nmedium), dim3(256),
+                       LMn::total, s, A, B, medium_list.get(), nprod.get(), (int *)nullptr, Cp.get(), Ci.get(),
+                       Cx.get());
+  if (nxlarge > 0)
+    hipLaunchKernelGGL((spgemm_block_kernel<kLargeProducts, kLargeB, true>), dim3((unsigned)nxlarge), dim3(256),
+                       LXn::total, s, A, B, xlarge_list.get(), nprod.get(), (int *)nullptr, Cp.get(), Ci.get(),
+                       Cx.get());
+  if (ndense > 0)
     hipLaunchKernelGGL(spgemm_dense_kernel<true>, dim3((unsigned)pool), dim3(256), 0, s, A, B, nrowsA,
-                       large_list.get(), nlarge, pool_flags.get(), pool_vals.get(), (int *)nullptr, Cp.get(),
+                       dense_list.get(), ndense, pool_flags.get(), pool_vals.get(), (int *)nullptr, Cp.get(),
                        Ci.get(), Cx.get());
   SPL_HIP(hipGetLastError());
-  // hash-table columns come out in slot order: sort them by row (dense-bin columns
-  // are already ascending and longer ones are skipped by the cap)
-  segmented_sort_pairs_capped(Cp.get(), ncolsB, Ci.get(), Cx.get(), kMediumProducts, s);
   SPL_HIP(hipStreamSynchronize(s));
 }
 

@@ -188,12 +188,11 @@ __device__ inline void gather_wait(double &v) {
 // while the first U chunks of block cb+1 are loaded into (idN, aN).  Register sets are passed
 // by reference and swapped by the caller (ping-pong), so nothing is copied between phases and
 // the next block's loads stay in flight across the barrier.
-template <int U, int FOLD, int PF>
+template <int U, int FOLD>
 __device__ inline void lockstep_phase(int (&idC)[U], double (&aC)[U], int (&idN)[U], double (&aN)[U],
                                       int64_t s, int64_t e, int64_t s2, int w, int wmask,
                                       const int *__restrict__ key, const double *__restrict__ val,
-                                      const double *__restrict__ xb, double *yp, const double *pf,
-                                      int &sink_prev, int &sink_new) {
+                                      const double *__restrict__ xb, double *yp) {
   const int lane = threadIdx.x & 63;
   double xv[U];
   const double *xp[U];
@@ -215,17 +214,8 @@ __device__ inline void lockstep_phase(int (&idC)[U], double (&aC)[U], int (&idN)
     aN[u] = __builtin_nontemporal_load(vn + u * 64);
   }
   __builtin_amdgcn_sched_barrier(0);
-  if (PF) {
-    // Warm the XCD's L2 with this wavefront's share of the NEXT x block: one 4-byte load per
-    // lane, lanes one line apart, result unused.  The lockstep keeps every CU of the XCD in
-    // the same phase, so the shares of its 512 wavefronts cover the block before anyone gathers
-    // from it, and next phase's gathers hit instead of waiting for fabric latency.  The sink
-    // register stays live until the next phase's gather wait has retired this (older) load.
-    asm volatile("global_load_dword %0, %1, off" : "=v"(sink_new) : "v"(pf) : "memory");
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // younger than gather u at this point: U-1-u gathers + 2*U stream loads (+ the warming load)
-  constexpr int Y = 3 * U - 1 + (PF ? 1 : 0);
+  // younger than gather u at this point: U-1-u gathers + 2*U stream loads
+  constexpr int Y = 3 * U - 1;
   gather_wait<Y>(xv[0]);
   if (U > 1) gather_wait<Y - 1>(xv[U > 1 ? 1 : 0]);
   if (U > 2) gather_wait<Y - 2>(xv[U > 2 ? 2 : 0]);
@@ -238,7 +228,6 @@ __device__ inline void lockstep_phase(int (&idC)[U], double (&aC)[U], int (&idN)
   if (U > 9) gather_wait<Y - 9>(xv[U > 9 ? 9 : 0]);
   if (U > 10) gather_wait<Y - 10>(xv[U > 10 ? 10 : 0]);
   if (U > 11) gather_wait<Y - 11>(xv[U > 11 ? 11 : 0]);
-  if (PF) asm volatile("" ::"v"(sink_prev));  // last phase's warming load has retired by now
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (s + u * 64 >= e) break;  // wave-uniform
@@ -254,7 +243,7 @@ __device__ inline void lockstep_phase(int (&idC)[U], double (&aC)[U], int (&idN)
   __builtin_amdgcn_s_barrier();  // pacing only: no fence, vector memory stays in flight
 }
 
-template <int U, int NW, int FOLD, int PF>
+template <int U, int NW, int FOLD>
 __global__ __launch_bounds__(NW * 64) void spmv_blocked_lockstep(
     int64_t nrows, int64_t npanels, int R, int w, int64_t ncb, int64_t ncols,
     const int64_t *__restrict__ segptr, const int *__restrict__ key, const double *__restrict__ val,
@@ -266,11 +255,7 @@ __global__ __launch_bounds__(NW * 64) void spmv_blocked_lockstep(
   const int wmask = (1 << w) - 1;
   const int64_t nb = gridDim.x;
   const int64_t ngen = (npanels + nb * NW - 1) / (nb * NW);
-  // L2 warming share of this wavefront inside an x block (workgroups b, b+8, ... share an XCD)
-  const int64_t blk = 1LL << w;
-  const int64_t share = blk / (32 * NW) > 64 ? blk / (32 * NW) : 64;  // doubles per wavefront
-  const int64_t pf_off = ((((int64_t)(blockIdx.x >> 3) & 31) * NW + wave) * share) % blk + lane * (share / 64);
-  int sinkA = 0, sinkB = 0;
+  (void)ncols;
   for (int64_t g = 0; g < ngen; ++g) {
     const int64_t p = (g * nb + blockIdx.x) * NW + wave;
     const bool have = p < npanels;
@@ -292,16 +277,10 @@ __global__ __launch_bounds__(NW * 64) void spmv_blocked_lockstep(
     __builtin_amdgcn_wave_barrier();
     for (int64_t cb = 0; cb < ncb; cb += 2) {
       const int64_t b0 = have ? sp[cb] : s0, b1 = have ? sp[cb + 1] : s0;
-      int64_t q1 = ((cb + 1) << w) + pf_off;
-      q1 = q1 < ncols ? q1 : ncols - 1;
-      lockstep_phase<U, FOLD, PF>(idA, aA, idB, aB, b0, b1, b1, w, wmask, key, val, x + (cb << w), yp, x + q1,
-                                  sinkA, sinkB);
+      lockstep_phase<U, FOLD>(idA, aA, idB, aB, b0, b1, b1, w, wmask, key, val, x + (cb << w), yp);
       if (cb + 1 < ncb) {
         const int64_t b2 = have ? sp[cb + 2] : s0;
-        int64_t q2 = ((cb + 2) << w) + pf_off;
-        q2 = q2 < ncols ? q2 : ncols - 1;
-        lockstep_phase<U, FOLD, PF>(idB, aB, idA, aA, b1, b2, b2, w, wmask, key, val, x + ((cb + 1) << w), yp,
-                                    x + q2, sinkB, sinkA);
+        lockstep_phase<U, FOLD>(idB, aB, idA, aA, b1, b2, b2, w, wmask, key, val, x + ((cb + 1) << w), yp);
       }
     }
     if (have)
@@ -429,19 +408,17 @@ int launch_spmv_blocked(const Matrix *m, const double *d_x, double *d_y, int acc
     SPL_HIP(hipMemsetAsync(b->arrive.get(), 0, sizeof(unsigned), s));
 #define SPL_LAUNCH_LS(UU, NN)                                                                            \
   do {                                                                                                   \
-    if (b->fold == 1 && b->warm) SPL_LAUNCH_LS2(UU, NN, 1, 1);                                           \
-    else if (b->fold == 1) SPL_LAUNCH_LS2(UU, NN, 1, 0);                                                 \
-    else SPL_LAUNCH_LS2(UU, NN, 0, 0);                                                                   \
+    if (b->fold == 1) SPL_LAUNCH_LS2(UU, NN, 1); else SPL_LAUNCH_LS2(UU, NN, 0);                         \
   } while (0)
-#define SPL_LAUNCH_LS2(UU, NN, FF, PP)                                                                     \
+#define SPL_LAUNCH_LS2(UU, NN, FF)                                                                         \
   do {                                                                                                   \
     static bool set_ = false;                                                                            \
     if (!set_) {                                                                                         \
-      SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_blocked_lockstep<UU, NN, FF, PP>),\
+      SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_blocked_lockstep<UU, NN, FF>),    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
       set_ = true;                                                                                       \
     }                                                                                                    \
-    hipLaunchKernelGGL((spmv_blocked_lockstep<UU, NN, FF, PP>), dim3((unsigned)nb), dim3(NN * 64), lds,  \
+    hipLaunchKernelGGL((spmv_blocked_lockstep<UU, NN, FF>), dim3((unsigned)nb), dim3(NN * 64), lds,      \
                        s, m->nrows_local, b->npanels, b->R, b->w, b->ncb, m->ncols, b->segptr.get(),       \
                        b->key.get(), b->val.get(), d_x, d_y, accumulate, b->arrive.get());               \
   } while (0)
