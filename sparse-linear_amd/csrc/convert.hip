@@ -295,7 +295,9 @@ void transpose_compressed(const int *d_ptr, const int *d_idx, const double *d_va
 
 void finalize_matrix(Matrix *m, hipStream_t s) {
   const int64_t nl = m->nrows_local;
-  if (m->nnz < (int64_t)0x7fffffff) {
+  // SPL_FORCE_PTR64=1 exercises the 64-bit row-pointer kernels on small matrices (tests only)
+  const char *force64 = getenv("SPL_FORCE_PTR64");
+  if (m->nnz < (int64_t)0x7fffffff && !(force64 && force64[0] == '1')) {
     m->rowptr.alloc((size_t)nl + 1);
     narrow_i64_to_i32(m->rowptr64.get(), m->rowptr.get(), nl + 1, s);
   }
