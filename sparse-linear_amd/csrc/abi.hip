@@ -506,7 +506,7 @@ int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unr
     }
     m->blocked_unroll = unroll;
     m->blocked->lockstep_waves = waves;
-    if (const char *ev = getenv("SPL_BLOCKED_FOLD")) m->blocked->fold = atoi(ev) ? 1 : 0;
+    if (const char *ev = getenv("SPL_BLOCKED_FOLD")) m->blocked->fold = atoi(ev);
     return SPL_OK;
   });
 }

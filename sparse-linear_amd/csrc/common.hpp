@@ -156,6 +156,12 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
                    int64_t ncolsB, const int *Bp, const int *Bi, const double *Bx, DBuf<int64_t> &Cp,
                    DBuf<int> &Ci, DBuf<double> &Cx, int64_t *nnzC, int64_t *products, hipStream_t s);
 
+// ---- blocked band LU without interchanges (band_nopiv.hip) --------------------------------------
+bool band_is_column_dominant(int n, const int *d_Ap, const int *d_Ai, const double *d_Ax, hipStream_t s);
+int band_nopiv_factor(int n, int kl, int ku, double *d_AB, const int *d_Ap, const int *d_Ai,
+                      const double *d_Ax, const int *d_inv, hipStream_t s);
+void band_nopiv_solve(int sys, int n, int kl, int ku, const double *d_AB, double *d_c, hipStream_t s);
+
 // ---- synthetic generators (generate.hip) --------------------------------------------
 void generate_synthetic(Matrix *m, int kind, int64_t n_or_m, int K, uint64_t seed, hipStream_t s);
 void generate_rmat_coo(uint64_t seed, int scale, uint32_t ta, uint32_t tb, uint32_t tc, int64_t nedges,

@@ -104,9 +104,24 @@ __device__ inline void fold_chunk_atomic(int id, double prod, int w, double *yp)
         (__attribute__((address_space(3))) double *)(yp + (id >> w)), prod);
 }
 
+// Hybrid fold: the first lane of every run of equal rows does a plain read-add-write, the
+// followers (a minority: most rows have one entry per 64-entry chunk) add atomically in a
+// second instruction.  Same order as the reference: head first, followers in lane order.
+__device__ inline void fold_chunk_hybrid(int id, double prod, int w, double *yp) {
+  const int lane = threadIdx.x & 63;
+  const bool ok = id >= 0;
+  const int lr = ok ? (id >> w) : 0x7fffffff;
+  const int prev = __shfl_up(lr, 1, 64);
+  const bool head = (lane == 0) || (prev != lr);
+  if (ok && head) yp[lr] = prod + yp[lr];
+  if (ok && !head)
+    __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)(yp + lr), prod);
+}
+
 template <int FOLD>
 __device__ inline void fold_any(int id, double prod, int w, double *yp) {
   if (FOLD == 1) fold_chunk_atomic(id, prod, w, yp);
+  else if (FOLD == 2) fold_chunk_hybrid(id, prod, w, yp);
   else fold_chunk(id, prod, w, yp);
 }
 
@@ -408,7 +423,9 @@ int launch_spmv_blocked(const Matrix *m, const double *d_x, double *d_y, int acc
     SPL_HIP(hipMemsetAsync(b->arrive.get(), 0, sizeof(unsigned), s));
 #define SPL_LAUNCH_LS(UU, NN)                                                                            \
   do {                                                                                                   \
-    if (b->fold == 1) SPL_LAUNCH_LS2(UU, NN, 1); else SPL_LAUNCH_LS2(UU, NN, 0);                         \
+    if (b->fold == 1) SPL_LAUNCH_LS2(UU, NN, 1);                                                         \
+    else if (b->fold == 2) SPL_LAUNCH_LS2(UU, NN, 2);                                                    \
+    else SPL_LAUNCH_LS2(UU, NN, 0);                                                                      \
   } while (0)
 #define SPL_LAUNCH_LS2(UU, NN, FF)                                                                         \
   do {                                                                                                   \

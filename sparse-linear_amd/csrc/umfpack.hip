@@ -46,6 +46,7 @@ struct Numeric {
   int device = 0;
   int n = 0, kl = 0, ku = 0, ldab = 1;
   int singular = 0;
+  int nopiv = 0;  // 1: blocked factorisation without interchanges (column diagonally dominant A)
   DBuf<double> AB;
   DBuf<int> ipiv, perm, inv;
   Matrix *A = nullptr;   // rows of A   (residual b - A x)
@@ -372,6 +373,10 @@ int validate_host_csc(int n_row, int n_col, const int *Ap, const int *Ai) {
 // c (device, permuted order) <- solution of B z = c or B^T z = c
 void band_solve(const Numeric *N, int sys, double *d_c, hipStream_t s) {
   if (N->n == 0) return;
+  if (N->nopiv) {
+    band_nopiv_solve(sys, N->n, N->kl, N->ku, N->AB.get(), d_c, s);
+    return;
+  }
   hipLaunchKernelGGL(band_solve_kernel, dim3(1), dim3(1024), 0, s, sys, N->n, N->kl, N->ku, N->ldab,
                      N->AB.get(), N->ipiv.get(), d_c);
 }
@@ -454,7 +459,22 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
     N->n = n;
     N->kl = S->kl;
     N->ku = S->ku;
-    N->ldab = 2 * S->kl + S->ku + 1;
+    // rows of A^T == the CSC arrays as they are: needed first, for the dominance test
+    void *hAt = nullptr;
+    {
+      int stc = spl_matrix_create_csr(n, n, 0, n, Ap, Ai, Ax, &hAt);
+      if (stc != SPL_OK) {
+        delete N;
+        return stc == SPL_ERROR_out_of_memory ? UMFPACK_ERROR_out_of_memory
+               : stc == SPL_ERROR_invalid_matrix ? UMFPACK_ERROR_invalid_matrix : UMFPACK_ERROR_internal_error;
+      }
+    }
+    N->At = static_cast<Matrix *>(hAt);
+    if (!N->At->rowptr.get()) { delete N; return UMFPACK_ERROR_out_of_memory; }
+    const char *force = getenv("SPL_LU_FORCE_PIVOT");
+    N->nopiv = (!(force && force[0] == '1') &&
+                band_is_column_dominant(n, N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), s)) ? 1 : 0;
+    N->ldab = N->nopiv ? (S->kl + S->ku + 1) : (2 * S->kl + S->ku + 1);
     const size_t band_elems = (size_t)N->ldab * (size_t)n;
     size_t free_b = 0, total_b = 0;
     SPL_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -471,18 +491,21 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
     SPL_HIP(hipMemcpyAsync(N->inv.get(), S->inv.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
     // device copies of A for the residuals of the refinement: rows of A (transposed on the
     // device) and rows of A^T (the CSC arrays as they are)
-    void *hA = nullptr, *hAt = nullptr;
+    void *hA = nullptr;
     int st = spl_matrix_create(n, n, Ap, Ai, Ax, &hA);
-    if (st == SPL_OK) st = spl_matrix_create_csr(n, n, 0, n, Ap, Ai, Ax, &hAt);
     if (st != SPL_OK) {
       spl_matrix_free(&hA);
-      spl_matrix_free(&hAt);
       delete N;
       return st == SPL_ERROR_out_of_memory ? UMFPACK_ERROR_out_of_memory
              : st == SPL_ERROR_invalid_matrix ? UMFPACK_ERROR_invalid_matrix : UMFPACK_ERROR_internal_error;
     }
     N->A = static_cast<Matrix *>(hA);
-    N->At = static_cast<Matrix *>(hAt);
+    if (N->nopiv) {
+      N->singular = band_nopiv_factor(n, N->kl, N->ku, N->AB.get(), N->At->rowptr.get(), N->At->colidx.get(),
+                                      N->At->val.get(), N->inv.get(), s);
+      *NumericOut = N;
+      return N->singular ? UMFPACK_WARNING_singular_matrix : UMFPACK_OK;
+    }
     // scatter P A P^T into band storage (reads the CSC arrays the At handle already holds)
     const int kv = N->kl + N->ku;
     if (N->At->nnz > 0)

@@ -97,7 +97,7 @@ def test_auto_choice(gpu, pkg, O):
     assert np.array_equal(y_auto[:2000], yo)
 
 
-@pytest.mark.parametrize("fold", [0, 1])
+@pytest.mark.parametrize("fold", [0, 1, 2])
 def test_fold_order_many_entries_per_row(gpu, pkg, O, fold, monkeypatch):
     """rows with 3..40 entries inside ONE column block: both folds must reproduce the reference's
     ascending-column order bit for bit (for the ds_add_f64 fold this pins the hardware's

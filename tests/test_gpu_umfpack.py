@@ -25,8 +25,12 @@ def test_feast_fixture_matrix(gpu, pkg, O):
     assert O.count_not_close(x, np.array([2.0 / 3.0, 1.0 / 3.0])) == 0
 
 
+@pytest.mark.parametrize("force_pivot", ["0", "1"])
 @pytest.mark.parametrize("m", [5, 30, 100])
-def test_poisson2d_manufactured(gpu, pkg, O, m):
+def test_poisson2d_manufactured(gpu, pkg, O, m, force_pivot, monkeypatch):
+    # Poisson matrices are column diagonally dominant: "0" takes the blocked no-interchange
+    # factorisation, "1" forces the partial-pivoting band LU; both must give the solution
+    monkeypatch.setenv("SPL_LU_FORCE_PIVOT", force_pivot)
     n = m * m
     rp, ci, v = O.gen_poisson2d_csr(m)
     A = pkg.Matrix(n, n, rp, ci, v)
@@ -41,8 +45,10 @@ def test_poisson2d_manufactured(gpu, pkg, O, m):
     assert O.count_not_close(x, xo, 1e-10) == 0
 
 
-def test_poisson3d_wide_band_path(gpu, pkg, O):
-    """m = 14: band half-width 196 -> the one-kernel-pair-per-column path"""
+@pytest.mark.parametrize("force_pivot", ["0", "1"])
+def test_poisson3d_wide_band_path(gpu, pkg, O, force_pivot, monkeypatch):
+    """m = 14: band half-width 196 -> the one-kernel-pair-per-column path when pivoting is forced"""
+    monkeypatch.setenv("SPL_LU_FORCE_PIVOT", force_pivot)
     m = 14
     n = m ** 3
     rp, ci, v = O.gen_poisson3d_csr(m)
@@ -126,3 +132,29 @@ def test_status_codes(gpu, pkg):
     h = C.c_void_p()
     L.umfpack_di_free_numeric(C.byref(h))  # NULL: no-op
     L.umfpack_di_free_symbolic(C.byref(h))
+
+
+def test_nopiv_path_unsymmetric_dominant_and_transposed(gpu, pkg, O):
+    """column diagonally dominant but unsymmetric, unequal bandwidths: exercises every masked edge of
+    the blocked factorisation and all four blocked solves (L, U, U^T, L^T)"""
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(17)
+    for n, lo, hi in ((70, 3, 9), (500, 40, 7), (1000, 1, 65), (333, 100, 100)):
+        rows, cols, vals = [], [], []
+        for j in range(n):
+            for i in range(max(0, j - hi), min(n, j + lo + 1)):
+                if i != j and rng.random() < 0.5:
+                    rows.append(i); cols.append(j); vals.append(rng.normal())
+        A0 = O.compress(n, n, rows, cols, vals)
+        colsum = np.zeros(n)
+        np.add.at(colsum, np.repeat(np.arange(n), np.diff(A0[2])), np.abs(A0[4]))
+        A = O.compress(n, n, rows + list(range(n)), cols + list(range(n)), vals + list(colsum + 1.0))
+        M = tuple_to_mat(pkg, A)
+        S = csc_tuple_to_scipy(A)
+        xs = rng.uniform(0.5, 1.5, n)
+        fact = pkg.umfpack.factor(M, pkg.umfpack.analyze(M))
+        for mode, op in ((0, S), (1, S.T.tocsc())):
+            b = op @ xs
+            x = pkg.umfpack.linearSolve_(fact, mode, M, b)
+            assert O.count_not_close(x, xs, 1e-10) == 0, (n, lo, hi, mode)
+            assert O.count_not_close(x, spla.spsolve(op.tocsc(), b), 1e-10) == 0
