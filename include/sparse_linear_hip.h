@@ -154,6 +154,9 @@ int spl_matrix_gaxpy(void *H, int xlen, const double *x, int ylen, double *y);
  * DEVICE pointers; the kernel is enqueued on `stream` and the call returns
  * without synchronising.  accumulate != 0: y <- A x + y. */
 int spl_matrix_spmv_dev(void *H, const double *d_x, double *d_y, int accumulate, void *stream);
+/* Device-resident sparse x dense (mulM): d_B is ncols x k, d_C is nrows_local x k, both
+ * row-major DEVICE arrays; A is read once for all k columns.  accumulate != 0: C <- A B + C. */
+int spl_matrix_spmm_dev(void *H, const double *d_B, double *d_C, int k, int accumulate, void *stream);
 /* select a kernel variant for spl_matrix_spmv_dev (tuning / ablation only):
  * 0 = default.  Returns SPL_ERROR_argument_missing for an unknown variant. */
 int spl_matrix_set_variant(void *H, int variant);

@@ -102,6 +102,7 @@ def _declare(L):
         "spl_matrix_mulv": [C.c_void_p, i, c_dbl_p, c_dbl_p],
         "spl_matrix_gaxpy": [C.c_void_p, i, c_dbl_p, i, c_dbl_p],
         "spl_matrix_spmv_dev": [C.c_void_p, C.c_void_p, C.c_void_p, i, C.c_void_p],
+        "spl_matrix_spmm_dev": [C.c_void_p, C.c_void_p, C.c_void_p, i, i, C.c_void_p],
         "spl_matrix_set_variant": [C.c_void_p, i],
         "spl_matrix_optimize": [C.c_void_p],
         "spl_matrix_build_blocked": [C.c_void_p, i, i, i],

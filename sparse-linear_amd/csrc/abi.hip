@@ -162,18 +162,6 @@ int host_spmv(Matrix *m, int xlen, const double *x, int ylen, double *y, int acc
   return SPL_OK;
 }
 
-__global__ __launch_bounds__(256) void transpose_dense_kernel(const double *__restrict__ in,
-                                                              double *__restrict__ out, int64_t rows,
-                                                              int64_t cols) {
-  // out[c*rows + r] = in[r*cols + c]
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t n = rows * cols, stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) {
-    const int64_t r = i / cols, c = i % cols;
-    out[c * rows + r] = in[i];
-  }
-}
-
 }  // namespace
 }  // namespace spl
 
@@ -596,17 +584,12 @@ int spl_mulm(int nrows, int ncols, const int *Ap, const int *Ai, const double *A
     try {
       hipStream_t s = nullptr;
       const size_t nb = (size_t)brows * bcols, nc = (size_t)nrows * bcols;
-      DBuf<double> dB, dBt(nb), dCt(nc), dC(nc);
+      DBuf<double> dB, dC(nc);
       upload(dB, B, nb, s);
-      if (nb) hipLaunchKernelGGL(transpose_dense_kernel, dim3(1024), dim3(256), 0, s, dB.get(), dBt.get(),
-                                 (int64_t)brows, (int64_t)bcols);
-      for (int j = 0; j < bcols && st == SPL_OK; ++j)  // one axpy_ per column (Sparse.hs:482-488)
-        st = launch_spmv(m, dBt.get() + (size_t)j * brows, dCt.get() + (size_t)j * nrows, 0, s);
-      if (st == SPL_OK && nc) {
-        hipLaunchKernelGGL(transpose_dense_kernel, dim3(1024), dim3(256), 0, s, dCt.get(), dC.get(),
-                           (int64_t)bcols, (int64_t)nrows);
-        SPL_HIP(hipMemcpyAsync(C, dC.get(), nc * sizeof(double), hipMemcpyDeviceToHost, s));
-      }
+      // the reference runs one axpy_ per column of B (Sparse.hs:482-488); the fused kernel reads A
+      // once for all columns and keeps each column's evaluation order
+      st = launch_spmm(m, dB.get(), dC.get(), bcols, 0, s);
+      if (st == SPL_OK && nc) SPL_HIP(hipMemcpyAsync(C, dC.get(), nc * sizeof(double), hipMemcpyDeviceToHost, s));
       SPL_HIP(hipStreamSynchronize(s));
     } catch (...) {
       delete m;
@@ -614,6 +597,17 @@ int spl_mulm(int nrows, int ncols, const int *Ap, const int *Ai, const double *A
     }
     delete m;
     return st;
+  });
+}
+
+int spl_matrix_spmm_dev(void *H, const double *d_B, double *d_C, int k, int accumulate, void *stream) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  if (k < 0) return SPL_ERROR_n_nonpositive;
+  if (k > 0 && ((m->ncols > 0 && !d_B) || (m->nrows_local > 0 && !d_C))) return SPL_ERROR_argument_missing;
+  return guarded([&]() -> int {
+    DeviceGuard g(m->device);
+    return launch_spmm(m, d_B, d_C, k, accumulate, as_stream(stream));
   });
 }
 

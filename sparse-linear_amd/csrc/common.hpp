@@ -171,6 +171,8 @@ void generate_vector(uint64_t seed, int64_t j0, int64_t j1, double *d_x, hipStre
 // ---- SpMV (spmv.hip) --------------------------------------------------------------------
 // y = A x (accumulate == 0) or y <- A x + y, rows of the block; enqueued on s
 int launch_spmv(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s);
+// C (nrows_local x k, row-major) = A B (+ C) for a row-major dense B (ncols x k): one pass over A
+int launch_spmm(const Matrix *m, const double *d_B, double *d_C, int k, int accumulate, hipStream_t s);
 constexpr int kNumSpmvVariants = 12;  // 0 auto, 1-6 CSR-stream shapes, 7 sub-wavefront, 8 column-blocked
 void build_blocked_image(Matrix *m, int rows_per_panel, int w, hipStream_t s);
 int launch_spmv_blocked(const Matrix *m, const double *d_x, double *d_y, int accumulate, int unroll,

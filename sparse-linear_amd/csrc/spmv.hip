@@ -189,6 +189,49 @@ __global__ __launch_bounds__(256) void spmv_subwave(int64_t nrows, const int *__
   if (valid && gl == 0) y[r] = accumulate ? acc + y[r] : acc;
 }
 
+// Sparse x dense (mulM, Sparse.hs:473-498): C = A B for a row-major dense B (ncols x k).  The
+// reference runs one axpy_ per column of B; here the matrix is read ONCE for all k columns: a
+// group of G lanes owns a row, lane j of the group owns output column j, and every stored entry
+// (r, c) gathers the k contiguous doubles B[c, :] (a full cache line for k >= 16 instead of 8
+// useful bytes of one).  Each (row, column) accumulator still folds a*b + acc over the row's
+// entries in ascending column order: bit-identical to the reference's per-column axpy_.
+template <typename PtrT>
+__global__ __launch_bounds__(256) void spmm_rowgroup_kernel(int64_t nrows, const PtrT *__restrict__ rowptr,
+                                                            const int *__restrict__ colidx,
+                                                            const double *__restrict__ val,
+                                                            const double *__restrict__ B,
+                                                            double *__restrict__ C, int k, int G,
+                                                            int accumulate) {
+  const int64_t gthread = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = gthread / G;
+  const int j0 = (int)(gthread % G);
+  if (row >= nrows) return;
+  const PtrT s = rowptr[row], e = rowptr[row + 1];
+  for (int j = j0; j < k; j += G) {
+    double acc = accumulate ? C[row * k + j] : 0.0;
+    for (PtrT p = s; p < e; ++p) acc = val[p] * B[(int64_t)colidx[p] * k + j] + acc;
+    C[row * k + j] = acc;
+  }
+}
+
+int launch_spmm_impl(const Matrix *m, const double *d_B, double *d_C, int k, int accumulate, hipStream_t s) {
+  if (m->nrows_local == 0 || k == 0) return SPL_OK;
+  int G = 1;
+  while (G < k && G < 64) G <<= 1;
+  const int64_t threads = m->nrows_local * G;
+  const int64_t grid = (threads + 255) / 256;
+  if (grid > 0x7fffffffLL) return SPL_ERROR_internal;
+  if (m->rowptr.get())
+    hipLaunchKernelGGL(spmm_rowgroup_kernel<int>, dim3((unsigned)grid), dim3(256), 0, s, m->nrows_local,
+                       m->rowptr.get(), m->colidx.get(), m->val.get(), d_B, d_C, k, G, accumulate);
+  else
+    hipLaunchKernelGGL(spmm_rowgroup_kernel<int64_t>, dim3((unsigned)grid), dim3(256), 0, s, m->nrows_local,
+                       m->rowptr64.get(), m->colidx.get(), m->val.get(), d_B, d_C, k, G, accumulate);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_last_error("spmm launch", e); return SPL_ERROR_device; }
+  return SPL_OK;
+}
+
 template <int EPL, int VW, bool NT, int GF = 0>
 int launch_stream(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s) {
   const int64_t nblocks = (m->nrows_local + kRowsPerBlock - 1) / kRowsPerBlock;
@@ -207,6 +250,10 @@ int launch_stream(const Matrix *m, const double *d_x, double *d_y, int accumulat
 }
 
 }  // namespace
+
+int launch_spmm(const Matrix *m, const double *d_B, double *d_C, int k, int accumulate, hipStream_t s) {
+  return launch_spmm_impl(m, d_B, d_C, k, accumulate, s);
+}
 
 int launch_spmv(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s) {
   if (m->nrows_local == 0) return SPL_OK;

@@ -200,6 +200,12 @@ class DeviceMatrix(object):
     def set_variant(self, variant):
         check("spl_matrix_set_variant", lib().spl_matrix_set_variant(self.handle, int(variant)))
 
+    def spmm_dev(self, b_ptr, c_ptr, k, accumulate=False, stream=0):
+        """C = A B for row-major device arrays B (ncols x k), C (nrows_local x k); no sync"""
+        check("spl_matrix_spmm_dev",
+              lib().spl_matrix_spmm_dev(self.handle, C.c_void_p(b_ptr), C.c_void_p(c_ptr), int(k),
+                                        1 if accumulate else 0, C.c_void_p(stream)))
+
     def optimize(self):
         """one-time analysis; may build the column-blocked image (csrc/spmv_blocked.hip)"""
         check("spl_matrix_optimize", lib().spl_matrix_optimize(self.handle))

@@ -239,3 +239,25 @@ def test_rowblock_partition(gpu, pkg, O):
             parts.append(H.mulv(x))
         assert covered == n
         assert np.array_equal(np.concatenate(parts), yo)  # row sums never cross ranks: bit-identical
+
+
+@pytest.mark.parametrize("k", [1, 3, 8, 16, 33, 70])
+def test_fused_spmm_matches_per_column_axpy(gpu, pkg, O, k):
+    """mulM (Sparse.hs:473-498): the fused sparse x dense kernel equals one axpy_ per column, bit for bit"""
+    torch = gpu
+    rng = np.random.default_rng(k)
+    nr, nc, nz = 3000, 2500, 40000
+    A = O.compress(nr, nc, rng.integers(0, nr, nz), rng.integers(0, nc, nz), rng.normal(size=nz))
+    B = rng.normal(size=(nc, k))
+    M = tuple_to_mat(pkg, A)
+    C = pkg.mulM(M, B)
+    assert np.array_equal(C, O.mulM(A, B))
+    # device-resident form, accumulate
+    H = M.device_handle()
+    dB = torch.from_numpy(B).cuda()
+    C0 = rng.normal(size=(nr, k))
+    dC = torch.from_numpy(C0.copy()).cuda()
+    H.spmm_dev(dB.data_ptr(), dC.data_ptr(), k, accumulate=True, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = np.stack([O.axpy(A, B[:, j].copy(), C0[:, j].copy()) for j in range(k)], axis=1)
+    assert np.array_equal(dC.cpu().numpy(), ref)
