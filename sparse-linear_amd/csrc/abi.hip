@@ -469,16 +469,16 @@ int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unr
   int waves = 16;
   if (rows_per_panel == 0 && cols_log2 == 0) {
     choose_blocking(m, &rows_per_panel, &cols_log2, &waves);
-    if (rows_per_panel == 0) { rows_per_panel = 1024; cols_log2 = 18; }  // explicit request: default shape
+    if (rows_per_panel == 0) { rows_per_panel = 1024; cols_log2 = 18; waves = 16; }  // explicit request: default shape
   }
   if (const char *ev = getenv("SPL_BLOCKED_LOCKSTEP")) waves = atoi(ev);
-  if (waves != 0 && waves != 8) waves = 16;
+  if (waves != 0 && waves != 8 && waves != 4) waves = 16;
   if (rows_per_panel < 1 || rows_per_panel > 20480 || cols_log2 < 4 || cols_log2 > 26 ||
       ((int64_t)rows_per_panel << cols_log2) > 0x7fffffffLL)
     return SPL_ERROR_argument_missing;
   // the lockstep workgroup keeps `waves` panels in one CU's LDS (160 KiB)
   while (waves > 0 && (size_t)waves * (size_t)rows_per_panel * sizeof(double) > 160 * 1024)
-    waves = waves == 16 ? 8 : 0;
+    waves = waves == 16 ? 8 : waves == 8 ? 4 : 0;
   if (waves == 0 && (size_t)4 * (size_t)rows_per_panel * sizeof(double) > 160 * 1024)
     return SPL_ERROR_argument_missing;
   return guarded([&]() -> int {
@@ -505,7 +505,7 @@ int spl_matrix_optimize(void *H) {
   int R = 0, w = 0, waves = 16;
   choose_blocking(m, &R, &w, &waves);
   if (R == 0) return SPL_OK;  // the CSR-stream kernel is already the right one
-  return spl_matrix_build_blocked(H, R, w, 0);
+  return spl_matrix_build_blocked(H, 0, 0, 0);  // 0,0: the same choice, including wavefronts per CU
 }
 
 int spl_vector_synthetic_dev(uint64_t seed, int64_t j0, int64_t j1, double *d_x, void *stream) {

@@ -446,6 +446,13 @@ int launch_spmv_blocked(const Matrix *m, const double *d_x, double *d_y, int acc
         case 12: SPL_LAUNCH_LS(12, 16); break;
         default: SPL_LAUNCH_LS(10, 16); break;
       }
+    } else if (NW == 4) {
+      switch (unroll) {
+        case 4: SPL_LAUNCH_LS(4, 4); break;
+        case 8: SPL_LAUNCH_LS(8, 4); break;
+        case 12: SPL_LAUNCH_LS(12, 4); break;
+        default: SPL_LAUNCH_LS(10, 4); break;
+      }
     } else {
       switch (unroll) {
         case 4: SPL_LAUNCH_LS(4, 8); break;
