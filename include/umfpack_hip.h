@@ -24,7 +24,10 @@
  * LU with partial pivoting of the permuted matrix in LAPACK band storage entirely on the GPU
  * (numeric), banded forward/back substitution and SpMV-based iterative refinement on the GPU
  * (solve).  Square matrices only (the reference's linearSolve_ assumes square, Umfpack.hs:93).
- * The complex (`zi`) entry points are not built yet.
+ * The complex (`zi`) entry points (Internal.hs:69-115) are served through the real 2n x 2n
+ * embedding with interleaved unknowns (csrc/umfpack_zi.hip): packed complex arrays (imaginary
+ * pointer NULL, the only form the reference uses, Internal.hs:124-132) ARE the real arrays of the
+ * embedded system; sys = 1 is the conjugate transpose, as in UMFPACK.
  */
 #ifndef UMFPACK_HIP_H
 #define UMFPACK_HIP_H
@@ -60,6 +63,22 @@ int umfpack_di_solve(int sys, const int Ap[], const int Ai[], const double Ax[],
 void umfpack_di_free_symbolic(void **Symbolic);
 void umfpack_di_free_numeric(void **Numeric);
 void umfpack_di_report_status(const double Control[], int status);
+
+/* ---- complex: Ax/Az, Xx/Xz, Bx/Bz are split real/imaginary arrays, or, when the imaginary
+ * pointer is NULL, packed interleaved (re, im) pairs in the real pointer ---------------------- */
+int umfpack_zi_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], const double Ax[],
+                        const double Az[], void **Symbolic, const double Control[], double Info[]);
+int umfpack_zi_numeric(const int Ap[], const int Ai[], const double Ax[], const double Az[],
+                       void *Symbolic, void **Numeric, const double Control[], double Info[]);
+int umfpack_zi_solve(int sys, const int Ap[], const int Ai[], const double Ax[], const double Az[],
+                     double Xx[], double Xz[], const double Bx[], const double Bz[], void *Numeric,
+                     const double Control[], double Info[]);
+void umfpack_zi_free_symbolic(void **Symbolic);
+void umfpack_zi_free_numeric(void **Numeric);
+void umfpack_zi_report_status(const double Control[], int status);
+
+/* dimension of the system a Numeric object factors (0 if invalid); helper of the zi wrappers */
+int spl_umfpack_dimension(void *Numeric);
 
 #ifdef __cplusplus
 }

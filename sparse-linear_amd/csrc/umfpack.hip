@@ -599,6 +599,12 @@ int umfpack_di_solve(int sys, const int Ap[], const int Ai[], const double Ax[],
   }
 }
 
+// dimension of the factored system (used by the `zi` wrappers in split-array mode); 0 if invalid
+int spl_umfpack_dimension(void *NumericIn) {
+  Numeric *N = as_numeric(NumericIn);
+  return N ? N->n : 0;
+}
+
 void umfpack_di_free_symbolic(void **SymbolicIO) {
   if (!SymbolicIO || !*SymbolicIO) return;
   Symbolic *S = as_symbolic(*SymbolicIO);

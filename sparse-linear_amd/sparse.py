@@ -28,6 +28,7 @@ from ._ffi import (SPL_ERROR_dimension_mismatch, SPL_ERROR_index_out_of_bounds, 
 
 I64 = np.int64
 F64 = np.float64
+C128 = np.complex128
 
 
 class SparseError(ValueError):
@@ -48,8 +49,14 @@ class Matrix(object):
         self.nrows = int(nrows)
         self.pointers = np.ascontiguousarray(pointers, dtype=I64)
         self.indices = np.ascontiguousarray(indices, dtype=I64)
-        self.values = np.ascontiguousarray(values, dtype=F64)
+        values = np.asarray(values)
+        # Double, or Complex Double (the reference's two SPECIALIZE instances, Sparse.hs:456-457)
+        self.values = np.ascontiguousarray(values, dtype=C128 if np.iscomplexobj(values) else F64)
         self._handle = None
+
+    @property
+    def is_complex(self):
+        return self.values.dtype == C128
 
     # deriving Eq (Sparse.hs:78): structural equality, explicit zeros included
     def __eq__(self, other):
@@ -91,8 +98,35 @@ class Matrix(object):
 
     # -- FFI seam -----------------------------------------------------------------------
     def _tuple32(self):
-        """withConstMatrix's marshalling (Foreign.hs:24-41): fresh int32 copies."""
-        return (self.nrows, self.ncols, as_i32(self.pointers), as_i32(self.indices), as_f64(self.values))
+        """withConstMatrix's marshalling (Foreign.hs:24-41): fresh int32 copies.  Complex values
+        cross as packed (re, im) pairs, the form the reference passes to umfpack_zi_* with the
+        imaginary pointer NULL (Umfpack/Internal.hs:124-132)."""
+        vals = self.values.view(F64) if self.is_complex else self.values
+        return (self.nrows, self.ncols, as_i32(self.pointers), as_i32(self.indices), as_f64(vals))
+
+    def _parts(self):
+        """real and imaginary parts as two real matrices with the same pattern"""
+        return (Matrix(self.ncols, self.nrows, self.pointers, self.indices, self.values.real.copy()),
+                Matrix(self.ncols, self.nrows, self.pointers, self.indices, self.values.imag.copy()))
+
+    def _embedded(self):
+        """the real 2nrows x 2ncols matrix with interleaved (re, im) unknowns whose action on packed
+        complex vectors equals this complex matrix's: block (i,j) = [[re, -im], [im, re]].  Complex
+        arithmetic on the device goes through this embedding in round 1 (native complex kernels:
+        SURVEY.md §8f rank 3)."""
+        p, i, x = self.pointers, self.indices, self.values
+        lens = np.diff(p)
+        nnz = int(p[-1])
+        newp = np.concatenate([[0], np.cumsum(np.repeat(2 * lens, 2))]).astype(I64)
+        col = np.repeat(np.arange(self.ncols), lens)
+        t = np.arange(nnz) - p[col]
+        idx = np.zeros(4 * nnz, dtype=I64)
+        val = np.zeros(4 * nnz, dtype=F64)
+        a = newp[2 * col] + 2 * t
+        b = newp[2 * col + 1] + 2 * t
+        idx[a], idx[a + 1], idx[b], idx[b + 1] = 2 * i, 2 * i + 1, 2 * i, 2 * i + 1
+        val[a], val[a + 1], val[b], val[b + 1] = x.real, x.imag, -x.imag, x.real
+        return Matrix(2 * self.ncols, 2 * self.nrows, newp, idx, val)
 
     def device_handle(self):
         """Upload once, reuse for every later SpMV (handle API)."""
@@ -271,6 +305,12 @@ def compress(nrows, ncols, rows, cols, vals):
     """COO -> CSC, duplicates summed, explicit zeros kept (Sparse.hs:184-255)."""
     rows = np.asarray(rows)
     cols = np.asarray(cols)
+    vals = np.asarray(vals)
+    if np.iscomplexobj(vals) and len(rows) == len(cols) == len(vals):
+        # complex addition is componentwise: the duplicate sums of the two real runs ARE the complex sums
+        re = compress(nrows, ncols, rows, cols, vals.real)
+        im = compress(nrows, ncols, rows, cols, vals.imag)
+        return Matrix(ncols, nrows, re.pointers, re.indices, re.values + 1j * im.values)
     vals = np.asarray(vals, dtype=F64)
     if len(rows) != len(cols):
         _oops("compress", "row and column array lengths differ")
@@ -310,6 +350,9 @@ def fromTriples(nr, nc, triples):
 
 def transpose(mat):
     """Counting-sort transpose (Sparse.hs:301-329); also the CSC -> CSR converter."""
+    if mat.is_complex:
+        re, im = (transpose(m) for m in mat._parts())
+        return Matrix(re.ncols, re.nrows, re.pointers, re.indices, re.values + 1j * im.values)
     _ffi.require_gpu()
     nr, nc, ap, ai, ax = mat._tuple32()
     nz = int(ap[nc])
@@ -322,7 +365,9 @@ def transpose(mat):
 
 
 def ctrans(mat):
-    return transpose(mat)  # conj is the identity on Double (Sparse.hs:371-375)
+    """omap conj . transpose (Sparse.hs:371-375); conj is the identity on Double"""
+    t = transpose(mat)
+    return cmap(np.conj, t) if t.is_complex else t
 
 
 def hermitian(mat):
@@ -349,6 +394,12 @@ def axpy(mat, x, y):
 
 
 def mulV(mat, x):
+    if mat.is_complex or np.iscomplexobj(x):
+        x = np.ascontiguousarray(x, dtype=C128)
+        if len(x) != mat.ncols:
+            _oops("axpy_", "column dimension %d does not match operand dimension %d" % (mat.ncols, len(x)))
+        m = mat if mat.is_complex else cmap(lambda v: v.astype(C128), mat)
+        return mulV(m._embedded(), x.view(F64)).view(C128)
     x = np.asarray(x, dtype=F64)
     if len(x) != mat.ncols:
         _oops("axpy_", "column dimension %d does not match operand dimension %d" % (mat.ncols, len(x)))
@@ -396,6 +447,15 @@ def mm(matA, matB):
     """C = A B (Sparse.hs:691-702): union pattern, cancellation keeps a stored 0."""
     if matA.ncols != matB.nrows:
         _oops("mm", "inner dimension mismatch")
+    if matA.is_complex or matB.is_complex:
+        a = matA if matA.is_complex else cmap(lambda v: v.astype(C128), matA)
+        b = matB if matB.is_complex else cmap(lambda v: v.astype(C128), matB)
+        e = mm(a._embedded(), b._embedded())  # embedding of the product: 2x2 blocks [[re,-im],[im,re]]
+        even = e.pointers[0:-1:2]
+        lens = np.diff(e.pointers)[0::2] // 2
+        ptrs = np.concatenate([[0], np.cumsum(lens)]).astype(I64)
+        take = np.repeat(even - 2 * ptrs[:-1], lens) + 2 * np.arange(int(ptrs[-1]))
+        return Matrix(matB.ncols, matA.nrows, ptrs, e.indices[take] // 2, e.values[take] + 1j * e.values[take + 1])
     _ffi.require_gpu()
     a, b = matA._tuple32(), matB._tuple32()
     nr, nc = C.c_int(), C.c_int()
@@ -412,6 +472,14 @@ def lin(alpha, matA, beta, matB):
         _oops("glin", "row number mismatch")
     if matA.ncols != matB.ncols:
         _oops("glin", "column number mismatch")
+    if matA.is_complex or matB.is_complex:
+        if np.iscomplexobj(alpha) and complex(alpha).imag != 0 or np.iscomplexobj(beta) and complex(beta).imag != 0:
+            raise NotImplementedError("lin: complex scalars need the native complex kernels (SURVEY.md §8f rank 3)")
+        al, be = float(np.real(alpha)), float(np.real(beta))
+        ar, ai = (matA if matA.is_complex else cmap(lambda v: v.astype(C128), matA))._parts()
+        br, bi = (matB if matB.is_complex else cmap(lambda v: v.astype(C128), matB))._parts()
+        re, im = lin(al, ar, be, br), lin(al, ai, be, bi)  # real scalars act componentwise: exact
+        return Matrix(re.ncols, re.nrows, re.pointers, re.indices, re.values + 1j * im.values)
     _ffi.require_gpu()
     a, b = matA._tuple32(), matB._tuple32()
     nr, nc = C.c_int(), C.c_int()
@@ -429,7 +497,8 @@ def _lengths(mat):
 
 
 def diag(values):
-    values = np.asarray(values, dtype=F64)
+    values = np.asarray(values)
+    values = values.astype(C128) if np.iscomplexobj(values) else values.astype(F64)
     n = len(values)
     return Matrix(n, n, np.arange(n + 1, dtype=I64), np.arange(n, dtype=I64), values)  # :650-657
 
@@ -557,7 +626,7 @@ def kronecker(matA, matB):
 
 def pack(mat):
     """dense copy (Sparse.hs:679-689)"""
-    out = np.zeros((mat.nrows, mat.ncols), dtype=F64)
+    out = np.zeros((mat.nrows, mat.ncols), dtype=mat.values.dtype)
     cols = np.repeat(np.arange(mat.ncols), _lengths(mat))
     out[mat.indices, cols] = mat.values
     return out

@@ -39,6 +39,19 @@ def _declare():
     L.umfpack_di_free_numeric.argtypes = [C.POINTER(vp)]
     L.umfpack_di_report_status.restype = None
     L.umfpack_di_report_status.argtypes = [dp, i]
+    # instance Umfpack (Complex Double) (Umfpack/Internal.hs:117-135): packed mode, Az = Xz = Bz = NULL
+    L.umfpack_zi_symbolic.restype = i
+    L.umfpack_zi_symbolic.argtypes = [i, i, ip, ip, dp, dp, C.POINTER(vp), dp, dp]
+    L.umfpack_zi_numeric.restype = i
+    L.umfpack_zi_numeric.argtypes = [ip, ip, dp, dp, vp, C.POINTER(vp), dp, dp]
+    L.umfpack_zi_solve.restype = i
+    L.umfpack_zi_solve.argtypes = [i, ip, ip, dp, dp, dp, dp, dp, dp, vp, dp, dp]
+    L.umfpack_zi_free_symbolic.restype = None
+    L.umfpack_zi_free_symbolic.argtypes = [C.POINTER(vp)]
+    L.umfpack_zi_free_numeric.restype = None
+    L.umfpack_zi_free_numeric.argtypes = [C.POINTER(vp)]
+    L.umfpack_zi_report_status.restype = None
+    L.umfpack_zi_report_status.argtypes = [dp, i]
     L._umf_declared = True
     return L
 
@@ -70,11 +83,13 @@ class _Handle(object):
 
 class Analysis(_Handle):
     """newtype Analysis a = Analysis { fsym :: ForeignPtr (Symbolic a) } (Umfpack.hs:56)"""
+    complex = False
 
 
 class Factors(_Handle):
     """newtype Factors a = Factors { fnum :: ForeignPtr (Numeric a) } (Umfpack.hs:58)"""
     status = 0
+    complex = False
 
 
 def analyze(mat):
@@ -82,6 +97,12 @@ def analyze(mat):
     L = _declare()
     nr, nc, ap, ai, ax = mat._tuple32()
     sym = C.c_void_p()
+    if mat.is_complex:
+        st = L.umfpack_zi_symbolic(nr, nc, p_i32(ap), p_i32(ai), p_f64(ax), None, C.byref(sym), None, None)
+        a = Analysis(sym.value, "umfpack_zi_free_symbolic")
+        a.complex = True
+        _report("analyze: umfpack_symbolic", st)
+        return a
     st = L.umfpack_di_symbolic(nr, nc, p_i32(ap), p_i32(ai), p_f64(ax), C.byref(sym), None, None)
     a = Analysis(sym.value, "umfpack_di_free_symbolic")
     _report("analyze: umfpack_symbolic", st)
@@ -94,6 +115,12 @@ def factor(mat, analysis):
     _ffi.require_gpu()
     nr, nc, ap, ai, ax = mat._tuple32()
     num = C.c_void_p()
+    if mat.is_complex:
+        st = L.umfpack_zi_numeric(p_i32(ap), p_i32(ai), p_f64(ax), None, analysis.value, C.byref(num), None, None)
+        f = Factors(num.value, "umfpack_zi_free_numeric")
+        f.complex = True
+        f.status = _report("factor: umfpack_numeric", st)
+        return f
     st = L.umfpack_di_numeric(p_i32(ap), p_i32(ai), p_f64(ax), analysis.value, C.byref(num), None, None)
     f = Factors(num.value, "umfpack_di_free_numeric")
     f.status = _report("factor: umfpack_numeric", st)
@@ -104,6 +131,13 @@ def linearSolve_(fact, mode, mat, b):
     """solve with existing factors (Umfpack.hs:87-102); returns the solution vector"""
     L = _declare()
     nr, nc, ap, ai, ax = mat._tuple32()
+    if mat.is_complex:
+        b = np.ascontiguousarray(b, dtype=np.complex128)
+        soln = np.zeros(mat.ncols, dtype=np.complex128)
+        st = L.umfpack_zi_solve(int(mode), p_i32(ap), p_i32(ai), p_f64(ax), None, p_f64(soln.view(np.float64)), None,
+                                p_f64(b.view(np.float64)), None, fact.value, None, None)
+        _report("linearSolve_: umfpack_solve", st)
+        return soln
     b = as_f64(b)
     soln = np.zeros(mat.ncols, dtype=np.float64)  # MV.replicate ncols 0 (:93)
     st = L.umfpack_di_solve(int(mode), p_i32(ap), p_i32(ai), p_f64(ax), p_f64(soln), p_f64(b), fact.value,

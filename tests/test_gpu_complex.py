@@ -1,0 +1,70 @@
+"""Complex Double (the reference's second SPECIALIZE instance): the complex fixtures of
+sparse-linear/tests/Sparse.hs:61-73 and the reference's only UMFPACK test
+(suitesparse/tests/test-umfpack.hs:16-19, `ident <\\> v == v` on Vector (Complex Double)).
+Round 1 serves complex arithmetic through the real embedding / componentwise real kernels."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+pytestmark = pytest.mark.gpu
+
+cval = st.builds(complex, st.integers(-20, 20), st.integers(-20, 20))
+
+
+def test_ctrans_fixtures(gpu, pkg):
+    m = pkg.fromTriples(2, 2, [(0, 0, 2 + 0j), (0, 1, -1 + 0j), (1, 0, -1 + 0j), (1, 1, 2 + 0j)])
+    assert m == pkg.ctrans(m)                                   # "preserves hermitian matrices"
+    sx = pkg.fromTriples(2, 2, [(0, 1, 1 + 0j), (1, 0, 1 + 0j)])
+    assert sx == pkg.ctrans(sx)                                 # "preserves sigma_x"
+    sy = pkg.fromTriples(2, 2, [(0, 1, -1j), (1, 0, 1j)])
+    assert sy == pkg.ctrans(sy) and pkg.hermitian(sy)           # "preserves sigma_y"
+    assert not (pkg.transpose(sy) == sy)
+
+
+@settings(max_examples=20, deadline=None, suppress_health_check=list(HealthCheck))
+@given(st.lists(st.builds(complex, st.floats(-1e6, 1e6, allow_nan=False), st.floats(-1e6, 1e6, allow_nan=False)),
+                min_size=1, max_size=40))
+def test_ident_solve_complex_exact(gpu, pkg, v):
+    v = np.array(v, dtype=np.complex128)
+    A = pkg.diag(np.ones(len(v), dtype=np.complex128))
+    assert np.array_equal(pkg.umfpack.solve(A, v), v)           # prop_linSolveId
+
+
+def test_complex_arithmetic_vs_numpy(gpu, pkg):
+    rng = np.random.default_rng(8)
+    nr, nc, k = 30, 25, 200
+    tri = lambda n1, n2: [(int(rng.integers(0, n1)), int(rng.integers(0, n2)),
+                           complex(rng.integers(-5, 6), rng.integers(-5, 6))) for _ in range(k)]
+    A, B = pkg.fromTriples(nr, nc, tri(nr, nc)), pkg.fromTriples(nc, 17, tri(nc, 17))
+    A2 = pkg.fromTriples(nr, nc, tri(nr, nc))
+    x = rng.integers(-4, 5, nc) + 1j * rng.integers(-4, 5, nc)
+    assert np.array_equal(pkg.mulV(A, x), pkg.pack(A) @ x)      # integer-valued: exact
+    assert np.array_equal(pkg.pack(A * B), pkg.pack(A) @ pkg.pack(B))
+    assert np.array_equal(pkg.pack(A + A2), pkg.pack(A) + pkg.pack(A2))
+    assert A - A == pkg.cmap(lambda v: v * 0, A)
+    assert np.array_equal(pkg.pack(pkg.ctrans(A)), pkg.pack(A).conj().T)
+    assert (A * B).is_complex
+
+
+def test_complex_solve_and_conjugate_transpose(gpu, pkg, O):
+    rng = np.random.default_rng(9)
+    n = 120
+    rows = list(rng.integers(0, n, 700)) + list(range(n))
+    cols = list(rng.integers(0, n, 700)) + list(range(n))
+    vals = list(rng.normal(size=700) + 1j * rng.normal(size=700)) + [complex(25.0, 3.0)] * n
+    A = pkg.fromTriples(n, n, list(zip(map(int, rows), map(int, cols), vals)))
+    D = pkg.pack(A)
+    xs = rng.normal(size=n) + 1j * rng.normal(size=n)
+    fact = pkg.umfpack.factor(A, pkg.umfpack.analyze(A))
+    x = pkg.umfpack.linearSolve_(fact, pkg.umfpack.UmfpackNormal, A, D @ xs)
+    assert np.max(np.abs(x - xs)) < 1e-10
+    xh = pkg.umfpack.linearSolve_(fact, pkg.umfpack.UmfpackTrans, A, D.conj().T @ xs)  # UMFPACK_At = A^H
+    assert np.max(np.abs(xh - xs)) < 1e-10
+    # the FEAST-style shifted matrix ze*I - A of feast/tests/test-feast.hs:25 at a complex contour point
+    F = pkg.fromTriples(2, 2, [(0, 0, 2 + 0j), (0, 1, -1 + 0j), (1, 0, -1 + 0j), (1, 1, 2 + 0j)])
+    ze = 2.0 + 1.5j
+    S = pkg.lin(-1.0, F, 1.0, pkg.diag(np.full(2, ze)))
+    b = np.array([1.0 + 0j, 0.0])
+    y = pkg.umfpack.solve(S, b)
+    assert np.max(np.abs(pkg.pack(S) @ y - b)) < 1e-13
