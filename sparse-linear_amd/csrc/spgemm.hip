@@ -62,15 +62,22 @@ __global__ __launch_bounds__(256) void products_kernel(Csc A, Csc B, int64_t nco
                                                        int64_t *__restrict__ xlarge_list,
                                                        int64_t *__restrict__ dense_list,
                                                        int *__restrict__ list_counts) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ncolsB) return;
+  // 8 lanes per column of B: the extents of the selected columns of A are independent loads
+  const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  const int64_t j = g < ncolsB ? g : ncolsB - 1;
   int64_t n = 0;
-  for (int q = B.p[j]; q < B.p[j + 1]; ++q) {
+  const int qs = B.p[j], qe = B.p[j + 1];
+  for (int q = qs + sub; q < qe; q += 8) {
     const int k = B.i[q];
     n += A.p[k + 1] - A.p[k];
   }
+  n += __shfl_xor(n, 1, 64);
+  n += __shfl_xor(n, 2, 64);
+  n += __shfl_xor(n, 4, 64);
+  if (g >= ncolsB || sub != 0) return;
   nprod[j] = n;
-  const int bin = bin_of(n, B.p[j + 1] - B.p[j]);
+  const int bin = bin_of(n, qe - qs);
   if (bin == 2) medium_list[atomicAdd(&list_counts[0], 1)] = j;
   else if (bin == 3) xlarge_list[atomicAdd(&list_counts[1], 1)] = j;
   else if (bin == 4) dense_list[atomicAdd(&list_counts[2], 1)] = j;
@@ -83,9 +90,13 @@ __device__ inline void group_sync() {
 }
 
 // LDS footprint of one group (NT threads cooperating on one column)
-template <int CAP, int NBCAP, bool NUMERIC>
+constexpr int ilog2_ceil(int v) { return v <= 1 ? 0 : 1 + ilog2_ceil((v + 1) / 2); }
+
+// KEY32: numeric keys are (row << tbits) | t in 32 bits (possible when nrows < 2^(31 - tbits));
+// the sort then moves 4-byte keys only and the values stay where the expansion put them
+template <int CAP, int NBCAP, bool NUMERIC, bool KEY32 = false>
 struct EscLds {
-  static constexpr size_t key_bytes = NUMERIC ? CAP * sizeof(int64_t) : CAP * sizeof(int);
+  static constexpr size_t key_bytes = (NUMERIC && !KEY32) ? CAP * sizeof(int64_t) : CAP * sizeof(int);
   static constexpr size_t val_bytes = NUMERIC ? CAP * sizeof(double) : 0;
   static constexpr size_t kb_bytes = NUMERIC ? NBCAP * sizeof(double) : 0;
   static constexpr size_t start_bytes = NBCAP * sizeof(int);
@@ -96,11 +107,13 @@ struct EscLds {
 
 // expand - sort - compress for ONE column j with np products and nb entries in B[:,j];
 // `tid` in [0, NT) is the thread's index inside the group, `lds` the group's LDS region.
-template <int NT, int CAP, int NBCAP, bool NUMERIC>
+template <int NT, int CAP, int NBCAP, bool NUMERIC, bool KEY32 = false>
 __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np, unsigned char *lds, int tid,
                                   int *__restrict__ counts, const int64_t *__restrict__ Cp,
                                   int *__restrict__ Ci, double *__restrict__ Cx) {
-  typedef EscLds<CAP, NBCAP, NUMERIC> L;
+  typedef EscLds<CAP, NBCAP, NUMERIC, KEY32> L;
+  constexpr int TB = ilog2_ceil(CAP);  // bits of the tie-break t
+  constexpr bool K64 = NUMERIC && !KEY32;
   int64_t *key64 = reinterpret_cast<int64_t *>(lds);
   int *key32 = reinterpret_cast<int *>(lds);
   double *vals = reinterpret_cast<double *>(lds + L::key_bytes);
@@ -161,9 +174,12 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
     }
     const int p = kstart[lo] + (t - koff[lo]);
     const int row = A.i[p];
-    if (NUMERIC) {
+    if (K64) {
       key64[t] = ((int64_t)row << 32) | (int64_t)t;  // ties: ascending t = ascending k
       vals[t] = A.x[p] * kb[lo];                     // a * b
+    } else if (NUMERIC) {
+      key32[t] = (row << TB) | t;
+      vals[t] = A.x[p] * kb[lo];
     } else {
       key32[t] = row;
     }
@@ -180,7 +196,7 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
         const int lo = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
         const int hi = flip ? (lo ^ (size - 1)) : (lo | jj);
         if (hi < np) {
-          if (NUMERIC) {
+          if (K64) {
             const int64_t ka = key64[lo], kb2 = key64[hi];
             if (kb2 < ka) {
               key64[lo] = kb2; key64[hi] = ka;
@@ -204,8 +220,8 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
     int row = 0;
     bool head = false;
     if (t < np) {
-      row = NUMERIC ? (int)(key64[t] >> 32) : key32[t];
-      const int prev = t > 0 ? (NUMERIC ? (int)(key64[t - 1] >> 32) : key32[t - 1]) : -1;
+      row = K64 ? (int)(key64[t] >> 32) : NUMERIC ? (key32[t] >> TB) : key32[t];
+      const int prev = t > 0 ? (K64 ? (int)(key64[t - 1] >> 32) : NUMERIC ? (key32[t - 1] >> TB) : key32[t - 1]) : -1;
       head = (t == 0) || (row != prev);
     }
     const unsigned long long m = __ballot(head);
@@ -223,7 +239,11 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
     }
     if (NUMERIC && head) {
       double acc = 0.0;  // SG.reset 0
-      for (int u = t; u < np && (int)(key64[u] >> 32) == row; ++u) acc = acc + vals[u];  // c + a * b
+      if (K64) {
+        for (int u = t; u < np && (int)(key64[u] >> 32) == row; ++u) acc = acc + vals[u];  // c + a * b
+      } else {
+        for (int u = t; u < np && (key32[u] >> TB) == row; ++u) acc = acc + vals[key32[u] & ((1 << TB) - 1)];
+      }
       Ci[base + off] = row;
       Cx[base + off] = acc;
     }
@@ -233,13 +253,13 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
 }
 
 // bin S: one wavefront per column of B, four columns per workgroup
-template <bool NUMERIC>
+template <bool NUMERIC, bool KEY32>
 __global__ __launch_bounds__(256) void spgemm_wave_kernel(Csc A, Csc B, int64_t ncolsB,
                                                           const int64_t *__restrict__ nprod,
                                                           int *__restrict__ counts,
                                                           const int64_t *__restrict__ Cp,
                                                           int *__restrict__ Ci, double *__restrict__ Cx) {
-  typedef EscLds<kSmallProducts, kSmallProducts, NUMERIC> L;
+  typedef EscLds<kSmallProducts, kSmallProducts, NUMERIC, KEY32> L;
   __shared__ __attribute__((aligned(16))) unsigned char lds_all[4][(L::total + 15) / 16 * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t j = (int64_t)blockIdx.x * 4 + wave;
@@ -250,12 +270,12 @@ __global__ __launch_bounds__(256) void spgemm_wave_kernel(Csc A, Csc B, int64_t 
     if (!NUMERIC && lane == 0) counts[j] = 0;
     return;
   }
-  esc_column<64, kSmallProducts, kSmallProducts, NUMERIC>(A, B, j, (int)np, lds_all[wave], lane, counts, Cp, Ci,
-                                                         Cx);
+  esc_column<64, kSmallProducts, kSmallProducts, NUMERIC, KEY32>(A, B, j, (int)np, lds_all[wave], lane, counts,
+                                                                Cp, Ci, Cx);
 }
 
 // bins M and X: one workgroup per listed column
-template <int CAP, int NBCAP, bool NUMERIC>
+template <int CAP, int NBCAP, bool NUMERIC, bool KEY32>
 __global__ __launch_bounds__(256) void spgemm_block_kernel(Csc A, Csc B, const int64_t *__restrict__ list,
                                                            const int64_t *__restrict__ nprod,
                                                            int *__restrict__ counts,
@@ -263,7 +283,7 @@ __global__ __launch_bounds__(256) void spgemm_block_kernel(Csc A, Csc B, const i
                                                            int *__restrict__ Ci, double *__restrict__ Cx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int64_t j = list[blockIdx.x];
-  esc_column<256, CAP, NBCAP, NUMERIC>(A, B, j, (int)nprod[j], smem, (int)threadIdx.x, counts, Cp, Ci, Cx);
+  esc_column<256, CAP, NBCAP, NUMERIC, KEY32>(A, B, j, (int)nprod[j], smem, (int)threadIdx.x, counts, Cp, Ci, Cx);
 }
 
 // bin L: persistent workgroups, each owning one dense accumulator of the pool
@@ -345,7 +365,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
       dense_list((size_t)ncolsB);
   DBuf<int> list_counts(3), counts((size_t)ncolsB);
   SPL_HIP(hipMemsetAsync(list_counts.get(), 0, 3 * sizeof(int), s));
-  hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 256)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
+  hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 32)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
                      medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get());
   int hc[3] = {0, 0, 0};
   SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 3 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -357,14 +377,21 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     SPL_HIP(hipMemcpy(products, pscan.get() + ncolsB, sizeof(int64_t), hipMemcpyDeviceToHost));
   }
   typedef EscLds<kMediumProducts, kMediumB, false> LMs;
-  typedef EscLds<kMediumProducts, kMediumB, true> LMn;
   typedef EscLds<kLargeProducts, kLargeB, false> LXs;
-  typedef EscLds<kLargeProducts, kLargeB, true> LXn;
+  typedef EscLds<kLargeProducts, kLargeB, true, false> LXn;
+  typedef EscLds<kLargeProducts, kLargeB, true, true> LXn32;
+  // 32-bit packed sort keys need row + tie-break bits to fit 31 bits in every bin
+  const bool key32_s = nrowsA <= (1LL << (31 - ilog2_ceil(kSmallProducts)));
+  const bool key32_m = nrowsA <= (1LL << (31 - ilog2_ceil(kMediumProducts)));
+  const bool key32_x = nrowsA <= (1LL << (31 - ilog2_ceil(kLargeProducts)));
   static bool attr_set = false;
   if (!attr_set) {
     SPL_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void *>(&spgemm_block_kernel<kLargeProducts, kLargeB, true>),
+        reinterpret_cast<const void *>(&spgemm_block_kernel<kLargeProducts, kLargeB, true, false>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LXn::total));
+    SPL_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void *>(&spgemm_block_kernel<kLargeProducts, kLargeB, true, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LXn32::total));
     attr_set = true;
   }
   int pool = ndense < kMaxPool ? ndense : kMaxPool;
@@ -382,14 +409,14 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   }
 
   // ---- symbolic: nnz per column
-  hipLaunchKernelGGL(spgemm_wave_kernel<false>, dim3(blocks_for(ncolsB, 4)), dim3(256), 0, s, A, B, ncolsB,
+  hipLaunchKernelGGL((spgemm_wave_kernel<false, false>), dim3(blocks_for(ncolsB, 4)), dim3(256), 0, s, A, B, ncolsB,
                      nprod.get(), counts.get(), (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
   if (nmedium > 0)
-    hipLaunchKernelGGL((spgemm_block_kernel<kMediumProducts, kMediumB, false>), dim3((unsigned)nmedium), dim3(256),
+    hipLaunchKernelGGL((spgemm_block_kernel<kMediumProducts, kMediumB, false, false>), dim3((unsigned)nmedium), dim3(256),
                        LMs::total, s, A, B, medium_list.get(), nprod.get(), counts.get(),
                        (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
   if (nxlarge > 0)
-    hipLaunchKernelGGL((spgemm_block_kernel<kLargeProducts, kLargeB, false>), dim3((unsigned)nxlarge), dim3(256),
+    hipLaunchKernelGGL((spgemm_block_kernel<kLargeProducts, kLargeB, false, false>), dim3((unsigned)nxlarge), dim3(256),
                        LXs::total, s, A, B, xlarge_list.get(), nprod.get(), counts.get(),
                        (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
   if (ndense > 0)
@@ -406,16 +433,24 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   if (nz == 0) return;
 
   // ---- numeric: every path writes its column already sorted by row
-  hipLaunchKernelGGL(spgemm_wave_kernel<true>, dim3(blocks_for(ncolsB, 4)), dim3(256), 0, s, A, B, ncolsB,
-                     nprod.get(), (int *)nullptr, Cp.get(), Ci.get(), Cx.get());
-  if (nmedium > 0)
-    hipLaunchKernelGGL((spgemm_block_kernel<kMediumProducts, kMediumB, true>), dim3((unsigned)nmedium), dim3(256),
-                       LMn::total, s, A, B, medium_list.get(), nprod.get(), (int *)nullptr, Cp.get(), Ci.get(),
-                       Cx.get());
-  if (nxlarge > 0)
-    hipLaunchKernelGGL((spgemm_block_kernel<kLargeProducts, kLargeB, true>), dim3((unsigned)nxlarge), dim3(256),
-                       LXn::total, s, A, B, xlarge_list.get(), nprod.get(), (int *)nullptr, Cp.get(), Ci.get(),
-                       Cx.get());
+#define SPL_NUMERIC_WAVE(K32)                                                                                  \
+  hipLaunchKernelGGL((spgemm_wave_kernel<true, K32>), dim3(blocks_for(ncolsB, 4)), dim3(256), 0, s, A, B, ncolsB, \
+                     nprod.get(), (int *)nullptr, Cp.get(), Ci.get(), Cx.get())
+#define SPL_NUMERIC_BLOCK(CAP, NBCAP, K32, LIST, COUNT)                                                        \
+  hipLaunchKernelGGL((spgemm_block_kernel<CAP, NBCAP, true, K32>), dim3((unsigned)(COUNT)), dim3(256),         \
+                     (EscLds<CAP, NBCAP, true, K32>::total), s, A, B, LIST.get(), nprod.get(), (int *)nullptr,  \
+                     Cp.get(), Ci.get(), Cx.get())
+  if (key32_s) SPL_NUMERIC_WAVE(true); else SPL_NUMERIC_WAVE(false);
+  if (nmedium > 0) {
+    if (key32_m) SPL_NUMERIC_BLOCK(kMediumProducts, kMediumB, true, medium_list, nmedium);
+    else SPL_NUMERIC_BLOCK(kMediumProducts, kMediumB, false, medium_list, nmedium);
+  }
+  if (nxlarge > 0) {
+    if (key32_x) SPL_NUMERIC_BLOCK(kLargeProducts, kLargeB, true, xlarge_list, nxlarge);
+    else SPL_NUMERIC_BLOCK(kLargeProducts, kLargeB, false, xlarge_list, nxlarge);
+  }
+#undef SPL_NUMERIC_WAVE
+#undef SPL_NUMERIC_BLOCK
   if (ndense > 0)
     hipLaunchKernelGGL(spgemm_dense_kernel<true>, dim3((unsigned)pool), dim3(256), 0, s, A, B, nrowsA,
                        dense_list.get(), ndense, pool_flags.get(), pool_vals.get(), (int *)nullptr, Cp.get(),
