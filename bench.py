@@ -143,7 +143,8 @@ def main():
     kern_ms = ev0.elapsed_time(ev1) / args.steps
     achieved = B_local / (kern_ms * 1e-3) / 1e9
     info = H.info()
-    kernel = "spmv_blocked_lockstep" if info["blocked_rows"] else "spmv_stream"
+    kernel = ("spmv_blocked_lockstep" if info["blocked_rows"] > 0 else
+              "spmv_sell" if info["blocked_rows"] < 0 else "spmv_stream")
     traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (N = 1, default sizes only)
     tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
     if N == 1 and n == 10_000_000 and args.draws == 20 and os.path.exists(tfile):
@@ -151,7 +152,7 @@ def main():
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "kernel": kernel, "kernel_ms": round(kern_ms, 4), "bytes_per_launch": B_local}
-    if info["blocked_rows"]:
+    if info["blocked_rows"] > 0:
         roofline["image"] = "column-blocked: %d rows/panel, 2^%d columns/block" % (info["blocked_rows"], info["blocked_cols_log2"])
 
     out = {

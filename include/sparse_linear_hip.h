@@ -136,7 +136,8 @@ int spl_matrix_spgemm(void *HA, void *HB, void **HC, int64_t *products);
 void spl_matrix_free(void **H);
 
 /* info[0..7] = nrows_global, ncols, row0, nrows_local, nnz_local, device,
- * rows per panel of the column-blocked image (0 = CSR-stream kernel in use), its cols_log2 */
+ * rows per panel of the column-blocked image (0 = CSR-stream kernel in use, -64 = sliced-ELL
+ * image in use), its cols_log2 */
 int spl_matrix_info(void *H, int64_t info[8]);
 /* copy the device CSR image back: rowptr[nrows_local+1] (relative to the block,
  * rowptr[0]=0), colidx[nnz_local], val[nnz_local] */
@@ -161,9 +162,10 @@ int spl_matrix_spmm_dev(void *H, const double *d_B, double *d_C, int k, int accu
  * 0 = default.  Returns SPL_ERROR_argument_missing for an unknown variant. */
 int spl_matrix_set_variant(void *H, int variant);
 
-/* Analyse the matrix once (like umfpack_*_symbolic) and, if its columns have no
- * locality and x exceeds the L2s, build the column-blocked image that variant 0
- * then uses (csrc/spmv_blocked.hip).  Results are bit-identical either way. */
+/* Analyse the matrix once (like umfpack_*_symbolic) and build the image variant 0 then uses:
+ * the column-blocked image when columns have no locality and x exceeds the L2s
+ * (csrc/spmv_blocked.hip), the sliced-ELL image for regular rows with locality
+ * (csrc/spmv_sell.hip), or nothing (CSR-stream kernel).  Results are bit-identical either way. */
 int spl_matrix_optimize(void *H);
 /* build that image with an explicit shape (tuning / ablation): panels of rows_per_panel rows,
  * column blocks of 2^cols_log2 columns (rows_per_panel << cols_log2 must fit 31 bits);

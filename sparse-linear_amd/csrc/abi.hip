@@ -385,8 +385,9 @@ int spl_matrix_info(void *H, int64_t info[8]) {
   info[3] = m->nrows_local;
   info[4] = m->nnz;
   info[5] = m->device;
-  const bool blocked = m->blocked && (m->variant == 0 || m->variant == 8);
-  info[6] = blocked ? m->blocked->R : 0;
+  const bool sell = m->sell && (m->variant == 0 || m->variant == 15);
+  const bool blocked = !sell && m->blocked && (m->variant == 0 || m->variant == 8);
+  info[6] = blocked ? m->blocked->R : sell ? -64 : 0;  // -64: sliced-ELL image (64-row slices) in use
   info[7] = blocked ? m->blocked->w : 0;
   return SPL_OK;
 }
@@ -459,6 +460,14 @@ int spl_matrix_set_variant(void *H, int variant) {
     int st = spl_matrix_build_blocked(H, 0, 0, 0);
     if (st != SPL_OK) return st;
   }
+  if (variant == 15 && !m->sell) {
+    int st = guarded([&]() -> int {
+      DeviceGuard g(m->device);
+      build_sell_image(m, nullptr);
+      return SPL_OK;
+    });
+    if (st != SPL_OK) return st;
+  }
   m->variant = variant;
   return SPL_OK;
 }
@@ -504,7 +513,19 @@ int spl_matrix_optimize(void *H) {
   if (!m) return SPL_ERROR_invalid_handle;
   int R = 0, w = 0, waves = 16;
   choose_blocking(m, &R, &w, &waves);
-  if (R == 0) return SPL_OK;  // the CSR-stream kernel is already the right one
+  if (R == 0) {
+    // no blocking needed.  Regular rows with column locality (banded, stencil): the sliced-ELL
+    // image turns the x gathers into near-coalesced loads; build it when padding stays < 1/8.
+    if (m->nnz > 0 && m->new_line_fraction < 0.5 && m->nrows_local >= 64 * 256) {
+      return guarded([&]() -> int {
+        DeviceGuard g(m->device);
+        const int64_t padded = sell_padded_entries(m, nullptr);
+        if (padded - m->nnz <= m->nnz / 8) build_sell_image(m, nullptr);
+        return SPL_OK;
+      });
+    }
+    return SPL_OK;  // the CSR-stream kernel is already the right one
+  }
   return spl_matrix_build_blocked(H, 0, 0, 0);  // 0,0: the same choice, including wavefronts per CU
 }
 

@@ -86,6 +86,14 @@ struct BlockedImage {
   int lockstep_waves = 16;        // wavefronts (= panels) per lockstep workgroup: 16 or 8; 0 = ablation kernel
 };
 
+// sliced-ELL image of a row block (spmv_sell.hip)
+struct SellImage {
+  int64_t nslices = 0, entries = 0;
+  DBuf<int64_t> sliceoff;  // nslices + 1, in units of 64 entries
+  DBuf<int> col;
+  DBuf<double> val;
+};
+
 // A device-resident block of rows [row0, row0+nrows_local) of a sparse matrix
 // with nrows_global x ncols entries, stored row-major (CSR, int32 column
 // indices, int64 row pointers relative to the block).
@@ -101,11 +109,12 @@ struct Matrix {
   int64_t max_row_len = 0;
   double new_line_fraction = 0.0;  // share of entries whose x line the previous row did not touch
   BlockedImage *blocked = nullptr;  // built on demand (spl_matrix_build_blocked / auto)
+  SellImage *sell = nullptr;        // built on demand (spl_matrix_optimize on regular matrices)
   int blocked_unroll = 0;  // 0 = default; < 0 selects the ablation kernel
   Matrix() = default;
   Matrix(const Matrix &) = delete;
   Matrix &operator=(const Matrix &) = delete;
-  ~Matrix() { delete blocked; }
+  ~Matrix() { delete blocked; delete sell; }
 };
 
 inline Matrix *as_matrix(void *h) {
@@ -173,7 +182,10 @@ void generate_vector(uint64_t seed, int64_t j0, int64_t j1, double *d_x, hipStre
 int launch_spmv(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s);
 // C (nrows_local x k, row-major) = A B (+ C) for a row-major dense B (ncols x k): one pass over A
 int launch_spmm(const Matrix *m, const double *d_B, double *d_C, int k, int accumulate, hipStream_t s);
-constexpr int kNumSpmvVariants = 12;  // 0 auto, 1-6 CSR-stream shapes, 7 sub-wavefront, 8 column-blocked
+int64_t sell_padded_entries(const Matrix *m, hipStream_t s);
+void build_sell_image(Matrix *m, hipStream_t s);
+int launch_spmv_sell(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s);
+constexpr int kNumSpmvVariants = 16;  // 15 = sliced-ELL image;  // 12-14: timing-only ablations of the CSR-stream kernel (wrong results)  // 0 auto, 1-6 CSR-stream shapes, 7 sub-wavefront, 8 column-blocked
 void build_blocked_image(Matrix *m, int rows_per_panel, int w, hipStream_t s);
 int launch_spmv_blocked(const Matrix *m, const double *d_x, double *d_y, int accumulate, int unroll,
                         hipStream_t s);

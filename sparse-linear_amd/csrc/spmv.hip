@@ -63,7 +63,7 @@ __device__ inline double wave_sum(double v) {
 
 // EPL: elements per lane per pass (chunk = 64*EPL products in LDS per wavefront)
 // VW : elements per vector load (1, 2 or 4)
-template <int EPL, int VW, bool NT, typename PtrT, int GF = 0>
+template <int EPL, int VW, bool NT, typename PtrT, int GF = 0, int ABL = 0>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void spmv_stream(
     int64_t nrows, int64_t nblocks, const PtrT *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
@@ -128,7 +128,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void spmv_stream(
     }
     double p[EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) p[e] = a[e] * gather_load<GF>(x + c[e]);
+    for (int e = 0; e < EPL; ++e) {
+      if (ABL >= 1) p[e] = a[e] * (double)(c[e] & 1);  // ablation: no x gather (timing only, wrong result)
+      else p[e] = a[e] * gather_load<GF>(x + c[e]);
+    }
+    if (ABL == 2) {  // ablation: no LDS staging / fold either
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc += p[e];
+      continue;
+    }
 
     // ---- one long row covers the whole chunk: wavefront-wide reduction
     const bool covers = (my_s <= b0) && (my_e >= b0 + CH);
@@ -232,17 +240,17 @@ int launch_spmm_impl(const Matrix *m, const double *d_B, double *d_C, int k, int
   return SPL_OK;
 }
 
-template <int EPL, int VW, bool NT, int GF = 0>
+template <int EPL, int VW, bool NT, int GF = 0, int ABL = 0>
 int launch_stream(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s) {
   const int64_t nblocks = (m->nrows_local + kRowsPerBlock - 1) / kRowsPerBlock;
   const int64_t grid = ((nblocks + 7) / 8) * 8;
   if (grid > 0x7fffffffLL) return SPL_ERROR_internal;
   if (m->rowptr.get()) {
-    hipLaunchKernelGGL((spmv_stream<EPL, VW, NT, int, GF>), dim3((unsigned)grid), dim3(kWavesPerBlock * 64),
+    hipLaunchKernelGGL((spmv_stream<EPL, VW, NT, int, GF, ABL>), dim3((unsigned)grid), dim3(kWavesPerBlock * 64),
                        0, s, m->nrows_local, nblocks, m->rowptr.get(), m->colidx.get(), m->val.get(),
                        d_x, d_y, accumulate);
   } else {
-    hipLaunchKernelGGL((spmv_stream<EPL, VW, NT, int64_t, GF>), dim3((unsigned)grid),
+    hipLaunchKernelGGL((spmv_stream<EPL, VW, NT, int64_t, GF, ABL>), dim3((unsigned)grid),
                        dim3(kWavesPerBlock * 64), 0, s, m->nrows_local, nblocks, m->rowptr64.get(),
                        m->colidx.get(), m->val.get(), d_x, d_y, accumulate);
   }
@@ -258,6 +266,10 @@ int launch_spmm(const Matrix *m, const double *d_B, double *d_C, int k, int accu
 int launch_spmv(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s) {
   if (m->nrows_local == 0) return SPL_OK;
   int st = SPL_OK;
+  if (m->variant == 15 || (m->variant == 0 && m->sell)) {
+    if (!m->sell) return SPL_ERROR_argument_missing;
+    return launch_spmv_sell(m, d_x, d_y, accumulate, s);
+  }
   if (m->variant == 8 || (m->variant == 0 && m->blocked)) {
     if (!m->blocked) return SPL_ERROR_argument_missing;
     return launch_spmv_blocked(m, d_x, d_y, accumulate, m->blocked_unroll, s);
@@ -273,6 +285,9 @@ int launch_spmv(const Matrix *m, const double *d_x, double *d_y, int accumulate,
     case 9: st = launch_stream<8, 2, true, 1>(m, d_x, d_y, accumulate, s); break;
     case 10: st = launch_stream<8, 2, true, 2>(m, d_x, d_y, accumulate, s); break;
     case 11: st = launch_stream<8, 2, true, 3>(m, d_x, d_y, accumulate, s); break;
+    case 12: st = launch_stream<8, 2, true, 0, 1>(m, d_x, d_y, accumulate, s); break;  // timing ablations
+    case 13: st = launch_stream<8, 2, true, 0, 2>(m, d_x, d_y, accumulate, s); break;
+    case 14: st = launch_stream<16, 4, true, 0, 2>(m, d_x, d_y, accumulate, s); break;
     case 7: {
       if (!m->rowptr.get()) return SPL_ERROR_index_overflow;
       const int64_t threads = m->nrows_local * 16;

@@ -261,3 +261,50 @@ def test_fused_spmm_matches_per_column_axpy(gpu, pkg, O, k):
     torch.cuda.synchronize()
     ref = np.stack([O.axpy(A, B[:, j].copy(), C0[:, j].copy()) for j in range(k)], axis=1)
     assert np.array_equal(dC.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("kind,n", [("random", 100003), ("banded", 50021), ("poisson3d", 23), ("poisson2d", 300)])
+def test_sliced_ell_image_bitwise(gpu, pkg, O, kind, n):
+    """variant 15 (csrc/spmv_sell.hip): one lane per row, sequential fold -> bit-identical for every row"""
+    torch = gpu
+    H = pkg.DeviceMatrix.synthetic(kind, n, 20)
+    H.set_variant(15)
+    assert H.info()["blocked_rows"] == -64
+    N = H.info()["nrows_global"]
+    rp, ci, v = H.export_csr()
+    xh = O.gen_vector(N)
+    x = torch.from_numpy(xh).cuda()
+    y = torch.from_numpy(O.gen_vector(N, seed=5)).cuda()
+    yo = y.cpu().numpy().copy()
+    s = torch.cuda.current_stream().cuda_stream
+    H.spmv_dev(x.data_ptr(), y.data_ptr(), accumulate=True, stream=s)
+    torch.cuda.synchronize()
+    O.csr_gaxpy32(rp, ci, v, xh, yo)
+    assert np.array_equal(y.cpu().numpy(), yo)
+    H.spmv_dev(x.data_ptr(), y.data_ptr(), accumulate=False, stream=s)
+    torch.cuda.synchronize()
+    yo2 = np.zeros(N)
+    O.csr_gaxpy32(rp, ci, v, xh, yo2)
+    assert np.array_equal(y.cpu().numpy(), yo2)
+
+
+def test_sliced_ell_ragged_and_auto(gpu, pkg, O):
+    rng = np.random.default_rng(23)
+    n = 20000
+    lens = rng.integers(0, 9, size=n)
+    lens[100] = 700
+    lens[n - 1] = 0
+    rows = np.repeat(np.arange(n), lens)
+    cols = np.concatenate([np.sort(rng.choice(n, size=l, replace=False)) for l in lens])
+    A = O.compress(n, n, rows, cols, rng.normal(size=len(rows)))
+    x = rng.normal(size=n)
+    M = tuple_to_mat(pkg, A)
+    H = pkg.DeviceMatrix.from_csc(M)
+    H.set_variant(15)
+    assert np.array_equal(H.mulv(x), O.mulV(A, x))  # long row included: still sequential, still exact
+    # optimize() picks the sliced-ELL image for a large stencil matrix and keeps the bits
+    P = pkg.DeviceMatrix.synthetic("poisson3d", 40)
+    y0 = P.mulv(O.gen_vector(64000))
+    P.optimize()
+    assert P.info()["blocked_rows"] == -64
+    assert np.array_equal(P.mulv(O.gen_vector(64000)), y0)
