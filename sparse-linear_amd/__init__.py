@@ -8,6 +8,7 @@ Layout:
   foreign.py mirror of Data.Matrix.Sparse.Foreign
   umfpack.py mirror of Numeric.LinearAlgebra.Umfpack
   dist.py    1-D row-block multi-GPU SpMV (torch.distributed, RCCL all-gather of y)
+  feast.py   FEAST-style caller of the hot path (reference: feast/src/Numeric/LinearAlgebra/Feast.hs)
 
 The directory name is not a Python identifier; ``__graft_entry__.load_package()``
 registers it as the module ``sparse_linear_amd``.
@@ -19,3 +20,4 @@ from .sparse import DeviceMatrix, Matrix, SparseError  # noqa: F401
 from .foreign import fromForeign, withConstMatrix  # noqa: F401
 from . import dist  # noqa: F401
 from . import umfpack  # noqa: F401
+from . import feast  # noqa: F401

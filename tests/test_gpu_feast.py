@@ -1,0 +1,51 @@
+"""feast/tests/test-feast.hs:23-32 — the reference's end-to-end known-answer test through
+FEAST -> UMFPACK -> axpy_: eigenvalues of [[2,-1],[-1,2]] on (0,4) are [1,3], closeness
+`x == y || |x-y|/|x+y| < 1e-10` (test-feast.hs:14-19).  Here the contour driver is
+sparse-linear_amd/feast.py and every sparse operation (complex sparse add, numeric LU per contour
+point with ONE symbolic analysis, solves, SpMV) runs on the GPU through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def close_enough(a, b, tol=1e-10):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return a.shape == b.shape and bool(np.all((a == b) | (np.abs(a - b) / np.abs(a + b) < tol)))
+
+
+def test_feast_reference_fixture(gpu, pkg):
+    m = pkg.fromTriples(2, 2, [(0, 0, 2 + 0j), (0, 1, -1 + 0j), (1, 0, -1 + 0j), (1, 1, 2 + 0j)])
+    eigenvalues, vectors = pkg.feast.eigSHParams(pkg.feast.FeastParams(feastDebug=False), 2, (0.0, 4.0), m)
+    assert len(eigenvalues) == 2                       # "gives the correct number of eigenvalues"
+    assert close_enough(eigenvalues, [1.0, 3.0])       # "gives the correct eigenvalues"
+    D = pkg.pack(m)
+    for lam, v in zip(eigenvalues, vectors.T):
+        assert np.max(np.abs(D @ v - lam * v)) < 1e-9
+
+
+def test_feast_poisson_interior_window(gpu, pkg, O):
+    """1-D Laplacian, n = 60: eigenvalues 2 - 2cos(k pi/(n+1)) known in closed form; pick a window with 4"""
+    n = 60
+    tri = []
+    for c in range(n):
+        for r_, x in ((c - 1, -1.0), (c, 2.0), (c + 1, -1.0)):
+            if 0 <= r_ < n:
+                tri.append((r_, c, x))
+    A = pkg.fromTriples(n, n, tri)
+    exact = 2 - 2 * np.cos(np.arange(1, n + 1) * np.pi / (n + 1))
+    lo, hi = 0.5 * (exact[9] + exact[10]), 0.5 * (exact[13] + exact[14])
+    lam, X = pkg.feast.eigSH(8, (lo, hi), A)
+    assert close_enough(np.sort(lam), exact[10:14], 1e-9)
+
+
+def test_feast_generalized(gpu, pkg):
+    rng = np.random.default_rng(4)
+    n = 40
+    d = np.arange(1.0, n + 1)
+    A = pkg.diag(d) + pkg.fromTriples(n, n, [(i, i + 1, 0.1) for i in range(n - 1)] + [(i + 1, i, 0.1) for i in range(n - 1)])
+    B = pkg.diag(np.full(n, 2.0))
+    lam, X = pkg.feast.geigSH(6, (2.2, 4.3), A, B)
+    ref = np.linalg.eigvalsh(pkg.pack(A)) / 2.0
+    inside = ref[(ref > 2.2) & (ref < 4.3)]
+    assert close_enough(np.sort(lam), inside, 1e-9)
