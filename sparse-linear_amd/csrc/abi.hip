@@ -494,11 +494,12 @@ int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unr
     DeviceGuard g(m->device);
     build_blocked_image(m, rows_per_panel, cols_log2, nullptr);
     if (unroll == 0) {
-      // register pipeline depth: the smallest of {4,8,10,12} chunks that covers 1.25x the mean
-      // segment (a deeper pipeline only streams entries of the next segment it cannot use yet)
+      // register pipeline depth: the smallest of {4,8,10,12} chunks that covers the mean segment
+      // (longer segments take the un-pipelined tail loop; a deeper pipeline only streams entries
+      // of the next segment it cannot use yet — measured at C2: 10 chunks 1.19 ms, 12 chunks 1.22 ms)
       const double seg = (double)m->nnz / (double)(m->blocked->npanels * m->blocked->ncb > 0
                                                        ? m->blocked->npanels * m->blocked->ncb : 1);
-      const double want = 1.25 * seg / 64.0;
+      const double want = seg / 64.0;
       unroll = want <= 4 ? 4 : want <= 8 ? 8 : want <= 10 ? 10 : 12;
     }
     m->blocked_unroll = unroll;
