@@ -158,8 +158,11 @@ int spl_matrix_spmv_dev(void *H, const double *d_x, double *d_y, int accumulate,
 /* Device-resident sparse x dense (mulM): d_B is ncols x k, d_C is nrows_local x k, both
  * row-major DEVICE arrays; A is read once for all k columns.  accumulate != 0: C <- A B + C. */
 int spl_matrix_spmm_dev(void *H, const double *d_B, double *d_C, int k, int accumulate, void *stream);
-/* select a kernel variant for spl_matrix_spmv_dev (tuning / ablation only):
- * 0 = default.  Returns SPL_ERROR_argument_missing for an unknown variant. */
+/* select a kernel variant for spl_matrix_spmv_dev (tuning / ablation only): 0 = default
+ * (whatever spl_matrix_optimize chose), 1-6 CSR-stream shapes, 7 sub-wavefront kernel, 8
+ * column-blocked image, 9-11 gather cache policies, 15 sliced-ELL image; 12-14 are timing-only
+ * ablations that do not compute A x and are refused unless SPL_ALLOW_ABLATION=1.
+ * Returns SPL_ERROR_argument_missing for an unknown or refused variant. */
 int spl_matrix_set_variant(void *H, int variant);
 
 /* Analyse the matrix once (like umfpack_*_symbolic) and build the image variant 0 then uses:

@@ -456,6 +456,12 @@ int spl_matrix_set_variant(void *H, int variant) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;
   if (variant < 0 || variant >= kNumSpmvVariants) return SPL_ERROR_argument_missing;
+  if (variant >= 12 && variant <= 14) {
+    // timing-only ablations of the CSR-stream kernel (they do NOT compute A x): refuse them unless
+    // a profiling session asks explicitly
+    const char *ok = getenv("SPL_ALLOW_ABLATION");
+    if (!(ok && ok[0] == '1')) return SPL_ERROR_argument_missing;
+  }
   if (variant == 8 && !m->blocked) {
     int st = spl_matrix_build_blocked(H, 0, 0, 0);
     if (st != SPL_OK) return st;

@@ -308,3 +308,35 @@ def test_sliced_ell_ragged_and_auto(gpu, pkg, O):
     P.optimize()
     assert P.info()["blocked_rows"] == -64
     assert np.array_equal(P.mulv(O.gen_vector(64000)), y0)
+
+
+def test_abi_is_reentrant_across_threads(gpu, pkg, O):
+    """the reference makes `safe` foreign calls that may arrive concurrently from several OS
+    threads: same handle from 4 threads, and per-thread handles, all at once"""
+    import threading
+    rng = np.random.default_rng(31)
+    n = 20000
+    A = O.compress(n, n, rng.integers(0, n, 200000), rng.integers(0, n, 200000), rng.normal(size=200000))
+    M = tuple_to_mat(pkg, A)
+    shared = M.device_handle()
+    xs = [rng.normal(size=n) for _ in range(4)]
+    refs = [O.mulV(A, x) for x in xs]
+    out, errs = [None] * 4, []
+
+    def work(t):
+        try:
+            own = pkg.DeviceMatrix.from_csc(M)          # concurrent create / transpose on the device
+            for _ in range(5):
+                y1 = shared.mulv(xs[t])                 # concurrent SpMV on one handle
+                y2 = own.mulv(xs[t])
+                T = pkg.transpose(M)                    # concurrent one-shot calls
+                assert np.array_equal(y1, refs[t]) and np.array_equal(y2, refs[t])
+                assert T.nrows == n
+            out[t] = True
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs and all(out)
