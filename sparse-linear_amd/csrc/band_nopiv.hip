@@ -7,17 +7,15 @@
 // M-matrix of the C5 ladder is of this kind; anything else takes the pivoting path in
 // umfpack.hip.  (UMFPACK's own "symmetric strategy" prefers the diagonal for such matrices.)
 //
-// Storage: AB[(ku + i - j) + j*ldab], ldab = kl + ku + 1, i.e. A(i,j) = AB[ku + i + j*(ldab-1)]:
+// Storage: AB[(ku + i - j) + j*ldab], ldab >= kl + ku + 1 (band_nopiv_ldab pads it), i.e. A(i,j) = AB[ku + i + j*(ldab-1)]:
 // any sub-block inside the band is a dense column-major matrix with leading dimension ldab-1.
-// Right-looking, block size NB = 32:
-//   diag   : LU of the NB x NB diagonal block in LDS (one workgroup)
-//   trsm_L : L21 = A21 U11^-1      one thread per row   (rows below the block, <= kl+NB-1 of them)
-//   trsm_U : U12 = L11^-1 A12      one thread per column
+// Right-looking, block size NB = 64:
+//   diag   : LU of the NB x NB diagonal block in LDS (one workgroup) + explicit inverses of its factors
+//   trsm   : L21 = A21 inv(U11), U12 = inv(L11) A12 as 64x64x64 products on the matrix cores
 //   gemm   : A22 -= L21 U12        64x64 tiles, K = NB, operands staged in LDS; entries outside
 //            the band are read as zero and never written
-// fp64 dense-kernel work: this GEMM is the one contraction-shaped step of the whole backend
-// (it is outside the headline metric); it uses plain fp64 FMAs here, an MFMA-f64 tile is the
-// obvious follow-up.  The solves are blocked the same way (diagonal block in LDS, then one
+// fp64 dense-kernel work: this GEMM is the one contraction-shaped step of the whole backend (it
+// is outside the headline metric) and runs on the fp64 matrix cores (v_mfma_f64_16x16x4).  The solves are blocked the same way (diagonal block in LDS, then one
 // thread per affected row / one workgroup per affected column for the transposed forms).
 #include <algorithm>
 
@@ -31,7 +29,7 @@ namespace spl {
 
 namespace {
 
-constexpr int NB = 32;
+constexpr int NB = 64;   // panel width
 
 struct Band {
   double *AB;
@@ -76,206 +74,377 @@ __global__ __launch_bounds__(256) void band2_scatter_kernel(int n, const int *__
 }
 
 // ---- factorisation ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void diag_lu_kernel(Band b, int j0, int jb, int *__restrict__ singular) {
-  __shared__ double D[NB][NB + 1];
+typedef double double4v __attribute__((ext_vector_type(4)));
+constexpr int LDP = NB + 1;                                  // padded leading dimension in LDS
+constexpr size_t kTileBytes = (size_t)NB * LDP * sizeof(double);
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// LU of the diagonal block held in LDS tile D (identity-padded beyond jb), then the explicit
+// inverses of its two triangular factors: the triangular solves of the panel then become small
+// GEMMs on the matrix cores, and a block of the triangular solve a matrix-vector product.
+// Diagonally dominant blocks are well conditioned, so explicit inverses are safe here.
+//
+// This chain of 64 dependent pivots sits on the critical path of every block step, so it is kept
+// in registers: 256 threads, lane = row, wave w owns the columns c = w mod 4 (16 per thread, all
+// indices static after unrolling).  Row k of a rank-1 update comes from lane k of the same wave
+// (v_readlane); only the multiplier column crosses waves, through LDS, one barrier per pivot.
+// The two inverses are built the same way (right-looking substitution on an identity), U^-1 with
+// k descending and L^-1 with k ascending in the same loop.
+// Results: LU'd block to band storage and tile D, inverses (NB x NB column-major) to invL / invU.
+__device__ __forceinline__ void diag_block_factor(const Band &b, int j0, int jb, double (*D)[LDP],
+                                                  double (*lcol)[NB], int *__restrict__ singular,
+                                                  double *__restrict__ invL, double *__restrict__ invU) {
   const int tid = threadIdx.x;
-  for (int t = tid; t < NB * NB; t += 256) {
-    const int r = t % NB, c = t / NB;
-    D[r][c] = (r < jb && c < jb) ? b.get(j0 + r, j0 + c) : (r == c ? 1.0 : 0.0);
+  const int tr = tid & 63, tc = tid >> 6;
+  double a[NB / 4];
+#pragma unroll
+  for (int u = 0; u < NB / 4; ++u) a[u] = D[tr][4 * u + tc];
+  // the pivot loops stay rolled (straight-line code of this size would run at instruction-fetch
+  // speed); register slots are indexed statically and selected with compares instead
+#pragma unroll 1
+  for (int k = 0; k < NB; ++k) {
+    const int ks = k >> 2, kw = k & 3;  // slot and owning wave of column k
+    if (tc == kw) {
+      double ak = 0.0;
+#pragma unroll
+      for (int u = 0; u < NB / 4; ++u) ak = (u == ks) ? a[u] : ak;
+      const double piv = readlane_f64(ak, k);
+      if (piv == 0.0) {
+        if (tr == 0) atomicOr(singular, 1);
+      } else if (tr > k) {
+        ak = ak / piv;
+      }
+#pragma unroll
+      for (int u = 0; u < NB / 4; ++u) a[u] = (u == ks) ? ak : a[u];
+      lcol[k & 1][tr] = ak;
+    }
+    __syncthreads();
+    const double l = tr > k ? lcol[k & 1][tr] : 0.0;
+#pragma unroll
+    for (int u = 0; u < NB / 4; ++u) {
+      const double pk = readlane_f64(a[u], k);
+      if (4 * u + tc > k) a[u] -= l * pk;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NB / 4; ++u) {
+    const int c = 4 * u + tc;
+    D[tr][c] = a[u];
+    if (tr < jb && c < jb && b.in_band(j0 + tr, j0 + c)) b.at(j0 + tr, j0 + c) = a[u];
   }
   __syncthreads();
-  for (int k = 0; k < jb; ++k) {
-    const double piv = D[k][k];
-    if (piv == 0.0) {
-      if (tid == 0) atomicOr(singular, 1);
-    } else {
-      if (tid > k && tid < jb) D[tid][k] = D[tid][k] / piv;
+  double x[NB / 4], y[NB / 4];
+#pragma unroll
+  for (int u = 0; u < NB / 4; ++u) x[u] = y[u] = (tr == 4 * u + tc) ? 1.0 : 0.0;
+#pragma unroll 1
+  for (int s = 0; s < NB; ++s) {
+    {  // U^-1: row k final after scaling by 1/U(k,k); rows above lose U(i,k) * row k
+      const int k = NB - 1 - s;
+      const double d = D[k][k];
+      const double dinv = d != 0.0 ? 1.0 / d : 0.0;
+      const double uik = tr < k ? D[tr][k] : 0.0;
+#pragma unroll
+      for (int u = 0; u < NB / 4; ++u) {  // X(k, c) is zero for c < k
+        const double xk = readlane_f64(x[u], k) * dinv;
+        x[u] = (tr == k) ? xk : x[u] - uik * xk;
+      }
     }
-    __syncthreads();
-    const int m = jb - k - 1;
-    for (int t = tid; t < m * m; t += 256) {
-      const int r = k + 1 + t % m, c = k + 1 + t / m;
-      D[r][c] -= D[r][k] * D[k][c];
+    {  // L^-1 (unit diagonal): rows below lose L(i,k) * row k
+      const int k = s;
+      const double lik = tr > k ? D[tr][k] : 0.0;
+#pragma unroll
+      for (int u = 0; u < NB / 4; ++u) y[u] -= lik * readlane_f64(y[u], k);  // Y(k, c) is zero for c > k
     }
-    __syncthreads();
   }
-  for (int t = tid; t < jb * jb; t += 256) {
-    const int r = t % jb, c = t / jb;
-    if (b.in_band(j0 + r, j0 + c)) b.at(j0 + r, j0 + c) = D[r][c];
+#pragma unroll
+  for (int u = 0; u < NB / 4; ++u) {
+    const int c = 4 * u + tc;
+    invU[tr + c * NB] = x[u];
+    invL[tr + c * NB] = y[u];
   }
 }
 
-// L21 = A21 * U11^-1 (thread per row) and U12 = L11^-1 * A12 (thread per column) in one launch
-__global__ __launch_bounds__(256) void trsm_kernel(Band b, int j0, int jb, int nrows_below, int ncols_right) {
-  __shared__ double D[NB][NB + 1];
-  const int tid = threadIdx.x;
-  for (int t = tid; t < NB * NB; t += 256) {
-    const int r = t % NB, c = t / NB;
-    D[r][c] = (r < jb && c < jb) ? b.get(j0 + r, j0 + c) : (r == c ? 1.0 : 0.0);
-  }
+__global__ __launch_bounds__(256) void diag_lu_kernel(Band b, int j0, int jb, int *__restrict__ singular,
+                                                      double *__restrict__ invL, double *__restrict__ invU) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double(*D)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);
+  double(*lcol)[NB] = reinterpret_cast<double(*)[NB]>(dsm + NB * LDP);
+  const int tr = threadIdx.x & 63, tc = threadIdx.x >> 6;
+  for (int c = tc; c < NB; c += 4)
+    D[tr][c] = (tr < jb && c < jb) ? b.get(j0 + tr, j0 + c) : (tr == c ? 1.0 : 0.0);
   __syncthreads();
-  const int g = blockIdx.x * 256 + tid;
-  if (g < nrows_below) {
-    const int i = j0 + jb + g;
-    double x[NB];
+  diag_block_factor(b, j0, jb, D, lcol, singular, invL, invU);
+}
+
+// 64 x 64 x 64 product of two LDS tiles on the fp64 matrix cores:
+//     acc[a][c][r] = sum_k Cs[k][qc + a*16 + lane/16 + 4r] * Rs[k][qr + c*16 + lane%16]
+// Cs[k][.] is indexed by the output COLUMN, Rs[k][.] by the output ROW, so a lane's 16 neighbours
+// hold 16 consecutive rows of one column: 128 contiguous bytes of band storage per access.  Each
+// of the 4 wavefronts owns a 32 x 32 quadrant = 2 x 2 MFMA tiles.  v_mfma_f64_16x16x4_f64 layout
+// probed on gfx950 (tools/probe/mfma_f64_probe.hip): lane l supplies A[l%16][l/16] and
+// B[l/16][l%16] and holds C[(l/16) + 4*r][l%16] in element r.
+struct TilePos {
+  int qr, qc, li, lk;
+  __device__ TilePos() {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    qr = (wave & 1) * 32, qc = (wave >> 1) * 32, li = lane & 15, lk = lane >> 4;
+  }
+  __device__ int row(int c) const { return qr + c * 16 + li; }
+  __device__ int col(int a, int r) const { return qc + a * 16 + lk + 4 * r; }
+};
+
+__device__ __forceinline__ void mfma_tile_64(const double (*Cs)[LDP], const double (*Rs)[LDP], const TilePos &p,
+                                             double4v (&acc)[2][2]) {
 #pragma unroll
-    for (int t = 0; t < NB; ++t) x[t] = (t < jb) ? b.get(i, j0 + t) : 0.0;
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int t = 0; t < NB; ++t) {
-      double acc = x[t];
+    for (int c = 0; c < 2; ++c) acc[a][c] = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int k0 = 0; k0 < NB; k0 += 4) {
+    double af[2], bf[2];
 #pragma unroll
-      for (int s = 0; s < NB; ++s)
-        if (s < t) acc -= x[s] * D[s][t];
-      x[t] = acc / D[t][t];
-    }
+    for (int a = 0; a < 2; ++a) af[a] = Cs[k0 + p.lk][p.qc + a * 16 + p.li];
 #pragma unroll
-    for (int t = 0; t < NB; ++t)
-      if (t < jb && b.in_band(i, j0 + t)) b.at(i, j0 + t) = x[t];
-  } else if (g - nrows_below < ncols_right) {
-    const int j = j0 + jb + (g - nrows_below);
-    double u[NB];
+    for (int c = 0; c < 2; ++c) bf[c] = Rs[k0 + p.lk][p.qr + c * 16 + p.li];
 #pragma unroll
-    for (int t = 0; t < NB; ++t) u[t] = (t < jb) ? b.get(j0 + t, j) : 0.0;
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int t = 0; t < NB; ++t) {
-      double acc = u[t];
-#pragma unroll
-      for (int s = 0; s < NB; ++s)
-        if (s < t) acc -= D[t][s] * u[s];
-      u[t] = acc;  // unit lower triangular
-    }
-#pragma unroll
-    for (int t = 0; t < NB; ++t)
-      if (t < jb && b.in_band(j0 + t, j)) b.at(j0 + t, j) = u[t];
+      for (int c = 0; c < 2; ++c)
+        acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[c], acc[a][c], 0, 0, 0);
   }
 }
 
-// A22 -= L21 * U12 on 64x64 tiles (4x4 outputs per thread), K = jb <= NB
-__global__ __launch_bounds__(256) void gemm_update_kernel(Band b, int j0, int jb, int nrows_below,
-                                                          int ncols_right) {
+// panel solves as GEMMs: tiles [0, ntile_l): L21 tile (64 rows) <- A21 tile * invU;
+// tiles [ntile_l, ...): U12 tile (64 columns) <- invL * A12 tile.  In place.
+__global__ __launch_bounds__(256) void trsm_gemm_kernel(Band b, int j0, int jb, int nrows_below, int ncols_right,
+                                                        const double *__restrict__ invL,
+                                                        const double *__restrict__ invU) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double(*Cs)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);            // [k][output column]
+  double(*Rs)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + NB * LDP);  // [k][output row]
+  const int tid = threadIdx.x;
+  const int ntile_l = (nrows_below + 63) / 64;
+  const bool is_l = (int)blockIdx.x < ntile_l;
+  const int rend = j0 + jb + nrows_below, cend = j0 + jb + ncols_right;
+  int r0, c0;
+  if (is_l) {
+    r0 = j0 + jb + blockIdx.x * 64, c0 = j0;
+    for (int t = tid; t < NB * 64; t += 256) {  // Rs[k][r] = A21(r0 + r, j0 + k)
+      const int r = t % 64, k = t / 64;
+      Rs[k][r] = (k < jb && r0 + r < rend) ? b.get(r0 + r, j0 + k) : 0.0;
+    }
+    for (int t = tid; t < NB * NB; t += 256) Cs[t % NB][t / NB] = invU[t];  // Cs[k][c] = invU(k, c)
+  } else {
+    r0 = j0, c0 = j0 + jb + ((int)blockIdx.x - ntile_l) * 64;
+    for (int t = tid; t < NB * NB; t += 256) Rs[t / NB][t % NB] = invL[t];  // Rs[k][r] = invL(r, k)
+    for (int t = tid; t < NB * 64; t += 256) {  // Cs[k][c] = A12(j0 + k, c0 + c)
+      const int k = t % NB, c = t / NB;
+      Cs[k][c] = (k < jb && c0 + c < cend) ? b.get(j0 + k, c0 + c) : 0.0;
+    }
+  }
+  __syncthreads();
+  const TilePos p;
+  double4v acc[2][2];
+  mfma_tile_64(Cs, Rs, p, acc);
+  const int rlim = is_l ? rend : j0 + jb, clim = is_l ? j0 + jb : cend;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = r0 + p.row(c), j = c0 + p.col(a, r);
+        if (i < rlim && j < clim && b.in_band(i, j)) b.at(i, j) = acc[a][c][r];
+      }
+}
+
+// A22 -= L21 * U12 on 64x64 tiles, K = jb <= NB, same MFMA tile; entries outside the band read as
+// zero and are never written.
+// Look-ahead: the workgroup of tile (0,0) -- the next diagonal block -- goes on to factor and
+// invert it while the other tiles are still being updated, which takes the diagonal-block chain
+// off the critical path.
+__global__ __launch_bounds__(256) void gemm_update_kernel(Band b, int j0, int jb, int nrows_below, int ncols_right,
+                                                          int *__restrict__ singular,
+                                                          double *__restrict__ next_invL,
+                                                          double *__restrict__ next_invU) {
   const int r0 = j0 + jb + blockIdx.x * 64, c0 = j0 + jb + blockIdx.y * 64;
-  // the whole tile lies outside the band: nothing to do
-  if (r0 - (c0 + 63) > b.kl || c0 - (r0 + 63) > b.ku) return;
-  __shared__ double Ls[NB][64 + 1];  // Ls[t][r] = L(r0 + r, j0 + t)
-  __shared__ double Us[NB][64 + 1];  // Us[t][c] = U(j0 + t, c0 + c)
+  if (r0 - (c0 + 63) > b.kl || c0 - (r0 + 63) > b.ku) return;  // tile entirely outside the band
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double(*Us)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);            // Us[k][c] = U(j0 + k, c0 + c)
+  double(*Ls)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + NB * LDP);  // Ls[k][r] = L(r0 + r, j0 + k)
   const int tid = threadIdx.x;
   const int rend = j0 + jb + nrows_below, cend = j0 + jb + ncols_right;
+  // the tile of A22 is requested first, so that its HBM latency overlaps the staging and the MFMAs
+  // (entries outside this step's update range get a zero product; tile (0,0) needs them below)
+  const TilePos p;
+  double cold[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = r0 + p.row(c), j = c0 + p.col(a, r);
+        cold[a][c][r] = (i < b.n && j < b.n && b.in_band(i, j)) ? b.at(i, j) : 0.0;  // also beyond rend/cend
+      }
   for (int t = tid; t < NB * 64; t += 256) {
     const int r = t % 64, k = t / 64;
-    const int i = r0 + r;
-    Ls[k][r] = (k < jb && i < rend) ? b.get(i, j0 + k) : 0.0;
+    Ls[k][r] = (k < jb && r0 + r < rend) ? b.get(r0 + r, j0 + k) : 0.0;
   }
   for (int t = tid; t < NB * 64; t += 256) {
     const int k = t % NB, c = t / NB;
-    const int j = c0 + c;
-    Us[k][c] = (k < jb && j < cend) ? b.get(j0 + k, j) : 0.0;
+    Us[k][c] = (k < jb && c0 + c < cend) ? b.get(j0 + k, c0 + c) : 0.0;
   }
   __syncthreads();
-  const int tr = (tid % 16) * 4, tc = (tid / 16) * 4;
-  double acc[4][4] = {};
-#pragma unroll 8
-  for (int k = 0; k < NB; ++k) {
-    double l[4], u[4];
+  double4v acc[2][2];
+  mfma_tile_64(Us, Ls, p, acc);
 #pragma unroll
-    for (int a = 0; a < 4; ++a) { l[a] = Ls[k][tr + a]; u[a] = Us[k][tc + a]; }
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][c] += l[a] * u[c];
-  }
+      for (int r = 0; r < 4; ++r) {
+        const int i = r0 + p.row(c), j = c0 + p.col(a, r);
+        cold[a][c][r] -= acc[a][c][r];
+        if (i < rend && j < cend && b.in_band(i, j)) b.at(i, j) = cold[a][c][r];
+      }
+  if (blockIdx.x != 0 || blockIdx.y != 0) return;
+  // next diagonal block: rows/columns r0 .. r0 + jbn - 1, values still in registers
+  const int jbn = min(NB, b.n - r0);
+  __syncthreads();  // all waves are done reading Us / Ls
+  double(*D)[LDP] = Us;
+  double(*lcol)[NB] = reinterpret_cast<double(*)[NB]>(&Ls[0][0]);
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int i = r0 + tr + a, j = c0 + tc + c;
-      if (i < rend && j < cend && b.in_band(i, j)) b.at(i, j) -= acc[a][c];
-    }
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tr = p.row(c), tcn = p.col(a, r);
+        D[tr][tcn] = (tr < jbn && tcn < jbn) ? cold[a][c][r] : (tr == tcn ? 1.0 : 0.0);
+      }
+  __syncthreads();
+  diag_block_factor(b, r0, jbn, D, lcol, singular, next_invL, next_invU);
 }
 
 // ---- blocked solves -----------------------------------------------------------------------------
-// mode 0: L (unit lower) forward, 1: U backward, 2: U^T forward, 3: L^T (unit) backward.
-// One workgroup: fold in the contributions of already-solved entries for modes 2/3 ("left-
-// looking" dots, coalesced down a column), solve the diagonal block in LDS, write the block.
-__global__ __launch_bounds__(256) void solve_diag_kernel(Band b, int mode, int j0, int jb, double *c) {
-  __shared__ double D[NB][NB + 1];
-  __shared__ double v[NB];
-  const int tid = threadIdx.x;
-  for (int t = tid; t < NB * NB; t += 256) {
-    const int r = t % NB, cc = t / NB;
-    D[r][cc] = (r < jb && cc < jb) ? b.get(j0 + r, j0 + cc) : (r == cc ? 1.0 : 0.0);
-  }
-  if (tid < NB) v[tid] = tid < jb ? c[j0 + tid] : 0.0;
-  __syncthreads();
-  if (mode == 2 || mode == 3) {
-    // v[t] -= sum_i M(i, j0+t) * c[i] over the solved entries i adjacent to the block:
-    // 8 threads per block column t, consecutive threads on consecutive i (contiguous down a column)
-    const int t = tid >> 3, part = tid & 7;
-    double s = 0.0;
-    if (t < jb) {
-      const int j = j0 + t;
-      if (mode == 2) {
-        const int lo = max(0, j - b.ku);
-        for (int i = lo + part; i < j0; i += 8) s += b.at(i, j) * c[i];  // U(i,j), i < j0
-      } else {
-        const int hi = min(b.n - 1, j + b.kl);
-        for (int i = j0 + jb + part; i <= hi; i += 8) s += b.at(i, j) * c[i];  // L(i,j) beyond the block
+// The factorisation keeps inv(L11) and inv(U11) of every diagonal block, so a block of the
+// triangular solve is a 64 x 64 matrix-vector product instead of a 64-step substitution chain.
+// One launch eliminates a super block of SB = 4 blocks (256 unknowns).  `in` holds the right-hand
+// side entries not yet eliminated, `out` receives the solved super block; they are different
+// arrays, so every workgroup redoes the small in-super-block solve from the same read-only inputs
+// and then updates its own 64 rows of `in` outside the super block.
+//   MODE 0: L z = c (unit lower, forward)     1: U x = z (backward)
+//   MODE 2: U^T z = c (lower, forward)        3: L^T x = z (unit upper, backward)
+constexpr int SB = 4;
+
+// res[l] = sum_{t < nc} M(rb + l, cb + t) * vv[t], l < 64; M = matrix of the triangular system.
+// Untransposed (MODE 0/1) band storage runs down the rows: lane = row, wave q takes t = q mod 4,
+// partial sums meet in LDS.  Transposed (MODE 2/3) it runs along t: lanes along t, wave q takes
+// rows l = q mod 4, butterfly reduction.  Ends with the result visible to the whole workgroup.
+template <int MODE>
+__device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, const double *vv, double *res,
+                                       double (*part)[64]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (MODE <= 1) {
+    const int i = rb + lane;
+    double s0 = 0.0, s1 = 0.0;
+    if (i >= 0 && i < b.n) {
+      int t = wave;
+      for (; t + 28 < nc; t += 32) {  // 8 independent loads in flight per lane
+        double e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = b.get(i, cb + t + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+          s0 += e[u] * vv[t + 4 * u];
+          s1 += e[u + 1] * vv[t + 4 * u + 4];
+        }
       }
+      for (; t < nc; t += 4) s0 += b.get(i, cb + t) * vv[t];
     }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if (part == 0 && t < jb) v[t] -= s;
+    part[wave][lane] = s0 + s1;
     __syncthreads();
-  }
-  if (tid < 64) {  // NB x NB triangular solve by one wavefront: lane l owns v[l], columns broadcast by shuffle
-    const int l = tid;
-    double x = l < NB ? v[l] : 0.0;
-    if (mode == 0) {  // L unit lower, forward
-      for (int t = 0; t < jb; ++t) {
-        const double xt = __shfl(x, t, 64);
-        if (l > t && l < jb) x -= D[l][t] * xt;
-      }
-    } else if (mode == 1) {  // U, backward
-      for (int t = jb - 1; t >= 0; --t) {
-        if (l == t) x = x / D[t][t];
-        const double xt = __shfl(x, t, 64);
-        if (l < t) x -= D[l][t] * xt;
-      }
-    } else if (mode == 2) {  // U^T lower, forward
-      for (int t = 0; t < jb; ++t) {
-        if (l == t) x = x / D[t][t];
-        const double xt = __shfl(x, t, 64);
-        if (l > t && l < jb) x -= D[t][l] * xt;
-      }
-    } else {  // L^T unit upper, backward
-      for (int t = jb - 1; t >= 0; --t) {
-        const double xt = __shfl(x, t, 64);
-        if (l < t) x -= D[t][l] * xt;
-      }
+    if (threadIdx.x < 64) res[lane] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  } else {
+    for (int l = wave; l < 64; l += 4) {
+      const int i = rb + l;
+      double sacc = 0.0;
+      if (i >= 0 && i < b.n)
+        for (int t = lane; t < nc; t += 64) sacc += b.get(cb + t, i) * vv[t];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
+      if (lane == 0) res[l] = sacc;
     }
-    if (l < jb) c[j0 + l] = x;
   }
+  __syncthreads();
 }
 
-// right-looking update after a diagonal solve (modes 0 and 1): one thread per affected row
-__global__ __launch_bounds__(256) void solve_update_kernel(Band b, int mode, int j0, int jb, double *c) {
-  __shared__ double v[NB];
-  if (threadIdx.x < NB) v[threadIdx.x] = threadIdx.x < jb ? c[j0 + threadIdx.x] : 0.0;
-  __syncthreads();
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  int i;
-  if (mode == 0) {
-    i = j0 + jb + g;
-    if (i >= b.n || i > j0 + jb - 1 + b.kl) return;
-  } else {
-    i = j0 - 1 - g;
-    if (i < 0 || i < j0 - b.ku) return;
-  }
-  double s = 0.0;
+// res[l] = sum_t T(l, t) * w[t] with T = inv(L11), inv(U11), inv(U11)^T, inv(L11)^T (MODE 0..3);
+// inv is column-major NB x NB.
+template <int MODE>
+__device__ __forceinline__ void gemv_inv(const double *__restrict__ inv, const double *w, double *res,
+                                         double (*part)[64]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (MODE <= 1) {
+    double sacc = 0.0;
 #pragma unroll
-  for (int t = 0; t < NB; ++t)
-    if (t < jb) s += b.get(i, j0 + t) * v[t];
-  c[i] -= s;
+    for (int u = 0; u < NB / 4; ++u) {
+      const int t = wave + 4 * u;
+      sacc += inv[lane + t * NB] * w[t];
+    }
+    part[wave][lane] = sacc;
+    __syncthreads();
+    if (threadIdx.x < 64) res[lane] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  } else {
+    for (int l = wave; l < 64; l += 4) {
+      double sacc = inv[lane + l * NB] * w[lane];  // T(l, t) = inv(t, l)
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
+      if (lane == 0) res[l] = sacc;
+    }
+  }
+  __syncthreads();
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void solve_super_kernel(Band b, const double *__restrict__ invs, int j0, int jbs,
+                                                          double *in, double *__restrict__ out) {
+  __shared__ double v[SB * NB], w[NB], res[NB], part[4][64];
+  constexpr bool fwd = (MODE == 0 || MODE == 2);
+  const int tid = threadIdx.x;
+  const int nsub = (jbs + NB - 1) / NB;
+  for (int t = tid; t < SB * NB; t += 256) v[t] = 0.0;
+  __syncthreads();
+  for (int k = 0; k < nsub; ++k) {
+    const int sblk = fwd ? k : nsub - 1 - k;
+    const int js = j0 + sblk * NB, jb = min(NB, j0 + jbs - js);
+    // couplings with the sub-blocks of this super block that are already solved
+    const int cb = fwd ? j0 : js + jb;
+    const int nc = fwd ? js - j0 : j0 + jbs - (js + jb);
+    gemv64<MODE>(b, js, cb, nc, v + (cb - j0), res, part);
+    if (tid < NB) w[tid] = tid < jb ? in[js + tid] - res[tid] : 0.0;
+    __syncthreads();
+    const double *inv = invs + (size_t)(js / NB) * (2 * NB * NB) + ((MODE == 1 || MODE == 2) ? NB * NB : 0);
+    gemv_inv<MODE>(inv, w, res, part);
+    if (tid < jb) v[js - j0 + tid] = res[tid];
+    __syncthreads();
+  }
+  if (blockIdx.x == 0)
+    for (int t = tid; t < jbs; t += 256) out[j0 + t] = v[t];
+  // the 64 rows of this workgroup outside the super block
+  const int rb = fwd ? j0 + jbs + (int)blockIdx.x * 64 : j0 - ((int)blockIdx.x + 1) * 64;
+  gemv64<MODE>(b, rb, j0, jbs, v, res, part);
+  if (tid < 64) {
+    const int i = rb + tid;
+    const bool ok = fwd ? (i < b.n) : (i >= 0);
+    if (ok) in[i] -= res[tid];
+  }
 }
 
 }  // namespace
@@ -292,25 +461,44 @@ bool band_is_column_dominant(int n, const int *d_Ap, const int *d_Ai, const doub
   return h == 0;
 }
 
-// scatter P A P^T into AB (zeroed, ldab = kl+ku+1) and factor it in place; returns the singular flag
-int band_nopiv_factor(int n, int kl, int ku, double *d_AB, const int *d_Ap, const int *d_Ai,
-                      const double *d_Ax, const int *d_inv, hipStream_t s) {
-  Band b{d_AB, n, kl, ku, kl + ku + 1};
+// scatter P A P^T into AB (zeroed, ldab = band_nopiv_ldab(kl, ku)) and factor it in place; returns the singular flag
+size_t band_nopiv_inverse_elems(int n) { return (size_t)((n + NB - 1) / NB) * (2 * NB * NB); }
+
+int band_nopiv_factor(int n, int kl, int ku, int ldab, double *d_AB, double *d_invs, const int *d_Ap,
+                      const int *d_Ai, const double *d_Ax, const int *d_inv, hipStream_t s) {
+  Band b{d_AB, n, kl, ku, ldab};
+  static bool attr_set = false;
+  if (!attr_set) {
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_lu_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_gemm_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_update_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
+    attr_set = true;
+  }
   hipLaunchKernelGGL(band2_scatter_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, n, d_Ap, d_Ai, d_Ax,
                      d_inv, b);
   DBuf<int> singular(1);
   SPL_HIP(hipMemsetAsync(singular.get(), 0, sizeof(int), s));
+  bool diag_done = false;  // the previous step's update already factored this diagonal block
   for (int j0 = 0; j0 < n; j0 += NB) {
     const int jb = std::min(NB, n - j0);
-    hipLaunchKernelGGL(diag_lu_kernel, dim3(1), dim3(256), 0, s, b, j0, jb, singular.get());
+    double *invL = d_invs + (size_t)(j0 / NB) * (2 * NB * NB), *invU = invL + NB * NB;
+    if (!diag_done)
+      hipLaunchKernelGGL(diag_lu_kernel, dim3(1), dim3(256), 2 * kTileBytes, s, b, j0, jb, singular.get(), invL,
+                         invU);
     const int below = std::max(0, std::min(n, j0 + jb + kl) - (j0 + jb));   // rows with any in-band entry
     const int right = std::max(0, std::min(n, j0 + jb + ku) - (j0 + jb));
-    if (below + right > 0)
-      hipLaunchKernelGGL(trsm_kernel, dim3((unsigned)((below + right + 255) / 256)), dim3(256), 0, s, b, j0, jb,
-                         below, right);
-    if (below > 0 && right > 0)
+    const int tiles = (below + 63) / 64 + (right + 63) / 64;
+    if (tiles > 0)
+      hipLaunchKernelGGL(trsm_gemm_kernel, dim3((unsigned)tiles), dim3(256), 2 * kTileBytes, s, b, j0, jb, below,
+                         right, invL, invU);
+    diag_done = below > 0 && right > 0;
+    if (diag_done)
       hipLaunchKernelGGL(gemm_update_kernel, dim3((unsigned)((below + 63) / 64), (unsigned)((right + 63) / 64)),
-                         dim3(256), 0, s, b, j0, jb, below, right);
+                         dim3(256), 2 * kTileBytes, s, b, j0, jb, below, right, singular.get(),
+                         invL + 2 * NB * NB, invU + 2 * NB * NB);
   }
   int h = 0;
   SPL_HIP(hipMemcpyAsync(&h, singular.get(), sizeof(int), hipMemcpyDeviceToHost, s));
@@ -319,38 +507,32 @@ int band_nopiv_factor(int n, int kl, int ku, double *d_AB, const int *d_Ap, cons
   return h;
 }
 
-// c (device, permuted order) <- B^-1 c (sys 0) or B^-T c (sys 1) with the no-pivot factors
-void band_nopiv_solve(int sys, int n, int kl, int ku, const double *d_AB, double *d_c, hipStream_t s) {
-  if (n == 0) return;
-  Band b{const_cast<double *>(d_AB), n, kl, ku, kl + ku + 1};
-  const int nblk = (n + NB - 1) / NB;
-  if (sys == 0) {
-    for (int k = 0; k < nblk; ++k) {  // L forward
-      const int j0 = k * NB, jb = std::min(NB, n - j0);
-      hipLaunchKernelGGL(solve_diag_kernel, dim3(1), dim3(256), 0, s, b, 0, j0, jb, d_c);
-      const int rows = std::max(0, std::min(n, j0 + jb + kl) - (j0 + jb));
-      if (rows > 0)
-        hipLaunchKernelGGL(solve_update_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, b, 0, j0, jb,
-                           d_c);
-    }
-    for (int k = nblk - 1; k >= 0; --k) {  // U backward
-      const int j0 = k * NB, jb = std::min(NB, n - j0);
-      hipLaunchKernelGGL(solve_diag_kernel, dim3(1), dim3(256), 0, s, b, 1, j0, jb, d_c);
-      const int rows = std::min(j0, ku);
-      if (rows > 0)
-        hipLaunchKernelGGL(solve_update_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, b, 1, j0, jb,
-                           d_c);
-    }
-  } else {
-    for (int k = 0; k < nblk; ++k) {  // U^T forward
-      const int j0 = k * NB, jb = std::min(NB, n - j0);
-      hipLaunchKernelGGL(solve_diag_kernel, dim3(1), dim3(256), 0, s, b, 2, j0, jb, d_c);
-    }
-    for (int k = nblk - 1; k >= 0; --k) {  // L^T backward
-      const int j0 = k * NB, jb = std::min(NB, n - j0);
-      hipLaunchKernelGGL(solve_diag_kernel, dim3(1), dim3(256), 0, s, b, 3, j0, jb, d_c);
-    }
+template <int MODE>
+static void solve_pass(const Band &b, const double *d_invs, int bw, double *in, double *out, hipStream_t s) {
+  constexpr bool fwd = (MODE == 0 || MODE == 2);
+  const int n = b.n, step = SB * NB, nsup = (n + step - 1) / step;
+  for (int k = 0; k < nsup; ++k) {
+    const int j0 = (fwd ? k : nsup - 1 - k) * step, jbs = std::min(step, n - j0);
+    const int rows = fwd ? std::max(0, std::min(n, j0 + jbs + bw) - (j0 + jbs)) : std::min(j0, bw);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_super_kernel<MODE>), dim3((unsigned)std::max(1, (rows + 63) / 64)),
+                       dim3(256), 0, s, b, d_invs, j0, jbs, in, out);
   }
+}
+
+// c (device, permuted order) <- B^-1 c (sys 0) or B^-T c (sys 1) with the no-pivot factors
+void band_nopiv_solve(int sys, int n, int kl, int ku, int ldab, const double *d_AB, const double *d_invs,
+                      double *d_c, hipStream_t s) {
+  if (n == 0) return;
+  Band b{const_cast<double *>(d_AB), n, kl, ku, ldab};
+  DBuf<double> z((size_t)n);
+  if (sys == 0) {
+    solve_pass<0>(b, d_invs, kl, d_c, z.get(), s);  // L forward: c -> z
+    solve_pass<1>(b, d_invs, ku, z.get(), d_c, s);  // U backward: z -> c
+  } else {
+    solve_pass<2>(b, d_invs, ku, d_c, z.get(), s);  // U^T forward: c -> z
+    solve_pass<3>(b, d_invs, kl, z.get(), d_c, s);  // L^T backward: z -> c
+  }
+  SPL_HIP(hipStreamSynchronize(s));  // z is freed on return
 }
 
 }  // namespace spl

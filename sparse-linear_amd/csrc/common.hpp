@@ -167,9 +167,17 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
 
 // ---- blocked band LU without interchanges (band_nopiv.hip) --------------------------------------
 bool band_is_column_dominant(int n, const int *d_Ap, const int *d_Ai, const double *d_Ax, hipStream_t s);
-int band_nopiv_factor(int n, int kl, int ku, double *d_AB, const int *d_Ap, const int *d_Ai,
+// leading dimension of the band storage: >= kl+ku+1, padded so that the stride between the same row
+// of adjacent columns (ldab-1 doubles) is an odd multiple of 128 bytes, not a power of two
+inline int band_nopiv_ldab(int kl, int ku) {
+  int l = kl + ku + 1;
+  while ((l - 1) % 32 != 16) ++l;
+  return l;
+}
+size_t band_nopiv_inverse_elems(int n);  // doubles needed for the per-block inverse factors
+int band_nopiv_factor(int n, int kl, int ku, int ldab, double *d_AB, double *d_invs, const int *d_Ap, const int *d_Ai,
                       const double *d_Ax, const int *d_inv, hipStream_t s);
-void band_nopiv_solve(int sys, int n, int kl, int ku, const double *d_AB, double *d_c, hipStream_t s);
+void band_nopiv_solve(int sys, int n, int kl, int ku, int ldab, const double *d_AB, const double *d_invs, double *d_c, hipStream_t s);
 
 // ---- synthetic generators (generate.hip) --------------------------------------------
 void generate_synthetic(Matrix *m, int kind, int64_t n_or_m, int K, uint64_t seed, hipStream_t s);

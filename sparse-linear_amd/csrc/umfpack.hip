@@ -48,6 +48,7 @@ struct Numeric {
   int singular = 0;
   int nopiv = 0;  // 1: blocked factorisation without interchanges (column diagonally dominant A)
   DBuf<double> AB;
+  DBuf<double> blkinv;  // no-pivot path: inv(L11), inv(U11) of every diagonal block
   DBuf<int> ipiv, perm, inv;
   Matrix *A = nullptr;   // rows of A   (residual b - A x)
   Matrix *At = nullptr;  // rows of A^T (residual b - A^T x)
@@ -374,7 +375,7 @@ int validate_host_csc(int n_row, int n_col, const int *Ap, const int *Ai) {
 void band_solve(const Numeric *N, int sys, double *d_c, hipStream_t s) {
   if (N->n == 0) return;
   if (N->nopiv) {
-    band_nopiv_solve(sys, N->n, N->kl, N->ku, N->AB.get(), d_c, s);
+    band_nopiv_solve(sys, N->n, N->kl, N->ku, N->ldab, N->AB.get(), N->blkinv.get(), d_c, s);
     return;
   }
   hipLaunchKernelGGL(band_solve_kernel, dim3(1), dim3(1024), 0, s, sys, N->n, N->kl, N->ku, N->ldab,
@@ -474,7 +475,7 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
     const char *force = getenv("SPL_LU_FORCE_PIVOT");
     N->nopiv = (!(force && force[0] == '1') &&
                 band_is_column_dominant(n, N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), s)) ? 1 : 0;
-    N->ldab = N->nopiv ? (S->kl + S->ku + 1) : (2 * S->kl + S->ku + 1);
+    N->ldab = N->nopiv ? band_nopiv_ldab(S->kl, S->ku) : (2 * S->kl + S->ku + 1);
     const size_t band_elems = (size_t)N->ldab * (size_t)n;
     size_t free_b = 0, total_b = 0;
     SPL_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -483,6 +484,7 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
       return UMFPACK_ERROR_out_of_memory;
     }
     N->AB.alloc(band_elems);
+    if (N->nopiv) N->blkinv.alloc(band_nopiv_inverse_elems(n));
     SPL_HIP(hipMemsetAsync(N->AB.get(), 0, band_elems * sizeof(double), s));
     N->ipiv.alloc((size_t)n);
     N->perm.alloc((size_t)n);
@@ -501,7 +503,7 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
     }
     N->A = static_cast<Matrix *>(hA);
     if (N->nopiv) {
-      N->singular = band_nopiv_factor(n, N->kl, N->ku, N->AB.get(), N->At->rowptr.get(), N->At->colidx.get(),
+      N->singular = band_nopiv_factor(n, N->kl, N->ku, N->ldab, N->AB.get(), N->blkinv.get(), N->At->rowptr.get(), N->At->colidx.get(),
                                       N->At->val.get(), N->inv.get(), s);
       *NumericOut = N;
       return N->singular ? UMFPACK_WARNING_singular_matrix : UMFPACK_OK;
