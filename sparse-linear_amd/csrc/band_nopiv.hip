@@ -7,16 +7,24 @@
 // M-matrix of the C5 ladder is of this kind; anything else takes the pivoting path in
 // umfpack.hip.  (UMFPACK's own "symmetric strategy" prefers the diagonal for such matrices.)
 //
-// Storage: AB[(ku + i - j) + j*ldab], ldab >= kl + ku + 1 (band_nopiv_ldab pads it), i.e. A(i,j) = AB[ku + i + j*(ldab-1)]:
-// any sub-block inside the band is a dense column-major matrix with leading dimension ldab-1.
-// Right-looking, block size NB = 64:
-//   diag   : LU of the NB x NB diagonal block in LDS (one workgroup) + explicit inverses of its factors
+// Storage: AB[(ku + i - j) + j*ldab], ldab >= kl + ku + 1 (band_nopiv_ldab pads it), i.e.
+// A(i,j) = AB[ku + i + j*(ldab-1)]: any sub-block inside the band is a dense column-major matrix
+// with leading dimension ldab-1.
+// Right-looking, block size NB = 64, block steps taken in pairs:
+//   diag   : LU of the 64 x 64 diagonal block + explicit inverses of its two factors, one
+//            workgroup, the block held in registers (diag_block_factor).  Runs as a look-ahead
+//            inside the update kernel (the workgroup of tile (0,0)), off the critical path of
+//            the other tiles; the inverses are kept per block for the solves.
 //   trsm   : L21 = A21 inv(U11), U12 = inv(L11) A12 as 64x64x64 products on the matrix cores
-//   gemm   : A22 -= L21 U12        64x64 tiles, K = NB, operands staged in LDS; entries outside
-//            the band are read as zero and never written
-// fp64 dense-kernel work: this GEMM is the one contraction-shaped step of the whole backend (it
-// is outside the headline metric) and runs on the fp64 matrix cores (v_mfma_f64_16x16x4).  The solves are blocked the same way (diagonal block in LDS, then one
-// thread per affected row / one workgroup per affected column for the transposed forms).
+//   update : A22 -= L21 U12 on 64x64 tiles, K staged through LDS in slices of 32.  The first
+//            block step of a pair only updates the panels of the second (an L-shaped strip);
+//            then both update the rest of the window in one pass with K = 128, which halves
+//            the read-modify-write traffic of the window.  Entries outside the band are read
+//            as zero and never written.
+// fp64 dense-kernel work: these products are the one contraction-shaped step of the whole backend
+// (outside the headline metric) and run on the fp64 matrix cores (v_mfma_f64_16x16x4).
+// The solves run in super blocks of 256 unknowns, one launch each: the in-block part is four
+// 64x64 matrix-vector products with the stored inverses, the rest a band matrix-vector update.
 #include <algorithm>
 
 #include "common.hpp"
@@ -101,68 +109,88 @@ __device__ __forceinline__ void diag_block_factor(const Band &b, int j0, int jb,
                                                   double *__restrict__ invL, double *__restrict__ invU) {
   const int tid = threadIdx.x;
   const int tr = tid & 63, tc = tid >> 6;
-  double a[NB / 4];
+  constexpr int NS = NB / 4;  // register slots per thread
+  double a[NS];
 #pragma unroll
-  for (int u = 0; u < NB / 4; ++u) a[u] = D[tr][4 * u + tc];
-  // the pivot loops stay rolled (straight-line code of this size would run at instruction-fetch
-  // speed); register slots are indexed statically and selected with compares instead
+  for (int u = 0; u < NS; ++u) a[u] = D[tr][4 * u + tc];
+  // The pivot loops stay rolled (straight-line code of this size would run at instruction-fetch
+  // speed).  Register slots must be indexed statically, so the slots are shifted down by one
+  // after every group of 4 pivots: in group g slot j holds column 4 (g + j) + wave, the pivot
+  // columns of the group are always slot 0, and finished columns leave through tile D.
 #pragma unroll 1
-  for (int k = 0; k < NB; ++k) {
-    const int ks = k >> 2, kw = k & 3;  // slot and owning wave of column k
-    if (tc == kw) {
-      double ak = 0.0;
+  for (int g = 0; g < NS; ++g) {
 #pragma unroll
-      for (int u = 0; u < NB / 4; ++u) ak = (u == ks) ? a[u] : ak;
-      const double piv = readlane_f64(ak, k);
-      if (piv == 0.0) {
-        if (tr == 0) atomicOr(singular, 1);
-      } else if (tr > k) {
-        ak = ak / piv;
+    for (int kw = 0; kw < 4; ++kw) {
+      const int k = 4 * g + kw;
+      if (tc == kw) {
+        const double piv = readlane_f64(a[0], k);
+        if (piv == 0.0) {
+          if (tr == 0) atomicOr(singular, 1);
+        } else if (tr > k) {
+          a[0] = a[0] / piv;
+        }
+        lcol[k & 1][tr] = a[0];
       }
+      __syncthreads();
+      const double l = tr > k ? lcol[k & 1][tr] : 0.0;
+      if (tc > kw) a[0] -= l * readlane_f64(a[0], k);
 #pragma unroll
-      for (int u = 0; u < NB / 4; ++u) a[u] = (u == ks) ? ak : a[u];
-      lcol[k & 1][tr] = ak;
+      for (int qd = 0; qd < 4; ++qd) {
+        if (g + 4 * qd < NS) {  // some slot of this quarter still holds a live column
+#pragma unroll
+          for (int j = (qd == 0 ? 1 : 4 * qd); j < 4 * qd + 4; ++j) a[j] -= l * readlane_f64(a[j], k);
+        }
+      }
     }
-    __syncthreads();
-    const double l = tr > k ? lcol[k & 1][tr] : 0.0;
+    D[tr][4 * g + tc] = a[0];
 #pragma unroll
-    for (int u = 0; u < NB / 4; ++u) {
-      const double pk = readlane_f64(a[u], k);
-      if (4 * u + tc > k) a[u] -= l * pk;
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < NB / 4; ++u) {
-    const int c = 4 * u + tc;
-    D[tr][c] = a[u];
-    if (tr < jb && c < jb && b.in_band(j0 + tr, j0 + c)) b.at(j0 + tr, j0 + c) = a[u];
+    for (int j = 0; j + 1 < NS; ++j) a[j] = a[j + 1];
+    a[NS - 1] = 0.0;
   }
   __syncthreads();
-  double x[NB / 4], y[NB / 4];
+  for (int c = tc; c < jb; c += 4)
+    if (tr < jb && b.in_band(j0 + tr, j0 + c)) b.at(j0 + tr, j0 + c) = D[tr][c];
+  // reciprocals of the pivots, once
+  double *dinv = &lcol[0][0];
+  if (tid < NB) {
+    const double d = D[tid][tid];
+    dinv[tid] = d != 0.0 ? 1.0 / d : 0.0;
+  }
+  __syncthreads();
+  double x[NS], y[NS];
 #pragma unroll
-  for (int u = 0; u < NB / 4; ++u) x[u] = y[u] = (tr == 4 * u + tc) ? 1.0 : 0.0;
+  for (int u = 0; u < NS; ++u) x[u] = y[u] = (tr == 4 * u + tc) ? 1.0 : 0.0;
 #pragma unroll 1
   for (int s = 0; s < NB; ++s) {
     {  // U^-1: row k final after scaling by 1/U(k,k); rows above lose U(i,k) * row k
-      const int k = NB - 1 - s;
-      const double d = D[k][k];
-      const double dinv = d != 0.0 ? 1.0 / d : 0.0;
+      const int k = NB - 1 - s, ks = k >> 2;
+      const double dk = dinv[k];
       const double uik = tr < k ? D[tr][k] : 0.0;
 #pragma unroll
-      for (int u = 0; u < NB / 4; ++u) {  // X(k, c) is zero for c < k
-        const double xk = readlane_f64(x[u], k) * dinv;
-        x[u] = (tr == k) ? xk : x[u] - uik * xk;
+      for (int qd = 0; qd < 4; ++qd) {
+        if (4 * qd + 3 >= ks) {  // X(k, c) is zero for c < k
+#pragma unroll
+          for (int u = 4 * qd; u < 4 * qd + 4; ++u) {
+            const double xk = readlane_f64(x[u], k) * dk;
+            x[u] = (tr == k) ? xk : x[u] - uik * xk;
+          }
+        }
       }
     }
     {  // L^-1 (unit diagonal): rows below lose L(i,k) * row k
-      const int k = s;
+      const int k = s, ks = k >> 2;
       const double lik = tr > k ? D[tr][k] : 0.0;
 #pragma unroll
-      for (int u = 0; u < NB / 4; ++u) y[u] -= lik * readlane_f64(y[u], k);  // Y(k, c) is zero for c > k
+      for (int qd = 0; qd < 4; ++qd) {
+        if (4 * qd <= ks) {  // Y(k, c) is zero for c > k
+#pragma unroll
+          for (int u = 4 * qd; u < 4 * qd + 4; ++u) y[u] -= lik * readlane_f64(y[u], k);
+        }
+      }
     }
   }
 #pragma unroll
-  for (int u = 0; u < NB / 4; ++u) {
+  for (int u = 0; u < NS; ++u) {
     const int c = 4 * u + tc;
     invU[tr + c * NB] = x[u];
     invL[tr + c * NB] = y[u];
@@ -198,14 +226,11 @@ struct TilePos {
   __device__ int col(int a, int r) const { return qc + a * 16 + lk + 4 * r; }
 };
 
+template <int KD>
 __device__ __forceinline__ void mfma_tile_64(const double (*Cs)[LDP], const double (*Rs)[LDP], const TilePos &p,
                                              double4v (&acc)[2][2]) {
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) acc[a][c] = (double4v){0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
-  for (int k0 = 0; k0 < NB; k0 += 4) {
+  for (int k0 = 0; k0 < KD; k0 += 4) {
     double af[2], bf[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) af[a] = Cs[k0 + p.lk][p.qc + a * 16 + p.li];
@@ -217,6 +242,13 @@ __device__ __forceinline__ void mfma_tile_64(const double (*Cs)[LDP], const doub
       for (int c = 0; c < 2; ++c)
         acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[c], acc[a][c], 0, 0, 0);
   }
+}
+
+__device__ __forceinline__ void zero_acc(double4v (&acc)[2][2]) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[a][c] = (double4v){0.0, 0.0, 0.0, 0.0};
 }
 
 // panel solves as GEMMs: tiles [0, ntile_l): L21 tile (64 rows) <- A21 tile * invU;
@@ -250,7 +282,8 @@ __global__ __launch_bounds__(256) void trsm_gemm_kernel(Band b, int j0, int jb, 
   __syncthreads();
   const TilePos p;
   double4v acc[2][2];
-  mfma_tile_64(Cs, Rs, p, acc);
+  zero_acc(acc);
+  mfma_tile_64<NB>(Cs, Rs, p, acc);
   const int rlim = is_l ? rend : j0 + jb, clim = is_l ? j0 + jb : cend;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -263,22 +296,37 @@ __global__ __launch_bounds__(256) void trsm_gemm_kernel(Band b, int j0, int jb, 
       }
 }
 
-// A22 -= L21 * U12 on 64x64 tiles, K = jb <= NB, same MFMA tile; entries outside the band read as
-// zero and are never written.
+// Trailing update  A(rows, cols) -= L(rows, kb .. kb+klen) * U(kb .. kb+klen, cols)  on 64 x 64
+// tiles of the region rows [rb, re) x columns [cb, ce), rb == cb on the diagonal.  K is staged
+// through LDS in slices of KS = 32 (34 KB per workgroup, 4 workgroups per CU); klen is 64 for a
+// single block step and 128 when two block steps share one pass over the window, which halves
+// the read-modify-write traffic of the window.  Entries outside the band read as zero and are
+// never written.
+//   lshape = 0: 2-D grid over the whole region.
+//   lshape = 1: 1-D grid over the first tile column and the first tile row only (the panels the
+//               second block step of a pair needs before the shared pass).
 // Look-ahead: the workgroup of tile (0,0) -- the next diagonal block -- goes on to factor and
 // invert it while the other tiles are still being updated, which takes the diagonal-block chain
 // off the critical path.
-__global__ __launch_bounds__(256) void gemm_update_kernel(Band b, int j0, int jb, int nrows_below, int ncols_right,
-                                                          int *__restrict__ singular,
+constexpr int KS = 32;
+struct Region {
+  int rb, re, cb, ce, kb, klen, lshape, ntile_rows;
+};
+
+__global__ __launch_bounds__(256) void gemm_update_kernel(Band b, Region g, int *__restrict__ singular,
                                                           double *__restrict__ next_invL,
                                                           double *__restrict__ next_invU) {
-  const int r0 = j0 + jb + blockIdx.x * 64, c0 = j0 + jb + blockIdx.y * 64;
+  int tx = blockIdx.x, ty = blockIdx.y;
+  if (g.lshape) {
+    tx = (int)blockIdx.x < g.ntile_rows ? (int)blockIdx.x : 0;
+    ty = (int)blockIdx.x < g.ntile_rows ? 0 : (int)blockIdx.x - g.ntile_rows + 1;
+  }
+  const int r0 = g.rb + tx * 64, c0 = g.cb + ty * 64;
   if (r0 - (c0 + 63) > b.kl || c0 - (r0 + 63) > b.ku) return;  // tile entirely outside the band
   extern __shared__ __attribute__((aligned(16))) double dsm[];
-  double(*Us)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);            // Us[k][c] = U(j0 + k, c0 + c)
-  double(*Ls)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + NB * LDP);  // Ls[k][r] = L(r0 + r, j0 + k)
+  double(*Us)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);            // Us[k][c] = U(kb + k, c0 + c)
+  double(*Ls)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + KS * LDP);  // Ls[k][r] = L(r0 + r, kb + k)
   const int tid = threadIdx.x;
-  const int rend = j0 + jb + nrows_below, cend = j0 + jb + ncols_right;
   // the tile of A22 is requested first, so that its HBM latency overlaps the staging and the MFMAs
   // (entries outside this step's update range get a zero product; tile (0,0) needs them below)
   const TilePos p;
@@ -290,19 +338,23 @@ __global__ __launch_bounds__(256) void gemm_update_kernel(Band b, int j0, int jb
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = r0 + p.row(c), j = c0 + p.col(a, r);
-        cold[a][c][r] = (i < b.n && j < b.n && b.in_band(i, j)) ? b.at(i, j) : 0.0;  // also beyond rend/cend
+        cold[a][c][r] = (i < b.n && j < b.n && b.in_band(i, j)) ? b.at(i, j) : 0.0;  // also beyond re/ce
       }
-  for (int t = tid; t < NB * 64; t += 256) {
-    const int r = t % 64, k = t / 64;
-    Ls[k][r] = (k < jb && r0 + r < rend) ? b.get(r0 + r, j0 + k) : 0.0;
-  }
-  for (int t = tid; t < NB * 64; t += 256) {
-    const int k = t % NB, c = t / NB;
-    Us[k][c] = (k < jb && c0 + c < cend) ? b.get(j0 + k, c0 + c) : 0.0;
-  }
-  __syncthreads();
   double4v acc[2][2];
-  mfma_tile_64(Us, Ls, p, acc);
+  zero_acc(acc);
+  for (int k0 = 0; k0 < g.klen; k0 += KS) {
+    if (k0) __syncthreads();
+    for (int t = tid; t < KS * 64; t += 256) {
+      const int r = t % 64, k = t / 64;
+      Ls[k][r] = (k0 + k < g.klen && r0 + r < g.re) ? b.get(r0 + r, g.kb + k0 + k) : 0.0;
+    }
+    for (int t = tid; t < KS * 64; t += 256) {
+      const int k = t % KS, c = t / KS;
+      Us[k][c] = (k0 + k < g.klen && c0 + c < g.ce) ? b.get(g.kb + k0 + k, c0 + c) : 0.0;
+    }
+    __syncthreads();
+    mfma_tile_64<KS>(Us, Ls, p, acc);
+  }
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -311,14 +363,14 @@ __global__ __launch_bounds__(256) void gemm_update_kernel(Band b, int j0, int jb
       for (int r = 0; r < 4; ++r) {
         const int i = r0 + p.row(c), j = c0 + p.col(a, r);
         cold[a][c][r] -= acc[a][c][r];
-        if (i < rend && j < cend && b.in_band(i, j)) b.at(i, j) = cold[a][c][r];
+        if (i < g.re && j < g.ce && b.in_band(i, j)) b.at(i, j) = cold[a][c][r];
       }
-  if (blockIdx.x != 0 || blockIdx.y != 0) return;
+  if (tx != 0 || ty != 0) return;
   // next diagonal block: rows/columns r0 .. r0 + jbn - 1, values still in registers
   const int jbn = min(NB, b.n - r0);
   __syncthreads();  // all waves are done reading Us / Ls
-  double(*D)[LDP] = Us;
-  double(*lcol)[NB] = reinterpret_cast<double(*)[NB]>(&Ls[0][0]);
+  double(*D)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);
+  double(*lcol)[NB] = reinterpret_cast<double(*)[NB]>(dsm + NB * LDP);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -474,31 +526,59 @@ int band_nopiv_factor(int n, int kl, int ku, int ldab, double *d_AB, double *d_i
     SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_gemm_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
     SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_update_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));  // uses less
     attr_set = true;
   }
   hipLaunchKernelGGL(band2_scatter_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, n, d_Ap, d_Ai, d_Ax,
                      d_inv, b);
   DBuf<int> singular(1);
   SPL_HIP(hipMemsetAsync(singular.get(), 0, sizeof(int), s));
-  bool diag_done = false;  // the previous step's update already factored this diagonal block
-  for (int j0 = 0; j0 < n; j0 += NB) {
-    const int jb = std::min(NB, n - j0);
-    double *invL = d_invs + (size_t)(j0 / NB) * (2 * NB * NB), *invU = invL + NB * NB;
-    if (!diag_done)
-      hipLaunchKernelGGL(diag_lu_kernel, dim3(1), dim3(256), 2 * kTileBytes, s, b, j0, jb, singular.get(), invL,
-                         invU);
-    const int below = std::max(0, std::min(n, j0 + jb + kl) - (j0 + jb));   // rows with any in-band entry
-    const int right = std::max(0, std::min(n, j0 + jb + ku) - (j0 + jb));
+  const size_t gemm_lds = kTileBytes + 2 * NB * sizeof(double);
+  auto slot = [&](int j) { return d_invs + (size_t)(j / NB) * (2 * NB * NB); };
+  auto below_of = [&](int jend) { return std::max(0, std::min(n, jend + kl) - jend); };  // rows with in-band entries
+  auto right_of = [&](int jend) { return std::max(0, std::min(n, jend + ku) - jend); };
+  auto diag = [&](int j0, int jb) {
+    hipLaunchKernelGGL(diag_lu_kernel, dim3(1), dim3(256), kTileBytes + 2 * NB * sizeof(double), s, b, j0, jb,
+                       singular.get(), slot(j0), slot(j0) + NB * NB);
+  };
+  auto trsm = [&](int j0, int jb) {
+    const int below = below_of(j0 + jb), right = right_of(j0 + jb);
     const int tiles = (below + 63) / 64 + (right + 63) / 64;
     if (tiles > 0)
       hipLaunchKernelGGL(trsm_gemm_kernel, dim3((unsigned)tiles), dim3(256), 2 * kTileBytes, s, b, j0, jb, below,
-                         right, invL, invU);
-    diag_done = below > 0 && right > 0;
-    if (diag_done)
-      hipLaunchKernelGGL(gemm_update_kernel, dim3((unsigned)((below + 63) / 64), (unsigned)((right + 63) / 64)),
-                         dim3(256), 2 * kTileBytes, s, b, j0, jb, below, right, singular.get(),
-                         invL + 2 * NB * NB, invU + 2 * NB * NB);
+                         right, slot(j0), slot(j0) + NB * NB);
+  };
+  // trailing update of rows/cols from `origin` with the K range [kb, kb+klen); factors the diagonal
+  // block at `origin` on the way (look-ahead).  Returns false when the region is empty.
+  auto update = [&](int origin, int kb, int klen, int kend, bool lshape) {
+    // rows/columns reached by the blocks in the K range end at the reach of its LAST block
+    const int re = std::min(n, kend + kl), ce = std::min(n, kend + ku);
+    if (re <= origin || ce <= origin) return false;
+    const int ntr = (re - origin + 63) / 64, ntc = (ce - origin + 63) / 64;
+    Region g{origin, re, origin, ce, kb, klen, lshape ? 1 : 0, ntr};
+    const dim3 grid = lshape ? dim3((unsigned)(ntr + ntc - 1)) : dim3((unsigned)ntr, (unsigned)ntc);
+    hipLaunchKernelGGL(gemm_update_kernel, grid, dim3(256), gemm_lds, s, b, g, singular.get(), slot(origin),
+                       slot(origin) + NB * NB);
+    return true;
+  };
+  bool diag_done = false;  // the previous update already factored this diagonal block
+  int j0 = 0;
+  while (j0 < n) {
+    const int jb = std::min(NB, n - j0);
+    if (!diag_done) diag(j0, jb);
+    trsm(j0, jb);
+    if (j0 + 2 * NB <= n && kl >= NB && ku >= NB) {
+      // pair of block steps: the first one only updates the panels of the second (L-shape), then
+      // both update the rest of the window in one pass with K = 2 NB
+      const int j1 = j0 + NB;
+      if (!update(j1, j0, NB, j0 + NB, true)) diag(j1, NB);
+      trsm(j1, NB);
+      diag_done = update(j1 + NB, j0, 2 * NB, j1 + NB, false);
+      j0 += 2 * NB;
+    } else {
+      diag_done = update(j0 + jb, j0, jb, j0 + jb, false);
+      j0 += jb;
+    }
   }
   int h = 0;
   SPL_HIP(hipMemcpyAsync(&h, singular.get(), sizeof(int), hipMemcpyDeviceToHost, s));
