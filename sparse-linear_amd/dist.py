@@ -1,4 +1,4 @@
-"""1-D row-block SpMV across the GPUs of one node.
+"""1-D row-block SpMV (and column-block SpGEMM, at the end) across the GPUs of one node.
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on
 ROCm).  Rank p owns the contiguous row block [r_p, r_{p+1}) of the CSR image —
@@ -87,3 +87,95 @@ def hip_local_spmv(handle, stream_getter):
     def run(x, y_local):
         handle.spmv_dev(x.data_ptr(), y_local.data_ptr(), accumulate=False, stream=stream_getter())
     return run
+
+
+# ---- SpGEMM: column blocks of the right operand ----------------------------------
+def product_balanced_col_bounds(a_pointers, b_pointers, b_indices, nparts):
+    """Contiguous column blocks of B with about equal numbers of scalar products a_ik * b_kj
+    (the work of Gustavson's column j is sum_{k in B(:,j)} nnz(A(:,k)), Sparse.hs:691-702)."""
+    a_len = np.diff(np.asarray(a_pointers, dtype=np.int64))
+    b_pointers = np.asarray(b_pointers, dtype=np.int64)
+    per_entry = a_len[np.asarray(b_indices, dtype=np.int64)]
+    cum = np.concatenate([[0], np.cumsum(per_entry)])[b_pointers]  # products before column j
+    total = int(cum[-1])
+    ncols = len(b_pointers) - 1
+    bounds = [0]
+    for p in range(1, nparts):
+        bounds.append(int(np.searchsorted(cum, (total * p) // nparts, side="left")))
+    bounds.append(ncols)
+    return [min(max(b, 0), ncols) for b in bounds]
+
+
+class ColBlockSpGEMM(object):
+    """C = A B with the columns of B (hence of C) split over the ranks of a process group.
+
+    Column j of C depends on A and on column j of B only (the reference's `mm` is a map over
+    the columns of B, Sparse.hs:691-702), so rank p multiplies the replicated A by the
+    zero-copy column slice B(:, c_p:c_{p+1}) and owns C(:, c_p:c_{p+1}); there is no data-path
+    collective.  `pointer_offsets()` is the one size exchange needed to address the blocks as
+    one CSC matrix; `gather()` assembles the full C on every rank (tests / small results).
+
+    local_mm(A, B_block) -> Matrix is the product's HIP SpGEMM (`sparse.mm`) in production."""
+
+    def __init__(self, matA, matB, rank, world, local_mm, bounds=None, group=None):
+        if matA.ncols != matB.nrows:
+            raise ValueError("ColBlockSpGEMM: inner dimension mismatch")
+        self.A, self.B, self.rank, self.world = matA, matB, int(rank), int(world)
+        self.local_mm, self.group = local_mm, group
+        self.bounds = list(bounds) if bounds is not None else \
+            product_balanced_col_bounds(matA.pointers, matB.pointers, matB.indices, world)
+        assert len(self.bounds) == world + 1 and self.bounds[0] == 0 and self.bounds[-1] == matB.ncols
+        self.C_local = None
+
+    def block_of_b(self, p):
+        c0, c1 = self.bounds[p], self.bounds[p + 1]
+        B = self.B
+        s, e = int(B.pointers[c0]), int(B.pointers[c1])
+        return type(B)(c1 - c0, B.nrows, B.pointers[c0:c1 + 1] - s, B.indices[s:e], B.values[s:e])
+
+    def step(self):
+        """this rank's column block of C"""
+        self.C_local = self.local_mm(self.A, self.block_of_b(self.rank))
+        return self.C_local
+
+    def pointer_offsets(self):
+        """nnz of the blocks before each rank's block (all-gather of one count per rank)"""
+        import torch
+        mine = torch.tensor([int(self.C_local.pointers[-1])], dtype=torch.int64)
+        if self.world == 1:
+            counts = mine
+        else:
+            import torch.distributed as dist
+            counts = torch.zeros(self.world, dtype=torch.int64)
+            dist.all_gather_into_tensor(counts, mine, group=self.group)
+        return np.concatenate([[0], np.cumsum(counts.numpy())]).astype(np.int64)
+
+    def gather(self):
+        """the full C on every rank"""
+        import torch
+        off = self.pointer_offsets()
+        Cl = self.C_local
+        if self.world == 1:
+            return Cl
+        import torch.distributed as dist
+        maxnz = int(np.max(np.diff(off)))
+        maxc = max(self.bounds[p + 1] - self.bounds[p] for p in range(self.world))
+
+        def padded(a, n, dtype):
+            t = torch.zeros(n, dtype=dtype)
+            t[: len(a)] = torch.from_numpy(np.ascontiguousarray(a))
+            return t
+
+        outs = []
+        for arr, n, dt in ((Cl.pointers[1:], maxc, torch.int64), (Cl.indices, maxnz, torch.int64),
+                           (Cl.values, maxnz, torch.float64)):
+            buf = torch.zeros(self.world * n, dtype=dt)
+            dist.all_gather_into_tensor(buf, padded(arr, n, dt), group=self.group)
+            outs.append(buf.numpy().reshape(self.world, n))
+        ptrs, idx, val = [np.zeros(1, dtype=np.int64)], [], []
+        for p in range(self.world):
+            nc, nz = self.bounds[p + 1] - self.bounds[p], int(off[p + 1] - off[p])
+            ptrs.append(outs[0][p, :nc] + off[p])
+            idx.append(outs[1][p, :nz])
+            val.append(outs[2][p, :nz])
+        return type(Cl)(self.B.ncols, self.A.nrows, np.concatenate(ptrs), np.concatenate(idx), np.concatenate(val))

@@ -72,6 +72,56 @@ def _worker(rank, world, port, balanced, out_dir):
         dist.destroy_process_group()
 
 
+def _spgemm_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import __graft_entry__ as g
+        pkg = g.load_package()
+        from oracle import oracle as O
+        from tests.helpers import mat_to_tuple, tuple_to_mat, tuples_equal
+        n = 700
+        rp, ci, v = O.gen_random_csr(n, 6)       # CSR arrays of a matrix == CSC arrays of its transpose
+        A = pkg.Matrix(n, n, rp, ci, v)
+        rp2, ci2, v2 = O.gen_random_csr(n, 9, seed=77)
+        # skew B: the last third of its columns is nearly empty, so balanced blocks are ragged
+        keep = np.ones(len(ci2), dtype=bool)
+        for c in range(2 * n // 3, n):
+            keep[rp2[c] + 1:rp2[c + 1]] = False
+        lens = np.array([keep[rp2[c]:rp2[c + 1]].sum() for c in range(n)])
+        B = pkg.Matrix(n, n, np.concatenate([[0], np.cumsum(lens)]), ci2[keep], v2[keep])
+
+        def local_mm(a, b):  # CPU ranks: the oracle stands in for the HIP SpGEMM
+            return tuple_to_mat(pkg, O.mm(mat_to_tuple(a), mat_to_tuple(b)))
+
+        op = pkg.dist.ColBlockSpGEMM(A, B, rank, world, local_mm)
+        op.step()
+        C = op.gather()
+        ref = O.mm(mat_to_tuple(A), mat_to_tuple(B))
+        ok = tuples_equal(mat_to_tuple(C), ref)
+        off = op.pointer_offsets()
+        ok_off = int(off[-1]) == int(ref[2][-1]) and len(off) == world + 1
+        b = op.bounds
+        a_len = np.diff(A.pointers)
+        work = [int(a_len[B.indices[B.pointers[b[p]]:B.pointers[b[p + 1]]]].sum()) for p in range(world)]
+        bal = max(work) - min(work) <= 2 * int(a_len.max()) * 9
+        ragged = len({b[p + 1] - b[p] for p in range(world)}) > 1
+        with open(os.path.join(out_dir, "rank%d" % rank), "w") as f:
+            f.write("%d %d %d %d" % (ok, ok_off, bal, ragged))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_colblock_spgemm_gloo(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_spgemm_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        ok, ok_off, bal, ragged = open(tmp_path / ("rank%d" % r)).read().split()
+        assert ok == "1" and ok_off == "1" and bal == "1" and ragged == "1"
+
+
 @pytest.mark.parametrize("world,balanced", [(2, False), (2, True), (3, False)])
 def test_rowblock_spmv_gloo(tmp_path, world, balanced):
     port = _free_port()

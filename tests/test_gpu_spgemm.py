@@ -98,3 +98,19 @@ def test_device_resident_spgemm_rmat(gpu, pkg, O):
         assert np.array_equal(crp, Ct[2]) and np.array_equal(cci, Ct[3]) and np.array_equal(cv, Ct[4])
         lens = np.diff(A_csc[2])
         assert products == int(np.sum(lens[A_csc[3]]))  # sum over entries (k, j) of |A[:,k]|
+
+
+@pytest.mark.parametrize("nparts", [1, 3, 8])
+def test_colblock_spgemm_hip_blocks_concatenate_to_mm(gpu, pkg, O, nparts):
+    """§8e: the column blocks of B each rank would multiply on its GPU (here one after the other
+    on one GPU, HIP SpGEMM as the local operator) concatenate to exactly A*B"""
+    rng = np.random.default_rng(31 + nparts)
+    A, B = rand_csc(O, rng, 900, 800, 9000), rand_csc(O, rng, 800, 1100, 7000)
+    Am, Bm = tuple_to_mat(pkg, A), tuple_to_mat(pkg, B)
+    blocks = []
+    for p in range(nparts):
+        op = pkg.dist.ColBlockSpGEMM(Am, Bm, p, nparts, pkg.mm)
+        blocks.append(op.step())
+        assert blocks[-1].ncols == op.bounds[p + 1] - op.bounds[p]
+    C = pkg.hcat(blocks)
+    assert tuples_equal(mat_to_tuple(C), O.mm(A, B))
