@@ -395,10 +395,14 @@ __global__ __launch_bounds__(256) void gemm_update_kernel(Band b, Region g, int 
 //   MODE 2: U^T z = c (lower, forward)        3: L^T x = z (unit upper, backward)
 constexpr int SB = 4;
 
+// Workgroups of SW = 16 wavefronts: these kernels are chains of short latency-bound phases, and the
+// wider workgroup shortens every phase (more loads in flight per row).
+constexpr int SW = 16;
+
 // res[l] = sum_{t < nc} M(rb + l, cb + t) * vv[t], l < 64; M = matrix of the triangular system.
-// Untransposed (MODE 0/1) band storage runs down the rows: lane = row, wave q takes t = q mod 4,
+// Untransposed (MODE 0/1) band storage runs down the rows: lane = row, wave q takes t = q mod SW,
 // partial sums meet in LDS.  Transposed (MODE 2/3) it runs along t: lanes along t, wave q takes
-// rows l = q mod 4, butterfly reduction.  Ends with the result visible to the whole workgroup.
+// rows l = q mod SW, butterfly reduction.  Ends with the result visible to the whole workgroup.
 template <int MODE>
 __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, const double *vv, double *res,
                                        double (*part)[64]) {
@@ -408,23 +412,28 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
     double s0 = 0.0, s1 = 0.0;
     if (i >= 0 && i < b.n) {
       int t = wave;
-      for (; t + 28 < nc; t += 32) {  // 8 independent loads in flight per lane
+      for (; t + 7 * SW < nc; t += 8 * SW) {  // 8 independent loads in flight per lane
         double e[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) e[u] = b.get(i, cb + t + 4 * u);
+        for (int u = 0; u < 8; ++u) e[u] = b.get(i, cb + t + SW * u);
 #pragma unroll
         for (int u = 0; u < 8; u += 2) {
-          s0 += e[u] * vv[t + 4 * u];
-          s1 += e[u + 1] * vv[t + 4 * u + 4];
+          s0 += e[u] * vv[t + SW * u];
+          s1 += e[u + 1] * vv[t + SW * u + SW];
         }
       }
-      for (; t < nc; t += 4) s0 += b.get(i, cb + t) * vv[t];
+      for (; t < nc; t += SW) s0 += b.get(i, cb + t) * vv[t];
     }
     part[wave][lane] = s0 + s1;
     __syncthreads();
-    if (threadIdx.x < 64) res[lane] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (threadIdx.x < 64) {
+      double tot = 0.0;
+#pragma unroll
+      for (int q = 0; q < SW; ++q) tot += part[q][lane];
+      res[lane] = tot;
+    }
   } else {
-    for (int l = wave; l < 64; l += 4) {
+    for (int l = wave; l < 64; l += SW) {
       const int i = rb + l;
       double sacc = 0.0;
       if (i >= 0 && i < b.n)
@@ -446,15 +455,20 @@ __device__ __forceinline__ void gemv_inv(const double *__restrict__ inv, const d
   if (MODE <= 1) {
     double sacc = 0.0;
 #pragma unroll
-    for (int u = 0; u < NB / 4; ++u) {
-      const int t = wave + 4 * u;
+    for (int u = 0; u < NB / SW; ++u) {
+      const int t = wave + SW * u;
       sacc += inv[lane + t * NB] * w[t];
     }
     part[wave][lane] = sacc;
     __syncthreads();
-    if (threadIdx.x < 64) res[lane] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (threadIdx.x < 64) {
+      double tot = 0.0;
+#pragma unroll
+      for (int q = 0; q < SW; ++q) tot += part[q][lane];
+      res[lane] = tot;
+    }
   } else {
-    for (int l = wave; l < 64; l += 4) {
+    for (int l = wave; l < 64; l += SW) {
       double sacc = inv[lane + l * NB] * w[lane];  // T(l, t) = inv(t, l)
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
@@ -465,13 +479,13 @@ __device__ __forceinline__ void gemv_inv(const double *__restrict__ inv, const d
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void solve_super_kernel(Band b, const double *__restrict__ invs, int j0, int jbs,
-                                                          double *in, double *__restrict__ out) {
-  __shared__ double v[SB * NB], w[NB], res[NB], part[4][64];
+__global__ __launch_bounds__(SW * 64) void solve_super_kernel(Band b, const double *__restrict__ invs, int j0,
+                                                              int jbs, double *in, double *__restrict__ out) {
+  __shared__ double v[SB * NB], w[NB], res[NB], part[SW][64];
   constexpr bool fwd = (MODE == 0 || MODE == 2);
   const int tid = threadIdx.x;
   const int nsub = (jbs + NB - 1) / NB;
-  for (int t = tid; t < SB * NB; t += 256) v[t] = 0.0;
+  for (int t = tid; t < SB * NB; t += SW * 64) v[t] = 0.0;
   __syncthreads();
   for (int k = 0; k < nsub; ++k) {
     const int sblk = fwd ? k : nsub - 1 - k;
@@ -488,7 +502,7 @@ __global__ __launch_bounds__(256) void solve_super_kernel(Band b, const double *
     __syncthreads();
   }
   if (blockIdx.x == 0)
-    for (int t = tid; t < jbs; t += 256) out[j0 + t] = v[t];
+    for (int t = tid; t < jbs; t += SW * 64) out[j0 + t] = v[t];
   // the 64 rows of this workgroup outside the super block
   const int rb = fwd ? j0 + jbs + (int)blockIdx.x * 64 : j0 - ((int)blockIdx.x + 1) * 64;
   gemv64<MODE>(b, rb, j0, jbs, v, res, part);
@@ -595,7 +609,7 @@ static void solve_pass(const Band &b, const double *d_invs, int bw, double *in, 
     const int j0 = (fwd ? k : nsup - 1 - k) * step, jbs = std::min(step, n - j0);
     const int rows = fwd ? std::max(0, std::min(n, j0 + jbs + bw) - (j0 + jbs)) : std::min(j0, bw);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_super_kernel<MODE>), dim3((unsigned)std::max(1, (rows + 63) / 64)),
-                       dim3(256), 0, s, b, d_invs, j0, jbs, in, out);
+                       dim3(SW * 64), 0, s, b, d_invs, j0, jbs, in, out);
   }
 }
 

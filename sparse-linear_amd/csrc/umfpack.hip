@@ -13,10 +13,11 @@
 //                    pivoting; a zero pivot sets the singular-matrix warning;
 //   solve    (GPU):  permute, banded forward/back substitution (or U^T, L^T for sys = 1),
 //                    un-permute, then up to 2 steps of iterative refinement with the residual
-//                    computed by the SpMV kernels (UMFPACK's default irstep = 2).
-// Band LU is dense-kernel-shaped fp64 work bounded by HBM traffic of the rank-1 updates in this
-// first version (one update per column); a blocked panel/TRSM/GEMM (fp64 MFMA) version and a
-// multifrontal ordering are the next steps.
+//                    computed by the SpMV kernels (UMFPACK's default irstep = 2) and UMFPACK's
+//                    stopping rules on the componentwise backward error.
+// The pivoting band LU here updates one column at a time (rank-1 updates, HBM-bound); matrices
+// that are diagonally dominant by columns take the blocked MFMA factorisation of band_nopiv.hip.
+// A fill-reducing multifrontal ordering is the next step.
 #include <stdio.h>
 #include <algorithm>
 #include <vector>
@@ -329,20 +330,40 @@ __global__ __launch_bounds__(1024) void band_solve_kernel(int sys, int n, int kl
   }
 }
 
+// absax[i] = sum_k |a_ik| |x_k| over the rows of a CSR image, 8 lanes per row
+__global__ __launch_bounds__(256) void abs_spmv_kernel(int n, const int64_t *__restrict__ rowptr,
+                                                       const int *__restrict__ colidx,
+                                                       const double *__restrict__ val, const double *__restrict__ x,
+                                                       double *__restrict__ absax) {
+  const int i = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 3), part = threadIdx.x & 7;
+  double s = 0.0;
+  if (i < n)
+    for (int64_t p = rowptr[i] + part; p < rowptr[i + 1]; p += 8) s += fabs(val[p]) * fabs(x[colidx[p]]);
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (i < n && part == 0) absax[i] = s;
+}
+
+// r = b - ax and the componentwise backward error  omega = max_i |r_i| / (|A||x| + |b|)_i
+// (Arioli, Demmel & Duff; the quantity UMFPACK's refinement monitors)
 __global__ void residual_kernel(int n, const double *__restrict__ b, const double *__restrict__ ax,
-                                double *__restrict__ r, double *__restrict__ rmax) {  // r = b - ax
+                                const double *__restrict__ absax, double *__restrict__ r,
+                                double *__restrict__ omega) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double a = 0.0;
   if (i < n) {
     const double v = b[i] - ax[i];
     r[i] = v;
+    const double den = absax[i] + fabs(b[i]);
     a = fabs(v);
+    if (a > 0.0) a = den > 0.0 ? a / den : 1e300 * 1e300;
     if (!(a == a)) a = 1e300 * 1e300;  // NaN counts as +inf
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) a = fmax(a, __shfl_xor(a, d, 64));
   if ((threadIdx.x & 63) == 0 && a > 0.0)
-    atomicMax(reinterpret_cast<unsigned long long *>(rmax), (unsigned long long)__double_as_longlong(a));
+    atomicMax(reinterpret_cast<unsigned long long *>(omega), (unsigned long long)__double_as_longlong(a));
 }
 
 __global__ void add_kernel(int n, double *__restrict__ x, const double *__restrict__ d) {
@@ -566,28 +587,37 @@ int umfpack_di_solve(int sys, const int Ap[], const int Ai[], const double Ax[],
     factor_solve(N, sys, db.get(), dx.get(), dwork.get(), s);
     if (!N->singular) {
       const Matrix *op = sys == UMFPACK_A ? N->A : N->At;
-      auto residual_norm = [&](const double *x, double *r) -> double {
+      DBuf<double> dabs((size_t)n);
+      auto backward_error = [&](const double *x, double *r) -> double {
         int st = launch_spmv(op, x, dax.get(), 0, s);
         if (st != SPL_OK) throw DeviceError{st};
+        hipLaunchKernelGGL(abs_spmv_kernel, dim3((unsigned)(((size_t)n * 8 + 255) / 256)), dim3(256), 0, s, n,
+                           op->rowptr64.get(), op->colidx.get(), op->val.get(), x, dabs.get());
         SPL_HIP(hipMemsetAsync(dnorm.get(), 0, sizeof(double), s));
-        hipLaunchKernelGGL(residual_kernel, dim3(grid), dim3(256), 0, s, n, db.get(), dax.get(), r, dnorm.get());
+        hipLaunchKernelGGL(residual_kernel, dim3(grid), dim3(256), 0, s, n, db.get(), dax.get(), dabs.get(), r,
+                           dnorm.get());
         double h = 0.0;
         SPL_HIP(hipMemcpyAsync(&h, dnorm.get(), sizeof(double), hipMemcpyDeviceToHost, s));
         SPL_HIP(hipStreamSynchronize(s));
         return h;
       };
-      // iterative refinement, UMFPACK default irstep = 2: keep a step only if it lowers ||b - op(A) x||
-      double rnorm = residual_norm(dx.get(), dr.get());
+      // Iterative refinement with UMFPACK's defaults and stopping rules (irstep = 2; umf_solve):
+      // stop when the componentwise backward error is below machine epsilon, or when a step does
+      // not at least halve it (a step that raises it is undone).
+      const double eps = 2.220446049250313e-16;
+      double omega = backward_error(dx.get(), dr.get());
       DBuf<double> dxn((size_t)n), drn((size_t)n);
-      for (int it = 0; it < 2 && rnorm > 0.0; ++it) {
+      for (int it = 0; it < 2 && omega >= eps; ++it) {
         factor_solve(N, sys, dr.get(), dd.get(), dwork.get(), s);
         SPL_HIP(hipMemcpyAsync(dxn.get(), dx.get(), (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(add_kernel, dim3(grid), dim3(256), 0, s, n, dxn.get(), dd.get());
-        const double rn = residual_norm(dxn.get(), drn.get());
-        if (!(rn < rnorm)) break;
+        const double on = backward_error(dxn.get(), drn.get());
+        if (!(on <= omega)) break;  // worse (or NaN): keep the previous iterate
         std::swap(dx.p, dxn.p);
         std::swap(dr.p, drn.p);
-        rnorm = rn;
+        const bool stagnated = on > omega / 2;
+        omega = on;
+        if (stagnated) break;
       }
     }
     SPL_HIP(hipMemcpyAsync(X, dx.get(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
