@@ -13,17 +13,23 @@
 // accumulator per column is replaced by work proportional to the column's number of
 // intermediate products P_j (an upper bound of its nnz), by which columns are binned:
 //   bin S  P <= 256    one wavefront per column   (4 columns per workgroup, no barrier)
-//   bin M  P <= 2048   one workgroup per column, 3 workgroups per CU
-//   bin X  P <= 4096   one workgroup per column, 1 workgroup per CU
+//   bin M  P <= 2048   one workgroup per column (<= 256 entries in the column of B), 8 per CU
+//   bin X  P <= 4096   one workgroup per column, 1-3 workgroups per CU
 //   bin L  more        one workgroup per column, dense accumulator in HBM from a small pool
 //                      (the reference's own data structure, only for the heavy columns)
 // ESC step for bins S/M/X: (1) the column's B entries and the extents of the A columns they
 // select are staged in LDS and prefix-summed, so product t of the column is found by a binary
 // search — ALL products of the column are gathered from HBM at once (no dependent chain per
-// k); (2) (row, t) keys and a*b values are bitonic-sorted in LDS (t = position in k-then-row
-// order breaks ties, which keeps equal rows in ascending-k order); (3) each run of equal rows
-// is summed left to right by its first element and written, already in ascending row order.
-// Two passes (symbolic: 32-bit keys, count distinct; 64-bit exclusive scan; numeric).
+// k); (2) the keys (row, t) — t = position in k-then-row order breaks ties, which keeps equal
+// rows in ascending-k order — are sorted in LDS: the products of one B entry are a column of
+// A, already ascending, so 32-bit keys go through a merge tree over these runs (merge-path);
+// 64-bit keys (more rows than 31 - log2 P bits) through a bitonic network with their values;
+// (3) each run of equal rows is summed left to right by its first element and written, already
+// in ascending row order.  With 32-bit keys the products a*b are NOT kept in LDS: the kernel is
+// latency-bound, LDS per column sets the workgroups per CU, and a run head recomputes its
+// products from operands the expansion has just pulled into L2.
+// One pass when 24 B x products fits in half of the free HBM (every column is written at its
+// upper-bound slot, one copy compacts); otherwise symbolic (count distinct) + scan + numeric.
 // HBM/latency-bound integer + fp64 work; no MFMA (no dense contraction).
 #include "common.hpp"
 
@@ -32,7 +38,7 @@ namespace spl {
 namespace {
 
 constexpr int kSmallProducts = 256;
-constexpr int kMediumProducts = 2048, kMediumB = 1024;
+constexpr int kMediumProducts = 2048, kMediumB = 256;
 constexpr int kLargeProducts = 4096, kLargeB = 2048;
 constexpr int kMaxPool = 512;
 
@@ -75,12 +81,26 @@ __global__ __launch_bounds__(256) void products_kernel(Csc A, Csc B, int64_t nco
   n += __shfl_xor(n, 1, 64);
   n += __shfl_xor(n, 2, 64);
   n += __shfl_xor(n, 4, 64);
-  if (g >= ncolsB || sub != 0) return;
-  nprod[j] = n;
-  const int bin = bin_of(n, qe - qs);
-  if (bin == 2) medium_list[atomicAdd(&list_counts[0], 1)] = j;
-  else if (bin == 3) xlarge_list[atomicAdd(&list_counts[1], 1)] = j;
-  else if (bin == 4) dense_list[atomicAdd(&list_counts[2], 1)] = j;
+  // bin lists: one global atomic per workgroup and bin (a million columns of one bin would
+  // otherwise serialise on one address), positions inside the workgroup from LDS counters
+  __shared__ int local_count[3], base[3];
+  if (threadIdx.x < 3) local_count[threadIdx.x] = 0;
+  __syncthreads();
+  const bool owner = g < ncolsB && sub == 0;
+  int bin = 0, pos = 0;
+  if (owner) {
+    nprod[j] = n;
+    bin = bin_of(n, qe - qs);
+    if (bin >= 2) pos = atomicAdd(&local_count[bin - 2], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 && local_count[threadIdx.x] > 0)
+    base[threadIdx.x] = atomicAdd(&list_counts[threadIdx.x], local_count[threadIdx.x]);
+  __syncthreads();
+  if (owner && bin >= 2) {
+    int64_t *list = bin == 2 ? medium_list : bin == 3 ? xlarge_list : dense_list;
+    list[base[bin - 2] + pos] = j;
+  }
 }
 
 template <int NT>
@@ -97,12 +117,15 @@ constexpr int ilog2_ceil(int v) { return v <= 1 ? 0 : 1 + ilog2_ceil((v + 1) / 2
 template <int CAP, int NBCAP, bool NUMERIC, bool KEY32 = false>
 struct EscLds {
   static constexpr size_t key_bytes = (NUMERIC && !KEY32) ? CAP * sizeof(int64_t) : CAP * sizeof(int);
-  static constexpr size_t val_bytes = NUMERIC ? CAP * sizeof(double) : 0;
+  static constexpr size_t val_bytes = (NUMERIC && !KEY32) ? CAP * sizeof(double) : 0;  // 32-bit keys: see fold
   static constexpr size_t kb_bytes = NUMERIC ? NBCAP * sizeof(double) : 0;
   static constexpr size_t start_bytes = NBCAP * sizeof(int);
   static constexpr size_t off_bytes = (NBCAP + 8) * sizeof(int);
   static constexpr size_t scratch_bytes = 16 * sizeof(int);
-  static constexpr size_t total = key_bytes + val_bytes + kb_bytes + start_bytes + off_bytes + scratch_bytes;
+  // second key buffer of the merge tree (32-bit keys only; 64-bit keys take the bitonic network)
+  static constexpr size_t key2_bytes = (NUMERIC && !KEY32) ? 0 : CAP * sizeof(int);
+  static constexpr size_t total =
+      key_bytes + val_bytes + kb_bytes + start_bytes + off_bytes + scratch_bytes + key2_bytes;
 };
 
 // expand - sort - compress for ONE column j with np products and nb entries in B[:,j];
@@ -121,6 +144,7 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
   int *kstart = reinterpret_cast<int *>(lds + L::key_bytes + L::val_bytes + L::kb_bytes);
   int *koff = reinterpret_cast<int *>(lds + L::key_bytes + L::val_bytes + L::kb_bytes + L::start_bytes);
   int *scratch = koff + NBCAP + 8;
+  int *key32b = scratch + 16;  // only when !K64
   const int lane = tid & 63;
   const int qs = B.p[j];
   const int nb = B.p[j + 1] - qs;
@@ -165,50 +189,120 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
   }
   group_sync<NT>();
 
-  // (2) expand: every product of the column is fetched independently
-  for (int t = tid; t < np; t += NT) {
-    int lo = 0, hi = nb - 1;  // largest q with koff[q] <= t
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (koff[mid] <= t) lo = mid; else hi = mid - 1;
+  // (2) expand: every product of the column is fetched independently; a thread first locates all
+  // of its products, then issues all of its loads, so that their latencies overlap
+  {
+    constexpr int PER = CAP / NT;
+    int pp[PER], src[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int t = tid + u * NT;
+      pp[u] = -1;
+      src[u] = 0;
+      if (t < np) {
+        int lo = 0, hi = nb - 1;  // largest q with koff[q] <= t
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (koff[mid] <= t) lo = mid; else hi = mid - 1;
+        }
+        pp[u] = kstart[lo] + (t - koff[lo]);
+        src[u] = lo;
+      }
     }
-    const int p = kstart[lo] + (t - koff[lo]);
-    const int row = A.i[p];
-    if (K64) {
-      key64[t] = ((int64_t)row << 32) | (int64_t)t;  // ties: ascending t = ascending k
-      vals[t] = A.x[p] * kb[lo];                     // a * b
-    } else if (NUMERIC) {
-      key32[t] = (row << TB) | t;
-      vals[t] = A.x[p] * kb[lo];
-    } else {
-      key32[t] = row;
+    int rows[PER];
+    double av[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      rows[u] = pp[u] >= 0 ? A.i[pp[u]] : 0;
+      av[u] = (K64 && pp[u] >= 0) ? A.x[pp[u]] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int t = tid + u * NT;
+      if (pp[u] >= 0) {
+        if (K64) {
+          key64[t] = ((int64_t)rows[u] << 32) | (int64_t)t;  // ties: ascending t = ascending k
+          vals[t] = av[u] * kb[src[u]];                       // a * b
+        } else if (NUMERIC) {
+          key32[t] = (rows[u] << TB) | t;
+        } else {
+          key32[t] = rows[u];
+        }
+      }
     }
   }
   group_sync<NT>();
 
-  // (3) bitonic sort, ascending-only network; pairs whose upper index is >= np are skipped
-  int n2 = 2;
-  while (n2 < np) n2 <<= 1;
-  for (int size = 2; size <= n2; size <<= 1) {
-    for (int jj = size >> 1; jj > 0; jj >>= 1) {
-      const bool flip = (jj == (size >> 1));
-      for (int t = tid; t < (n2 >> 1); t += NT) {
-        const int lo = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
-        const int hi = flip ? (lo ^ (size - 1)) : (lo | jj);
-        if (hi < np) {
-          if (K64) {
+  // (3) sort.  The products of one B entry are a column of A, already ascending by row, and the
+  // expansion laid these nb runs out one after the other, so 32-bit keys are sorted by a merge
+  // tree: ceil(log2 nb) levels of pairwise merges, every thread producing E consecutive outputs
+  // of a level (merge-path search for its start, then a sequential merge).  That is ~5 LDS
+  // accesses per product and level instead of the 2 x 66 of a bitonic network over 2048 keys.
+  // E is odd so that the output chunks of a wavefront fall into different LDS banks.
+  const int *skeys = key32;  // where the sorted 32-bit keys end up
+  if (!K64) {
+    constexpr int E = CAP / NT + 1;
+    int *src = key32, *dst = key32b;
+    for (int width = 1; width < nb; width <<= 1) {
+      for (int c0 = tid * E; c0 < np; c0 += NT * E) {
+        int pos = c0;
+        const int end = min(np, c0 + E);
+        while (pos < end) {
+          int lq = 0, hq = nb - 1;  // run holding output position pos: largest q with koff[q] <= pos
+          while (lq < hq) {
+            const int mid = (lq + hq + 1) >> 1;
+            if (koff[mid] <= pos) lq = mid; else hq = mid - 1;
+          }
+          const int g0 = lq & ~(2 * width - 1);
+          const int a0 = koff[g0], a1 = koff[min(nb, g0 + width)], b1 = koff[min(nb, g0 + 2 * width)];
+          const int d = pos - a0;  // outputs of this pair before pos
+          int lo = max(0, d - (b1 - a1)), hi = min(d, a1 - a0);
+          while (lo < hi) {  // merge path: how many of the first d outputs come from the left run
+            const int mid = (lo + hi) >> 1;
+            if (src[a0 + mid] <= src[a1 + d - mid - 1]) lo = mid + 1; else hi = mid;
+          }
+          int ia = a0 + lo, ib = a1 + d - lo;
+          const int stop = min(end, b1);
+          int ka = ia < a1 ? src[ia] : 0x7fffffff, kb2 = ib < b1 ? src[ib] : 0x7fffffff;
+          for (; pos < stop; ++pos) {
+            if (ia < a1 && (ib >= b1 || ka <= kb2)) {
+              dst[pos] = ka;
+              ++ia;
+              ka = ia < a1 ? src[ia] : 0x7fffffff;
+            } else {
+              dst[pos] = kb2;
+              ++ib;
+              kb2 = ib < b1 ? src[ib] : 0x7fffffff;
+            }
+          }
+        }
+      }
+      group_sync<NT>();
+      int *tmp = src;
+      src = dst;
+      dst = tmp;
+    }
+    skeys = src;
+  } else {
+    // 64-bit keys: bitonic sort, ascending-only network; pairs whose upper index is >= np are skipped
+    int n2 = 2;
+    while (n2 < np) n2 <<= 1;
+    for (int size = 2; size <= n2; size <<= 1) {
+      for (int jj = size >> 1; jj > 0; jj >>= 1) {
+        const bool flip = (jj == (size >> 1));
+        for (int t = tid; t < (n2 >> 1); t += NT) {
+          const int lo = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+          const int hi = flip ? (lo ^ (size - 1)) : (lo | jj);
+          if (hi < np) {
             const int64_t ka = key64[lo], kb2 = key64[hi];
             if (kb2 < ka) {
               key64[lo] = kb2; key64[hi] = ka;
               const double va = vals[lo]; vals[lo] = vals[hi]; vals[hi] = va;
             }
-          } else {
-            const int ka = key32[lo], kb2 = key32[hi];
-            if (kb2 < ka) { key32[lo] = kb2; key32[hi] = ka; }
           }
         }
+        group_sync<NT>();
       }
-      group_sync<NT>();
     }
   }
 
@@ -220,8 +314,8 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
     int row = 0;
     bool head = false;
     if (t < np) {
-      row = K64 ? (int)(key64[t] >> 32) : NUMERIC ? (key32[t] >> TB) : key32[t];
-      const int prev = t > 0 ? (K64 ? (int)(key64[t - 1] >> 32) : NUMERIC ? (key32[t - 1] >> TB) : key32[t - 1]) : -1;
+      row = K64 ? (int)(key64[t] >> 32) : NUMERIC ? (skeys[t] >> TB) : skeys[t];
+      const int prev = t > 0 ? (K64 ? (int)(key64[t - 1] >> 32) : NUMERIC ? (skeys[t - 1] >> TB) : skeys[t - 1]) : -1;
       head = (t == 0) || (row != prev);
     }
     const unsigned long long m = __ballot(head);
@@ -242,14 +336,25 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
       if (K64) {
         for (int u = t; u < np && (int)(key64[u] >> 32) == row; ++u) acc = acc + vals[u];  // c + a * b
       } else {
-        for (int u = t; u < np && (key32[u] >> TB) == row; ++u) acc = acc + vals[key32[u] & ((1 << TB) - 1)];
+        // 32-bit keys: the products are not kept in LDS (the kernel is latency-bound and the 8 bytes
+        // per product would halve the workgroups per CU); a run head recomputes a * b of its run
+        // from the operands, which the expansion has just pulled into L2
+        for (int u = t; u < np && (skeys[u] >> TB) == row; ++u) {
+          const int tt = skeys[u] & ((1 << TB) - 1);
+          int lo = 0, hi = nb - 1;  // largest q with koff[q] <= tt
+          while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (koff[mid] <= tt) lo = mid; else hi = mid - 1;
+          }
+          acc = acc + A.x[kstart[lo] + (tt - koff[lo])] * kb[lo];  // c + a * b
+        }
       }
       Ci[base + off] = row;
       Cx[base + off] = acc;
     }
     running += total;
   }
-  if (!NUMERIC && tid == 0) counts[j] = running;
+  if (counts && tid == 0) counts[j] = running;
 }
 
 // bin S: one wavefront per column of B, four columns per workgroup
@@ -267,7 +372,7 @@ __global__ __launch_bounds__(256) void spgemm_wave_kernel(Csc A, Csc B, int64_t 
   const int64_t np = nprod[j];
   if (np > kSmallProducts) return;
   if (np == 0) {
-    if (!NUMERIC && lane == 0) counts[j] = 0;
+    if (counts && lane == 0) counts[j] = 0;
     return;
   }
   esc_column<64, kSmallProducts, kSmallProducts, NUMERIC, KEY32>(A, B, j, (int)np, lds_all[wave], lane, counts,
@@ -338,8 +443,24 @@ __global__ __launch_bounds__(256) void spgemm_dense_kernel(Csc A, Csc B, int64_t
       if (threadIdx.x == 0) running += wave_counts[0] + wave_counts[1] + wave_counts[2] + wave_counts[3];
       __syncthreads();
     }
-    if (!NUMERIC && threadIdx.x == 0) counts[j] = (int)running;
+    if (counts && threadIdx.x == 0) counts[j] = (int)running;
     __syncthreads();
+  }
+}
+
+// single-pass mode: column j was written at its upper-bound slot (offset = products before j);
+// one wavefront per column moves it to its final place
+__global__ __launch_bounds__(256) void compact_columns_kernel(int64_t ncols, const int64_t *__restrict__ slot,
+                                                              const int64_t *__restrict__ Cp,
+                                                              const int *__restrict__ Ti, const double *__restrict__ Tx,
+                                                              int *__restrict__ Ci, double *__restrict__ Cx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= ncols) return;
+  const int64_t src = slot[j], dst = Cp[j], len = Cp[j + 1] - dst;
+  for (int64_t t = lane; t < len; t += 64) {
+    Ci[dst + t] = Ti[src + t];
+    Cx[dst + t] = Tx[src + t];
   }
 }
 
@@ -371,10 +492,22 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 3 * sizeof(int), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
   const int nmedium = hc[0], nxlarge = hc[1], ndense = hc[2];
-  if (products) {
-    DBuf<int64_t> pscan((size_t)ncolsB + 1);
-    exclusive_scan_i64(nprod.get(), pscan.get(), ncolsB, s);
-    SPL_HIP(hipMemcpy(products, pscan.get() + ncolsB, sizeof(int64_t), hipMemcpyDeviceToHost));
+  DBuf<int64_t> pscan((size_t)ncolsB + 1);  // products before column j: its upper-bound output slot
+  exclusive_scan_i64(nprod.get(), pscan.get(), ncolsB, s);
+  int64_t total_products = 0;
+  SPL_HIP(hipMemcpy(&total_products, pscan.get() + ncolsB, sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (products) *products = total_products;
+  // Single pass when the upper bound nnz(C) <= products fits comfortably in HBM: the numeric
+  // kernels write every column at its slot and report its length, one copy compacts.  This
+  // skips the symbolic pass (a second expand + sort of every column).  SPL_SPGEMM_TWO_PASS=1
+  // forces the symbolic + numeric form.
+  bool single_pass = false;
+  {
+    size_t free_b = 0, total_b = 0;
+    SPL_HIP(hipMemGetInfo(&free_b, &total_b));
+    const char *force = getenv("SPL_SPGEMM_TWO_PASS");
+    single_pass = !(force && force[0] == '1') && total_products > 0 &&
+                  (double)total_products * 24.0 < 0.5 * (double)free_b;
   }
   typedef EscLds<kMediumProducts, kMediumB, false> LMs;
   typedef EscLds<kLargeProducts, kLargeB, false> LXs;
@@ -408,38 +541,56 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     SPL_HIP(hipMemsetAsync(pool_vals.get(), 0, (size_t)pool * (size_t)nrowsA * sizeof(double), s));
   }
 
-  // ---- symbolic: nnz per column
-  hipLaunchKernelGGL((spgemm_wave_kernel<false, false>), dim3(blocks_for(ncolsB, 4)), dim3(256), 0, s, A, B, ncolsB,
-                     nprod.get(), counts.get(), (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
-  if (nmedium > 0)
-    hipLaunchKernelGGL((spgemm_block_kernel<kMediumProducts, kMediumB, false, false>), dim3((unsigned)nmedium), dim3(256),
-                       LMs::total, s, A, B, medium_list.get(), nprod.get(), counts.get(),
-                       (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
-  if (nxlarge > 0)
-    hipLaunchKernelGGL((spgemm_block_kernel<kLargeProducts, kLargeB, false, false>), dim3((unsigned)nxlarge), dim3(256),
-                       LXs::total, s, A, B, xlarge_list.get(), nprod.get(), counts.get(),
-                       (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
-  if (ndense > 0)
-    hipLaunchKernelGGL(spgemm_dense_kernel<false>, dim3((unsigned)pool), dim3(256), 0, s, A, B, nrowsA,
-                       dense_list.get(), ndense, pool_flags.get(), (double *)nullptr, counts.get(),
-                       (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
-  exclusive_scan_i32_to_i64(counts.get(), Cp.get(), ncolsB, s);
-  int64_t nz = 0;
-  SPL_HIP(hipMemcpyAsync(&nz, Cp.get() + ncolsB, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-  SPL_HIP(hipStreamSynchronize(s));
-  Ci.alloc((size_t)nz);
-  Cx.alloc((size_t)nz);
-  *nnzC = nz;
-  if (nz == 0) return;
+  DBuf<int> Ti;
+  DBuf<double> Tx;
+  const int64_t *slots = Cp.get();  // where the numeric kernels write column j
+  int *out_i = nullptr;
+  double *out_x = nullptr;
+  int *numeric_counts = nullptr;
+  if (single_pass) {
+    Ti.alloc((size_t)total_products);
+    Tx.alloc((size_t)total_products);
+    slots = pscan.get();
+    out_i = Ti.get();
+    out_x = Tx.get();
+    numeric_counts = counts.get();
+  } else {
+    // ---- symbolic: nnz per column
+    hipLaunchKernelGGL((spgemm_wave_kernel<false, false>), dim3(blocks_for(ncolsB, 4)), dim3(256), 0, s, A, B,
+                       ncolsB, nprod.get(), counts.get(), (const int64_t *)nullptr, (int *)nullptr,
+                       (double *)nullptr);
+    if (nmedium > 0)
+      hipLaunchKernelGGL((spgemm_block_kernel<kMediumProducts, kMediumB, false, false>), dim3((unsigned)nmedium),
+                         dim3(256), LMs::total, s, A, B, medium_list.get(), nprod.get(), counts.get(),
+                         (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
+    if (nxlarge > 0)
+      hipLaunchKernelGGL((spgemm_block_kernel<kLargeProducts, kLargeB, false, false>), dim3((unsigned)nxlarge),
+                         dim3(256), LXs::total, s, A, B, xlarge_list.get(), nprod.get(), counts.get(),
+                         (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
+    if (ndense > 0)
+      hipLaunchKernelGGL(spgemm_dense_kernel<false>, dim3((unsigned)pool), dim3(256), 0, s, A, B, nrowsA,
+                         dense_list.get(), ndense, pool_flags.get(), (double *)nullptr, counts.get(),
+                         (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
+    exclusive_scan_i32_to_i64(counts.get(), Cp.get(), ncolsB, s);
+    int64_t nz = 0;
+    SPL_HIP(hipMemcpyAsync(&nz, Cp.get() + ncolsB, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipStreamSynchronize(s));
+    Ci.alloc((size_t)nz);
+    Cx.alloc((size_t)nz);
+    *nnzC = nz;
+    if (nz == 0) return;
+    out_i = Ci.get();
+    out_x = Cx.get();
+  }
 
   // ---- numeric: every path writes its column already sorted by row
 #define SPL_NUMERIC_WAVE(K32)                                                                                  \
   hipLaunchKernelGGL((spgemm_wave_kernel<true, K32>), dim3(blocks_for(ncolsB, 4)), dim3(256), 0, s, A, B, ncolsB, \
-                     nprod.get(), (int *)nullptr, Cp.get(), Ci.get(), Cx.get())
+                     nprod.get(), numeric_counts, slots, out_i, out_x)
 #define SPL_NUMERIC_BLOCK(CAP, NBCAP, K32, LIST, COUNT)                                                        \
   hipLaunchKernelGGL((spgemm_block_kernel<CAP, NBCAP, true, K32>), dim3((unsigned)(COUNT)), dim3(256),         \
-                     (EscLds<CAP, NBCAP, true, K32>::total), s, A, B, LIST.get(), nprod.get(), (int *)nullptr,  \
-                     Cp.get(), Ci.get(), Cx.get())
+                     (EscLds<CAP, NBCAP, true, K32>::total), s, A, B, LIST.get(), nprod.get(), numeric_counts,   \
+                     slots, out_i, out_x)
   if (key32_s) SPL_NUMERIC_WAVE(true); else SPL_NUMERIC_WAVE(false);
   if (nmedium > 0) {
     if (key32_m) SPL_NUMERIC_BLOCK(kMediumProducts, kMediumB, true, medium_list, nmedium);
@@ -453,8 +604,25 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
 #undef SPL_NUMERIC_BLOCK
   if (ndense > 0)
     hipLaunchKernelGGL(spgemm_dense_kernel<true>, dim3((unsigned)pool), dim3(256), 0, s, A, B, nrowsA,
-                       dense_list.get(), ndense, pool_flags.get(), pool_vals.get(), (int *)nullptr, Cp.get(),
-                       Ci.get(), Cx.get());
+                       dense_list.get(), ndense, pool_flags.get(), pool_vals.get(), numeric_counts, slots, out_i,
+                       out_x);
+  if (single_pass) {
+    exclusive_scan_i32_to_i64(counts.get(), Cp.get(), ncolsB, s);
+    int64_t nz = 0;
+    SPL_HIP(hipMemcpyAsync(&nz, Cp.get() + ncolsB, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipStreamSynchronize(s));
+    *nnzC = nz;
+    if (nz == total_products) {  // no column compressed: the slots are the final layout
+      Ci = std::move(Ti);
+      Cx = std::move(Tx);
+    } else {
+      Ci.alloc((size_t)nz);
+      Cx.alloc((size_t)nz);
+      if (nz > 0)
+        hipLaunchKernelGGL(compact_columns_kernel, dim3(blocks_for(ncolsB, 4)), dim3(256), 0, s, ncolsB, pscan.get(),
+                           Cp.get(), Ti.get(), Tx.get(), Ci.get(), Cx.get());
+    }
+  }
   SPL_HIP(hipGetLastError());
   SPL_HIP(hipStreamSynchronize(s));
 }
