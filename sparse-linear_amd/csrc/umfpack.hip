@@ -20,6 +20,7 @@
 // A fill-reducing multifrontal ordering is the next step.
 #include <stdio.h>
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -47,7 +48,12 @@ struct Numeric {
   int device = 0;
   int n = 0, kl = 0, ku = 0, ldab = 1;
   int singular = 0;
-  int nopiv = 0;  // 1: blocked factorisation without interchanges (column diagonally dominant A)
+  int nopiv = 0;  // 1: blocked factorisation without interchanges
+  // 1: the matrix is NOT diagonally dominant by columns and the no-interchange factors are a
+  // speculation; solve checks the backward error it computes anyway and, if it is not at
+  // rounding level, refactors with partial pivoting (under `mu`) and solves again
+  int speculative = 0;
+  std::mutex mu;
   DBuf<double> AB;
   DBuf<double> blkinv;  // no-pivot path: inv(L11), inv(U11) of every diagonal block
   DBuf<int> ipiv, perm, inv;
@@ -414,6 +420,56 @@ void factor_solve(const Numeric *N, int sys, const double *d_b, double *d_x, dou
   hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(256), 0, s, n, N->inv.get(), d_work, d_x);  // x[i] = z[inv[i]]
 }
 
+// (re)build the band factors of P A P^T from the device copy of A^T's rows (= the CSC arrays);
+// nopiv selects the blocked no-interchange factorisation (band_nopiv.hip) or LAPACK-style
+// partial pivoting.  Throws DeviceError; sets N->singular.
+void factor_band(Numeric *N, bool nopiv, hipStream_t s) {
+  const int n = N->n;
+  N->nopiv = nopiv ? 1 : 0;
+  N->ldab = nopiv ? band_nopiv_ldab(N->kl, N->ku) : (2 * N->kl + N->ku + 1);
+  const size_t band_elems = (size_t)N->ldab * (size_t)n;
+  N->AB.release();
+  N->blkinv.release();
+  size_t free_b = 0, total_b = 0;
+  SPL_HIP(hipMemGetInfo(&free_b, &total_b));
+  if (band_elems * sizeof(double) > free_b - free_b / 8) throw DeviceError{SPL_ERROR_out_of_memory};  // too wide
+  N->AB.alloc(band_elems);
+  SPL_HIP(hipMemsetAsync(N->AB.get(), 0, band_elems * sizeof(double), s));
+  if (nopiv) {
+    N->blkinv.alloc(band_nopiv_inverse_elems(n));
+    N->singular = band_nopiv_factor(n, N->kl, N->ku, N->ldab, N->AB.get(), N->blkinv.get(), N->At->rowptr.get(),
+                                    N->At->colidx.get(), N->At->val.get(), N->inv.get(), s);
+    return;
+  }
+  // scatter P A P^T into band storage (reads the CSC arrays the At handle already holds)
+  const int kv = N->kl + N->ku;
+  if (N->At->nnz > 0)
+    hipLaunchKernelGGL(band_scatter_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, n, N->At->rowptr.get(),
+                       N->At->colidx.get(), N->At->val.get(), N->inv.get(), kv, N->ldab, N->AB.get());
+  DBuf<BandState> state(1);
+  SPL_HIP(hipMemsetAsync(state.get(), 0, sizeof(BandState), s));
+  const int64_t work_per_col = (int64_t)(N->kl) * (int64_t)(kv + 1);
+  if (work_per_col <= 16384) {
+    hipLaunchKernelGGL(band_lu_fused_kernel, dim3(1), dim3(1024), 0, s, n, N->kl, N->ku, N->ldab, N->AB.get(),
+                       N->ipiv.get(), state.get());
+  } else {
+    for (int j = 0; j < n; ++j) {
+      hipLaunchKernelGGL(band_pivot_kernel, dim3(1), dim3(256), 0, s, j, n, N->kl, N->ku, N->ldab, N->AB.get(),
+                         N->ipiv.get(), state.get());
+      const int km = std::min(N->kl, n - 1 - j);
+      const int width = std::min(kv, n - 1 - j);
+      if (km > 0 && width > 0)
+        hipLaunchKernelGGL(band_update_kernel, dim3((unsigned)((km + 255) / 256), (unsigned)width), dim3(256), 0, s,
+                           j, n, N->kl, N->ku, N->ldab, N->AB.get(), state.get());
+    }
+  }
+  BandState hs;
+  SPL_HIP(hipMemcpyAsync(&hs, state.get(), sizeof(BandState), hipMemcpyDeviceToHost, s));
+  SPL_HIP(hipStreamSynchronize(s));
+  SPL_HIP(hipGetLastError());
+  N->singular = hs.singular;
+}
+
 }  // namespace
 }  // namespace spl
 
@@ -493,20 +549,6 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
     }
     N->At = static_cast<Matrix *>(hAt);
     if (!N->At->rowptr.get()) { delete N; return UMFPACK_ERROR_out_of_memory; }
-    const char *force = getenv("SPL_LU_FORCE_PIVOT");
-    N->nopiv = (!(force && force[0] == '1') &&
-                band_is_column_dominant(n, N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), s)) ? 1 : 0;
-    N->ldab = N->nopiv ? band_nopiv_ldab(S->kl, S->ku) : (2 * S->kl + S->ku + 1);
-    const size_t band_elems = (size_t)N->ldab * (size_t)n;
-    size_t free_b = 0, total_b = 0;
-    SPL_HIP(hipMemGetInfo(&free_b, &total_b));
-    if (band_elems * sizeof(double) > free_b - free_b / 8) {  // profile too wide for this HBM
-      delete N;
-      return UMFPACK_ERROR_out_of_memory;
-    }
-    N->AB.alloc(band_elems);
-    if (N->nopiv) N->blkinv.alloc(band_nopiv_inverse_elems(n));
-    SPL_HIP(hipMemsetAsync(N->AB.get(), 0, band_elems * sizeof(double), s));
     N->ipiv.alloc((size_t)n);
     N->perm.alloc((size_t)n);
     N->inv.alloc((size_t)n);
@@ -523,40 +565,24 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
              : st == SPL_ERROR_invalid_matrix ? UMFPACK_ERROR_invalid_matrix : UMFPACK_ERROR_internal_error;
     }
     N->A = static_cast<Matrix *>(hA);
-    if (N->nopiv) {
-      N->singular = band_nopiv_factor(n, N->kl, N->ku, N->ldab, N->AB.get(), N->blkinv.get(), N->At->rowptr.get(), N->At->colidx.get(),
-                                      N->At->val.get(), N->inv.get(), s);
-      *NumericOut = N;
-      return N->singular ? UMFPACK_WARNING_singular_matrix : UMFPACK_OK;
-    }
-    // scatter P A P^T into band storage (reads the CSC arrays the At handle already holds)
-    const int kv = N->kl + N->ku;
-    if (N->At->nnz > 0)
-      hipLaunchKernelGGL(band_scatter_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, n,
-                         N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), N->inv.get(), kv, N->ldab,
-                         N->AB.get());
-    DBuf<BandState> state(1);
-    SPL_HIP(hipMemsetAsync(state.get(), 0, sizeof(BandState), s));
-    const int64_t work_per_col = (int64_t)(N->kl) * (int64_t)(kv + 1);
-    if (work_per_col <= 16384) {
-      hipLaunchKernelGGL(band_lu_fused_kernel, dim3(1), dim3(1024), 0, s, n, N->kl, N->ku, N->ldab,
-                         N->AB.get(), N->ipiv.get(), state.get());
-    } else {
-      for (int j = 0; j < n; ++j) {
-        hipLaunchKernelGGL(band_pivot_kernel, dim3(1), dim3(256), 0, s, j, n, N->kl, N->ku, N->ldab,
-                           N->AB.get(), N->ipiv.get(), state.get());
-        const int km = std::min(N->kl, n - 1 - j);
-        const int width = std::min(kv, n - 1 - j);
-        if (km > 0 && width > 0)
-          hipLaunchKernelGGL(band_update_kernel, dim3((unsigned)((km + 255) / 256), (unsigned)width), dim3(256),
-                             0, s, j, n, N->kl, N->ku, N->ldab, N->AB.get(), state.get());
+    // Path: SPL_LU_FORCE_PIVOT=1 -> partial pivoting; =0 -> only provably safe no-interchange
+    // factors (column diagonal dominance); default -> no-interchange factors for every matrix,
+    // as a speculation when dominance does not hold (checked by every solve, see Numeric).
+    const char *force = getenv("SPL_LU_FORCE_PIVOT");
+    const bool force_pivot = force && force[0] == '1', no_speculation = force && force[0] == '0';
+    bool dominant = false;
+    if (!force_pivot)
+      dominant = band_is_column_dominant(n, N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), s);
+    if (!force_pivot && (dominant || !no_speculation)) {
+      factor_band(N, true, s);
+      N->speculative = dominant ? 0 : 1;
+      if (N->speculative && N->singular) {  // a zero pivot without interchanges proves nothing
+        N->speculative = 0;
+        factor_band(N, false, s);
       }
+    } else {
+      factor_band(N, false, s);
     }
-    BandState hs;
-    SPL_HIP(hipMemcpyAsync(&hs, state.get(), sizeof(BandState), hipMemcpyDeviceToHost, s));
-    SPL_HIP(hipStreamSynchronize(s));
-    SPL_HIP(hipGetLastError());
-    N->singular = hs.singular;
     *NumericOut = N;
     return N->singular ? UMFPACK_WARNING_singular_matrix : UMFPACK_OK;
   } catch (const DeviceError &e) {
@@ -584,6 +610,11 @@ int umfpack_di_solve(int sys, const int Ap[], const int Ai[], const double Ax[],
     DBuf<double> db((size_t)n), dx((size_t)n), dwork((size_t)n), dr((size_t)n), dd((size_t)n), dax((size_t)n);
     DBuf<double> dnorm(1);
     SPL_HIP(hipMemcpyAsync(db.get(), B, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    // speculative factors may be replaced below: solves on such an object take turns
+    std::unique_lock<std::mutex> turn(N->mu, std::defer_lock);
+    if (N->speculative) turn.lock();
+    double omega = 0.0;
+  again:
     factor_solve(N, sys, db.get(), dx.get(), dwork.get(), s);
     if (!N->singular) {
       const Matrix *op = sys == UMFPACK_A ? N->A : N->At;
@@ -605,7 +636,7 @@ int umfpack_di_solve(int sys, const int Ap[], const int Ai[], const double Ax[],
       // stop when the componentwise backward error is below machine epsilon, or when a step does
       // not at least halve it (a step that raises it is undone).
       const double eps = 2.220446049250313e-16;
-      double omega = backward_error(dx.get(), dr.get());
+      omega = backward_error(dx.get(), dr.get());
       DBuf<double> dxn((size_t)n), drn((size_t)n);
       for (int it = 0; it < 2 && omega >= eps; ++it) {
         factor_solve(N, sys, dr.get(), dd.get(), dwork.get(), s);
@@ -618,6 +649,13 @@ int umfpack_di_solve(int sys, const int Ap[], const int Ai[], const double Ax[],
         const bool stagnated = on > omega / 2;
         omega = on;
         if (stagnated) break;
+      }
+      // no-interchange factors of a matrix without diagonal dominance: accepted only if the
+      // refined solution is backward stable to rounding level, as pivoted factors would make it
+      if (turn.owns_lock() && N->speculative && !(omega <= 1e-13)) {
+        N->speculative = 0;
+        factor_band(N, false, s);
+        goto again;
       }
     }
     SPL_HIP(hipMemcpyAsync(X, dx.get(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -635,6 +673,14 @@ int umfpack_di_solve(int sys, const int Ap[], const int Ai[], const double Ax[],
 int spl_umfpack_dimension(void *NumericIn) {
   Numeric *N = as_numeric(NumericIn);
   return N ? N->n : 0;
+}
+
+// which factorisation the object holds now: 0 partial pivoting, 1 no interchanges (diagonally
+// dominant matrix), 2 no interchanges as a speculation (see umfpack_hip.h); -1 if invalid
+int spl_umfpack_path(void *NumericIn) {
+  Numeric *N = as_numeric(NumericIn);
+  if (!N) return -1;
+  return N->nopiv ? (N->speculative ? 2 : 1) : 0;
 }
 
 void umfpack_di_free_symbolic(void **SymbolicIO) {

@@ -52,6 +52,8 @@ def _declare():
     L.umfpack_zi_free_numeric.argtypes = [C.POINTER(vp)]
     L.umfpack_zi_report_status.restype = None
     L.umfpack_zi_report_status.argtypes = [dp, i]
+    L.spl_umfpack_path.restype = i
+    L.spl_umfpack_path.argtypes = [vp]
     L._umf_declared = True
     return L
 
@@ -90,6 +92,12 @@ class Factors(_Handle):
     """newtype Factors a = Factors { fnum :: ForeignPtr (Numeric a) } (Umfpack.hs:58)"""
     status = 0
     complex = False
+
+    @property
+    def path(self):
+        """factorisation held now: 0 partial pivoting, 1 no interchanges (diagonally dominant),
+        2 no interchanges as a speculation that every solve checks (include/umfpack_hip.h)"""
+        return int(_declare().spl_umfpack_path(self.value))
 
 
 def analyze(mat):

@@ -158,3 +158,57 @@ def test_nopiv_path_unsymmetric_dominant_and_transposed(gpu, pkg, O):
             x = pkg.umfpack.linearSolve_(fact, mode, M, b)
             assert O.count_not_close(x, xs, 1e-10) == 0, (n, lo, hi, mode)
             assert O.count_not_close(x, spla.spsolve(op.tocsc(), b), 1e-10) == 0
+
+
+def test_speculative_no_interchange_path_spd(gpu, pkg, O):
+    """symmetric positive definite but NOT diagonally dominant (B^T B of a banded B): elimination
+    without interchanges is stable, the speculative path is taken and kept"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(23)
+    n = 600
+    Bm = sp.diags([rng.uniform(0.5, 1.5, n - abs(d)) for d in (-7, -1, 0, 1, 3)], (-7, -1, 0, 1, 3), format="csc")
+    S = (Bm.T @ Bm + 0.05 * sp.identity(n)).tocsc()
+    S.sort_indices()
+    assert np.any(np.abs(S.diagonal()) < np.asarray(abs(S).sum(axis=0)).ravel() - np.abs(S.diagonal()))
+    M = pkg.Matrix(n, n, S.indptr, S.indices, S.data)
+    xs = rng.uniform(0.5, 1.5, n)
+    fact = pkg.umfpack.factor(M, pkg.umfpack.analyze(M))
+    assert fact.path == 2
+    for mode in (0, 1):
+        b = S @ xs  # symmetric: same system both ways
+        x = pkg.umfpack.linearSolve_(fact, mode, M, b)
+        assert np.max(np.abs(S @ x - b)) / (np.max(np.abs(b)) + np.max(np.abs(x))) < 1e-13
+        assert np.max(np.abs(x - spla.spsolve(S, b))) / np.max(np.abs(xs)) < 1e-8
+    assert fact.path == 2  # the speculation held
+
+
+def test_speculation_that_fails_is_replaced_by_pivoting(gpu, pkg, O, monkeypatch):
+    """tiny (not zero) diagonal: the no-interchange factors exist but are useless; the solve
+    notices through the backward error, refactors with partial pivoting and answers correctly"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(29)
+    n = 300
+    # 2x2 diagonal blocks [[1e-14, 3], [3, 1e-14]] (well conditioned, but useless as pivots in
+    # the given order) plus a weak band coupling
+    off = np.zeros(n - 1)
+    off[0::2] = 3.0
+    S = sp.diags([off, np.full(n, 1e-14), off, rng.uniform(-0.1, 0.1, n - 2), rng.uniform(-0.1, 0.1, n - 5)],
+                 (-1, 0, 1, -2, 5), format="csc")
+    S.sort_indices()
+    M = pkg.Matrix(n, n, S.indptr, S.indices, S.data)
+    xs = rng.uniform(0.5, 1.5, n)
+    b = S @ xs
+    fact = pkg.umfpack.factor(M, pkg.umfpack.analyze(M))
+    assert fact.path == 2
+    x = pkg.umfpack.linearSolve_(fact, pkg.umfpack.UmfpackNormal, M, b)
+    assert fact.path == 0  # replaced
+    ref = spla.spsolve(S, b)
+    assert np.max(np.abs(S @ x - b)) / (np.max(np.abs(b)) + np.max(np.abs(x))) < 1e-12
+    assert np.max(np.abs(x - ref)) / np.max(np.abs(ref)) < 1e-8
+    xt = pkg.umfpack.linearSolve_(fact, pkg.umfpack.UmfpackTrans, M, S.T @ xs)
+    assert np.max(np.abs(S.T @ xt - S.T @ xs)) / np.max(np.abs(S.T @ xs)) < 1e-12
+    # SPL_LU_FORCE_PIVOT=0: no speculation, this matrix goes straight to partial pivoting
+    monkeypatch.setenv("SPL_LU_FORCE_PIVOT", "0")
+    assert pkg.umfpack.factor(M, pkg.umfpack.analyze(M)).path == 0
