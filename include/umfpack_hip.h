@@ -84,6 +84,19 @@ void umfpack_zi_free_symbolic(void **Symbolic);
 void umfpack_zi_free_numeric(void **Numeric);
 void umfpack_zi_report_status(const double Control[], int status);
 
+/* ---- batched linearSolve ------------------------------------------------------------------
+ * The reference's `linearSolve` (Umfpack.hs:103-108) maps `linearSolve_` over a list of
+ * right-hand sides, one umfpack_*_solve call each; FEAST solves a whole subspace that way
+ * (Feast.hs:197-201).  These entry points take all nrhs right-hand sides through the factors
+ * together (X and B are n x nrhs, column-major; complex ones packed when Xz = Bz = NULL): the
+ * blocked solves are latency-bound, so nrhs columns cost about as much as one.  Each column gets
+ * the same refinement as umfpack_*_solve; status as umfpack_*_solve. */
+int spl_umfpack_di_solve_many(int sys, const int Ap[], const int Ai[], const double Ax[], int nrhs, double X[],
+                              const double B[], void *Numeric);
+int spl_umfpack_zi_solve_many(int sys, const int Ap[], const int Ai[], const double Ax[], const double Az[],
+                              int nrhs, double Xx[], double Xz[], const double Bx[], const double Bz[],
+                              void *Numeric);
+
 /* dimension of the system a Numeric object factors (0 if invalid); helper of the zi wrappers */
 int spl_umfpack_dimension(void *Numeric);
 

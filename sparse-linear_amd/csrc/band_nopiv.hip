@@ -399,17 +399,20 @@ constexpr int SB = 4;
 // wider workgroup shortens every phase (more loads in flight per row).
 constexpr int SW = 16;
 
-// res[l] = sum_{t < nc} M(rb + l, cb + t) * vv[t], l < 64; M = matrix of the triangular system.
-// Untransposed (MODE 0/1) band storage runs down the rows: lane = row, wave q takes t = q mod SW,
-// partial sums meet in LDS.  Transposed (MODE 2/3) it runs along t: lanes along t, wave q takes
-// rows l = q mod SW, butterfly reduction.  Ends with the result visible to the whole workgroup.
-template <int MODE>
-__device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, const double *vv, double *res,
-                                       double (*part)[64]) {
+// res[l][r] = sum_{t < nc} M(rb + l, cb + t) * vv[t][r], l < 64, r < NR right-hand sides; M =
+// matrix of the triangular system.  Untransposed (MODE 0/1) band storage runs down the rows:
+// lane = row, wave q takes t = q mod SW, partial sums meet in LDS.  Transposed (MODE 2/3) it runs
+// along t: lanes along t, wave q takes rows l = q mod SW, butterfly reduction.  A band entry is
+// loaded once for all NR right-hand sides.  Ends with the result visible to the whole workgroup.
+template <int MODE, int NR>
+__device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, const double (*vv)[NR],
+                                       double (*res)[NR], double (*part)[64][NR]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (MODE <= 1) {
     const int i = rb + lane;
-    double s0 = 0.0, s1 = 0.0;
+    double acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = 0.0;
     if (i >= 0 && i < b.n) {
       int t = wave;
       for (; t + 7 * SW < nc; t += 8 * SW) {  // 8 independent loads in flight per lane
@@ -417,75 +420,105 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
 #pragma unroll
         for (int u = 0; u < 8; ++u) e[u] = b.get(i, cb + t + SW * u);
 #pragma unroll
-        for (int u = 0; u < 8; u += 2) {
-          s0 += e[u] * vv[t + SW * u];
-          s1 += e[u + 1] * vv[t + SW * u + SW];
-        }
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int r = 0; r < NR; ++r) acc[r] += e[u] * vv[t + SW * u][r];
       }
-      for (; t < nc; t += SW) s0 += b.get(i, cb + t) * vv[t];
+      for (; t < nc; t += SW) {
+        const double e = b.get(i, cb + t);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r] += e * vv[t][r];
+      }
     }
-    part[wave][lane] = s0 + s1;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) part[wave][lane][r] = acc[r];
     __syncthreads();
-    if (threadIdx.x < 64) {
+    for (int o = threadIdx.x; o < 64 * NR; o += SW * 64) {
+      const int l = o / NR, r = o % NR;
       double tot = 0.0;
 #pragma unroll
-      for (int q = 0; q < SW; ++q) tot += part[q][lane];
-      res[lane] = tot;
+      for (int q = 0; q < SW; ++q) tot += part[q][l][r];
+      res[l][r] = tot;
     }
   } else {
     for (int l = wave; l < 64; l += SW) {
       const int i = rb + l;
-      double sacc = 0.0;
-      if (i >= 0 && i < b.n)
-        for (int t = lane; t < nc; t += 64) sacc += b.get(cb + t, i) * vv[t];
+      double acc[NR];
 #pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
-      if (lane == 0) res[l] = sacc;
+      for (int r = 0; r < NR; ++r) acc[r] = 0.0;
+      if (i >= 0 && i < b.n)
+        for (int t = lane; t < nc; t += 64) {
+          const double e = b.get(cb + t, i);
+#pragma unroll
+          for (int r = 0; r < NR; ++r) acc[r] += e * vv[t][r];
+        }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc[r] += __shfl_xor(acc[r], m, 64);
+        if (lane == 0) res[l][r] = acc[r];
+      }
     }
   }
   __syncthreads();
 }
 
-// res[l] = sum_t T(l, t) * w[t] with T = inv(L11), inv(U11), inv(U11)^T, inv(L11)^T (MODE 0..3);
+// res[l][r] = sum_t T(l, t) * w[t][r] with T = inv(L11), inv(U11), inv(U11)^T, inv(L11)^T (MODE 0..3);
 // inv is column-major NB x NB.
-template <int MODE>
-__device__ __forceinline__ void gemv_inv(const double *__restrict__ inv, const double *w, double *res,
-                                         double (*part)[64]) {
+template <int MODE, int NR>
+__device__ __forceinline__ void gemv_inv(const double *__restrict__ inv, const double (*w)[NR], double (*res)[NR],
+                                         double (*part)[64][NR]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (MODE <= 1) {
-    double sacc = 0.0;
+    double acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = 0.0;
 #pragma unroll
     for (int u = 0; u < NB / SW; ++u) {
       const int t = wave + SW * u;
-      sacc += inv[lane + t * NB] * w[t];
+      const double e = inv[lane + t * NB];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[r] += e * w[t][r];
     }
-    part[wave][lane] = sacc;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) part[wave][lane][r] = acc[r];
     __syncthreads();
-    if (threadIdx.x < 64) {
+    for (int o = threadIdx.x; o < 64 * NR; o += SW * 64) {
+      const int l = o / NR, r = o % NR;
       double tot = 0.0;
 #pragma unroll
-      for (int q = 0; q < SW; ++q) tot += part[q][lane];
-      res[lane] = tot;
+      for (int q = 0; q < SW; ++q) tot += part[q][l][r];
+      res[l][r] = tot;
     }
   } else {
     for (int l = wave; l < 64; l += SW) {
-      double sacc = inv[lane + l * NB] * w[lane];  // T(l, t) = inv(t, l)
+      const double e = inv[lane + l * NB];  // T(l, t) = inv(t, l)
 #pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
-      if (lane == 0) res[l] = sacc;
+      for (int r = 0; r < NR; ++r) {
+        double sacc = e * w[lane][r];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
+        if (lane == 0) res[l][r] = sacc;
+      }
     }
   }
   __syncthreads();
 }
 
-template <int MODE>
+// NR right-hand sides at once: column r of in/out starts at r * stride
+template <int MODE, int NR>
 __global__ __launch_bounds__(SW * 64) void solve_super_kernel(Band b, const double *__restrict__ invs, int j0,
-                                                              int jbs, double *in, double *__restrict__ out) {
-  __shared__ double v[SB * NB], w[NB], res[NB], part[SW][64];
+                                                              int jbs, double *in, double *__restrict__ out,
+                                                              size_t stride) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double(*v)[NR] = reinterpret_cast<double(*)[NR]>(dsm);                          // [SB * NB]
+  double(*w)[NR] = reinterpret_cast<double(*)[NR]>(dsm + SB * NB * NR);           // [NB]
+  double(*res)[NR] = reinterpret_cast<double(*)[NR]>(dsm + (SB + 1) * NB * NR);   // [NB]
+  double(*part)[64][NR] = reinterpret_cast<double(*)[64][NR]>(dsm + (SB + 2) * NB * NR);  // [SW]
   constexpr bool fwd = (MODE == 0 || MODE == 2);
   const int tid = threadIdx.x;
   const int nsub = (jbs + NB - 1) / NB;
-  for (int t = tid; t < SB * NB; t += SW * 64) v[t] = 0.0;
+  for (int t = tid; t < SB * NB * NR; t += SW * 64) (&v[0][0])[t] = 0.0;
   __syncthreads();
   for (int k = 0; k < nsub; ++k) {
     const int sblk = fwd ? k : nsub - 1 - k;
@@ -493,23 +526,33 @@ __global__ __launch_bounds__(SW * 64) void solve_super_kernel(Band b, const doub
     // couplings with the sub-blocks of this super block that are already solved
     const int cb = fwd ? j0 : js + jb;
     const int nc = fwd ? js - j0 : j0 + jbs - (js + jb);
-    gemv64<MODE>(b, js, cb, nc, v + (cb - j0), res, part);
-    if (tid < NB) w[tid] = tid < jb ? in[js + tid] - res[tid] : 0.0;
+    gemv64<MODE, NR>(b, js, cb, nc, v + (cb - j0), res, part);
+    for (int o = tid; o < NB * NR; o += SW * 64) {
+      const int l = o % NB, r = o / NB;
+      w[l][r] = l < jb ? in[(size_t)r * stride + js + l] - res[l][r] : 0.0;
+    }
     __syncthreads();
     const double *inv = invs + (size_t)(js / NB) * (2 * NB * NB) + ((MODE == 1 || MODE == 2) ? NB * NB : 0);
-    gemv_inv<MODE>(inv, w, res, part);
-    if (tid < jb) v[js - j0 + tid] = res[tid];
+    gemv_inv<MODE, NR>(inv, w, res, part);
+    for (int o = tid; o < NB * NR; o += SW * 64) {
+      const int l = o % NB, r = o / NB;
+      if (l < jb) v[js - j0 + l][r] = res[l][r];
+    }
     __syncthreads();
   }
   if (blockIdx.x == 0)
-    for (int t = tid; t < jbs; t += SW * 64) out[j0 + t] = v[t];
+    for (int o = tid; o < jbs * NR; o += SW * 64) {
+      const int t = o % jbs, r = o / jbs;
+      out[(size_t)r * stride + j0 + t] = v[t][r];
+    }
   // the 64 rows of this workgroup outside the super block
   const int rb = fwd ? j0 + jbs + (int)blockIdx.x * 64 : j0 - ((int)blockIdx.x + 1) * 64;
-  gemv64<MODE>(b, rb, j0, jbs, v, res, part);
-  if (tid < 64) {
-    const int i = rb + tid;
+  gemv64<MODE, NR>(b, rb, j0, jbs, v, res, part);
+  for (int o = tid; o < 64 * NR; o += SW * 64) {
+    const int l = o % 64, r = o / 64;
+    const int i = rb + l;
     const bool ok = fwd ? (i < b.n) : (i >= 0);
-    if (ok) in[i] -= res[tid];
+    if (ok) in[(size_t)r * stride + i] -= res[l][r];
   }
 }
 
@@ -601,32 +644,55 @@ int band_nopiv_factor(int n, int kl, int ku, int ldab, double *d_AB, double *d_i
   return h;
 }
 
-template <int MODE>
-static void solve_pass(const Band &b, const double *d_invs, int bw, double *in, double *out, hipStream_t s) {
+template <int MODE, int NR>
+static void solve_pass(const Band &b, const double *d_invs, int bw, double *in, double *out, size_t stride,
+                       hipStream_t s) {
   constexpr bool fwd = (MODE == 0 || MODE == 2);
+  constexpr size_t lds = (size_t)((SB + 2) * NB + SW * 64) * NR * sizeof(double);
+  static bool attr_set = false;  // one flag per instantiation
+  if (!attr_set) {
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_super_kernel<MODE, NR>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
   const int n = b.n, step = SB * NB, nsup = (n + step - 1) / step;
   for (int k = 0; k < nsup; ++k) {
     const int j0 = (fwd ? k : nsup - 1 - k) * step, jbs = std::min(step, n - j0);
     const int rows = fwd ? std::max(0, std::min(n, j0 + jbs + bw) - (j0 + jbs)) : std::min(j0, bw);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_super_kernel<MODE>), dim3((unsigned)std::max(1, (rows + 63) / 64)),
-                       dim3(SW * 64), 0, s, b, d_invs, j0, jbs, in, out);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_super_kernel<MODE, NR>), dim3((unsigned)std::max(1, (rows + 63) / 64)),
+                       dim3(SW * 64), lds, s, b, d_invs, j0, jbs, in, out, stride);
   }
 }
 
-// c (device, permuted order) <- B^-1 c (sys 0) or B^-T c (sys 1) with the no-pivot factors
-void band_nopiv_solve(int sys, int n, int kl, int ku, int ldab, const double *d_AB, const double *d_invs,
-                      double *d_c, hipStream_t s) {
-  if (n == 0) return;
-  Band b{const_cast<double *>(d_AB), n, kl, ku, ldab};
-  DBuf<double> z((size_t)n);
+template <int NR>
+static void solve_group(int sys, const Band &b, const double *d_invs, double *d_c, double *d_z, size_t stride,
+                        hipStream_t s) {
   if (sys == 0) {
-    solve_pass<0>(b, d_invs, kl, d_c, z.get(), s);  // L forward: c -> z
-    solve_pass<1>(b, d_invs, ku, z.get(), d_c, s);  // U backward: z -> c
+    solve_pass<0, NR>(b, d_invs, b.kl, d_c, d_z, stride, s);  // L forward: c -> z
+    solve_pass<1, NR>(b, d_invs, b.ku, d_z, d_c, stride, s);  // U backward: z -> c
   } else {
-    solve_pass<2>(b, d_invs, ku, d_c, z.get(), s);  // U^T forward: c -> z
-    solve_pass<3>(b, d_invs, kl, z.get(), d_c, s);  // L^T backward: z -> c
+    solve_pass<2, NR>(b, d_invs, b.ku, d_c, d_z, stride, s);  // U^T forward: c -> z
+    solve_pass<3, NR>(b, d_invs, b.kl, d_z, d_c, stride, s);  // L^T backward: z -> c
   }
-  SPL_HIP(hipStreamSynchronize(s));  // z is freed on return
+}
+
+// columns of c (device, permuted order, column r at d_c + r * stride) <- B^-1 c (sys 0) or B^-T c
+// (sys 1) with the no-pivot factors.  Right-hand sides go through the band four at a time; the
+// caller pads to a multiple of kSolveGroup columns when nrhs > 1.
+void band_nopiv_solve(int sys, int n, int kl, int ku, int ldab, const double *d_AB, const double *d_invs,
+                      double *d_c, int nrhs, size_t stride, hipStream_t s) {
+  if (n == 0 || nrhs == 0) return;
+  Band b{const_cast<double *>(d_AB), n, kl, ku, ldab};
+  if (nrhs == 1) {
+    DBuf<double> z((size_t)n);
+    solve_group<1>(sys, b, d_invs, d_c, z.get(), stride, s);
+    SPL_HIP(hipStreamSynchronize(s));  // z is freed on return
+    return;
+  }
+  DBuf<double> z((size_t)kSolveGroup * stride);
+  for (int c0 = 0; c0 < nrhs; c0 += kSolveGroup)
+    solve_group<kSolveGroup>(sys, b, d_invs, d_c + (size_t)c0 * stride, z.get(), stride, s);
+  SPL_HIP(hipStreamSynchronize(s));
 }
 
 }  // namespace spl

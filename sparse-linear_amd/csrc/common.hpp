@@ -177,7 +177,9 @@ inline int band_nopiv_ldab(int kl, int ku) {
 size_t band_nopiv_inverse_elems(int n);  // doubles needed for the per-block inverse factors
 int band_nopiv_factor(int n, int kl, int ku, int ldab, double *d_AB, double *d_invs, const int *d_Ap, const int *d_Ai,
                       const double *d_Ax, const int *d_inv, hipStream_t s);
-void band_nopiv_solve(int sys, int n, int kl, int ku, int ldab, const double *d_AB, const double *d_invs, double *d_c, hipStream_t s);
+constexpr int kSolveGroup = 8;  // right-hand sides the blocked solves take through the band at once
+void band_nopiv_solve(int sys, int n, int kl, int ku, int ldab, const double *d_AB, const double *d_invs, double *d_c,
+                      int nrhs, size_t stride, hipStream_t s);
 
 // ---- synthetic generators (generate.hip) --------------------------------------------
 void generate_synthetic(Matrix *m, int kind, int64_t n_or_m, int K, uint64_t seed, hipStream_t s);

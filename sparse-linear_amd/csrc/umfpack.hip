@@ -263,10 +263,12 @@ __global__ __launch_bounds__(1024) void band_lu_fused_kernel(int n, int kl, int 
   }
 }
 
+// column blockIdx.y: out[k] = in[perm[k]]
 __global__ void gather_perm_kernel(int n, const int *__restrict__ perm, const double *__restrict__ in,
-                                   double *__restrict__ out) {  // out[k] = in[perm[k]]
+                                   double *__restrict__ out, size_t stride) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) out[k] = in[perm[k]];
+  const size_t col = (size_t)blockIdx.y * stride;
+  if (k < n) out[col + k] = in[col + perm[k]];
 }
 
 // banded solves with the factors, one workgroup, vector c in HBM (L2-resident)
@@ -336,32 +338,34 @@ __global__ __launch_bounds__(1024) void band_solve_kernel(int sys, int n, int kl
   }
 }
 
-// absax[i] = sum_k |a_ik| |x_k| over the rows of a CSR image, 8 lanes per row
+// column blockIdx.y: absax[i] = sum_k |a_ik| |x_k| over the rows of a CSR image, 8 lanes per row
 __global__ __launch_bounds__(256) void abs_spmv_kernel(int n, const int64_t *__restrict__ rowptr,
                                                        const int *__restrict__ colidx,
                                                        const double *__restrict__ val, const double *__restrict__ x,
-                                                       double *__restrict__ absax) {
+                                                       double *__restrict__ absax, size_t stride) {
   const int i = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 3), part = threadIdx.x & 7;
+  const size_t col = (size_t)blockIdx.y * stride;
   double s = 0.0;
   if (i < n)
-    for (int64_t p = rowptr[i] + part; p < rowptr[i + 1]; p += 8) s += fabs(val[p]) * fabs(x[colidx[p]]);
+    for (int64_t p = rowptr[i] + part; p < rowptr[i + 1]; p += 8) s += fabs(val[p]) * fabs(x[col + colidx[p]]);
   s += __shfl_xor(s, 1, 64);
   s += __shfl_xor(s, 2, 64);
   s += __shfl_xor(s, 4, 64);
-  if (i < n && part == 0) absax[i] = s;
+  if (i < n && part == 0) absax[col + i] = s;
 }
 
-// r = b - ax and the componentwise backward error  omega = max_i |r_i| / (|A||x| + |b|)_i
-// (Arioli, Demmel & Duff; the quantity UMFPACK's refinement monitors)
+// column blockIdx.y: r = b - ax and the componentwise backward error
+// omega = max_i |r_i| / (|A||x| + |b|)_i  (Arioli, Demmel & Duff; the quantity UMFPACK's refinement monitors)
 __global__ void residual_kernel(int n, const double *__restrict__ b, const double *__restrict__ ax,
                                 const double *__restrict__ absax, double *__restrict__ r,
-                                double *__restrict__ omega) {
+                                double *__restrict__ omega, size_t stride) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t col = (size_t)blockIdx.y * stride;
   double a = 0.0;
   if (i < n) {
-    const double v = b[i] - ax[i];
-    r[i] = v;
-    const double den = absax[i] + fabs(b[i]);
+    const double v = b[col + i] - ax[col + i];
+    r[col + i] = v;
+    const double den = absax[col + i] + fabs(b[col + i]);
     a = fabs(v);
     if (a > 0.0) a = den > 0.0 ? a / den : 1e300 * 1e300;
     if (!(a == a)) a = 1e300 * 1e300;  // NaN counts as +inf
@@ -369,11 +373,12 @@ __global__ void residual_kernel(int n, const double *__restrict__ b, const doubl
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) a = fmax(a, __shfl_xor(a, d, 64));
   if ((threadIdx.x & 63) == 0 && a > 0.0)
-    atomicMax(reinterpret_cast<unsigned long long *>(omega), (unsigned long long)__double_as_longlong(a));
+    atomicMax(reinterpret_cast<unsigned long long *>(omega + blockIdx.y),
+              (unsigned long long)__double_as_longlong(a));
 }
 
-__global__ void add_kernel(int n, double *__restrict__ x, const double *__restrict__ d) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void add_kernel(size_t n, double *__restrict__ x, const double *__restrict__ d) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] += d[i];
 }
 
@@ -398,26 +403,29 @@ int validate_host_csc(int n_row, int n_col, const int *Ap, const int *Ai) {
   return UMFPACK_OK;
 }
 
-// c (device, permuted order) <- solution of B z = c or B^T z = c
-void band_solve(const Numeric *N, int sys, double *d_c, hipStream_t s) {
-  if (N->n == 0) return;
+// columns of c (device, permuted order, column r at d_c + r * stride) <- solutions of B z = c or
+// B^T z = c; kalloc >= k columns are allocated (a multiple of kSolveGroup when k > 1)
+void band_solve(const Numeric *N, int sys, double *d_c, int k, size_t stride, hipStream_t s) {
+  if (N->n == 0 || k == 0) return;
   if (N->nopiv) {
-    band_nopiv_solve(sys, N->n, N->kl, N->ku, N->ldab, N->AB.get(), N->blkinv.get(), d_c, s);
+    band_nopiv_solve(sys, N->n, N->kl, N->ku, N->ldab, N->AB.get(), N->blkinv.get(), d_c, k, stride, s);
     return;
   }
-  hipLaunchKernelGGL(band_solve_kernel, dim3(1), dim3(1024), 0, s, sys, N->n, N->kl, N->ku, N->ldab,
-                     N->AB.get(), N->ipiv.get(), d_c);
+  for (int c = 0; c < k; ++c)
+    hipLaunchKernelGGL(band_solve_kernel, dim3(1), dim3(1024), 0, s, sys, N->n, N->kl, N->ku, N->ldab,
+                       N->AB.get(), N->ipiv.get(), d_c + (size_t)c * stride);
 }
 
-// d_x (device, original order) <- op(A)^-1 d_b using the factors only
-void factor_solve(const Numeric *N, int sys, const double *d_b, double *d_x, double *d_work, hipStream_t s) {
+// d_x (device, original order) <- op(A)^-1 d_b using the factors only, k columns
+void factor_solve(const Numeric *N, int sys, const double *d_b, double *d_x, double *d_work, int k, size_t stride,
+                  hipStream_t s) {
   const int n = N->n;
-  if (n == 0) return;
-  const unsigned g = (unsigned)((n + 255) / 256);
+  if (n == 0 || k == 0) return;
+  const dim3 g((unsigned)((n + 255) / 256), (unsigned)k);
   // B = P A P^T  =>  A x = b  <=>  B (P x) = P b ; (P v)[k] = v[perm[k]]
-  hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(256), 0, s, n, N->perm.get(), d_b, d_work);
-  band_solve(N, sys, d_work, s);
-  hipLaunchKernelGGL(gather_perm_kernel, dim3(g), dim3(256), 0, s, n, N->inv.get(), d_work, d_x);  // x[i] = z[inv[i]]
+  hipLaunchKernelGGL(gather_perm_kernel, g, dim3(256), 0, s, n, N->perm.get(), d_b, d_work, stride);
+  band_solve(N, sys, d_work, k, stride, s);
+  hipLaunchKernelGGL(gather_perm_kernel, g, dim3(256), 0, s, n, N->inv.get(), d_work, d_x, stride);  // x[i] = z[inv[i]]
 }
 
 // (re)build the band factors of P A P^T from the device copy of A^T's rows (= the CSC arrays);
@@ -594,71 +602,92 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
   }
 }
 
-int umfpack_di_solve(int sys, const int Ap[], const int Ai[], const double Ax[], double X[],
-                     const double B[], void *NumericIn, const double Control[], double Info[]) {
-  (void)Control; (void)Info;
-  Numeric *N = as_numeric(NumericIn);
-  if (!N) return UMFPACK_ERROR_invalid_Numeric_object;
-  if (!X || !B) return UMFPACK_ERROR_argument_missing;
-  if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;  // UMFPACK needs A for refinement
-  if (sys != UMFPACK_A && sys != UMFPACK_At) return UMFPACK_ERROR_invalid_system;
+// k systems op(A) X(:,c) = B(:,c) with the factors of N; X, B are n x k column-major on the host.
+// Iterative refinement with UMFPACK's defaults and stopping rules, column by column (irstep = 2;
+// umf_solve): stop when the componentwise backward error is below machine epsilon, or when a
+// step does not at least halve it (a step that raises it is undone).  All columns share every
+// pass over the factors.
+static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B) {
   const int n = N->n;
   try {
     DeviceGuard g(N->device);
     hipStream_t s = nullptr;
-    const unsigned grid = (unsigned)((n + 255) / 256);
-    DBuf<double> db((size_t)n), dx((size_t)n), dwork((size_t)n), dr((size_t)n), dd((size_t)n), dax((size_t)n);
-    DBuf<double> dnorm(1);
-    SPL_HIP(hipMemcpyAsync(db.get(), B, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    if (n == 0 || k == 0) return N->singular ? UMFPACK_WARNING_singular_matrix : UMFPACK_OK;
+    const size_t stride = (size_t)n;
+    const int kalloc = k == 1 ? 1 : (k + kSolveGroup - 1) / kSolveGroup * kSolveGroup;
+    const size_t total = stride * (size_t)kalloc, used = stride * (size_t)k;
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)k);
+    DBuf<double> db(total), dx(total), dwork(total), dr(total), dd(total), dax(total), dabs(total), dxn(total),
+        drn(total);
+    DBuf<double> domega((size_t)k);
+    for (DBuf<double> *buf : {&db, &dx, &dwork, &dr, &dd, &dxn, &drn})
+      if (kalloc > k) SPL_HIP(hipMemsetAsync(buf->get() + used, 0, (total - used) * sizeof(double), s));
+    SPL_HIP(hipMemcpyAsync(db.get(), B, used * sizeof(double), hipMemcpyHostToDevice, s));
     // speculative factors may be replaced below: solves on such an object take turns
     std::unique_lock<std::mutex> turn(N->mu, std::defer_lock);
     if (N->speculative) turn.lock();
-    double omega = 0.0;
+    std::vector<double> omega((size_t)k, 0.0), on((size_t)k, 0.0);
   again:
-    factor_solve(N, sys, db.get(), dx.get(), dwork.get(), s);
+    factor_solve(N, sys, db.get(), dx.get(), dwork.get(), k, stride, s);
     if (!N->singular) {
       const Matrix *op = sys == UMFPACK_A ? N->A : N->At;
-      DBuf<double> dabs((size_t)n);
-      auto backward_error = [&](const double *x, double *r) -> double {
-        int st = launch_spmv(op, x, dax.get(), 0, s);
-        if (st != SPL_OK) throw DeviceError{st};
-        hipLaunchKernelGGL(abs_spmv_kernel, dim3((unsigned)(((size_t)n * 8 + 255) / 256)), dim3(256), 0, s, n,
-                           op->rowptr64.get(), op->colidx.get(), op->val.get(), x, dabs.get());
-        SPL_HIP(hipMemsetAsync(dnorm.get(), 0, sizeof(double), s));
-        hipLaunchKernelGGL(residual_kernel, dim3(grid), dim3(256), 0, s, n, db.get(), dax.get(), dabs.get(), r,
-                           dnorm.get());
-        double h = 0.0;
-        SPL_HIP(hipMemcpyAsync(&h, dnorm.get(), sizeof(double), hipMemcpyDeviceToHost, s));
+      auto backward_error = [&](const double *x, double *r, std::vector<double> &out) {
+        for (int c = 0; c < k; ++c) {
+          int st = launch_spmv(op, x + (size_t)c * stride, dax.get() + (size_t)c * stride, 0, s);
+          if (st != SPL_OK) throw DeviceError{st};
+        }
+        hipLaunchKernelGGL(abs_spmv_kernel, dim3((unsigned)(((size_t)n * 8 + 255) / 256), (unsigned)k), dim3(256), 0,
+                           s, n, op->rowptr64.get(), op->colidx.get(), op->val.get(), x, dabs.get(), stride);
+        SPL_HIP(hipMemsetAsync(domega.get(), 0, (size_t)k * sizeof(double), s));
+        hipLaunchKernelGGL(residual_kernel, grid, dim3(256), 0, s, n, db.get(), dax.get(), dabs.get(), r,
+                           domega.get(), stride);
+        SPL_HIP(hipMemcpyAsync(out.data(), domega.get(), (size_t)k * sizeof(double), hipMemcpyDeviceToHost, s));
         SPL_HIP(hipStreamSynchronize(s));
-        return h;
       };
-      // Iterative refinement with UMFPACK's defaults and stopping rules (irstep = 2; umf_solve):
-      // stop when the componentwise backward error is below machine epsilon, or when a step does
-      // not at least halve it (a step that raises it is undone).
       const double eps = 2.220446049250313e-16;
-      omega = backward_error(dx.get(), dr.get());
-      DBuf<double> dxn((size_t)n), drn((size_t)n);
-      for (int it = 0; it < 2 && omega >= eps; ++it) {
-        factor_solve(N, sys, dr.get(), dd.get(), dwork.get(), s);
-        SPL_HIP(hipMemcpyAsync(dxn.get(), dx.get(), (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(add_kernel, dim3(grid), dim3(256), 0, s, n, dxn.get(), dd.get());
-        const double on = backward_error(dxn.get(), drn.get());
-        if (!(on <= omega)) break;  // worse (or NaN): keep the previous iterate
-        std::swap(dx.p, dxn.p);
-        std::swap(dr.p, drn.p);
-        const bool stagnated = on > omega / 2;
-        omega = on;
-        if (stagnated) break;
+      backward_error(dx.get(), dr.get(), omega);
+      std::vector<char> active((size_t)k);
+      int nactive = 0;
+      for (int c = 0; c < k; ++c) nactive += (active[(size_t)c] = omega[(size_t)c] >= eps);
+      for (int it = 0; it < 2 && nactive > 0; ++it) {
+        factor_solve(N, sys, dr.get(), dd.get(), dwork.get(), k, stride, s);
+        SPL_HIP(hipMemcpyAsync(dxn.get(), dx.get(), used * sizeof(double), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(add_kernel, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, s, used, dxn.get(),
+                           dd.get());
+        backward_error(dxn.get(), drn.get(), on);
+        for (int c = 0; c < k; ++c) {
+          if (!active[(size_t)c]) continue;
+          const double o_new = on[(size_t)c], o_old = omega[(size_t)c];
+          if (!(o_new <= o_old)) {  // worse (or NaN): keep the previous iterate of this column
+            active[(size_t)c] = 0;
+            --nactive;
+            continue;
+          }
+          const size_t off = (size_t)c * stride;
+          SPL_HIP(hipMemcpyAsync(dx.get() + off, dxn.get() + off, stride * sizeof(double), hipMemcpyDeviceToDevice, s));
+          SPL_HIP(hipMemcpyAsync(dr.get() + off, drn.get() + off, stride * sizeof(double), hipMemcpyDeviceToDevice, s));
+          omega[(size_t)c] = o_new;
+          if (o_new > o_old / 2 || o_new < eps) {  // stagnated, or converged
+            active[(size_t)c] = 0;
+            --nactive;
+          }
+        }
+        // columns that are done must not move any more: their residual no longer drives a step
+        for (int c = 0; c < k; ++c)
+          if (!active[(size_t)c])
+            SPL_HIP(hipMemsetAsync(dr.get() + (size_t)c * stride, 0, stride * sizeof(double), s));
       }
-      // no-interchange factors of a matrix without diagonal dominance: accepted only if the
+      // no-interchange factors of a matrix without diagonal dominance: accepted only if every
       // refined solution is backward stable to rounding level, as pivoted factors would make it
-      if (turn.owns_lock() && N->speculative && !(omega <= 1e-13)) {
+      double worst = 0.0;
+      for (int c = 0; c < k; ++c) worst = (omega[(size_t)c] <= worst) ? worst : omega[(size_t)c];  // NaN -> worst
+      if (turn.owns_lock() && N->speculative && !(worst <= 1e-13)) {
         N->speculative = 0;
         factor_band(N, false, s);
         goto again;
       }
     }
-    SPL_HIP(hipMemcpyAsync(X, dx.get(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipMemcpyAsync(X, dx.get(), used * sizeof(double), hipMemcpyDeviceToHost, s));
     SPL_HIP(hipStreamSynchronize(s));
     SPL_HIP(hipGetLastError());
     return N->singular ? UMFPACK_WARNING_singular_matrix : UMFPACK_OK;
@@ -667,6 +696,29 @@ int umfpack_di_solve(int sys, const int Ap[], const int Ai[], const double Ax[],
   } catch (const std::bad_alloc &) {
     return UMFPACK_ERROR_out_of_memory;
   }
+}
+
+int umfpack_di_solve(int sys, const int Ap[], const int Ai[], const double Ax[], double X[],
+                     const double B[], void *NumericIn, const double Control[], double Info[]) {
+  (void)Control; (void)Info;
+  Numeric *N = as_numeric(NumericIn);
+  if (!N) return UMFPACK_ERROR_invalid_Numeric_object;
+  if (!X || !B) return UMFPACK_ERROR_argument_missing;
+  if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;  // UMFPACK needs A for refinement
+  if (sys != UMFPACK_A && sys != UMFPACK_At) return UMFPACK_ERROR_invalid_system;
+  return solve_columns(N, sys, 1, X, B);
+}
+
+// batched linearSolve: nrhs right-hand sides in one call (see umfpack_hip.h)
+int spl_umfpack_di_solve_many(int sys, const int Ap[], const int Ai[], const double Ax[], int nrhs, double X[],
+                              const double B[], void *NumericIn) {
+  Numeric *N = as_numeric(NumericIn);
+  if (!N) return UMFPACK_ERROR_invalid_Numeric_object;
+  if (nrhs < 0) return UMFPACK_ERROR_argument_missing;
+  if (nrhs > 0 && N->n > 0 && (!X || !B)) return UMFPACK_ERROR_argument_missing;
+  if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;
+  if (sys != UMFPACK_A && sys != UMFPACK_At) return UMFPACK_ERROR_invalid_system;
+  return solve_columns(N, sys, nrhs, X, B);
 }
 
 // dimension of the factored system (used by the `zi` wrappers in split-array mode); 0 if invalid

@@ -130,6 +130,38 @@ int umfpack_zi_solve(int sys, const int Ap[], const int Ai[], const double Ax[],
   }
 }
 
+// batched complex linearSolve: nrhs right-hand sides, each packed (re, im) pairs when the
+// imaginary pointers are NULL, else split arrays of n x nrhs (column-major)
+int spl_umfpack_zi_solve_many(int sys, const int Ap[], const int Ai[], const double Ax[], const double Az[],
+                              int nrhs, double Xx[], double Xz[], const double Bx[], const double Bz[],
+                              void *Numeric) {
+  (void)Az;
+  if (nrhs < 0) return UMFPACK_ERROR_argument_missing;
+  if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;
+  const int n2 = spl_umfpack_dimension(Numeric);
+  if (n2 < 0 || (n2 == 0 && !Numeric)) return UMFPACK_ERROR_invalid_Numeric_object;
+  if (nrhs > 0 && n2 > 0 && (!Xx || !Bx)) return UMFPACK_ERROR_argument_missing;
+  if (!Xz && !Bz) return spl_umfpack_di_solve_many(sys, Ap, Ai, Ax, nrhs, Xx, Bx, Numeric);
+  try {
+    const size_t n = (size_t)n2 / 2, tot = (size_t)n2 * (size_t)nrhs;
+    std::vector<double> b(tot), x(tot);
+    for (size_t c = 0; c < (size_t)nrhs; ++c)
+      for (size_t k = 0; k < n; ++k) {
+        b[c * n2 + 2 * k] = Bx[c * n + k];
+        b[c * n2 + 2 * k + 1] = Bz ? Bz[c * n + k] : 0.0;
+      }
+    const int st = spl_umfpack_di_solve_many(sys, Ap, Ai, Ax, nrhs, x.data(), b.data(), Numeric);
+    for (size_t c = 0; c < (size_t)nrhs; ++c)
+      for (size_t k = 0; k < n; ++k) {
+        Xx[c * n + k] = x[c * n2 + 2 * k];
+        if (Xz) Xz[c * n + k] = x[c * n2 + 2 * k + 1];
+      }
+    return st;
+  } catch (const std::bad_alloc &) {
+    return UMFPACK_ERROR_out_of_memory;
+  }
+}
+
 void umfpack_zi_free_symbolic(void **Symbolic) {
   if (!Symbolic || !*Symbolic) return;
   ZiSymbolic *S = static_cast<ZiSymbolic *>(*Symbolic);

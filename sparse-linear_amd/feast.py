@@ -61,9 +61,11 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
             ze = c + r * np.exp(1j * th)
             mat = lin(-1.0, A, 1.0, cmap(lambda v: v * ze, B))    # ijob 10: ze*B - A, sparse add on the GPU
             fact = U.factor(mat, analysis)                          #          numeric LU, same analysis
-            for j in range(m0):                                     # ijob 11: one rhs at a time
-                q = U.linearSolve_(fact, U.UmfpackNormal, mat, np.ascontiguousarray(BY[:, j]))
-                Q[:, j] += (r * np.exp(1j * th) / ne) * q
+            # ijob 11 (Feast.hs:197-201 solves one subspace column at a time): all m0 columns in
+            # one pass through the factors
+            qs = U.linearSolveMany_(fact, U.UmfpackNormal, mat, [BY[:, j] for j in range(m0)])
+            for j in range(m0):
+                Q[:, j] += (r * np.exp(1j * th) / ne) * qs[j]
         # Rayleigh-Ritz on the filtered subspace (dense, m0 x m0)
         AQ = np.stack([mulV(A, np.ascontiguousarray(Q[:, j])) for j in range(m0)], axis=1)        # ijob 30
         BQ = np.stack([mulV(B, np.ascontiguousarray(Q[:, j])) for j in range(m0)], axis=1)        # ijob 40

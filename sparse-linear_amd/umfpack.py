@@ -52,6 +52,10 @@ def _declare():
     L.umfpack_zi_free_numeric.argtypes = [C.POINTER(vp)]
     L.umfpack_zi_report_status.restype = None
     L.umfpack_zi_report_status.argtypes = [dp, i]
+    L.spl_umfpack_di_solve_many.restype = i
+    L.spl_umfpack_di_solve_many.argtypes = [i, ip, ip, dp, i, dp, dp, vp]
+    L.spl_umfpack_zi_solve_many.restype = i
+    L.spl_umfpack_zi_solve_many.argtypes = [i, ip, ip, dp, dp, i, dp, dp, dp, dp, vp]
     L.spl_umfpack_path.restype = i
     L.spl_umfpack_path.argtypes = [vp]
     L._umf_declared = True
@@ -154,10 +158,38 @@ def linearSolve_(fact, mode, mat, b):
     return soln
 
 
+def linearSolveMany_(fact, mode, mat, bs):
+    """`map (linearSolve_ fact mode mat) bs` (Umfpack.hs:103-108) in ONE pass of all right-hand
+    sides through the factors (spl_umfpack_{di,zi}_solve_many); returns the list of solutions"""
+    L = _declare()
+    bs = list(bs)
+    k = len(bs)
+    if k == 0:
+        return []
+    nr, nc, ap, ai, ax = mat._tuple32()
+    dt = np.complex128 if mat.is_complex else np.float64
+    B = np.empty((k, mat.nrows), dtype=dt)  # row c = right-hand side c: column-major n x k for the C side
+    for c, b in enumerate(bs):
+        b = np.asarray(b)
+        if b.shape != (mat.nrows,):
+            raise UmfpackError("linearSolveMany_: right-hand side %d has shape %s" % (c, b.shape))
+        B[c] = b
+    X = np.zeros((k, mat.ncols), dtype=dt)
+    if mat.is_complex:
+        st = L.spl_umfpack_zi_solve_many(int(mode), p_i32(ap), p_i32(ai), p_f64(ax), None, k,
+                                         p_f64(X.view(np.float64)), None, p_f64(B.view(np.float64)), None,
+                                         fact.value)
+    else:
+        st = L.spl_umfpack_di_solve_many(int(mode), p_i32(ap), p_i32(ai), p_f64(ax), k, p_f64(X), p_f64(B),
+                                         fact.value)
+    _report("linearSolveMany_: umfpack_solve", st)
+    return [X[c] for c in range(k)]
+
+
 def linearSolve(mat, bs):
     """factor once, solve for every right-hand side (Umfpack.hs:38-46)"""
     fact = factor(mat, analyze(mat))
-    return [linearSolve_(fact, UmfpackNormal, mat, b) for b in bs]
+    return linearSolveMany_(fact, UmfpackNormal, mat, bs)
 
 
 def solve(mat, b):

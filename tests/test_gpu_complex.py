@@ -68,3 +68,22 @@ def test_complex_solve_and_conjugate_transpose(gpu, pkg, O):
     b = np.array([1.0 + 0j, 0.0])
     y = pkg.umfpack.solve(S, b)
     assert np.max(np.abs(pkg.pack(S) @ y - b)) < 1e-13
+
+
+def test_complex_batched_solve(gpu, pkg, O):
+    """spl_umfpack_zi_solve_many: packed complex right-hand sides, both systems"""
+    import scipy.sparse as sp
+    m = 14
+    n = m * m
+    rp, ci, v = O.gen_poisson2d_csr(m)
+    S = ((2.0 + 0.7j) * sp.identity(n) - sp.csc_matrix((v, ci, rp), shape=(n, n))).tocsc()
+    S.sort_indices()
+    M = pkg.Matrix(n, n, S.indptr, S.indices, S.data)
+    rng = np.random.default_rng(3)
+    xs = [rng.uniform(0.5, 1.5, n) + 1j * rng.uniform(-1.0, 1.0, n) for _ in range(5)]
+    U = pkg.umfpack
+    fact = U.factor(M, U.analyze(M))
+    for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, S.conj().T.tocsc())):
+        got = U.linearSolveMany_(fact, mode, M, [op @ x for x in xs])
+        for x, g in zip(xs, got):
+            assert np.max(np.abs(g - x)) / np.max(np.abs(x)) < 1e-10

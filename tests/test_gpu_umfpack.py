@@ -212,3 +212,31 @@ def test_speculation_that_fails_is_replaced_by_pivoting(gpu, pkg, O, monkeypatch
     # SPL_LU_FORCE_PIVOT=0: no speculation, this matrix goes straight to partial pivoting
     monkeypatch.setenv("SPL_LU_FORCE_PIVOT", "0")
     assert pkg.umfpack.factor(M, pkg.umfpack.analyze(M)).path == 0
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 7])
+@pytest.mark.parametrize("force_pivot", ["0", "1"])
+def test_batched_linear_solve_matches_one_at_a_time(gpu, pkg, O, k, force_pivot, monkeypatch):
+    """linearSolveMany_ (all right-hand sides through the factors together, groups of 4 in the
+    blocked solves) == map linearSolve_ (Umfpack.hs:103-108), both systems, both LU paths"""
+    monkeypatch.setenv("SPL_LU_FORCE_PIVOT", force_pivot)
+    m = 23
+    n = m * m
+    rp, ci, v = O.gen_poisson2d_csr(m)
+    v = v.copy()
+    v[ci == np.repeat(np.arange(n), np.diff(rp))] += 0.25  # unsymmetric-ish scaling keeps dominance
+    A = pkg.Matrix(n, n, rp, ci, v)
+    rng = np.random.default_rng(k)
+    bs = [rng.uniform(0.5, 1.5, n) for _ in range(k)]
+    U = pkg.umfpack
+    fact = U.factor(A, U.analyze(A))
+    for mode in (U.UmfpackNormal, U.UmfpackTrans):
+        many = U.linearSolveMany_(fact, mode, A, bs)
+        assert len(many) == k
+        for b, x in zip(bs, many):
+            one = U.linearSolve_(fact, mode, A, b)
+            assert O.count_not_close(x, one, 1e-12) == 0
+    assert U.linearSolveMany_(fact, U.UmfpackNormal, A, []) == []
+    xs = U.linearSolve(A, bs)  # the reference's API: factor once, every right-hand side
+    for b, x in zip(bs, xs):
+        assert O.count_not_close(x, U.linearSolve_(fact, U.UmfpackNormal, A, b), 1e-12) == 0

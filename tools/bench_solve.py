@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--grid", default="16,24,32")
     ap.add_argument("--cpu-max", type=int, default=32, help="largest m for the SuperLU stand-in")
+    ap.add_argument("--nrhs", type=int, default=0, help="also time a batched solve of this many right-hand sides")
     args = ap.parse_args()
     import numpy as np
     import scipy.sparse as sp
@@ -47,6 +48,15 @@ def main():
                "gpu": {"analyze_s": round(t1 - t0, 3), "factor_s": round(t2 - t1, 3), "solve_s": round(t3 - t2, 3),
                        "total_s": round(t3 - t0, 3)},
                "max_rel_err_vs_manufactured": err, "scaled_residual": res, "within_1e-10": bool(err < 1e-10)}
+        if args.nrhs > 1:
+            bs = [b * (1.0 + 0.01 * c) for c in range(args.nrhs)]
+            t = time.perf_counter(); xm = U.linearSolveMany_(fa, U.UmfpackNormal, A, bs); tm = time.perf_counter() - t
+            t = time.perf_counter()
+            xo = [U.linearSolve_(fa, U.UmfpackNormal, A, bb) for bb in bs]
+            to = time.perf_counter() - t
+            out["batched_solve"] = {"nrhs": args.nrhs, "together_s": round(tm, 3), "one_at_a_time_s": round(to, 3),
+                                    "max_rel_diff": float(max(np.max(np.abs(p - q)) / np.max(np.abs(q))
+                                                              for p, q in zip(xm, xo)))}
         if m <= args.cpu_max:
             t = time.perf_counter(); lu = spla.splu(S); tf = time.perf_counter() - t
             t = time.perf_counter(); xc = lu.solve(b); ts = time.perf_counter() - t
