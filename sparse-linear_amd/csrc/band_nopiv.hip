@@ -441,24 +441,45 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
       res[l][r] = tot;
     }
   } else {
-    for (int l = wave; l < 64; l += SW) {
-      const int i = rb + l;
-      double acc[NR];
+    // nc <= SB * NB = 256: at most 4 strips of 64 columns; the 4 rows of this wave and the strips
+    // are unrolled so that all 16 loads of a lane are in flight together
+    constexpr int RPW = 64 / SW;
+    double acc[RPW][NR];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) acc[r] = 0.0;
-      if (i >= 0 && i < b.n)
-        for (int t = lane; t < nc; t += 64) {
-          const double e = b.get(cb + t, i);
+    for (int q = 0; q < RPW; ++q)
 #pragma unroll
-          for (int r = 0; r < NR; ++r) acc[r] += e * vv[t][r];
-        }
+      for (int r = 0; r < NR; ++r) acc[q][r] = 0.0;
+    double e[SB][RPW];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) {
+    for (int u = 0; u < SB; ++u) {
+      const int t = lane + 64 * u;
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) acc[r] += __shfl_xor(acc[r], m, 64);
-        if (lane == 0) res[l][r] = acc[r];
+      for (int q = 0; q < RPW; ++q) {
+        const int i = rb + wave + SW * q;
+        e[u][q] = (t < nc && i >= 0 && i < b.n) ? b.get(cb + t, i) : 0.0;
       }
     }
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const int t = lane + 64 * u;
+      if (t < nc) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const double x = vv[t][r];
+#pragma unroll
+          for (int q = 0; q < RPW; ++q) acc[q][r] += e[u][q] * x;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RPW; ++q)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        double sacc = acc[q][r];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
+        if (lane == 0) res[wave + SW * q][r] = sacc;
+      }
   }
   __syncthreads();
 }

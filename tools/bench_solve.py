@@ -48,6 +48,9 @@ def main():
                "gpu": {"analyze_s": round(t1 - t0, 3), "factor_s": round(t2 - t1, 3), "solve_s": round(t3 - t2, 3),
                        "total_s": round(t3 - t0, 3)},
                "max_rel_err_vs_manufactured": err, "scaled_residual": res, "within_1e-10": bool(err < 1e-10)}
+        t = time.perf_counter(); xt = U.linearSolve_(fa, U.UmfpackTrans, A, b); tt = time.perf_counter() - t
+        out["gpu"]["solve_transposed_s"] = round(tt, 3)  # symmetric matrix: same system, U^T / L^T kernels
+        out["transposed_max_rel_err"] = float(np.max(np.abs(xt - xs) / np.abs(xs)))
         if args.nrhs > 1:
             bs = [b * (1.0 + 0.01 * c) for c in range(args.nrhs)]
             t = time.perf_counter(); xm = U.linearSolveMany_(fa, U.UmfpackNormal, A, bs); tm = time.perf_counter() - t
