@@ -99,6 +99,17 @@ int spl_lin(double alpha, int nrowsA, int ncolsA, const int *Ap, const int *Ai, 
 int spl_transpose(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax,
                   int *Tp, int *Ti, double *Tx);
 
+/* C = A (x) B, the Kronecker product (`kronecker`, Sparse.hs:597-634): column ja*ncolsB + jb of C
+ * holds the rows ia*nrowsB + ib (ascending) with values b*a.  The reference assembles its model
+ * problems this way (`kronecker (ident n) T + kronecker T (ident n)`).  Outputs malloc()'d as for
+ * spl_spgemm; SPL_ERROR_index_overflow when a dimension or nnz(A)*nnz(B) does not fit int32. */
+int spl_kronecker(int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Ax, int nrowsB,
+                  int ncolsB, const int *Bp, const int *Bi, const double *Bx, int *nrowsC, int *ncolsC,
+                  int **Cp, int **Ci, double **Cx);
+
+/* d[c] = A[c,c], or 0 where no entry is stored, c < min(nrows, ncols) (`takeDiag`, Sparse.hs:636-648) */
+int spl_take_diag(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax, double *d);
+
 /* compress / fromTriples (Sparse.hs:184-255): COO -> CSC, duplicates summed,
  * explicit zeros kept.  Ap[ncols+1] caller-allocated; *Ai,*Ax malloc()'d with
  * Ap[ncols] entries.  On SPL_ERROR_index_out_of_bounds *bad is the first

@@ -339,6 +339,37 @@ def count_not_close(a, b, tol=1e-10):
     return int(lib().orc_count_not_close(C.c_int64(a.size), _D(a), _D(b), C.c_double(tol)))
 
 
+def kronecker(a, b):
+    """kronecker (Sparse.hs:597-634), numpy restatement: pointers = scan of lenA[ja]*lenB[jb];
+    column (ja, jb): rows ia*nrows(B)+ib for every ia (outer) and ib (inner), values b*a."""
+    ar, ac, ap, ai, ax = _mat(a)
+    br, bc, bp, bi, bx = _mat(b)
+    la, lb = np.diff(ap[:ac + 1]), np.diff(bp[:bc + 1])
+    ptrs = np.concatenate([[0], np.cumsum(np.outer(la, lb).ravel())]).astype(I64)
+    idx = np.zeros(int(ptrs[-1]), dtype=I64)
+    val = np.zeros(int(ptrs[-1]), dtype=np.float64)
+    for ja in range(ac):
+        ia_, xa = ai[ap[ja]:ap[ja + 1]], ax[ap[ja]:ap[ja + 1]]
+        for jb in range(bc):
+            ib_, xb = bi[bp[jb]:bp[jb + 1]], bx[bp[jb]:bp[jb + 1]]
+            s = int(ptrs[ja * bc + jb])
+            n = len(ia_) * len(ib_)
+            idx[s:s + n] = (ia_[:, None] * br + ib_[None, :]).ravel()
+            val[s:s + n] = (xb[None, :] * xa[:, None]).ravel()
+    return (ar * br, ac * bc, ptrs, idx, val)
+
+
+def take_diag(m):
+    """takeDiag (Sparse.hs:636-648): first stored entry with row == column, else 0"""
+    nrows, ncols, p, i, x = _mat(m)
+    out = np.zeros(min(nrows, ncols), dtype=np.float64)
+    for c in range(len(out)):
+        hit = np.nonzero(i[p[c]:p[c + 1]] == c)[0]
+        if len(hit):
+            out[c] = x[p[c] + hit[0]]
+    return out
+
+
 # -- solve --------------------------------------------------------------------------------
 
 def linear_solve(m, b, sys=0):

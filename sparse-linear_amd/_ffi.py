@@ -89,6 +89,8 @@ def _declare(L):
         "spl_transpose": tup + [c_int_p, c_int_p, c_dbl_p],
         "spl_spgemm": tup + tup + [c_int_p, c_int_p, c_void_pp, c_void_pp, c_void_pp],
         "spl_lin": [d] + tup + [d] + tup + [c_int_p, c_int_p, c_void_pp, c_void_pp, c_void_pp],
+        "spl_kronecker": tup + tup + [c_int_p, c_int_p, c_void_pp, c_void_pp, c_void_pp],
+        "spl_take_diag": tup + [c_dbl_p],
         "spl_compress": [i, i, i64, c_int_p, c_int_p, c_dbl_p, c_int_p, c_void_pp, c_void_pp, c_i64_p],
         "spl_matrix_create": tup + [c_void_pp],
         "spl_matrix_create_rowblock": tup + [i, i, c_void_pp],

@@ -790,6 +790,56 @@ int spl_lin(double alpha, int nrowsA, int ncolsA, const int *Ap, const int *Ai, 
   });
 }
 
+int spl_kronecker(int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Ax, int nrowsB,
+                  int ncolsB, const int *Bp, const int *Bi, const double *Bx, int *nrowsC, int *ncolsC,
+                  int **Cp, int **Ci, double **Cx) {
+  if (!nrowsC || !ncolsC || !Cp || !Ci || !Cx) return SPL_ERROR_argument_missing;
+  *Cp = nullptr; *Ci = nullptr; *Cx = nullptr;
+  if (nrowsA < 0 || ncolsA < 0 || nrowsB < 0 || ncolsB < 0) return SPL_ERROR_n_nonpositive;
+  if ((int64_t)nrowsA * nrowsB >= 0x7fffffffLL || (int64_t)ncolsA * ncolsB >= 0x7fffffffLL)
+    return SPL_ERROR_index_overflow;  // the seam is int32 (Foreign.hs:24-28)
+  return guarded([&]() -> int {
+    (void)current_device();
+    hipStream_t s = nullptr;
+    DeviceCsc A, B;
+    int st = upload_csc(nrowsA, ncolsA, Ap, Ai, Ax, A, s);
+    if (st != SPL_OK) return st;
+    st = upload_csc(nrowsB, ncolsB, Bp, Bi, Bx, B, s);
+    if (st != SPL_OK) return st;
+    DBuf<int64_t> dCp;
+    DBuf<int> dCi;
+    DBuf<double> dCx;
+    int64_t nnzC = 0;
+    kronecker_device(nrowsB, A.p.get(), A.i.get(), A.x.get(), ncolsA, B.p.get(), B.i.get(), B.x.get(), ncolsB,
+                     dCp, dCi, dCx, &nnzC, s);
+    st = download_result((int64_t)ncolsA * ncolsB, nnzC, dCp.get(), dCi.get(), dCx.get(), Cp, Ci, Cx, s);
+    if (st != SPL_OK) return st;
+    *nrowsC = nrowsA * nrowsB;
+    *ncolsC = ncolsA * ncolsB;
+    return SPL_OK;
+  });
+}
+
+int spl_take_diag(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax, double *d) {
+  if (nrows < 0 || ncols < 0) return SPL_ERROR_n_nonpositive;
+  const int n = nrows < ncols ? nrows : ncols;
+  if (n > 0 && !d) return SPL_ERROR_argument_missing;
+  return guarded([&]() -> int {
+    (void)current_device();
+    hipStream_t s = nullptr;
+    DeviceCsc A;
+    int st = upload_csc(nrows, ncols, Ap, Ai, Ax, A, s);
+    if (st != SPL_OK) return st;
+    if (n == 0) return SPL_OK;
+    DBuf<double> dd((size_t)n);
+    take_diag_device(A.p.get(), A.i.get(), A.x.get(), n, dd.get(), s);
+    SPL_HIP(hipMemcpyAsync(d, dd.get(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipStreamSynchronize(s));
+    SPL_HIP(hipGetLastError());
+    return SPL_OK;
+  });
+}
+
 int spl_compress(int nrows, int ncols, int64_t nnz, const int *rows, const int *cols, const double *vals,
                  int *Ap, int **Ai, double **Ax, int64_t *bad) {
   if (!Ap || !Ai || !Ax) return SPL_ERROR_argument_missing;

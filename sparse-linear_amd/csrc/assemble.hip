@@ -244,4 +244,87 @@ void lin_device(double alpha, const int *Ap, const int *Ai, const double *Ax, do
   *nnzC = nz;
 }
 
+// ---- kronecker / takeDiag (Sparse.hs:597-648) --------------------------------------------------
+namespace {
+
+// lengths of the columns of C = A (x) B: column ja * ncolsB + jb has len(A[:,ja]) * len(B[:,jb]) entries
+__global__ void kron_count_kernel(const int *__restrict__ Ap, const int *__restrict__ Bp, int64_t ncolsA,
+                                  int64_t ncolsB, int64_t *__restrict__ counts) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ncolsA * ncolsB) return;
+  const int64_t ja = j / ncolsB, jb = j % ncolsB;
+  counts[j] = (int64_t)(Ap[ja + 1] - Ap[ja]) * (int64_t)(Bp[jb + 1] - Bp[jb]);
+}
+
+// one wavefront per output column: entry e of the column is (a = e / lenB, b = e % lenB) -> row
+// ia * nrowsB + ib (ascending, as the rows of both operands ascend), value b * a
+__global__ __launch_bounds__(256) void kron_fill_kernel(const int *__restrict__ Ap, const int *__restrict__ Ai,
+                                                        const double *__restrict__ Ax,
+                                                        const int *__restrict__ Bp, const int *__restrict__ Bi,
+                                                        const double *__restrict__ Bx, int64_t ncolsA,
+                                                        int64_t ncolsB, int nrowsB,
+                                                        const int64_t *__restrict__ Cp, int *__restrict__ Ci,
+                                                        double *__restrict__ Cx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= ncolsA * ncolsB) return;
+  const int64_t ja = j / ncolsB, jb = j % ncolsB;
+  const int pa = Ap[ja], pb = Bp[jb], lb = Bp[jb + 1] - pb;
+  const int64_t base = Cp[j], len = Cp[j + 1] - base;
+  for (int64_t e = lane; e < len; e += 64) {
+    const int ea = (int)(e / lb), eb = (int)(e % lb);
+    Ci[base + e] = Ai[pa + ea] * nrowsB + Bi[pb + eb];
+    Cx[base + e] = Bx[pb + eb] * Ax[pa + ea];  // U.map (* a) bs
+  }
+}
+
+// d[c] = A[c, c] or 0: 8 lanes search column c (rows ascend, at most one hit)
+__global__ __launch_bounds__(256) void take_diag_kernel(const int *__restrict__ Ap, const int *__restrict__ Ai,
+                                                        const double *__restrict__ Ax, int n,
+                                                        double *__restrict__ d) {
+  const int c = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 3), part = threadIdx.x & 7;
+  double v = 0.0;
+  if (c < n)
+    for (int p = Ap[c] + part; p < Ap[c + 1]; p += 8)
+      if (Ai[p] == c) v = Ax[p];
+  // exactly one lane can hold a hit; OR the bit patterns together (0.0 is all-zero bits)
+  unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+  bits |= __shfl_xor(bits, 1, 64);
+  bits |= __shfl_xor(bits, 2, 64);
+  bits |= __shfl_xor(bits, 4, 64);
+  if (c < n && part == 0) d[c] = __longlong_as_double((long long)bits);
+}
+
+}  // namespace
+
+// C = A (x) B on device CSC arrays; Cp is 64-bit (the caller checks the int32 seam)
+void kronecker_device(int nrowsB, const int *Ap, const int *Ai, const double *Ax, int64_t ncolsA, const int *Bp,
+                      const int *Bi, const double *Bx, int64_t ncolsB, DBuf<int64_t> &Cp, DBuf<int> &Ci,
+                      DBuf<double> &Cx, int64_t *nnzC, hipStream_t s) {
+  const int64_t nc = ncolsA * ncolsB;
+  Cp.alloc((size_t)nc + 1);
+  DBuf<int64_t> counts((size_t)(nc ? nc : 1));
+  if (nc > 0)
+    hipLaunchKernelGGL(kron_count_kernel, dim3(blocks_for(nc, 256)), dim3(256), 0, s, Ap, Bp, ncolsA, ncolsB,
+                       counts.get());
+  exclusive_scan_i64(counts.get(), Cp.get(), nc, s);
+  int64_t nz = 0;
+  SPL_HIP(hipMemcpyAsync(&nz, Cp.get() + nc, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  SPL_HIP(hipStreamSynchronize(s));
+  *nnzC = nz;
+  if (nz >= 0x7fffffffLL) return;  // does not fit the int32 seam: the caller reports the overflow
+  Ci.alloc((size_t)nz);
+  Cx.alloc((size_t)nz);
+  if (nz > 0)
+    hipLaunchKernelGGL(kron_fill_kernel, dim3(blocks_for(nc, 4)), dim3(256), 0, s, Ap, Ai, Ax, Bp, Bi, Bx, ncolsA,
+                       ncolsB, nrowsB, Cp.get(), Ci.get(), Cx.get());
+  SPL_HIP(hipStreamSynchronize(s));
+}
+
+void take_diag_device(const int *Ap, const int *Ai, const double *Ax, int n, double *d, hipStream_t s) {
+  if (n > 0)
+    hipLaunchKernelGGL(take_diag_kernel, dim3((unsigned)(((size_t)n * 8 + 255) / 256)), dim3(256), 0, s, Ap, Ai, Ax,
+                       n, d);
+}
+
 }  // namespace spl

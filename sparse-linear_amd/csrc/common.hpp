@@ -160,6 +160,11 @@ void lin_device(double alpha, const int *Ap, const int *Ai, const double *Ax, do
                 const int *Bi, const double *Bx, int64_t ncols, DBuf<int64_t> &Cp, DBuf<int> &Ci,
                 DBuf<double> &Cx, int64_t *nnzC, hipStream_t s);
 
+void kronecker_device(int nrowsB, const int *Ap, const int *Ai, const double *Ax, int64_t ncolsA, const int *Bp,
+                      const int *Bi, const double *Bx, int64_t ncolsB, DBuf<int64_t> &Cp, DBuf<int> &Ci,
+                      DBuf<double> &Cx, int64_t *nnzC, hipStream_t s);
+void take_diag_device(const int *Ap, const int *Ai, const double *Ax, int n, double *d, hipStream_t s);
+
 // ---- SpGEMM (spgemm.hip) ------------------------------------------------------------------
 void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai, const double *Ax,
                    int64_t ncolsB, const int *Bp, const int *Bi, const double *Bx, DBuf<int64_t> &Cp,

@@ -490,7 +490,8 @@ def lin(alpha, matA, beta, matB):
     return _take_matrix("spl_lin", st, nr, nc, cp, ci, cx)
 
 
-# ---- structural combinators (host-side index plumbing) -----------------------------------------------
+# ---- structural combinators: concatenations are host-side index plumbing (pure data movement
+# between host arrays); kronecker and takeDiag run on the device ----------------------------------
 
 def _lengths(mat):
     return np.diff(mat.pointers)
@@ -513,12 +514,14 @@ def zeros(nrows, ncols):
 
 
 def takeDiag(mat):
-    out = np.zeros(min(mat.nrows, mat.ncols), dtype=F64)  # :636-648
-    for c in range(len(out)):
-        _, ix, xs = slice(mat, c)
-        hit = np.nonzero(ix == c)[0]
-        if len(hit):
-            out[c] = xs[hit[0]]
+    """diagonal as a dense vector, 0 where nothing is stored (Sparse.hs:636-648); on the device"""
+    if mat.is_complex:
+        re, im = mat._parts()
+        return takeDiag(re) + 1j * takeDiag(im)
+    _ffi.require_gpu()
+    a = mat._tuple32()
+    out = np.zeros(min(mat.nrows, mat.ncols), dtype=F64)
+    check("spl_take_diag", lib().spl_take_diag(a[0], a[1], p_i32(a[2]), p_i32(a[3]), p_f64(a[4]), p_f64(out)))
     return out
 
 
@@ -609,19 +612,23 @@ def blockDiag(mats):
 
 
 def kronecker(matA, matB):
-    """Kronecker product (Sparse.hs:599-634)."""
-    lA, lB = _lengths(matA), _lengths(matB)
-    ptrs = np.concatenate([[0], np.cumsum(np.outer(lA, lB).ravel())]).astype(I64)
-    idx_parts, val_parts = [], []
-    for na in range(matA.ncols):
-        _, ia, xa = slice(matA, na)
-        for nb in range(matB.ncols):
-            _, ib, xb = slice(matB, nb)
-            idx_parts.append((ia[:, None] * matB.nrows + ib[None, :]).ravel())
-            val_parts.append((xa[:, None] * xb[None, :]).ravel())
-    idx = np.concatenate(idx_parts) if idx_parts else np.zeros(0, dtype=I64)
-    val = np.concatenate(val_parts) if val_parts else np.zeros(0, dtype=F64)
-    return Matrix(matA.ncols * matB.ncols, matA.nrows * matB.nrows, ptrs, idx, val)
+    """Kronecker product (Sparse.hs:597-634), assembled on the device: column ja*ncols(B)+jb holds
+    the rows ia*nrows(B)+ib with values b*a."""
+    if matA.is_complex or matB.is_complex:
+        ar, ai = (matA if matA.is_complex else cmap(lambda v: v.astype(C128), matA))._parts()
+        br, bi = (matB if matB.is_complex else cmap(lambda v: v.astype(C128), matB))._parts()
+        rr, ii, ri, ir = kronecker(ar, br), kronecker(ai, bi), kronecker(ar, bi), kronecker(ai, br)
+        # all four share the pattern of the complex product; (ar + i ai)(br + i bi) componentwise
+        return Matrix(rr.ncols, rr.nrows, rr.pointers, rr.indices,
+                      (rr.values - ii.values) + 1j * (ri.values + ir.values))
+    _ffi.require_gpu()
+    a, b = matA._tuple32(), matB._tuple32()
+    nr, nc = C.c_int(), C.c_int()
+    cp, ci, cx = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    st = lib().spl_kronecker(a[0], a[1], p_i32(a[2]), p_i32(a[3]), p_f64(a[4]), b[0], b[1], p_i32(b[2]),
+                             p_i32(b[3]), p_f64(b[4]), C.byref(nr), C.byref(nc), C.byref(cp), C.byref(ci),
+                             C.byref(cx))
+    return _take_matrix("spl_kronecker", st, nr, nc, cp, ci, cx)
 
 
 def pack(mat):

@@ -77,6 +77,8 @@ def test_kronecker_format(gpu, pkg, O, a, b):
     K = pkg.kronecker(A, B)
     assert check_matrix(O, K)
     assert np.array_equal(pkg.pack(K), np.kron(pkg.pack(A), pkg.pack(B)))
+    assert tuples_equal(mat_to_tuple(K), O.kronecker(mat_to_tuple(A), mat_to_tuple(B)))  # device == restatement
+    assert np.array_equal(pkg.takeDiag(K), O.take_diag(mat_to_tuple(K)))
 
 
 # describe "diag"
@@ -213,3 +215,24 @@ def test_fromBlocksDiag_format(gpu, pkg, O, data):
 def test_fromForeign_withConstMatrix(gpu, pkg, a):
     A = pkg.fromTriples(*a)
     assert pkg.withConstMatrix(A, lambda *t: pkg.fromForeign(True, *t)) == A
+
+
+def test_kronecker_large_and_edges(gpu, pkg, O):
+    """the reference's own model problem at size: kronecker (ident n) T + kronecker T (ident n) has
+    5 n^2 - 4 n entries; plus empty operands, rectangular operands and complex values"""
+    n = 300
+    T = pkg.fromTriples(n, n, [(i, i, 2.0) for i in range(n)] + [(i, i + 1, -1.0) for i in range(n - 1)] +
+                        [(i + 1, i, -1.0) for i in range(n - 1)])
+    A = pkg.kronecker(pkg.ident(n), T) + pkg.kronecker(T, pkg.ident(n))
+    assert A.nrows == n * n and int(A.pointers[-1]) == 5 * n * n - 4 * n
+    assert np.array_equal(pkg.takeDiag(A), np.full(n * n, 4.0))
+    assert check_matrix(O, A)
+    Z = pkg.kronecker(pkg.zeros(3, 2), T)
+    assert Z == pkg.zeros(3 * n, 2 * n)
+    R = pkg.fromTriples(2, 3, [(0, 2, 1.5), (1, 0, -2.0)])
+    K = pkg.kronecker(R, R)
+    assert (K.nrows, K.ncols) == (4, 9) and np.array_equal(pkg.pack(K), np.kron(pkg.pack(R), pkg.pack(R)))
+    Cm = pkg.Matrix(2, 2, [0, 1, 2], [0, 1], np.array([1 + 2j, 3 - 1j]))
+    Kc = pkg.kronecker(Cm, Cm)
+    assert np.array_equal(pkg.pack(Kc), np.kron(pkg.pack(Cm), pkg.pack(Cm)))
+    assert np.array_equal(pkg.takeDiag(Cm), np.array([1 + 2j, 3 - 1j]))

@@ -303,3 +303,22 @@ def test_rmat_generator(O):
     assert abs(np.mean(r) - 511.5) < 20
     rs, _, _ = O.gen_rmat_coo(10, 5000, abc=(0.57, 0.19, 0.19))
     assert np.mean(rs) < 400  # Graph500 skew towards low ids
+
+
+def test_oracle_kronecker_and_take_diag_against_dense():
+    """numpy restatement of kronecker / takeDiag (Sparse.hs:597-648) against np.kron"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(12)
+    for (ar, ac, ak), (br, bc, bk) in (((4, 3, 7), (2, 5, 6)), ((1, 1, 1), (6, 6, 20)), ((3, 3, 0), (2, 2, 3))):
+        A = O.compress(ar, ac, rng.integers(0, ar, ak), rng.integers(0, ac, ak), rng.integers(-4, 5, ak).astype(float))
+        B = O.compress(br, bc, rng.integers(0, br, bk), rng.integers(0, bc, bk), rng.integers(-4, 5, bk).astype(float))
+        K = O.kronecker(A, B)
+        assert O.check_matrix(K) == 0
+
+        def dense(m):
+            out = np.zeros((m[0], m[1]))
+            out[m[3], np.repeat(np.arange(m[1]), np.diff(m[2]))] = m[4]
+            return out
+
+        assert np.array_equal(dense(K), np.kron(dense(A), dense(B)))
+        assert np.array_equal(O.take_diag(K), np.diag(dense(K))[:min(K[0], K[1])])
