@@ -20,6 +20,7 @@
 // A fill-reducing multifrontal ordering is the next step.
 #include <stdio.h>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -52,7 +53,7 @@ struct Numeric {
   // 1: the matrix is NOT diagonally dominant by columns and the no-interchange factors are a
   // speculation; solve checks the backward error it computes anyway and, if it is not at
   // rounding level, refactors with partial pivoting (under `mu`) and solves again
-  int speculative = 0;
+  std::atomic<int> speculative{0};
   std::mutex mu;
   DBuf<double> AB;
   DBuf<double> blkinv;  // no-pivot path: inv(L11), inv(U11) of every diagonal block
@@ -682,8 +683,8 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B)
       double worst = 0.0;
       for (int c = 0; c < k; ++c) worst = (omega[(size_t)c] <= worst) ? worst : omega[(size_t)c];  // NaN -> worst
       if (turn.owns_lock() && N->speculative && !(worst <= 1e-13)) {
-        N->speculative = 0;
         factor_band(N, false, s);
+        N->speculative = 0;  // only now may other threads use the object without taking turns
         goto again;
       }
     }
