@@ -1,0 +1,638 @@
+// dense_lu_kernels.hpp — the blocked LU kernels WITHOUT row interchanges and their blocked solves,
+// shared by the band path (band_nopiv.hip) and the multifrontal fronts (multifrontal.hip).  Included
+// into each of those translation units; everything lives in an anonymous namespace.  See
+// band_nopiv.hip for the algorithm notes.
+#pragma once
+
+#include <algorithm>
+
+#include "common.hpp"
+
+// dense-kernel work with no bit-parity contract (parity of the solve step is defined on the
+// solution): allow fused multiply-adds here although the library default is -ffp-contract=off
+#pragma clang fp contract(fast)
+
+namespace spl {
+namespace {
+
+constexpr int NB = 64;   // panel width
+
+// View of the matrix being factored.  Band storage: A(i,j) = AB[(ku + i) + j*(ldab-1)], doff = ku.
+// A dense column-major matrix with leading dimension ld is the same thing with doff = 0,
+// ldab = ld + 1 and kl = ku = n (every entry "in band"): the multifrontal fronts use that.
+struct Band {
+  double *AB;
+  int n, kl, ku, ldab, doff;
+  __device__ __forceinline__ bool in_band(int i, int j) const { return i - j <= kl && j - i <= ku; }
+  __device__ __forceinline__ double &at(int i, int j) const {
+    return AB[(size_t)(doff + i) + (size_t)j * (size_t)(ldab - 1)];
+  }
+  __device__ __forceinline__ double get(int i, int j) const { return in_band(i, j) ? at(i, j) : 0.0; }
+};
+inline Band band_view(double *AB, int n, int kl, int ku, int ldab) { return Band{AB, n, kl, ku, ldab, ku}; }
+inline Band dense_view(double *F, int n, int ld) { return Band{F, n, n, n, ld + 1, 0}; }
+
+// ---- factorisation ----------------------------------------------------------------------------
+typedef double double4v __attribute__((ext_vector_type(4)));
+constexpr int LDP = NB + 1;                                  // padded leading dimension in LDS
+constexpr size_t kTileBytes = (size_t)NB * LDP * sizeof(double);
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// LU of the diagonal block held in LDS tile D (identity-padded beyond jb), then the explicit
+// inverses of its two triangular factors: the triangular solves of the panel then become small
+// GEMMs on the matrix cores, and a block of the triangular solve a matrix-vector product.
+// Diagonally dominant blocks are well conditioned, so explicit inverses are safe here.
+//
+// This chain of 64 dependent pivots sits on the critical path of every block step, so it is kept
+// in registers: 256 threads, lane = row, wave w owns the columns c = w mod 4 (16 per thread, all
+// indices static after unrolling).  Row k of a rank-1 update comes from lane k of the same wave
+// (v_readlane); only the multiplier column crosses waves, through LDS, one barrier per pivot.
+// The two inverses are built the same way (right-looking substitution on an identity), U^-1 with
+// k descending and L^-1 with k ascending in the same loop.
+// Results: LU'd block to band storage and tile D, inverses (NB x NB column-major) to invL / invU.
+__device__ __forceinline__ void diag_block_factor(const Band &b, int j0, int jb, double (*D)[LDP],
+                                                  double (*lcol)[NB], int *__restrict__ singular,
+                                                  double *__restrict__ invL, double *__restrict__ invU) {
+  const int tid = threadIdx.x;
+  const int tr = tid & 63, tc = tid >> 6;
+  constexpr int NS = NB / 4;  // register slots per thread
+  double a[NS];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) a[u] = D[tr][4 * u + tc];
+  // The pivot loops stay rolled (straight-line code of this size would run at instruction-fetch
+  // speed).  Register slots must be indexed statically, so the slots are shifted down by one
+  // after every group of 4 pivots: in group g slot j holds column 4 (g + j) + wave, the pivot
+  // columns of the group are always slot 0, and finished columns leave through tile D.
+#pragma unroll 1
+  for (int g = 0; g < NS; ++g) {
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw) {
+      const int k = 4 * g + kw;
+      if (tc == kw) {
+        const double piv = readlane_f64(a[0], k);
+        if (piv == 0.0) {
+          if (tr == 0) atomicOr(singular, 1);
+        } else if (tr > k) {
+          a[0] = a[0] / piv;
+        }
+        lcol[k & 1][tr] = a[0];
+      }
+      __syncthreads();
+      const double l = tr > k ? lcol[k & 1][tr] : 0.0;
+      if (tc > kw) a[0] -= l * readlane_f64(a[0], k);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        if (g + 4 * qd < NS) {  // some slot of this quarter still holds a live column
+#pragma unroll
+          for (int j = (qd == 0 ? 1 : 4 * qd); j < 4 * qd + 4; ++j) a[j] -= l * readlane_f64(a[j], k);
+        }
+      }
+    }
+    D[tr][4 * g + tc] = a[0];
+#pragma unroll
+    for (int j = 0; j + 1 < NS; ++j) a[j] = a[j + 1];
+    a[NS - 1] = 0.0;
+  }
+  __syncthreads();
+  for (int c = tc; c < jb; c += 4)
+    if (tr < jb && b.in_band(j0 + tr, j0 + c)) b.at(j0 + tr, j0 + c) = D[tr][c];
+  // reciprocals of the pivots, once
+  double *dinv = &lcol[0][0];
+  if (tid < NB) {
+    const double d = D[tid][tid];
+    dinv[tid] = d != 0.0 ? 1.0 / d : 0.0;
+  }
+  __syncthreads();
+  double x[NS], y[NS];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) x[u] = y[u] = (tr == 4 * u + tc) ? 1.0 : 0.0;
+#pragma unroll 1
+  for (int s = 0; s < NB; ++s) {
+    {  // U^-1: row k final after scaling by 1/U(k,k); rows above lose U(i,k) * row k
+      const int k = NB - 1 - s, ks = k >> 2;
+      const double dk = dinv[k];
+      const double uik = tr < k ? D[tr][k] : 0.0;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        if (4 * qd + 3 >= ks) {  // X(k, c) is zero for c < k
+#pragma unroll
+          for (int u = 4 * qd; u < 4 * qd + 4; ++u) {
+            const double xk = readlane_f64(x[u], k) * dk;
+            x[u] = (tr == k) ? xk : x[u] - uik * xk;
+          }
+        }
+      }
+    }
+    {  // L^-1 (unit diagonal): rows below lose L(i,k) * row k
+      const int k = s, ks = k >> 2;
+      const double lik = tr > k ? D[tr][k] : 0.0;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        if (4 * qd <= ks) {  // Y(k, c) is zero for c > k
+#pragma unroll
+          for (int u = 4 * qd; u < 4 * qd + 4; ++u) y[u] -= lik * readlane_f64(y[u], k);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const int c = 4 * u + tc;
+    invU[tr + c * NB] = x[u];
+    invL[tr + c * NB] = y[u];
+  }
+}
+
+__global__ __launch_bounds__(256) void diag_lu_kernel(Band b, int j0, int jb, int *__restrict__ singular,
+                                                      double *__restrict__ invL, double *__restrict__ invU) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double(*D)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);
+  double(*lcol)[NB] = reinterpret_cast<double(*)[NB]>(dsm + NB * LDP);
+  const int tr = threadIdx.x & 63, tc = threadIdx.x >> 6;
+  for (int c = tc; c < NB; c += 4)
+    D[tr][c] = (tr < jb && c < jb) ? b.get(j0 + tr, j0 + c) : (tr == c ? 1.0 : 0.0);
+  __syncthreads();
+  diag_block_factor(b, j0, jb, D, lcol, singular, invL, invU);
+}
+
+// 64 x 64 x 64 product of two LDS tiles on the fp64 matrix cores:
+//     acc[a][c][r] = sum_k Cs[k][qc + a*16 + lane/16 + 4r] * Rs[k][qr + c*16 + lane%16]
+// Cs[k][.] is indexed by the output COLUMN, Rs[k][.] by the output ROW, so a lane's 16 neighbours
+// hold 16 consecutive rows of one column: 128 contiguous bytes of band storage per access.  Each
+// of the 4 wavefronts owns a 32 x 32 quadrant = 2 x 2 MFMA tiles.  v_mfma_f64_16x16x4_f64 layout
+// probed on gfx950 (tools/probe/mfma_f64_probe.hip): lane l supplies A[l%16][l/16] and
+// B[l/16][l%16] and holds C[(l/16) + 4*r][l%16] in element r.
+struct TilePos {
+  int qr, qc, li, lk;
+  __device__ TilePos() {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    qr = (wave & 1) * 32, qc = (wave >> 1) * 32, li = lane & 15, lk = lane >> 4;
+  }
+  __device__ int row(int c) const { return qr + c * 16 + li; }
+  __device__ int col(int a, int r) const { return qc + a * 16 + lk + 4 * r; }
+};
+
+template <int KD>
+__device__ __forceinline__ void mfma_tile_64(const double (*Cs)[LDP], const double (*Rs)[LDP], const TilePos &p,
+                                             double4v (&acc)[2][2]) {
+#pragma unroll 4
+  for (int k0 = 0; k0 < KD; k0 += 4) {
+    double af[2], bf[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) af[a] = Cs[k0 + p.lk][p.qc + a * 16 + p.li];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bf[c] = Rs[k0 + p.lk][p.qr + c * 16 + p.li];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[c], acc[a][c], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void zero_acc(double4v (&acc)[2][2]) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[a][c] = (double4v){0.0, 0.0, 0.0, 0.0};
+}
+
+// panel solves as GEMMs: tiles [0, ntile_l): L21 tile (64 rows) <- A21 tile * invU;
+// tiles [ntile_l, ...): U12 tile (64 columns) <- invL * A12 tile.  In place.
+__global__ __launch_bounds__(256) void trsm_gemm_kernel(Band b, int j0, int jb, int nrows_below, int ncols_right,
+                                                        const double *__restrict__ invL,
+                                                        const double *__restrict__ invU) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double(*Cs)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);            // [k][output column]
+  double(*Rs)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + NB * LDP);  // [k][output row]
+  const int tid = threadIdx.x;
+  const int ntile_l = (nrows_below + 63) / 64;
+  const bool is_l = (int)blockIdx.x < ntile_l;
+  const int rend = j0 + jb + nrows_below, cend = j0 + jb + ncols_right;
+  int r0, c0;
+  if (is_l) {
+    r0 = j0 + jb + blockIdx.x * 64, c0 = j0;
+    for (int t = tid; t < NB * 64; t += 256) {  // Rs[k][r] = A21(r0 + r, j0 + k)
+      const int r = t % 64, k = t / 64;
+      Rs[k][r] = (k < jb && r0 + r < rend) ? b.get(r0 + r, j0 + k) : 0.0;
+    }
+    for (int t = tid; t < NB * NB; t += 256) Cs[t % NB][t / NB] = invU[t];  // Cs[k][c] = invU(k, c)
+  } else {
+    r0 = j0, c0 = j0 + jb + ((int)blockIdx.x - ntile_l) * 64;
+    for (int t = tid; t < NB * NB; t += 256) Rs[t / NB][t % NB] = invL[t];  // Rs[k][r] = invL(r, k)
+    for (int t = tid; t < NB * 64; t += 256) {  // Cs[k][c] = A12(j0 + k, c0 + c)
+      const int k = t % NB, c = t / NB;
+      Cs[k][c] = (k < jb && c0 + c < cend) ? b.get(j0 + k, c0 + c) : 0.0;
+    }
+  }
+  __syncthreads();
+  const TilePos p;
+  double4v acc[2][2];
+  zero_acc(acc);
+  mfma_tile_64<NB>(Cs, Rs, p, acc);
+  const int rlim = is_l ? rend : j0 + jb, clim = is_l ? j0 + jb : cend;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = r0 + p.row(c), j = c0 + p.col(a, r);
+        if (i < rlim && j < clim && b.in_band(i, j)) b.at(i, j) = acc[a][c][r];
+      }
+}
+
+// Trailing update  A(rows, cols) -= L(rows, kb .. kb+klen) * U(kb .. kb+klen, cols)  on 64 x 64
+// tiles of the region rows [rb, re) x columns [cb, ce), rb == cb on the diagonal.  K is staged
+// through LDS in slices of KS = 32 (34 KB per workgroup, 4 workgroups per CU); klen is 64 for a
+// single block step and 128 when two block steps share one pass over the window, which halves
+// the read-modify-write traffic of the window.  Entries outside the band read as zero and are
+// never written.
+//   lshape = 0: 2-D grid over the whole region.
+//   lshape = 1: 1-D grid over the first tile column and the first tile row only (the panels the
+//               second block step of a pair needs before the shared pass).
+// Look-ahead: the workgroup of tile (0,0) -- the next diagonal block -- goes on to factor and
+// invert it while the other tiles are still being updated, which takes the diagonal-block chain
+// off the critical path.
+constexpr int KS = 32;
+struct Region {
+  int rb, re, cb, ce, kb, klen, lshape, ntile_rows;
+  int npiv;  // pivots of the (partial) factorisation: the look-ahead only factors blocks below it
+};
+
+__global__ __launch_bounds__(256) void gemm_update_kernel(Band b, Region g, int *__restrict__ singular,
+                                                          double *__restrict__ next_invL,
+                                                          double *__restrict__ next_invU) {
+  int tx = blockIdx.x, ty = blockIdx.y;
+  if (g.lshape) {
+    tx = (int)blockIdx.x < g.ntile_rows ? (int)blockIdx.x : 0;
+    ty = (int)blockIdx.x < g.ntile_rows ? 0 : (int)blockIdx.x - g.ntile_rows + 1;
+  }
+  const int r0 = g.rb + tx * 64, c0 = g.cb + ty * 64;
+  if (r0 - (c0 + 63) > b.kl || c0 - (r0 + 63) > b.ku) return;  // tile entirely outside the band
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double(*Us)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);            // Us[k][c] = U(kb + k, c0 + c)
+  double(*Ls)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + KS * LDP);  // Ls[k][r] = L(r0 + r, kb + k)
+  const int tid = threadIdx.x;
+  // the tile of A22 is requested first, so that its HBM latency overlaps the staging and the MFMAs
+  // (entries outside this step's update range get a zero product; tile (0,0) needs them below)
+  const TilePos p;
+  double cold[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = r0 + p.row(c), j = c0 + p.col(a, r);
+        cold[a][c][r] = (i < b.n && j < b.n && b.in_band(i, j)) ? b.at(i, j) : 0.0;  // also beyond re/ce
+      }
+  double4v acc[2][2];
+  zero_acc(acc);
+  for (int k0 = 0; k0 < g.klen; k0 += KS) {
+    if (k0) __syncthreads();
+    for (int t = tid; t < KS * 64; t += 256) {
+      const int r = t % 64, k = t / 64;
+      Ls[k][r] = (k0 + k < g.klen && r0 + r < g.re) ? b.get(r0 + r, g.kb + k0 + k) : 0.0;
+    }
+    for (int t = tid; t < KS * 64; t += 256) {
+      const int k = t % KS, c = t / KS;
+      Us[k][c] = (k0 + k < g.klen && c0 + c < g.ce) ? b.get(g.kb + k0 + k, c0 + c) : 0.0;
+    }
+    __syncthreads();
+    mfma_tile_64<KS>(Us, Ls, p, acc);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = r0 + p.row(c), j = c0 + p.col(a, r);
+        cold[a][c][r] -= acc[a][c][r];
+        if (i < g.re && j < g.ce && b.in_band(i, j)) b.at(i, j) = cold[a][c][r];
+      }
+  if (tx != 0 || ty != 0 || r0 >= g.npiv) return;
+  // next diagonal block: rows/columns r0 .. r0 + jbn - 1, values still in registers
+  const int jbn = min(NB, g.npiv - r0);
+  __syncthreads();  // all waves are done reading Us / Ls
+  double(*D)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);
+  double(*lcol)[NB] = reinterpret_cast<double(*)[NB]>(dsm + NB * LDP);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tr = p.row(c), tcn = p.col(a, r);
+        D[tr][tcn] = (tr < jbn && tcn < jbn) ? cold[a][c][r] : (tr == tcn ? 1.0 : 0.0);
+      }
+  __syncthreads();
+  diag_block_factor(b, r0, jbn, D, lcol, singular, next_invL, next_invU);
+}
+
+// ---- blocked solves -----------------------------------------------------------------------------
+// The factorisation keeps inv(L11) and inv(U11) of every diagonal block, so a block of the
+// triangular solve is a 64 x 64 matrix-vector product instead of a 64-step substitution chain.
+// One launch eliminates a super block of SB = 4 blocks (256 unknowns).  `in` holds the right-hand
+// side entries not yet eliminated, `out` receives the solved super block; they are different
+// arrays, so every workgroup redoes the small in-super-block solve from the same read-only inputs
+// and then updates its own 64 rows of `in` outside the super block.
+//   MODE 0: L z = c (unit lower, forward)     1: U x = z (backward)
+//   MODE 2: U^T z = c (lower, forward)        3: L^T x = z (unit upper, backward)
+constexpr int SB = 4;
+
+// Workgroups of SW = 16 wavefronts: these kernels are chains of short latency-bound phases, and the
+// wider workgroup shortens every phase (more loads in flight per row).
+constexpr int SW = 16;
+
+// res[l][r] = sum_{t < nc} M(rb + l, cb + t) * vv[t][r], l < 64, r < NR right-hand sides; M =
+// matrix of the triangular system.  Untransposed (MODE 0/1) band storage runs down the rows:
+// lane = row, wave q takes t = q mod SW, partial sums meet in LDS.  Transposed (MODE 2/3) it runs
+// along t: lanes along t, wave q takes rows l = q mod SW, butterfly reduction.  A band entry is
+// loaded once for all NR right-hand sides.  Ends with the result visible to the whole workgroup.
+template <int MODE, int NR>
+__device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, const double (*vv)[NR],
+                                       double (*res)[NR], double (*part)[64][NR]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (MODE <= 1) {
+    const int i = rb + lane;
+    double acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = 0.0;
+    if (i >= 0 && i < b.n) {
+      int t = wave;
+      for (; t + 7 * SW < nc; t += 8 * SW) {  // 8 independent loads in flight per lane
+        double e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = b.get(i, cb + t + SW * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int r = 0; r < NR; ++r) acc[r] += e[u] * vv[t + SW * u][r];
+      }
+      for (; t < nc; t += SW) {
+        const double e = b.get(i, cb + t);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r] += e * vv[t][r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) part[wave][lane][r] = acc[r];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 64 * NR; o += SW * 64) {
+      const int l = o / NR, r = o % NR;
+      double tot = 0.0;
+#pragma unroll
+      for (int q = 0; q < SW; ++q) tot += part[q][l][r];
+      res[l][r] = tot;
+    }
+  } else {
+    // nc <= SB * NB = 256: at most 4 strips of 64 columns; the 4 rows of this wave and the strips
+    // are unrolled so that all 16 loads of a lane are in flight together
+    constexpr int RPW = 64 / SW;
+    double acc[RPW][NR];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[q][r] = 0.0;
+    double e[SB][RPW];
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const int t = lane + 64 * u;
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int i = rb + wave + SW * q;
+        e[u][q] = (t < nc && i >= 0 && i < b.n) ? b.get(cb + t, i) : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const int t = lane + 64 * u;
+      if (t < nc) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const double x = vv[t][r];
+#pragma unroll
+          for (int q = 0; q < RPW; ++q) acc[q][r] += e[u][q] * x;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RPW; ++q)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        double sacc = acc[q][r];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
+        if (lane == 0) res[wave + SW * q][r] = sacc;
+      }
+  }
+  __syncthreads();
+}
+
+// res[l][r] = sum_t T(l, t) * w[t][r] with T = inv(L11), inv(U11), inv(U11)^T, inv(L11)^T (MODE 0..3);
+// inv is column-major NB x NB.
+template <int MODE, int NR>
+__device__ __forceinline__ void gemv_inv(const double *__restrict__ inv, const double (*w)[NR], double (*res)[NR],
+                                         double (*part)[64][NR]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (MODE <= 1) {
+    double acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = 0.0;
+#pragma unroll
+    for (int u = 0; u < NB / SW; ++u) {
+      const int t = wave + SW * u;
+      const double e = inv[lane + t * NB];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[r] += e * w[t][r];
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) part[wave][lane][r] = acc[r];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 64 * NR; o += SW * 64) {
+      const int l = o / NR, r = o % NR;
+      double tot = 0.0;
+#pragma unroll
+      for (int q = 0; q < SW; ++q) tot += part[q][l][r];
+      res[l][r] = tot;
+    }
+  } else {
+    for (int l = wave; l < 64; l += SW) {
+      const double e = inv[lane + l * NB];  // T(l, t) = inv(t, l)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        double sacc = e * w[lane][r];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
+        if (lane == 0) res[l][r] = sacc;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// NR right-hand sides at once: column r of in/out starts at r * stride
+template <int MODE, int NR>
+__global__ __launch_bounds__(SW * 64) void solve_super_kernel(Band b, const double *__restrict__ invs, int j0,
+                                                              int jbs, double *in, double *__restrict__ out,
+                                                              size_t stride) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double(*v)[NR] = reinterpret_cast<double(*)[NR]>(dsm);                          // [SB * NB]
+  double(*w)[NR] = reinterpret_cast<double(*)[NR]>(dsm + SB * NB * NR);           // [NB]
+  double(*res)[NR] = reinterpret_cast<double(*)[NR]>(dsm + (SB + 1) * NB * NR);   // [NB]
+  double(*part)[64][NR] = reinterpret_cast<double(*)[64][NR]>(dsm + (SB + 2) * NB * NR);  // [SW]
+  constexpr bool fwd = (MODE == 0 || MODE == 2);
+  const int tid = threadIdx.x;
+  const int nsub = (jbs + NB - 1) / NB;
+  for (int t = tid; t < SB * NB * NR; t += SW * 64) (&v[0][0])[t] = 0.0;
+  __syncthreads();
+  for (int k = 0; k < nsub; ++k) {
+    const int sblk = fwd ? k : nsub - 1 - k;
+    const int js = j0 + sblk * NB, jb = min(NB, j0 + jbs - js);
+    // couplings with the sub-blocks of this super block that are already solved
+    const int cb = fwd ? j0 : js + jb;
+    const int nc = fwd ? js - j0 : j0 + jbs - (js + jb);
+    gemv64<MODE, NR>(b, js, cb, nc, v + (cb - j0), res, part);
+    for (int o = tid; o < NB * NR; o += SW * 64) {
+      const int l = o % NB, r = o / NB;
+      w[l][r] = l < jb ? in[(size_t)r * stride + js + l] - res[l][r] : 0.0;
+    }
+    __syncthreads();
+    const double *inv = invs + (size_t)(js / NB) * (2 * NB * NB) + ((MODE == 1 || MODE == 2) ? NB * NB : 0);
+    gemv_inv<MODE, NR>(inv, w, res, part);
+    for (int o = tid; o < NB * NR; o += SW * 64) {
+      const int l = o % NB, r = o / NB;
+      if (l < jb) v[js - j0 + l][r] = res[l][r];
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0)
+    for (int o = tid; o < jbs * NR; o += SW * 64) {
+      const int t = o % jbs, r = o / jbs;
+      out[(size_t)r * stride + j0 + t] = v[t][r];
+    }
+  // the 64 rows of this workgroup outside the super block
+  const int rb = fwd ? j0 + jbs + (int)blockIdx.x * 64 : j0 - ((int)blockIdx.x + 1) * 64;
+  gemv64<MODE, NR>(b, rb, j0, jbs, v, res, part);
+  for (int o = tid; o < 64 * NR; o += SW * 64) {
+    const int l = o % 64, r = o / 64;
+    const int i = rb + l;
+    const bool ok = fwd ? (i < b.n) : (i >= 0);
+    if (ok) in[(size_t)r * stride + i] -= res[l][r];
+  }
+}
+
+
+// ---- host drivers shared by the band path and the multifrontal fronts ---------------------------
+inline size_t inverse_block_elems(int npiv) { return (size_t)((npiv + NB - 1) / NB) * (2 * NB * NB); }
+
+inline void set_factor_attributes() {
+  static bool attr_set = false;
+  if (attr_set) return;
+  SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_lu_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
+  SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_gemm_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
+  SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_update_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));  // uses less
+  attr_set = true;
+}
+
+// Right-looking blocked LU without interchanges of the first npiv columns/rows of the view b
+// (npiv = b.n: the whole matrix); the trailing block is left holding the Schur complement.  The
+// inverses of the diagonal blocks go to d_invs (inverse_block_elems(npiv) doubles), a zero pivot sets
+// *d_singular.  Asynchronous on stream s.
+inline void factor_loop(const Band &b, int npiv, double *d_invs, int *d_singular, hipStream_t s) {
+  set_factor_attributes();
+  const int n = b.n, kl = b.kl, ku = b.ku;
+  const size_t gemm_lds = kTileBytes + 2 * NB * sizeof(double);
+  auto slot = [&](int j) { return d_invs + (size_t)(j / NB) * (2 * NB * NB); };
+  auto below_of = [&](int jend) { return std::max(0, std::min(n, jend + kl) - jend); };  // rows with in-band entries
+  auto right_of = [&](int jend) { return std::max(0, std::min(n, jend + ku) - jend); };
+  auto diag = [&](int j0, int jb) {
+    hipLaunchKernelGGL(diag_lu_kernel, dim3(1), dim3(256), kTileBytes + 2 * NB * sizeof(double), s, b, j0, jb,
+                       d_singular, slot(j0), slot(j0) + NB * NB);
+  };
+  auto trsm = [&](int j0, int jb) {
+    const int below = below_of(j0 + jb), right = right_of(j0 + jb);
+    const int tiles = (below + 63) / 64 + (right + 63) / 64;
+    if (tiles > 0)
+      hipLaunchKernelGGL(trsm_gemm_kernel, dim3((unsigned)tiles), dim3(256), 2 * kTileBytes, s, b, j0, jb, below,
+                         right, slot(j0), slot(j0) + NB * NB);
+  };
+  // trailing update of rows/cols from `origin` with the K range [kb, kb+klen); factors the diagonal
+  // block at `origin` on the way (look-ahead) when it is a pivot block.  Returns whether it did.
+  auto update = [&](int origin, int kb, int klen, int kend, bool lshape) {
+    // rows/columns reached by the blocks in the K range end at the reach of its LAST block
+    const int re = std::min(n, kend + kl), ce = std::min(n, kend + ku);
+    if (re <= origin || ce <= origin) return false;
+    const int ntr = (re - origin + 63) / 64, ntc = (ce - origin + 63) / 64;
+    Region g{origin, re, origin, ce, kb, klen, lshape ? 1 : 0, ntr, npiv};
+    const dim3 grid = lshape ? dim3((unsigned)(ntr + ntc - 1)) : dim3((unsigned)ntr, (unsigned)ntc);
+    hipLaunchKernelGGL(gemm_update_kernel, grid, dim3(256), gemm_lds, s, b, g, d_singular, slot(origin),
+                       slot(origin) + NB * NB);
+    return origin < npiv;
+  };
+  bool diag_done = false;  // the previous update already factored this diagonal block
+  int j0 = 0;
+  while (j0 < npiv) {
+    const int jb = std::min(NB, npiv - j0);
+    if (!diag_done) diag(j0, jb);
+    trsm(j0, jb);
+    if (j0 + 2 * NB <= npiv && kl >= NB && ku >= NB) {
+      // pair of block steps: the first one only updates the panels of the second (L-shape), then
+      // both update the rest of the window in one pass with K = 2 NB
+      const int j1 = j0 + NB;
+      if (!update(j1, j0, NB, j0 + NB, true)) diag(j1, NB);
+      trsm(j1, NB);
+      diag_done = update(j1 + NB, j0, 2 * NB, j1 + NB, false);
+      j0 += 2 * NB;
+    } else {
+      diag_done = update(j0 + jb, j0, jb, j0 + jb, false);
+      j0 += jb;
+    }
+  }
+}
+
+template <int MODE, int NR>
+inline void solve_pass(const Band &b, const double *d_invs, int bw, double *in, double *out, size_t stride,
+                       hipStream_t s) {
+  constexpr bool fwd = (MODE == 0 || MODE == 2);
+  constexpr size_t lds = (size_t)((SB + 2) * NB + SW * 64) * NR * sizeof(double);
+  static bool attr_set = false;  // one flag per instantiation
+  if (!attr_set) {
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_super_kernel<MODE, NR>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int n = b.n, step = SB * NB, nsup = (n + step - 1) / step;
+  for (int k = 0; k < nsup; ++k) {
+    const int j0 = (fwd ? k : nsup - 1 - k) * step, jbs = std::min(step, n - j0);
+    const int rows = fwd ? std::max(0, std::min(n, j0 + jbs + bw) - (j0 + jbs)) : std::min(j0, bw);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_super_kernel<MODE, NR>), dim3((unsigned)std::max(1, (rows + 63) / 64)),
+                       dim3(SW * 64), lds, s, b, d_invs, j0, jbs, in, out, stride);
+  }
+}
+
+template <int NR>
+inline void solve_group(int sys, const Band &b, const double *d_invs, double *d_c, double *d_z, size_t stride,
+                        hipStream_t s) {
+  if (sys == 0) {
+    solve_pass<0, NR>(b, d_invs, b.kl, d_c, d_z, stride, s);  // L forward: c -> z
+    solve_pass<1, NR>(b, d_invs, b.ku, d_z, d_c, stride, s);  // U backward: z -> c
+  } else {
+    solve_pass<2, NR>(b, d_invs, b.ku, d_c, d_z, stride, s);  // U^T forward: c -> z
+    solve_pass<3, NR>(b, d_invs, b.kl, d_z, d_c, stride, s);  // L^T backward: z -> c
+  }
+}
+
+
+}  // namespace
+}  // namespace spl

@@ -1,0 +1,321 @@
+// mf_symbolic.hpp — host side of the multifrontal LU: nested-dissection ordering of the pattern of
+// A + A^T and the frontal (assembly) tree built on it.  Plain C++17, no HIP: the same header is
+// compiled into the library (umfpack_di_symbolic) and into the CPU self-check tests/mf_check.cpp.
+//
+// Why: the band profile of umfpack.hip stores n x (kl + ku + 1) entries — 160 GB at 100^3 unknowns of
+// a 3-D grid, impossible at 200^3 (config C5).  Nested dissection cuts the fill to O(n^{4/3}) and the
+// work to O(n^2): each tree node is a dense frontal matrix [pivots | boundary] that is partially
+// factored by the same blocked fp64-MFMA kernels as the band path (a dense matrix is a band whose
+// kl, ku exceed its size), and passes its Schur complement to its parent (multifrontal.hip).
+//
+// Ordering: "automatic nested dissection" (George & Liu): a breadth-first level structure from a
+// pseudo-peripheral vertex of the current region, a middle level as vertex separator (smallest
+// level among the balanced ones, thinned by one pass), recursion on the two sides; regions of at most
+// `leaf` vertices become leaves.  Fronts are numbered in post-order, unknowns by front.
+#pragma once
+
+#include <stdint.h>
+#include <algorithm>
+#include <vector>
+
+namespace spl {
+namespace mf {
+
+constexpr int kBlock = 64;  // pivot block of the dense kernels (NB of band_nopiv.hip)
+
+struct Tree {
+  int n = 0, nfronts = 0, maxdepth = 0;
+  std::vector<int> perm, inv;            // new -> old, old -> new
+  std::vector<int> parent, slot, depth;  // per front; children have smaller ids than their parent;
+                                         // slot = position among the parent's children (0 or 1)
+  std::vector<int> p0, np, nb;           // pivots are the new indices [p0, p0 + np); nb boundary indices
+  std::vector<int64_t> bptr;             // nfronts + 1
+  std::vector<int> bidx;                 // boundary indices of every front (new numbering, ascending)
+  std::vector<int> front_of;             // front that eliminates a new index
+  std::vector<int> ld;                   // leading dimension of the dense front (>= np + nb)
+  std::vector<int64_t> foff, ioff, woff, roff;  // offsets: front matrix, inverse blocks, work vector, rel map
+  int64_t front_elems = 0, inv_elems = 0, work_elems = 0, rel_elems = 0;
+  double flops = 0.0;
+  std::vector<std::vector<int>> by_depth;  // fronts of each tree level
+  int fs(int f) const { return np[(size_t)f] + nb[(size_t)f]; }
+};
+
+namespace detail {
+
+struct Node {
+  int left = -1, right = -1;
+  int64_t pbeg = 0, pend = 0;  // pivots in `pool`
+};
+
+struct Dissector {
+  int n;
+  const std::vector<int64_t> &xadj;
+  const std::vector<int> &adj;
+  int leaf;
+  std::vector<int> verts, pool, in_region, seen, level, queue;
+  std::vector<int64_t> level_ptr;
+  std::vector<Node> nodes;
+  int region_stamp = 0, bfs_stamp = 0;
+
+  Dissector(int n_, const std::vector<int64_t> &xa, const std::vector<int> &ad, int leaf_)
+      : n(n_), xadj(xa), adj(ad), leaf(leaf_), verts((size_t)n_), in_region((size_t)n_, 0), seen((size_t)n_, 0),
+        level((size_t)n_, 0) {
+    for (int i = 0; i < n; ++i) verts[(size_t)i] = i;
+    pool.reserve((size_t)n);
+    queue.reserve((size_t)n);
+  }
+
+  // BFS inside the current region; fills queue (BFS order), level[], level_ptr; returns #reached
+  int bfs(int root) {
+    ++bfs_stamp;
+    queue.clear();
+    level_ptr.clear();
+    queue.push_back(root);
+    seen[(size_t)root] = bfs_stamp;
+    level[(size_t)root] = 0;
+    level_ptr.push_back(0);
+    size_t head = 0;
+    int cur = 0;
+    while (head < queue.size()) {
+      const int v = queue[head];
+      if (level[(size_t)v] != cur) {
+        cur = level[(size_t)v];
+        level_ptr.push_back((int64_t)head);
+      }
+      ++head;
+      for (int64_t p = xadj[(size_t)v]; p < xadj[(size_t)v + 1]; ++p) {
+        const int u = adj[(size_t)p];
+        if (in_region[(size_t)u] == region_stamp && seen[(size_t)u] != bfs_stamp) {
+          seen[(size_t)u] = bfs_stamp;
+          level[(size_t)u] = cur + 1;
+          queue.push_back(u);
+        }
+      }
+    }
+    level_ptr.push_back((int64_t)queue.size());
+    return (int)queue.size();
+  }
+
+  int make_leaf(int lo, int hi) {
+    Node nd;
+    nd.pbeg = (int64_t)pool.size();
+    for (int i = lo; i < hi; ++i) pool.push_back(verts[(size_t)i]);
+    nd.pend = (int64_t)pool.size();
+    nodes.push_back(nd);
+    return (int)nodes.size() - 1;
+  }
+
+  int dissect(int lo, int hi) {
+    const int size = hi - lo;
+    if (size <= leaf) return make_leaf(lo, hi);
+    ++region_stamp;
+    for (int i = lo; i < hi; ++i) in_region[(size_t)verts[(size_t)i]] = region_stamp;
+    int reached = bfs(verts[(size_t)lo]);
+    if (reached == size) reached = bfs(queue.back());  // from the far end: deeper, narrower levels
+    if (reached < size) {
+      // disconnected region: no separator needed.  All components are found and dealt into two
+      // groups of about equal size (largest first, each to the lighter group), so that a region
+      // with many small fragments does not become a chain of single-fragment nodes.
+      std::vector<int> comp_verts;
+      std::vector<int64_t> comp_ptr(1, 0);
+      comp_verts.reserve((size_t)size);
+      comp_verts.insert(comp_verts.end(), queue.begin(), queue.end());
+      comp_ptr.push_back((int64_t)comp_verts.size());
+      // mark by moving found vertices out of the region
+      for (int v : queue) in_region[(size_t)v] = 0;
+      for (int i = lo; i < hi; ++i) {
+        const int v = verts[(size_t)i];
+        if (in_region[(size_t)v] != region_stamp) continue;
+        bfs(v);
+        comp_verts.insert(comp_verts.end(), queue.begin(), queue.end());
+        comp_ptr.push_back((int64_t)comp_verts.size());
+        for (int u : queue) in_region[(size_t)u] = 0;
+      }
+      const int ncomp = (int)comp_ptr.size() - 1;
+      std::vector<int> order((size_t)ncomp);
+      for (int c = 0; c < ncomp; ++c) order[(size_t)c] = c;
+      std::sort(order.begin(), order.end(), [&](int a, int b) {
+        const int64_t sa = comp_ptr[(size_t)a + 1] - comp_ptr[(size_t)a], sb = comp_ptr[(size_t)b + 1] - comp_ptr[(size_t)b];
+        return sa != sb ? sa > sb : a < b;
+      });
+      std::vector<int> ga, gb;
+      int64_t wa = 0, wb = 0;
+      for (int c : order) {
+        const int64_t sz = comp_ptr[(size_t)c + 1] - comp_ptr[(size_t)c];
+        std::vector<int> &g = wa <= wb ? ga : gb;
+        (wa <= wb ? wa : wb) += sz;
+        g.insert(g.end(), comp_verts.begin() + comp_ptr[(size_t)c], comp_verts.begin() + comp_ptr[(size_t)c + 1]);
+      }
+      std::copy(ga.begin(), ga.end(), verts.begin() + lo);
+      std::copy(gb.begin(), gb.end(), verts.begin() + lo + (int)ga.size());
+      const int na = (int)ga.size();
+      std::vector<int>().swap(ga);
+      std::vector<int>().swap(gb);
+      std::vector<int>().swap(comp_verts);
+      Node nd;
+      nd.pbeg = nd.pend = (int64_t)pool.size();
+      const int l = dissect(lo, lo + na);
+      const int r = dissect(lo + na, hi);
+      nd.left = l;
+      nd.right = r;
+      nodes.push_back(nd);
+      return (int)nodes.size() - 1;
+    }
+    const int nlev = (int)level_ptr.size() - 1;
+    if (nlev < 3) return make_leaf(lo, hi);  // no interior level: nothing to separate
+    // smallest level among the balanced ones; the balance requirement is relaxed until one exists
+    int best = -1;
+    for (double frac : {0.30, 0.20, 0.10, 0.0}) {
+      int64_t best_size = -1;
+      for (int t = 1; t + 1 < nlev; ++t) {
+        const int64_t before = level_ptr[(size_t)t], after = (int64_t)size - level_ptr[(size_t)t + 1];
+        if ((double)std::min(before, after) < frac * size) continue;
+        const int64_t sz = level_ptr[(size_t)t + 1] - level_ptr[(size_t)t];
+        if (best < 0 || sz < best_size) { best = t; best_size = sz; }
+      }
+      if (best >= 0) break;
+    }
+    const int t = best;
+    // queue = [levels < t | level t | levels > t]; thin the separator: a vertex of level t without a
+    // neighbour in level t+1 can join the first side
+    std::vector<int> side1(queue.begin(), queue.begin() + level_ptr[(size_t)t]);
+    std::vector<int> sep, side2(queue.begin() + level_ptr[(size_t)t + 1], queue.end());
+    for (int64_t q = level_ptr[(size_t)t]; q < level_ptr[(size_t)t + 1]; ++q) {
+      const int v = queue[(size_t)q];
+      bool touches = false;
+      for (int64_t p = xadj[(size_t)v]; p < xadj[(size_t)v + 1] && !touches; ++p) {
+        const int u = adj[(size_t)p];
+        touches = in_region[(size_t)u] == region_stamp && level[(size_t)u] == t + 1;
+      }
+      if (touches) sep.push_back(v); else side1.push_back(v);
+    }
+    std::copy(side1.begin(), side1.end(), verts.begin() + lo);
+    std::copy(side2.begin(), side2.end(), verts.begin() + lo + (int)side1.size());
+    Node nd;
+    nd.pbeg = (int64_t)pool.size();
+    pool.insert(pool.end(), sep.begin(), sep.end());
+    nd.pend = (int64_t)pool.size();
+    const int n1 = (int)side1.size(), n2 = (int)side2.size();
+    std::vector<int>().swap(side1);
+    std::vector<int>().swap(side2);
+    std::vector<int>().swap(sep);
+    const int l = n1 > 0 ? dissect(lo, lo + n1) : -1;
+    const int r = n2 > 0 ? dissect(lo + n1, lo + n1 + n2) : -1;
+    nd.left = l;
+    nd.right = r;
+    nodes.push_back(nd);
+    return (int)nodes.size() - 1;
+  }
+};
+
+}  // namespace detail
+
+// Pattern of A given as CSC arrays (n x n); leaf = largest region that is not dissected further.
+inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T) {
+  T = Tree();
+  T.n = n;
+  // adjacency of A + A^T without the diagonal (duplicates are harmless for BFS and are removed from
+  // the boundary lists by sort + unique)
+  std::vector<int64_t> xadj((size_t)n + 1, 0);
+  for (int j = 0; j < n; ++j)
+    for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
+      const int i = Ai[p];
+      if (i != j) { ++xadj[(size_t)i + 1]; ++xadj[(size_t)j + 1]; }
+    }
+  for (int i = 0; i < n; ++i) xadj[(size_t)i + 1] += xadj[(size_t)i];
+  std::vector<int> adj((size_t)xadj[(size_t)n]);
+  {
+    std::vector<int64_t> cur(xadj.begin(), xadj.end() - 1);
+    for (int j = 0; j < n; ++j)
+      for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
+        const int i = Ai[p];
+        if (i != j) { adj[(size_t)cur[(size_t)i]++] = j; adj[(size_t)cur[(size_t)j]++] = i; }
+      }
+  }
+  detail::Dissector D(n, xadj, adj, leaf);
+  const int root = n > 0 ? D.dissect(0, n) : -1;
+  // nodes were pushed children-first, so node order is already a post-order
+  const int nf = (int)D.nodes.size();
+  (void)root;
+  T.nfronts = nf;
+  T.parent.assign((size_t)nf, -1);
+  T.slot.assign((size_t)nf, 0);
+  T.depth.assign((size_t)nf, 0);
+  T.p0.assign((size_t)nf, 0);
+  T.np.assign((size_t)nf, 0);
+  T.nb.assign((size_t)nf, 0);
+  T.perm.assign((size_t)n, 0);
+  T.inv.assign((size_t)n, 0);
+  T.front_of.assign((size_t)n, 0);
+  int next = 0;
+  for (int f = 0; f < nf; ++f) {
+    const detail::Node &nd = D.nodes[(size_t)f];
+    if (nd.left >= 0) { T.parent[(size_t)nd.left] = f; T.slot[(size_t)nd.left] = 0; }
+    if (nd.right >= 0) { T.parent[(size_t)nd.right] = f; T.slot[(size_t)nd.right] = nd.left >= 0 ? 1 : 0; }
+    T.p0[(size_t)f] = next;
+    T.np[(size_t)f] = (int)(nd.pend - nd.pbeg);
+    for (int64_t q = nd.pbeg; q < nd.pend; ++q) {
+      const int v = D.pool[(size_t)q];
+      T.perm[(size_t)next] = v;
+      T.inv[(size_t)v] = next;
+      T.front_of[(size_t)next] = f;
+      ++next;
+    }
+  }
+  for (int f = nf - 1; f >= 0; --f)
+    T.depth[(size_t)f] = T.parent[(size_t)f] < 0 ? 0 : T.depth[(size_t)T.parent[(size_t)f]] + 1;
+  T.maxdepth = 0;
+  for (int f = 0; f < nf; ++f) T.maxdepth = std::max(T.maxdepth, T.depth[(size_t)f]);
+  T.by_depth.assign((size_t)T.maxdepth + 1, std::vector<int>());
+  for (int f = 0; f < nf; ++f) T.by_depth[(size_t)T.depth[(size_t)f]].push_back(f);
+  // boundaries, bottom-up: later-eliminated neighbours of the pivots + what the children pass on
+  T.bptr.assign((size_t)nf + 1, 0);
+  std::vector<int> b;
+  for (int f = 0; f < nf; ++f) {
+    const detail::Node &nd = D.nodes[(size_t)f];
+    const int last = T.p0[(size_t)f] + T.np[(size_t)f];
+    b.clear();
+    for (int g = T.p0[(size_t)f]; g < last; ++g) {
+      const int v = T.perm[(size_t)g];
+      for (int64_t p = xadj[(size_t)v]; p < xadj[(size_t)v + 1]; ++p) {
+        const int h = T.inv[(size_t)adj[(size_t)p]];
+        if (h >= last) b.push_back(h);
+      }
+    }
+    for (int c : {nd.left, nd.right}) {
+      if (c < 0) continue;
+      for (int64_t q = T.bptr[(size_t)c]; q < T.bptr[(size_t)c + 1]; ++q)
+        if (T.bidx[(size_t)q] >= last) b.push_back(T.bidx[(size_t)q]);
+    }
+    std::sort(b.begin(), b.end());
+    b.erase(std::unique(b.begin(), b.end()), b.end());
+    T.bidx.insert(T.bidx.end(), b.begin(), b.end());
+    T.nb[(size_t)f] = (int)b.size();
+    T.bptr[(size_t)f + 1] = (int64_t)T.bidx.size();
+  }
+  // storage layout and work estimate
+  T.ld.assign((size_t)nf, 0);
+  T.foff.assign((size_t)nf, 0);
+  T.ioff.assign((size_t)nf, 0);
+  T.woff.assign((size_t)nf, 0);
+  T.roff.assign((size_t)nf, 0);
+  for (int f = 0; f < nf; ++f) {
+    const int64_t fs = T.fs(f), p = T.np[(size_t)f], q = T.nb[(size_t)f];
+    // leading dimension off the multiples of 32 doubles (column stride not a power of two)
+    int64_t ld = std::max<int64_t>(fs, 1);
+    if (ld % 32 == 0) ld += 2;
+    T.ld[(size_t)f] = (int)ld;
+    T.foff[(size_t)f] = T.front_elems;
+    T.front_elems += (ld * std::max<int64_t>(fs, 1) + 15) / 16 * 16;
+    T.ioff[(size_t)f] = T.inv_elems;
+    T.inv_elems += ((p + kBlock - 1) / kBlock) * 2 * kBlock * kBlock;
+    T.woff[(size_t)f] = T.work_elems;
+    T.work_elems += fs;
+    T.roff[(size_t)f] = T.rel_elems;
+    T.rel_elems += q;
+    T.flops += 2.0 / 3.0 * (double)p * p * p + 2.0 * (double)p * p * q + 2.0 * (double)p * q * q;
+  }
+}
+
+}  // namespace mf
+}  // namespace spl
