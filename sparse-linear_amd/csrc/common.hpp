@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <memory>
 #include <new>
 
 #include "../../include/sparse_linear_hip.h"
@@ -164,6 +165,18 @@ void kronecker_device(int nrowsB, const int *Ap, const int *Ai, const double *Ax
                       const int *Bi, const double *Bx, int64_t ncolsB, DBuf<int64_t> &Cp, DBuf<int> &Ci,
                       DBuf<double> &Cx, int64_t *nnzC, hipStream_t s);
 void take_diag_device(const int *Ap, const int *Ai, const double *Ax, int n, double *d, hipStream_t s);
+
+// ---- multifrontal LU without interchanges (multifrontal.hip, mf_symbolic.hpp) ------------------
+namespace mf {
+struct Tree;
+struct Factors;
+}  // namespace mf
+size_t mf_device_bytes(const mf::Tree &T);
+mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, const int *d_Ai, const double *d_Ax,
+                       const int *d_inv, hipStream_t s);
+int mf_singular(const mf::Factors *F);
+void mf_solve(const mf::Factors *F, int sys, double *d_c, int k, size_t stride, hipStream_t s);
+void mf_free(mf::Factors *F);
 
 // ---- SpGEMM (spgemm.hip) ------------------------------------------------------------------
 void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai, const double *Ax,

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "mf_symbolic.hpp"
 #include "../../include/umfpack_hip.h"
 
 namespace spl {
@@ -39,9 +40,11 @@ struct Symbolic {
   int n = 0;
   int nnz = 0;
   int kl = 0, ku = 0;
-  std::vector<int> perm;  // new -> old
+  std::vector<int> perm;  // new -> old (reverse Cuthill-McKee: the band paths)
   std::vector<int> inv;   // old -> new
   std::vector<int> Ap;    // pattern check in numeric (UMFPACK_ERROR_different_pattern)
+  // nested-dissection tree of the multifrontal path, present when that path is the cheaper one
+  std::shared_ptr<const mf::Tree> tree;
 };
 
 struct Numeric {
@@ -58,11 +61,17 @@ struct Numeric {
   DBuf<double> AB;
   DBuf<double> blkinv;  // no-pivot path: inv(L11), inv(U11) of every diagonal block
   DBuf<int> ipiv, perm, inv;
+  // multifrontal factors (then AB is empty and perm/inv hold the nested-dissection ordering); the
+  // band ordering is kept for the pivoting fallback
+  mf::Factors *mfact = nullptr;
+  std::shared_ptr<const mf::Tree> tree;
+  std::vector<int> band_perm, band_inv;
   Matrix *A = nullptr;   // rows of A   (residual b - A x)
   Matrix *At = nullptr;  // rows of A^T (residual b - A^T x)
   ~Numeric() {
     delete A;
     delete At;
+    if (mfact) mf_free(mfact);
   }
 };
 
@@ -408,6 +417,10 @@ int validate_host_csc(int n_row, int n_col, const int *Ap, const int *Ai) {
 // B^T z = c; kalloc >= k columns are allocated (a multiple of kSolveGroup when k > 1)
 void band_solve(const Numeric *N, int sys, double *d_c, int k, size_t stride, hipStream_t s) {
   if (N->n == 0 || k == 0) return;
+  if (N->mfact) {
+    mf_solve(N->mfact, sys, d_c, k, stride, s);
+    return;
+  }
   if (N->nopiv) {
     band_nopiv_solve(sys, N->n, N->kl, N->ku, N->ldab, N->AB.get(), N->blkinv.get(), d_c, k, stride, s);
     return;
@@ -429,11 +442,37 @@ void factor_solve(const Numeric *N, int sys, const double *d_b, double *d_x, dou
   hipLaunchKernelGGL(gather_perm_kernel, g, dim3(256), 0, s, n, N->inv.get(), d_work, d_x, stride);  // x[i] = z[inv[i]]
 }
 
+// install an ordering (new -> old, old -> new) on the device
+void set_ordering(Numeric *N, const std::vector<int> &perm, const std::vector<int> &inv, hipStream_t s) {
+  const size_t n = (size_t)N->n;
+  SPL_HIP(hipMemcpyAsync(N->perm.get(), perm.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
+  SPL_HIP(hipMemcpyAsync(N->inv.get(), inv.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
+  SPL_HIP(hipStreamSynchronize(s));
+}
+
+// multifrontal factors without interchanges on the nested-dissection tree (multifrontal.hip)
+void factor_multifrontal(Numeric *N, hipStream_t s) {
+  N->AB.release();
+  N->blkinv.release();
+  if (N->mfact) { mf_free(N->mfact); N->mfact = nullptr; }
+  size_t free_b = 0, total_b = 0;
+  SPL_HIP(hipMemGetInfo(&free_b, &total_b));
+  if (mf_device_bytes(*N->tree) > free_b - free_b / 8) throw DeviceError{SPL_ERROR_out_of_memory};
+  N->nopiv = 1;
+  N->mfact = mf_factor(N->tree, N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), N->inv.get(), s);
+  N->singular = mf_singular(N->mfact);
+}
+
 // (re)build the band factors of P A P^T from the device copy of A^T's rows (= the CSC arrays);
 // nopiv selects the blocked no-interchange factorisation (band_nopiv.hip) or LAPACK-style
 // partial pivoting.  Throws DeviceError; sets N->singular.
 void factor_band(Numeric *N, bool nopiv, hipStream_t s) {
   const int n = N->n;
+  if (N->mfact || N->tree) {  // leaving the multifrontal path: the band paths use the RCM ordering
+    if (N->mfact) { mf_free(N->mfact); N->mfact = nullptr; }
+    N->tree.reset();
+    set_ordering(N, N->band_perm, N->band_inv, s);
+  }
   N->nopiv = nopiv ? 1 : 0;
   N->ldab = nopiv ? band_nopiv_ldab(N->kl, N->ku) : (2 * N->kl + N->ku + 1);
   const size_t band_elems = (size_t)N->ldab * (size_t)n;
@@ -516,6 +555,19 @@ int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
     }
     S->kl = kl;
     S->ku = ku;
+    // Multifrontal or band?  The band factorisation costs about 2 n kl ku flops and n (kl+ku+1)
+    // entries; nested dissection is far cheaper on 2-D / 3-D meshes and no better on narrow bands.
+    // SPL_LU_METHOD=mf / band forces the choice (tests).
+    {
+      const char *method = getenv("SPL_LU_METHOD");
+      const bool force_mf = method && method[0] == 'm', force_band = method && method[0] == 'b';
+      const double band_flops = 2.0 * S->n * (double)kl * (double)ku;
+      if (!force_band && (force_mf || (S->n >= 4096 && band_flops > 1e9))) {
+        std::shared_ptr<mf::Tree> T = std::make_shared<mf::Tree>();
+        mf::build_tree(S->n, Ap, Ai, 256, *T);
+        if (force_mf || 4.0 * T->flops < band_flops) S->tree = T;
+      }
+    }
     *SymbolicOut = S;
     return UMFPACK_OK;
   } catch (const std::bad_alloc &) {
@@ -561,8 +613,10 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
     N->ipiv.alloc((size_t)n);
     N->perm.alloc((size_t)n);
     N->inv.alloc((size_t)n);
-    SPL_HIP(hipMemcpyAsync(N->perm.get(), S->perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
-    SPL_HIP(hipMemcpyAsync(N->inv.get(), S->inv.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    N->band_perm = S->perm;
+    N->band_inv = S->inv;
+    N->tree = S->tree;
+    set_ordering(N, N->tree ? N->tree->perm : N->band_perm, N->tree ? N->tree->inv : N->band_inv, s);
     // device copies of A for the residuals of the refinement: rows of A (transposed on the
     // device) and rows of A^T (the CSC arrays as they are)
     void *hA = nullptr;
@@ -583,7 +637,7 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
     if (!force_pivot)
       dominant = band_is_column_dominant(n, N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), s);
     if (!force_pivot && (dominant || !no_speculation)) {
-      factor_band(N, true, s);
+      if (N->tree) factor_multifrontal(N, s); else factor_band(N, true, s);
       N->speculative = dominant ? 0 : 1;
       if (N->speculative && N->singular) {  // a zero pivot without interchanges proves nothing
         N->speculative = 0;
@@ -728,11 +782,13 @@ int spl_umfpack_dimension(void *NumericIn) {
   return N ? N->n : 0;
 }
 
-// which factorisation the object holds now: 0 partial pivoting, 1 no interchanges (diagonally
-// dominant matrix), 2 no interchanges as a speculation (see umfpack_hip.h); -1 if invalid
+// which factorisation the object holds now: 0 band, partial pivoting; 1 band, no interchanges
+// (diagonally dominant matrix); 2 the same as a speculation; 3 / 4 multifrontal, no interchanges
+// (dominant / speculation) (see umfpack_hip.h); -1 if invalid
 int spl_umfpack_path(void *NumericIn) {
   Numeric *N = as_numeric(NumericIn);
   if (!N) return -1;
+  if (N->mfact) return N->speculative ? 4 : 3;
   return N->nopiv ? (N->speculative ? 2 : 1) : 0;
 }
 

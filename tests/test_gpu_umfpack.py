@@ -174,13 +174,13 @@ def test_speculative_no_interchange_path_spd(gpu, pkg, O):
     M = pkg.Matrix(n, n, S.indptr, S.indices, S.data)
     xs = rng.uniform(0.5, 1.5, n)
     fact = pkg.umfpack.factor(M, pkg.umfpack.analyze(M))
-    assert fact.path == 2
+    assert fact.path in (2, 4)  # band or multifrontal (SPL_LU_METHOD), as a speculation
     for mode in (0, 1):
         b = S @ xs  # symmetric: same system both ways
         x = pkg.umfpack.linearSolve_(fact, mode, M, b)
         assert np.max(np.abs(S @ x - b)) / (np.max(np.abs(b)) + np.max(np.abs(x))) < 1e-13
         assert np.max(np.abs(x - spla.spsolve(S, b))) / np.max(np.abs(xs)) < 1e-8
-    assert fact.path == 2  # the speculation held
+    assert fact.path in (2, 4)  # the speculation held
 
 
 def test_speculation_that_fails_is_replaced_by_pivoting(gpu, pkg, O, monkeypatch):
@@ -201,7 +201,7 @@ def test_speculation_that_fails_is_replaced_by_pivoting(gpu, pkg, O, monkeypatch
     xs = rng.uniform(0.5, 1.5, n)
     b = S @ xs
     fact = pkg.umfpack.factor(M, pkg.umfpack.analyze(M))
-    assert fact.path == 2
+    assert fact.path in (2, 4)
     x = pkg.umfpack.linearSolve_(fact, pkg.umfpack.UmfpackNormal, M, b)
     assert fact.path == 0  # replaced
     ref = spla.spsolve(S, b)
