@@ -204,26 +204,25 @@ __device__ __forceinline__ void zero_acc(double4v (&acc)[2][2]) {
 
 // panel solves as GEMMs: tiles [0, ntile_l): L21 tile (64 rows) <- A21 tile * invU;
 // tiles [ntile_l, ...): U12 tile (64 columns) <- invL * A12 tile.  In place.
-__global__ __launch_bounds__(256) void trsm_gemm_kernel(Band b, int j0, int jb, int nrows_below, int ncols_right,
-                                                        const double *__restrict__ invL,
-                                                        const double *__restrict__ invU) {
-  extern __shared__ __attribute__((aligned(16))) double dsm[];
+__device__ __forceinline__ void trsm_tile(const Band &b, int j0, int jb, int nrows_below, int ncols_right,
+                                          const double *__restrict__ invL, const double *__restrict__ invU,
+                                          int tile, double *dsm) {
   double(*Cs)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);            // [k][output column]
   double(*Rs)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + NB * LDP);  // [k][output row]
   const int tid = threadIdx.x;
   const int ntile_l = (nrows_below + 63) / 64;
-  const bool is_l = (int)blockIdx.x < ntile_l;
+  const bool is_l = tile < ntile_l;
   const int rend = j0 + jb + nrows_below, cend = j0 + jb + ncols_right;
   int r0, c0;
   if (is_l) {
-    r0 = j0 + jb + blockIdx.x * 64, c0 = j0;
+    r0 = j0 + jb + tile * 64, c0 = j0;
     for (int t = tid; t < NB * 64; t += 256) {  // Rs[k][r] = A21(r0 + r, j0 + k)
       const int r = t % 64, k = t / 64;
       Rs[k][r] = (k < jb && r0 + r < rend) ? b.get(r0 + r, j0 + k) : 0.0;
     }
     for (int t = tid; t < NB * NB; t += 256) Cs[t % NB][t / NB] = invU[t];  // Cs[k][c] = invU(k, c)
   } else {
-    r0 = j0, c0 = j0 + jb + ((int)blockIdx.x - ntile_l) * 64;
+    r0 = j0, c0 = j0 + jb + (tile - ntile_l) * 64;
     for (int t = tid; t < NB * NB; t += 256) Rs[t / NB][t % NB] = invL[t];  // Rs[k][r] = invL(r, k)
     for (int t = tid; t < NB * 64; t += 256) {  // Cs[k][c] = A12(j0 + k, c0 + c)
       const int k = t % NB, c = t / NB;
@@ -247,6 +246,13 @@ __global__ __launch_bounds__(256) void trsm_gemm_kernel(Band b, int j0, int jb, 
       }
 }
 
+__global__ __launch_bounds__(256) void trsm_gemm_kernel(Band b, int j0, int jb, int nrows_below, int ncols_right,
+                                                        const double *__restrict__ invL,
+                                                        const double *__restrict__ invU) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  trsm_tile(b, j0, jb, nrows_below, ncols_right, invL, invU, (int)blockIdx.x, dsm);
+}
+
 // Trailing update  A(rows, cols) -= L(rows, kb .. kb+klen) * U(kb .. kb+klen, cols)  on 64 x 64
 // tiles of the region rows [rb, re) x columns [cb, ce), rb == cb on the diagonal.  K is staged
 // through LDS in slices of KS = 32 (34 KB per workgroup, 4 workgroups per CU); klen is 64 for a
@@ -265,17 +271,12 @@ struct Region {
   int npiv;  // pivots of the (partial) factorisation: the look-ahead only factors blocks below it
 };
 
-__global__ __launch_bounds__(256) void gemm_update_kernel(Band b, Region g, int *__restrict__ singular,
-                                                          double *__restrict__ next_invL,
-                                                          double *__restrict__ next_invU) {
-  int tx = blockIdx.x, ty = blockIdx.y;
-  if (g.lshape) {
-    tx = (int)blockIdx.x < g.ntile_rows ? (int)blockIdx.x : 0;
-    ty = (int)blockIdx.x < g.ntile_rows ? 0 : (int)blockIdx.x - g.ntile_rows + 1;
-  }
+// one 64 x 64 tile (tx, ty) of the update; `lookahead`: tile (0,0) goes on to factor the next block
+__device__ __forceinline__ void update_tile(const Band &b, const Region &g, int tx, int ty, bool lookahead,
+                                            int *__restrict__ singular, double *__restrict__ next_invL,
+                                            double *__restrict__ next_invU, double *dsm) {
   const int r0 = g.rb + tx * 64, c0 = g.cb + ty * 64;
   if (r0 - (c0 + 63) > b.kl || c0 - (r0 + 63) > b.ku) return;  // tile entirely outside the band
-  extern __shared__ __attribute__((aligned(16))) double dsm[];
   double(*Us)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);            // Us[k][c] = U(kb + k, c0 + c)
   double(*Ls)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + KS * LDP);  // Ls[k][r] = L(r0 + r, kb + k)
   const int tid = threadIdx.x;
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void gemm_update_kernel(Band b, Region g, int 
         cold[a][c][r] -= acc[a][c][r];
         if (i < g.re && j < g.ce && b.in_band(i, j)) b.at(i, j) = cold[a][c][r];
       }
-  if (tx != 0 || ty != 0 || r0 >= g.npiv) return;
+  if (!lookahead || tx != 0 || ty != 0 || r0 >= g.npiv) return;
   // next diagonal block: rows/columns r0 .. r0 + jbn - 1, values still in registers
   const int jbn = min(NB, g.npiv - r0);
   __syncthreads();  // all waves are done reading Us / Ls
@@ -334,6 +335,50 @@ __global__ __launch_bounds__(256) void gemm_update_kernel(Band b, Region g, int 
       }
   __syncthreads();
   diag_block_factor(b, r0, jbn, D, lcol, singular, next_invL, next_invU);
+}
+
+__global__ __launch_bounds__(256) void gemm_update_kernel(Band b, Region g, int *__restrict__ singular,
+                                                          double *__restrict__ next_invL,
+                                                          double *__restrict__ next_invU) {
+  int tx = blockIdx.x, ty = blockIdx.y;
+  if (g.lshape) {
+    tx = (int)blockIdx.x < g.ntile_rows ? (int)blockIdx.x : 0;
+    ty = (int)blockIdx.x < g.ntile_rows ? 0 : (int)blockIdx.x - g.ntile_rows + 1;
+  }
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  update_tile(b, g, tx, ty, true, singular, next_invL, next_invU, dsm);
+}
+
+// The whole partial factorisation of one SMALL dense front by ONE workgroup (the multifrontal tree
+// has thousands of them per level; a launch per block step and front would serialise them).  Same
+// device code as the kernels above, tiles taken one after the other; the front lives in HBM / L2.
+__device__ __forceinline__ void front_factor_by_workgroup(const Band &b, int npiv, double *invs,
+                                                          int *__restrict__ singular, double *dsm) {
+  double(*D)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);
+  double(*lcol)[NB] = reinterpret_cast<double(*)[NB]>(dsm + NB * LDP);
+  const int n = b.n;
+  for (int j0 = 0; j0 < npiv; j0 += NB) {
+    const int jb = min(NB, npiv - j0);
+    double *invL = invs + (size_t)(j0 / NB) * (2 * NB * NB), *invU = invL + NB * NB;
+    const int tr = threadIdx.x & 63, tc = threadIdx.x >> 6;
+    for (int c = tc; c < NB; c += 4)
+      D[tr][c] = (tr < jb && c < jb) ? b.get(j0 + tr, j0 + c) : (tr == c ? 1.0 : 0.0);
+    __syncthreads();
+    diag_block_factor(b, j0, jb, D, lcol, singular, invL, invU);
+    __syncthreads();  // factors and inverses of the block are visible to the whole workgroup
+    const int rest = n - (j0 + jb);
+    if (rest <= 0) break;
+    const int ntile = (rest + 63) / 64;
+    for (int tile = 0; tile < 2 * ntile; ++tile) {
+      trsm_tile(b, j0, jb, rest, rest, invL, invU, tile, dsm);
+      __syncthreads();
+    }
+    Region g{j0 + jb, n, j0 + jb, n, j0, jb, 0, ntile, npiv};
+    for (int t = 0; t < ntile * ntile; ++t) {
+      update_tile(b, g, t % ntile, t / ntile, false, singular, nullptr, nullptr, dsm);
+      __syncthreads();
+    }
+  }
 }
 
 // ---- blocked solves -----------------------------------------------------------------------------
@@ -601,9 +646,12 @@ inline void factor_loop(const Band &b, int npiv, double *d_invs, int *d_singular
   }
 }
 
+// one triangular pass over the first npiv unknowns of the view (npiv = b.n: the whole system); in a
+// forward pass the rows of the view beyond npiv still receive their updates (the boundary rows of a
+// multifrontal front)
 template <int MODE, int NR>
 inline void solve_pass(const Band &b, const double *d_invs, int bw, double *in, double *out, size_t stride,
-                       hipStream_t s) {
+                       hipStream_t s, int npiv = -1) {
   constexpr bool fwd = (MODE == 0 || MODE == 2);
   constexpr size_t lds = (size_t)((SB + 2) * NB + SW * 64) * NR * sizeof(double);
   static bool attr_set = false;  // one flag per instantiation
@@ -612,9 +660,10 @@ inline void solve_pass(const Band &b, const double *d_invs, int bw, double *in, 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const int n = b.n, step = SB * NB, nsup = (n + step - 1) / step;
+  if (npiv < 0) npiv = b.n;
+  const int n = b.n, step = SB * NB, nsup = (npiv + step - 1) / step;
   for (int k = 0; k < nsup; ++k) {
-    const int j0 = (fwd ? k : nsup - 1 - k) * step, jbs = std::min(step, n - j0);
+    const int j0 = (fwd ? k : nsup - 1 - k) * step, jbs = std::min(step, npiv - j0);
     const int rows = fwd ? std::max(0, std::min(n, j0 + jbs + bw) - (j0 + jbs)) : std::min(j0, bw);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_super_kernel<MODE, NR>), dim3((unsigned)std::max(1, (rows + 63) / 64)),
                        dim3(SW * 64), lds, s, b, d_invs, j0, jbs, in, out, stride);

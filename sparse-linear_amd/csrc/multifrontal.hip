@@ -95,6 +95,22 @@ __global__ __launch_bounds__(256) void extend_add_kernel(const int *__restrict__
   fronts[t.foff[p] + (int64_t)rel[r] + (int64_t)rel[cc] * t.ld[p]] += v;
 }
 
+// small fronts of a tree level: one workgroup per front runs the whole partial factorisation
+__global__ __launch_bounds__(256) void front_factor_kernel(const int *__restrict__ list, TreeView t,
+                                                           double *__restrict__ fronts, double *__restrict__ invs,
+                                                           int *__restrict__ singular) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  const int f = list[blockIdx.x];
+  const int np = t.np[f];
+  if (np == 0) return;
+  const int fs = np + t.nb[f];
+  const Band b{fronts + t.foff[f], fs, fs, fs, t.ld[f] + 1, 0};
+  front_factor_by_workgroup(b, np, invs + t.ioff[f], singular, dsm);
+}
+
+constexpr int kSmallFront = 1024;  // fronts up to this size are factored by one workgroup each
+constexpr int kStreams = 8;        // larger fronts of a level are spread over this many streams
+
 // ---- solves: one workgroup per front -------------------------------------------------------------
 // M(i, j) of the triangular system a front contributes: F(i, j), or F(j, i) for the transposed systems
 template <bool TRANS>
@@ -115,6 +131,49 @@ __device__ __forceinline__ void apply_inverse_block(const double *__restrict__ i
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
   if (q == 0) v[l] = acc;
+}
+
+// W[i] -= sum_{tt < jb} M(i, c0 + tt) v[tt] for i in [ilo, ihi), by the 256 threads of the workgroup.
+// Untransposed the front runs down i (thread = row, 8 loads in flight); transposed it runs along tt
+// (a wavefront per row, lanes along tt, butterfly sum).
+template <bool TRANS>
+__device__ __forceinline__ void couple_block(const double *__restrict__ F, int ld, int ilo, int ihi, int c0, int jb,
+                                             const double *v, double *W) {
+  if (!TRANS) {
+    for (int i = ilo + threadIdx.x; i < ihi; i += blockDim.x) {
+      const double *row = F + (size_t)i + (size_t)c0 * ld;
+      double a0 = 0.0, a1 = 0.0;
+      int tt = 0;
+      for (; tt + 8 <= jb; tt += 8) {
+        double e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = row[(size_t)(tt + u) * ld];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+          a0 += e[u] * v[tt + u];
+          a1 += e[u + 1] * v[tt + u + 1];
+        }
+      }
+      for (; tt < jb; ++tt) a0 += row[(size_t)tt * ld] * v[tt];
+      W[i] -= a0 + a1;
+    }
+  } else {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const double vl = lane < jb ? v[lane] : 0.0;
+    constexpr int RW = 8;  // rows per wavefront and trip: 8 loads in flight per lane
+    for (int i0 = ilo + wave * RW; i0 < ihi; i0 += nw * RW) {
+      double e[RW];
+#pragma unroll
+      for (int u = 0; u < RW; ++u)
+        e[u] = (i0 + u < ihi && lane < jb) ? F[(size_t)(c0 + lane) + (size_t)(i0 + u) * ld] * vl : 0.0;
+#pragma unroll
+      for (int u = 0; u < RW; ++u) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) e[u] += __shfl_xor(e[u], m, 64);
+        if (lane == 0 && i0 + u < ihi) W[i0 + u] -= e[u];
+      }
+    }
+  }
 }
 
 // W = [rhs at the pivots | 0]
@@ -158,11 +217,7 @@ __global__ __launch_bounds__(256) void solve_forward_kernel(const int *__restric
     apply_inverse_block<TRANS>(inv, w, v);
     __syncthreads();
     if (threadIdx.x < jb) W[j0 + threadIdx.x] = v[threadIdx.x];
-    for (int i = j0 + jb + threadIdx.x; i < fs; i += blockDim.x) {
-      double acc = 0.0;
-      for (int tt = 0; tt < jb; ++tt) acc += sys_elem<TRANS>(F, ld, i, j0 + tt) * v[tt];
-      W[i] -= acc;
-    }
+    couple_block<TRANS>(F, ld, j0 + jb, fs, j0, jb, v, W);
     __syncthreads();
   }
 }
@@ -182,12 +237,13 @@ __global__ __launch_bounds__(256) void solve_backward_kernel(const int *__restri
   const int *b = t.bidx + t.bptr[f];
   for (int k = threadIdx.x; k < nb; k += blockDim.x) W[np + k] = x[b[k]];
   __syncthreads();
-  for (int i = threadIdx.x; i < np; i += blockDim.x) {
-    double acc = 0.0;
-    for (int k = 0; k < nb; ++k) acc += sys_elem<TRANS>(F, ld, i, np + k) * W[np + k];
-    W[i] -= acc;
+  for (int k0 = 0; k0 < nb; k0 += NB) {  // boundary columns in strips of 64, through LDS
+    const int kb = min(NB, nb - k0);
+    if (threadIdx.x < NB) v[threadIdx.x] = threadIdx.x < kb ? W[np + k0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    couple_block<TRANS>(F, ld, 0, np, np + k0, kb, v, W);
+    __syncthreads();
   }
-  __syncthreads();
   const int nblk = (np + NB - 1) / NB;
   for (int blk = nblk - 1; blk >= 0; --blk) {
     const int j0 = blk * NB, jb = min(NB, np - j0);
@@ -201,14 +257,68 @@ __global__ __launch_bounds__(256) void solve_backward_kernel(const int *__restri
       W[j0 + threadIdx.x] = v[threadIdx.x];
       x[p0 + j0 + threadIdx.x] = v[threadIdx.x];
     }
-    for (int i = threadIdx.x; i < j0; i += blockDim.x) {
-      double acc = 0.0;
-      for (int tt = 0; tt < jb; ++tt) acc += sys_elem<TRANS>(F, ld, i, j0 + tt) * v[tt];
-      W[i] -= acc;
-    }
+    couple_block<TRANS>(F, ld, 0, j0, j0, jb, v, W);
     __syncthreads();
   }
 }
+
+// ---- large fronts: the same steps spread over many workgroups -----------------------------------
+// boundary part of the solution into the front's work vector: W[np + k] = x[bidx[k]]
+__global__ __launch_bounds__(256) void front_gather_x_kernel(const int *__restrict__ b, int nb,
+                                                             const double *__restrict__ x, double *__restrict__ dst) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nb) dst[k] = x[b[k]];
+}
+
+// z[i] -= sum_k M(i, np + k) xb[k], i < np: 64 rows per workgroup
+template <bool TRANS>
+__global__ __launch_bounds__(256) void front_gemv_kernel(const double *__restrict__ F, int ld, int np, int nb,
+                                                         const double *__restrict__ xb, double *__restrict__ z) {
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * 64;
+  if (!TRANS) {
+    const int i = i0 + lane;
+    double a0 = 0.0, a1 = 0.0;
+    if (i < np) {
+      const double *row = F + (size_t)i + (size_t)np * ld;
+      int k = wave;
+      for (; k + 28 < nb; k += 32) {
+        double e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = row[(size_t)(k + 4 * u) * ld];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+          a0 += e[u] * xb[k + 4 * u];
+          a1 += e[u + 1] * xb[k + 4 * u + 4];
+        }
+      }
+      for (; k < nb; k += 4) a0 += row[(size_t)k * ld] * xb[k];
+    }
+    part[wave][lane] = a0 + a1;
+    __syncthreads();
+    if (wave == 0 && i < np) z[i] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  } else {
+    for (int r = wave; r < 64; r += 4) {
+      const int i = i0 + r;
+      if (i >= np) break;
+      const double *col = F + (size_t)np + (size_t)i * ld;  // M(i, np + k) = F(np + k, i)
+      double acc = 0.0;
+      for (int k = lane; k < nb; k += 64) acc += col[k] * xb[k];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+      if (lane == 0) z[i] -= acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void front_scatter_x_kernel(int p0, int np, const double *__restrict__ src,
+                                                              double *__restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < np) x[p0 + i] = src[i];
+}
+
+constexpr int kBigSolve = 3072;  // fronts above this size are solved by many workgroups
 
 }  // namespace
 
@@ -220,6 +330,10 @@ struct Factors {
   TreeView view;
   DBuf<double> fronts, invs;
   std::vector<DBuf<int>> level_lists;                // fronts of each depth
+  std::vector<DBuf<int>> small_lists;                // ... those factored by one workgroup each
+  std::vector<int> small_counts;
+  std::vector<DBuf<int>> solve_lists;                // ... those solved by one workgroup each
+  std::vector<int> solve_counts;
   std::vector<DBuf<int>> child_lists[2];             // children (by slot) of the fronts of each depth
   std::vector<int> child_counts[2];
   int singular = 0;
@@ -261,14 +375,32 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
                     D.rel.get(), D.bptr.get(), D.foff.get(), D.ioff.get(), D.woff.get(), D.roff.get()};
   const int nd = T.maxdepth + 1;
   F.level_lists.resize((size_t)nd);
+  F.small_lists.resize((size_t)nd);
+  F.small_counts.assign((size_t)nd, 0);
+  F.solve_lists.resize((size_t)nd);
+  F.solve_counts.assign((size_t)nd, 0);
   for (int sl = 0; sl < 2; ++sl) {
     F.child_lists[sl].resize((size_t)nd);
     F.child_counts[sl].assign((size_t)nd, 0);
   }
   std::vector<std::vector<int>> staged;  // host copies must outlive the asynchronous uploads
-  staged.reserve((size_t)2 * nd);
+  staged.reserve((size_t)4 * nd);
   for (int d = 0; d < nd; ++d) {
     upload_vec(F.level_lists[(size_t)d], T.by_depth[(size_t)d], s);
+    {
+      std::vector<int> small;
+      for (int f : T.by_depth[(size_t)d])
+        if (T.np[(size_t)f] > 0 && T.fs(f) <= kSmallFront) small.push_back(f);
+      F.small_counts[(size_t)d] = (int)small.size();
+      staged.push_back(std::move(small));
+      upload_vec(F.small_lists[(size_t)d], staged.back(), s);
+      std::vector<int> one_wg;
+      for (int f : T.by_depth[(size_t)d])
+        if (T.fs(f) <= kBigSolve) one_wg.push_back(f);
+      F.solve_counts[(size_t)d] = (int)one_wg.size();
+      staged.push_back(std::move(one_wg));
+      upload_vec(F.solve_lists[(size_t)d], staged.back(), s);
+    }
     if (d + 1 < nd) {
       std::vector<int> ch[2];
       for (int c : T.by_depth[(size_t)d + 1]) ch[T.slot[(size_t)c]].push_back(c);
@@ -291,6 +423,15 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
                        d_Ai, d_Ax, d_inv, F.view, F.fronts.get());
   DBuf<int> singular(1);
   SPL_HIP(hipMemsetAsync(singular.get(), 0, sizeof(int), s));
+  set_factor_attributes();
+  static bool attr_set = false;
+  if (!attr_set) {
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&front_factor_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
+    attr_set = true;
+  }
+  hipStream_t side[kStreams];
+  for (int i = 0; i < kStreams; ++i) SPL_HIP(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
   for (int d = nd - 1; d >= 0; --d) {
     // Schur complements of the children, one child slot after the other (two children of a parent
     // may touch the same entry: a fixed order keeps the sums reproducible)
@@ -303,12 +444,22 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
           hipLaunchKernelGGL(extend_add_kernel, dim3((unsigned)(ntile * ntile), (unsigned)F.child_counts[sl][(size_t)d]),
                              dim3(256), 0, s, F.child_lists[sl][(size_t)d].get(), F.view, F.fronts.get());
     }
+    // small fronts: one launch, one workgroup each; large fronts: the multi-launch blocked
+    // factorisation, independent fronts spread over side streams
+    SPL_HIP(hipStreamSynchronize(s));
+    if (F.small_counts[(size_t)d] > 0)
+      hipLaunchKernelGGL(front_factor_kernel, dim3((unsigned)F.small_counts[(size_t)d]), dim3(256), 2 * kTileBytes, s,
+                         F.small_lists[(size_t)d].get(), F.view, F.fronts.get(), F.invs.get(), singular.get());
+    int turn = 0;
     for (int f : T.by_depth[(size_t)d]) {
-      if (T.np[(size_t)f] == 0) continue;
+      if (T.np[(size_t)f] == 0 || T.fs(f) <= kSmallFront) continue;
       const Band b = dense_view(F.fronts.get() + T.foff[(size_t)f], T.fs(f), T.ld[(size_t)f]);
-      factor_loop(b, T.np[(size_t)f], F.invs.get() + T.ioff[(size_t)f], singular.get(), s);
+      factor_loop(b, T.np[(size_t)f], F.invs.get() + T.ioff[(size_t)f], singular.get(), side[turn++ % kStreams]);
     }
+    if (turn > 0)
+      for (int i = 0; i < kStreams && i < turn; ++i) SPL_HIP(hipStreamSynchronize(side[i]));
   }
+  for (int i = 0; i < kStreams; ++i) (void)hipStreamDestroy(side[i]);
   SPL_HIP(hipMemcpyAsync(&F.singular, singular.get(), sizeof(int), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
   SPL_HIP(hipGetLastError());
@@ -321,37 +472,76 @@ void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride,
   const mf::Tree &T = *F.tree;
   if (T.n == 0 || k == 0) return;
   const int nd = T.maxdepth + 1;
-  DBuf<double> work((size_t)T.work_elems);
+  DBuf<double> work((size_t)T.work_elems), zbuf((size_t)T.work_elems);
+  double *fronts = F.fronts.get();
+  double *invs = F.invs.get();
   for (int col = 0; col < k; ++col) {
     double *c = d_c + (size_t)col * stride;
+    // up the tree: L y = c (or U^T y = c)
     for (int d = nd - 1; d >= 0; --d) {
       const unsigned nf = (unsigned)T.by_depth[(size_t)d].size();
-      const int *list = F.level_lists[(size_t)d].get();
-      hipLaunchKernelGGL(solve_init_kernel, dim3(nf), dim3(256), 0, s, list, F.view, c, work.get());
+      hipLaunchKernelGGL(solve_init_kernel, dim3(nf), dim3(256), 0, s, F.level_lists[(size_t)d].get(), F.view, c,
+                         work.get());
       if (d + 1 < nd)
         for (int sl = 0; sl < 2; ++sl)
           if (F.child_counts[sl][(size_t)d] > 0)
             hipLaunchKernelGGL(solve_gather_kernel, dim3((unsigned)F.child_counts[sl][(size_t)d]), dim3(256), 0, s,
                                F.child_lists[sl][(size_t)d].get(), F.view, work.get());
-      if (sys == 0)
-        hipLaunchKernelGGL(solve_forward_kernel<false>, dim3(nf), dim3(256), 0, s, list, F.view, F.fronts.get(),
-                           F.invs.get(), work.get());
-      else
-        hipLaunchKernelGGL(solve_forward_kernel<true>, dim3(nf), dim3(256), 0, s, list, F.view, F.fronts.get(),
-                           F.invs.get(), work.get());
+      if (F.solve_counts[(size_t)d] > 0) {
+        const unsigned ns = (unsigned)F.solve_counts[(size_t)d];
+        const int *list = F.solve_lists[(size_t)d].get();
+        if (sys == 0)
+          hipLaunchKernelGGL(solve_forward_kernel<false>, dim3(ns), dim3(256), 0, s, list, F.view, fronts, invs,
+                             work.get());
+        else
+          hipLaunchKernelGGL(solve_forward_kernel<true>, dim3(ns), dim3(256), 0, s, list, F.view, fronts, invs,
+                             work.get());
+      }
+      for (int f : T.by_depth[(size_t)d]) {
+        if (T.fs(f) <= kBigSolve || T.np[(size_t)f] == 0) continue;
+        const Band b = dense_view(fronts + T.foff[(size_t)f], T.fs(f), T.ld[(size_t)f]);
+        double *W = work.get() + T.woff[(size_t)f], *Z = zbuf.get() + T.woff[(size_t)f];
+        if (sys == 0) solve_pass<0, 1>(b, invs + T.ioff[(size_t)f], b.n, W, Z, 0, s, T.np[(size_t)f]);
+        else solve_pass<2, 1>(b, invs + T.ioff[(size_t)f], b.n, W, Z, 0, s, T.np[(size_t)f]);
+      }
     }
+    // down the tree: U x = y (or L^T x = y); the pivots' part of x overwrites c
     for (int d = 0; d < nd; ++d) {
-      const unsigned nf = (unsigned)T.by_depth[(size_t)d].size();
-      const int *list = F.level_lists[(size_t)d].get();
-      if (sys == 0)
-        hipLaunchKernelGGL(solve_backward_kernel<false>, dim3(nf), dim3(256), 0, s, list, F.view, F.fronts.get(),
-                           F.invs.get(), work.get(), c);
-      else
-        hipLaunchKernelGGL(solve_backward_kernel<true>, dim3(nf), dim3(256), 0, s, list, F.view, F.fronts.get(),
-                           F.invs.get(), work.get(), c);
+      if (F.solve_counts[(size_t)d] > 0) {
+        const unsigned ns = (unsigned)F.solve_counts[(size_t)d];
+        const int *list = F.solve_lists[(size_t)d].get();
+        if (sys == 0)
+          hipLaunchKernelGGL(solve_backward_kernel<false>, dim3(ns), dim3(256), 0, s, list, F.view, fronts, invs,
+                             work.get(), c);
+        else
+          hipLaunchKernelGGL(solve_backward_kernel<true>, dim3(ns), dim3(256), 0, s, list, F.view, fronts, invs,
+                             work.get(), c);
+      }
+      for (int f : T.by_depth[(size_t)d]) {
+        const int np = T.np[(size_t)f], nb = T.nb[(size_t)f];
+        if (T.fs(f) <= kBigSolve || np == 0) continue;
+        double *Ff = fronts + T.foff[(size_t)f];
+        const int ld = T.ld[(size_t)f];
+        double *W = work.get() + T.woff[(size_t)f], *Z = zbuf.get() + T.woff[(size_t)f];
+        if (nb > 0) {
+          hipLaunchKernelGGL(front_gather_x_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s,
+                             F.D.bidx.get() + T.bptr[(size_t)f], nb, c, W + np);
+          if (sys == 0)
+            hipLaunchKernelGGL(front_gemv_kernel<false>, dim3((unsigned)((np + 63) / 64)), dim3(256), 0, s, Ff, ld, np,
+                               nb, W + np, Z);
+          else
+            hipLaunchKernelGGL(front_gemv_kernel<true>, dim3((unsigned)((np + 63) / 64)), dim3(256), 0, s, Ff, ld, np,
+                               nb, W + np, Z);
+        }
+        const Band b = dense_view(Ff, np, ld);  // the pivot block alone
+        if (sys == 0) solve_pass<1, 1>(b, invs + T.ioff[(size_t)f], np, Z, W, 0, s);
+        else solve_pass<3, 1>(b, invs + T.ioff[(size_t)f], np, Z, W, 0, s);
+        hipLaunchKernelGGL(front_scatter_x_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s,
+                           T.p0[(size_t)f], np, W, c);
+      }
     }
   }
-  SPL_HIP(hipStreamSynchronize(s));  // work is freed on return
+  SPL_HIP(hipStreamSynchronize(s));  // the work vectors are freed on return
 }
 
 }  // namespace spl
