@@ -16,6 +16,8 @@
 // workgroup per front and a per-front work vector; children hand their boundary part to the parent
 // in the same fixed order.  No interchanges: used under the same rule as the band path (diagonal
 // dominance, or a speculation that every solve checks — umfpack.hip).
+#include <stdio.h>
+#include <chrono>
 #include <memory>
 #include <vector>
 
@@ -79,15 +81,15 @@ __global__ __launch_bounds__(256) void rel_kernel(int nfronts, TreeView t, int *
   for (int k = threadIdx.x; k < t.nb[c]; k += blockDim.x) rel[t.roff[c] + k] = local_pos(t, p, b[k]);
 }
 
-// parent += Schur complement of the listed children (16 x 16 tiles; blockIdx.y = child)
+// parent += Schur complement of the listed children; blockIdx.y = child, a workgroup moves a tile of
+// 64 rows x 4 columns (lanes run down the rows: contiguous in the child, nearly so in the parent)
 __global__ __launch_bounds__(256) void extend_add_kernel(const int *__restrict__ children, TreeView t,
                                                          double *__restrict__ fronts) {
   const int c = children[blockIdx.y];
   const int nb = t.nb[c];
-  const int ntile = (nb + 15) >> 4;
-  if ((int)blockIdx.x >= ntile * ntile) return;
-  const int tr = blockIdx.x % ntile, tc = blockIdx.x / ntile;
-  const int r = tr * 16 + (threadIdx.x & 15), cc = tc * 16 + (threadIdx.x >> 4);
+  const int ntr = (nb + 63) >> 6, ntc = (nb + 3) >> 2;
+  if ((int64_t)blockIdx.x >= (int64_t)ntr * ntc) return;
+  const int r = (int)(blockIdx.x % ntr) * 64 + (threadIdx.x & 63), cc = (int)(blockIdx.x / ntr) * 4 + (threadIdx.x >> 6);
   if (r >= nb || cc >= nb) return;
   const int p = t.parent[c], npc = t.np[c];
   const int *rel = t.rel + t.roff[c];
@@ -118,9 +120,11 @@ __device__ __forceinline__ double sys_elem(const double *F, int ld, int i, int j
   return TRANS ? F[(size_t)j + (size_t)i * ld] : F[(size_t)i + (size_t)j * ld];
 }
 
-// v = T w for the 64 x 64 inverse diagonal block (column-major), T = inv or inv^T; 256 threads, 4 per row
+// v = T w for the 64 x 64 inverse diagonal block (column-major), T = inv or inv^T; the first 256
+// threads of the workgroup, 4 per row
 template <bool TRANS>
 __device__ __forceinline__ void apply_inverse_block(const double *__restrict__ inv, const double *w, double *v) {
+  if (threadIdx.x >= 256) return;
   const int l = threadIdx.x >> 2, q = threadIdx.x & 3;
   double acc = 0.0;
 #pragma unroll 4
@@ -198,8 +202,10 @@ __global__ __launch_bounds__(256) void solve_gather_kernel(const int *__restrict
 
 // forward elimination inside a front: y = M11^-1 W[0:np) block by block (stored inverses of the diagonal
 // blocks), every later entry of W loses its coupling with the block just solved
+constexpr int kSolveThreads = 1024;  // one workgroup per front, 16 wavefronts for the coupling loops
+
 template <bool TRANS>
-__global__ __launch_bounds__(256) void solve_forward_kernel(const int *__restrict__ list, TreeView t,
+__global__ __launch_bounds__(kSolveThreads) void solve_forward_kernel(const int *__restrict__ list, TreeView t,
                                                             const double *__restrict__ fronts,
                                                             const double *__restrict__ invs,
                                                             double *__restrict__ work) {
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(256) void solve_forward_kernel(const int *__restric
 // back substitution inside a front: x_piv = M11^-1 (y - M12 x_bnd), x_bnd read from the solution of
 // the ancestors; writes the pivots' part of the solution
 template <bool TRANS>
-__global__ __launch_bounds__(256) void solve_backward_kernel(const int *__restrict__ list, TreeView t,
+__global__ __launch_bounds__(kSolveThreads) void solve_backward_kernel(const int *__restrict__ list, TreeView t,
                                                              const double *__restrict__ fronts,
                                                              const double *__restrict__ invs,
                                                              double *__restrict__ work, double *__restrict__ x) {
@@ -299,15 +305,20 @@ __global__ __launch_bounds__(256) void front_gemv_kernel(const double *__restric
     __syncthreads();
     if (wave == 0 && i < np) z[i] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
   } else {
-    for (int r = wave; r < 64; r += 4) {
-      const int i = i0 + r;
-      if (i >= np) break;
-      const double *col = F + (size_t)np + (size_t)i * ld;  // M(i, np + k) = F(np + k, i)
-      double acc = 0.0;
-      for (int k = lane; k < nb; k += 64) acc += col[k] * xb[k];
+    for (int r = wave * 4; r < 64; r += 16) {  // 4 rows of the chunk per wavefront and trip
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int k = lane; k < nb; k += 64) {
+        const double xk = xb[k];
 #pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-      if (lane == 0) z[i] -= acc;
+        for (int u = 0; u < 4; ++u)  // M(i, np + k) = F(np + k, i)
+          if (i0 + r + u < np) acc[u] += F[(size_t)(np + k) + (size_t)(i0 + r + u) * ld] * xk;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc[u] += __shfl_xor(acc[u], m, 64);
+        if (lane == 0 && i0 + r + u < np) z[i0 + r + u] -= acc[u];
+      }
     }
   }
 }
@@ -354,6 +365,16 @@ int mf_singular(const mf::Factors *F) { return F->singular; }
 mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, const int *d_Ai, const double *d_Ax,
                        const int *d_inv, hipStream_t s) {
   const mf::Tree &T = *tree;
+  const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // phase times on stderr (diagnostic)
+  auto clock_now = [] { return std::chrono::steady_clock::now(); };
+  auto t_start = clock_now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    (void)hipDeviceSynchronize();
+    const auto now = clock_now();
+    fprintf(stderr, "[mf_factor] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_start).count());
+    t_start = now;
+  };
   std::unique_ptr<mf::Factors> Fp(new mf::Factors());
   mf::Factors &F = *Fp;
   F.tree = tree;
@@ -413,6 +434,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   }
   SPL_HIP(hipStreamSynchronize(s));
   staged.clear();
+  lap("tree upload");
   F.fronts.alloc((size_t)T.front_elems);
   F.invs.alloc((size_t)T.inv_elems);
   SPL_HIP(hipMemsetAsync(F.fronts.get(), 0, (size_t)T.front_elems * sizeof(double), s));
@@ -421,6 +443,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   if (T.n > 0)
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(((size_t)T.n * 8 + 255) / 256)), dim3(256), 0, s, T.n, d_Ap,
                        d_Ai, d_Ax, d_inv, F.view, F.fronts.get());
+  lap("alloc + zero + assemble");
   DBuf<int> singular(1);
   SPL_HIP(hipMemsetAsync(singular.get(), 0, sizeof(int), s));
   set_factor_attributes();
@@ -438,10 +461,10 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
     if (d + 1 < nd) {
       int max_nb = 0;
       for (int c : T.by_depth[(size_t)d + 1]) max_nb = std::max(max_nb, T.nb[(size_t)c]);
-      const int ntile = (max_nb + 15) / 16;
+      const int64_t ntile = (int64_t)((max_nb + 63) / 64) * ((max_nb + 3) / 4);
       for (int sl = 0; sl < 2; ++sl)
         if (F.child_counts[sl][(size_t)d] > 0 && ntile > 0)
-          hipLaunchKernelGGL(extend_add_kernel, dim3((unsigned)(ntile * ntile), (unsigned)F.child_counts[sl][(size_t)d]),
+          hipLaunchKernelGGL(extend_add_kernel, dim3((unsigned)ntile, (unsigned)F.child_counts[sl][(size_t)d]),
                              dim3(256), 0, s, F.child_lists[sl][(size_t)d].get(), F.view, F.fronts.get());
     }
     // small fronts: one launch, one workgroup each; large fronts: the multi-launch blocked
@@ -459,6 +482,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
     if (turn > 0)
       for (int i = 0; i < kStreams && i < turn; ++i) SPL_HIP(hipStreamSynchronize(side[i]));
   }
+  lap("levels");
   for (int i = 0; i < kStreams; ++i) (void)hipStreamDestroy(side[i]);
   SPL_HIP(hipMemcpyAsync(&F.singular, singular.get(), sizeof(int), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
@@ -491,10 +515,10 @@ void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride,
         const unsigned ns = (unsigned)F.solve_counts[(size_t)d];
         const int *list = F.solve_lists[(size_t)d].get();
         if (sys == 0)
-          hipLaunchKernelGGL(solve_forward_kernel<false>, dim3(ns), dim3(256), 0, s, list, F.view, fronts, invs,
+          hipLaunchKernelGGL(solve_forward_kernel<false>, dim3(ns), dim3(kSolveThreads), 0, s, list, F.view, fronts, invs,
                              work.get());
         else
-          hipLaunchKernelGGL(solve_forward_kernel<true>, dim3(ns), dim3(256), 0, s, list, F.view, fronts, invs,
+          hipLaunchKernelGGL(solve_forward_kernel<true>, dim3(ns), dim3(kSolveThreads), 0, s, list, F.view, fronts, invs,
                              work.get());
       }
       for (int f : T.by_depth[(size_t)d]) {
@@ -511,10 +535,10 @@ void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride,
         const unsigned ns = (unsigned)F.solve_counts[(size_t)d];
         const int *list = F.solve_lists[(size_t)d].get();
         if (sys == 0)
-          hipLaunchKernelGGL(solve_backward_kernel<false>, dim3(ns), dim3(256), 0, s, list, F.view, fronts, invs,
+          hipLaunchKernelGGL(solve_backward_kernel<false>, dim3(ns), dim3(kSolveThreads), 0, s, list, F.view, fronts, invs,
                              work.get(), c);
         else
-          hipLaunchKernelGGL(solve_backward_kernel<true>, dim3(ns), dim3(256), 0, s, list, F.view, fronts, invs,
+          hipLaunchKernelGGL(solve_backward_kernel<true>, dim3(ns), dim3(kSolveThreads), 0, s, list, F.view, fronts, invs,
                              work.get(), c);
       }
       for (int f : T.by_depth[(size_t)d]) {
