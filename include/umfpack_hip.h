@@ -20,17 +20,20 @@
  * idempotent and may run on any thread; status: 0 OK, 1 singular-matrix warning, < 0 error;
  * only sys = 0 (A x = b) and sys = 1 (A^T x = b; UMFPACK_At) are ever passed (Umfpack.hs:95-97).
  *
- * Algorithm (round 1): a reverse-Cuthill-McKee profile ordering on the host (symbolic), then LU
- * of the permuted matrix in band storage entirely on the GPU (numeric): blocked, on the fp64
- * matrix cores, WITHOUT row interchanges when the matrix is diagonally dominant by columns
- * (provably safe) and, as a speculation, for every other matrix too; LAPACK-style partial
- * pivoting otherwise (a zero pivot, SPL_LU_FORCE_PIVOT=1, or a failed speculation).  Solve:
- * blocked banded substitution and SpMV-based iterative refinement with UMFPACK's stopping
- * rules on the GPU.  A speculation is checked by every solve: unless the refined solution is
- * backward stable to rounding level (componentwise backward error <= 1e-13), the object is
- * refactored with partial pivoting and the system solved again, so the caller sees pivoted-LU
- * accuracy either way.  Square matrices only (the reference's linearSolve_ assumes square,
- * Umfpack.hs:93).
+ * Algorithm (round 1).  symbolic (host): a reverse-Cuthill-McKee band ordering and, for anything
+ * larger than a narrow band, a nested-dissection ordering with its frontal tree; the cheaper of
+ * the two by flop count is kept (2-D / 3-D meshes: nested dissection).  numeric (GPU): LU of the
+ * permuted matrix WITHOUT row interchanges, blocked on the fp64 matrix cores — in band storage,
+ * or multifrontal on the tree (dense frontal matrices, Schur complements passed to the parent) —
+ * when the matrix is diagonally dominant by columns (provably safe) and, as a speculation, for
+ * every other matrix too; LAPACK-style band LU with partial pivoting otherwise (a zero pivot,
+ * SPL_LU_FORCE_PIVOT=1, or a failed speculation).  solve (GPU): blocked substitution through the
+ * band or up and down the tree, and SpMV-based iterative refinement with UMFPACK's stopping rules.
+ * A speculation is checked by every solve: unless the refined solution is backward stable to
+ * rounding level (componentwise backward error <= 1e-13), the object is refactored with partial
+ * pivoting and the system solved again, so the caller sees pivoted-LU accuracy either way.
+ * SPL_LU_METHOD=band|mf forces the ordering.  Square matrices only (the reference's linearSolve_
+ * assumes square, Umfpack.hs:93).
  * The complex (`zi`) entry points (Internal.hs:69-115) are served through the real 2n x 2n
  * embedding with interleaved unknowns (csrc/umfpack_zi.hip): packed complex arrays (imaginary
  * pointer NULL, the only form the reference uses, Internal.hs:124-132) ARE the real arrays of the
@@ -100,8 +103,9 @@ int spl_umfpack_zi_solve_many(int sys, const int Ap[], const int Ai[], const dou
 /* dimension of the system a Numeric object factors (0 if invalid); helper of the zi wrappers */
 int spl_umfpack_dimension(void *Numeric);
 
-/* factorisation a Numeric object holds now: 0 partial pivoting, 1 no interchanges (diagonally
- * dominant matrix), 2 no interchanges as a speculation; -1 if invalid */
+/* factorisation a Numeric object holds now: 0 band, partial pivoting; 1 band, no interchanges
+ * (diagonally dominant matrix); 2 the same as a speculation; 3 multifrontal, no interchanges
+ * (dominant); 4 the same as a speculation; -1 if invalid */
 int spl_umfpack_path(void *Numeric);
 
 #ifdef __cplusplus

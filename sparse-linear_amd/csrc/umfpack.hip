@@ -5,19 +5,23 @@
 // All arithmetic of that step lives in third-party UMFPACK in the reference (un-vendored);
 // parity is defined on the SOLUTION (ident <\> v == v exactly, residual checks otherwise).
 //
-//   symbolic (host): reverse Cuthill-McKee ordering of the pattern of A + A^T, bandwidths
-//                    kl, ku of the permuted matrix  (UMFPACK also orders on the CPU);
-//   numeric  (GPU):  B = P A P^T scattered into LAPACK band storage AB[2kl+ku+1][n] in HBM,
-//                    LU with partial pivoting inside the band (row interchanges, fill limited
-//                    to kl extra super-diagonals) — numerically the same as dense partial
-//                    pivoting; a zero pivot sets the singular-matrix warning;
-//   solve    (GPU):  permute, banded forward/back substitution (or U^T, L^T for sys = 1),
-//                    un-permute, then up to 2 steps of iterative refinement with the residual
-//                    computed by the SpMV kernels (UMFPACK's default irstep = 2) and UMFPACK's
-//                    stopping rules on the componentwise backward error.
-// The pivoting band LU here updates one column at a time (rank-1 updates, HBM-bound); matrices
-// that are diagonally dominant by columns take the blocked MFMA factorisation of band_nopiv.hip.
-// A fill-reducing multifrontal ordering is the next step.
+//   symbolic (host): reverse Cuthill-McKee ordering of the pattern of A + A^T (bandwidths kl, ku)
+//                    and, unless the band is narrow, a nested-dissection ordering with its frontal
+//                    tree (mf_symbolic.hpp); the cheaper one by flop count is used (UMFPACK also
+//                    orders on the CPU);
+//   numeric  (GPU):  LU of B = P A P^T without row interchanges — blocked in band storage
+//                    (band_nopiv.hip) or multifrontal on the tree (multifrontal.hip), both on the
+//                    fp64 matrix cores — when A is diagonally dominant by columns, and as a checked
+//                    speculation otherwise; fallback: LAPACK band storage AB[2kl+ku+1][n] with
+//                    partial pivoting inside the band (this file), numerically the same as dense
+//                    partial pivoting; a zero pivot sets the singular-matrix warning;
+//   solve    (GPU):  permute, forward/back substitution (or U^T, L^T for sys = 1) through the band
+//                    or the tree, un-permute, then up to 2 steps of iterative refinement with the
+//                    residual computed by the SpMV kernels (UMFPACK's default irstep = 2) and
+//                    UMFPACK's stopping rules on the componentwise backward error; all right-hand
+//                    sides of a batched call share the passes.
+// The pivoting band LU here updates one column at a time (rank-1 updates, HBM-bound): it is the
+// safety net, not the fast path.
 #include <stdio.h>
 #include <algorithm>
 #include <atomic>

@@ -99,8 +99,9 @@ class Factors(_Handle):
 
     @property
     def path(self):
-        """factorisation held now: 0 partial pivoting, 1 no interchanges (diagonally dominant),
-        2 no interchanges as a speculation that every solve checks (include/umfpack_hip.h)"""
+        """factorisation held now: 0 band with partial pivoting, 1 band without interchanges
+        (diagonally dominant), 2 the same as a speculation that every solve checks, 3 / 4
+        multifrontal without interchanges (dominant / speculation) (include/umfpack_hip.h)"""
         return int(_declare().spl_umfpack_path(self.value))
 
 

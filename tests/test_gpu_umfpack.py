@@ -240,3 +240,74 @@ def test_batched_linear_solve_matches_one_at_a_time(gpu, pkg, O, k, force_pivot,
     xs = U.linearSolve(A, bs)  # the reference's API: factor once, every right-hand side
     for b, x in zip(bs, xs):
         assert O.count_not_close(x, U.linearSolve_(fact, U.UmfpackNormal, A, b), 1e-12) == 0
+
+
+# ---- multifrontal path (SPL_LU_METHOD=mf forces it on small matrices; large meshes take it by themselves)
+def _grid_matrix(pkg, O, kind, m):
+    if kind == "2d":
+        rp, ci, v = O.gen_poisson2d_csr(m)
+        n = m * m
+    else:
+        rp, ci, v = O.gen_poisson3d_csr(m)
+        n = m ** 3
+    return n, pkg.Matrix(n, n, rp, ci, v)
+
+
+@pytest.mark.parametrize("kind,m", [("2d", 7), ("2d", 45), ("2d", 130), ("3d", 9), ("3d", 22)])
+def test_multifrontal_matches_band_and_oracle(gpu, pkg, O, kind, m, monkeypatch):
+    """nested-dissection multifrontal factors == band factors == the CPU oracle, both systems,
+    several right-hand sides at once; sizes from a single front to thousands"""
+    n, A = _grid_matrix(pkg, O, kind, m)
+    U = pkg.umfpack
+    rng = np.random.default_rng(m)
+    bs = [rng.uniform(0.5, 1.5, n) for _ in range(3)]
+    monkeypatch.setenv("SPL_LU_METHOD", "band")
+    fb = U.factor(A, U.analyze(A))
+    assert fb.path == 1
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    fm = U.factor(A, U.analyze(A))
+    assert fm.path == 3
+    for mode in (U.UmfpackNormal, U.UmfpackTrans):
+        xb = U.linearSolveMany_(fb, mode, A, bs)
+        xm = U.linearSolveMany_(fm, mode, A, bs)
+        for p, q in zip(xb, xm):
+            assert O.count_not_close(p, q, 1e-10) == 0
+    if n <= 3000:
+        xo, _ = O.linear_solve(mat_to_tuple(A), bs[0])
+        assert O.count_not_close(U.linearSolve_(fm, U.UmfpackNormal, A, bs[0]), xo, 1e-10) == 0
+
+
+def test_multifrontal_unsymmetric_values_and_fallback(gpu, pkg, O, monkeypatch):
+    """unsymmetric values on a mesh pattern (the tree is built on A + A^T); then a matrix whose
+    no-interchange factors are useless: the speculation is replaced by band partial pivoting"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    U = pkg.umfpack
+    rng = np.random.default_rng(41)
+    m = 40
+    n = m * m
+    rp, ci, v = O.gen_poisson2d_csr(m)
+    v = v * rng.uniform(0.5, 1.0, len(v))
+    diag = ci == np.repeat(np.arange(n), np.diff(rp))
+    v[diag] = 4.5  # column sums of |off-diagonal| <= 4: dominant, unsymmetric
+    A = pkg.Matrix(n, n, rp, ci, v)
+    S = sp.csc_matrix((v, ci, rp), shape=(n, n))
+    xs = rng.uniform(0.5, 1.5, n)
+    fact = U.factor(A, U.analyze(A))
+    assert fact.path == 3
+    for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, S.T.tocsc())):
+        x = U.linearSolve_(fact, mode, A, op @ xs)
+        assert O.count_not_close(x, xs, 1e-10) == 0
+    # 2x2 blocks [[1e-14, 3], [3, 1e-14]] + weak coupling: needs interchanges
+    off = np.zeros(n - 1)
+    off[0::2] = 3.0
+    B = sp.diags([off, np.full(n, 1e-14), off, rng.uniform(-0.1, 0.1, n - m)], (-1, 0, 1, m), format="csc")
+    B.sort_indices()
+    M = pkg.Matrix(n, n, B.indptr, B.indices, B.data)
+    fact = U.factor(M, U.analyze(M))
+    assert fact.path == 4
+    x = U.linearSolve_(fact, U.UmfpackNormal, M, B @ xs)
+    assert fact.path == 0
+    assert np.max(np.abs(x - xs)) / np.max(np.abs(xs)) < 1e-8
+    assert np.max(np.abs(x - spla.spsolve(B, B @ xs))) / np.max(np.abs(xs)) < 1e-8

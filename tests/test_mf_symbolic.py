@@ -1,0 +1,62 @@
+"""Host side of the multifrontal LU (csrc/mf_symbolic.hpp): the nested-dissection ordering and the
+frontal tree are plain C++, so their invariants are checked on the CPU with a small native driver
+(tests/native/mf_check.cpp): permutation, post-order, boundary lists ascending / owned by ancestors /
+passed on to the parent, every entry of A + A^T inside the front of its earlier-eliminated index."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("mf") / "mf_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "sparse-linear_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "native", "mf_check.cpp"), "-o", exe], check=True)
+    return exe
+
+
+def run(checker, S, leaf):
+    S = sp.csc_matrix(S)
+    S.sort_indices()
+    text = "%d %d\n%s\n%s\n" % (S.shape[0], S.nnz, " ".join(map(str, S.indptr)), " ".join(map(str, S.indices)))
+    r = subprocess.run([checker, str(leaf)], input=text, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return dict(kv.split("=") for kv in r.stdout.split())
+
+
+def poisson(m, dim):
+    T = sp.diags([-np.ones(m - 1), 2 * np.ones(m), -np.ones(m - 1)], (-1, 0, 1))
+    I = sp.identity(m)
+    if dim == 2:
+        return sp.kron(I, T) + sp.kron(T, I)
+    return sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(T, I), I)
+
+
+@pytest.mark.parametrize("m,dim,leaf", [(30, 2, 64), (60, 2, 256), (12, 3, 64), (24, 3, 256)])
+def test_tree_invariants_on_grids(checker, m, dim, leaf):
+    out = run(checker, poisson(m, dim), leaf)
+    assert int(out["bad"]) == 0 and int(out["fronts"]) > 1
+    # nested dissection beats the band: the largest front is far smaller than n
+    assert int(out["maxfront"]) < int(out["n"]) // 2
+
+
+def test_tree_invariants_on_irregular_patterns(checker):
+    rng = np.random.default_rng(4)
+    n = 3000
+    # unsymmetric random pattern (the tree is built on A + A^T), with isolated vertices and two components
+    rows, cols = rng.integers(0, n // 2, 6000), rng.integers(0, n // 2, 6000)
+    rows2, cols2 = rng.integers(n // 2, n - 50, 4000), rng.integers(n // 2, n - 50, 4000)
+    S = sp.coo_matrix((np.ones(10000), (np.concatenate([rows, rows2]), np.concatenate([cols, cols2]))), shape=(n, n))
+    out = run(checker, S + sp.identity(n), 64)
+    assert int(out["bad"]) == 0
+    # a dense matrix cannot be dissected: one front
+    out = run(checker, np.ones((40, 40)), 8)
+    assert int(out["bad"]) == 0 and int(out["fronts"]) == 1
+    # 1 x 1 and diagonal matrices
+    assert int(run(checker, sp.identity(1), 64)["bad"]) == 0
+    assert int(run(checker, sp.identity(500), 64)["bad"]) == 0
