@@ -113,179 +113,229 @@ __global__ __launch_bounds__(256) void front_factor_kernel(const int *__restrict
 constexpr int kSmallFront = 1024;  // fronts up to this size are factored by one workgroup each
 constexpr int kStreams = 8;        // larger fronts of a level are spread over this many streams
 
-// ---- solves: one workgroup per front -------------------------------------------------------------
+// ---- solves ---------------------------------------------------------------------------------------
+// NR right-hand sides travel through the tree together: every front has a work matrix W (fs x NR,
+// column-major), column r of the right-hand sides / solution is c + r * stride.
+constexpr int kSolveThreads = 1024;  // one workgroup per front, 16 wavefronts for the coupling loops
+constexpr int kBigSolve = 3072;      // fronts above this size are solved by many workgroups
+
 // M(i, j) of the triangular system a front contributes: F(i, j), or F(j, i) for the transposed systems
 template <bool TRANS>
 __device__ __forceinline__ double sys_elem(const double *F, int ld, int i, int j) {
   return TRANS ? F[(size_t)j + (size_t)i * ld] : F[(size_t)i + (size_t)j * ld];
 }
 
-// v = T w for the 64 x 64 inverse diagonal block (column-major), T = inv or inv^T; the first 256
-// threads of the workgroup, 4 per row
-template <bool TRANS>
-__device__ __forceinline__ void apply_inverse_block(const double *__restrict__ inv, const double *w, double *v) {
+// v = T w for the 64 x 64 inverse diagonal block (column-major), T = inv or inv^T, NR columns; the
+// first 256 threads of the workgroup, 4 per row
+template <bool TRANS, int NR>
+__device__ __forceinline__ void apply_inverse_block(const double *__restrict__ inv, const double (*w)[NR],
+                                                    double (*v)[NR]) {
   if (threadIdx.x >= 256) return;
   const int l = threadIdx.x >> 2, q = threadIdx.x & 3;
-  double acc = 0.0;
+  double acc[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) acc[r] = 0.0;
 #pragma unroll 4
   for (int u = 0; u < NB / 4; ++u) {
     const int tt = q + 4 * u;
-    acc += (TRANS ? inv[tt + l * NB] : inv[l + tt * NB]) * w[tt];
+    const double e = TRANS ? inv[tt + l * NB] : inv[l + tt * NB];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] += e * w[tt][r];
   }
-  acc += __shfl_xor(acc, 1, 64);
-  acc += __shfl_xor(acc, 2, 64);
-  if (q == 0) v[l] = acc;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    acc[r] += __shfl_xor(acc[r], 1, 64);
+    acc[r] += __shfl_xor(acc[r], 2, 64);
+    if (q == 0) v[l][r] = acc[r];
+  }
 }
 
-// W[i] -= sum_{tt < jb} M(i, c0 + tt) v[tt] for i in [ilo, ihi), by the 256 threads of the workgroup.
-// Untransposed the front runs down i (thread = row, 8 loads in flight); transposed it runs along tt
-// (a wavefront per row, lanes along tt, butterfly sum).
-template <bool TRANS>
+// W[i][:] -= sum_{tt < jb} M(i, c0 + tt) v[tt][:] for i in [ilo, ihi), by all threads of the workgroup;
+// a matrix entry is loaded once for all NR columns.  Untransposed the front runs down i (thread =
+// row, 8 loads in flight); transposed it runs along tt (a wavefront per row, lanes along tt,
+// butterfly sums).  W is fs x NR column-major (leading dimension fs).
+template <bool TRANS, int NR>
 __device__ __forceinline__ void couple_block(const double *__restrict__ F, int ld, int ilo, int ihi, int c0, int jb,
-                                             const double *v, double *W) {
+                                             const double (*v)[NR], double *W, int fs) {
   if (!TRANS) {
     for (int i = ilo + threadIdx.x; i < ihi; i += blockDim.x) {
       const double *row = F + (size_t)i + (size_t)c0 * ld;
-      double a0 = 0.0, a1 = 0.0;
+      double acc[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[r] = 0.0;
       int tt = 0;
       for (; tt + 8 <= jb; tt += 8) {
         double e[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) e[u] = row[(size_t)(tt + u) * ld];
 #pragma unroll
-        for (int u = 0; u < 8; u += 2) {
-          a0 += e[u] * v[tt + u];
-          a1 += e[u + 1] * v[tt + u + 1];
-        }
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int r = 0; r < NR; ++r) acc[r] += e[u] * v[tt + u][r];
       }
-      for (; tt < jb; ++tt) a0 += row[(size_t)tt * ld] * v[tt];
-      W[i] -= a0 + a1;
+      for (; tt < jb; ++tt) {
+        const double e = row[(size_t)tt * ld];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r] += e * v[tt][r];
+      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) W[(size_t)r * fs + i] -= acc[r];
     }
   } else {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const double vl = lane < jb ? v[lane] : 0.0;
-    constexpr int RW = 8;  // rows per wavefront and trip: 8 loads in flight per lane
+    constexpr int RW = NR == 1 ? 8 : 2;  // rows per wavefront and trip
     for (int i0 = ilo + wave * RW; i0 < ihi; i0 += nw * RW) {
       double e[RW];
 #pragma unroll
       for (int u = 0; u < RW; ++u)
-        e[u] = (i0 + u < ihi && lane < jb) ? F[(size_t)(c0 + lane) + (size_t)(i0 + u) * ld] * vl : 0.0;
+        e[u] = (i0 + u < ihi && lane < jb) ? F[(size_t)(c0 + lane) + (size_t)(i0 + u) * ld] : 0.0;
 #pragma unroll
-      for (int u = 0; u < RW; ++u) {
+      for (int u = 0; u < RW; ++u)
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) e[u] += __shfl_xor(e[u], m, 64);
-        if (lane == 0 && i0 + u < ihi) W[i0 + u] -= e[u];
-      }
+        for (int r = 0; r < NR; ++r) {
+          double sacc = lane < jb ? e[u] * v[lane][r] : 0.0;
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
+          if (lane == 0 && i0 + u < ihi) W[(size_t)r * fs + i0 + u] -= sacc;
+        }
     }
   }
 }
 
 // W = [rhs at the pivots | 0]
+template <int NR>
 __global__ __launch_bounds__(256) void solve_init_kernel(const int *__restrict__ list, TreeView t,
-                                                         const double *__restrict__ c, double *__restrict__ work) {
+                                                         const double *__restrict__ c, size_t stride,
+                                                         double *__restrict__ work) {
   const int f = list[blockIdx.x];
   const int np = t.np[f], fs = np + t.nb[f];
-  double *W = work + t.woff[f];
-  for (int i = threadIdx.x; i < fs; i += blockDim.x) W[i] = i < np ? c[t.p0[f] + i] : 0.0;
+  double *W = work + (size_t)t.woff[f] * NR;
+  for (int o = threadIdx.x; o < fs * NR; o += blockDim.x) {
+    const int i = o % fs, r = o / fs;
+    W[o] = i < np ? c[(size_t)r * stride + t.p0[f] + i] : 0.0;
+  }
 }
 
 // W(parent)[rel] += boundary part of W(child), for the listed children
+template <int NR>
 __global__ __launch_bounds__(256) void solve_gather_kernel(const int *__restrict__ children, TreeView t,
                                                            double *__restrict__ work) {
   const int c = children[blockIdx.x];
-  const int p = t.parent[c], npc = t.np[c];
+  const int p = t.parent[c], npc = t.np[c], nbc = t.nb[c];
+  const int fsc = npc + nbc, fsp = t.np[p] + t.nb[p];
   const int *rel = t.rel + t.roff[c];
-  const double *Wc = work + t.woff[c];
-  double *Wp = work + t.woff[p];
-  for (int k = threadIdx.x; k < t.nb[c]; k += blockDim.x) Wp[rel[k]] += Wc[npc + k];
+  const double *Wc = work + (size_t)t.woff[c] * NR;
+  double *Wp = work + (size_t)t.woff[p] * NR;
+  for (int o = threadIdx.x; o < nbc * NR; o += blockDim.x) {
+    const int k = o % nbc, r = o / nbc;
+    Wp[(size_t)r * fsp + rel[k]] += Wc[(size_t)r * fsc + npc + k];
+  }
 }
 
 // forward elimination inside a front: y = M11^-1 W[0:np) block by block (stored inverses of the diagonal
 // blocks), every later entry of W loses its coupling with the block just solved
-constexpr int kSolveThreads = 1024;  // one workgroup per front, 16 wavefronts for the coupling loops
-
-template <bool TRANS>
+template <bool TRANS, int NR>
 __global__ __launch_bounds__(kSolveThreads) void solve_forward_kernel(const int *__restrict__ list, TreeView t,
-                                                            const double *__restrict__ fronts,
-                                                            const double *__restrict__ invs,
-                                                            double *__restrict__ work) {
-  __shared__ double w[NB], v[NB];
+                                                                      const double *__restrict__ fronts,
+                                                                      const double *__restrict__ invs,
+                                                                      double *__restrict__ work) {
+  __shared__ double w[NB][NR], v[NB][NR];
   const int f = list[blockIdx.x];
   const int np = t.np[f], fs = np + t.nb[f], ld = t.ld[f];
   const double *F = fronts + t.foff[f];
-  double *W = work + t.woff[f];
+  double *W = work + (size_t)t.woff[f] * NR;
   for (int j0 = 0; j0 < np; j0 += NB) {
     const int jb = min(NB, np - j0);
-    if (threadIdx.x < NB) w[threadIdx.x] = threadIdx.x < jb ? W[j0 + threadIdx.x] : 0.0;
+    for (int o = threadIdx.x; o < NB * NR; o += blockDim.x) {
+      const int l = o % NB, r = o / NB;
+      w[l][r] = l < jb ? W[(size_t)r * fs + j0 + l] : 0.0;
+    }
     __syncthreads();
     // forward: L (unit lower) or U^T -> inverse of L11, or of U11 transposed
     const double *inv = invs + t.ioff[f] + (size_t)(j0 / NB) * (2 * NB * NB) + (TRANS ? NB * NB : 0);
-    apply_inverse_block<TRANS>(inv, w, v);
+    apply_inverse_block<TRANS, NR>(inv, w, v);
     __syncthreads();
-    if (threadIdx.x < jb) W[j0 + threadIdx.x] = v[threadIdx.x];
-    couple_block<TRANS>(F, ld, j0 + jb, fs, j0, jb, v, W);
+    for (int o = threadIdx.x; o < jb * NR; o += blockDim.x) {
+      const int l = o % jb, r = o / jb;
+      W[(size_t)r * fs + j0 + l] = v[l][r];
+    }
+    couple_block<TRANS, NR>(F, ld, j0 + jb, fs, j0, jb, v, W, fs);
     __syncthreads();
   }
 }
 
 // back substitution inside a front: x_piv = M11^-1 (y - M12 x_bnd), x_bnd read from the solution of
 // the ancestors; writes the pivots' part of the solution
-template <bool TRANS>
+template <bool TRANS, int NR>
 __global__ __launch_bounds__(kSolveThreads) void solve_backward_kernel(const int *__restrict__ list, TreeView t,
-                                                             const double *__restrict__ fronts,
-                                                             const double *__restrict__ invs,
-                                                             double *__restrict__ work, double *__restrict__ x) {
-  __shared__ double w[NB], v[NB];
+                                                                       const double *__restrict__ fronts,
+                                                                       const double *__restrict__ invs,
+                                                                       double *__restrict__ work,
+                                                                       double *__restrict__ x, size_t stride) {
+  __shared__ double w[NB][NR], v[NB][NR];
   const int f = list[blockIdx.x];
-  const int np = t.np[f], nb = t.nb[f], ld = t.ld[f], p0 = t.p0[f];
+  const int np = t.np[f], nb = t.nb[f], ld = t.ld[f], p0 = t.p0[f], fs = np + nb;
   const double *F = fronts + t.foff[f];
-  double *W = work + t.woff[f];
+  double *W = work + (size_t)t.woff[f] * NR;
   const int *b = t.bidx + t.bptr[f];
-  for (int k = threadIdx.x; k < nb; k += blockDim.x) W[np + k] = x[b[k]];
-  __syncthreads();
   for (int k0 = 0; k0 < nb; k0 += NB) {  // boundary columns in strips of 64, through LDS
     const int kb = min(NB, nb - k0);
-    if (threadIdx.x < NB) v[threadIdx.x] = threadIdx.x < kb ? W[np + k0 + threadIdx.x] : 0.0;
+    for (int o = threadIdx.x; o < NB * NR; o += blockDim.x) {
+      const int l = o % NB, r = o / NB;
+      v[l][r] = l < kb ? x[(size_t)r * stride + b[k0 + l]] : 0.0;
+    }
     __syncthreads();
-    couple_block<TRANS>(F, ld, 0, np, np + k0, kb, v, W);
+    couple_block<TRANS, NR>(F, ld, 0, np, np + k0, kb, v, W, fs);
     __syncthreads();
   }
   const int nblk = (np + NB - 1) / NB;
   for (int blk = nblk - 1; blk >= 0; --blk) {
     const int j0 = blk * NB, jb = min(NB, np - j0);
-    if (threadIdx.x < NB) w[threadIdx.x] = threadIdx.x < jb ? W[j0 + threadIdx.x] : 0.0;
+    for (int o = threadIdx.x; o < NB * NR; o += blockDim.x) {
+      const int l = o % NB, r = o / NB;
+      w[l][r] = l < jb ? W[(size_t)r * fs + j0 + l] : 0.0;
+    }
     __syncthreads();
     // backward: U or L^T -> inverse of U11, or of L11 transposed
     const double *inv = invs + t.ioff[f] + (size_t)blk * (2 * NB * NB) + (TRANS ? 0 : NB * NB);
-    apply_inverse_block<TRANS>(inv, w, v);
+    apply_inverse_block<TRANS, NR>(inv, w, v);
     __syncthreads();
-    if (threadIdx.x < jb) {
-      W[j0 + threadIdx.x] = v[threadIdx.x];
-      x[p0 + j0 + threadIdx.x] = v[threadIdx.x];
+    for (int o = threadIdx.x; o < jb * NR; o += blockDim.x) {
+      const int l = o % jb, r = o / jb;
+      x[(size_t)r * stride + p0 + j0 + l] = v[l][r];
     }
-    couple_block<TRANS>(F, ld, 0, j0, j0, jb, v, W);
+    couple_block<TRANS, NR>(F, ld, 0, j0, j0, jb, v, W, fs);
     __syncthreads();
   }
 }
 
 // ---- large fronts: the same steps spread over many workgroups -----------------------------------
-// boundary part of the solution into the front's work vector: W[np + k] = x[bidx[k]]
+// boundary part of the solution into the front's work matrix: dst[r * fs + k] = x[r * stride + bidx[k]]
+template <int NR>
 __global__ __launch_bounds__(256) void front_gather_x_kernel(const int *__restrict__ b, int nb,
-                                                             const double *__restrict__ x, double *__restrict__ dst) {
+                                                             const double *__restrict__ x, size_t stride,
+                                                             double *__restrict__ dst, int fs) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < nb) dst[k] = x[b[k]];
+  if (k >= nb) return;
+  const int g = b[k];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) dst[(size_t)r * fs + k] = x[(size_t)r * stride + g];
 }
 
-// z[i] -= sum_k M(i, np + k) xb[k], i < np: 64 rows per workgroup
-template <bool TRANS>
+// z[i][:] -= sum_k M(i, np + k) xb[k][:], i < np: 64 rows per workgroup; z and xb are columns of
+// fs-strided work matrices
+template <bool TRANS, int NR>
 __global__ __launch_bounds__(256) void front_gemv_kernel(const double *__restrict__ F, int ld, int np, int nb,
-                                                         const double *__restrict__ xb, double *__restrict__ z) {
-  __shared__ double part[4][64];
+                                                         const double *__restrict__ xb, double *__restrict__ z,
+                                                         int fs) {
+  __shared__ double part[4][64][NR];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i0 = blockIdx.x * 64;
   if (!TRANS) {
     const int i = i0 + lane;
-    double a0 = 0.0, a1 = 0.0;
+    double acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = 0.0;
     if (i < np) {
       const double *row = F + (size_t)i + (size_t)np * ld;
       int k = wave;
@@ -294,42 +344,60 @@ __global__ __launch_bounds__(256) void front_gemv_kernel(const double *__restric
 #pragma unroll
         for (int u = 0; u < 8; ++u) e[u] = row[(size_t)(k + 4 * u) * ld];
 #pragma unroll
-        for (int u = 0; u < 8; u += 2) {
-          a0 += e[u] * xb[k + 4 * u];
-          a1 += e[u + 1] * xb[k + 4 * u + 4];
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int r = 0; r < NR; ++r) acc[r] += e[u] * xb[(size_t)r * fs + k + 4 * u];
+      }
+      for (; k < nb; k += 4) {
+        const double e = row[(size_t)k * ld];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r] += e * xb[(size_t)r * fs + k];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) part[wave][lane][r] = acc[r];
+    __syncthreads();
+    if (wave == 0 && i < np)
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        z[(size_t)r * fs + i] -= (part[0][lane][r] + part[1][lane][r]) + (part[2][lane][r] + part[3][lane][r]);
+  } else {
+    constexpr int RW = NR == 1 ? 4 : 1;  // rows of the chunk per wavefront and trip
+    for (int rr = wave * RW; rr < 64; rr += 4 * RW) {
+      double acc[RW][NR];
+#pragma unroll
+      for (int u = 0; u < RW; ++u)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[u][r] = 0.0;
+      for (int k = lane; k < nb; k += 64) {
+#pragma unroll
+        for (int u = 0; u < RW; ++u) {  // M(i, np + k) = F(np + k, i)
+          if (i0 + rr + u >= np) continue;
+          const double e = F[(size_t)(np + k) + (size_t)(i0 + rr + u) * ld];
+#pragma unroll
+          for (int r = 0; r < NR; ++r) acc[u][r] += e * xb[(size_t)r * fs + k];
         }
       }
-      for (; k < nb; k += 4) a0 += row[(size_t)k * ld] * xb[k];
-    }
-    part[wave][lane] = a0 + a1;
-    __syncthreads();
-    if (wave == 0 && i < np) z[i] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-  } else {
-    for (int r = wave * 4; r < 64; r += 16) {  // 4 rows of the chunk per wavefront and trip
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int k = lane; k < nb; k += 64) {
-        const double xk = xb[k];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)  // M(i, np + k) = F(np + k, i)
-          if (i0 + r + u < np) acc[u] += F[(size_t)(np + k) + (size_t)(i0 + r + u) * ld] * xk;
-      }
+      for (int u = 0; u < RW; ++u)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+        for (int r = 0; r < NR; ++r) {
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) acc[u] += __shfl_xor(acc[u], m, 64);
-        if (lane == 0 && i0 + r + u < np) z[i0 + r + u] -= acc[u];
-      }
+          for (int m = 32; m >= 1; m >>= 1) acc[u][r] += __shfl_xor(acc[u][r], m, 64);
+          if (lane == 0 && i0 + rr + u < np) z[(size_t)r * fs + i0 + rr + u] -= acc[u][r];
+        }
     }
   }
 }
 
-__global__ __launch_bounds__(256) void front_scatter_x_kernel(int p0, int np, const double *__restrict__ src,
-                                                              double *__restrict__ x) {
+template <int NR>
+__global__ __launch_bounds__(256) void front_scatter_x_kernel(int p0, int np, const double *__restrict__ src, int fs,
+                                                              double *__restrict__ x, size_t stride) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < np) x[p0 + i] = src[i];
+  if (i >= np) return;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) x[(size_t)r * stride + p0 + i] = src[(size_t)r * fs + i];
 }
-
-constexpr int kBigSolve = 3072;  // fronts above this size are solved by many workgroups
 
 }  // namespace
 
@@ -490,82 +558,78 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   return Fp.release();
 }
 
-// columns of c (device, new ordering, column r at d_c + r * stride) <- (P A P^T)^-1 c or its transpose
+// NR columns (c + r * stride) through the tree: up with L (or U^T), down with U (or L^T)
+template <bool TRANS, int NR>
+static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride, double *work, double *zbuf,
+                                  hipStream_t s) {
+  const mf::Tree &T = *F.tree;
+  const int nd = T.maxdepth + 1;
+  double *fronts = F.fronts.get();
+  double *invs = F.invs.get();
+  constexpr int FWD = TRANS ? 2 : 0, BWD = TRANS ? 3 : 1;
+  for (int d = nd - 1; d >= 0; --d) {
+    const unsigned nf = (unsigned)T.by_depth[(size_t)d].size();
+    hipLaunchKernelGGL(solve_init_kernel<NR>, dim3(nf), dim3(256), 0, s, F.level_lists[(size_t)d].get(), F.view, c,
+                       stride, work);
+    if (d + 1 < nd)
+      for (int sl = 0; sl < 2; ++sl)
+        if (F.child_counts[sl][(size_t)d] > 0)
+          hipLaunchKernelGGL(solve_gather_kernel<NR>, dim3((unsigned)F.child_counts[sl][(size_t)d]), dim3(256), 0, s,
+                             F.child_lists[sl][(size_t)d].get(), F.view, work);
+    if (F.solve_counts[(size_t)d] > 0)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_forward_kernel<TRANS, NR>), dim3((unsigned)F.solve_counts[(size_t)d]),
+                         dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, fronts, invs, work);
+    for (int f : T.by_depth[(size_t)d]) {
+      if (T.fs(f) <= kBigSolve || T.np[(size_t)f] == 0) continue;
+      const Band b = dense_view(fronts + T.foff[(size_t)f], T.fs(f), T.ld[(size_t)f]);
+      double *W = work + (size_t)T.woff[(size_t)f] * NR, *Z = zbuf + (size_t)T.woff[(size_t)f] * NR;
+      solve_pass<FWD, NR>(b, invs + T.ioff[(size_t)f], b.n, W, Z, (size_t)b.n, s, T.np[(size_t)f]);
+    }
+  }
+  for (int d = 0; d < nd; ++d) {
+    if (F.solve_counts[(size_t)d] > 0)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_backward_kernel<TRANS, NR>), dim3((unsigned)F.solve_counts[(size_t)d]),
+                         dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, fronts, invs, work, c,
+                         stride);
+    for (int f : T.by_depth[(size_t)d]) {
+      const int np = T.np[(size_t)f], nb = T.nb[(size_t)f], fs = np + nb;
+      if (fs <= kBigSolve || np == 0) continue;
+      double *Ff = fronts + T.foff[(size_t)f];
+      const int ld = T.ld[(size_t)f];
+      double *W = work + (size_t)T.woff[(size_t)f] * NR, *Z = zbuf + (size_t)T.woff[(size_t)f] * NR;
+      if (nb > 0) {
+        hipLaunchKernelGGL(front_gather_x_kernel<NR>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s,
+                           F.D.bidx.get() + T.bptr[(size_t)f], nb, c, stride, W + np, fs);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(front_gemv_kernel<TRANS, NR>), dim3((unsigned)((np + 63) / 64)), dim3(256),
+                           0, s, Ff, ld, np, nb, W + np, Z, fs);
+      }
+      const Band b = dense_view(Ff, np, ld);  // the pivot block alone; columns of Z / W are fs apart
+      solve_pass<BWD, NR>(b, invs + T.ioff[(size_t)f], np, Z, W, (size_t)fs, s);
+      hipLaunchKernelGGL(front_scatter_x_kernel<NR>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s,
+                         T.p0[(size_t)f], np, W, fs, c, stride);
+    }
+  }
+}
+
+// columns of c (device, new ordering, column r at d_c + r * stride) <- (P A P^T)^-1 c or its transpose;
+// k > 1: the caller allocates a multiple of kSolveGroup columns (zero-padded), taken 8 at a time
 void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride, hipStream_t s) {
   const mf::Factors &F = *Fp;
   const mf::Tree &T = *F.tree;
   if (T.n == 0 || k == 0) return;
-  const int nd = T.maxdepth + 1;
-  DBuf<double> work((size_t)T.work_elems), zbuf((size_t)T.work_elems);
-  double *fronts = F.fronts.get();
-  double *invs = F.invs.get();
-  for (int col = 0; col < k; ++col) {
-    double *c = d_c + (size_t)col * stride;
-    // up the tree: L y = c (or U^T y = c)
-    for (int d = nd - 1; d >= 0; --d) {
-      const unsigned nf = (unsigned)T.by_depth[(size_t)d].size();
-      hipLaunchKernelGGL(solve_init_kernel, dim3(nf), dim3(256), 0, s, F.level_lists[(size_t)d].get(), F.view, c,
-                         work.get());
-      if (d + 1 < nd)
-        for (int sl = 0; sl < 2; ++sl)
-          if (F.child_counts[sl][(size_t)d] > 0)
-            hipLaunchKernelGGL(solve_gather_kernel, dim3((unsigned)F.child_counts[sl][(size_t)d]), dim3(256), 0, s,
-                               F.child_lists[sl][(size_t)d].get(), F.view, work.get());
-      if (F.solve_counts[(size_t)d] > 0) {
-        const unsigned ns = (unsigned)F.solve_counts[(size_t)d];
-        const int *list = F.solve_lists[(size_t)d].get();
-        if (sys == 0)
-          hipLaunchKernelGGL(solve_forward_kernel<false>, dim3(ns), dim3(kSolveThreads), 0, s, list, F.view, fronts, invs,
-                             work.get());
-        else
-          hipLaunchKernelGGL(solve_forward_kernel<true>, dim3(ns), dim3(kSolveThreads), 0, s, list, F.view, fronts, invs,
-                             work.get());
-      }
-      for (int f : T.by_depth[(size_t)d]) {
-        if (T.fs(f) <= kBigSolve || T.np[(size_t)f] == 0) continue;
-        const Band b = dense_view(fronts + T.foff[(size_t)f], T.fs(f), T.ld[(size_t)f]);
-        double *W = work.get() + T.woff[(size_t)f], *Z = zbuf.get() + T.woff[(size_t)f];
-        if (sys == 0) solve_pass<0, 1>(b, invs + T.ioff[(size_t)f], b.n, W, Z, 0, s, T.np[(size_t)f]);
-        else solve_pass<2, 1>(b, invs + T.ioff[(size_t)f], b.n, W, Z, 0, s, T.np[(size_t)f]);
-      }
-    }
-    // down the tree: U x = y (or L^T x = y); the pivots' part of x overwrites c
-    for (int d = 0; d < nd; ++d) {
-      if (F.solve_counts[(size_t)d] > 0) {
-        const unsigned ns = (unsigned)F.solve_counts[(size_t)d];
-        const int *list = F.solve_lists[(size_t)d].get();
-        if (sys == 0)
-          hipLaunchKernelGGL(solve_backward_kernel<false>, dim3(ns), dim3(kSolveThreads), 0, s, list, F.view, fronts, invs,
-                             work.get(), c);
-        else
-          hipLaunchKernelGGL(solve_backward_kernel<true>, dim3(ns), dim3(kSolveThreads), 0, s, list, F.view, fronts, invs,
-                             work.get(), c);
-      }
-      for (int f : T.by_depth[(size_t)d]) {
-        const int np = T.np[(size_t)f], nb = T.nb[(size_t)f];
-        if (T.fs(f) <= kBigSolve || np == 0) continue;
-        double *Ff = fronts + T.foff[(size_t)f];
-        const int ld = T.ld[(size_t)f];
-        double *W = work.get() + T.woff[(size_t)f], *Z = zbuf.get() + T.woff[(size_t)f];
-        if (nb > 0) {
-          hipLaunchKernelGGL(front_gather_x_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s,
-                             F.D.bidx.get() + T.bptr[(size_t)f], nb, c, W + np);
-          if (sys == 0)
-            hipLaunchKernelGGL(front_gemv_kernel<false>, dim3((unsigned)((np + 63) / 64)), dim3(256), 0, s, Ff, ld, np,
-                               nb, W + np, Z);
-          else
-            hipLaunchKernelGGL(front_gemv_kernel<true>, dim3((unsigned)((np + 63) / 64)), dim3(256), 0, s, Ff, ld, np,
-                               nb, W + np, Z);
-        }
-        const Band b = dense_view(Ff, np, ld);  // the pivot block alone
-        if (sys == 0) solve_pass<1, 1>(b, invs + T.ioff[(size_t)f], np, Z, W, 0, s);
-        else solve_pass<3, 1>(b, invs + T.ioff[(size_t)f], np, Z, W, 0, s);
-        hipLaunchKernelGGL(front_scatter_x_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s,
-                           T.p0[(size_t)f], np, W, c);
-      }
+  const int nr = k == 1 ? 1 : kSolveGroup;
+  DBuf<double> work((size_t)T.work_elems * nr), zbuf((size_t)T.work_elems * nr);
+  if (k == 1) {
+    if (sys == 0) solve_columns_on_tree<false, 1>(F, d_c, stride, work.get(), zbuf.get(), s);
+    else solve_columns_on_tree<true, 1>(F, d_c, stride, work.get(), zbuf.get(), s);
+  } else {
+    for (int c0 = 0; c0 < k; c0 += kSolveGroup) {
+      double *c = d_c + (size_t)c0 * stride;
+      if (sys == 0) solve_columns_on_tree<false, kSolveGroup>(F, c, stride, work.get(), zbuf.get(), s);
+      else solve_columns_on_tree<true, kSolveGroup>(F, c, stride, work.get(), zbuf.get(), s);
     }
   }
-  SPL_HIP(hipStreamSynchronize(s));  // the work vectors are freed on return
+  SPL_HIP(hipStreamSynchronize(s));  // the work matrices are freed on return
 }
 
 }  // namespace spl
