@@ -11,11 +11,14 @@
 // Ordering: "automatic nested dissection" (George & Liu): a breadth-first level structure from a
 // pseudo-peripheral vertex of the current region, a middle level as vertex separator (smallest
 // level among the balanced ones, thinned by one pass), recursion on the two sides; regions of at most
-// `leaf` vertices become leaves.  Fronts are numbered in post-order, unknowns by front.
+// `leaf` vertices become leaves.  Fronts are numbered in post-order, unknowns by front.  The two
+// sides of a large region are dissected by separate threads (they share nothing but the graph).
 #pragma once
 
 #include <stdint.h>
 #include <algorithm>
+#include <atomic>
+#include <future>
 #include <vector>
 
 namespace spl {
@@ -43,51 +46,57 @@ struct Tree {
 namespace detail {
 
 struct Node {
-  int left = -1, right = -1;
-  int64_t pbeg = 0, pend = 0;  // pivots in `pool`
+  int left = -1, right = -1;  // indices in the same vector (post-order: children before the parent)
+  std::vector<int> piv;       // pivots (separator, or all vertices of a leaf), original numbering
 };
 
-struct Dissector {
+// State shared by all workers: the graph, the vertex array (workers own disjoint ranges of it) and
+// three per-vertex marks (a worker only touches the vertices of its own region).  Stamps come from
+// one atomic counter so that they are unique across workers.
+struct Shared {
   int n;
   const std::vector<int64_t> &xadj;
   const std::vector<int> &adj;
   int leaf;
-  std::vector<int> verts, pool, in_region, seen, level, queue;
-  std::vector<int64_t> level_ptr;
-  std::vector<Node> nodes;
-  int region_stamp = 0, bfs_stamp = 0;
-
-  Dissector(int n_, const std::vector<int64_t> &xa, const std::vector<int> &ad, int leaf_)
+  std::vector<int> verts, in_region, seen, level;
+  std::atomic<int> stamp{0};
+  Shared(int n_, const std::vector<int64_t> &xa, const std::vector<int> &ad, int leaf_)
       : n(n_), xadj(xa), adj(ad), leaf(leaf_), verts((size_t)n_), in_region((size_t)n_, 0), seen((size_t)n_, 0),
         level((size_t)n_, 0) {
     for (int i = 0; i < n; ++i) verts[(size_t)i] = i;
-    pool.reserve((size_t)n);
-    queue.reserve((size_t)n);
   }
+};
+
+struct Worker {
+  Shared &S;
+  std::vector<int> queue;
+  std::vector<int64_t> level_ptr;
+  int region_stamp = 0, bfs_stamp = 0;
+  explicit Worker(Shared &s) : S(s) {}
 
   // BFS inside the current region; fills queue (BFS order), level[], level_ptr; returns #reached
   int bfs(int root) {
-    ++bfs_stamp;
+    bfs_stamp = ++S.stamp;
     queue.clear();
     level_ptr.clear();
     queue.push_back(root);
-    seen[(size_t)root] = bfs_stamp;
-    level[(size_t)root] = 0;
+    S.seen[(size_t)root] = bfs_stamp;
+    S.level[(size_t)root] = 0;
     level_ptr.push_back(0);
     size_t head = 0;
     int cur = 0;
     while (head < queue.size()) {
       const int v = queue[head];
-      if (level[(size_t)v] != cur) {
-        cur = level[(size_t)v];
+      if (S.level[(size_t)v] != cur) {
+        cur = S.level[(size_t)v];
         level_ptr.push_back((int64_t)head);
       }
       ++head;
-      for (int64_t p = xadj[(size_t)v]; p < xadj[(size_t)v + 1]; ++p) {
-        const int u = adj[(size_t)p];
-        if (in_region[(size_t)u] == region_stamp && seen[(size_t)u] != bfs_stamp) {
-          seen[(size_t)u] = bfs_stamp;
-          level[(size_t)u] = cur + 1;
+      for (int64_t p = S.xadj[(size_t)v]; p < S.xadj[(size_t)v + 1]; ++p) {
+        const int u = S.adj[(size_t)p];
+        if (S.in_region[(size_t)u] == region_stamp && S.seen[(size_t)u] != bfs_stamp) {
+          S.seen[(size_t)u] = bfs_stamp;
+          S.level[(size_t)u] = cur + 1;
           queue.push_back(u);
         }
       }
@@ -96,21 +105,57 @@ struct Dissector {
     return (int)queue.size();
   }
 
-  int make_leaf(int lo, int hi) {
-    Node nd;
-    nd.pbeg = (int64_t)pool.size();
-    for (int i = lo; i < hi; ++i) pool.push_back(verts[(size_t)i]);
-    nd.pend = (int64_t)pool.size();
-    nodes.push_back(nd);
-    return (int)nodes.size() - 1;
+  static void append(std::vector<Node> &dst, std::vector<Node> &&src) {
+    const int off = (int)dst.size();
+    for (Node &nd : src) {
+      if (nd.left >= 0) nd.left += off;
+      if (nd.right >= 0) nd.right += off;
+      dst.push_back(std::move(nd));
+    }
   }
 
-  int dissect(int lo, int hi) {
+  // subtrees of the two vertex ranges, then `top` as their parent; large ranges get their own thread
+  std::vector<Node> join(int lo, int mid, int hi, Node &&top, int depth) {
+    std::vector<Node> left, right;
+    const bool fork = depth < 6 && mid - lo >= 50000 && hi - mid >= 50000;
+    if (fork) {
+      std::future<std::vector<Node>> other = std::async(std::launch::async, [this, lo, mid, depth] {
+        Worker w(S);
+        return w.dissect(lo, mid, depth + 1);
+      });
+      right = dissect(mid, hi, depth + 1);
+      left = other.get();
+    } else {
+      if (mid > lo) left = dissect(lo, mid, depth + 1);
+      if (hi > mid) right = dissect(mid, hi, depth + 1);
+    }
+    std::vector<Node> out;
+    out.reserve(left.size() + right.size() + 1);
+    const bool has_l = !left.empty(), has_r = !right.empty();
+    append(out, std::move(left));
+    const int l = has_l ? (int)out.size() - 1 : -1;
+    append(out, std::move(right));
+    const int r = has_r ? (int)out.size() - 1 : -1;
+    top.left = l;
+    top.right = r;
+    out.push_back(std::move(top));
+    return out;
+  }
+
+  std::vector<Node> make_leaf(int lo, int hi) {
+    Node nd;
+    nd.piv.assign(S.verts.begin() + lo, S.verts.begin() + hi);
+    std::vector<Node> out;
+    out.push_back(std::move(nd));
+    return out;
+  }
+
+  std::vector<Node> dissect(int lo, int hi, int depth) {
     const int size = hi - lo;
-    if (size <= leaf) return make_leaf(lo, hi);
-    ++region_stamp;
-    for (int i = lo; i < hi; ++i) in_region[(size_t)verts[(size_t)i]] = region_stamp;
-    int reached = bfs(verts[(size_t)lo]);
+    if (size <= S.leaf) return make_leaf(lo, hi);
+    region_stamp = ++S.stamp;
+    for (int i = lo; i < hi; ++i) S.in_region[(size_t)S.verts[(size_t)i]] = region_stamp;
+    int reached = bfs(S.verts[(size_t)lo]);
     if (reached == size) reached = bfs(queue.back());  // from the far end: deeper, narrower levels
     if (reached < size) {
       // disconnected region: no separator needed.  All components are found and dealt into two
@@ -121,15 +166,14 @@ struct Dissector {
       comp_verts.reserve((size_t)size);
       comp_verts.insert(comp_verts.end(), queue.begin(), queue.end());
       comp_ptr.push_back((int64_t)comp_verts.size());
-      // mark by moving found vertices out of the region
-      for (int v : queue) in_region[(size_t)v] = 0;
+      for (int v : queue) S.in_region[(size_t)v] = 0;  // found vertices leave the region
       for (int i = lo; i < hi; ++i) {
-        const int v = verts[(size_t)i];
-        if (in_region[(size_t)v] != region_stamp) continue;
+        const int v = S.verts[(size_t)i];
+        if (S.in_region[(size_t)v] != region_stamp) continue;
         bfs(v);
         comp_verts.insert(comp_verts.end(), queue.begin(), queue.end());
         comp_ptr.push_back((int64_t)comp_verts.size());
-        for (int u : queue) in_region[(size_t)u] = 0;
+        for (int u : queue) S.in_region[(size_t)u] = 0;
       }
       const int ncomp = (int)comp_ptr.size() - 1;
       std::vector<int> order((size_t)ncomp);
@@ -146,20 +190,13 @@ struct Dissector {
         (wa <= wb ? wa : wb) += sz;
         g.insert(g.end(), comp_verts.begin() + comp_ptr[(size_t)c], comp_verts.begin() + comp_ptr[(size_t)c + 1]);
       }
-      std::copy(ga.begin(), ga.end(), verts.begin() + lo);
-      std::copy(gb.begin(), gb.end(), verts.begin() + lo + (int)ga.size());
+      std::copy(ga.begin(), ga.end(), S.verts.begin() + lo);
+      std::copy(gb.begin(), gb.end(), S.verts.begin() + lo + (int)ga.size());
       const int na = (int)ga.size();
       std::vector<int>().swap(ga);
       std::vector<int>().swap(gb);
       std::vector<int>().swap(comp_verts);
-      Node nd;
-      nd.pbeg = nd.pend = (int64_t)pool.size();
-      const int l = dissect(lo, lo + na);
-      const int r = dissect(lo + na, hi);
-      nd.left = l;
-      nd.right = r;
-      nodes.push_back(nd);
-      return (int)nodes.size() - 1;
+      return join(lo, lo + na, hi, Node(), depth);
     }
     const int nlev = (int)level_ptr.size() - 1;
     if (nlev < 3) return make_leaf(lo, hi);  // no interior level: nothing to separate
@@ -179,32 +216,23 @@ struct Dissector {
     // queue = [levels < t | level t | levels > t]; thin the separator: a vertex of level t without a
     // neighbour in level t+1 can join the first side
     std::vector<int> side1(queue.begin(), queue.begin() + level_ptr[(size_t)t]);
-    std::vector<int> sep, side2(queue.begin() + level_ptr[(size_t)t + 1], queue.end());
+    std::vector<int> side2(queue.begin() + level_ptr[(size_t)t + 1], queue.end());
+    Node top;
     for (int64_t q = level_ptr[(size_t)t]; q < level_ptr[(size_t)t + 1]; ++q) {
       const int v = queue[(size_t)q];
       bool touches = false;
-      for (int64_t p = xadj[(size_t)v]; p < xadj[(size_t)v + 1] && !touches; ++p) {
-        const int u = adj[(size_t)p];
-        touches = in_region[(size_t)u] == region_stamp && level[(size_t)u] == t + 1;
+      for (int64_t p = S.xadj[(size_t)v]; p < S.xadj[(size_t)v + 1] && !touches; ++p) {
+        const int u = S.adj[(size_t)p];
+        touches = S.in_region[(size_t)u] == region_stamp && S.level[(size_t)u] == t + 1;
       }
-      if (touches) sep.push_back(v); else side1.push_back(v);
+      if (touches) top.piv.push_back(v); else side1.push_back(v);
     }
-    std::copy(side1.begin(), side1.end(), verts.begin() + lo);
-    std::copy(side2.begin(), side2.end(), verts.begin() + lo + (int)side1.size());
-    Node nd;
-    nd.pbeg = (int64_t)pool.size();
-    pool.insert(pool.end(), sep.begin(), sep.end());
-    nd.pend = (int64_t)pool.size();
+    std::copy(side1.begin(), side1.end(), S.verts.begin() + lo);
+    std::copy(side2.begin(), side2.end(), S.verts.begin() + lo + (int)side1.size());
     const int n1 = (int)side1.size(), n2 = (int)side2.size();
     std::vector<int>().swap(side1);
     std::vector<int>().swap(side2);
-    std::vector<int>().swap(sep);
-    const int l = n1 > 0 ? dissect(lo, lo + n1) : -1;
-    const int r = n2 > 0 ? dissect(lo + n1, lo + n1 + n2) : -1;
-    nd.left = l;
-    nd.right = r;
-    nodes.push_back(nd);
-    return (int)nodes.size() - 1;
+    return join(lo, lo + n1, lo + n1 + n2, std::move(top), depth);
   }
 };
 
@@ -232,11 +260,14 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T) {
         if (i != j) { adj[(size_t)cur[(size_t)i]++] = j; adj[(size_t)cur[(size_t)j]++] = i; }
       }
   }
-  detail::Dissector D(n, xadj, adj, leaf);
-  const int root = n > 0 ? D.dissect(0, n) : -1;
-  // nodes were pushed children-first, so node order is already a post-order
-  const int nf = (int)D.nodes.size();
-  (void)root;
+  detail::Shared shared(n, xadj, adj, leaf);
+  std::vector<detail::Node> nodes;
+  if (n > 0) {
+    detail::Worker w(shared);
+    nodes = w.dissect(0, n, 0);
+  }
+  // the node vector is a post-order: children before their parent
+  const int nf = (int)nodes.size();
   T.nfronts = nf;
   T.parent.assign((size_t)nf, -1);
   T.slot.assign((size_t)nf, 0);
@@ -249,13 +280,12 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T) {
   T.front_of.assign((size_t)n, 0);
   int next = 0;
   for (int f = 0; f < nf; ++f) {
-    const detail::Node &nd = D.nodes[(size_t)f];
+    const detail::Node &nd = nodes[(size_t)f];
     if (nd.left >= 0) { T.parent[(size_t)nd.left] = f; T.slot[(size_t)nd.left] = 0; }
     if (nd.right >= 0) { T.parent[(size_t)nd.right] = f; T.slot[(size_t)nd.right] = nd.left >= 0 ? 1 : 0; }
     T.p0[(size_t)f] = next;
-    T.np[(size_t)f] = (int)(nd.pend - nd.pbeg);
-    for (int64_t q = nd.pbeg; q < nd.pend; ++q) {
-      const int v = D.pool[(size_t)q];
+    T.np[(size_t)f] = (int)nd.piv.size();
+    for (int v : nd.piv) {
       T.perm[(size_t)next] = v;
       T.inv[(size_t)v] = next;
       T.front_of[(size_t)next] = f;
@@ -272,7 +302,7 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T) {
   T.bptr.assign((size_t)nf + 1, 0);
   std::vector<int> b;
   for (int f = 0; f < nf; ++f) {
-    const detail::Node &nd = D.nodes[(size_t)f];
+    const detail::Node &nd = nodes[(size_t)f];
     const int last = T.p0[(size_t)f] + T.np[(size_t)f];
     b.clear();
     for (int g = T.p0[(size_t)f]; g < last; ++g) {
