@@ -505,13 +505,15 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   lap("tree upload");
   F.fronts.alloc((size_t)T.front_elems);
   F.invs.alloc((size_t)T.inv_elems);
+  lap("hipMalloc fronts");
   SPL_HIP(hipMemsetAsync(F.fronts.get(), 0, (size_t)T.front_elems * sizeof(double), s));
+  lap("zero fronts");
   if (T.nfronts > 0)
     hipLaunchKernelGGL(rel_kernel, dim3((unsigned)T.nfronts), dim3(256), 0, s, T.nfronts, F.view, D.rel.get());
   if (T.n > 0)
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(((size_t)T.n * 8 + 255) / 256)), dim3(256), 0, s, T.n, d_Ap,
                        d_Ai, d_Ax, d_inv, F.view, F.fronts.get());
-  lap("alloc + zero + assemble");
+  lap("rel + assemble");
   DBuf<int> singular(1);
   SPL_HIP(hipMemsetAsync(singular.get(), 0, sizeof(int), s));
   set_factor_attributes();

@@ -311,3 +311,36 @@ def test_multifrontal_unsymmetric_values_and_fallback(gpu, pkg, O, monkeypatch):
     assert fact.path == 0
     assert np.max(np.abs(x - xs)) / np.max(np.abs(xs)) < 1e-8
     assert np.max(np.abs(x - spla.spsolve(B, B @ xs))) / np.max(np.abs(xs)) < 1e-8
+
+
+def test_multifrontal_random_patterns_against_oracle(gpu, pkg, O, monkeypatch):
+    """random unsymmetric sparse matrices made diagonally dominant (isolated vertices, several
+    components, dense rows): the multifrontal path against the CPU oracle's LU, both systems"""
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    U = pkg.umfpack
+    rng = np.random.default_rng(77)
+    for n, k in ((1, 0), (2, 1), (60, 150), (333, 900), (700, 5000), (1500, 4000)):
+        rows = rng.integers(0, n, k)
+        cols = rng.integers(0, n, k)
+        if n >= 300:  # a dense-ish row and column
+            rows = np.concatenate([rows, np.full(n // 3, 7), rng.integers(0, n, n // 3)])
+            cols = np.concatenate([cols, rng.integers(0, n, n // 3), np.full(n // 3, 11)])
+        vals = rng.normal(size=len(rows))
+        off = rows != cols
+        A0 = O.compress(n, n, rows[off], cols[off], vals[off])
+        colsum = np.zeros(n)
+        np.add.at(colsum, np.repeat(np.arange(n), np.diff(A0[2])), np.abs(A0[4]))
+        A = O.compress(n, n, np.concatenate([A0[3], np.arange(n)]),
+                       np.concatenate([np.repeat(np.arange(n), np.diff(A0[2])), np.arange(n)]),
+                       np.concatenate([A0[4], colsum + 1.0]))
+        M = tuple_to_mat(pkg, A)
+        fact = U.factor(M, U.analyze(M))
+        assert fact.path == 3
+        xs = rng.uniform(0.5, 1.5, n)
+        S = csc_tuple_to_scipy(A)
+        for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, S.T.tocsc())):
+            b = np.asarray(op @ xs).ravel()
+            x = U.linearSolve_(fact, mode, M, b)
+            assert O.count_not_close(x, xs, 1e-10) == 0, (n, mode)
+        xo, _ = O.linear_solve(A, np.asarray(S @ xs).ravel())
+        assert O.count_not_close(U.linearSolve_(fact, U.UmfpackNormal, M, np.asarray(S @ xs).ravel()), xo, 1e-10) == 0
