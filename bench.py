@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--n", "--rows", dest="n", type=int, default=10_000_000)  # --rows: unambiguous under torchrun
     ap.add_argument("--draws", type=int, default=20)
     ap.add_argument("--matrix", default="random", choices=["random", "banded"])
     ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (ablation)")
@@ -67,9 +67,18 @@ def main():
             sys.exit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # SPL_BENCH_REHEARSAL=1 (tests only): every rank on cuda:0 and the gloo backend, so that the whole
+    # N > 1 flow (row blocks, all-gather of y, max over ranks) can be rehearsed on a one-GPU box.  The
+    # numbers of such a run mean nothing; the driver's runs use one GPU per rank over RCCL.
+    rehearsal = os.environ.get("SPL_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = load_package()
     ffi = pkg._ffi

@@ -1,0 +1,51 @@
+"""The N > 1 flow of bench.py (the driver's multi-GPU scaling run) rehearsed on ONE GPU: two ranks
+share cuda:0 and exchange y over gloo (SPL_BENCH_REHEARSAL=1).  Checks that the launch contract
+holds end to end — row blocks, all-gather, max over ranks, one JSON line from rank 0 — and that the
+gathered y equals the single-rank y."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(nproc, extra):
+    env = dict(os.environ, SPL_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")]
+    cmd += ["--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("matrix", ["random", "banded"])
+def test_two_ranks_on_one_gpu(gpu, matrix):
+    args = ["--rows", "400000", "--matrix", matrix]
+    one = _run(1, args)
+    two = _run(2, args)
+    for out, n in ((one, 1), (two, 2)):
+        assert out["n_gpus"] == n and out["steps"] == 3 and out["warmup"] == 1
+        assert out["metric"] == "fp64 CSR SpMV effective GB/s" and out["unit"] == "GB/s"
+        assert out["scaling"] == "strong" and out["dtype"] == "f64" and out["vs_baseline"] is None
+        assert out["value"] > 0 and out["roofline"]["frac"] > 0
+    # the same matrix: identical nnz, hence identical algorithmic bytes, whatever the rank count
+    assert one["config"]["algorithmic_bytes"] == two["config"]["algorithmic_bytes"]
