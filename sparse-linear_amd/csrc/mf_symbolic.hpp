@@ -36,8 +36,19 @@ struct Tree {
   std::vector<int> bidx;                 // boundary indices of every front (new numbering, ascending)
   std::vector<int> front_of;             // front that eliminates a new index
   std::vector<int> ld;                   // leading dimension of the dense front (>= np + nb)
-  std::vector<int64_t> foff, ioff, woff, roff;  // offsets: front matrix, inverse blocks, work vector, rel map
-  int64_t front_elems = 0, inv_elems = 0, work_elems = 0, rel_elems = 0;
+  // Storage.  While a level is being factored its fronts are whole dense matrices in a transient
+  // region (levels alternate between two regions: a level and its children are alive together);
+  // afterwards only the factor panels are kept, compactly: P = columns [0, np) of the front
+  // (fs x np, leading dimension ldp: L11\U11 and L21), U = rows [0, np) of the remaining columns
+  // (np x nb, leading dimension ldu: U12).
+  std::vector<int64_t> foff;             // offset of the whole front inside its level's region
+  std::vector<int64_t> poff, uoff;       // offsets of the panels in the factor arena
+  std::vector<int> ldp, ldu;
+  std::vector<int64_t> ioff, woff, roff;  // offsets: inverse blocks, work vector, rel map
+  std::vector<int64_t> level_elems;      // whole fronts of each tree level
+  int64_t region_elems[2] = {0, 0};      // the two transient regions (even / odd levels)
+  int64_t front_elems = 0;               // sum of all whole fronts (what resident fronts would take)
+  int64_t panel_elems = 0, inv_elems = 0, work_elems = 0, rel_elems = 0;
   double flops = 0.0;
   std::vector<std::vector<int>> by_depth;  // fronts of each tree level
   int fs(int f) const { return np[(size_t)f] + nb[(size_t)f]; }
@@ -326,17 +337,32 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T) {
   // storage layout and work estimate
   T.ld.assign((size_t)nf, 0);
   T.foff.assign((size_t)nf, 0);
+  T.poff.assign((size_t)nf, 0);
+  T.uoff.assign((size_t)nf, 0);
+  T.ldp.assign((size_t)nf, 0);
+  T.ldu.assign((size_t)nf, 0);
   T.ioff.assign((size_t)nf, 0);
   T.woff.assign((size_t)nf, 0);
   T.roff.assign((size_t)nf, 0);
+  T.level_elems.assign((size_t)T.maxdepth + 1, 0);
+  auto pad_ld = [](int64_t v) {  // off the multiples of 32 doubles (column stride not a power of two)
+    v = std::max<int64_t>(v, 1);
+    return v % 32 == 0 ? v + 2 : v;
+  };
   for (int f = 0; f < nf; ++f) {
     const int64_t fs = T.fs(f), p = T.np[(size_t)f], q = T.nb[(size_t)f];
-    // leading dimension off the multiples of 32 doubles (column stride not a power of two)
-    int64_t ld = std::max<int64_t>(fs, 1);
-    if (ld % 32 == 0) ld += 2;
+    const int64_t ld = pad_ld(fs);
     T.ld[(size_t)f] = (int)ld;
-    T.foff[(size_t)f] = T.front_elems;
+    int64_t &lev = T.level_elems[(size_t)T.depth[(size_t)f]];
+    T.foff[(size_t)f] = lev;
+    lev += (ld * std::max<int64_t>(fs, 1) + 15) / 16 * 16;
     T.front_elems += (ld * std::max<int64_t>(fs, 1) + 15) / 16 * 16;
+    T.ldp[(size_t)f] = (int)pad_ld(fs);
+    T.ldu[(size_t)f] = (int)pad_ld(p);
+    T.poff[(size_t)f] = T.panel_elems;
+    T.panel_elems += ((int64_t)T.ldp[(size_t)f] * p + 15) / 16 * 16;
+    T.uoff[(size_t)f] = T.panel_elems;
+    T.panel_elems += ((int64_t)T.ldu[(size_t)f] * q + 15) / 16 * 16;
     T.ioff[(size_t)f] = T.inv_elems;
     T.inv_elems += ((p + kBlock - 1) / kBlock) * 2 * kBlock * kBlock;
     T.woff[(size_t)f] = T.work_elems;
@@ -345,6 +371,8 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T) {
     T.rel_elems += q;
     T.flops += 2.0 / 3.0 * (double)p * p * p + 2.0 * (double)p * p * q + 2.0 * (double)p * q * q;
   }
+  for (int d = 0; d <= T.maxdepth; ++d)
+    T.region_elems[d & 1] = std::max(T.region_elems[d & 1], T.level_elems[(size_t)d]);
 }
 
 }  // namespace mf

@@ -3,19 +3,24 @@
 // band profile is too expensive (2-D / 3-D meshes): the work drops from O(n * band^2) to the
 // O(n^2) (3-D) / O(n^1.5) (2-D) of nested dissection, the storage from n * band to the fronts.
 //
-// Every tree node owns a dense column-major frontal matrix F = [pivots | boundary]^2 in one big HBM
-// allocation.  Numeric factorisation, level by level from the leaves:
-//   assemble   : the entries of P A P^T go to the front of their earlier-eliminated index (one kernel
-//                for all fronts); the Schur complements of the children are added into their parent
-//                ("extend-add", children in a fixed order, so the result is deterministic);
+// Every tree node has a dense column-major frontal matrix F = [pivots | boundary]^2.  Numeric
+// factorisation, level by level from the leaves; the whole fronts of a level live in one of two
+// transient HBM regions (a level and its children are alive together, levels alternate):
+//   assemble   : the entries of P A P^T go to the front of their earlier-eliminated index; the Schur
+//                complements of the children are added into their parent ("extend-add", children in
+//                a fixed order, so the result is deterministic);
+//   compact    : the children are done: their factor panels — P = the pivot columns (fs x np:
+//                L11\U11, L21) and U = the pivot rows of the other columns (np x nb: U12) — move to
+//                the factor arena, which is all that stays resident (a quarter of the whole fronts);
 //   factor     : the first np columns/rows of F are eliminated by the blocked fp64-MFMA kernels of
-//                dense_lu_kernels.hpp on a dense view (factor_loop with a pivot limit) — large fronts —
-//                or by one workgroup per front running the same device code — the many small ones;
-//                the trailing nb x nb block is then the front's Schur complement.
-// Fronts stay resident: a solve walks the tree up (L, or U^T) and down (U, or L^T) with one
-// workgroup per front and a per-front work vector; children hand their boundary part to the parent
-// in the same fixed order.  No interchanges: used under the same rule as the band path (diagonal
-// dominance, or a speculation that every solve checks — umfpack.hip).
+//                dense_lu_kernels.hpp on a dense view (factor_loop with a pivot limit) — large fronts,
+//                spread over side streams — or by one workgroup per front running the same device
+//                code — the many small ones; the trailing nb x nb block is then the front's Schur
+//                complement.
+// A solve walks the tree up (L, or U^T) and down (U, or L^T) on the panels with a per-front work
+// matrix (8 right-hand sides together); children hand their boundary part to the parent in the same
+// fixed order.  No interchanges: used under the same rule as the band path (diagonal dominance, or
+// a speculation that every solve checks — umfpack.hip).
 #include <stdio.h>
 #include <chrono>
 #include <memory>
@@ -29,13 +34,16 @@ namespace spl {
 namespace {
 
 struct DeviceTree {
-  DBuf<int> p0, np, nb, ld, parent, front_of, bidx, rel;
-  DBuf<int64_t> bptr, foff, ioff, woff, roff;
+  DBuf<int> p0, np, nb, ld, parent, front_of, bidx, rel, depth, ldp, ldu;
+  DBuf<int64_t> bptr, foff, ioff, woff, roff, poff, uoff;
 };
 
 struct TreeView {  // raw pointers for kernels
-  const int *p0, *np, *nb, *ld, *parent, *front_of, *bidx, *rel;
-  const int64_t *bptr, *foff, *ioff, *woff, *roff;
+  const int *p0, *np, *nb, *ld, *parent, *front_of, *bidx, *rel, *depth, *ldp, *ldu;
+  const int64_t *bptr, *foff, *ioff, *woff, *roff, *poff, *uoff;
+  double *region[2];  // whole fronts of the even / odd tree levels (transient)
+  double *arena;      // factor panels (resident)
+  __device__ __forceinline__ double *front(int f) const { return region[depth[f] & 1] + foff[f]; }
 };
 
 template <typename T>
@@ -57,18 +65,19 @@ __device__ __forceinline__ int local_pos(const TreeView &t, int f, int g) {
   return np + lo;
 }
 
-// entries of A (CSC arrays, original numbering) -> fronts; 8 lanes per column
+// entries of A (CSC arrays, original numbering) -> the fronts of tree level `level`; 8 lanes per column
 __global__ __launch_bounds__(256) void assemble_kernel(int n, const int *__restrict__ Ap, const int *__restrict__ Ai,
                                                        const double *__restrict__ Ax, const int *__restrict__ inv,
-                                                       TreeView t, double *__restrict__ fronts) {
+                                                       TreeView t, int level) {
   const int j = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 3), part = threadIdx.x & 7;
   if (j >= n) return;
   const int gj = inv[j];
   for (int p = Ap[j] + part; p < Ap[j + 1]; p += 8) {
     const int gi = inv[Ai[p]];
     const int f = t.front_of[min(gi, gj)];
+    if (t.depth[f] != level) continue;
     const int r = local_pos(t, f, gi), c = local_pos(t, f, gj);
-    fronts[t.foff[f] + (int64_t)r + (int64_t)c * t.ld[f]] = Ax[p];
+    t.front(f)[(int64_t)r + (int64_t)c * t.ld[f]] = Ax[p];
   }
 }
 
@@ -83,8 +92,7 @@ __global__ __launch_bounds__(256) void rel_kernel(int nfronts, TreeView t, int *
 
 // parent += Schur complement of the listed children; blockIdx.y = child, a workgroup moves a tile of
 // 64 rows x 4 columns (lanes run down the rows: contiguous in the child, nearly so in the parent)
-__global__ __launch_bounds__(256) void extend_add_kernel(const int *__restrict__ children, TreeView t,
-                                                         double *__restrict__ fronts) {
+__global__ __launch_bounds__(256) void extend_add_kernel(const int *__restrict__ children, TreeView t) {
   const int c = children[blockIdx.y];
   const int nb = t.nb[c];
   const int ntr = (nb + 63) >> 6, ntc = (nb + 3) >> 2;
@@ -93,20 +101,35 @@ __global__ __launch_bounds__(256) void extend_add_kernel(const int *__restrict__
   if (r >= nb || cc >= nb) return;
   const int p = t.parent[c], npc = t.np[c];
   const int *rel = t.rel + t.roff[c];
-  const double v = fronts[t.foff[c] + (int64_t)(npc + r) + (int64_t)(npc + cc) * t.ld[c]];
-  fronts[t.foff[p] + (int64_t)rel[r] + (int64_t)rel[cc] * t.ld[p]] += v;
+  const double v = t.front(c)[(int64_t)(npc + r) + (int64_t)(npc + cc) * t.ld[c]];
+  t.front(p)[(int64_t)rel[r] + (int64_t)rel[cc] * t.ld[p]] += v;
+}
+
+// factor panels of the listed (finished) fronts -> arena; blockIdx.y = front, 64 x 4 tiles over the
+// fs x fs front, of which only the pivot columns and pivot rows are copied
+__global__ __launch_bounds__(256) void compact_kernel(const int *__restrict__ list, TreeView t) {
+  const int f = list[blockIdx.y];
+  const int np = t.np[f], nb = t.nb[f], fs = np + nb;
+  const int ntr = (fs + 63) >> 6, ntc = (fs + 3) >> 2;
+  if ((int64_t)blockIdx.x >= (int64_t)ntr * ntc) return;
+  const int i = (int)(blockIdx.x % ntr) * 64 + (threadIdx.x & 63), j = (int)(blockIdx.x / ntr) * 4 + (threadIdx.x >> 6);
+  if (i >= fs || j >= fs) return;
+  if (j < np) {
+    t.arena[t.poff[f] + (int64_t)i + (int64_t)j * t.ldp[f]] = t.front(f)[(int64_t)i + (int64_t)j * t.ld[f]];
+  } else if (i < np) {
+    t.arena[t.uoff[f] + (int64_t)i + (int64_t)(j - np) * t.ldu[f]] = t.front(f)[(int64_t)i + (int64_t)j * t.ld[f]];
+  }
 }
 
 // small fronts of a tree level: one workgroup per front runs the whole partial factorisation
 __global__ __launch_bounds__(256) void front_factor_kernel(const int *__restrict__ list, TreeView t,
-                                                           double *__restrict__ fronts, double *__restrict__ invs,
-                                                           int *__restrict__ singular) {
+                                                           double *__restrict__ invs, int *__restrict__ singular) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   const int f = list[blockIdx.x];
   const int np = t.np[f];
   if (np == 0) return;
   const int fs = np + t.nb[f];
-  const Band b{fronts + t.foff[f], fs, fs, fs, t.ld[f] + 1, 0};
+  const Band b{t.front(f), fs, fs, fs, t.ld[f] + 1, 0};
   front_factor_by_workgroup(b, np, invs + t.ioff[f], singular, dsm);
 }
 
@@ -119,10 +142,21 @@ constexpr int kStreams = 8;        // larger fronts of a level are spread over t
 constexpr int kSolveThreads = 1024;  // one workgroup per front, 16 wavefronts for the coupling loops
 constexpr int kBigSolve = 3072;      // fronts above this size are solved by many workgroups
 
-// M(i, j) of the triangular system a front contributes: F(i, j), or F(j, i) for the transposed systems
-template <bool TRANS>
-__device__ __forceinline__ double sys_elem(const double *F, int ld, int i, int j) {
-  return TRANS ? F[(size_t)j + (size_t)i * ld] : F[(size_t)i + (size_t)j * ld];
+// The panels of a front as the solves see them.  M is the triangular system a front contributes:
+// M(i, j) = F(i, j), or F(j, i) for the transposed systems, where F(i, j) lives in P for j < np and in
+// U for j >= np (then i < np).
+struct Panels {
+  const double *P, *U;
+  int np, nb, fs, ldp, ldu;
+  // column j of F, rows from 0 (valid rows: fs for j < np, np otherwise)
+  __device__ __forceinline__ const double *col(int j) const {
+    return j < np ? P + (size_t)j * ldp : U + (size_t)(j - np) * ldu;
+  }
+  __device__ __forceinline__ int col_stride(int j) const { return j < np ? ldp : ldu; }
+};
+
+__device__ __forceinline__ Panels panels_of(const TreeView &t, int f) {
+  return Panels{t.arena + t.poff[f], t.arena + t.uoff[f], t.np[f], t.nb[f], t.np[f] + t.nb[f], t.ldp[f], t.ldu[f]};
 }
 
 // v = T w for the 64 x 64 inverse diagonal block (column-major), T = inv or inv^T, NR columns; the
@@ -151,15 +185,18 @@ __device__ __forceinline__ void apply_inverse_block(const double *__restrict__ i
 }
 
 // W[i][:] -= sum_{tt < jb} M(i, c0 + tt) v[tt][:] for i in [ilo, ihi), by all threads of the workgroup;
-// a matrix entry is loaded once for all NR columns.  Untransposed the front runs down i (thread =
-// row, 8 loads in flight); transposed it runs along tt (a wavefront per row, lanes along tt,
-// butterfly sums).  W is fs x NR column-major (leading dimension fs).
+// a matrix entry is loaded once for all NR columns.  The jb columns c0 .. c0+jb-1 lie on one side of
+// np.  Untransposed the panels run down i (thread = row, 8 loads in flight); transposed they run
+// along tt (a wavefront per row, lanes along tt, butterfly sums).  W is fs x NR column-major.
 template <bool TRANS, int NR>
-__device__ __forceinline__ void couple_block(const double *__restrict__ F, int ld, int ilo, int ihi, int c0, int jb,
-                                             const double (*v)[NR], double *W, int fs) {
+__device__ __forceinline__ void couple_block(const Panels &fr, int ilo, int ihi, int c0, int jb,
+                                             const double (*v)[NR], double *W) {
+  const int fs = fr.fs;
   if (!TRANS) {
+    const double *base = fr.col(c0);
+    const size_t cs = (size_t)fr.col_stride(c0);
     for (int i = ilo + threadIdx.x; i < ihi; i += blockDim.x) {
-      const double *row = F + (size_t)i + (size_t)c0 * ld;
+      const double *row = base + i;
       double acc[NR];
 #pragma unroll
       for (int r = 0; r < NR; ++r) acc[r] = 0.0;
@@ -167,14 +204,14 @@ __device__ __forceinline__ void couple_block(const double *__restrict__ F, int l
       for (; tt + 8 <= jb; tt += 8) {
         double e[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) e[u] = row[(size_t)(tt + u) * ld];
+        for (int u = 0; u < 8; ++u) e[u] = row[(size_t)(tt + u) * cs];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
           for (int r = 0; r < NR; ++r) acc[r] += e[u] * v[tt + u][r];
       }
       for (; tt < jb; ++tt) {
-        const double e = row[(size_t)tt * ld];
+        const double e = row[(size_t)tt * cs];
 #pragma unroll
         for (int r = 0; r < NR; ++r) acc[r] += e * v[tt][r];
       }
@@ -182,13 +219,13 @@ __device__ __forceinline__ void couple_block(const double *__restrict__ F, int l
       for (int r = 0; r < NR; ++r) W[(size_t)r * fs + i] -= acc[r];
     }
   } else {
+    // M(i, c0 + tt) = F(c0 + tt, i): rows c0 .. of column i of F, contiguous
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     constexpr int RW = NR == 1 ? 8 : 2;  // rows per wavefront and trip
     for (int i0 = ilo + wave * RW; i0 < ihi; i0 += nw * RW) {
       double e[RW];
 #pragma unroll
-      for (int u = 0; u < RW; ++u)
-        e[u] = (i0 + u < ihi && lane < jb) ? F[(size_t)(c0 + lane) + (size_t)(i0 + u) * ld] : 0.0;
+      for (int u = 0; u < RW; ++u) e[u] = (i0 + u < ihi && lane < jb) ? fr.col(i0 + u)[c0 + lane] : 0.0;
 #pragma unroll
       for (int u = 0; u < RW; ++u)
 #pragma unroll
@@ -236,13 +273,12 @@ __global__ __launch_bounds__(256) void solve_gather_kernel(const int *__restrict
 // blocks), every later entry of W loses its coupling with the block just solved
 template <bool TRANS, int NR>
 __global__ __launch_bounds__(kSolveThreads) void solve_forward_kernel(const int *__restrict__ list, TreeView t,
-                                                                      const double *__restrict__ fronts,
                                                                       const double *__restrict__ invs,
                                                                       double *__restrict__ work) {
   __shared__ double w[NB][NR], v[NB][NR];
   const int f = list[blockIdx.x];
-  const int np = t.np[f], fs = np + t.nb[f], ld = t.ld[f];
-  const double *F = fronts + t.foff[f];
+  const Panels fr = panels_of(t, f);
+  const int np = fr.np, fs = fr.fs;
   double *W = work + (size_t)t.woff[f] * NR;
   for (int j0 = 0; j0 < np; j0 += NB) {
     const int jb = min(NB, np - j0);
@@ -259,7 +295,7 @@ __global__ __launch_bounds__(kSolveThreads) void solve_forward_kernel(const int 
       const int l = o % jb, r = o / jb;
       W[(size_t)r * fs + j0 + l] = v[l][r];
     }
-    couple_block<TRANS, NR>(F, ld, j0 + jb, fs, j0, jb, v, W, fs);
+    couple_block<TRANS, NR>(fr, j0 + jb, fs, j0, jb, v, W);
     __syncthreads();
   }
 }
@@ -268,14 +304,13 @@ __global__ __launch_bounds__(kSolveThreads) void solve_forward_kernel(const int 
 // the ancestors; writes the pivots' part of the solution
 template <bool TRANS, int NR>
 __global__ __launch_bounds__(kSolveThreads) void solve_backward_kernel(const int *__restrict__ list, TreeView t,
-                                                                       const double *__restrict__ fronts,
                                                                        const double *__restrict__ invs,
                                                                        double *__restrict__ work,
                                                                        double *__restrict__ x, size_t stride) {
   __shared__ double w[NB][NR], v[NB][NR];
   const int f = list[blockIdx.x];
-  const int np = t.np[f], nb = t.nb[f], ld = t.ld[f], p0 = t.p0[f], fs = np + nb;
-  const double *F = fronts + t.foff[f];
+  const Panels fr = panels_of(t, f);
+  const int np = fr.np, nb = fr.nb, p0 = t.p0[f], fs = fr.fs;
   double *W = work + (size_t)t.woff[f] * NR;
   const int *b = t.bidx + t.bptr[f];
   for (int k0 = 0; k0 < nb; k0 += NB) {  // boundary columns in strips of 64, through LDS
@@ -285,7 +320,7 @@ __global__ __launch_bounds__(kSolveThreads) void solve_backward_kernel(const int
       v[l][r] = l < kb ? x[(size_t)r * stride + b[k0 + l]] : 0.0;
     }
     __syncthreads();
-    couple_block<TRANS, NR>(F, ld, 0, np, np + k0, kb, v, W, fs);
+    couple_block<TRANS, NR>(fr, 0, np, np + k0, kb, v, W);
     __syncthreads();
   }
   const int nblk = (np + NB - 1) / NB;
@@ -304,7 +339,7 @@ __global__ __launch_bounds__(kSolveThreads) void solve_backward_kernel(const int
       const int l = o % jb, r = o / jb;
       x[(size_t)r * stride + p0 + j0 + l] = v[l][r];
     }
-    couple_block<TRANS, NR>(F, ld, 0, j0, j0, jb, v, W, fs);
+    couple_block<TRANS, NR>(fr, 0, j0, j0, jb, v, W);
     __syncthreads();
   }
 }
@@ -323,9 +358,10 @@ __global__ __launch_bounds__(256) void front_gather_x_kernel(const int *__restri
 }
 
 // z[i][:] -= sum_k M(i, np + k) xb[k][:], i < np: 64 rows per workgroup; z and xb are columns of
-// fs-strided work matrices
+// fs-strided work matrices.  Untransposed M(i, np + k) = U(i, k); transposed = F(np + k, i) in P.
 template <bool TRANS, int NR>
-__global__ __launch_bounds__(256) void front_gemv_kernel(const double *__restrict__ F, int ld, int np, int nb,
+__global__ __launch_bounds__(256) void front_gemv_kernel(const double *__restrict__ P, int ldp,
+                                                         const double *__restrict__ U, int ldu, int np, int nb,
                                                          const double *__restrict__ xb, double *__restrict__ z,
                                                          int fs) {
   __shared__ double part[4][64][NR];
@@ -337,19 +373,19 @@ __global__ __launch_bounds__(256) void front_gemv_kernel(const double *__restric
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = 0.0;
     if (i < np) {
-      const double *row = F + (size_t)i + (size_t)np * ld;
+      const double *row = U + (size_t)i;
       int k = wave;
       for (; k + 28 < nb; k += 32) {
         double e[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) e[u] = row[(size_t)(k + 4 * u) * ld];
+        for (int u = 0; u < 8; ++u) e[u] = row[(size_t)(k + 4 * u) * ldu];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
           for (int r = 0; r < NR; ++r) acc[r] += e[u] * xb[(size_t)r * fs + k + 4 * u];
       }
       for (; k < nb; k += 4) {
-        const double e = row[(size_t)k * ld];
+        const double e = row[(size_t)k * ldu];
 #pragma unroll
         for (int r = 0; r < NR; ++r) acc[r] += e * xb[(size_t)r * fs + k];
       }
@@ -371,9 +407,9 @@ __global__ __launch_bounds__(256) void front_gemv_kernel(const double *__restric
         for (int r = 0; r < NR; ++r) acc[u][r] = 0.0;
       for (int k = lane; k < nb; k += 64) {
 #pragma unroll
-        for (int u = 0; u < RW; ++u) {  // M(i, np + k) = F(np + k, i)
+        for (int u = 0; u < RW; ++u) {
           if (i0 + rr + u >= np) continue;
-          const double e = F[(size_t)(np + k) + (size_t)(i0 + rr + u) * ld];
+          const double e = P[(size_t)(np + k) + (size_t)(i0 + rr + u) * ldp];
 #pragma unroll
           for (int r = 0; r < NR; ++r) acc[u][r] += e * xb[(size_t)r * fs + k];
         }
@@ -387,6 +423,32 @@ __global__ __launch_bounds__(256) void front_gemv_kernel(const double *__restric
           if (lane == 0 && i0 + rr + u < np) z[(size_t)r * fs + i0 + rr + u] -= acc[u][r];
         }
     }
+  }
+}
+
+// transposed forward elimination of a large front, boundary part: w[np + k][:] -= sum_t U(t, k) y[t][:]
+// (U^T y); one wavefront per boundary index, lanes along t
+template <int NR>
+__global__ __launch_bounds__(256) void front_boundary_t_kernel(const double *__restrict__ U, int ldu, int np, int nb,
+                                                               const double *__restrict__ y, double *__restrict__ w,
+                                                               int fs) {
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= nb) return;
+  const double *col = U + (size_t)k * ldu;
+  double acc[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) acc[r] = 0.0;
+  for (int tt = lane; tt < np; tt += 64) {
+    const double e = col[tt];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] += e * y[(size_t)r * fs + tt];
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc[r] += __shfl_xor(acc[r], m, 64);
+    if (lane == 0) w[(size_t)r * fs + np + k] -= acc[r];
   }
 }
 
@@ -407,7 +469,7 @@ struct Factors {
   std::shared_ptr<const Tree> tree;
   DeviceTree D;
   TreeView view;
-  DBuf<double> fronts, invs;
+  DBuf<double> arena, invs;  // factor panels, inverses of the diagonal blocks
   std::vector<DBuf<int>> level_lists;                // fronts of each depth
   std::vector<DBuf<int>> small_lists;                // ... those factored by one workgroup each
   std::vector<int> small_counts;
@@ -420,9 +482,10 @@ struct Factors {
 
 }  // namespace mf
 
-size_t mf_device_bytes(const mf::Tree &T) {
-  return ((size_t)T.front_elems + (size_t)T.inv_elems + (size_t)T.work_elems) * sizeof(double) +
-         ((size_t)T.bidx.size() + (size_t)T.rel_elems + 8 * (size_t)T.nfronts + (size_t)T.n) * sizeof(int64_t);
+size_t mf_device_bytes(const mf::Tree &T) {  // peak during the factorisation
+  return ((size_t)T.panel_elems + (size_t)T.region_elems[0] + (size_t)T.region_elems[1] + (size_t)T.inv_elems +
+          (size_t)T.work_elems) * sizeof(double) +
+         ((size_t)T.bidx.size() + (size_t)T.rel_elems + 12 * (size_t)T.nfronts + (size_t)T.n) * sizeof(int64_t);
 }
 
 void mf_free(mf::Factors *F) { delete F; }
@@ -459,9 +522,19 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   upload_vec(D.ioff, T.ioff, s);
   upload_vec(D.woff, T.woff, s);
   upload_vec(D.roff, T.roff, s);
+  upload_vec(D.depth, T.depth, s);
+  upload_vec(D.ldp, T.ldp, s);
+  upload_vec(D.ldu, T.ldu, s);
+  upload_vec(D.poff, T.poff, s);
+  upload_vec(D.uoff, T.uoff, s);
   D.rel.alloc((size_t)T.rel_elems);
-  F.view = TreeView{D.p0.get(), D.np.get(), D.nb.get(), D.ld.get(), D.parent.get(), D.front_of.get(), D.bidx.get(),
-                    D.rel.get(), D.bptr.get(), D.foff.get(), D.ioff.get(), D.woff.get(), D.roff.get()};
+  F.arena.alloc((size_t)T.panel_elems);
+  F.invs.alloc((size_t)T.inv_elems);
+  DBuf<double> region0((size_t)T.region_elems[0]), region1((size_t)T.region_elems[1]);  // transient
+  F.view = TreeView{D.p0.get(),    D.np.get(),   D.nb.get(),   D.ld.get(),   D.parent.get(), D.front_of.get(),
+                    D.bidx.get(),  D.rel.get(),  D.depth.get(), D.ldp.get(), D.ldu.get(),    D.bptr.get(),
+                    D.foff.get(),  D.ioff.get(), D.woff.get(), D.roff.get(), D.poff.get(),   D.uoff.get(),
+                    {region0.get(), region1.get()}, F.arena.get()};
   const int nd = T.maxdepth + 1;
   F.level_lists.resize((size_t)nd);
   F.small_lists.resize((size_t)nd);
@@ -503,17 +576,10 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   SPL_HIP(hipStreamSynchronize(s));
   staged.clear();
   lap("tree upload");
-  F.fronts.alloc((size_t)T.front_elems);
-  F.invs.alloc((size_t)T.inv_elems);
-  lap("hipMalloc fronts");
-  SPL_HIP(hipMemsetAsync(F.fronts.get(), 0, (size_t)T.front_elems * sizeof(double), s));
-  lap("zero fronts");
+  lap("hipMalloc");
   if (T.nfronts > 0)
     hipLaunchKernelGGL(rel_kernel, dim3((unsigned)T.nfronts), dim3(256), 0, s, T.nfronts, F.view, D.rel.get());
-  if (T.n > 0)
-    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(((size_t)T.n * 8 + 255) / 256)), dim3(256), 0, s, T.n, d_Ap,
-                       d_Ai, d_Ax, d_inv, F.view, F.fronts.get());
-  lap("rel + assemble");
+  lap("rel");
   DBuf<int> singular(1);
   SPL_HIP(hipMemsetAsync(singular.get(), 0, sizeof(int), s));
   set_factor_attributes();
@@ -525,9 +591,22 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   }
   hipStream_t side[kStreams];
   for (int i = 0; i < kStreams; ++i) SPL_HIP(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+  auto region_of = [&](int d) { return (d & 1) ? region1.get() : region0.get(); };
+  auto compact_level = [&](int d) {  // factor panels of the fronts of level d -> arena
+    int max_fs = 0;
+    for (int f : T.by_depth[(size_t)d]) max_fs = std::max(max_fs, T.fs(f));
+    const int64_t ntile = (int64_t)((max_fs + 63) / 64) * ((max_fs + 3) / 4);
+    if (ntile > 0)
+      hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ntile, (unsigned)T.by_depth[(size_t)d].size()), dim3(256), 0, s,
+                         F.level_lists[(size_t)d].get(), F.view);
+  };
   for (int d = nd - 1; d >= 0; --d) {
-    // Schur complements of the children, one child slot after the other (two children of a parent
-    // may touch the same entry: a fixed order keeps the sums reproducible)
+    // this level's fronts start from zero in their region, receive their entries of A ...
+    SPL_HIP(hipMemsetAsync(region_of(d), 0, (size_t)T.level_elems[(size_t)d] * sizeof(double), s));
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(((size_t)T.n * 8 + 255) / 256)), dim3(256), 0, s, T.n, d_Ap,
+                       d_Ai, d_Ax, d_inv, F.view, d);
+    // ... and the Schur complements of the children, one child slot after the other (two children
+    // of a parent may touch the same entry: a fixed order keeps the sums reproducible)
     if (d + 1 < nd) {
       int max_nb = 0;
       for (int c : T.by_depth[(size_t)d + 1]) max_nb = std::max(max_nb, T.nb[(size_t)c]);
@@ -535,28 +614,32 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
       for (int sl = 0; sl < 2; ++sl)
         if (F.child_counts[sl][(size_t)d] > 0 && ntile > 0)
           hipLaunchKernelGGL(extend_add_kernel, dim3((unsigned)ntile, (unsigned)F.child_counts[sl][(size_t)d]),
-                             dim3(256), 0, s, F.child_lists[sl][(size_t)d].get(), F.view, F.fronts.get());
+                             dim3(256), 0, s, F.child_lists[sl][(size_t)d].get(), F.view);
+      compact_level(d + 1);  // the children are done with: keep their panels, their region is free again
     }
     // small fronts: one launch, one workgroup each; large fronts: the multi-launch blocked
     // factorisation, independent fronts spread over side streams
     SPL_HIP(hipStreamSynchronize(s));
     if (F.small_counts[(size_t)d] > 0)
       hipLaunchKernelGGL(front_factor_kernel, dim3((unsigned)F.small_counts[(size_t)d]), dim3(256), 2 * kTileBytes, s,
-                         F.small_lists[(size_t)d].get(), F.view, F.fronts.get(), F.invs.get(), singular.get());
+                         F.small_lists[(size_t)d].get(), F.view, F.invs.get(), singular.get());
     int turn = 0;
     for (int f : T.by_depth[(size_t)d]) {
       if (T.np[(size_t)f] == 0 || T.fs(f) <= kSmallFront) continue;
-      const Band b = dense_view(F.fronts.get() + T.foff[(size_t)f], T.fs(f), T.ld[(size_t)f]);
+      const Band b = dense_view(region_of(d) + T.foff[(size_t)f], T.fs(f), T.ld[(size_t)f]);
       factor_loop(b, T.np[(size_t)f], F.invs.get() + T.ioff[(size_t)f], singular.get(), side[turn++ % kStreams]);
     }
     if (turn > 0)
       for (int i = 0; i < kStreams && i < turn; ++i) SPL_HIP(hipStreamSynchronize(side[i]));
   }
+  compact_level(0);
+  SPL_HIP(hipStreamSynchronize(s));
   lap("levels");
   for (int i = 0; i < kStreams; ++i) (void)hipStreamDestroy(side[i]);
   SPL_HIP(hipMemcpyAsync(&F.singular, singular.get(), sizeof(int), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
   SPL_HIP(hipGetLastError());
+  F.view.region[0] = F.view.region[1] = nullptr;  // the transient regions are released here
   return Fp.release();
 }
 
@@ -566,7 +649,7 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
                                   hipStream_t s) {
   const mf::Tree &T = *F.tree;
   const int nd = T.maxdepth + 1;
-  double *fronts = F.fronts.get();
+  const double *arena = F.arena.get();
   double *invs = F.invs.get();
   constexpr int FWD = TRANS ? 2 : 0, BWD = TRANS ? 3 : 1;
   for (int d = nd - 1; d >= 0; --d) {
@@ -580,32 +663,45 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
                              F.child_lists[sl][(size_t)d].get(), F.view, work);
     if (F.solve_counts[(size_t)d] > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_forward_kernel<TRANS, NR>), dim3((unsigned)F.solve_counts[(size_t)d]),
-                         dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, fronts, invs, work);
+                         dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work);
     for (int f : T.by_depth[(size_t)d]) {
-      if (T.fs(f) <= kBigSolve || T.np[(size_t)f] == 0) continue;
-      const Band b = dense_view(fronts + T.foff[(size_t)f], T.fs(f), T.ld[(size_t)f]);
+      const int np = T.np[(size_t)f], nb = T.nb[(size_t)f], fs = np + nb;
+      if (fs <= kBigSolve || np == 0) continue;
+      double *P = const_cast<double *>(arena) + T.poff[(size_t)f];
+      const double *U = arena + T.uoff[(size_t)f];
       double *W = work + (size_t)T.woff[(size_t)f] * NR, *Z = zbuf + (size_t)T.woff[(size_t)f] * NR;
-      solve_pass<FWD, NR>(b, invs + T.ioff[(size_t)f], b.n, W, Z, (size_t)b.n, s, T.np[(size_t)f]);
+      if (!TRANS) {
+        // the pivot columns of the front: the boundary rows get their updates inside the pass
+        const Band b = dense_view(P, fs, T.ldp[(size_t)f]);
+        solve_pass<FWD, NR>(b, invs + T.ioff[(size_t)f], fs, W, Z, (size_t)fs, s, np);
+      } else {
+        const Band b = dense_view(P, np, T.ldp[(size_t)f]);  // U11^T; then the boundary with U12^T
+        solve_pass<FWD, NR>(b, invs + T.ioff[(size_t)f], np, W, Z, (size_t)fs, s);
+        if (nb > 0)
+          hipLaunchKernelGGL(front_boundary_t_kernel<NR>, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, s, U,
+                             T.ldu[(size_t)f], np, nb, Z, W, fs);
+      }
     }
   }
   for (int d = 0; d < nd; ++d) {
     if (F.solve_counts[(size_t)d] > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_backward_kernel<TRANS, NR>), dim3((unsigned)F.solve_counts[(size_t)d]),
-                         dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, fronts, invs, work, c,
+                         dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work, c,
                          stride);
     for (int f : T.by_depth[(size_t)d]) {
       const int np = T.np[(size_t)f], nb = T.nb[(size_t)f], fs = np + nb;
       if (fs <= kBigSolve || np == 0) continue;
-      double *Ff = fronts + T.foff[(size_t)f];
-      const int ld = T.ld[(size_t)f];
+      double *P = const_cast<double *>(arena) + T.poff[(size_t)f];
+      const double *U = arena + T.uoff[(size_t)f];
+      const int ldp = T.ldp[(size_t)f], ldu = T.ldu[(size_t)f];
       double *W = work + (size_t)T.woff[(size_t)f] * NR, *Z = zbuf + (size_t)T.woff[(size_t)f] * NR;
       if (nb > 0) {
         hipLaunchKernelGGL(front_gather_x_kernel<NR>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s,
                            F.D.bidx.get() + T.bptr[(size_t)f], nb, c, stride, W + np, fs);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(front_gemv_kernel<TRANS, NR>), dim3((unsigned)((np + 63) / 64)), dim3(256),
-                           0, s, Ff, ld, np, nb, W + np, Z, fs);
+                           0, s, P, ldp, U, ldu, np, nb, W + np, Z, fs);
       }
-      const Band b = dense_view(Ff, np, ld);  // the pivot block alone; columns of Z / W are fs apart
+      const Band b = dense_view(P, np, ldp);  // the pivot block alone; columns of Z / W are fs apart
       solve_pass<BWD, NR>(b, invs + T.ioff[(size_t)f], np, Z, W, (size_t)fs, s);
       hipLaunchKernelGGL(front_scatter_x_kernel<NR>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s,
                          T.p0[(size_t)f], np, W, fs, c, stride);
