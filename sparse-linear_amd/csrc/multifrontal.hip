@@ -35,7 +35,7 @@ namespace {
 
 struct DeviceTree {
   DBuf<int> p0, np, nb, ld, parent, front_of, bidx, rel, depth, ldp, ldu;
-  DBuf<int64_t> bptr, foff, ioff, woff, roff, poff, uoff;
+  DBuf<int64_t> bptr, foff, ioff, woff, roff, poff, uoff, cboff;
 };
 
 struct TreeView {  // raw pointers for kernels
@@ -43,6 +43,8 @@ struct TreeView {  // raw pointers for kernels
   const int64_t *bptr, *foff, *ioff, *woff, *roff, *poff, *uoff;
   double *region[2];  // whole fronts of the even / odd tree levels (transient)
   double *arena;      // factor panels (resident)
+  const int64_t *cboff;  // >= 0: the Schur complement of this front was saved to `cut` (nb x nb, ld nb)
+  double *cut;
   __device__ __forceinline__ double *front(int f) const { return region[depth[f] & 1] + foff[f]; }
 };
 
@@ -68,14 +70,14 @@ __device__ __forceinline__ int local_pos(const TreeView &t, int f, int g) {
 // entries of A (CSC arrays, original numbering) -> the fronts of tree level `level`; 8 lanes per column
 __global__ __launch_bounds__(256) void assemble_kernel(int n, const int *__restrict__ Ap, const int *__restrict__ Ai,
                                                        const double *__restrict__ Ax, const int *__restrict__ inv,
-                                                       TreeView t, int level) {
+                                                       TreeView t, int level, int id_lo, int id_hi) {
   const int j = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 3), part = threadIdx.x & 7;
   if (j >= n) return;
   const int gj = inv[j];
   for (int p = Ap[j] + part; p < Ap[j + 1]; p += 8) {
     const int gi = inv[Ai[p]];
     const int f = t.front_of[min(gi, gj)];
-    if (t.depth[f] != level) continue;
+    if (t.depth[f] != level || f < id_lo || f > id_hi) continue;
     const int r = local_pos(t, f, gi), c = local_pos(t, f, gj);
     t.front(f)[(int64_t)r + (int64_t)c * t.ld[f]] = Ax[p];
   }
@@ -101,8 +103,19 @@ __global__ __launch_bounds__(256) void extend_add_kernel(const int *__restrict__
   if (r >= nb || cc >= nb) return;
   const int p = t.parent[c], npc = t.np[c];
   const int *rel = t.rel + t.roff[c];
-  const double v = t.front(c)[(int64_t)(npc + r) + (int64_t)(npc + cc) * t.ld[c]];
+  const int64_t saved = t.cboff[c];
+  const double v = saved >= 0 ? t.cut[saved + (int64_t)r + (int64_t)cc * nb]
+                              : t.front(c)[(int64_t)(npc + r) + (int64_t)(npc + cc) * t.ld[c]];
   t.front(p)[(int64_t)rel[r] + (int64_t)rel[cc] * t.ld[p]] += v;
+}
+
+// Schur complement of a finished front -> the cut buffer (its parent is assembled much later)
+__global__ __launch_bounds__(256) void save_cb_kernel(int f, TreeView t) {
+  const int np = t.np[f], nb = t.nb[f];
+  const int ntr = (nb + 63) >> 6;
+  const int r = (int)(blockIdx.x % ntr) * 64 + (threadIdx.x & 63), cc = (int)(blockIdx.x / ntr) * 4 + (threadIdx.x >> 6);
+  if (r >= nb || cc >= nb) return;
+  t.cut[t.cboff[f] + (int64_t)r + (int64_t)cc * nb] = t.front(f)[(int64_t)(np + r) + (int64_t)(np + cc) * t.ld[f]];
 }
 
 // factor panels of the listed (finished) fronts -> arena; blockIdx.y = front, 64 x 4 tiles over the
@@ -477,20 +490,88 @@ struct Factors {
   std::vector<int> solve_counts;
   std::vector<DBuf<int>> child_lists[2];             // children (by slot) of the fronts of each depth
   std::vector<int> child_counts[2];
+  std::vector<std::vector<int>> h_small, h_child[2];  // host copies (ascending ids) of small_lists / child_lists
   int singular = 0;
 };
 
 }  // namespace mf
 
-size_t mf_device_bytes(const mf::Tree &T) {  // peak during the factorisation
-  return ((size_t)T.panel_elems + (size_t)T.region_elems[0] + (size_t)T.region_elems[1] + (size_t)T.inv_elems +
-          (size_t)T.work_elems) * sizeof(double) +
-         ((size_t)T.bidx.size() + (size_t)T.rel_elems + 12 * (size_t)T.nfronts + (size_t)T.n) * sizeof(int64_t);
-}
-
 void mf_free(mf::Factors *F) { delete F; }
 
 int mf_singular(const mf::Factors *F) { return F->singular; }
+
+namespace {
+
+// Transient memory plan of the numeric factorisation.  With cut = 0 the tree is processed level by
+// level as a whole: the whole fronts of a level and of its children are alive together.  With
+// cut = K > 0 the subtrees hanging below depth K are processed one after the other (each needs
+// only its own share of every level), the Schur complement of each subtree root waits in the
+// `cut` buffer, and the top K levels come last.  The smallest K that fits the budget is used.
+struct Plan {
+  int cut = 0;
+  std::vector<int64_t> foff;         // offset of every whole front inside its region (per segment and level)
+  std::vector<int64_t> cboff;        // offset of the saved Schur complement of a subtree root, or -1
+  std::vector<int> first;            // smallest id of the subtree of every front
+  std::vector<int> roots;            // the fronts at depth `cut` (ascending ids); empty for cut = 0
+  int64_t region_elems[2] = {0, 0}, cut_elems = 0;
+  int64_t transient_elems() const { return region_elems[0] + region_elems[1] + cut_elems; }
+};
+
+Plan make_plan(const mf::Tree &T, int cut) {
+  Plan P;
+  P.cut = cut;
+  const int nf = T.nfronts, nd = T.maxdepth + 1;
+  P.foff.assign((size_t)nf, 0);
+  P.cboff.assign((size_t)nf, -1);
+  P.first.resize((size_t)nf);
+  for (int f = 0; f < nf; ++f) P.first[(size_t)f] = f;
+  for (int f = 0; f < nf; ++f)
+    if (T.parent[(size_t)f] >= 0)
+      P.first[(size_t)T.parent[(size_t)f]] = std::min(P.first[(size_t)T.parent[(size_t)f]], P.first[(size_t)f]);
+  auto front_elems = [&](int f) {
+    return ((int64_t)T.ld[(size_t)f] * std::max(T.fs(f), 1) + 15) / 16 * 16;
+  };
+  // lays out the fronts with ids in [lo, hi] and depths in [dtop, nd): returns nothing, grows the regions
+  auto layout = [&](int lo, int hi, int dtop) {
+    for (int d = dtop; d < nd; ++d) {
+      const std::vector<int> &L = T.by_depth[(size_t)d];
+      int64_t off = 0;
+      for (auto it = std::lower_bound(L.begin(), L.end(), lo); it != L.end() && *it <= hi; ++it) {
+        P.foff[(size_t)*it] = off;
+        off += front_elems(*it);
+      }
+      P.region_elems[d & 1] = std::max(P.region_elems[d & 1], off);
+    }
+  };
+  if (cut <= 0 || cut >= nd) {
+    P.cut = 0;
+    layout(0, nf - 1, 0);
+    return P;
+  }
+  P.roots = T.by_depth[(size_t)cut];
+  for (int r : P.roots) {
+    layout(P.first[(size_t)r], r, cut);
+    P.cboff[(size_t)r] = P.cut_elems;
+    P.cut_elems += ((int64_t)T.nb[(size_t)r] * T.nb[(size_t)r] + 15) / 16 * 16;
+  }
+  // the top: depths < cut (their lists hold nothing else)
+  for (int d = 0; d < cut; ++d) {
+    int64_t off = 0;
+    for (int f : T.by_depth[(size_t)d]) {
+      P.foff[(size_t)f] = off;
+      off += front_elems(f);
+    }
+    P.region_elems[d & 1] = std::max(P.region_elems[d & 1], off);
+  }
+  return P;
+}
+
+}  // namespace
+
+size_t mf_device_bytes(const mf::Tree &T) {  // resident part; the transient part is planned in mf_factor
+  return ((size_t)T.panel_elems + (size_t)T.inv_elems + 3 * (size_t)T.work_elems) * sizeof(double) +
+         ((size_t)T.bidx.size() + (size_t)T.rel_elems + 14 * (size_t)T.nfronts + (size_t)T.n) * sizeof(int64_t);
+}
 
 // numeric factorisation of P A P^T; d_Ap/d_Ai/d_Ax: CSC arrays of A on the device, d_inv: old -> new
 mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, const int *d_Ai, const double *d_Ax,
@@ -509,6 +590,24 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   std::unique_ptr<mf::Factors> Fp(new mf::Factors());
   mf::Factors &F = *Fp;
   F.tree = tree;
+  const int nd = T.maxdepth + 1, nf = T.nfronts;
+  // ---- memory plan: the smallest cut depth whose transient part fits next to the resident part
+  Plan plan;
+  {
+    size_t free_b = 0, total_b = 0;
+    SPL_HIP(hipMemGetInfo(&free_b, &total_b));
+    const double budget = (double)free_b - (double)free_b / 16 - (double)mf_device_bytes(T);
+    const char *force = getenv("SPL_MF_CUT");  // tests: force a cut depth
+    bool ok = false;
+    for (int cut = force ? std::max(0, std::min(atoi(force), nd - 1)) : 0; cut < std::max(nd, 1) && cut <= 10; ++cut) {
+      plan = make_plan(T, cut);
+      if ((double)plan.transient_elems() * sizeof(double) <= budget || force) { ok = true; break; }
+    }
+    if (!ok) throw DeviceError{SPL_ERROR_out_of_memory};
+    if (timing)
+      fprintf(stderr, "[mf_factor] panels %.1f GB, transient %.1f GB at cut depth %d (free %.1f GB)\n",
+              T.panel_elems * 8e-9, plan.transient_elems() * 8e-9, plan.cut, free_b * 1e-9);
+  }
   DeviceTree &D = F.D;
   upload_vec(D.p0, T.p0, s);
   upload_vec(D.np, T.np, s);
@@ -518,7 +617,8 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   upload_vec(D.front_of, T.front_of, s);
   upload_vec(D.bidx, T.bidx, s);
   upload_vec(D.bptr, T.bptr, s);
-  upload_vec(D.foff, T.foff, s);
+  upload_vec(D.foff, plan.foff, s);
+  upload_vec(D.cboff, plan.cboff, s);
   upload_vec(D.ioff, T.ioff, s);
   upload_vec(D.woff, T.woff, s);
   upload_vec(D.roff, T.roff, s);
@@ -530,56 +630,49 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   D.rel.alloc((size_t)T.rel_elems);
   F.arena.alloc((size_t)T.panel_elems);
   F.invs.alloc((size_t)T.inv_elems);
-  DBuf<double> region0((size_t)T.region_elems[0]), region1((size_t)T.region_elems[1]);  // transient
+  DBuf<double> region0((size_t)plan.region_elems[0]), region1((size_t)plan.region_elems[1]),
+      cutbuf((size_t)plan.cut_elems);  // transient
   F.view = TreeView{D.p0.get(),    D.np.get(),   D.nb.get(),   D.ld.get(),   D.parent.get(), D.front_of.get(),
                     D.bidx.get(),  D.rel.get(),  D.depth.get(), D.ldp.get(), D.ldu.get(),    D.bptr.get(),
                     D.foff.get(),  D.ioff.get(), D.woff.get(), D.roff.get(), D.poff.get(),   D.uoff.get(),
-                    {region0.get(), region1.get()}, F.arena.get()};
-  const int nd = T.maxdepth + 1;
+                    {region0.get(), region1.get()}, F.arena.get(), D.cboff.get(), cutbuf.get()};
   F.level_lists.resize((size_t)nd);
   F.small_lists.resize((size_t)nd);
   F.small_counts.assign((size_t)nd, 0);
   F.solve_lists.resize((size_t)nd);
   F.solve_counts.assign((size_t)nd, 0);
+  F.h_small.assign((size_t)nd, std::vector<int>());
   for (int sl = 0; sl < 2; ++sl) {
     F.child_lists[sl].resize((size_t)nd);
     F.child_counts[sl].assign((size_t)nd, 0);
+    F.h_child[sl].assign((size_t)nd, std::vector<int>());
   }
   std::vector<std::vector<int>> staged;  // host copies must outlive the asynchronous uploads
-  staged.reserve((size_t)4 * nd);
+  staged.reserve((size_t)nd);
   for (int d = 0; d < nd; ++d) {
     upload_vec(F.level_lists[(size_t)d], T.by_depth[(size_t)d], s);
-    {
-      std::vector<int> small;
-      for (int f : T.by_depth[(size_t)d])
-        if (T.np[(size_t)f] > 0 && T.fs(f) <= kSmallFront) small.push_back(f);
-      F.small_counts[(size_t)d] = (int)small.size();
-      staged.push_back(std::move(small));
-      upload_vec(F.small_lists[(size_t)d], staged.back(), s);
-      std::vector<int> one_wg;
-      for (int f : T.by_depth[(size_t)d])
-        if (T.fs(f) <= kBigSolve) one_wg.push_back(f);
-      F.solve_counts[(size_t)d] = (int)one_wg.size();
-      staged.push_back(std::move(one_wg));
-      upload_vec(F.solve_lists[(size_t)d], staged.back(), s);
-    }
+    for (int f : T.by_depth[(size_t)d])
+      if (T.np[(size_t)f] > 0 && T.fs(f) <= kSmallFront) F.h_small[(size_t)d].push_back(f);
+    F.small_counts[(size_t)d] = (int)F.h_small[(size_t)d].size();
+    upload_vec(F.small_lists[(size_t)d], F.h_small[(size_t)d], s);
+    std::vector<int> one_wg;
+    for (int f : T.by_depth[(size_t)d])
+      if (T.fs(f) <= kBigSolve) one_wg.push_back(f);
+    F.solve_counts[(size_t)d] = (int)one_wg.size();
+    staged.push_back(std::move(one_wg));
+    upload_vec(F.solve_lists[(size_t)d], staged.back(), s);
     if (d + 1 < nd) {
-      std::vector<int> ch[2];
-      for (int c : T.by_depth[(size_t)d + 1]) ch[T.slot[(size_t)c]].push_back(c);
+      for (int c : T.by_depth[(size_t)d + 1]) F.h_child[T.slot[(size_t)c]][(size_t)d].push_back(c);
       for (int sl = 0; sl < 2; ++sl) {
-        F.child_counts[sl][(size_t)d] = (int)ch[sl].size();
-        staged.push_back(std::move(ch[sl]));
-        upload_vec(F.child_lists[sl][(size_t)d], staged.back(), s);
+        F.child_counts[sl][(size_t)d] = (int)F.h_child[sl][(size_t)d].size();
+        upload_vec(F.child_lists[sl][(size_t)d], F.h_child[sl][(size_t)d], s);
       }
     }
   }
   SPL_HIP(hipStreamSynchronize(s));
   staged.clear();
-  lap("tree upload");
-  lap("hipMalloc");
-  if (T.nfronts > 0)
-    hipLaunchKernelGGL(rel_kernel, dim3((unsigned)T.nfronts), dim3(256), 0, s, T.nfronts, F.view, D.rel.get());
-  lap("rel");
+  lap("uploads + hipMalloc");
+  if (nf > 0) hipLaunchKernelGGL(rel_kernel, dim3((unsigned)nf), dim3(256), 0, s, nf, F.view, D.rel.get());
   DBuf<int> singular(1);
   SPL_HIP(hipMemsetAsync(singular.get(), 0, sizeof(int), s));
   set_factor_attributes();
@@ -592,54 +685,96 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   hipStream_t side[kStreams];
   for (int i = 0; i < kStreams; ++i) SPL_HIP(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
   auto region_of = [&](int d) { return (d & 1) ? region1.get() : region0.get(); };
-  auto compact_level = [&](int d) {  // factor panels of the fronts of level d -> arena
-    int max_fs = 0;
-    for (int f : T.by_depth[(size_t)d]) max_fs = std::max(max_fs, T.fs(f));
-    const int64_t ntile = (int64_t)((max_fs + 63) / 64) * ((max_fs + 3) / 4);
-    if (ntile > 0)
-      hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ntile, (unsigned)T.by_depth[(size_t)d].size()), dim3(256), 0, s,
-                         F.level_lists[(size_t)d].get(), F.view);
+  // [begin, end) of the ids lo..hi inside an ascending list
+  auto range_of = [](const std::vector<int> &L, int lo, int hi, int &begin, int &end) {
+    begin = (int)(std::lower_bound(L.begin(), L.end(), lo) - L.begin());
+    end = (int)(std::upper_bound(L.begin(), L.end(), hi) - L.begin());
   };
-  for (int d = nd - 1; d >= 0; --d) {
-    // this level's fronts start from zero in their region, receive their entries of A ...
-    SPL_HIP(hipMemsetAsync(region_of(d), 0, (size_t)T.level_elems[(size_t)d] * sizeof(double), s));
-    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(((size_t)T.n * 8 + 255) / 256)), dim3(256), 0, s, T.n, d_Ap,
-                       d_Ai, d_Ax, d_inv, F.view, d);
-    // ... and the Schur complements of the children, one child slot after the other (two children
-    // of a parent may touch the same entry: a fixed order keeps the sums reproducible)
-    if (d + 1 < nd) {
-      int max_nb = 0;
-      for (int c : T.by_depth[(size_t)d + 1]) max_nb = std::max(max_nb, T.nb[(size_t)c]);
-      const int64_t ntile = (int64_t)((max_nb + 63) / 64) * ((max_nb + 3) / 4);
-      for (int sl = 0; sl < 2; ++sl)
-        if (F.child_counts[sl][(size_t)d] > 0 && ntile > 0)
-          hipLaunchKernelGGL(extend_add_kernel, dim3((unsigned)ntile, (unsigned)F.child_counts[sl][(size_t)d]),
-                             dim3(256), 0, s, F.child_lists[sl][(size_t)d].get(), F.view);
-      compact_level(d + 1);  // the children are done with: keep their panels, their region is free again
+  auto compact_fronts = [&](int d, int lo, int hi) {  // factor panels of the fronts lo..hi of level d -> arena
+    int b0, b1;
+    range_of(T.by_depth[(size_t)d], lo, hi, b0, b1);
+    int max_fs = 0;
+    for (int i = b0; i < b1; ++i) max_fs = std::max(max_fs, T.fs(T.by_depth[(size_t)d][(size_t)i]));
+    const int64_t ntile = (int64_t)((max_fs + 63) / 64) * ((max_fs + 3) / 4);
+    if (ntile > 0 && b1 > b0)
+      hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ntile, (unsigned)(b1 - b0)), dim3(256), 0, s,
+                         F.level_lists[(size_t)d].get() + b0, F.view);
+  };
+  // levels dbot .. dtop (bottom-up) of the fronts with ids lo..hi.  children_saved: the children of
+  // level plan.cut - 1 are subtree roots, already compacted, their Schur complements in the cut buffer
+  auto process = [&](int lo, int hi, int dtop, int dbot, bool children_saved) {
+    for (int d = dbot; d >= dtop; --d) {
+      int b0, b1;
+      range_of(T.by_depth[(size_t)d], lo, hi, b0, b1);
+      if (b1 == b0) continue;
+      // this level's fronts start from zero in their region, receive their entries of A ...
+      int64_t extent = 0;
+      for (int i = b0; i < b1; ++i) {
+        const int f = T.by_depth[(size_t)d][(size_t)i];
+        extent = std::max(extent, plan.foff[(size_t)f] + (int64_t)T.ld[(size_t)f] * std::max(T.fs(f), 1));
+      }
+      SPL_HIP(hipMemsetAsync(region_of(d), 0, (size_t)extent * sizeof(double), s));
+      hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(((size_t)T.n * 8 + 255) / 256)), dim3(256), 0, s, T.n, d_Ap,
+                         d_Ai, d_Ax, d_inv, F.view, d, lo, hi);
+      // ... and the Schur complements of the children, one child slot after the other (two children
+      // of a parent may touch the same entry: a fixed order keeps the sums reproducible)
+      if (d + 1 < nd) {
+        for (int sl = 0; sl < 2; ++sl) {
+          int c0, c1;
+          range_of(F.h_child[sl][(size_t)d], lo, hi, c0, c1);
+          int max_nb = 0;
+          for (int i = c0; i < c1; ++i) max_nb = std::max(max_nb, T.nb[(size_t)F.h_child[sl][(size_t)d][(size_t)i]]);
+          const int64_t ntile = (int64_t)((max_nb + 63) / 64) * ((max_nb + 3) / 4);
+          if (c1 > c0 && ntile > 0)
+            hipLaunchKernelGGL(extend_add_kernel, dim3((unsigned)ntile, (unsigned)(c1 - c0)), dim3(256), 0, s,
+                               F.child_lists[sl][(size_t)d].get() + c0, F.view);
+        }
+        // the children are done with: keep their panels, their region is free again (subtree
+        // roots were compacted when their subtree finished)
+        if (!(children_saved && d + 1 == plan.cut)) compact_fronts(d + 1, lo, hi);
+      }
+      // small fronts: one launch, one workgroup each; large fronts: the multi-launch blocked
+      // factorisation, independent fronts spread over side streams
+      SPL_HIP(hipStreamSynchronize(s));
+      int s0, s1;
+      range_of(F.h_small[(size_t)d], lo, hi, s0, s1);
+      if (s1 > s0)
+        hipLaunchKernelGGL(front_factor_kernel, dim3((unsigned)(s1 - s0)), dim3(256), 2 * kTileBytes, s,
+                           F.small_lists[(size_t)d].get() + s0, F.view, F.invs.get(), singular.get());
+      int turn = 0;
+      for (int i = b0; i < b1; ++i) {
+        const int f = T.by_depth[(size_t)d][(size_t)i];
+        if (T.np[(size_t)f] == 0 || T.fs(f) <= kSmallFront) continue;
+        const Band b = dense_view(region_of(d) + plan.foff[(size_t)f], T.fs(f), T.ld[(size_t)f]);
+        factor_loop(b, T.np[(size_t)f], F.invs.get() + T.ioff[(size_t)f], singular.get(), side[turn++ % kStreams]);
+      }
+      if (turn > 0)
+        for (int i = 0; i < kStreams && i < turn; ++i) SPL_HIP(hipStreamSynchronize(side[i]));
     }
-    // small fronts: one launch, one workgroup each; large fronts: the multi-launch blocked
-    // factorisation, independent fronts spread over side streams
-    SPL_HIP(hipStreamSynchronize(s));
-    if (F.small_counts[(size_t)d] > 0)
-      hipLaunchKernelGGL(front_factor_kernel, dim3((unsigned)F.small_counts[(size_t)d]), dim3(256), 2 * kTileBytes, s,
-                         F.small_lists[(size_t)d].get(), F.view, F.invs.get(), singular.get());
-    int turn = 0;
-    for (int f : T.by_depth[(size_t)d]) {
-      if (T.np[(size_t)f] == 0 || T.fs(f) <= kSmallFront) continue;
-      const Band b = dense_view(region_of(d) + T.foff[(size_t)f], T.fs(f), T.ld[(size_t)f]);
-      factor_loop(b, T.np[(size_t)f], F.invs.get() + T.ioff[(size_t)f], singular.get(), side[turn++ % kStreams]);
+  };
+  if (plan.cut == 0) {
+    process(0, nf - 1, 0, nd - 1, false);
+    compact_fronts(0, 0, nf - 1);
+  } else {
+    for (int r : plan.roots) {  // one subtree after the other; its root's Schur complement is saved
+      process(plan.first[(size_t)r], r, plan.cut, nd - 1, false);
+      compact_fronts(plan.cut, r, r);
+      const int nb = T.nb[(size_t)r];
+      const int64_t ntile = (int64_t)((nb + 63) / 64) * ((nb + 3) / 4);
+      if (ntile > 0) hipLaunchKernelGGL(save_cb_kernel, dim3((unsigned)ntile), dim3(256), 0, s, r, F.view);
+      SPL_HIP(hipStreamSynchronize(s));
     }
-    if (turn > 0)
-      for (int i = 0; i < kStreams && i < turn; ++i) SPL_HIP(hipStreamSynchronize(side[i]));
+    process(0, nf - 1, 0, plan.cut - 1, true);  // the top of the tree
+    compact_fronts(0, 0, nf - 1);
   }
-  compact_level(0);
   SPL_HIP(hipStreamSynchronize(s));
   lap("levels");
   for (int i = 0; i < kStreams; ++i) (void)hipStreamDestroy(side[i]);
   SPL_HIP(hipMemcpyAsync(&F.singular, singular.get(), sizeof(int), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
   SPL_HIP(hipGetLastError());
-  F.view.region[0] = F.view.region[1] = nullptr;  // the transient regions are released here
+  F.view.region[0] = F.view.region[1] = nullptr;  // the transient buffers are released here
+  F.view.cut = nullptr;
   return Fp.release();
 }
 
