@@ -569,9 +569,9 @@ int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
       if (!force_band && (force_mf || (S->n >= 4096 && band_flops > 1e9))) {
         std::shared_ptr<mf::Tree> T = std::make_shared<mf::Tree>();
         mf::build_tree(S->n, Ap, Ai, 256, *T);
-        // measured: the tree wins from about 12x fewer flops on (many small fronts run below the
+        // measured: the tree wins from about 10x fewer flops on (many small fronts run below the
         // MFMA rate of the band's large windows; 32^3 Poisson is the break-even)
-        if (force_mf || 12.0 * T->flops < band_flops) S->tree = T;
+        if (force_mf || 10.0 * T->flops < band_flops) S->tree = T;
       }
     }
     *SymbolicOut = S;
