@@ -119,19 +119,19 @@ __global__ __launch_bounds__(256) void save_cb_kernel(int f, TreeView t) {
 }
 
 // factor panels of the listed (finished) fronts -> arena; blockIdx.y = front, 64 x 4 tiles over the
-// fs x fs front, of which only the pivot columns and pivot rows are copied
-__global__ __launch_bounds__(256) void compact_kernel(const int *__restrict__ list, TreeView t) {
+// panel only: which = 0: P = columns [0, np) (fs rows); which = 1: U = rows [0, np) of the other columns
+__global__ __launch_bounds__(256) void compact_kernel(const int *__restrict__ list, TreeView t, int which) {
   const int f = list[blockIdx.y];
   const int np = t.np[f], nb = t.nb[f], fs = np + nb;
-  const int ntr = (fs + 63) >> 6, ntc = (fs + 3) >> 2;
+  const int rows = which == 0 ? fs : np, cols = which == 0 ? np : nb;
+  const int ntr = (rows + 63) >> 6, ntc = (cols + 3) >> 2;
   if ((int64_t)blockIdx.x >= (int64_t)ntr * ntc) return;
   const int i = (int)(blockIdx.x % ntr) * 64 + (threadIdx.x & 63), j = (int)(blockIdx.x / ntr) * 4 + (threadIdx.x >> 6);
-  if (i >= fs || j >= fs) return;
-  if (j < np) {
+  if (i >= rows || j >= cols) return;
+  if (which == 0)
     t.arena[t.poff[f] + (int64_t)i + (int64_t)j * t.ldp[f]] = t.front(f)[(int64_t)i + (int64_t)j * t.ld[f]];
-  } else if (i < np) {
-    t.arena[t.uoff[f] + (int64_t)i + (int64_t)(j - np) * t.ldu[f]] = t.front(f)[(int64_t)i + (int64_t)j * t.ld[f]];
-  }
+  else
+    t.arena[t.uoff[f] + (int64_t)i + (int64_t)j * t.ldu[f]] = t.front(f)[(int64_t)i + (int64_t)(np + j) * t.ld[f]];
 }
 
 // small fronts of a tree level: one workgroup per front runs the whole partial factorisation
@@ -693,12 +693,19 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   auto compact_fronts = [&](int d, int lo, int hi) {  // factor panels of the fronts lo..hi of level d -> arena
     int b0, b1;
     range_of(T.by_depth[(size_t)d], lo, hi, b0, b1);
-    int max_fs = 0;
-    for (int i = b0; i < b1; ++i) max_fs = std::max(max_fs, T.fs(T.by_depth[(size_t)d][(size_t)i]));
-    const int64_t ntile = (int64_t)((max_fs + 63) / 64) * ((max_fs + 3) / 4);
-    if (ntile > 0 && b1 > b0)
-      hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ntile, (unsigned)(b1 - b0)), dim3(256), 0, s,
-                         F.level_lists[(size_t)d].get() + b0, F.view);
+    int64_t tiles_p = 0, tiles_u = 0;
+    for (int i = b0; i < b1; ++i) {
+      const int f = T.by_depth[(size_t)d][(size_t)i];
+      const int64_t np = T.np[(size_t)f], nb = T.nb[(size_t)f];
+      tiles_p = std::max(tiles_p, ((np + nb + 63) / 64) * ((np + 3) / 4));
+      tiles_u = std::max(tiles_u, ((np + 63) / 64) * ((nb + 3) / 4));
+    }
+    if (tiles_p > 0 && b1 > b0)
+      hipLaunchKernelGGL(compact_kernel, dim3((unsigned)tiles_p, (unsigned)(b1 - b0)), dim3(256), 0, s,
+                         F.level_lists[(size_t)d].get() + b0, F.view, 0);
+    if (tiles_u > 0 && b1 > b0)
+      hipLaunchKernelGGL(compact_kernel, dim3((unsigned)tiles_u, (unsigned)(b1 - b0)), dim3(256), 0, s,
+                         F.level_lists[(size_t)d].get() + b0, F.view, 1);
   };
   // levels dbot .. dtop (bottom-up) of the fronts with ids lo..hi.  children_saved: the children of
   // level plan.cut - 1 are subtree roots, already compacted, their Schur complements in the cut buffer
