@@ -19,12 +19,16 @@
 #include <algorithm>
 #include <atomic>
 #include <future>
+#include <thread>
 #include <vector>
 
 namespace spl {
 namespace mf {
 
 constexpr int kBlock = 64;  // pivot block of the dense kernels (NB of band_nopiv.hip)
+// regions up to this size start their level structure from the end vertex their parent hands down
+// (one BFS instead of two); larger regions, whose separators carry the flops, search properly
+constexpr int kHintBelow = 40000;
 
 struct Tree {
   int n = 0, nfronts = 0, maxdepth = 0;
@@ -62,18 +66,20 @@ struct Node {
 };
 
 // State shared by all workers: the graph, the vertex array (workers own disjoint ranges of it) and
-// three per-vertex marks (a worker only touches the vertices of its own region).  Stamps come from
+// two per-vertex arrays (a worker only touches the vertices of its own region).  Stamps come from
 // one atomic counter so that they are unique across workers.
 struct Shared {
   int n;
   const std::vector<int64_t> &xadj;
   const std::vector<int> &adj;
   int leaf;
-  std::vector<int> verts, in_region, seen, level;
+  // mark[v] = stamp of the last thing that happened to v: put into a region (region stamp), or
+  // reached by a BFS (that BFS's stamp).  One word per vertex answers "in my region and not yet
+  // reached" during a traversal.
+  std::vector<int> verts, mark, level;
   std::atomic<int> stamp{0};
   Shared(int n_, const std::vector<int64_t> &xa, const std::vector<int> &ad, int leaf_)
-      : n(n_), xadj(xa), adj(ad), leaf(leaf_), verts((size_t)n_), in_region((size_t)n_, 0), seen((size_t)n_, 0),
-        level((size_t)n_, 0) {
+      : n(n_), xadj(xa), adj(ad), leaf(leaf_), verts((size_t)n_), mark((size_t)n_, 0), level((size_t)n_, 0) {
     for (int i = 0; i < n; ++i) verts[(size_t)i] = i;
   }
 };
@@ -85,13 +91,14 @@ struct Worker {
   int region_stamp = 0, bfs_stamp = 0;
   explicit Worker(Shared &s) : S(s) {}
 
-  // BFS inside the current region; fills queue (BFS order), level[], level_ptr; returns #reached
-  int bfs(int root) {
+  // BFS over the vertices whose mark is `accept`; they get this BFS's stamp.  Fills queue (BFS
+  // order), level[], level_ptr; returns #reached
+  int bfs(int root, int accept) {
     bfs_stamp = ++S.stamp;
     queue.clear();
     level_ptr.clear();
     queue.push_back(root);
-    S.seen[(size_t)root] = bfs_stamp;
+    S.mark[(size_t)root] = bfs_stamp;
     S.level[(size_t)root] = 0;
     level_ptr.push_back(0);
     size_t head = 0;
@@ -105,8 +112,8 @@ struct Worker {
       ++head;
       for (int64_t p = S.xadj[(size_t)v]; p < S.xadj[(size_t)v + 1]; ++p) {
         const int u = S.adj[(size_t)p];
-        if (S.in_region[(size_t)u] == region_stamp && S.seen[(size_t)u] != bfs_stamp) {
-          S.seen[(size_t)u] = bfs_stamp;
+        if (S.mark[(size_t)u] == accept) {
+          S.mark[(size_t)u] = bfs_stamp;
           S.level[(size_t)u] = cur + 1;
           queue.push_back(u);
         }
@@ -126,19 +133,20 @@ struct Worker {
   }
 
   // subtrees of the two vertex ranges, then `top` as their parent; large ranges get their own thread
-  std::vector<Node> join(int lo, int mid, int hi, Node &&top, int depth) {
+  // hint_l / hint_r: an extreme vertex of each side to start its level structure from (-1: none)
+  std::vector<Node> join(int lo, int mid, int hi, Node &&top, int depth, int hint_l = -1, int hint_r = -1) {
     std::vector<Node> left, right;
-    const bool fork = depth < 6 && mid - lo >= 50000 && hi - mid >= 50000;
+    const bool fork = depth < 8 && mid - lo >= 20000 && hi - mid >= 20000;
     if (fork) {
-      std::future<std::vector<Node>> other = std::async(std::launch::async, [this, lo, mid, depth] {
+      std::future<std::vector<Node>> other = std::async(std::launch::async, [this, lo, mid, depth, hint_l] {
         Worker w(S);
-        return w.dissect(lo, mid, depth + 1);
+        return w.dissect(lo, mid, depth + 1, hint_l);
       });
-      right = dissect(mid, hi, depth + 1);
+      right = dissect(mid, hi, depth + 1, hint_r);
       left = other.get();
     } else {
-      if (mid > lo) left = dissect(lo, mid, depth + 1);
-      if (hi > mid) right = dissect(mid, hi, depth + 1);
+      if (mid > lo) left = dissect(lo, mid, depth + 1, hint_l);
+      if (hi > mid) right = dissect(mid, hi, depth + 1, hint_r);
     }
     std::vector<Node> out;
     out.reserve(left.size() + right.size() + 1);
@@ -161,13 +169,22 @@ struct Worker {
     return out;
   }
 
-  std::vector<Node> dissect(int lo, int hi, int depth) {
+  // hint: a vertex of the region known to lie at one of its ends (the root or the deepest vertex of
+  // the parent's level structure): one BFS from it replaces the two of the pseudo-peripheral search
+  std::vector<Node> dissect(int lo, int hi, int depth, int hint = -1) {
     const int size = hi - lo;
     if (size <= S.leaf) return make_leaf(lo, hi);
     region_stamp = ++S.stamp;
-    for (int i = lo; i < hi; ++i) S.in_region[(size_t)S.verts[(size_t)i]] = region_stamp;
-    int reached = bfs(S.verts[(size_t)lo]);
-    if (reached == size) reached = bfs(queue.back());  // from the far end: deeper, narrower levels
+    for (int i = lo; i < hi; ++i) S.mark[(size_t)S.verts[(size_t)i]] = region_stamp;
+    int reached;
+    if (hint >= 0 && size <= kHintBelow && S.mark[(size_t)hint] == region_stamp) {
+      reached = bfs(hint, region_stamp);
+    } else {
+      reached = bfs(S.verts[(size_t)lo], region_stamp);
+      // connected: once more from the far end (deeper, narrower levels); every vertex now carries
+      // the first traversal's stamp
+      if (reached == size) reached = bfs(queue.back(), bfs_stamp);
+    }
     if (reached < size) {
       // disconnected region: no separator needed.  All components are found and dealt into two
       // groups of about equal size (largest first, each to the lighter group), so that a region
@@ -177,14 +194,12 @@ struct Worker {
       comp_verts.reserve((size_t)size);
       comp_verts.insert(comp_verts.end(), queue.begin(), queue.end());
       comp_ptr.push_back((int64_t)comp_verts.size());
-      for (int v : queue) S.in_region[(size_t)v] = 0;  // found vertices leave the region
-      for (int i = lo; i < hi; ++i) {
+      for (int i = lo; i < hi; ++i) {  // vertices not reached yet still carry the region stamp
         const int v = S.verts[(size_t)i];
-        if (S.in_region[(size_t)v] != region_stamp) continue;
-        bfs(v);
+        if (S.mark[(size_t)v] != region_stamp) continue;
+        bfs(v, region_stamp);
         comp_verts.insert(comp_verts.end(), queue.begin(), queue.end());
         comp_ptr.push_back((int64_t)comp_verts.size());
-        for (int u : queue) S.in_region[(size_t)u] = 0;
       }
       const int ncomp = (int)comp_ptr.size() - 1;
       std::vector<int> order((size_t)ncomp);
@@ -234,16 +249,17 @@ struct Worker {
       bool touches = false;
       for (int64_t p = S.xadj[(size_t)v]; p < S.xadj[(size_t)v + 1] && !touches; ++p) {
         const int u = S.adj[(size_t)p];
-        touches = S.in_region[(size_t)u] == region_stamp && S.level[(size_t)u] == t + 1;
+        touches = S.mark[(size_t)u] == bfs_stamp && S.level[(size_t)u] == t + 1;  // reached by this BFS
       }
       if (touches) top.piv.push_back(v); else side1.push_back(v);
     }
     std::copy(side1.begin(), side1.end(), S.verts.begin() + lo);
     std::copy(side2.begin(), side2.end(), S.verts.begin() + lo + (int)side1.size());
     const int n1 = (int)side1.size(), n2 = (int)side2.size();
+    const int end1 = queue.front(), end2 = queue.back();  // the two ends of this level structure
     std::vector<int>().swap(side1);
     std::vector<int>().swap(side2);
-    return join(lo, lo + n1, lo + n1 + n2, std::move(top), depth);
+    return join(lo, lo + n1, lo + n1 + n2, std::move(top), depth, end1, end2);
   }
 };
 
@@ -309,30 +325,54 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T) {
   for (int f = 0; f < nf; ++f) T.maxdepth = std::max(T.maxdepth, T.depth[(size_t)f]);
   T.by_depth.assign((size_t)T.maxdepth + 1, std::vector<int>());
   for (int f = 0; f < nf; ++f) T.by_depth[(size_t)T.depth[(size_t)f]].push_back(f);
-  // boundaries, bottom-up: later-eliminated neighbours of the pivots + what the children pass on
+  // boundaries, bottom-up: later-eliminated neighbours of the pivots + what the children pass on.
+  // The fronts of one tree level are independent (they only read their children's lists), so each
+  // level is shared out among threads; the lists are concatenated in front order afterwards.
   T.bptr.assign((size_t)nf + 1, 0);
-  std::vector<int> b;
-  for (int f = 0; f < nf; ++f) {
-    const detail::Node &nd = nodes[(size_t)f];
-    const int last = T.p0[(size_t)f] + T.np[(size_t)f];
-    b.clear();
-    for (int g = T.p0[(size_t)f]; g < last; ++g) {
-      const int v = T.perm[(size_t)g];
-      for (int64_t p = xadj[(size_t)v]; p < xadj[(size_t)v + 1]; ++p) {
-        const int h = T.inv[(size_t)adj[(size_t)p]];
-        if (h >= last) b.push_back(h);
+  {
+    std::vector<std::vector<int>> bnd((size_t)nf);
+    auto boundary_of = [&](int f) {
+      const detail::Node &nd = nodes[(size_t)f];
+      const int last = T.p0[(size_t)f] + T.np[(size_t)f];
+      std::vector<int> &b = bnd[(size_t)f];
+      for (int g = T.p0[(size_t)f]; g < last; ++g) {
+        const int v = T.perm[(size_t)g];
+        for (int64_t p = xadj[(size_t)v]; p < xadj[(size_t)v + 1]; ++p) {
+          const int h = T.inv[(size_t)adj[(size_t)p]];
+          if (h >= last) b.push_back(h);
+        }
       }
+      for (int c : {nd.left, nd.right}) {
+        if (c < 0) continue;
+        for (int h : bnd[(size_t)c])
+          if (h >= last) b.push_back(h);
+      }
+      std::sort(b.begin(), b.end());
+      b.erase(std::unique(b.begin(), b.end()), b.end());
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = (int)std::min<unsigned>(hw ? hw : 1, 32);
+    for (int d = T.maxdepth; d >= 0; --d) {
+      const std::vector<int> &L = T.by_depth[(size_t)d];
+      if (nthreads <= 1 || L.size() < 64) {
+        for (int f : L) boundary_of(f);
+        continue;
+      }
+      std::atomic<size_t> next_item{0};
+      std::vector<std::thread> pool;
+      for (int w = 0; w < nthreads; ++w)
+        pool.emplace_back([&] {
+          for (size_t i = next_item.fetch_add(16); i < L.size(); i = next_item.fetch_add(16))
+            for (size_t k = i; k < std::min(i + 16, L.size()); ++k) boundary_of(L[k]);
+        });
+      for (std::thread &th : pool) th.join();
     }
-    for (int c : {nd.left, nd.right}) {
-      if (c < 0) continue;
-      for (int64_t q = T.bptr[(size_t)c]; q < T.bptr[(size_t)c + 1]; ++q)
-        if (T.bidx[(size_t)q] >= last) b.push_back(T.bidx[(size_t)q]);
+    for (int f = 0; f < nf; ++f) {
+      T.nb[(size_t)f] = (int)bnd[(size_t)f].size();
+      T.bptr[(size_t)f + 1] = T.bptr[(size_t)f] + (int64_t)bnd[(size_t)f].size();
     }
-    std::sort(b.begin(), b.end());
-    b.erase(std::unique(b.begin(), b.end()), b.end());
-    T.bidx.insert(T.bidx.end(), b.begin(), b.end());
-    T.nb[(size_t)f] = (int)b.size();
-    T.bptr[(size_t)f + 1] = (int64_t)T.bidx.size();
+    T.bidx.resize((size_t)T.bptr[(size_t)nf]);
+    for (int f = 0; f < nf; ++f) std::copy(bnd[(size_t)f].begin(), bnd[(size_t)f].end(), T.bidx.begin() + T.bptr[(size_t)f]);
   }
   // storage layout and work estimate
   T.ld.assign((size_t)nf, 0);

@@ -25,6 +25,7 @@
 #include <stdio.h>
 #include <algorithm>
 #include <atomic>
+#include <future>
 #include <mutex>
 #include <vector>
 
@@ -545,34 +546,46 @@ int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
     S->n = n_col;
     S->nnz = Ap[n_col];
     S->Ap.assign(Ap, Ap + n_col + 1);
-    rcm_order(S->n, Ap, Ai, S->perm);
-    S->inv.assign((size_t)S->n, 0);
-    for (int k = 0; k < S->n; ++k) S->inv[(size_t)S->perm[(size_t)k]] = k;
-    int kl = 0, ku = 0;
-    for (int j = 0; j < S->n; ++j) {
-      const int nj = S->inv[(size_t)j];
-      for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
-        const int ni = S->inv[(size_t)Ai[p]];
-        kl = std::max(kl, ni - nj);
-        ku = std::max(ku, nj - ni);
-      }
-    }
-    S->kl = kl;
-    S->ku = ku;
+    // The two orderings are independent host work: for anything that is not tiny the nested
+    // dissection runs on its own thread(s) while this one does the band ordering.
     // Multifrontal or band?  The band factorisation costs about 2 n kl ku flops and n (kl+ku+1)
     // entries; nested dissection is far cheaper on 2-D / 3-D meshes and no better on narrow bands.
     // SPL_LU_METHOD=mf / band forces the choice (tests).
-    {
-      const char *method = getenv("SPL_LU_METHOD");
-      const bool force_mf = method && method[0] == 'm', force_band = method && method[0] == 'b';
-      const double band_flops = 2.0 * S->n * (double)kl * (double)ku;
-      if (!force_band && (force_mf || (S->n >= 4096 && band_flops > 1e9))) {
+    const char *method = getenv("SPL_LU_METHOD");
+    const bool force_mf = method && method[0] == 'm', force_band = method && method[0] == 'b';
+    const int n = S->n;
+    std::future<std::shared_ptr<mf::Tree>> tree_job;
+    if (!force_band && (force_mf || n >= 4096))
+      tree_job = std::async(std::launch::async, [n, Ap, Ai] {
         std::shared_ptr<mf::Tree> T = std::make_shared<mf::Tree>();
-        mf::build_tree(S->n, Ap, Ai, 256, *T);
-        // measured: the tree wins from about 10x fewer flops on (many small fronts run below the
-        // MFMA rate of the band's large windows; 32^3 Poisson is the break-even)
-        if (force_mf || 10.0 * T->flops < band_flops) S->tree = T;
+        mf::build_tree(n, Ap, Ai, 256, *T);
+        return T;
+      });
+    try {
+      rcm_order(S->n, Ap, Ai, S->perm);
+      S->inv.assign((size_t)S->n, 0);
+      for (int k = 0; k < S->n; ++k) S->inv[(size_t)S->perm[(size_t)k]] = k;
+      int kl = 0, ku = 0;
+      for (int j = 0; j < S->n; ++j) {
+        const int nj = S->inv[(size_t)j];
+        for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
+          const int ni = S->inv[(size_t)Ai[p]];
+          kl = std::max(kl, ni - nj);
+          ku = std::max(ku, nj - ni);
+        }
       }
+      S->kl = kl;
+      S->ku = ku;
+    } catch (...) {
+      if (tree_job.valid()) tree_job.wait();  // Ap / Ai are borrowed: nobody may outlive this call
+      throw;
+    }
+    if (tree_job.valid()) {
+      std::shared_ptr<mf::Tree> T = tree_job.get();
+      const double band_flops = 2.0 * S->n * (double)S->kl * (double)S->ku;
+      // measured: the tree wins from about 10x fewer flops on (many small fronts run below the
+      // MFMA rate of the band's large windows; 32^3 Poisson is the break-even)
+      if (force_mf || (band_flops > 1e9 && 10.0 * T->flops < band_flops)) S->tree = T;
     }
     *SymbolicOut = S;
     return UMFPACK_OK;

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--grid", default="16,24,32")
     ap.add_argument("--cpu-max", type=int, default=32, help="largest m for the SuperLU stand-in")
     ap.add_argument("--nrhs", type=int, default=0, help="also time a batched solve of this many right-hand sides")
+    ap.add_argument("--dim", type=int, default=3, choices=[2, 3], help="3: m^3 grid, 7-point; 2: m^2 grid, 5-point")
     args = ap.parse_args()
     import numpy as np
     import scipy.sparse as sp
@@ -33,8 +34,8 @@ def main():
     W = pkg.Matrix(512, 512, rp, ci, v)
     U.linearSolve_(U.factor(W, U.analyze(W)), U.UmfpackNormal, W, np.ones(512))
     for m in [int(t) for t in args.grid.split(",")]:
-        n = m ** 3
-        rp, ci, v = O.gen_poisson3d_csr(m)
+        n = m ** args.dim
+        rp, ci, v = O.gen_poisson3d_csr(m) if args.dim == 3 else O.gen_poisson2d_csr(m)
         A = pkg.Matrix(n, n, rp, ci, v)  # symmetric: CSR arrays == CSC arrays
         xs = O.gen_vector(n)
         S = sp.csc_matrix((v, ci, rp), shape=(n, n))
@@ -44,7 +45,7 @@ def main():
         x = U.linearSolve_(fa, U.UmfpackNormal, A, b); torch.cuda.synchronize(); t3 = time.perf_counter()
         err = float(np.max(np.abs(x - xs) / np.abs(xs)))
         res = float(np.max(np.abs(S @ x - b)) / (np.max(np.abs(b)) + 6 * np.max(np.abs(x))))
-        out = {"metric": "sparse LU factor+solve seconds", "m": m, "n": n, "nnz": int(rp[-1]),
+        out = {"metric": "sparse LU factor+solve seconds", "dim": args.dim, "m": m, "n": n, "nnz": int(rp[-1]),
                "gpu": {"analyze_s": round(t1 - t0, 3), "factor_s": round(t2 - t1, 3), "solve_s": round(t3 - t2, 3),
                        "total_s": round(t3 - t0, 3)},
                "max_rel_err_vs_manufactured": err, "scaled_residual": res, "within_1e-10": bool(err < 1e-10)}
