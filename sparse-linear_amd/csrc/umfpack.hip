@@ -583,9 +583,9 @@ int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
     if (tree_job.valid()) {
       std::shared_ptr<mf::Tree> T = tree_job.get();
       const double band_flops = 2.0 * S->n * (double)S->kl * (double)S->ku;
-      // measured: the tree wins from about 10x fewer flops on (many small fronts run below the
+      // measured: the tree wins from about 7x fewer flops on (many small fronts run below the
       // MFMA rate of the band's large windows; 32^3 Poisson is the break-even)
-      if (force_mf || (band_flops > 1e9 && 10.0 * T->flops < band_flops)) S->tree = T;
+      if (force_mf || (band_flops > 1e9 && 7.0 * T->flops < band_flops)) S->tree = T;
     }
     *SymbolicOut = S;
     return UMFPACK_OK;
