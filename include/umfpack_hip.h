@@ -32,7 +32,8 @@
  * A speculation is checked by every solve: unless the refined solution is backward stable to
  * rounding level (componentwise backward error <= 1e-13), the object is refactored with partial
  * pivoting and the system solved again, so the caller sees pivoted-LU accuracy either way.
- * SPL_LU_METHOD=band|mf forces the ordering.  Square matrices only (the reference's linearSolve_
+ * (A fallback whose band does not fit the HBM — a failed speculation on a large mesh — returns
+ * UMFPACK_ERROR_out_of_memory from solve.)  SPL_LU_METHOD=band|mf forces the ordering.  Square matrices only (the reference's linearSolve_
  * assumes square, Umfpack.hs:93).
  * The complex (`zi`) entry points (Internal.hs:69-115) are served through the real 2n x 2n
  * embedding with interleaved unknowns (csrc/umfpack_zi.hip): packed complex arrays (imaginary
