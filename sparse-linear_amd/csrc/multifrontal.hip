@@ -92,21 +92,47 @@ __global__ __launch_bounds__(256) void rel_kernel(int nfronts, TreeView t, int *
   for (int k = threadIdx.x; k < t.nb[c]; k += blockDim.x) rel[t.roff[c] + k] = local_pos(t, p, b[k]);
 }
 
-// parent += Schur complement of the listed children; blockIdx.y = child, a workgroup moves a tile of
-// 64 rows x 4 columns (lanes run down the rows: contiguous in the child, nearly so in the parent)
-__global__ __launch_bounds__(256) void extend_add_kernel(const int *__restrict__ children, TreeView t) {
-  const int c = children[blockIdx.y];
+// Tile-to-item lookup of the flat grids below: items [0, count) own the tiles
+// [prefix[i], prefix[i+1]); returns the item of tile `flat` (prefix[0] <= flat < prefix[count]).
+__device__ __forceinline__ int item_of_tile(const int64_t *__restrict__ prefix, int count, int64_t flat) {
+  int lo = 0, hi = count - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (prefix[mid] <= flat) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+constexpr int kTileCols = 16;  // a workgroup moves 64 rows x 16 columns: 4 columns per thread
+
+// parent += Schur complement of the listed children.  Flat 1-D grid over the 64 x 16 tiles of all
+// children (prefix = tiles before each child): no workgroup is launched for nothing, whatever the
+// mix of sizes.  Lanes run down the rows: contiguous in the child, nearly so in the parent.
+__global__ __launch_bounds__(256) void extend_add_kernel(const int *__restrict__ children,
+                                                         const int64_t *__restrict__ prefix, int count,
+                                                         TreeView t) {
+  const int64_t flat = prefix[0] + blockIdx.x;
+  const int ci = item_of_tile(prefix, count, flat);
+  const int c = children[ci];
   const int nb = t.nb[c];
-  const int ntr = (nb + 63) >> 6, ntc = (nb + 3) >> 2;
-  if ((int64_t)blockIdx.x >= (int64_t)ntr * ntc) return;
-  const int r = (int)(blockIdx.x % ntr) * 64 + (threadIdx.x & 63), cc = (int)(blockIdx.x / ntr) * 4 + (threadIdx.x >> 6);
-  if (r >= nb || cc >= nb) return;
+  const int ntr = (nb + 63) >> 6;
+  const int64_t tile = flat - prefix[ci];
+  const int r = (int)(tile % ntr) * 64 + (threadIdx.x & 63);
+  const int cc0 = (int)(tile / ntr) * kTileCols + (threadIdx.x >> 6) * 4;
+  if (r >= nb) return;
   const int p = t.parent[c], npc = t.np[c];
   const int *rel = t.rel + t.roff[c];
   const int64_t saved = t.cboff[c];
-  const double v = saved >= 0 ? t.cut[saved + (int64_t)r + (int64_t)cc * nb]
-                              : t.front(c)[(int64_t)(npc + r) + (int64_t)(npc + cc) * t.ld[c]];
-  t.front(p)[(int64_t)rel[r] + (int64_t)rel[cc] * t.ld[p]] += v;
+  double *dst = t.front(p) + rel[r];
+  const int64_t ldp = t.ld[p];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int cc = cc0 + u;
+    if (cc >= nb) break;
+    const double v = saved >= 0 ? t.cut[saved + (int64_t)r + (int64_t)cc * nb]
+                                : t.front(c)[(int64_t)(npc + r) + (int64_t)(npc + cc) * t.ld[c]];
+    dst[(int64_t)rel[cc] * ldp] += v;
+  }
 }
 
 // Schur complement of a finished front -> the cut buffer (its parent is assembled much later)
@@ -118,20 +144,30 @@ __global__ __launch_bounds__(256) void save_cb_kernel(int f, TreeView t) {
   t.cut[t.cboff[f] + (int64_t)r + (int64_t)cc * nb] = t.front(f)[(int64_t)(np + r) + (int64_t)(np + cc) * t.ld[f]];
 }
 
-// factor panels of the listed (finished) fronts -> arena; blockIdx.y = front, 64 x 4 tiles over the
-// panel only: which = 0: P = columns [0, np) (fs rows); which = 1: U = rows [0, np) of the other columns
-__global__ __launch_bounds__(256) void compact_kernel(const int *__restrict__ list, TreeView t, int which) {
-  const int f = list[blockIdx.y];
+// factor panels of the listed (finished) fronts -> arena, flat grid over the 64 x 16 tiles of the
+// panels: which = 0: P = columns [0, np) (fs rows); which = 1: U = rows [0, np) of the other columns
+__global__ __launch_bounds__(256) void compact_kernel(const int *__restrict__ list,
+                                                      const int64_t *__restrict__ prefix, int count, TreeView t,
+                                                      int which) {
+  const int64_t flat = prefix[0] + blockIdx.x;
+  const int fi = item_of_tile(prefix, count, flat);
+  const int f = list[fi];
   const int np = t.np[f], nb = t.nb[f], fs = np + nb;
   const int rows = which == 0 ? fs : np, cols = which == 0 ? np : nb;
-  const int ntr = (rows + 63) >> 6, ntc = (cols + 3) >> 2;
-  if ((int64_t)blockIdx.x >= (int64_t)ntr * ntc) return;
-  const int i = (int)(blockIdx.x % ntr) * 64 + (threadIdx.x & 63), j = (int)(blockIdx.x / ntr) * 4 + (threadIdx.x >> 6);
-  if (i >= rows || j >= cols) return;
-  if (which == 0)
-    t.arena[t.poff[f] + (int64_t)i + (int64_t)j * t.ldp[f]] = t.front(f)[(int64_t)i + (int64_t)j * t.ld[f]];
-  else
-    t.arena[t.uoff[f] + (int64_t)i + (int64_t)j * t.ldu[f]] = t.front(f)[(int64_t)i + (int64_t)(np + j) * t.ld[f]];
+  const int ntr = (rows + 63) >> 6;
+  const int64_t tile = flat - prefix[fi];
+  const int i = (int)(tile % ntr) * 64 + (threadIdx.x & 63);
+  const int j0 = (int)(tile / ntr) * kTileCols + (threadIdx.x >> 6) * 4;
+  if (i >= rows) return;
+  const double *src = t.front(f) + i;
+  const int64_t ld = t.ld[f];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int j = j0 + u;
+    if (j >= cols) break;
+    if (which == 0) t.arena[t.poff[f] + (int64_t)i + (int64_t)j * t.ldp[f]] = src[(int64_t)j * ld];
+    else t.arena[t.uoff[f] + (int64_t)i + (int64_t)j * t.ldu[f]] = src[(int64_t)(np + j) * ld];
+  }
 }
 
 // small fronts of a tree level: one workgroup per front runs the whole partial factorisation
@@ -491,6 +527,10 @@ struct Factors {
   std::vector<DBuf<int>> child_lists[2];             // children (by slot) of the fronts of each depth
   std::vector<int> child_counts[2];
   std::vector<std::vector<int>> h_small, h_child[2];  // host copies (ascending ids) of small_lists / child_lists
+  // tiles (64 x 16) before each item of child_lists (Schur complements) and of level_lists (P and
+  // U panels): the flat grids of extend-add and compaction
+  std::vector<std::vector<int64_t>> h_ctile[2], h_ptile, h_utile;
+  std::vector<DBuf<int64_t>> ctile[2], ptile, utile;
   int singular = 0;
 };
 
@@ -669,6 +709,34 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
       }
     }
   }
+  {
+    auto tiles = [](int64_t rows, int64_t cols) { return ((rows + 63) / 64) * ((cols + kTileCols - 1) / kTileCols); };
+    F.h_ptile.assign((size_t)nd, std::vector<int64_t>());
+    F.h_utile.assign((size_t)nd, std::vector<int64_t>());
+    F.ptile.resize((size_t)nd);
+    F.utile.resize((size_t)nd);
+    for (int sl = 0; sl < 2; ++sl) {
+      F.h_ctile[sl].assign((size_t)nd, std::vector<int64_t>());
+      F.ctile[sl].resize((size_t)nd);
+    }
+    for (int d = 0; d < nd; ++d) {
+      std::vector<int64_t> &pp = F.h_ptile[(size_t)d], &uu = F.h_utile[(size_t)d];
+      pp.assign(1, 0);
+      uu.assign(1, 0);
+      for (int f : T.by_depth[(size_t)d]) {
+        pp.push_back(pp.back() + tiles(T.fs(f), T.np[(size_t)f]));
+        uu.push_back(uu.back() + tiles(T.np[(size_t)f], T.nb[(size_t)f]));
+      }
+      upload_vec(F.ptile[(size_t)d], pp, s);
+      upload_vec(F.utile[(size_t)d], uu, s);
+      for (int sl = 0; sl < 2; ++sl) {
+        std::vector<int64_t> &cc = F.h_ctile[sl][(size_t)d];
+        cc.assign(1, 0);
+        for (int c : F.h_child[sl][(size_t)d]) cc.push_back(cc.back() + tiles(T.nb[(size_t)c], T.nb[(size_t)c]));
+        upload_vec(F.ctile[sl][(size_t)d], cc, s);
+      }
+    }
+  }
   SPL_HIP(hipStreamSynchronize(s));
   staged.clear();
   lap("uploads + hipMalloc");
@@ -693,19 +761,15 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   auto compact_fronts = [&](int d, int lo, int hi) {  // factor panels of the fronts lo..hi of level d -> arena
     int b0, b1;
     range_of(T.by_depth[(size_t)d], lo, hi, b0, b1);
-    int64_t tiles_p = 0, tiles_u = 0;
-    for (int i = b0; i < b1; ++i) {
-      const int f = T.by_depth[(size_t)d][(size_t)i];
-      const int64_t np = T.np[(size_t)f], nb = T.nb[(size_t)f];
-      tiles_p = std::max(tiles_p, ((np + nb + 63) / 64) * ((np + 3) / 4));
-      tiles_u = std::max(tiles_u, ((np + 63) / 64) * ((nb + 3) / 4));
-    }
-    if (tiles_p > 0 && b1 > b0)
-      hipLaunchKernelGGL(compact_kernel, dim3((unsigned)tiles_p, (unsigned)(b1 - b0)), dim3(256), 0, s,
-                         F.level_lists[(size_t)d].get() + b0, F.view, 0);
-    if (tiles_u > 0 && b1 > b0)
-      hipLaunchKernelGGL(compact_kernel, dim3((unsigned)tiles_u, (unsigned)(b1 - b0)), dim3(256), 0, s,
-                         F.level_lists[(size_t)d].get() + b0, F.view, 1);
+    if (b1 == b0) return;
+    const int64_t tp = F.h_ptile[(size_t)d][(size_t)b1] - F.h_ptile[(size_t)d][(size_t)b0];
+    const int64_t tu = F.h_utile[(size_t)d][(size_t)b1] - F.h_utile[(size_t)d][(size_t)b0];
+    if (tp > 0)
+      hipLaunchKernelGGL(compact_kernel, dim3((unsigned)tp), dim3(256), 0, s, F.level_lists[(size_t)d].get() + b0,
+                         F.ptile[(size_t)d].get() + b0, b1 - b0, F.view, 0);
+    if (tu > 0)
+      hipLaunchKernelGGL(compact_kernel, dim3((unsigned)tu), dim3(256), 0, s, F.level_lists[(size_t)d].get() + b0,
+                         F.utile[(size_t)d].get() + b0, b1 - b0, F.view, 1);
   };
   // levels dbot .. dtop (bottom-up) of the fronts with ids lo..hi.  children_saved: the children of
   // level plan.cut - 1 are subtree roots, already compacted, their Schur complements in the cut buffer
@@ -729,12 +793,12 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
         for (int sl = 0; sl < 2; ++sl) {
           int c0, c1;
           range_of(F.h_child[sl][(size_t)d], lo, hi, c0, c1);
-          int max_nb = 0;
-          for (int i = c0; i < c1; ++i) max_nb = std::max(max_nb, T.nb[(size_t)F.h_child[sl][(size_t)d][(size_t)i]]);
-          const int64_t ntile = (int64_t)((max_nb + 63) / 64) * ((max_nb + 3) / 4);
-          if (c1 > c0 && ntile > 0)
-            hipLaunchKernelGGL(extend_add_kernel, dim3((unsigned)ntile, (unsigned)(c1 - c0)), dim3(256), 0, s,
-                               F.child_lists[sl][(size_t)d].get() + c0, F.view);
+          if (c1 == c0) continue;
+          const int64_t tc = F.h_ctile[sl][(size_t)d][(size_t)c1] - F.h_ctile[sl][(size_t)d][(size_t)c0];
+          if (tc > 0)
+            hipLaunchKernelGGL(extend_add_kernel, dim3((unsigned)tc), dim3(256), 0, s,
+                               F.child_lists[sl][(size_t)d].get() + c0, F.ctile[sl][(size_t)d].get() + c0, c1 - c0,
+                               F.view);
         }
         // the children are done with: keep their panels, their region is free again (subtree
         // roots were compacted when their subtree finished)
