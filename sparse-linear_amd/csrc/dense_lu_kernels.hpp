@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256) void trsm_gemm_kernel(Band b, int j0, int jb, 
 
 // Trailing update  A(rows, cols) -= L(rows, kb .. kb+klen) * U(kb .. kb+klen, cols)  on 64 x 64
 // tiles of the region rows [rb, re) x columns [cb, ce), rb == cb on the diagonal.  K is staged
-// through LDS in slices of KS = 32 (34 KB per workgroup, 4 workgroups per CU); klen is 64 for a
+// through LDS in slices of KS = 32, software-pipelined through registers (the loads of the next
+// slice are in flight during the MFMAs of this one; 2 workgroups per CU); klen is 64 for a
 // single block step and 128 when two block steps share one pass over the window, which halves
 // the read-modify-write traffic of the window.  Entries outside the band read as zero and are
 // never written.
@@ -295,17 +296,32 @@ __device__ __forceinline__ void update_tile(const Band &b, const Region &g, int 
       }
   double4v acc[2][2];
   zero_acc(acc);
+  // K slices are software-pipelined through registers: the global loads of slice s+1 are issued
+  // before the MFMAs of slice s, so their latency hides behind the matrix cores inside the
+  // workgroup (each thread carries 8 + 8 operands)
+  constexpr int PER = KS * 64 / 256;
+  double el[PER], eu[PER];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int t = tid + u * 256;
+      const int r = t % 64, k = t / 64;
+      el[u] = (k0 + k < g.klen && r0 + r < g.re) ? b.get(r0 + r, g.kb + k0 + k) : 0.0;
+      const int k2 = t % KS, c = t / KS;
+      eu[u] = (k0 + k2 < g.klen && c0 + c < g.ce) ? b.get(g.kb + k0 + k2, c0 + c) : 0.0;
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < g.klen; k0 += KS) {
     if (k0) __syncthreads();
-    for (int t = tid; t < KS * 64; t += 256) {
-      const int r = t % 64, k = t / 64;
-      Ls[k][r] = (k0 + k < g.klen && r0 + r < g.re) ? b.get(r0 + r, g.kb + k0 + k) : 0.0;
-    }
-    for (int t = tid; t < KS * 64; t += 256) {
-      const int k = t % KS, c = t / KS;
-      Us[k][c] = (k0 + k < g.klen && c0 + c < g.ce) ? b.get(g.kb + k0 + k, c0 + c) : 0.0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int t = tid + u * 256;
+      Ls[t / 64][t % 64] = el[u];
+      Us[t % KS][t / KS] = eu[u];
     }
     __syncthreads();
+    if (k0 + KS < g.klen) fetch(k0 + KS);
     mfma_tile_64<KS>(Us, Ls, p, acc);
   }
 #pragma unroll
