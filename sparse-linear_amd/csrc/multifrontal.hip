@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void front_gemv_kernel(const double *__restric
       for (int r = 0; r < NR; ++r)
         z[(size_t)r * fs + i] -= (part[0][lane][r] + part[1][lane][r]) + (part[2][lane][r] + part[3][lane][r]);
   } else {
-    constexpr int RW = NR == 1 ? 4 : 1;  // rows of the chunk per wavefront and trip
+    constexpr int RW = NR == 1 ? 16 : 2;  // rows of the chunk per wavefront and trip (= loads in flight)
     for (int rr = wave * RW; rr < 64; rr += 4 * RW) {
       double acc[RW][NR];
 #pragma unroll
@@ -455,12 +455,15 @@ __global__ __launch_bounds__(256) void front_gemv_kernel(const double *__restric
 #pragma unroll
         for (int r = 0; r < NR; ++r) acc[u][r] = 0.0;
       for (int k = lane; k < nb; k += 64) {
+        double e[RW];
 #pragma unroll
-        for (int u = 0; u < RW; ++u) {
-          if (i0 + rr + u >= np) continue;
-          const double e = P[(size_t)(np + k) + (size_t)(i0 + rr + u) * ldp];
+        for (int u = 0; u < RW; ++u)
+          e[u] = i0 + rr + u < np ? P[(size_t)(np + k) + (size_t)(i0 + rr + u) * ldp] : 0.0;
 #pragma unroll
-          for (int r = 0; r < NR; ++r) acc[u][r] += e * xb[(size_t)r * fs + k];
+        for (int r = 0; r < NR; ++r) {
+          const double xk = xb[(size_t)r * fs + k];
+#pragma unroll
+          for (int u = 0; u < RW; ++u) acc[u][r] += e[u] * xk;
         }
       }
 #pragma unroll
