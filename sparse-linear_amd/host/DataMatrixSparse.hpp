@@ -14,6 +14,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <algorithm>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -192,6 +193,24 @@ inline Matrix lin(double alpha, const Matrix &a, double beta, const Matrix &b) {
 inline Matrix operator+(const Matrix &a, const Matrix &b) { return lin(1.0, a, 1.0, b); }
 inline Matrix operator-(const Matrix &a, const Matrix &b) { return lin(1.0, a, -1.0, b); }
 
+// kronecker (Sparse.hs:597-634)
+inline Matrix kronecker(const Matrix &a, const Matrix &b) {
+  detail::Const ca(a), cb(b);
+  int nr = 0, nc = 0, *cp = nullptr, *ci = nullptr;
+  double *cx = nullptr;
+  detail::check("kronecker", spl_kronecker(ca.nrows, ca.ncols, ca.p.data(), ca.i.data(), ca.x, cb.nrows, cb.ncols,
+                                           cb.p.data(), cb.i.data(), cb.x, &nr, &nc, &cp, &ci, &cx));
+  return detail::adopt(nr, nc, cp, ci, cx);
+}
+
+// takeDiag (Sparse.hs:636-648)
+inline std::vector<double> takeDiag(const Matrix &a) {
+  detail::Const ca(a);
+  std::vector<double> d((size_t)std::min(a.nrows, a.ncols), 0.0);
+  detail::check("takeDiag", spl_take_diag(ca.nrows, ca.ncols, ca.p.data(), ca.i.data(), ca.x, d.data()));
+  return d;
+}
+
 }}}  // namespace Data::Matrix::Sparse
 
 namespace Numeric { namespace LinearAlgebra { namespace Umfpack {
@@ -239,11 +258,28 @@ inline std::vector<double> linearSolve_(const Factors &fact, UmfpackMode mode, c
   return soln;
 }
 
+// map (linearSolve_ fact mode mat) bs (Umfpack.hs:103-108) in one pass of all right-hand sides
+// through the factors (spl_umfpack_di_solve_many)
+inline std::vector<std::vector<double>> linearSolveMany_(const Factors &fact, UmfpackMode mode, const Matrix &mat,
+                                                         const std::vector<std::vector<double>> &bs) {
+  detail::Const c(mat);
+  const size_t k = bs.size(), n = (size_t)mat.ncols;
+  std::vector<double> B(k * (size_t)mat.nrows), X(k * n, 0.0);
+  for (size_t j = 0; j < k; ++j) {
+    if (bs[j].size() != (size_t)mat.nrows) detail::oops("linearSolveMany_", "right-hand side of the wrong length");
+    std::copy(bs[j].begin(), bs[j].end(), B.begin() + j * (size_t)mat.nrows);
+  }
+  const int st = spl_umfpack_di_solve_many((int)mode, c.p.data(), c.i.data(), c.x, (int)k, X.data(), B.data(), *fact.fnum);
+  umfpack_di_report_status(nullptr, st);
+  if (st < 0) detail::oops("linearSolveMany_", "umfpack_solve failed");
+  std::vector<std::vector<double>> xs(k);
+  for (size_t j = 0; j < k; ++j) xs[j].assign(X.begin() + j * n, X.begin() + (j + 1) * n);
+  return xs;
+}
+
 inline std::vector<std::vector<double>> linearSolve(const Matrix &mat, const std::vector<std::vector<double>> &bs) {
   const Factors fact = factor(mat, analyze(mat));  // Umfpack.hs:38-46
-  std::vector<std::vector<double>> xs;
-  for (const auto &b : bs) xs.push_back(linearSolve_(fact, UmfpackNormal, mat, b));
-  return xs;
+  return linearSolveMany_(fact, UmfpackNormal, mat, bs);
 }
 
 // (<\>) (Umfpack.hs:48-50)

@@ -105,6 +105,34 @@ int main() {
     for (size_t k = 0; k < v.size(); ++k) rel = std::fmax(rel, std::fabs(x[k] - v[k]) / std::fabs(v[k] + x[k]));
     EXPECT(rel < 1e-10);  // closeness predicate of feast/tests/test-feast.hs:17-19
   }
+  // the reference's own construction of that matrix: kronecker (ident n) T + kronecker T (ident n);
+  // takeDiag; several right-hand sides in one batched solve
+  {
+    const Int n = 30;
+    std::vector<std::tuple<Int, Int, double>> t;
+    for (Int i = 0; i < n; ++i) {
+      t.emplace_back(i, i, 2.0);
+      if (i > 0) t.emplace_back(i, i - 1, -1.0);
+      if (i + 1 < n) t.emplace_back(i, i + 1, -1.0);
+    }
+    Matrix T = fromTriples(n, n, t);
+    Matrix A = kronecker(ident(n), T) + kronecker(T, ident(n));
+    EXPECT(A.nrows == n * n && nonZero(A) == 5 * n * n - 4 * n);
+    EXPECT(takeDiag(A) == std::vector<double>((size_t)(n * n), 4.0));
+    EXPECT(kronecker(ident(3), ident(4)) == ident(12));
+    std::vector<std::vector<double>> xs, bs;
+    for (int j = 0; j < 3; ++j) {
+      std::vector<double> x((size_t)(n * n));
+      for (size_t k = 0; k < x.size(); ++k) x[k] = 1.0 + 0.001 * (double)((k * (size_t)(j + 7)) % 97);
+      xs.push_back(x);
+      bs.push_back(mulV(A, x));
+    }
+    std::vector<std::vector<double>> got = U::linearSolve(A, bs);
+    double rel = 0;
+    for (size_t j = 0; j < xs.size(); ++j)
+      for (size_t k = 0; k < xs[j].size(); ++k) rel = std::fmax(rel, std::fabs(got[j][k] - xs[j][k]) / std::fabs(xs[j][k]));
+    EXPECT(rel < 1e-10);
+  }
   // ident <\> v == v, exactly (suitesparse/tests/test-umfpack.hs:16-19)
   {
     std::vector<double> v{3.5, -1.25, 1e6, 0.0, 7.0};
