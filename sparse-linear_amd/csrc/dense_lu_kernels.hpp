@@ -281,19 +281,40 @@ __device__ __forceinline__ void update_tile(const Band &b, const Region &g, int 
   double(*Us)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);            // Us[k][c] = U(kb + k, c0 + c)
   double(*Ls)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + KS * LDP);  // Ls[k][r] = L(r0 + r, kb + k)
   const int tid = threadIdx.x;
+  // Interior tile: the tile of A22 and both operand panels lie wholly inside the update range, the
+  // matrix and the band, and K is a whole number of slices.  Then nothing is predicated and every
+  // address is a pointer plus a constant stride (the predicated form spends more VALU cycles on
+  // addresses and masks than the matrix cores spend on the products).
+  const int klast = g.kb + g.klen - 1;
+  const bool interior = r0 + 64 <= g.re && c0 + 64 <= g.ce && g.klen % KS == 0 &&            // range
+                        r0 + 63 - c0 <= b.kl && c0 + 63 - r0 <= b.ku &&                        // C in band
+                        r0 + 63 - g.kb <= b.kl && klast - r0 <= b.ku &&                        // L panel in band
+                        klast - c0 <= b.kl && c0 + 63 - g.kb <= b.ku;                          // U panel in band
+  const size_t cs = (size_t)(b.ldab - 1);  // column stride
   // the tile of A22 is requested first, so that its HBM latency overlaps the staging and the MFMAs
   // (entries outside this step's update range get a zero product; tile (0,0) needs them below)
   const TilePos p;
   double cold[2][2][4];
+  if (interior) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < 2; ++c) {
+        const double *src = &b.at(r0 + p.row(c), c0 + p.col(a, 0));
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = r0 + p.row(c), j = c0 + p.col(a, r);
-        cold[a][c][r] = (i < b.n && j < b.n && b.in_band(i, j)) ? b.at(i, j) : 0.0;  // also beyond re/ce
+        for (int r = 0; r < 4; ++r) cold[a][c][r] = src[(size_t)(4 * r) * cs];  // col(a, r) = col(a, 0) + 4 r
       }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = r0 + p.row(c), j = c0 + p.col(a, r);
+          cold[a][c][r] = (i < b.n && j < b.n && b.in_band(i, j)) ? b.at(i, j) : 0.0;  // also beyond re/ce
+        }
+  }
   double4v acc[2][2];
   zero_acc(acc);
   // K slices are software-pipelined through registers: the global loads of slice s+1 are issued
@@ -301,7 +322,18 @@ __device__ __forceinline__ void update_tile(const Band &b, const Region &g, int 
   // workgroup (each thread carries 8 + 8 operands)
   constexpr int PER = KS * 64 / 256;
   double el[PER], eu[PER];
+  // thread t stages L(r0 + t % 64, kb + k0 + t / 64 + 4 u) and U(kb + k0 + t % KS, c0 + t / KS + 8 u)
+  const double *lsrc = interior ? &b.at(r0 + tid % 64, g.kb + tid / 64) : nullptr;
+  const double *usrc = interior ? &b.at(g.kb + tid % KS, c0 + tid / KS) : nullptr;
   auto fetch = [&](int k0) {
+    if (interior) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        el[u] = lsrc[(size_t)(k0 + 4 * u) * cs];
+        eu[u] = usrc[(size_t)k0 + (size_t)(256 / KS * u) * cs];
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int t = tid + u * 256;
@@ -324,16 +356,30 @@ __device__ __forceinline__ void update_tile(const Band &b, const Region &g, int 
     if (k0 + KS < g.klen) fetch(k0 + KS);
     mfma_tile_64<KS>(Us, Ls, p, acc);
   }
+  if (interior) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < 2; ++c) {
+        double *dst = &b.at(r0 + p.row(c), c0 + p.col(a, 0));
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = r0 + p.row(c), j = c0 + p.col(a, r);
-        cold[a][c][r] -= acc[a][c][r];
-        if (i < g.re && j < g.ce && b.in_band(i, j)) b.at(i, j) = cold[a][c][r];
+        for (int r = 0; r < 4; ++r) {
+          cold[a][c][r] -= acc[a][c][r];
+          dst[(size_t)(4 * r) * cs] = cold[a][c][r];
+        }
       }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = r0 + p.row(c), j = c0 + p.col(a, r);
+          cold[a][c][r] -= acc[a][c][r];
+          if (i < g.re && j < g.ce && b.in_band(i, j)) b.at(i, j) = cold[a][c][r];
+        }
+  }
   if (!lookahead || tx != 0 || ty != 0 || r0 >= g.npiv) return;
   // next diagonal block: rows/columns r0 .. r0 + jbn - 1, values still in registers
   const int jbn = min(NB, g.npiv - r0);
