@@ -22,10 +22,10 @@
 // search — ALL products of the column are gathered from HBM at once (no dependent chain per
 // k); (2) the keys (row, t) — t = position in k-then-row order breaks ties, which keeps equal
 // rows in ascending-k order — are sorted in LDS: the products of one B entry are a column of
-// A, already ascending, so 32-bit keys go through a merge tree over these runs (merge-path);
-// 64-bit keys (more rows than 31 - log2 P bits) through a bitonic network with their values;
+// A, already ascending, so the keys go through a merge tree over these runs (merge-path): packed
+// (row << bits | t) in 32 bits when the rows fit, else the row with t as a 16-bit payload;
 // (3) each run of equal rows is summed left to right by its first element and written, already
-// in ascending row order.  With 32-bit keys the products a*b are NOT kept in LDS: the kernel is
+// in ascending row order.  The products a*b are NOT kept in LDS: the kernel is
 // latency-bound, LDS per column sets the workgroups per CU, and a run head recomputes its
 // products from operands the expansion has just pulled into L2.
 // One pass when 24 B x products fits in half of the free HBM (every column is written at its
@@ -112,20 +112,22 @@ __device__ inline void group_sync() {
 // LDS footprint of one group (NT threads cooperating on one column)
 constexpr int ilog2_ceil(int v) { return v <= 1 ? 0 : 1 + ilog2_ceil((v + 1) / 2); }
 
-// KEY32: numeric keys are (row << tbits) | t in 32 bits (possible when nrows < 2^(31 - tbits));
-// the sort then moves 4-byte keys only and the values stay where the expansion put them
+// Numeric sort keys.  KEY32: (row << tbits) | t packed in 32 bits (possible when nrows < 2^(31 - tbits));
+// otherwise the key is the row alone and t (position in k-then-row order, < CAP <= 4096) travels with
+// it as a 16-bit payload — the merge is stable, so equal rows keep their ascending-t order either
+// way.  The products themselves are never kept in LDS (see the fold).
 template <int CAP, int NBCAP, bool NUMERIC, bool KEY32 = false>
 struct EscLds {
-  static constexpr size_t key_bytes = (NUMERIC && !KEY32) ? CAP * sizeof(int64_t) : CAP * sizeof(int);
-  static constexpr size_t val_bytes = (NUMERIC && !KEY32) ? CAP * sizeof(double) : 0;  // 32-bit keys: see fold
+  static constexpr bool kSplit = NUMERIC && !KEY32;
+  static constexpr size_t key_bytes = CAP * sizeof(int);
+  static constexpr size_t key2_bytes = CAP * sizeof(int);  // second buffer of the merge tree
+  static constexpr size_t tpos_bytes = kSplit ? 2 * CAP * sizeof(unsigned short) : 0;  // both buffers
   static constexpr size_t kb_bytes = NUMERIC ? NBCAP * sizeof(double) : 0;
   static constexpr size_t start_bytes = NBCAP * sizeof(int);
   static constexpr size_t off_bytes = (NBCAP + 8) * sizeof(int);
   static constexpr size_t scratch_bytes = 16 * sizeof(int);
-  // second key buffer of the merge tree (32-bit keys only; 64-bit keys take the bitonic network)
-  static constexpr size_t key2_bytes = (NUMERIC && !KEY32) ? 0 : CAP * sizeof(int);
   static constexpr size_t total =
-      key_bytes + val_bytes + kb_bytes + start_bytes + off_bytes + scratch_bytes + key2_bytes;
+      kb_bytes + key_bytes + key2_bytes + tpos_bytes + start_bytes + off_bytes + scratch_bytes;
 };
 
 // expand - sort - compress for ONE column j with np products and nb entries in B[:,j];
@@ -136,15 +138,15 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
                                   int *__restrict__ Ci, double *__restrict__ Cx) {
   typedef EscLds<CAP, NBCAP, NUMERIC, KEY32> L;
   constexpr int TB = ilog2_ceil(CAP);  // bits of the tie-break t
-  constexpr bool K64 = NUMERIC && !KEY32;
-  int64_t *key64 = reinterpret_cast<int64_t *>(lds);
-  int *key32 = reinterpret_cast<int *>(lds);
-  double *vals = reinterpret_cast<double *>(lds + L::key_bytes);
-  double *kb = reinterpret_cast<double *>(lds + L::key_bytes + L::val_bytes);
-  int *kstart = reinterpret_cast<int *>(lds + L::key_bytes + L::val_bytes + L::kb_bytes);
-  int *koff = reinterpret_cast<int *>(lds + L::key_bytes + L::val_bytes + L::kb_bytes + L::start_bytes);
+  constexpr bool SPLIT = L::kSplit;  // key = row, t carried as a 16-bit payload
+  // 8-byte values first (alignment), then the 4-byte and 2-byte arrays
+  double *kb = reinterpret_cast<double *>(lds);
+  int *key32 = reinterpret_cast<int *>(lds + L::kb_bytes);
+  int *key32b = key32 + CAP;
+  int *kstart = key32b + CAP;
+  int *koff = kstart + NBCAP;
   int *scratch = koff + NBCAP + 8;
-  int *key32b = scratch + 16;  // only when !K64
+  unsigned short *tpa = reinterpret_cast<unsigned short *>(scratch + 16), *tpb = tpa + CAP;  // SPLIT only
   const int lane = tid & 63;
   const int qs = B.p[j];
   const int nb = B.p[j + 1] - qs;
@@ -193,12 +195,11 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
   // of its products, then issues all of its loads, so that their latencies overlap
   {
     constexpr int PER = CAP / NT;
-    int pp[PER], src[PER];
+    int pp[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int t = tid + u * NT;
       pp[u] = -1;
-      src[u] = 0;
       if (t < np) {
         int lo = 0, hi = nb - 1;  // largest q with koff[q] <= t
         while (lo < hi) {
@@ -206,23 +207,18 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
           if (koff[mid] <= t) lo = mid; else hi = mid - 1;
         }
         pp[u] = kstart[lo] + (t - koff[lo]);
-        src[u] = lo;
       }
     }
     int rows[PER];
-    double av[PER];
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      rows[u] = pp[u] >= 0 ? A.i[pp[u]] : 0;
-      av[u] = (K64 && pp[u] >= 0) ? A.x[pp[u]] : 0.0;
-    }
+    for (int u = 0; u < PER; ++u) rows[u] = pp[u] >= 0 ? A.i[pp[u]] : 0;
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int t = tid + u * NT;
       if (pp[u] >= 0) {
-        if (K64) {
-          key64[t] = ((int64_t)rows[u] << 32) | (int64_t)t;  // ties: ascending t = ascending k
-          vals[t] = av[u] * kb[src[u]];                       // a * b
+        if (SPLIT) {
+          key32[t] = rows[u];
+          tpa[t] = (unsigned short)t;  // ties: ascending t = ascending k (kept by the stable merge)
         } else if (NUMERIC) {
           key32[t] = (rows[u] << TB) | t;
         } else {
@@ -234,15 +230,18 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
   group_sync<NT>();
 
   // (3) sort.  The products of one B entry are a column of A, already ascending by row, and the
-  // expansion laid these nb runs out one after the other, so 32-bit keys are sorted by a merge
-  // tree: ceil(log2 nb) levels of pairwise merges, every thread producing E consecutive outputs
-  // of a level (merge-path search for its start, then a sequential merge).  That is ~5 LDS
-  // accesses per product and level instead of the 2 x 66 of a bitonic network over 2048 keys.
-  // E is odd so that the output chunks of a wavefront fall into different LDS banks.
-  const int *skeys = key32;  // where the sorted 32-bit keys end up
-  if (!K64) {
+  // expansion laid these nb runs out one after the other, so the keys are sorted by a merge tree:
+  // ceil(log2 nb) levels of pairwise merges, every thread producing E consecutive outputs of a
+  // level (merge-path search for its start, then a sequential merge; ties take the left run first,
+  // which is the one with the smaller t).  That is ~5 LDS accesses per product and level instead of
+  // the 2 x 66 of a bitonic network over 2048 keys.  E is odd so that the output chunks of a
+  // wavefront fall into different LDS banks.
+  const int *skeys = key32;              // where the sorted keys end up
+  const unsigned short *stp = tpa;       // ... and their t (SPLIT)
+  {
     constexpr int E = CAP / NT + 1;
     int *src = key32, *dst = key32b;
+    unsigned short *tsrc = tpa, *tdst = tpb;
     for (int width = 1; width < nb; width <<= 1) {
       for (int c0 = tid * E; c0 < np; c0 += NT * E) {
         int pos = c0;
@@ -267,10 +266,12 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
           for (; pos < stop; ++pos) {
             if (ia < a1 && (ib >= b1 || ka <= kb2)) {
               dst[pos] = ka;
+              if (SPLIT) tdst[pos] = tsrc[ia];
               ++ia;
               ka = ia < a1 ? src[ia] : 0x7fffffff;
             } else {
               dst[pos] = kb2;
+              if (SPLIT) tdst[pos] = tsrc[ib];
               ++ib;
               kb2 = ib < b1 ? src[ib] : 0x7fffffff;
             }
@@ -281,29 +282,12 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
       int *tmp = src;
       src = dst;
       dst = tmp;
+      unsigned short *ttmp = tsrc;
+      tsrc = tdst;
+      tdst = ttmp;
     }
     skeys = src;
-  } else {
-    // 64-bit keys: bitonic sort, ascending-only network; pairs whose upper index is >= np are skipped
-    int n2 = 2;
-    while (n2 < np) n2 <<= 1;
-    for (int size = 2; size <= n2; size <<= 1) {
-      for (int jj = size >> 1; jj > 0; jj >>= 1) {
-        const bool flip = (jj == (size >> 1));
-        for (int t = tid; t < (n2 >> 1); t += NT) {
-          const int lo = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
-          const int hi = flip ? (lo ^ (size - 1)) : (lo | jj);
-          if (hi < np) {
-            const int64_t ka = key64[lo], kb2 = key64[hi];
-            if (kb2 < ka) {
-              key64[lo] = kb2; key64[hi] = ka;
-              const double va = vals[lo]; vals[lo] = vals[hi]; vals[hi] = va;
-            }
-          }
-        }
-        group_sync<NT>();
-      }
-    }
+    stp = tsrc;
   }
 
   // (4) compress: run heads in ascending row order; numeric heads fold their run left to right
@@ -314,8 +298,9 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
     int row = 0;
     bool head = false;
     if (t < np) {
-      row = K64 ? (int)(key64[t] >> 32) : NUMERIC ? (skeys[t] >> TB) : skeys[t];
-      const int prev = t > 0 ? (K64 ? (int)(key64[t - 1] >> 32) : NUMERIC ? (skeys[t - 1] >> TB) : skeys[t - 1]) : -1;
+      constexpr bool PACKED = NUMERIC && !SPLIT;
+      row = PACKED ? (skeys[t] >> TB) : skeys[t];
+      const int prev = t > 0 ? (PACKED ? (skeys[t - 1] >> TB) : skeys[t - 1]) : -1;
       head = (t == 0) || (row != prev);
     }
     const unsigned long long m = __ballot(head);
@@ -333,21 +318,18 @@ __device__ inline void esc_column(const Csc &A, const Csc &B, int64_t j, int np,
     }
     if (NUMERIC && head) {
       double acc = 0.0;  // SG.reset 0
-      if (K64) {
-        for (int u = t; u < np && (int)(key64[u] >> 32) == row; ++u) acc = acc + vals[u];  // c + a * b
-      } else {
-        // 32-bit keys: the products are not kept in LDS (the kernel is latency-bound and the 8 bytes
-        // per product would halve the workgroups per CU); a run head recomputes a * b of its run
-        // from the operands, which the expansion has just pulled into L2
-        for (int u = t; u < np && (skeys[u] >> TB) == row; ++u) {
-          const int tt = skeys[u] & ((1 << TB) - 1);
-          int lo = 0, hi = nb - 1;  // largest q with koff[q] <= tt
-          while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (koff[mid] <= tt) lo = mid; else hi = mid - 1;
-          }
-          acc = acc + A.x[kstart[lo] + (tt - koff[lo])] * kb[lo];  // c + a * b
+      // the products are not kept in LDS (the kernel is latency-bound and the 8 bytes per product
+      // would halve the workgroups per CU); a run head recomputes a * b of its run from the
+      // operands, which the expansion has just pulled into L2
+      for (int u = t; u < np; ++u) {
+        const int tt = SPLIT ? (int)stp[u] : (skeys[u] & ((1 << TB) - 1));
+        if ((SPLIT ? skeys[u] : (skeys[u] >> TB)) != row) break;
+        int lo = 0, hi = nb - 1;  // largest q with koff[q] <= tt
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (koff[mid] <= tt) lo = mid; else hi = mid - 1;
         }
+        acc = acc + A.x[kstart[lo] + (tt - koff[lo])] * kb[lo];  // c + a * b
       }
       Ci[base + off] = row;
       Cx[base + off] = acc;
@@ -514,9 +496,12 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   typedef EscLds<kLargeProducts, kLargeB, true, false> LXn;
   typedef EscLds<kLargeProducts, kLargeB, true, true> LXn32;
   // 32-bit packed sort keys need row + tie-break bits to fit 31 bits in every bin
-  const bool key32_s = nrowsA <= (1LL << (31 - ilog2_ceil(kSmallProducts)));
-  const bool key32_m = nrowsA <= (1LL << (31 - ilog2_ceil(kMediumProducts)));
-  const bool key32_x = nrowsA <= (1LL << (31 - ilog2_ceil(kLargeProducts)));
+  // SPL_SPGEMM_SPLIT_KEYS=1 (tests) forces the row + 16-bit-position keys that large matrices need
+  const char *split_env = getenv("SPL_SPGEMM_SPLIT_KEYS");
+  const bool allow32 = !(split_env && split_env[0] == '1');
+  const bool key32_s = allow32 && nrowsA <= (1LL << (31 - ilog2_ceil(kSmallProducts)));
+  const bool key32_m = allow32 && nrowsA <= (1LL << (31 - ilog2_ceil(kMediumProducts)));
+  const bool key32_x = allow32 && nrowsA <= (1LL << (31 - ilog2_ceil(kLargeProducts)));
   static bool attr_set = false;
   if (!attr_set) {
     SPL_HIP(hipFuncSetAttribute(
