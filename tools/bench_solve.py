@@ -25,19 +25,24 @@ def main():
     import scipy.sparse.linalg as spla
     import torch
     from __graft_entry__ import load_package
-    from oracle import oracle as O
     pkg = load_package()
     torch.cuda.set_device(0)
     U = pkg.umfpack
     # warm-up on an 8^3 grid: the first launch of each kernel pays the one-time code-object load
-    rp, ci, v = O.gen_poisson3d_csr(8)
+    def poisson(m, dim):  # generated in HBM by the product's own generator (include/spl_synth.h), exported once
+        H = pkg.DeviceMatrix.synthetic("poisson3d" if dim == 3 else "poisson2d", m)
+        rp, ci, v = H.export_csr()  # symmetric: CSR arrays == CSC arrays
+        H.free()
+        return rp, ci, v
+
+    rp, ci, v = poisson(8, 3)
     W = pkg.Matrix(512, 512, rp, ci, v)
     U.linearSolve_(U.factor(W, U.analyze(W)), U.UmfpackNormal, W, np.ones(512))
     for m in [int(t) for t in args.grid.split(",")]:
         n = m ** args.dim
-        rp, ci, v = O.gen_poisson3d_csr(m) if args.dim == 3 else O.gen_poisson2d_csr(m)
+        rp, ci, v = poisson(m, args.dim)
         A = pkg.Matrix(n, n, rp, ci, v)  # symmetric: CSR arrays == CSC arrays
-        xs = O.gen_vector(n)
+        xs = np.random.default_rng(0xBEEF).uniform(0.5, 1.5, n)  # manufactured solution, no cancellation
         S = sp.csc_matrix((v, ci, rp), shape=(n, n))
         b = S @ xs
         t0 = time.perf_counter(); an = U.analyze(A); t1 = time.perf_counter()

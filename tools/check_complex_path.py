@@ -15,13 +15,12 @@ def main():
     import scipy.sparse as sp
     import torch
     from __graft_entry__ import load_package
-    from oracle import oracle as O
     pkg = load_package()
     U = pkg.umfpack
     m = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     n = m * m
-    rp, ci, v = O.gen_poisson2d_csr(m)
-    A = sp.csc_matrix((v, ci, rp), shape=(n, n))
+    T = sp.diags([-np.ones(m - 1), 2 * np.ones(m), -np.ones(m - 1)], (-1, 0, 1))
+    A = (sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m))).tocsc()
     rng = np.random.default_rng(1)
     xs = rng.uniform(0.5, 1.5, n) + 1j * rng.uniform(0.5, 1.5, n)
     for z in (2 + 0.5j, 4 + 0.01j, 0.1 + 3j, 3.9 + 2j, 8.5 + 0j):
