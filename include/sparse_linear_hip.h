@@ -61,6 +61,13 @@ int spl_device_count(void);
 /* last HIP error text seen by this thread ("" if none) */
 const char *spl_last_error(void);
 void spl_free(void *p);
+/* Device blocks of 1 GiB and more (LU factors, fronts, SpGEMM work space) are kept by the library
+ * when their owner is freed and reused by the next request they fit, because on this platform a
+ * fresh hipMalloc of memory released a moment before waits seconds for the driver's wipe
+ * (csrc/device_pool.hip).  They are given back automatically when an allocation of this library
+ * fails; this gives them back now (e.g. before another library needs the memory) and returns the
+ * number of bytes released.  SPL_CACHE_DEVICE_MEMORY=0 in the environment: never keep any. */
+unsigned long long spl_release_cached_memory(void);
 
 /* ---- one-shot operations on borrowed host CSC 5-tuples ---------------------- */
 

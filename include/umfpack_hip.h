@@ -109,6 +109,14 @@ int spl_umfpack_dimension(void *Numeric);
  * (dominant); 4 the same as a speculation; -1 if invalid */
 int spl_umfpack_path(void *Numeric);
 
+/* figures of the factorisation a Numeric object holds now (diagnostics and benchmarks; UMFPACK
+ * reports the like through Info[], which the reference never reads: Umfpack/Internal.hs passes
+ * nullPtr).  out[0] path as above, out[1] n, out[2] kl and out[3] ku of the reordered matrix
+ * (band paths), out[4] bytes of device memory the factors occupy, out[5] flops of the numeric
+ * factorisation (band: 2 n kl ku; multifrontal: summed over the fronts), out[6] number of fronts
+ * (0 on the band paths), out[7] 0.  Returns 0, or -1 if the object is invalid. */
+int spl_umfpack_stats(void *Numeric, double out[8]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,8 @@ def _declare(L):
     L.spl_last_error.argtypes = []
     L.spl_device_count.restype = i
     L.spl_device_count.argtypes = []
+    L.spl_release_cached_memory.restype = C.c_ulonglong
+    L.spl_release_cached_memory.argtypes = []
     L.spl_free.restype = None
     L.spl_free.argtypes = [C.c_void_p]
     sigs = {
@@ -134,6 +136,11 @@ def check(where, status):
 
 def device_count():
     return int(lib().spl_device_count())
+
+
+def release_cached_memory():
+    """Gives the device blocks the library keeps for reuse back to the driver; returns the bytes released."""
+    return int(lib().spl_release_cached_memory())
 
 
 def require_gpu():

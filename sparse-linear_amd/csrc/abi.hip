@@ -197,6 +197,8 @@ const char *spl_last_error(void) { return g_last_error; }
 
 void spl_free(void *p) { free(p); }
 
+unsigned long long spl_release_cached_memory(void) { return (unsigned long long)device_release_cached(); }
+
 int spl_matrix_create(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax, void **H) {
   return spl_matrix_create_rowblock(nrows, ncols, Ap, Ai, Ax, 0, 1, H);
 }

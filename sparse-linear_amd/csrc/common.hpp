@@ -30,7 +30,13 @@ struct DeviceError {
     }                                                                        \
   } while (0)
 
-// RAII device buffer (hipMalloc / hipFree), movable
+// device memory for DBuf (device_pool.hip): large blocks are kept on release and reused
+void *device_alloc(size_t bytes);
+void device_free(void *p) noexcept;
+size_t device_free_bytes();      // free memory as the driver reports it + what the pool would give back
+size_t device_release_cached();  // returns the bytes given back to the driver
+
+// RAII device buffer, movable
 template <typename T>
 struct DBuf {
   T *p = nullptr;
@@ -50,10 +56,10 @@ struct DBuf {
     n = count;
     // +64 B slack: vector loads of the streaming kernels may read (never use) a
     // few elements past the logical end
-    SPL_HIP(hipMalloc(reinterpret_cast<void **>(&p), (count ? count : 1) * sizeof(T) + 64));
+    p = static_cast<T *>(device_alloc((count ? count : 1) * sizeof(T) + 64));
   }
   void release() {
-    if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+    if (p) { device_free(p); p = nullptr; n = 0; }
   }
   T *get() const { return p; }
 };

@@ -1,0 +1,138 @@
+// device_pool.hip — where DBuf gets its memory.
+//
+// Small blocks go straight to hipMalloc / hipFree.  Blocks of kCacheMin bytes and more are kept
+// when they are released and handed out again to the next request they fit: on this platform the
+// driver wipes released VRAM in the background and a later hipMalloc that lands on memory still
+// being wiped waits for it — measured with tools/probe/malloc_probe.hip: 3–6 s for a request that
+// reaches into ~100 GB released a moment before, during which no kernel of the process runs.  A
+// sparse LU at 8 M unknowns holds 172 GB of factor panels and 83 GB of transient fronts; FEAST
+// factors one such matrix per contour point.  Kept blocks are given back to the driver when a
+// hipMalloc fails (then retried), by spl_release_cached_memory(), or never kept at all with
+// SPL_CACHE_DEVICE_MEMORY=0.
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
+#include "common.hpp"
+
+namespace spl {
+namespace {
+
+constexpr size_t kCacheMin = (size_t)1 << 30;
+
+struct Pool {
+  std::mutex mu;
+  struct Block { size_t bytes; int device; };
+  std::unordered_map<void *, Block> live;               // big blocks handed out
+  std::multimap<size_t, std::pair<void *, int>> kept;   // size -> (block, device)
+  size_t kept_bytes = 0;
+  bool enabled = true;
+  Pool() {
+    const char *e = getenv("SPL_CACHE_DEVICE_MEMORY");
+    if (e && atoi(e) == 0) enabled = false;
+  }
+  // caller holds mu
+  void release_kept(int device) {
+    for (auto it = kept.begin(); it != kept.end();) {
+      if (device < 0 || it->second.second == device) {
+        DeviceGuard g(it->second.second);
+        (void)hipFree(it->second.first);
+        kept_bytes -= it->first;
+        it = kept.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+};
+
+Pool &pool() {
+  static Pool *p = new Pool();  // never destroyed: DBufs of static lifetime may outlive any order
+  return *p;
+}
+
+}  // namespace
+
+void *device_alloc(size_t bytes) {
+  Pool &P = pool();
+  void *p = nullptr;
+  if (bytes < kCacheMin || !P.enabled) {
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipErrorOutOfMemory && P.kept_bytes) {
+      (void)hipGetLastError();
+      std::lock_guard<std::mutex> lk(P.mu);
+      P.release_kept(-1);
+      e = hipMalloc(&p, bytes);
+    }
+    SPL_HIP(e);
+    return p;
+  }
+  int device = 0;
+  SPL_HIP(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lk(P.mu);
+  // smallest kept block of this device that holds the request without wasting more than half of it
+  for (auto it = P.kept.lower_bound(bytes); it != P.kept.end() && it->first <= bytes + bytes / 2; ++it) {
+    if (it->second.second != device) continue;
+    p = it->second.first;
+    P.live[p] = Pool::Block{it->first, device};
+    P.kept_bytes -= it->first;
+    P.kept.erase(it);
+    return p;
+  }
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e == hipErrorOutOfMemory && P.kept_bytes) {
+    (void)hipGetLastError();
+    P.release_kept(-1);
+    e = hipMalloc(&p, bytes);
+  }
+  SPL_HIP(e);
+  P.live[p] = Pool::Block{bytes, device};
+  return p;
+}
+
+void device_free(void *p) noexcept {
+  if (!p) return;
+  Pool &P = pool();
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    auto it = P.live.find(p);
+    if (it != P.live.end()) {
+      const Pool::Block b = it->second;
+      P.live.erase(it);
+      // hipFree waits for the device; a kept block must be just as idle before its next owner
+      int cur = 0;
+      (void)hipGetDevice(&cur);
+      if (cur != b.device) (void)hipSetDevice(b.device);
+      (void)hipDeviceSynchronize();
+      if (cur != b.device) (void)hipSetDevice(cur);
+      P.kept.emplace(b.bytes, std::make_pair(p, b.device));
+      P.kept_bytes += b.bytes;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+
+// free device memory as a planner should see it: what the driver reports plus what this library
+// would give back on demand
+size_t device_free_bytes() {
+  size_t free_b = 0, total_b = 0;
+  SPL_HIP(hipMemGetInfo(&free_b, &total_b));
+  int device = 0;
+  SPL_HIP(hipGetDevice(&device));
+  Pool &P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  for (const auto &kv : P.kept)
+    if (kv.second.second == device) free_b += kv.first;
+  return free_b;
+}
+
+size_t device_release_cached() {
+  Pool &P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  const size_t had = P.kept_bytes;
+  P.release_kept(-1);
+  return had;
+}
+
+}  // namespace spl

@@ -228,7 +228,7 @@ struct Worker {
     if (nlev < 3) return make_leaf(lo, hi);  // no interior level: nothing to separate
     // smallest level among the balanced ones; the balance requirement is relaxed until one exists
     int best = -1;
-    for (double frac : {0.30, 0.20, 0.10, 0.0}) {
+    for (double frac : {0.35, 0.20, 0.10, 0.0}) {
       int64_t best_size = -1;
       for (int t = 1; t + 1 < nlev; ++t) {
         const int64_t before = level_ptr[(size_t)t], after = (int64_t)size - level_ptr[(size_t)t + 1];

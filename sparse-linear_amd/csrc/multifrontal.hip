@@ -637,8 +637,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   // ---- memory plan: the smallest cut depth whose transient part fits next to the resident part
   Plan plan;
   {
-    size_t free_b = 0, total_b = 0;
-    SPL_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t free_b = device_free_bytes();
     const double budget = (double)free_b - (double)free_b / 16 - (double)mf_device_bytes(T);
     const char *force = getenv("SPL_MF_CUT");  // tests: force a cut depth
     bool ok = false;
@@ -670,11 +669,13 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   upload_vec(D.ldu, T.ldu, s);
   upload_vec(D.poff, T.poff, s);
   upload_vec(D.uoff, T.uoff, s);
+  lap("tree uploads (queued)");
   D.rel.alloc((size_t)T.rel_elems);
   F.arena.alloc((size_t)T.panel_elems);
   F.invs.alloc((size_t)T.inv_elems);
   DBuf<double> region0((size_t)plan.region_elems[0]), region1((size_t)plan.region_elems[1]),
       cutbuf((size_t)plan.cut_elems);  // transient
+  lap("hipMalloc");
   F.view = TreeView{D.p0.get(),    D.np.get(),   D.nb.get(),   D.ld.get(),   D.parent.get(), D.front_of.get(),
                     D.bidx.get(),  D.rel.get(),  D.depth.get(), D.ldp.get(), D.ldu.get(),    D.bptr.get(),
                     D.foff.get(),  D.ioff.get(), D.woff.get(), D.roff.get(), D.poff.get(),   D.uoff.get(),
@@ -742,7 +743,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   }
   SPL_HIP(hipStreamSynchronize(s));
   staged.clear();
-  lap("uploads + hipMalloc");
+  lap("level lists");
   if (nf > 0) hipLaunchKernelGGL(rel_kernel, dim3((unsigned)nf), dim3(256), 0, s, nf, F.view, D.rel.get());
   DBuf<int> singular(1);
   SPL_HIP(hipMemsetAsync(singular.get(), 0, sizeof(int), s));
@@ -824,6 +825,13 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
       }
       if (turn > 0)
         for (int i = 0; i < kStreams && i < turn; ++i) SPL_HIP(hipStreamSynchronize(side[i]));
+      if (timing && d < 8) {
+        int big = 0;
+        for (int i = b0; i < b1; ++i) big = std::max(big, T.fs(T.by_depth[(size_t)d][(size_t)i]));
+        char what[64];
+        snprintf(what, sizeof what, "level %d: %d fronts, max %d", d, b1 - b0, big);
+        lap(what);
+      }
     }
   };
   if (plan.cut == 0) {

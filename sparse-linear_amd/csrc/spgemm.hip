@@ -485,8 +485,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   // forces the symbolic + numeric form.
   bool single_pass = false;
   {
-    size_t free_b = 0, total_b = 0;
-    SPL_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t free_b = device_free_bytes();
     const char *force = getenv("SPL_SPGEMM_TWO_PASS");
     single_pass = !(force && force[0] == '1') && total_products > 0 &&
                   (double)total_products * 24.0 < 0.5 * (double)free_b;

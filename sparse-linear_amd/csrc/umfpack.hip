@@ -460,8 +460,7 @@ void factor_multifrontal(Numeric *N, hipStream_t s) {
   N->AB.release();
   N->blkinv.release();
   if (N->mfact) { mf_free(N->mfact); N->mfact = nullptr; }
-  size_t free_b = 0, total_b = 0;
-  SPL_HIP(hipMemGetInfo(&free_b, &total_b));
+  const size_t free_b = device_free_bytes();
   if (mf_device_bytes(*N->tree) > free_b - free_b / 8) throw DeviceError{SPL_ERROR_out_of_memory};
   N->nopiv = 1;
   N->mfact = mf_factor(N->tree, N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), N->inv.get(), s);
@@ -483,8 +482,7 @@ void factor_band(Numeric *N, bool nopiv, hipStream_t s) {
   const size_t band_elems = (size_t)N->ldab * (size_t)n;
   N->AB.release();
   N->blkinv.release();
-  size_t free_b = 0, total_b = 0;
-  SPL_HIP(hipMemGetInfo(&free_b, &total_b));
+  const size_t free_b = device_free_bytes();
   if (band_elems * sizeof(double) > free_b - free_b / 8) throw DeviceError{SPL_ERROR_out_of_memory};  // too wide
   N->AB.alloc(band_elems);
   SPL_HIP(hipMemsetAsync(N->AB.get(), 0, band_elems * sizeof(double), s));
@@ -809,6 +807,25 @@ int spl_umfpack_path(void *NumericIn) {
   if (!N) return -1;
   if (N->mfact) return N->speculative ? 4 : 3;
   return N->nopiv ? (N->speculative ? 2 : 1) : 0;
+}
+
+int spl_umfpack_stats(void *NumericIn, double out[8]) {
+  Numeric *N = as_numeric(NumericIn);
+  if (!N || !out) return -1;
+  for (int i = 0; i < 8; ++i) out[i] = 0.0;
+  out[0] = (double)spl_umfpack_path(NumericIn);
+  out[1] = (double)N->n;
+  if (N->mfact) {
+    out[4] = (double)mf_device_bytes(*N->tree);
+    out[5] = N->tree->flops;
+    out[6] = (double)N->tree->nfronts;
+  } else {
+    out[2] = (double)N->kl;
+    out[3] = (double)N->ku;
+    out[4] = (double)(N->AB.n + N->blkinv.n) * sizeof(double);
+    out[5] = 2.0 * (double)N->n * (double)N->kl * (double)N->ku;
+  }
+  return 0;
 }
 
 void umfpack_di_free_symbolic(void **SymbolicIO) {

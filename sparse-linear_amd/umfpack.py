@@ -58,6 +58,8 @@ def _declare():
     L.spl_umfpack_zi_solve_many.argtypes = [i, ip, ip, dp, dp, i, dp, dp, dp, dp, vp]
     L.spl_umfpack_path.restype = i
     L.spl_umfpack_path.argtypes = [vp]
+    L.spl_umfpack_stats.restype = C.c_int
+    L.spl_umfpack_stats.argtypes = [vp, C.POINTER(C.c_double)]
     L._umf_declared = True
     return L
 
@@ -103,6 +105,15 @@ class Factors(_Handle):
         (diagonally dominant), 2 the same as a speculation that every solve checks, 3 / 4
         multifrontal without interchanges (dominant / speculation) (include/umfpack_hip.h)"""
         return int(_declare().spl_umfpack_path(self.value))
+
+    @property
+    def stats(self):
+        """figures of the factorisation held now (spl_umfpack_stats, include/umfpack_hip.h)"""
+        buf = (C.c_double * 8)()
+        if _declare().spl_umfpack_stats(self.value, buf) != 0:
+            raise UmfpackError("spl_umfpack_stats: invalid Numeric object")
+        keys = ("path", "n", "kl", "ku", "device_bytes", "flops", "fronts")
+        return dict(zip(keys, [float(v) if k in ("device_bytes", "flops") else int(v) for k, v in zip(keys, buf)]))
 
 
 def analyze(mat):

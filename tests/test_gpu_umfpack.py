@@ -267,6 +267,11 @@ def test_multifrontal_matches_band_and_oracle(gpu, pkg, O, kind, m, monkeypatch)
     monkeypatch.setenv("SPL_LU_METHOD", "mf")
     fm = U.factor(A, U.analyze(A))
     assert fm.path == 3
+    sb, sm = fb.stats, fm.stats
+    assert (sb["path"], sb["n"], sb["fronts"]) == (1, n, 0) and (sm["path"], sm["n"]) == (3, n)
+    assert 0 < sb["kl"] == sb["ku"] <= (m if kind == "2d" else m * m)  # symmetric pattern, RCM no worse than natural
+    assert sb["flops"] == 2.0 * n * sb["kl"] * sb["ku"] and sb["device_bytes"] >= 8.0 * n * (2 * sb["kl"] + 1)
+    assert sm["fronts"] >= 1 and 0 < sm["flops"] and sm["device_bytes"] > 0
     for mode in (U.UmfpackNormal, U.UmfpackTrans):
         xb = U.linearSolveMany_(fb, mode, A, bs)
         xm = U.linearSolveMany_(fm, mode, A, bs)

@@ -25,7 +25,7 @@ def main():
             continue
         name = r"\*\*200³ \(config C5\)\*\*" if m == 200 else "%d³" % m
         label = "**200³ (config C5)**" if m == 200 else "%d³" % m
-        b = ("%s s" % fmt(band[m]["gpu"]["total_s"]) + (" (160 GB)" if m == 100 else "")) if m in band else "does not fit"
+        b = ("%s s" % fmt(band[m]["gpu"]["total_s"]) + (" (%.0f GB)" % band[m]["factorisation"]["device_GB"] if m == 100 else "")) if m in band else "does not fit"
         tot = "**%s s**" % fmt(g["total_s"]) if m == 200 else "%s s" % fmt(g["total_s"])
         new = "| %s | %s | %s | %s | %s | %s | %s | %.1e |\n" % (
             label, format(d["n"], ",").replace(",", " "), fmt(g["analyze_s"]), fmt(g["factor_s"]), fmt(g["solve_s"]), tot, b,
