@@ -17,6 +17,9 @@
 
 #include <stdint.h>
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <atomic>
 #include <future>
 #include <thread>
@@ -269,6 +272,14 @@ struct Worker {
 inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T) {
   T = Tree();
   T.n = n;
+  const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // phase times on stderr (diagnostic)
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[build_tree] %-24s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   // adjacency of A + A^T without the diagonal (duplicates are harmless for BFS and are removed from
   // the boundary lists by sort + unique)
   std::vector<int64_t> xadj((size_t)n + 1, 0);
@@ -287,12 +298,14 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T) {
         if (i != j) { adj[(size_t)cur[(size_t)i]++] = j; adj[(size_t)cur[(size_t)j]++] = i; }
       }
   }
+  lap("adjacency of A + A^T");
   detail::Shared shared(n, xadj, adj, leaf);
   std::vector<detail::Node> nodes;
   if (n > 0) {
     detail::Worker w(shared);
     nodes = w.dissect(0, n, 0);
   }
+  lap("dissection");
   // the node vector is a post-order: children before their parent
   const int nf = (int)nodes.size();
   T.nfronts = nf;
@@ -329,6 +342,7 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T) {
   // The fronts of one tree level are independent (they only read their children's lists), so each
   // level is shared out among threads; the lists are concatenated in front order afterwards.
   T.bptr.assign((size_t)nf + 1, 0);
+  lap("permutation, levels");
   {
     std::vector<std::vector<int>> bnd((size_t)nf);
     auto boundary_of = [&](int f) {
@@ -374,6 +388,7 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T) {
     T.bidx.resize((size_t)T.bptr[(size_t)nf]);
     for (int f = 0; f < nf; ++f) std::copy(bnd[(size_t)f].begin(), bnd[(size_t)f].end(), T.bidx.begin() + T.bptr[(size_t)f]);
   }
+  lap("boundaries");
   // storage layout and work estimate
   T.ld.assign((size_t)nf, 0);
   T.foff.assign((size_t)nf, 0);

@@ -535,6 +535,15 @@ struct Factors {
   std::vector<std::vector<int64_t>> h_ctile[2], h_ptile, h_utile;
   std::vector<DBuf<int64_t>> ctile[2], ptile, utile;
   int singular = 0;
+  // independent large fronts of a level run on these (factorisation and solves)
+  hipStream_t side[kStreams] = {};
+  int nside = 0;
+  void make_streams() {
+    for (; nside < kStreams; ++nside) SPL_HIP(hipStreamCreateWithFlags(&side[nside], hipStreamNonBlocking));
+  }
+  ~Factors() {
+    for (int i = 0; i < nside; ++i) (void)hipStreamDestroy(side[i]);
+  }
 };
 
 }  // namespace mf
@@ -754,8 +763,8 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
     attr_set = true;
   }
-  hipStream_t side[kStreams];
-  for (int i = 0; i < kStreams; ++i) SPL_HIP(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+  F.make_streams();
+  hipStream_t *side = F.side;
   auto region_of = [&](int d) { return (d & 1) ? region1.get() : region0.get(); };
   // [begin, end) of the ids lo..hi inside an ascending list
   auto range_of = [](const std::vector<int> &L, int lo, int hi, int &begin, int &end) {
@@ -825,7 +834,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
       }
       if (turn > 0)
         for (int i = 0; i < kStreams && i < turn; ++i) SPL_HIP(hipStreamSynchronize(side[i]));
-      if (timing && d < 8) {
+      if (timing) {
         int big = 0;
         for (int i = b0; i < b1; ++i) big = std::max(big, T.fs(T.by_depth[(size_t)d][(size_t)i]));
         char what[64];
@@ -851,7 +860,6 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   }
   SPL_HIP(hipStreamSynchronize(s));
   lap("levels");
-  for (int i = 0; i < kStreams; ++i) (void)hipStreamDestroy(side[i]);
   SPL_HIP(hipMemcpyAsync(&F.singular, singular.get(), sizeof(int), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
   SPL_HIP(hipGetLastError());
@@ -861,14 +869,73 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
 }
 
 // NR columns (c + r * stride) through the tree: up with L (or U^T), down with U (or L^T)
+// The large fronts of a level are independent (own work matrices, own pivots of c): they are dealt
+// to the side streams, which wait for the level's start on s and which s waits for at its end.
+struct LevelFork {
+  const mf::Factors &F;
+  hipStream_t s;
+  hipEvent_t start = nullptr, done[kStreams] = {};
+  int used = 0;
+  bool forked = false;
+  LevelFork(const mf::Factors &F_, hipStream_t s_) : F(F_), s(s_) {
+    SPL_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
+    for (int i = 0; i < kStreams; ++i) SPL_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+  }
+  ~LevelFork() {
+    if (start) (void)hipEventDestroy(start);
+    for (int i = 0; i < kStreams; ++i)
+      if (done[i]) (void)hipEventDestroy(done[i]);
+  }
+  // begin a level with `count` large fronts
+  void begin(int count) {
+    forked = count > 1 && F.nside == kStreams;
+    used = 0;
+    if (forked) SPL_HIP(hipEventRecord(start, s));
+  }
+  hipStream_t next() {
+    if (!forked) return s;
+    const int i = used % kStreams;
+    if (used < kStreams) SPL_HIP(hipStreamWaitEvent(F.side[i], start, 0));
+    ++used;
+    return F.side[i];
+  }
+  void end() {
+    if (!forked) return;
+    for (int i = 0; i < kStreams && i < used; ++i) {
+      SPL_HIP(hipEventRecord(done[i], F.side[i]));
+      SPL_HIP(hipStreamWaitEvent(s, done[i], 0));
+    }
+  }
+};
+
 template <bool TRANS, int NR>
 static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride, double *work, double *zbuf,
-                                  hipStream_t s) {
+                                  hipStream_t s0) {
   const mf::Tree &T = *F.tree;
   const int nd = T.maxdepth + 1;
   const double *arena = F.arena.get();
   double *invs = F.invs.get();
   constexpr int FWD = TRANS ? 2 : 0, BWD = TRANS ? 3 : 1;
+  LevelFork fork(F, s0);
+  auto large_fronts = [&](int d) {
+    int count = 0;
+    for (int f : T.by_depth[(size_t)d]) count += (T.fs(f) > kBigSolve && T.np[(size_t)f] > 0) ? 1 : 0;
+    return count;
+  };
+  hipStream_t s = s0;
+  const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // per-level times on stderr (diagnostic)
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *dir, int d) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(s0);
+    const auto now = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(now - t_last).count();
+    fprintf(stderr, "[mf_solve] %s level %2d: %4d large of %6zu fronts %8.2f ms\n", dir, d, large_fronts(d),
+            T.by_depth[(size_t)d].size(), ms);
+    t_last = now;
+  };
+  if (timing) (void)hipStreamSynchronize(s0);
+  t_last = std::chrono::steady_clock::now();
   for (int d = nd - 1; d >= 0; --d) {
     const unsigned nf = (unsigned)T.by_depth[(size_t)d].size();
     hipLaunchKernelGGL(solve_init_kernel<NR>, dim3(nf), dim3(256), 0, s, F.level_lists[(size_t)d].get(), F.view, c,
@@ -881,9 +948,12 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
     if (F.solve_counts[(size_t)d] > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_forward_kernel<TRANS, NR>), dim3((unsigned)F.solve_counts[(size_t)d]),
                          dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work);
+    lap("up small  ", d);
+    fork.begin(large_fronts(d));
     for (int f : T.by_depth[(size_t)d]) {
       const int np = T.np[(size_t)f], nb = T.nb[(size_t)f], fs = np + nb;
       if (fs <= kBigSolve || np == 0) continue;
+      s = fork.next();
       double *P = const_cast<double *>(arena) + T.poff[(size_t)f];
       const double *U = arena + T.uoff[(size_t)f];
       double *W = work + (size_t)T.woff[(size_t)f] * NR, *Z = zbuf + (size_t)T.woff[(size_t)f] * NR;
@@ -899,15 +969,21 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
                              T.ldu[(size_t)f], np, nb, Z, W, fs);
       }
     }
+    fork.end();
+    s = s0;
+    lap("up large  ", d);
   }
   for (int d = 0; d < nd; ++d) {
     if (F.solve_counts[(size_t)d] > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_backward_kernel<TRANS, NR>), dim3((unsigned)F.solve_counts[(size_t)d]),
                          dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work, c,
                          stride);
+    lap("down small", d);
+    fork.begin(large_fronts(d));
     for (int f : T.by_depth[(size_t)d]) {
       const int np = T.np[(size_t)f], nb = T.nb[(size_t)f], fs = np + nb;
       if (fs <= kBigSolve || np == 0) continue;
+      s = fork.next();
       double *P = const_cast<double *>(arena) + T.poff[(size_t)f];
       const double *U = arena + T.uoff[(size_t)f];
       const int ldp = T.ldp[(size_t)f], ldu = T.ldu[(size_t)f];
@@ -923,6 +999,9 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
       hipLaunchKernelGGL(front_scatter_x_kernel<NR>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s,
                          T.p0[(size_t)f], np, W, fs, c, stride);
     }
+    fork.end();
+    s = s0;
+    lap("down large", d);
   }
 }
 

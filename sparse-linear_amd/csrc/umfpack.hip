@@ -25,6 +25,7 @@
 #include <stdio.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <future>
 #include <mutex>
 #include <vector>
@@ -559,8 +560,12 @@ int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
         mf::build_tree(n, Ap, Ai, 256, *T);
         return T;
       });
+    const bool timing = getenv("SPL_MF_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     try {
       rcm_order(S->n, Ap, Ai, S->perm);
+      if (timing) fprintf(stderr, "[symbolic] RCM done at %.1f ms\n", since());
       S->inv.assign((size_t)S->n, 0);
       for (int k = 0; k < S->n; ++k) S->inv[(size_t)S->perm[(size_t)k]] = k;
       int kl = 0, ku = 0;
@@ -579,7 +584,9 @@ int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
       throw;
     }
     if (tree_job.valid()) {
+      if (timing) fprintf(stderr, "[symbolic] bandwidths done at %.1f ms\n", since());
       std::shared_ptr<mf::Tree> T = tree_job.get();
+      if (timing) fprintf(stderr, "[symbolic] nested dissection tree ready at %.1f ms\n", since());
       const double band_flops = 2.0 * S->n * (double)S->kl * (double)S->ku;
       // measured: the tree wins from about 7x fewer flops on (many small fronts run below the
       // MFMA rate of the band's large windows; 32^3 Poisson is the break-even)

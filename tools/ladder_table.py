@@ -8,6 +8,13 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def steady(g):
+    """factor time with the memory coming from the library's pool (the same matrix factored again) and the
+    total built on it; the first factorisation of a size is in the JSON as factor_s / total_s"""
+    f = g.get("refactor_s", g["factor_s"])
+    return f, g["analyze_s"] + f + g["solve_s"]
+
+
 def fmt(x):
     return "%.3f" % x if x < 1 else "%.2f" % x if x < 10 else "%.1f" % x
 
@@ -25,23 +32,23 @@ def main():
             continue
         name = r"\*\*200³ \(config C5\)\*\*" if m == 200 else "%d³" % m
         label = "**200³ (config C5)**" if m == 200 else "%d³" % m
-        b = ("%s s" % fmt(band[m]["gpu"]["total_s"]) + (" (%.0f GB)" % band[m]["factorisation"]["device_GB"] if m == 100 else "")) if m in band else "does not fit"
-        tot = "**%s s**" % fmt(g["total_s"]) if m == 200 else "%s s" % fmt(g["total_s"])
+        b = ("%s s" % fmt(steady(band[m]["gpu"])[1]) + (" (%.0f GB)" % band[m]["factorisation"]["device_GB"] if m == 100 else "")) if m in band else "does not fit"
+        fac, total = steady(g)
+        tot = "**%s s**" % fmt(total) if m == 200 else "%s s" % fmt(total)
         new = "| %s | %s | %s | %s | %s | %s | %s | %.1e |\n" % (
-            label, format(d["n"], ",").replace(",", " "), fmt(g["analyze_s"]), fmt(g["factor_s"]), fmt(g["solve_s"]), tot, b,
+            label, format(d["n"], ",").replace(",", " "), fmt(g["analyze_s"]), fmt(fac), fmt(g["solve_s"]), tot, b,
             d["max_rel_err_vs_manufactured"])
         s, k = re.subn(r"\| %s \| [^\n]*\n" % name, lambda _m: new, s, count=1)
         assert k == 1, m
     for d in rows2:
         m, g = d["m"], d["gpu"]
+        fac, total = steady(g)
         new = "| %d² | %s | %s | %s | %s | %s s | %.1e |\n" % (
-            m, format(d["n"], ",").replace(",", " "), fmt(g["analyze_s"]), fmt(g["factor_s"]), fmt(g["solve_s"]),
-            fmt(g["total_s"]), d["max_rel_err_vs_manufactured"])
+            m, format(d["n"], ",").replace(",", " "), fmt(g["analyze_s"]), fmt(fac), fmt(g["solve_s"]),
+            fmt(total), d["max_rel_err_vs_manufactured"])
         s, k = re.subn(r"\| %d² \| [^\n]*\n" % m, lambda _m: new, s, count=1)
         assert k == 1, m
     c5 = [d for d in rows3 if d["m"] == 200][0]["gpu"]
-    s = re.sub(r"3\.9e14 flops in [0-9.]+ s of factorisation =\n[0-9]+ TFLOP/s fp64;",
-               "3.9e14 flops in %.1f s of factorisation =\n%d TFLOP/s fp64;" % (c5["factor_s"], round(3.89e14 / c5["factor_s"] / 1e12)), s)
     open(path, "w").write(s)
     print("C5:", c5)
 
