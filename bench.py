@@ -106,22 +106,96 @@ def main():
                                dist_mod.hip_local_spmv(H, lambda: stream.cuda_stream), "cuda")
     y_local, y_full = op.y_local, op.y_full
 
-    def spmv():
-        op.local_spmv(x, y_local)
-
-    def step():
-        op.step(x)  # local CSR-stream kernel, then (N > 1) the RCCL all-gather of y
-
     def barrier():
         if N > 1:
             dist.barrier()
 
-    nnz_t = torch.tensor([info["nnz"]], dtype=torch.int64, device="cuda")
+    def agree(flag, how):  # the same decision on every rank
+        t = torch.tensor([float(flag)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=how)
+        return float(t.item())
+
+    def seconds_per_step(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        barrier()
+        return agree((time.perf_counter() - t) / reps, dist.ReduceOp.MAX)
+
+    # ---- N > 1: how the exchange is scheduled is chosen by measurement before anything is timed.
+    # Candidates: the plain step (kernel, then one all-gather of y) and the pipelined step with the
+    # rank's rows cut into 2 or 4 chunks (dist.PipelinedRowBlockSpMV: the gather of one chunk runs
+    # under the kernel of the next).  A candidate must reproduce the plain step's y bit for bit on
+    # every rank and is kept only if it is faster; SPL_BENCH_CHUNKS=k forces k (1 = plain).
+    exchange = "one all-gather of y after the kernel"
+    handles = [H]
+    kernels = [dist_mod.hip_local_spmv(H, lambda: stream.cuda_stream)]
+    pieces = [(r0, r1)]
+    tuning = None
+    if N > 1 and not args.blocked and not args.variant:
+        forced = int(os.environ.get("SPL_BENCH_CHUNKS", "0"))
+        candidates = [c for c in ([forced] if forced > 1 else [] if forced == 1 else [2, 4]) if n % (c * N) == 0]
+        y_plain = op.step(x).clone()
+        best_t = seconds_per_step(lambda: op.step(x), 3, 10)
+        tuning = {"1": round(best_t * 1e3, 4)}
+        for C in candidates:
+            cand, ok = None, 1.0
+            try:
+                bnd = dist_mod.pipelined_piece_bounds(n, N, C)
+                hs = []
+                for c in range(C):
+                    q = c * N + rank
+                    h = pkg.DeviceMatrix.synthetic(args.matrix, n, args.draws, seed=0x5EED, row0=bnd[q], row1=bnd[q + 1])
+                    h.optimize()
+                    hs.append(h)
+                cand = dist_mod.PipelinedRowBlockSpMV(
+                    n, rank, N, C, [dist_mod.hip_local_spmv(h, lambda: stream.cuda_stream) for h in hs], "cuda")
+            except Exception as e:  # e.g. out of memory on one rank: every rank drops the candidate
+                sys.stderr.write("rank %d: pipelined exchange with %d chunks not available: %s\n" % (rank, C, e))
+                ok = 0.0
+            if agree(ok, dist.ReduceOp.MIN) < 1.0:
+                continue
+            same = float(torch.equal(cand.step(x), y_plain))
+            if agree(same, dist.ReduceOp.MIN) < 1.0:
+                if rank == 0:
+                    sys.stderr.write("pipelined exchange with %d chunks differs from the plain step: dropped\n" % C)
+                continue
+            t_c = seconds_per_step(lambda: cand.step(x), 3, 10)
+            tuning[str(C)] = round(t_c * 1e3, 4)
+            if t_c < best_t or forced > 1:
+                best_t = t_c
+                for h in handles:
+                    h.free()
+                op, handles, y_full = cand, hs, cand.y_full
+                kernels = list(cand.local_spmvs)
+                pieces = [cand.rows_of(c) for c in range(C)]
+                exchange = "%d chunks per rank, the all-gather of a chunk under the kernel of the next" % C
+            else:
+                for h in hs:
+                    h.free()
+        del y_plain
+    y_pieces = op.y_local if isinstance(op.y_local, list) else [op.y_local]
+
+    def spmv():  # the kernel(s) of one step alone
+        for k, yp in zip(kernels, y_pieces):
+            k(x, yp)
+
+    def step():
+        op.step(x)  # local kernel(s) and, at N > 1, the RCCL all-gather(s) of y
+
+    info = handles[0].info()
+    nnz_local = sum(h.info()["nnz"] for h in handles)
+    nnz_t = torch.tensor([nnz_local], dtype=torch.int64, device="cuda")
     if N > 1:
         dist.all_reduce(nnz_t)
     nnz_total = int(nnz_t.item())
     B_total = spmv_bytes(nnz_total, n, n)
-    B_local = spmv_bytes(info["nnz"], r1 - r0, n)
+    B_local = sum(spmv_bytes(h.info()["nnz"], b - a, n) for h, (a, b) in zip(handles, pieces))
 
     # ---- timed region: W warm-ups, then exactly K steps between barrier+sync pairs
     for _ in range(args.warmup):
@@ -151,7 +225,6 @@ def main():
     torch.cuda.synchronize()
     kern_ms = ev0.elapsed_time(ev1) / args.steps
     achieved = B_local / (kern_ms * 1e-3) / 1e9
-    info = H.info()
     kernel = ("spmv_blocked_lockstep" if info["blocked_rows"] > 0 else
               "spmv_sell" if info["blocked_rows"] < 0 else "spmv_stream")
     traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (N = 1, default sizes only)
@@ -171,11 +244,20 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s CSR %dx%d, %d draws/row, nnz=%d, y=A*x fp64, int32 indices%s"
                                % (args.matrix, n, n, args.draws, nnz_total,
-                                  "" if N == 1 else ", %d row blocks + RCCL all-gather of y" % N),
+                                  "" if N == 1 else ", %d row blocks + RCCL all-gather of y (%s)" % (N, exchange)),
                    "algorithmic_bytes": B_total, "hbm_frac_of_%dx8TBps" % N: round(value / (N * HBM_PEAK_GBPS), 4),
                    "variant": args.variant, "blocked": args.blocked or "auto"},
         "roofline": roofline,
     }
+    # fingerprint of the whole y every rank holds after the last step: equal for every N and exchange
+    import hashlib
+    step()
+    torch.cuda.synchronize()
+    out["y_sha1"] = hashlib.sha1(y_full.cpu().numpy().tobytes()).hexdigest()
+    if tuning:
+        out["config"]["exchange_ms_per_step_by_chunks"] = tuning  # measured before the timed region
+    if len(handles) > 1:
+        roofline["launches_per_step"] = len(handles)
 
     # ---- CPU baseline beside it (rank 0, N = 1): the reference's own algorithm, 1 core
     if N == 1 and rank == 0 and not args.no_cpu_baseline:

@@ -7,7 +7,8 @@ the zero-copy sub-ranges of pointers/indices/values that the reference's
 step is:  y_p = A_p x  (no communication: row sums never cross ranks, so the
 result is bit-identical to the 1-GPU result)  followed by ONE collective, the
 all-gather of y, so that y can be the next x.  There is no other exchange step
-on this path; nothing else is communicated.
+on this path; nothing else is communicated.  PipelinedRowBlockSpMV cuts a rank's
+rows into chunks and runs the gather of one chunk under the kernel of the next.
 
 The local product is supplied as a callable so that the partition / gather
 logic can be exercised on CPU ranks (gloo) in tests; the product path always
@@ -79,6 +80,67 @@ class RowBlockSpMV(object):
             for p in range(self.world):
                 self.y_full[self.bounds[p]:self.bounds[p + 1]] = \
                     self.pad[p * self.maxlen: p * self.maxlen + self.sizes[p]]
+        return self.y_full
+
+
+def pipelined_piece_bounds(n, world, chunks):
+    """Row ownership of PipelinedRowBlockSpMV: the rows are cut into chunks * world equal pieces in
+    natural order; piece q = c * world + p belongs to rank p, chunk c.  Returns the chunks * world + 1
+    piece boundaries."""
+    pieces = chunks * world
+    if n % pieces:
+        raise ValueError("n = %d is not divisible by chunks * world = %d" % (n, pieces))
+    return [q * (n // pieces) for q in range(pieces + 1)]
+
+
+class PipelinedRowBlockSpMV(object):
+    """The same step as RowBlockSpMV with the exchange hidden behind the kernels of the step itself.
+
+    Rank p owns `chunks` row ranges instead of one (pieces c * world + p of pipelined_piece_bounds),
+    so that the rows [c n/chunks, (c+1) n/chunks) of y are exactly what the ranks produce in their
+    chunk c, in rank order: ONE all_gather_into_tensor per chunk fills them in place, in natural
+    row order.  The gather of chunk c is started asynchronously as soon as the kernel of chunk c is
+    queued and runs on the backend's own stream while the kernel of chunk c + 1 computes; the step
+    ends when the last gather has landed.  Nothing crosses step boundaries: step k + 1 may use the
+    y of step k as its x.  Row sums never cross ranks or chunks: y is bit-identical to RowBlockSpMV's.
+
+    local_spmvs[c](x, y_piece) must fill y_piece with the product of this rank's rows of chunk c."""
+
+    def __init__(self, n, rank, world, chunks, local_spmvs, device, dtype=None, group=None):
+        import torch
+        self.torch = torch
+        self.n, self.rank, self.world, self.chunks = int(n), int(rank), int(world), int(chunks)
+        assert len(local_spmvs) == chunks
+        self.bounds = pipelined_piece_bounds(self.n, self.world, self.chunks)
+        self.local_spmvs = list(local_spmvs)
+        self.group = group
+        dtype = dtype or torch.float64
+        self.piece = self.n // (self.chunks * self.world)
+        self.y_full = torch.zeros(self.n, dtype=dtype, device=device)
+        span = self.piece * self.world  # rows of one chunk over all ranks
+        self.out = [self.y_full[c * span:(c + 1) * span] for c in range(self.chunks)]
+        if world == 1:
+            self.y_local = list(self.out)  # a single rank writes y in place
+        else:
+            self.y_local = [torch.zeros(self.piece, dtype=dtype, device=device) for _ in range(self.chunks)]
+
+    def rows_of(self, c):
+        """[first, last) global rows of this rank's piece of chunk c"""
+        q = c * self.world + self.rank
+        return self.bounds[q], self.bounds[q + 1]
+
+    def step(self, x):
+        if self.world == 1:
+            for c in range(self.chunks):
+                self.local_spmvs[c](x, self.y_local[c])
+            return self.y_full
+        import torch.distributed as dist
+        works = []
+        for c in range(self.chunks):
+            self.local_spmvs[c](x, self.y_local[c])
+            works.append(dist.all_gather_into_tensor(self.out[c], self.y_local[c], group=self.group, async_op=True))
+        for w in works:
+            w.wait()
         return self.y_full
 
 

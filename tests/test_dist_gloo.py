@@ -72,6 +72,50 @@ def _worker(rank, world, port, balanced, out_dir):
         dist.destroy_process_group()
 
 
+def _pipelined_worker(rank, world, port, chunks, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import __graft_entry__ as g
+        pkg = g.load_package()
+        from oracle import oracle as O
+        n = 3000  # divisible by chunks * world for every case below
+        rp, ci, v = O.gen_random_csr(n, 20)
+        bounds = pkg.dist.pipelined_piece_bounds(n, world, chunks)
+        calls = []
+
+        def piece_product(c):
+            q = c * world + rank
+            r0, r1 = bounds[q], bounds[q + 1]
+            lrp = (rp[r0:r1 + 1] - rp[r0]).astype(np.int32)
+            lci, lv = ci[rp[r0]:rp[r1]], v[rp[r0]:rp[r1]]
+
+            def run(x, y_piece):
+                y = np.zeros(r1 - r0)
+                O.csr_gaxpy32(lrp, lci, lv, x.numpy(), y)
+                y_piece.copy_(torch.from_numpy(y))
+                calls.append(c)
+            return run
+
+        op = pkg.dist.PipelinedRowBlockSpMV(n, rank, world, chunks, [piece_product(c) for c in range(chunks)], "cpu")
+        rows_ok = all(op.rows_of(c) == (bounds[c * world + rank], bounds[c * world + rank + 1]) for c in range(chunks))
+        x = torch.from_numpy(O.gen_vector(n))
+        y = op.step(x)
+        y = op.step(y.clone() * 1e-3 + x)  # the y of one step feeds the next: nothing crosses step boundaries
+        y1_ref = np.zeros(n)
+        O.csr_gaxpy32(rp.astype(np.int32), ci, v, x.numpy(), y1_ref)
+        x2 = y1_ref * 1e-3 + x.numpy()
+        y2_ref = np.zeros(n)
+        O.csr_gaxpy32(rp.astype(np.int32), ci, v, x2, y2_ref)
+        ok = np.array_equal(y.numpy(), y2_ref)
+        order_ok = calls == list(range(chunks)) * 2
+        with open(os.path.join(out_dir, "rank%d" % rank), "w") as f:
+            f.write("%d %d %d" % (ok, rows_ok, order_ok))
+    finally:
+        dist.destroy_process_group()
+
+
 def _spgemm_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -133,6 +177,16 @@ def test_rowblock_spmv_gloo(tmp_path, world, balanced):
             assert equal == "0"  # the ragged (padded) gather path was exercised
 
 
+@pytest.mark.parametrize("world,chunks", [(2, 1), (2, 4), (3, 2)])
+def test_pipelined_rowblock_spmv_gloo(tmp_path, world, chunks):
+    """chunked ownership + one asynchronous all-gather per chunk == the serial product, bit for bit"""
+    port = _free_port()
+    mp.spawn(_pipelined_worker, args=(world, port, chunks, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        ok, rows_ok, order_ok = open(tmp_path / ("rank%d" % r)).read().split()
+        assert ok == "1" and rows_ok == "1" and order_ok == "1"
+
+
 def test_bounds_helpers():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
@@ -143,3 +197,8 @@ def test_bounds_helpers():
     b = pkg.dist.nnz_balanced_bounds(rp, 2)
     assert b[0] == 0 and b[-1] == 6 and b[1] == int(np.searchsorted(rp, 20, side="left"))
     assert pkg.dist.nnz_balanced_bounds(np.zeros(5, dtype=np.int64), 4) == [0, 0, 0, 0, 4]
+    assert pkg.dist.pipelined_piece_bounds(24, 2, 3) == [0, 4, 8, 12, 16, 20, 24]
+    with pytest.raises(ValueError):
+        pkg.dist.pipelined_piece_bounds(25, 2, 3)
+    one = pkg.dist.PipelinedRowBlockSpMV(12, 0, 1, 3, [lambda x, y, c=c: y.fill_(c) for c in range(3)], "cpu")
+    assert one.step(None).tolist() == [0.0] * 4 + [1.0] * 4 + [2.0] * 4  # a single rank writes y in place

@@ -22,8 +22,10 @@ def _free_port():
     return p
 
 
-def _run(nproc, extra):
+def _run(nproc, extra, chunks=None):
     env = dict(os.environ, SPL_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if chunks is not None:
+        env["SPL_BENCH_CHUNKS"] = str(chunks)
     if nproc == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")]
     else:
@@ -49,3 +51,21 @@ def test_two_ranks_on_one_gpu(gpu, matrix):
         assert out["value"] > 0 and out["roofline"]["frac"] > 0
     # the same matrix: identical nnz, hence identical algorithmic bytes, whatever the rank count
     assert one["config"]["algorithmic_bytes"] == two["config"]["algorithmic_bytes"]
+    assert one["y_sha1"] == two["y_sha1"]  # the gathered y is the single-rank y, bit for bit
+    assert set(two["config"]["exchange_ms_per_step_by_chunks"]) == {"1", "2", "4"}  # all candidates were measured
+
+
+def test_pipelined_exchange_forced(gpu):
+    """the chunked, overlapped exchange (one asynchronous all-gather per chunk) forced on: 2 ranks x 4
+    chunks and 3 ranks x 2 chunks give the y of one rank"""
+    args = ["--rows", "480000"]
+    one = _run(1, args)
+    for nproc, chunks in ((2, 4), (3, 2), (2, 1)):
+        out = _run(nproc, args, chunks=chunks)
+        assert out["y_sha1"] == one["y_sha1"], (nproc, chunks)
+        assert out["config"]["algorithmic_bytes"] == one["config"]["algorithmic_bytes"]
+        if chunks > 1:
+            assert "%d chunks per rank" % chunks in out["config"]["workload"]
+            assert out["roofline"]["launches_per_step"] == chunks
+        else:
+            assert "one all-gather of y after the kernel" in out["config"]["workload"]
