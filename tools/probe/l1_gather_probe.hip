@@ -24,6 +24,46 @@ __global__ __launch_bounds__(1024) void gather_kernel(const double *__restrict__
   out[blockIdx.x * 1024 + threadIdx.x] = acc;
 }
 
+// MIX of the U gathers of a trip go through the L2 atomic unit instead (fetch-or with 0 returns the
+// value; it does not allocate a line in L1): does that path add to the L1-miss path's throughput?
+template <int U, int MIX>
+__global__ __launch_bounds__(1024) void gather_mix_kernel(double *__restrict__ table, uint32_t mask, int iters,
+                                                          double *__restrict__ out) {
+  uint32_t s = (blockIdx.x * 1024u + threadIdx.x) * 2654435761u + 12345u;
+  double acc = 0.0;
+  unsigned long long *t64 = reinterpret_cast<unsigned long long *>(table);
+  for (int it = 0; it < iters; ++it) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      s = s * 1664525u + 1013904223u;
+      const uint32_t i = (s >> 7) & mask;
+      if (u < MIX)
+        v[u] = __longlong_as_double((long long)__hip_atomic_fetch_or(t64 + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      else
+        v[u] = table[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += v[u];
+  }
+  out[blockIdx.x * 1024 + threadIdx.x] = acc;
+}
+
+template <int U, int MIX>
+double run_mix(double *table, uint32_t mask, int wgs, int iters, double *out) {
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  hipLaunchKernelGGL((gather_mix_kernel<U, MIX>), dim3(wgs), dim3(1024), 0, 0, table, mask, 4, out);
+  hipEventRecord(a);
+  hipLaunchKernelGGL((gather_mix_kernel<U, MIX>), dim3(wgs), dim3(1024), 0, 0, table, mask, iters, out);
+  hipEventRecord(b);
+  hipEventSynchronize(b);
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  return ms;
+}
+
 template <int U>
 double run(const double *table, uint32_t mask, int wgs, int iters, double *out) {
   hipEvent_t a, b;
@@ -55,6 +95,12 @@ int main() {
     const double g = (double)wgs * 1024 * iters * 8;
     printf("table %8.0f KB: U=8 %.3f ms = %.1f Ggather/s = %.3f gathers/clk/CU (2.4 GHz) | U=16 %.3f ms = %.3f gathers/clk/CU\n",
            n * 8 / 1024.0, ms8, g / ms8 / 1e6, g / (ms8 * 1e-3) / 256 / 2.4e9, ms16, g / (ms16 * 1e-3) / 256 / 2.4e9);
+    if (logn == 18) {
+      const double per = (double)wgs * 1024 * iters * 8 / 1e-3 / 256 / 2.4e9;
+      printf("  through the L2 atomic unit (fetch-or 0), of 8 gathers per trip: 8: %.3f  4: %.3f  2: %.3f  1: %.3f gathers/clk/CU\n",
+             per / run_mix<8, 8>(table, (uint32_t)(n - 1), wgs, iters, out), per / run_mix<8, 4>(table, (uint32_t)(n - 1), wgs, iters, out),
+             per / run_mix<8, 2>(table, (uint32_t)(n - 1), wgs, iters, out), per / run_mix<8, 1>(table, (uint32_t)(n - 1), wgs, iters, out));
+    }
     hipFree(table);
   }
   return 0;
