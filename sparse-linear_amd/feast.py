@@ -15,7 +15,7 @@ Interface: `eigSH m0 (emin, emax) A`, `geigSH m0 (emin, emax) A B` (Feast.hs:53-
 import numpy as np
 
 from . import umfpack as U
-from .sparse import Matrix, cmap, diag, hermitian, lin, mulV
+from .sparse import cmap, diag, hermitian, lin, mulV
 
 
 class FeastParams(object):

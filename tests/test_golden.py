@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import mat_to_tuple, tuples_equal
+from helpers import tuples_equal
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 

@@ -6,7 +6,7 @@ import pytest
 from hypothesis import HealthCheck, given, settings
 from hypothesis import strategies as st
 
-from helpers import arbdim, arbitrary_dims_triples, arbitrary_triples, arbval, mat_to_tuple, tuples_equal
+from helpers import arbdim, arbitrary_triples, arbval, mat_to_tuple, tuples_equal
 
 pytestmark = pytest.mark.gpu
 S = dict(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
@@ -72,7 +72,6 @@ def test_kronecker_identities(gpu, pkg, m, n):
 @settings(**S)
 @given(arb_matrix_args(), arb_matrix_args())
 def test_kronecker_format(gpu, pkg, O, a, b):
-    import scipy.sparse as sp
     A, B = pkg.fromTriples(*a), pkg.fromTriples(*b)
     K = pkg.kronecker(A, B)
     assert check_matrix(O, K)

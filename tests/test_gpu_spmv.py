@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings
 
-from helpers import arbdim, arbitrary_dims_triples, arbval, tuple_to_mat
+from helpers import arbitrary_dims_triples, arbval, tuple_to_mat
 from hypothesis import strategies as st
 
 pytestmark = pytest.mark.gpu
