@@ -32,6 +32,13 @@ constexpr int kBlock = 64;  // pivot block of the dense kernels (NB of band_nopi
 // regions up to this size start their level structure from the end vertex their parent hands down
 // (one BFS instead of two); larger regions, whose separators carry the flops, search properly
 constexpr int kHintBelow = 40000;
+// Level structures of regions of kTeamRegion vertices and more are built by a team of threads
+// (team_bfs): these traversals are the serial part of the dissection — the top regions, one after
+// the other down the tree.  A region's team is its share of the threads (the regions of a depth run
+// side by side).
+constexpr int kTeamRegion = 200000;
+constexpr unsigned kMaxTeam = 16;
+constexpr int kTeamFrontier = 4096;  // narrower levels are expanded by one thread
 
 struct Tree {
   int n = 0, nfronts = 0, maxdepth = 0;
@@ -80,10 +87,39 @@ struct Shared {
   // reached by a BFS (that BFS's stamp).  One word per vertex answers "in my region and not yet
   // reached" during a traversal.
   std::vector<int> verts, mark, level;
+  // claim[u] = (stamp of a team traversal << 32) | ~position of the frontier vertex that takes u
+  // (team_bfs); allocated only when the graph is large enough for a team
+  std::vector<uint64_t> claim;
+  int max_team = 1;
+  bool timing = false;
   std::atomic<int> stamp{0};
   Shared(int n_, const std::vector<int64_t> &xa, const std::vector<int> &ad, int leaf_)
       : n(n_), xadj(xa), adj(ad), leaf(leaf_), verts((size_t)n_), mark((size_t)n_, 0), level((size_t)n_, 0) {
     for (int i = 0; i < n; ++i) verts[(size_t)i] = i;
+    const unsigned hw = std::thread::hardware_concurrency();
+    max_team = (int)std::min<unsigned>(hw ? hw : 1, kMaxTeam);
+    timing = getenv("SPL_MF_TIMING") != nullptr;
+    if (const char *e = getenv("SPL_ND_TEAM")) max_team = std::max(1, std::min(atoi(e), 64));
+    if (n >= kTeamRegion && max_team > 1) claim.assign((size_t)n, 0);
+  }
+};
+
+// Barrier of a team of threads that exists for one traversal: spins briefly, then yields (the
+// process may own fewer cores than it sees).
+struct TeamBarrier {
+  const int n;
+  std::atomic<int> waiting{0};
+  std::atomic<int> generation{0};
+  explicit TeamBarrier(int n_) : n(n_) {}
+  void wait() {
+    const int gen = generation.load(std::memory_order_acquire);
+    if (waiting.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+      waiting.store(0, std::memory_order_relaxed);
+      generation.store(gen + 1, std::memory_order_release);
+      return;
+    }
+    for (int spins = 0; generation.load(std::memory_order_acquire) == gen; ++spins)
+      if (spins > 2000) std::this_thread::yield();
   }
 };
 
@@ -124,6 +160,123 @@ struct Worker {
     }
     level_ptr.push_back((int64_t)queue.size());
     return (int)queue.size();
+  }
+
+  // The same traversal by a team of threads, with the same result: queue order, level[] and
+  // level_ptr are exactly those of bfs().  A level is expanded in two sweeps over the frontier, each
+  // thread taking a contiguous slice of it: first every unreached neighbour u is claimed for the
+  // frontier position of the vertex that sees it (atomic max of stamp : ~position — the smallest
+  // position wins, as it would in the sequential scan; claims of older traversals carry smaller
+  // stamps); then every thread collects, in adjacency order, the neighbours its positions won, and
+  // the slices are concatenated in order.
+  int team_bfs(int root, int accept, int team, int cap) {
+    bfs_stamp = ++S.stamp;
+    const uint64_t tag = (uint64_t)(uint32_t)bfs_stamp << 32;
+    queue.assign((size_t)cap, 0);  // sized once for the whole region; qsize entries are valid
+    level_ptr.clear();
+    queue[0] = root;
+    S.mark[(size_t)root] = bfs_stamp;
+    S.level[(size_t)root] = 0;
+    level_ptr.push_back(0);
+    std::vector<std::vector<int>> found((size_t)team);
+    TeamBarrier barrier(team);
+    size_t lo = 0, hi = 1;  // current frontier = queue[lo, hi)
+    int cur = 0;
+    bool more = true;
+    std::atomic<uint64_t> *claim = reinterpret_cast<std::atomic<uint64_t> *>(S.claim.data());
+    auto body = [&](int t) {
+      for (;;) {
+        if (!more) return;
+        if (hi - lo < (size_t)kTeamFrontier) {
+          // narrow levels are not worth a barrier each: the first thread expands them by itself,
+          // as bfs() does, until the frontier is wide again or the traversal ends
+          if (t == 0) {
+            while (more && hi - lo < (size_t)kTeamFrontier) {
+              size_t end = hi;
+              for (size_t i = lo; i < hi; ++i) {
+                const int v = queue[i];
+                for (int64_t p = S.xadj[(size_t)v]; p < S.xadj[(size_t)v + 1]; ++p) {
+                  const int u = S.adj[(size_t)p];
+                  if (S.mark[(size_t)u] != accept) continue;
+                  S.mark[(size_t)u] = bfs_stamp;
+                  S.level[(size_t)u] = cur + 1;
+                  queue[end++] = u;
+                }
+              }
+              more = end > hi;
+              if (more) {
+                level_ptr.push_back((int64_t)hi);
+                lo = hi;
+                hi = end;
+                ++cur;
+              }
+            }
+          }
+          barrier.wait();
+          continue;
+        }
+        const size_t len = hi - lo, a = lo + len * (size_t)t / (size_t)team, b = lo + len * (size_t)(t + 1) / (size_t)team;
+        for (size_t i = a; i < b; ++i) {
+          const int v = queue[i];
+          const uint64_t mine = tag | (uint32_t)~(uint32_t)i;
+          for (int64_t p = S.xadj[(size_t)v]; p < S.xadj[(size_t)v + 1]; ++p) {
+            const int u = S.adj[(size_t)p];
+            if (__atomic_load_n(&S.mark[(size_t)u], __ATOMIC_RELAXED) != accept) continue;
+            uint64_t seen = claim[(size_t)u].load(std::memory_order_relaxed);
+            while (seen < mine && !claim[(size_t)u].compare_exchange_weak(seen, mine, std::memory_order_relaxed)) {
+            }
+          }
+        }
+        barrier.wait();
+        std::vector<int> &out = found[(size_t)t];
+        out.clear();
+        for (size_t i = a; i < b; ++i) {
+          const int v = queue[i];
+          const uint64_t mine = tag | (uint32_t)~(uint32_t)i;
+          for (int64_t p = S.xadj[(size_t)v]; p < S.xadj[(size_t)v + 1]; ++p) {
+            const int u = S.adj[(size_t)p];
+            if (__atomic_load_n(&S.mark[(size_t)u], __ATOMIC_RELAXED) != accept) continue;
+            if (claim[(size_t)u].load(std::memory_order_relaxed) != mine) continue;
+            __atomic_store_n(&S.mark[(size_t)u], bfs_stamp, __ATOMIC_RELAXED);  // also stops a repeated neighbour
+            S.level[(size_t)u] = cur + 1;
+            out.push_back(u);
+          }
+        }
+        barrier.wait();
+        size_t before = hi, total = 0;
+        for (int k = 0; k < team; ++k) {
+          if (k < t) before += found[(size_t)k].size();
+          total += found[(size_t)k].size();
+        }
+        std::copy(out.begin(), out.end(), queue.begin() + (int64_t)before);
+        barrier.wait();
+        if (t == 0) {
+          more = total > 0;
+          if (more) {
+            level_ptr.push_back((int64_t)hi);
+            lo = hi;
+            hi += total;
+            ++cur;
+          }
+        }
+        barrier.wait();
+      }
+    };
+    std::vector<std::thread> others;
+    for (int t = 1; t < team; ++t) others.emplace_back(body, t);
+    body(0);
+    for (std::thread &th : others) th.join();
+    queue.resize(hi);
+    level_ptr.push_back((int64_t)queue.size());
+    return (int)queue.size();
+  }
+
+  // bfs or team_bfs, by the size of the region
+  int traverse(int root, int accept, int size) {
+    // regions of one depth run side by side: each gets its share of the threads
+    const int team = (int)(((int64_t)S.max_team * size + S.n / 2) / std::max(S.n, 1));
+    if (team >= 2 && size >= kTeamRegion && !S.claim.empty()) return team_bfs(root, accept, team, size);
+    return bfs(root, accept);
   }
 
   static void append(std::vector<Node> &dst, std::vector<Node> &&src) {
@@ -177,16 +330,27 @@ struct Worker {
   std::vector<Node> dissect(int lo, int hi, int depth, int hint = -1) {
     const int size = hi - lo;
     if (size <= S.leaf) return make_leaf(lo, hi);
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {  // SPL_MF_TIMING: the phases of the top regions
+      if (!S.timing || depth > 2) return;
+      const auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "[dissect] depth %d, %9d vertices: %-22s %8.1f ms\n", depth, size, what,
+              std::chrono::duration<double, std::milli>(now - t_last).count());
+      t_last = now;
+    };
     region_stamp = ++S.stamp;
     for (int i = lo; i < hi; ++i) S.mark[(size_t)S.verts[(size_t)i]] = region_stamp;
+    lap("region stamp");
     int reached;
     if (hint >= 0 && size <= kHintBelow && S.mark[(size_t)hint] == region_stamp) {
       reached = bfs(hint, region_stamp);
     } else {
-      reached = bfs(S.verts[(size_t)lo], region_stamp);
+      reached = traverse(S.verts[(size_t)lo], region_stamp, size);
+      lap("first level structure");
       // connected: once more from the far end (deeper, narrower levels); every vertex now carries
       // the first traversal's stamp
-      if (reached == size) reached = bfs(queue.back(), bfs_stamp);
+      if (reached == size) reached = traverse(queue.back(), bfs_stamp, size);
+      lap("second level structure");
     }
     if (reached < size) {
       // disconnected region: no separator needed.  All components are found and dealt into two
@@ -259,6 +423,7 @@ struct Worker {
     std::copy(side1.begin(), side1.end(), S.verts.begin() + lo);
     std::copy(side2.begin(), side2.end(), S.verts.begin() + lo + (int)side1.size());
     const int n1 = (int)side1.size(), n2 = (int)side2.size();
+    lap("separator and sides");
     const int end1 = queue.front(), end2 = queue.back();  // the two ends of this level structure
     std::vector<int>().swap(side1);
     std::vector<int>().swap(side2);

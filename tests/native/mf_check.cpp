@@ -65,6 +65,10 @@ int main(int argc, char **argv) {
     }
   int maxfs = 0;
   for (int f = 0; f < T.nfronts; ++f) maxfs = maxfs > T.fs(f) ? maxfs : T.fs(f);
-  printf("n=%d fronts=%d depth=%d maxfront=%d flops=%.4g bad=%ld\n", n, T.nfronts, T.maxdepth, maxfs, T.flops, bad);
+  unsigned long long h = 1469598103934665603ull;  // FNV-1a of the ordering and the tree
+  for (int v : T.perm) { h ^= (unsigned)v; h *= 1099511628211ull; }
+  for (int v : T.parent) { h ^= (unsigned)v; h *= 1099511628211ull; }
+  printf("n=%d fronts=%d depth=%d maxfront=%d flops=%.4g bad=%ld hash=%016llx\n", n, T.nfronts, T.maxdepth, maxfs, T.flops,
+         bad, h);
   return bad != 0;
 }

@@ -15,16 +15,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def checker(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("mf") / "mf_check")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "sparse-linear_amd", "csrc"),
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "sparse-linear_amd", "csrc"),
                     os.path.join(ROOT, "tests", "native", "mf_check.cpp"), "-o", exe], check=True)
     return exe
 
 
-def run(checker, S, leaf):
+def run(checker, S, leaf, team=None):
     S = sp.csc_matrix(S)
     S.sort_indices()
     text = "%d %d\n%s\n%s\n" % (S.shape[0], S.nnz, " ".join(map(str, S.indptr)), " ".join(map(str, S.indices)))
-    r = subprocess.run([checker, str(leaf)], input=text, capture_output=True, text=True)
+    env = dict(os.environ) if team is None else dict(os.environ, SPL_ND_TEAM=str(team))
+    r = subprocess.run([checker, str(leaf)], input=text, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     return dict(kv.split("=") for kv in r.stdout.split())
 
@@ -60,3 +61,13 @@ def test_tree_invariants_on_irregular_patterns(checker):
     # 1 x 1 and diagonal matrices
     assert int(run(checker, sp.identity(1), 64)["bad"]) == 0
     assert int(run(checker, sp.identity(500), 64)["bad"]) == 0
+
+
+def test_team_traversals_reproduce_the_sequential_tree(checker):
+    """regions of 200 000 vertices and more build their level structures with a team of threads
+    (team_bfs): the ordering and the tree must be those of one thread, whatever the team"""
+    A = poisson(62, 3)  # 238 328 vertices: the root region and nothing else goes to the team
+    outs = [run(checker, A, 256, team=t) for t in (1, 2, 5)]
+    assert all(int(o["bad"]) == 0 for o in outs)
+    assert outs[0]["hash"] == outs[1]["hash"] == outs[2]["hash"]
+    assert outs[0]["flops"] == outs[1]["flops"]
