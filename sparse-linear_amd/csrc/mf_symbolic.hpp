@@ -186,11 +186,15 @@ struct Worker {
     std::atomic<uint64_t> *claim = reinterpret_cast<std::atomic<uint64_t> *>(S.claim.data());
     auto body = [&](int t) {
       for (;;) {
+        // The shared state (more, lo, hi, cur) is only written by the first thread, in the two
+        // places marked (W); a barrier separates each of them from the reads of every thread on
+        // either side, so all threads take the same branch here.
         if (!more) return;
         if (hi - lo < (size_t)kTeamFrontier) {
           // narrow levels are not worth a barrier each: the first thread expands them by itself,
           // as bfs() does, until the frontier is wide again or the traversal ends
-          if (t == 0) {
+          barrier.wait();  // everyone has read the state
+          if (t == 0) {    // (W)
             while (more && hi - lo < (size_t)kTeamFrontier) {
               size_t end = hi;
               for (size_t i = lo; i < hi; ++i) {
@@ -250,7 +254,7 @@ struct Worker {
         }
         std::copy(out.begin(), out.end(), queue.begin() + (int64_t)before);
         barrier.wait();
-        if (t == 0) {
+        if (t == 0) {  // (W)
           more = total > 0;
           if (more) {
             level_ptr.push_back((int64_t)hi);
