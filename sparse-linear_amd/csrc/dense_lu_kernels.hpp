@@ -272,8 +272,11 @@ struct Region {
   int npiv;  // pivots of the (partial) factorisation: the look-ahead only factors blocks below it
 };
 
-// one 64 x 64 tile (tx, ty) of the update; `lookahead`: tile (0,0) goes on to factor the next block
-__device__ __forceinline__ void update_tile(const Band &b, const Region &g, int tx, int ty, bool lookahead,
+// one 64 x 64 tile (tx, ty) of the update; LOOKAHEAD: tile (0,0) goes on to factor the next block
+// (a template parameter: the one-workgroup front kernel calls this without the look-ahead and must
+// not carry the registers of the diagonal-block factorisation through its update tiles)
+template <bool LOOKAHEAD>
+__device__ __forceinline__ void update_tile(const Band &b, const Region &g, int tx, int ty,
                                             int *__restrict__ singular, double *__restrict__ next_invL,
                                             double *__restrict__ next_invU, double *dsm) {
   const int r0 = g.rb + tx * 64, c0 = g.cb + ty * 64;
@@ -380,7 +383,8 @@ __device__ __forceinline__ void update_tile(const Band &b, const Region &g, int 
           if (i < g.re && j < g.ce && b.in_band(i, j)) b.at(i, j) = cold[a][c][r];
         }
   }
-  if (!lookahead || tx != 0 || ty != 0 || r0 >= g.npiv) return;
+  if (!LOOKAHEAD) return;
+  if (tx != 0 || ty != 0 || r0 >= g.npiv) return;
   // next diagonal block: rows/columns r0 .. r0 + jbn - 1, values still in registers
   const int jbn = min(NB, g.npiv - r0);
   __syncthreads();  // all waves are done reading Us / Ls
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(256) void gemm_update_kernel(Band b, Region g, int 
     ty = (int)blockIdx.x < g.ntile_rows ? 0 : (int)blockIdx.x - g.ntile_rows + 1;
   }
   extern __shared__ __attribute__((aligned(16))) double dsm[];
-  update_tile(b, g, tx, ty, true, singular, next_invL, next_invU, dsm);
+  update_tile<true>(b, g, tx, ty, singular, next_invL, next_invU, dsm);
 }
 
 // The whole partial factorisation of one SMALL dense front by ONE workgroup (the multifrontal tree
@@ -437,7 +441,7 @@ __device__ __forceinline__ void front_factor_by_workgroup(const Band &b, int npi
     }
     Region g{j0 + jb, n, j0 + jb, n, j0, jb, 0, ntile, npiv};
     for (int t = 0; t < ntile * ntile; ++t) {
-      update_tile(b, g, t % ntile, t / ntile, false, singular, nullptr, nullptr, dsm);
+      update_tile<false>(b, g, t % ntile, t / ntile, singular, nullptr, nullptr, dsm);
       __syncthreads();
     }
   }

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const int *__restrict__ li
 }
 
 // small fronts of a tree level: one workgroup per front runs the whole partial factorisation
-__global__ __launch_bounds__(256) void front_factor_kernel(const int *__restrict__ list, TreeView t,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void front_factor_kernel(const int *__restrict__ list, TreeView t,
                                                            double *__restrict__ invs, int *__restrict__ singular) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   const int f = list[blockIdx.x];
