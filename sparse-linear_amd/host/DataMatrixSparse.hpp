@@ -227,7 +227,23 @@ struct Analysis {
 struct Factors {
   std::shared_ptr<void *> fnum;
   int status = 0;
+  // what the object holds now (spl_umfpack_stats): path, n, kl, ku, device bytes, flops, fronts
+  struct Stats {
+    int path = -1, n = 0, kl = 0, ku = 0, fronts = 0;
+    double device_bytes = 0, flops = 0;
+  };
+  Stats stats() const {
+    double out[8];
+    Stats s;
+    if (spl_umfpack_stats(*fnum, out) != 0) detail::oops("Factors::stats", "invalid Numeric object");
+    s.path = (int)out[0]; s.n = (int)out[1]; s.kl = (int)out[2]; s.ku = (int)out[3];
+    s.device_bytes = out[4]; s.flops = out[5]; s.fronts = (int)out[6];
+    return s;
+  }
 };
+
+// gives the device blocks the library keeps for reuse back to the driver (spl_release_cached_memory)
+inline unsigned long long releaseCachedMemory() { return spl_release_cached_memory(); }
 
 inline Analysis analyze(const Matrix &mat) {  // Umfpack.hs:60-69
   detail::Const c(mat);

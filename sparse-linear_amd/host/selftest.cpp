@@ -139,7 +139,10 @@ int main() {
     EXPECT(U::solve(ident(5), v) == v);
     U::Factors f = U::factor(ident(5), U::analyze(ident(5)));
     EXPECT(U::linearSolve_(f, U::UmfpackTrans, ident(5), v) == v);
+    const U::Factors::Stats st = f.stats();
+    EXPECT(st.n == 5 && st.path == 1 && st.kl == 0 && st.ku == 0 && st.fronts == 0 && st.device_bytes > 0);
   }
+  EXPECT(U::releaseCachedMemory() == 0);  // nothing of 1 GiB was ever allocated here
   std::printf(failures ? "selftest: %d FAILED\n" : "selftest: all passed\n", failures);
   return failures ? 1 : 0;
 }
