@@ -182,7 +182,67 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   front_factor_by_workgroup(b, np, invs + t.ioff[f], singular, dsm);
 }
 
-constexpr int kSmallFront = 1024;  // fronts up to this size are factored by one workgroup each
+// Medium fronts of a tree level, all together, one block step at a time: a front of a few
+// thousand rows is a chain of launches that each fill a fraction of the chip, and a level holds tens
+// to hundreds of them.  Step s of every listed front that still has pivots left goes into ONE
+// launch per phase (flat grids: prefix = tiles before each front at this step, computed on the host):
+// the diagonal blocks first (mid_diag_kernel, step 0 only), then per step the panel solves and the
+// K = 64 update whose tile (0,0) factors the next diagonal block on the way (the look-ahead).
+__device__ __forceinline__ Band mid_front(const TreeView &t, int f) {
+  const int fs = t.np[f] + t.nb[f];
+  return Band{t.front(f), fs, fs, fs, t.ld[f] + 1, 0};
+}
+__device__ __forceinline__ double *mid_slot(const TreeView &t, double *invs, int f, int j0) {
+  return invs + t.ioff[f] + (int64_t)(j0 / NB) * (2 * NB * NB);
+}
+
+__global__ __launch_bounds__(256) void mid_diag_kernel(const int *__restrict__ list, TreeView t,
+                                                       double *__restrict__ invs, int *__restrict__ singular) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  const int f = list[blockIdx.x];
+  const Band b = mid_front(t, f);
+  const int jb = min(NB, t.np[f]);
+  double(*D)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);
+  double(*lcol)[NB] = reinterpret_cast<double(*)[NB]>(dsm + NB * LDP);
+  const int tr = threadIdx.x & 63, tc = threadIdx.x >> 6;
+  for (int c = tc; c < NB; c += 4) D[tr][c] = (tr < jb && c < jb) ? b.get(tr, c) : (tr == c ? 1.0 : 0.0);
+  __syncthreads();
+  double *slot = mid_slot(t, invs, f, 0);
+  diag_block_factor(b, 0, jb, D, lcol, singular, slot, slot + NB * NB);
+}
+
+__global__ __launch_bounds__(256) void mid_trsm_kernel(const int *__restrict__ list,
+                                                       const int64_t *__restrict__ prefix, int count, int step,
+                                                       TreeView t, double *__restrict__ invs) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  const int64_t flat = prefix[0] + blockIdx.x;
+  const int fi = item_of_tile(prefix, count, flat);
+  const int f = list[fi];
+  const Band b = mid_front(t, f);
+  const int j0 = step * NB, jb = min(NB, t.np[f] - j0), rest = b.n - (j0 + jb);
+  const double *slot = mid_slot(t, invs, f, j0);
+  trsm_tile(b, j0, jb, rest, rest, slot, slot + NB * NB, (int)(flat - prefix[fi]), dsm);
+}
+
+__global__ __launch_bounds__(256) void mid_update_kernel(const int *__restrict__ list,
+                                                         const int64_t *__restrict__ prefix, int count, int step,
+                                                         TreeView t, double *__restrict__ invs,
+                                                         int *__restrict__ singular) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  const int64_t flat = prefix[0] + blockIdx.x;
+  const int fi = item_of_tile(prefix, count, flat);
+  const int f = list[fi];
+  const Band b = mid_front(t, f);
+  const int np = t.np[f], j0 = step * NB, jb = min(NB, np - j0), origin = j0 + jb;
+  const int ntile = (b.n - origin + 63) / 64;
+  const int tile = (int)(flat - prefix[fi]);
+  const Region g{origin, b.n, origin, b.n, j0, jb, 0, ntile, np};
+  double *next = mid_slot(t, invs, f, origin);  // only written when origin is a pivot block
+  update_tile<true>(b, g, tile % ntile, tile / ntile, singular, next, next + NB * NB, dsm);
+}
+
+constexpr int kSmallFront = 128;   // fronts up to this size are factored by one workgroup each
+constexpr int kMidFront = 4096;    // ... up to this size in lockstep with the others of their level
 constexpr int kStreams = 8;        // larger fronts of a level are spread over this many streams
 
 // ---- solves ---------------------------------------------------------------------------------------
@@ -643,6 +703,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   mf::Factors &F = *Fp;
   F.tree = tree;
   const int nd = T.maxdepth + 1, nf = T.nfronts;
+  const int small_limit = getenv("SPL_MF_SMALL") ? std::max(64, atoi(getenv("SPL_MF_SMALL"))) : kSmallFront;  // tuning knob
   // ---- memory plan: the smallest cut depth whose transient part fits next to the resident part
   Plan plan;
   {
@@ -705,7 +766,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   for (int d = 0; d < nd; ++d) {
     upload_vec(F.level_lists[(size_t)d], T.by_depth[(size_t)d], s);
     for (int f : T.by_depth[(size_t)d])
-      if (T.np[(size_t)f] > 0 && T.fs(f) <= kSmallFront) F.h_small[(size_t)d].push_back(f);
+      if (T.np[(size_t)f] > 0 && T.fs(f) <= small_limit) F.h_small[(size_t)d].push_back(f);
     F.small_counts[(size_t)d] = (int)F.h_small[(size_t)d].size();
     upload_vec(F.small_lists[(size_t)d], F.h_small[(size_t)d], s);
     std::vector<int> one_wg;
@@ -761,11 +822,19 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   if (!attr_set) {
     SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&front_factor_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mid_trsm_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
     attr_set = true;
   }
   F.make_streams();
   hipStream_t *side = F.side;
   auto region_of = [&](int d) { return (d & 1) ? region1.get() : region0.get(); };
+  // medium fronts (kSmallFront < size <= mid_limit) go through the lockstep kernels; SPL_MF_MID=0
+  // sends them down the per-front pipeline instead (ablation)
+  const int mid_limit = (getenv("SPL_MF_MID") && atoi(getenv("SPL_MF_MID")) == 0) ? small_limit : std::max(kMidFront, small_limit);
+  std::vector<DBuf<int>> mid_lists;          // alive until the factorisation has run
+  std::vector<DBuf<int64_t>> mid_prefixes;
+  std::vector<std::vector<int64_t>> staged64;
   // [begin, end) of the ids lo..hi inside an ascending list
   auto range_of = [](const std::vector<int> &L, int lo, int hi, int &begin, int &end) {
     begin = (int)(std::lower_bound(L.begin(), L.end(), lo) - L.begin());
@@ -820,15 +889,73 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
       // small fronts: one launch, one workgroup each; large fronts: the multi-launch blocked
       // factorisation, independent fronts spread over side streams
       SPL_HIP(hipStreamSynchronize(s));
+      if (timing) {
+        char what[64];
+        snprintf(what, sizeof what, "level %d: assembly", d);
+        lap(what);
+      }
       int s0, s1;
       range_of(F.h_small[(size_t)d], lo, hi, s0, s1);
       if (s1 > s0)
         hipLaunchKernelGGL(front_factor_kernel, dim3((unsigned)(s1 - s0)), dim3(256), 2 * kTileBytes, s,
                            F.small_lists[(size_t)d].get() + s0, F.view, F.invs.get(), singular.get());
+      // medium fronts: lockstep over block steps, one flat launch per phase and step
+      {
+        std::vector<int> mid;
+        int steps = 0;
+        for (int i = b0; i < b1; ++i) {
+          const int f = T.by_depth[(size_t)d][(size_t)i];
+          if (T.np[(size_t)f] == 0 || T.fs(f) <= small_limit || T.fs(f) > mid_limit) continue;
+          mid.push_back(f);
+          steps = std::max(steps, (T.np[(size_t)f] + NB - 1) / NB);
+        }
+        if (!mid.empty()) {
+          const int count = (int)mid.size();
+          // prefix arrays of all steps: [step][phase 0 = panel solves, 1 = update][count + 1]
+          std::vector<int64_t> pre((size_t)steps * 2 * (size_t)(count + 1), 0);
+          for (int st = 0; st < steps; ++st) {
+            int64_t *pt = pre.data() + ((size_t)st * 2) * (size_t)(count + 1), *pu = pt + (count + 1);
+            for (int k = 0; k < count; ++k) {
+              const int f = mid[(size_t)k], np = T.np[(size_t)f], j0 = st * NB;
+              int64_t tt = 0, tu = 0;
+              if (j0 < np) {
+                const int jb = std::min(NB, np - j0), rest = T.fs(f) - (j0 + jb);
+                const int64_t nt = (rest + 63) / 64;
+                tt = 2 * nt;
+                tu = nt * nt;
+              }
+              pt[k + 1] = pt[k] + tt;
+              pu[k + 1] = pu[k] + tu;
+            }
+          }
+          mid_lists.emplace_back();
+          mid_prefixes.emplace_back();
+          upload_vec(mid_lists.back(), mid, s);
+          upload_vec(mid_prefixes.back(), pre, s);
+          staged.push_back(std::move(mid));
+          staged64.push_back(std::move(pre));
+          const std::vector<int64_t> &hp = staged64.back();
+          const int *dl = mid_lists.back().get();
+          const int64_t *dp = mid_prefixes.back().get();
+          hipLaunchKernelGGL(mid_diag_kernel, dim3((unsigned)count), dim3(256), kTileBytes + 2 * NB * sizeof(double), s,
+                             dl, F.view, F.invs.get(), singular.get());
+          for (int st = 0; st < steps; ++st) {
+            const size_t base = ((size_t)st * 2) * (size_t)(count + 1);
+            const int64_t nt = hp[base + (size_t)count], nu = hp[base + (size_t)(count + 1) + (size_t)count];
+            if (nt > 0)
+              hipLaunchKernelGGL(mid_trsm_kernel, dim3((unsigned)nt), dim3(256), 2 * kTileBytes, s, dl, dp + base, count,
+                                 st, F.view, F.invs.get());
+            if (nu > 0)
+              hipLaunchKernelGGL(mid_update_kernel, dim3((unsigned)nu), dim3(256),
+                                 kTileBytes + 2 * NB * sizeof(double), s, dl, dp + base + (size_t)(count + 1), count, st,
+                                 F.view, F.invs.get(), singular.get());
+          }
+        }
+      }
       int turn = 0;
       for (int i = b0; i < b1; ++i) {
         const int f = T.by_depth[(size_t)d][(size_t)i];
-        if (T.np[(size_t)f] == 0 || T.fs(f) <= kSmallFront) continue;
+        if (T.np[(size_t)f] == 0 || T.fs(f) <= mid_limit) continue;
         const Band b = dense_view(region_of(d) + plan.foff[(size_t)f], T.fs(f), T.ld[(size_t)f]);
         factor_loop(b, T.np[(size_t)f], F.invs.get() + T.ioff[(size_t)f], singular.get(), side[turn++ % kStreams]);
       }

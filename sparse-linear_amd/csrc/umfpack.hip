@@ -588,9 +588,14 @@ int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
       std::shared_ptr<mf::Tree> T = tree_job.get();
       if (timing) fprintf(stderr, "[symbolic] nested dissection tree ready at %.1f ms\n", since());
       const double band_flops = 2.0 * S->n * (double)S->kl * (double)S->ku;
-      // measured: the tree wins from about 7x fewer flops on (many small fronts run below the
-      // MFMA rate of the band's large windows; 32^3 Poisson is the break-even)
-      if (force_mf || (band_flops > 1e9 && 7.0 * T->flops < band_flops)) S->tree = T;
+      // Measured model of the two factorisations (MI355X, tools/bench_band_vs_tree.py): the band
+      // is a chain of n / 64 block steps of a few launches each, about 1.4 us per column however
+      // narrow it is, plus its flops at the rate of its large windows; the tree costs a few
+      // launches per level (about 6 ms for a whole tree) plus its flops at a lower rate (many small
+      // fronts).  The break-even is near n = 5 000 on 2-D and 3-D meshes alike.
+      const double t_band = 1.4e-6 * S->n + band_flops / 3e13;
+      const double t_tree = 6e-3 + T->flops / 2e13;
+      if (force_mf || t_tree < t_band) S->tree = T;
     }
     *SymbolicOut = S;
     return UMFPACK_OK;
