@@ -595,6 +595,7 @@ struct Factors {
   std::vector<std::vector<int64_t>> h_ctile[2], h_ptile, h_utile;
   std::vector<DBuf<int64_t>> ctile[2], ptile, utile;
   int singular = 0;
+  int big_solve = 0;  // fronts above this size are solved by many workgroups (kBigSolve; SPL_MF_BIGSOLVE)
   // independent large fronts of a level run on these (factorisation and solves)
   hipStream_t side[kStreams] = {};
   int nside = 0;
@@ -702,6 +703,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   std::unique_ptr<mf::Factors> Fp(new mf::Factors());
   mf::Factors &F = *Fp;
   F.tree = tree;
+  F.big_solve = getenv("SPL_MF_BIGSOLVE") ? std::max(256, atoi(getenv("SPL_MF_BIGSOLVE"))) : kBigSolve;
   const int nd = T.maxdepth + 1, nf = T.nfronts;
   const int small_limit = getenv("SPL_MF_SMALL") ? std::max(64, atoi(getenv("SPL_MF_SMALL"))) : kSmallFront;  // tuning knob
   // ---- memory plan: the smallest cut depth whose transient part fits next to the resident part
@@ -771,7 +773,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
     upload_vec(F.small_lists[(size_t)d], F.h_small[(size_t)d], s);
     std::vector<int> one_wg;
     for (int f : T.by_depth[(size_t)d])
-      if (T.fs(f) <= kBigSolve) one_wg.push_back(f);
+      if (T.fs(f) <= F.big_solve) one_wg.push_back(f);
     F.solve_counts[(size_t)d] = (int)one_wg.size();
     staged.push_back(std::move(one_wg));
     upload_vec(F.solve_lists[(size_t)d], staged.back(), s);
@@ -831,7 +833,8 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   auto region_of = [&](int d) { return (d & 1) ? region1.get() : region0.get(); };
   // medium fronts (kSmallFront < size <= mid_limit) go through the lockstep kernels; SPL_MF_MID=0
   // sends them down the per-front pipeline instead (ablation)
-  const int mid_limit = (getenv("SPL_MF_MID") && atoi(getenv("SPL_MF_MID")) == 0) ? small_limit : std::max(kMidFront, small_limit);
+  const int mid_limit = (getenv("SPL_MF_MID") && atoi(getenv("SPL_MF_MID")) == 0) ? small_limit
+                        : std::max(getenv("SPL_MF_MIDMAX") ? atoi(getenv("SPL_MF_MIDMAX")) : kMidFront, small_limit);
   std::vector<DBuf<int>> mid_lists;          // alive until the factorisation has run
   std::vector<DBuf<int64_t>> mid_prefixes;
   std::vector<std::vector<int64_t>> staged64;
@@ -1046,7 +1049,7 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
   LevelFork fork(F, s0);
   auto large_fronts = [&](int d) {
     int count = 0;
-    for (int f : T.by_depth[(size_t)d]) count += (T.fs(f) > kBigSolve && T.np[(size_t)f] > 0) ? 1 : 0;
+    for (int f : T.by_depth[(size_t)d]) count += (T.fs(f) > F.big_solve && T.np[(size_t)f] > 0) ? 1 : 0;
     return count;
   };
   hipStream_t s = s0;
@@ -1079,7 +1082,7 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
     fork.begin(large_fronts(d));
     for (int f : T.by_depth[(size_t)d]) {
       const int np = T.np[(size_t)f], nb = T.nb[(size_t)f], fs = np + nb;
-      if (fs <= kBigSolve || np == 0) continue;
+      if (fs <= F.big_solve || np == 0) continue;
       s = fork.next();
       double *P = const_cast<double *>(arena) + T.poff[(size_t)f];
       const double *U = arena + T.uoff[(size_t)f];
@@ -1109,7 +1112,7 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
     fork.begin(large_fronts(d));
     for (int f : T.by_depth[(size_t)d]) {
       const int np = T.np[(size_t)f], nb = T.nb[(size_t)f], fs = np + nb;
-      if (fs <= kBigSolve || np == 0) continue;
+      if (fs <= F.big_solve || np == 0) continue;
       s = fork.next();
       double *P = const_cast<double *>(arena) + T.poff[(size_t)f];
       const double *U = arena + T.uoff[(size_t)f];
