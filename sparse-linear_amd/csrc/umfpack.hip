@@ -697,6 +697,15 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B)
     DeviceGuard g(N->device);
     hipStream_t s = nullptr;
     if (n == 0 || k == 0) return N->singular ? UMFPACK_WARNING_singular_matrix : UMFPACK_OK;
+    const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // phase times on stderr (diagnostic)
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+      if (!timing) return;
+      (void)hipStreamSynchronize(s);
+      const auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "[solve] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+      t_last = now;
+    };
     const size_t stride = (size_t)n;
     const int kalloc = k == 1 ? 1 : (k + kSolveGroup - 1) / kSolveGroup * kSolveGroup;
     const size_t total = stride * (size_t)kalloc, used = stride * (size_t)k;
@@ -711,8 +720,10 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B)
     std::unique_lock<std::mutex> turn(N->mu, std::defer_lock);
     if (N->speculative) turn.lock();
     std::vector<double> omega((size_t)k, 0.0), on((size_t)k, 0.0);
+    lap("buffers, upload of b");
   again:
     factor_solve(N, sys, db.get(), dx.get(), dwork.get(), k, stride, s);
+    lap("solve with the factors");
     if (!N->singular) {
       const Matrix *op = sys == UMFPACK_A ? N->A : N->At;
       auto backward_error = [&](const double *x, double *r, std::vector<double> &out) {
@@ -730,6 +741,7 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B)
       };
       const double eps = 2.220446049250313e-16;
       backward_error(dx.get(), dr.get(), omega);
+      lap("residual, backward error");
       std::vector<char> active((size_t)k);
       int nactive = 0;
       for (int c = 0; c < k; ++c) nactive += (active[(size_t)c] = omega[(size_t)c] >= eps);
@@ -739,6 +751,7 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B)
         hipLaunchKernelGGL(add_kernel, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, s, used, dxn.get(),
                            dd.get());
         backward_error(dxn.get(), drn.get(), on);
+        lap("refinement step");
         for (int c = 0; c < k; ++c) {
           if (!active[(size_t)c]) continue;
           const double o_new = on[(size_t)c], o_old = omega[(size_t)c];
@@ -774,6 +787,7 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B)
     SPL_HIP(hipMemcpyAsync(X, dx.get(), used * sizeof(double), hipMemcpyDeviceToHost, s));
     SPL_HIP(hipStreamSynchronize(s));
     SPL_HIP(hipGetLastError());
+    lap("download of x");
     return N->singular ? UMFPACK_WARNING_singular_matrix : UMFPACK_OK;
   } catch (const DeviceError &e) {
     return e.status == SPL_ERROR_out_of_memory ? UMFPACK_ERROR_out_of_memory : UMFPACK_ERROR_internal_error;
