@@ -23,7 +23,9 @@
 // a speculation that every solve checks — umfpack.hip).
 #include <stdio.h>
 #include <chrono>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "dense_lu_kernels.hpp"
@@ -596,14 +598,26 @@ struct Factors {
   std::vector<DBuf<int64_t>> ctile[2], ptile, utile;
   int singular = 0;
   int big_solve = 0;  // fronts above this size are solved by many workgroups (kBigSolve; SPL_MF_BIGSOLVE)
-  // independent large fronts of a level run on these (factorisation and solves)
-  hipStream_t side[kStreams] = {};
+  // independent large fronts of a level run on these (factorisation and solves): one set per
+  // device for the whole process, created on first use and never destroyed (objects come and go by
+  // the thousand in a contour integration; work of different objects on the same stream is merely
+  // ordered)
+  hipStream_t *side = nullptr;
   int nside = 0;
   void make_streams() {
-    for (; nside < kStreams; ++nside) SPL_HIP(hipStreamCreateWithFlags(&side[nside], hipStreamNonBlocking));
-  }
-  ~Factors() {
-    for (int i = 0; i < nside; ++i) (void)hipStreamDestroy(side[i]);
+    static std::mutex mu;
+    static std::map<int, std::unique_ptr<hipStream_t[]>> sets;
+    int device = 0;
+    SPL_HIP(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lk(mu);
+    std::unique_ptr<hipStream_t[]> &set = sets[device];
+    if (!set) {
+      std::unique_ptr<hipStream_t[]> fresh(new hipStream_t[kStreams]);
+      for (int i = 0; i < kStreams; ++i) SPL_HIP(hipStreamCreateWithFlags(&fresh[i], hipStreamNonBlocking));
+      set = std::move(fresh);
+    }
+    side = set.get();
+    nside = kStreams;
   }
 };
 
