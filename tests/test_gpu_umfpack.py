@@ -253,10 +253,18 @@ def _grid_matrix(pkg, O, kind, m):
     return n, pkg.Matrix(n, n, rp, ci, v)
 
 
+@pytest.mark.parametrize("limits", ["default", "small"])
 @pytest.mark.parametrize("kind,m", [("2d", 7), ("2d", 45), ("2d", 130), ("3d", 9), ("3d", 22)])
-def test_multifrontal_matches_band_and_oracle(gpu, pkg, O, kind, m, monkeypatch):
+def test_multifrontal_matches_band_and_oracle(gpu, pkg, O, kind, m, limits, monkeypatch):
     """nested-dissection multifrontal factors == band factors == the CPU oracle, both systems,
-    several right-hand sides at once; sizes from a single front to thousands"""
+    several right-hand sides at once; sizes from a single front to thousands.  "small" lowers the
+    size limits of the front classes so that these small trees also run the code of the large ones:
+    per-front multi-launch factorisation above 512 (lockstep from 64 up to there) and many-workgroup
+    solves above 256"""
+    if limits == "small":
+        monkeypatch.setenv("SPL_MF_SMALL", "64")
+        monkeypatch.setenv("SPL_MF_MIDMAX", "512")
+        monkeypatch.setenv("SPL_MF_BIGSOLVE", "256")
     n, A = _grid_matrix(pkg, O, kind, m)
     U = pkg.umfpack
     rng = np.random.default_rng(m)
