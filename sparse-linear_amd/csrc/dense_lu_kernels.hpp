@@ -590,11 +590,11 @@ __device__ __forceinline__ void gemv_inv(const double *__restrict__ inv, const d
 }
 
 // NR right-hand sides at once: column r of in/out starts at r * stride
+// `tile`: which 64 rows outside the super block this workgroup updates (tile 0 also writes `out`)
 template <int MODE, int NR>
-__global__ __launch_bounds__(SW * 64) void solve_super_kernel(Band b, const double *__restrict__ invs, int j0,
-                                                              int jbs, double *in, double *__restrict__ out,
-                                                              size_t stride) {
-  extern __shared__ __attribute__((aligned(16))) double dsm[];
+__device__ __forceinline__ void solve_super_tile(const Band &b, const double *__restrict__ invs, int j0, int jbs,
+                                                 double *in, double *__restrict__ out, size_t stride, int tile,
+                                                 double *dsm) {
   double(*v)[NR] = reinterpret_cast<double(*)[NR]>(dsm);                          // [SB * NB]
   double(*w)[NR] = reinterpret_cast<double(*)[NR]>(dsm + SB * NB * NR);           // [NB]
   double(*res)[NR] = reinterpret_cast<double(*)[NR]>(dsm + (SB + 1) * NB * NR);   // [NB]
@@ -624,13 +624,13 @@ __global__ __launch_bounds__(SW * 64) void solve_super_kernel(Band b, const doub
     }
     __syncthreads();
   }
-  if (blockIdx.x == 0)
+  if (tile == 0)
     for (int o = tid; o < jbs * NR; o += SW * 64) {
       const int t = o % jbs, r = o / jbs;
       out[(size_t)r * stride + j0 + t] = v[t][r];
     }
   // the 64 rows of this workgroup outside the super block
-  const int rb = fwd ? j0 + jbs + (int)blockIdx.x * 64 : j0 - ((int)blockIdx.x + 1) * 64;
+  const int rb = fwd ? j0 + jbs + tile * 64 : j0 - (tile + 1) * 64;
   gemv64<MODE, NR>(b, rb, j0, jbs, v, res, part);
   for (int o = tid; o < 64 * NR; o += SW * 64) {
     const int l = o % 64, r = o / 64;
@@ -638,6 +638,14 @@ __global__ __launch_bounds__(SW * 64) void solve_super_kernel(Band b, const doub
     const bool ok = fwd ? (i < b.n) : (i >= 0);
     if (ok) in[(size_t)r * stride + i] -= res[l][r];
   }
+}
+
+template <int MODE, int NR>
+__global__ __launch_bounds__(SW * 64) void solve_super_kernel(Band b, const double *__restrict__ invs, int j0,
+                                                              int jbs, double *in, double *__restrict__ out,
+                                                              size_t stride) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  solve_super_tile<MODE, NR>(b, invs, j0, jbs, in, out, stride, (int)blockIdx.x, dsm);
 }
 
 

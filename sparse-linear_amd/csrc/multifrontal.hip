@@ -251,7 +251,7 @@ constexpr int kStreams = 8;        // larger fronts of a level are spread over t
 // NR right-hand sides travel through the tree together: every front has a work matrix W (fs x NR,
 // column-major), column r of the right-hand sides / solution is c + r * stride.
 constexpr int kSolveThreads = 1024;  // one workgroup per front, 16 wavefronts for the coupling loops
-constexpr int kBigSolve = 3072;      // fronts above this size are solved by many workgroups
+constexpr int kBigSolve = 256;       // fronts above this size are solved by many workgroups, in lockstep
 
 // The panels of a front as the solves see them.  M is the triangular system a front contributes:
 // M(i, j) = F(i, j), or F(j, i) for the transposed systems, where F(i, j) lives in P for j < np and in
@@ -455,29 +455,82 @@ __global__ __launch_bounds__(kSolveThreads) void solve_backward_kernel(const int
   }
 }
 
-// ---- large fronts: the same steps spread over many workgroups -----------------------------------
-// boundary part of the solution into the front's work matrix: dst[r * fs + k] = x[r * stride + bidx[k]]
+// ---- large fronts: the same steps spread over many workgroups, all large fronts of a level in
+// lockstep.  Every kernel below runs on a flat grid over the workgroups of all listed fronts
+// (prefix = workgroups before each front, computed on the host when the factors are built): one
+// launch per step and level however many fronts the level holds.
+struct BigFront {
+  int f, np, nb, fs, ldp, ldu, blk;  // blk: index of this workgroup inside its front
+  const double *P, *U;
+  double *W, *Z;
+};
 template <int NR>
-__global__ __launch_bounds__(256) void front_gather_x_kernel(const int *__restrict__ b, int nb,
-                                                             const double *__restrict__ x, size_t stride,
-                                                             double *__restrict__ dst, int fs) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nb) return;
-  const int g = b[k];
-#pragma unroll
-  for (int r = 0; r < NR; ++r) dst[(size_t)r * fs + k] = x[(size_t)r * stride + g];
+__device__ __forceinline__ BigFront big_front(const int *__restrict__ list, const int64_t *__restrict__ prefix,
+                                              int count, const TreeView &t, double *work, double *zbuf) {
+  const int64_t flat = prefix[0] + blockIdx.x;
+  const int fi = item_of_tile(prefix, count, flat);
+  const int f = list[fi];
+  BigFront b;
+  b.f = f;
+  b.np = t.np[f];
+  b.nb = t.nb[f];
+  b.fs = b.np + b.nb;
+  b.ldp = t.ldp[f];
+  b.ldu = t.ldu[f];
+  b.blk = (int)(flat - prefix[fi]);
+  b.P = t.arena + t.poff[f];
+  b.U = t.arena + t.uoff[f];
+  b.W = work + (size_t)t.woff[f] * NR;
+  b.Z = zbuf + (size_t)t.woff[f] * NR;
+  return b;
 }
 
-// z[i][:] -= sum_k M(i, np + k) xb[k][:], i < np: 64 rows per workgroup; z and xb are columns of
-// fs-strided work matrices.  Untransposed M(i, np + k) = U(i, k); transposed = F(np + k, i) in P.
+// one super-block step (256 pivots) of the triangular pass MODE through the pivot columns of every
+// listed front that has a step `step`: forward passes take W -> Z, backward passes Z -> W
+template <int MODE, int NR>
+__global__ __launch_bounds__(SW * 64) void big_super_kernel(const int *__restrict__ list,
+                                                            const int64_t *__restrict__ prefix, int count, int step,
+                                                            TreeView t, const double *__restrict__ invs,
+                                                            double *work, double *zbuf) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  constexpr bool fwd = (MODE == 0 || MODE == 2);
+  const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
+  const int span = SB * NB, nsup = (b.np + span - 1) / span;
+  const int j0 = (fwd ? step : nsup - 1 - step) * span, jbs = min(span, b.np - j0);
+  // untransposed forward: the boundary rows of the front get their updates inside the pass
+  const int n = MODE == 0 ? b.fs : b.np;
+  const Band band{const_cast<double *>(b.P), n, n, n, b.ldp + 1, 0};
+  solve_super_tile<MODE, NR>(band, invs + t.ioff[b.f], j0, jbs, fwd ? b.W : b.Z, fwd ? b.Z : b.W, (size_t)b.fs,
+                             b.blk, dsm);
+}
+
+// boundary part of the solution into the front's work matrix: W[r * fs + np + k] = x[r * stride + bidx[k]]
+template <int NR>
+__global__ __launch_bounds__(256) void big_gather_x_kernel(const int *__restrict__ list,
+                                                           const int64_t *__restrict__ prefix, int count, TreeView t,
+                                                           const double *__restrict__ x, size_t stride, double *work,
+                                                           double *zbuf) {
+  const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
+  const int k = b.blk * 256 + (int)threadIdx.x;
+  if (k >= b.nb) return;
+  const int g = t.bidx[t.bptr[b.f] + k];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) b.W[(size_t)r * b.fs + b.np + k] = x[(size_t)r * stride + g];
+}
+
+// Z[i][:] -= sum_k M(i, np + k) W[np + k][:], i < np: 64 rows per workgroup.  Untransposed
+// M(i, np + k) = U(i, k); transposed = F(np + k, i) in P.
 template <bool TRANS, int NR>
-__global__ __launch_bounds__(256) void front_gemv_kernel(const double *__restrict__ P, int ldp,
-                                                         const double *__restrict__ U, int ldu, int np, int nb,
-                                                         const double *__restrict__ xb, double *__restrict__ z,
-                                                         int fs) {
+__global__ __launch_bounds__(256) void big_gemv_kernel(const int *__restrict__ list,
+                                                       const int64_t *__restrict__ prefix, int count, TreeView t,
+                                                       double *work, double *zbuf) {
   __shared__ double part[4][64][NR];
+  const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
+  const double *P = b.P, *U = b.U, *xb = b.W + b.np;
+  double *z = b.Z;
+  const int np = b.np, nb = b.nb, fs = b.fs, ldp = b.ldp, ldu = b.ldu;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i0 = blockIdx.x * 64;
+  const int i0 = b.blk * 64;
   if (!TRANS) {
     const int i = i0 + lane;
     double acc[NR];
@@ -540,39 +593,45 @@ __global__ __launch_bounds__(256) void front_gemv_kernel(const double *__restric
   }
 }
 
-// transposed forward elimination of a large front, boundary part: w[np + k][:] -= sum_t U(t, k) y[t][:]
-// (U^T y); one wavefront per boundary index, lanes along t
+// transposed forward elimination, boundary part: W[np + k][:] -= sum_t U(t, k) Z[t][:]  (U^T y); one
+// wavefront per boundary index, lanes along t
 template <int NR>
-__global__ __launch_bounds__(256) void front_boundary_t_kernel(const double *__restrict__ U, int ldu, int np, int nb,
-                                                               const double *__restrict__ y, double *__restrict__ w,
-                                                               int fs) {
+__global__ __launch_bounds__(256) void big_boundary_t_kernel(const int *__restrict__ list,
+                                                             const int64_t *__restrict__ prefix, int count,
+                                                             TreeView t, double *work, double *zbuf) {
+  const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
   const int lane = threadIdx.x & 63;
-  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (k >= nb) return;
-  const double *col = U + (size_t)k * ldu;
+  const int k = b.blk * 4 + (int)(threadIdx.x >> 6);
+  if (k >= b.nb) return;
+  const double *col = b.U + (size_t)k * b.ldu;
   double acc[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) acc[r] = 0.0;
-  for (int tt = lane; tt < np; tt += 64) {
+  for (int tt = lane; tt < b.np; tt += 64) {
     const double e = col[tt];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) acc[r] += e * y[(size_t)r * fs + tt];
+    for (int r = 0; r < NR; ++r) acc[r] += e * b.Z[(size_t)r * b.fs + tt];
   }
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) acc[r] += __shfl_xor(acc[r], m, 64);
-    if (lane == 0) w[(size_t)r * fs + np + k] -= acc[r];
+    if (lane == 0) b.W[(size_t)r * b.fs + b.np + k] -= acc[r];
   }
 }
 
+// the pivots' part of the solution of every listed front: x[p0 + i] = W[i]
 template <int NR>
-__global__ __launch_bounds__(256) void front_scatter_x_kernel(int p0, int np, const double *__restrict__ src, int fs,
-                                                              double *__restrict__ x, size_t stride) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= np) return;
+__global__ __launch_bounds__(256) void big_scatter_x_kernel(const int *__restrict__ list,
+                                                            const int64_t *__restrict__ prefix, int count,
+                                                            TreeView t, double *work, double *zbuf,
+                                                            double *__restrict__ x, size_t stride) {
+  const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
+  const int i = b.blk * 256 + (int)threadIdx.x;
+  if (i >= b.np) return;
+  const int p0 = t.p0[b.f];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) x[(size_t)r * stride + p0 + i] = src[(size_t)r * fs + i];
+  for (int r = 0; r < NR; ++r) x[(size_t)r * stride + p0 + i] = b.W[(size_t)r * b.fs + i];
 }
 
 }  // namespace
@@ -598,6 +657,23 @@ struct Factors {
   std::vector<DBuf<int64_t>> ctile[2], ptile, utile;
   int singular = 0;
   int big_solve = 0;  // fronts above this size are solved by many workgroups (kBigSolve; SPL_MF_BIGSOLVE)
+  // those fronts, per depth, and the flat grids of their lockstep solve kernels: segments of
+  // count + 1 prefix sums (workgroups before each front), in this order: untransposed forward
+  // steps [0, steps), transposed forward steps, backward steps, then the boundary kernel of the
+  // transposed forward pass, gather, gemv, scatter
+  struct BigLevel {
+    int count = 0, steps = 0;
+    DBuf<int> list;
+    std::vector<int64_t> h;
+    DBuf<int64_t> d;
+    size_t seg(int kind, int k = 0) const {  // kind 0 fwd, 1 fwd^T, 2 bwd, 3 boundary^T, 4 gather, 5 gemv, 6 scatter
+      const size_t which = kind < 3 ? (size_t)kind * (size_t)steps + (size_t)k : (size_t)3 * steps + (size_t)(kind - 3);
+      return which * (size_t)(count + 1);
+    }
+    unsigned total(int kind, int k = 0) const { return (unsigned)h[seg(kind, k) + (size_t)count]; }
+    const int64_t *prefix(int kind, int k = 0) const { return d.get() + seg(kind, k); }
+  };
+  std::vector<BigLevel> big;
   // independent large fronts of a level run on these (factorisation and solves): one set per
   // device for the whole process, created on first use and never destroyed (objects come and go by
   // the thousand in a contour integration; work of different objects on the same stream is merely
@@ -717,7 +793,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   std::unique_ptr<mf::Factors> Fp(new mf::Factors());
   mf::Factors &F = *Fp;
   F.tree = tree;
-  F.big_solve = getenv("SPL_MF_BIGSOLVE") ? std::max(256, atoi(getenv("SPL_MF_BIGSOLVE"))) : kBigSolve;
+  F.big_solve = getenv("SPL_MF_BIGSOLVE") ? std::max(64, atoi(getenv("SPL_MF_BIGSOLVE"))) : kBigSolve;
   const int nd = T.maxdepth + 1, nf = T.nfronts;
   const int small_limit = getenv("SPL_MF_SMALL") ? std::max(64, atoi(getenv("SPL_MF_SMALL"))) : kSmallFront;  // tuning knob
   // ---- memory plan: the smallest cut depth whose transient part fits next to the resident part
@@ -770,6 +846,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   F.small_lists.resize((size_t)nd);
   F.small_counts.assign((size_t)nd, 0);
   F.solve_lists.resize((size_t)nd);
+  F.big.resize((size_t)nd);
   F.solve_counts.assign((size_t)nd, 0);
   F.h_small.assign((size_t)nd, std::vector<int>());
   for (int sl = 0; sl < 2; ++sl) {
@@ -791,6 +868,44 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
     F.solve_counts[(size_t)d] = (int)one_wg.size();
     staged.push_back(std::move(one_wg));
     upload_vec(F.solve_lists[(size_t)d], staged.back(), s);
+    {
+      mf::Factors::BigLevel &B = F.big[(size_t)d];
+      std::vector<int> large;
+      for (int f : T.by_depth[(size_t)d])
+        if (T.fs(f) > F.big_solve && T.np[(size_t)f] > 0) large.push_back(f);
+      B.count = (int)large.size();
+      constexpr int span = SB * NB;
+      for (int f : large) B.steps = std::max(B.steps, (T.np[(size_t)f] + span - 1) / span);
+      if (B.count > 0) {
+        B.h.assign((size_t)(3 * B.steps + 4) * (size_t)(B.count + 1), 0);
+        auto fill = [&](int kind, int k, auto groups_of) {
+          int64_t *pre = B.h.data() + B.seg(kind, k);
+          for (int i = 0; i < B.count; ++i) pre[i + 1] = pre[i] + groups_of(large[(size_t)i]);
+        };
+        for (int k = 0; k < B.steps; ++k) {
+          auto fwd_rows = [&](int f, int n) -> int64_t {  // workgroups of forward step k of a pass over n rows
+            const int np = T.np[(size_t)f], j0 = k * span;
+            if (j0 >= np) return 0;
+            const int jbs = std::min(span, np - j0);
+            return std::max(1, (n - (j0 + jbs) + 63) / 64);
+          };
+          fill(0, k, [&](int f) { return fwd_rows(f, T.fs(f)); });
+          fill(1, k, [&](int f) { return fwd_rows(f, T.np[(size_t)f]); });
+          fill(2, k, [&](int f) -> int64_t {
+            const int np = T.np[(size_t)f], nsup = (np + span - 1) / span;
+            if (k >= nsup) return 0;
+            return std::max(1, ((nsup - 1 - k) * span + 63) / 64);
+          });
+        }
+        fill(3, 0, [&](int f) -> int64_t { return (T.nb[(size_t)f] + 3) / 4; });
+        fill(4, 0, [&](int f) -> int64_t { return (T.nb[(size_t)f] + 255) / 256; });
+        fill(5, 0, [&](int f) -> int64_t { return T.nb[(size_t)f] > 0 ? (T.np[(size_t)f] + 63) / 64 : 0; });
+        fill(6, 0, [&](int f) -> int64_t { return (T.np[(size_t)f] + 255) / 256; });
+        staged.push_back(std::move(large));
+        upload_vec(B.list, staged.back(), s);
+        upload_vec(B.d, B.h, s);
+      }
+    }
     if (d + 1 < nd) {
       for (int c : T.by_depth[(size_t)d + 1]) F.h_child[T.slot[(size_t)c]][(size_t)d].push_back(c);
       for (int sl = 0; sl < 2; ++sl) {
@@ -1012,73 +1127,44 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   return Fp.release();
 }
 
-// NR columns (c + r * stride) through the tree: up with L (or U^T), down with U (or L^T)
-// The large fronts of a level are independent (own work matrices, own pivots of c): they are dealt
-// to the side streams, which wait for the level's start on s and which s waits for at its end.
-struct LevelFork {
-  const mf::Factors &F;
-  hipStream_t s;
-  hipEvent_t start = nullptr, done[kStreams] = {};
-  int used = 0;
-  bool forked = false;
-  LevelFork(const mf::Factors &F_, hipStream_t s_) : F(F_), s(s_) {
-    SPL_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
-    for (int i = 0; i < kStreams; ++i) SPL_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+// NR columns (c + r * stride) through the tree: up with L (or U^T), down with U (or L^T).  Per level:
+// the fronts of up to big_solve rows by one workgroup each, the larger ones in lockstep — one flat
+// launch per super-block step over all of them (Factors::BigLevel).
+template <int MODE, int NR>
+static void launch_big_super(const mf::Factors &F, const mf::Factors::BigLevel &B, int kind, int step, double *work,
+                             double *zbuf, hipStream_t s) {
+  constexpr size_t lds = (size_t)((SB + 2) * NB + SW * 64) * NR * sizeof(double);
+  static bool attr_set = false;  // one flag per instantiation
+  if (!attr_set) {
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&big_super_kernel<MODE, NR>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
   }
-  ~LevelFork() {
-    if (start) (void)hipEventDestroy(start);
-    for (int i = 0; i < kStreams; ++i)
-      if (done[i]) (void)hipEventDestroy(done[i]);
-  }
-  // begin a level with `count` large fronts
-  void begin(int count) {
-    forked = count > 1 && F.nside == kStreams;
-    used = 0;
-    if (forked) SPL_HIP(hipEventRecord(start, s));
-  }
-  hipStream_t next() {
-    if (!forked) return s;
-    const int i = used % kStreams;
-    if (used < kStreams) SPL_HIP(hipStreamWaitEvent(F.side[i], start, 0));
-    ++used;
-    return F.side[i];
-  }
-  void end() {
-    if (!forked) return;
-    for (int i = 0; i < kStreams && i < used; ++i) {
-      SPL_HIP(hipEventRecord(done[i], F.side[i]));
-      SPL_HIP(hipStreamWaitEvent(s, done[i], 0));
-    }
-  }
-};
+  const unsigned groups = B.total(kind, step);
+  if (groups > 0)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(big_super_kernel<MODE, NR>), dim3(groups), dim3(SW * 64), lds, s, B.list.get(),
+                       B.prefix(kind, step), B.count, step, F.view, F.invs.get(), work, zbuf);
+}
 
 template <bool TRANS, int NR>
 static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride, double *work, double *zbuf,
-                                  hipStream_t s0) {
+                                  hipStream_t s) {
   const mf::Tree &T = *F.tree;
   const int nd = T.maxdepth + 1;
-  const double *arena = F.arena.get();
   double *invs = F.invs.get();
   constexpr int FWD = TRANS ? 2 : 0, BWD = TRANS ? 3 : 1;
-  LevelFork fork(F, s0);
-  auto large_fronts = [&](int d) {
-    int count = 0;
-    for (int f : T.by_depth[(size_t)d]) count += (T.fs(f) > F.big_solve && T.np[(size_t)f] > 0) ? 1 : 0;
-    return count;
-  };
-  hipStream_t s = s0;
   const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // per-level times on stderr (diagnostic)
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char *dir, int d) {
     if (!timing) return;
-    (void)hipStreamSynchronize(s0);
+    (void)hipStreamSynchronize(s);
     const auto now = std::chrono::steady_clock::now();
     const double ms = std::chrono::duration<double, std::milli>(now - t_last).count();
-    fprintf(stderr, "[mf_solve] %s level %2d: %4d large of %6zu fronts %8.2f ms\n", dir, d, large_fronts(d),
+    fprintf(stderr, "[mf_solve] %s level %2d: %4d large of %6zu fronts %8.2f ms\n", dir, d, F.big[(size_t)d].count,
             T.by_depth[(size_t)d].size(), ms);
     t_last = now;
   };
-  if (timing) (void)hipStreamSynchronize(s0);
+  if (timing) (void)hipStreamSynchronize(s);
   t_last = std::chrono::steady_clock::now();
   for (int d = nd - 1; d >= 0; --d) {
     const unsigned nf = (unsigned)T.by_depth[(size_t)d].size();
@@ -1093,28 +1179,15 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
       hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_forward_kernel<TRANS, NR>), dim3((unsigned)F.solve_counts[(size_t)d]),
                          dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work);
     lap("up small  ", d);
-    fork.begin(large_fronts(d));
-    for (int f : T.by_depth[(size_t)d]) {
-      const int np = T.np[(size_t)f], nb = T.nb[(size_t)f], fs = np + nb;
-      if (fs <= F.big_solve || np == 0) continue;
-      s = fork.next();
-      double *P = const_cast<double *>(arena) + T.poff[(size_t)f];
-      const double *U = arena + T.uoff[(size_t)f];
-      double *W = work + (size_t)T.woff[(size_t)f] * NR, *Z = zbuf + (size_t)T.woff[(size_t)f] * NR;
-      if (!TRANS) {
-        // the pivot columns of the front: the boundary rows get their updates inside the pass
-        const Band b = dense_view(P, fs, T.ldp[(size_t)f]);
-        solve_pass<FWD, NR>(b, invs + T.ioff[(size_t)f], fs, W, Z, (size_t)fs, s, np);
-      } else {
-        const Band b = dense_view(P, np, T.ldp[(size_t)f]);  // U11^T; then the boundary with U12^T
-        solve_pass<FWD, NR>(b, invs + T.ioff[(size_t)f], np, W, Z, (size_t)fs, s);
-        if (nb > 0)
-          hipLaunchKernelGGL(front_boundary_t_kernel<NR>, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, s, U,
-                             T.ldu[(size_t)f], np, nb, Z, W, fs);
-      }
+    const mf::Factors::BigLevel &B = F.big[(size_t)d];
+    if (B.count > 0) {
+      // untransposed: the boundary rows get their updates inside the pass over the pivot columns;
+      // transposed: U11^T on the pivots, then the boundary with U12^T
+      for (int k = 0; k < B.steps; ++k) launch_big_super<FWD, NR>(F, B, TRANS ? 1 : 0, k, work, zbuf, s);
+      if (TRANS && B.total(3) > 0)
+        hipLaunchKernelGGL(big_boundary_t_kernel<NR>, dim3(B.total(3)), dim3(256), 0, s, B.list.get(), B.prefix(3),
+                           B.count, F.view, work, zbuf);
     }
-    fork.end();
-    s = s0;
     lap("up large  ", d);
   }
   for (int d = 0; d < nd; ++d) {
@@ -1123,28 +1196,19 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
                          dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work, c,
                          stride);
     lap("down small", d);
-    fork.begin(large_fronts(d));
-    for (int f : T.by_depth[(size_t)d]) {
-      const int np = T.np[(size_t)f], nb = T.nb[(size_t)f], fs = np + nb;
-      if (fs <= F.big_solve || np == 0) continue;
-      s = fork.next();
-      double *P = const_cast<double *>(arena) + T.poff[(size_t)f];
-      const double *U = arena + T.uoff[(size_t)f];
-      const int ldp = T.ldp[(size_t)f], ldu = T.ldu[(size_t)f];
-      double *W = work + (size_t)T.woff[(size_t)f] * NR, *Z = zbuf + (size_t)T.woff[(size_t)f] * NR;
-      if (nb > 0) {
-        hipLaunchKernelGGL(front_gather_x_kernel<NR>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s,
-                           F.D.bidx.get() + T.bptr[(size_t)f], nb, c, stride, W + np, fs);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(front_gemv_kernel<TRANS, NR>), dim3((unsigned)((np + 63) / 64)), dim3(256),
-                           0, s, P, ldp, U, ldu, np, nb, W + np, Z, fs);
+    const mf::Factors::BigLevel &B = F.big[(size_t)d];
+    if (B.count > 0) {
+      if (B.total(4) > 0) {
+        hipLaunchKernelGGL(big_gather_x_kernel<NR>, dim3(B.total(4)), dim3(256), 0, s, B.list.get(), B.prefix(4),
+                           B.count, F.view, c, stride, work, zbuf);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_kernel<TRANS, NR>), dim3(B.total(5)), dim3(256), 0, s,
+                           B.list.get(), B.prefix(5), B.count, F.view, work, zbuf);
       }
-      const Band b = dense_view(P, np, ldp);  // the pivot block alone; columns of Z / W are fs apart
-      solve_pass<BWD, NR>(b, invs + T.ioff[(size_t)f], np, Z, W, (size_t)fs, s);
-      hipLaunchKernelGGL(front_scatter_x_kernel<NR>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s,
-                         T.p0[(size_t)f], np, W, fs, c, stride);
+      // the pivot block alone; columns of Z / W are fs apart
+      for (int k = 0; k < B.steps; ++k) launch_big_super<BWD, NR>(F, B, 2, k, work, zbuf, s);
+      hipLaunchKernelGGL(big_scatter_x_kernel<NR>, dim3(B.total(6)), dim3(256), 0, s, B.list.get(), B.prefix(6),
+                         B.count, F.view, work, zbuf, c, stride);
     }
-    fork.end();
-    s = s0;
     lap("down large", d);
   }
 }

@@ -260,11 +260,11 @@ def test_multifrontal_matches_band_and_oracle(gpu, pkg, O, kind, m, limits, monk
     several right-hand sides at once; sizes from a single front to thousands.  "small" lowers the
     size limits of the front classes so that these small trees also run the code of the large ones:
     per-front multi-launch factorisation above 512 (lockstep from 64 up to there) and many-workgroup
-    solves above 256"""
+    solves above 64"""
     if limits == "small":
         monkeypatch.setenv("SPL_MF_SMALL", "64")
         monkeypatch.setenv("SPL_MF_MIDMAX", "512")
-        monkeypatch.setenv("SPL_MF_BIGSOLVE", "256")
+        monkeypatch.setenv("SPL_MF_BIGSOLVE", "64")
     n, A = _grid_matrix(pkg, O, kind, m)
     U = pkg.umfpack
     rng = np.random.default_rng(m)
