@@ -20,9 +20,9 @@
  * idempotent and may run on any thread; status: 0 OK, 1 singular-matrix warning, < 0 error;
  * only sys = 0 (A x = b) and sys = 1 (A^T x = b; UMFPACK_At) are ever passed (Umfpack.hs:95-97).
  *
- * Algorithm (round 1).  symbolic (host): a reverse-Cuthill-McKee band ordering and, from 4096
+ * Algorithm (round 1).  symbolic (host): a reverse-Cuthill-McKee band ordering and, from 1024
  * unknowns on, a nested-dissection ordering with its frontal tree; the one a measured time model
- * predicts to factor faster is kept (the tree from about 5000 unknowns on, narrow bands included:
+ * predicts to factor faster is kept (the tree from about 2000 unknowns on, narrow bands included:
  * the band factorisation is a chain of n / 64 block steps however narrow the band).  numeric (GPU): LU of the
  * permuted matrix WITHOUT row interchanges, blocked on the fp64 matrix cores — in band storage,
  * or multifrontal on the tree (dense frontal matrices, Schur complements passed to the parent) —

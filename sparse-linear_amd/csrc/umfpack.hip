@@ -554,7 +554,7 @@ int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
     const bool force_mf = method && method[0] == 'm', force_band = method && method[0] == 'b';
     const int n = S->n;
     std::future<std::shared_ptr<mf::Tree>> tree_job;
-    if (!force_band && (force_mf || n >= 4096))
+    if (!force_band && (force_mf || n >= 1024))
       tree_job = std::async(std::launch::async, [n, Ap, Ai] {
         std::shared_ptr<mf::Tree> T = std::make_shared<mf::Tree>();
         mf::build_tree(n, Ap, Ai, 256, *T);
@@ -591,10 +591,10 @@ int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
       // Measured model of the two factorisations (MI355X, tools/bench_band_vs_tree.py): the band
       // is a chain of n / 64 block steps of a few launches each, about 1.4 us per column however
       // narrow it is, plus its flops at the rate of its large windows; the tree costs a few
-      // launches per level (about 6 ms for a whole tree) plus its flops at a lower rate (many small
-      // fronts).  The break-even is near n = 5 000 on 2-D and 3-D meshes alike.
+      // launches per level (about 2.5 ms for a whole tree) plus its flops at a lower rate (many
+      // small fronts).  The break-even is near n = 2 000 on 2-D and 3-D meshes alike.
       const double t_band = 1.4e-6 * S->n + band_flops / 3e13;
-      const double t_tree = 6e-3 + T->flops / 2e13;
+      const double t_tree = 2.5e-3 + T->flops / 2e13;
       if (force_mf || t_tree < t_band) S->tree = T;
     }
     *SymbolicOut = S;
