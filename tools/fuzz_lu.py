@@ -47,6 +47,17 @@ def main():
         method = ["band", "mf"][case % 2]
         os.environ["SPL_LU_METHOD"] = method
         os.environ["SPL_MF_CUT"] = str(int(rng.integers(0, 4)))
+        # size limits of the front classes (one workgroup / lockstep / per-front pipeline; one-workgroup
+        # solves): small values send these small trees through the code of the large ones
+        limits = {}
+        if rng.integers(0, 2):
+            limits = {"SPL_MF_SMALL": str(int(rng.choice([64, 128, 256]))),
+                      "SPL_MF_MIDMAX": str(int(rng.choice([128, 512, 4096]))),
+                      "SPL_MF_BIGSOLVE": str(int(rng.choice([64, 256, 1024])))}
+        for key in ("SPL_MF_SMALL", "SPL_MF_MIDMAX", "SPL_MF_BIGSOLVE"):
+            os.environ.pop(key, None)
+        os.environ.update(limits)
+        nrhs = int(rng.choice([1, 1, 3, 8, 9]))
         M = pkg.Matrix(n, n, S.indptr, S.indices, S.data)
         try:
             lu = spla.splu(S)
@@ -61,14 +72,18 @@ def main():
         fact = U.factor(M, U.analyze(M))
         for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, S.T.tocsc())):
             b = np.asarray(op @ xs).ravel()
-            x = U.linearSolve_(fact, mode, M, b)
+            if nrhs == 1:
+                x = U.linearSolve_(fact, mode, M, b)
+            else:  # several right-hand sides through the factors together; the first one is checked
+                x = U.linearSolveMany_(fact, mode, M, [b * (1.0 + 0.25 * c) for c in range(nrhs)])[0]
             ref = lu.solve(b, trans="N" if mode == U.UmfpackNormal else "T")
             res = np.max(np.abs(op @ x - b)) / (np.max(np.abs(b)) + np.max(np.abs(x)) + 1e-300)
             res_ref = np.max(np.abs(op @ ref - b)) / (np.max(np.abs(b)) + np.max(np.abs(ref)) + 1e-300)
             if not (res <= max(1e-12, 100 * res_ref)):
                 bad += 1
-                print("FAIL case %d n=%d kind=%d method=%s cut=%s mode=%d path=%d residual %.2e (SuperLU %.2e)"
-                      % (case, n, kind, method, os.environ["SPL_MF_CUT"], mode, fact.path, res, res_ref), flush=True)
+                print("FAIL case %d n=%d kind=%d method=%s cut=%s limits=%s nrhs=%d mode=%d path=%d residual %.2e "
+                      "(SuperLU %.2e)" % (case, n, kind, method, os.environ["SPL_MF_CUT"], limits, nrhs, mode, fact.path,
+                                          res, res_ref), flush=True)
     print("fuzz: %d cases, %d failures" % (ncase, bad))
     return 1 if bad else 0
 
