@@ -396,7 +396,28 @@ struct Worker {
       return join(lo, lo + na, hi, Node(), depth);
     }
     const int nlev = (int)level_ptr.size() - 1;
-    if (nlev < 3) return make_leaf(lo, hi);  // no interior level: nothing to separate
+    if (nlev < 3) {
+      // No interior level: every vertex is within one step of both ends.  A small region, or a
+      // genuinely dense one, becomes a leaf.  A large one held together by a few hubs (a dense row
+      // and column: an arrow matrix) must not become one dense front: the vertex of largest degree
+      // is taken out as a separator of its own and the rest is dissected again (it usually falls
+      // apart into components).
+      if (size <= 4 * S.leaf) return make_leaf(lo, hi);
+      int hub = lo;
+      int64_t best_deg = -1, edges = 0;
+      for (int i = lo; i < hi; ++i) {
+        const int v = S.verts[(size_t)i];
+        const int64_t deg = S.xadj[(size_t)v + 1] - S.xadj[(size_t)v];
+        edges += deg;
+        if (deg > best_deg) { best_deg = deg; hub = i; }
+      }
+      // dense on the whole (more than a quarter of all pairs are edges): a leaf after all
+      if ((double)edges > 0.25 * (double)size * (double)size) return make_leaf(lo, hi);
+      Node top;
+      top.piv.push_back(S.verts[(size_t)hub]);
+      std::swap(S.verts[(size_t)hub], S.verts[(size_t)hi - 1]);
+      return join(lo, hi - 1, hi - 1, std::move(top), depth);
+    }
     // smallest level among the balanced ones; the balance requirement is relaxed until one exists
     int best = -1;
     for (double frac : {0.35, 0.20, 0.10, 0.0}) {

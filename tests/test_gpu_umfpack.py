@@ -357,3 +357,25 @@ def test_multifrontal_random_patterns_against_oracle(gpu, pkg, O, monkeypatch):
             assert O.count_not_close(x, xs, 1e-10) == 0, (n, mode)
         xo, _ = O.linear_solve(A, np.asarray(S @ xs).ravel())
         assert O.count_not_close(U.linearSolve_(fact, U.UmfpackNormal, M, np.asarray(S @ xs).ravel()), xo, 1e-10) == 0
+
+
+def test_arrow_matrix_takes_the_tree(gpu, pkg, O):
+    """a dense row and column around a sparse rest (n = 30 000): as a band it is n wide, and a nested
+    dissection that cannot separate it would make one dense front; the hub becomes a separator of its
+    own and the system is solved on the tree in milliseconds"""
+    import scipy.sparse as sp
+    n = 30000
+    rng = np.random.default_rng(11)
+    A = sp.diags([-np.ones(n - 1), -np.ones(n - 1)], (-1, 1)).tolil()
+    A[0, 1:] = rng.uniform(-1.0, -0.1, n - 1)
+    A[1:, 0] = rng.uniform(-1.0, -0.1, (n - 1, 1))
+    A = sp.csc_matrix(A)
+    A = sp.csc_matrix(A + sp.diags(np.asarray(abs(A).sum(axis=0)).ravel() + 1.0))  # dominant by columns
+    A.sort_indices()
+    M = pkg.Matrix(n, n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data)
+    xs = rng.uniform(0.5, 1.5, n)
+    fact = pkg.umfpack.factor(M, pkg.umfpack.analyze(M))
+    assert fact.path == 3 and fact.stats["device_bytes"] < 1e9
+    for mode, op in ((pkg.umfpack.UmfpackNormal, A), (pkg.umfpack.UmfpackTrans, A.T)):
+        x = pkg.umfpack.linearSolve_(fact, mode, M, op @ xs)
+        assert O.count_not_close(x, xs, 1e-10) == 0

@@ -71,3 +71,23 @@ def test_team_traversals_reproduce_the_sequential_tree(checker):
         outs = [run(checker, A, 256, team=t) for t in (1, 2, 5, 16)]
         assert all(int(o["bad"]) == 0 for o in outs)
         assert len({o["hash"] for o in outs}) == 1 and len({o["flops"] for o in outs}) == 1
+
+
+def test_dense_row_and_column_do_not_make_a_dense_front(checker):
+    """arrow matrix (a hub joined to every vertex) and two hubs on a chain: the hubs become separators
+    of their own and the rest is dissected; without that the whole matrix would be one leaf"""
+    n = 6000
+    hub = sp.lil_matrix((n, n))
+    hub[0, :] = 1
+    hub[:, 0] = 1
+    out = run(checker, sp.csc_matrix(hub) + sp.identity(n), 64)
+    assert int(out["bad"]) == 0 and int(out["fronts"]) > 10 and int(out["maxfront"]) <= 4 * 64 + 1
+    chain = sp.diags([np.ones(n - 1), np.ones(n - 1)], (-1, 1)).tolil()
+    for h in (17, 4000):
+        chain[h, :] = 1
+        chain[:, h] = 1
+    out = run(checker, sp.csc_matrix(chain) + sp.identity(n), 64)
+    assert int(out["bad"]) == 0 and int(out["maxfront"]) <= 4 * 64 + 2
+    # a dense block stays one leaf
+    out = run(checker, np.ones((300, 300)), 64)
+    assert int(out["bad"]) == 0 and int(out["fronts"]) == 1
