@@ -745,7 +745,11 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B)
       std::vector<char> active((size_t)k);
       int nactive = 0;
       for (int c = 0; c < k; ++c) nactive += (active[(size_t)c] = omega[(size_t)c] >= eps);
-      for (int it = 0; it < 2 && nactive > 0; ++it) {
+      // UMFPACK's default is two steps.  Factors kept as a speculation (no interchanges, no
+      // diagonal dominance) may take more while each step still halves the backward error: static
+      // pivoting with refinement, before the factors are given up for pivoted ones below.
+      const int max_steps = N->speculative ? 10 : 2;
+      for (int it = 0; it < max_steps && nactive > 0; ++it) {
         factor_solve(N, sys, dr.get(), dd.get(), dwork.get(), k, stride, s);
         SPL_HIP(hipMemcpyAsync(dxn.get(), dx.get(), used * sizeof(double), hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(add_kernel, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, s, used, dxn.get(),
