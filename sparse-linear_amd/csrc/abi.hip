@@ -485,6 +485,10 @@ int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unr
   if (!m) return SPL_ERROR_invalid_handle;
   int waves = 16;
   if (rows_per_panel == 0 && cols_log2 == 0) {
+    {
+      int st = guarded([&]() -> int { DeviceGuard g(m->device); measure_locality(m, nullptr); return SPL_OK; });
+      if (st != SPL_OK) return st;
+    }
     choose_blocking(m, &rows_per_panel, &cols_log2, &waves);
     if (rows_per_panel == 0) { rows_per_panel = 1024; cols_log2 = 18; waves = 16; }  // explicit request: default shape
   }
@@ -521,6 +525,10 @@ int spl_matrix_optimize(void *H) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;
   int R = 0, w = 0, waves = 16;
+  {
+    int st = guarded([&]() -> int { DeviceGuard g(m->device); measure_locality(m, nullptr); return SPL_OK; });
+    if (st != SPL_OK) return st;
+  }
   choose_blocking(m, &R, &w, &waves);
   if (R == 0) {
     // no blocking needed.  Regular rows with column locality (banded, stencil): the sliced-ELL

@@ -114,7 +114,7 @@ struct Matrix {
   DBuf<double> val;        // nnz
   int variant = 0;
   int64_t max_row_len = 0;
-  double new_line_fraction = 0.0;  // share of entries whose x line the previous row did not touch
+  double new_line_fraction = -1.0;  // share of entries whose x line the previous row did not touch; < 0: not measured yet
   BlockedImage *blocked = nullptr;  // built on demand (spl_matrix_build_blocked / auto)
   SellImage *sell = nullptr;        // built on demand (spl_matrix_optimize on regular matrices)
   int blocked_unroll = 0;  // 0 = default; < 0 selects the ablation kernel
@@ -157,6 +157,7 @@ void segmented_sort_pairs64(const int64_t *d_ptr64, int64_t nseg, int64_t *d_key
                             hipStream_t s);
 // finish a Matrix whose rowptr64/colidx/val are filled: int32 pointers, stats
 void finalize_matrix(Matrix *m, hipStream_t s);
+void measure_locality(Matrix *m, hipStream_t s);  // fills new_line_fraction on first call
 
 // ---- assembly (assemble.hip) ------------------------------------------------------------
 int compress_device(int nrows, int ncols, int64_t nnz, const int *d_rows, const int *d_cols,

@@ -312,7 +312,13 @@ void finalize_matrix(Matrix *m, hipStream_t s) {
   SPL_HIP(hipMemcpyAsync(&h, mx.get(), sizeof(h), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
   m->max_row_len = (int64_t)h;
-  // sample about 64k rows for the locality estimate that steers choose_blocking()
+  m->new_line_fraction = -1.0;  // measured when a kernel choice first needs it (measure_locality)
+}
+
+// samples about 64k rows for the locality estimate that steers choose_blocking(); once per matrix
+void measure_locality(Matrix *m, hipStream_t s) {
+  if (m->new_line_fraction >= 0.0) return;
+  const int64_t nl = m->nrows_local;
   m->new_line_fraction = 0.0;
   if (nl > 1 && m->nnz > 0) {
     DBuf<unsigned long long> acc(2);
