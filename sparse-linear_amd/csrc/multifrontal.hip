@@ -69,19 +69,34 @@ __device__ __forceinline__ int local_pos(const TreeView &t, int f, int g) {
   return np + lo;
 }
 
-// entries of A (CSC arrays, original numbering) -> the fronts of tree level `level`; 8 lanes per column
-__global__ __launch_bounds__(256) void assemble_kernel(int n, const int *__restrict__ Ap, const int *__restrict__ Ai,
-                                                       const double *__restrict__ Ax, const int *__restrict__ inv,
-                                                       TreeView t, int level, int id_lo, int id_hi) {
-  const int j = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 3), part = threadIdx.x & 7;
-  if (j >= n) return;
-  const int gj = inv[j];
+__device__ __forceinline__ int item_of_tile(const int64_t *__restrict__ prefix, int count, int64_t flat);
+
+// Entries of A -> the fronts listed (those of one tree level): 8 lanes per pivot g of a front take
+// column g of P A P^T from the CSC arrays of A (the rows at or below the diagonal) and row g from
+// the CSR arrays (the columns right of it) — every entry lands in the front of its
+// earlier-eliminated index exactly once, and a level only reads the columns and rows of its own
+// pivots.  Flat grid: prefix = groups of 32 pivots before each front.
+__global__ __launch_bounds__(256) void assemble_kernel(const int *__restrict__ list,
+                                                       const int64_t *__restrict__ prefix, int count, TreeView t,
+                                                       const int *__restrict__ perm, const int *__restrict__ inv,
+                                                       const int *__restrict__ Ap, const int *__restrict__ Ai,
+                                                       const double *__restrict__ Ax, const int *__restrict__ Rp,
+                                                       const int *__restrict__ Rj, const double *__restrict__ Rx) {
+  const int64_t flat = prefix[0] + blockIdx.x;
+  const int fi = item_of_tile(prefix, count, flat);
+  const int f = list[fi];
+  const int lp = (int)(flat - prefix[fi]) * 32 + (int)(threadIdx.x >> 3), part = threadIdx.x & 7;
+  if (lp >= t.np[f]) return;
+  const int g = t.p0[f] + lp, j = perm[g];
+  double *F = t.front(f);
+  const int64_t ld = t.ld[f];
   for (int p = Ap[j] + part; p < Ap[j + 1]; p += 8) {
     const int gi = inv[Ai[p]];
-    const int f = t.front_of[min(gi, gj)];
-    if (t.depth[f] != level || f < id_lo || f > id_hi) continue;
-    const int r = local_pos(t, f, gi), c = local_pos(t, f, gj);
-    t.front(f)[(int64_t)r + (int64_t)c * t.ld[f]] = Ax[p];
+    if (gi >= g) F[(int64_t)local_pos(t, f, gi) + (int64_t)lp * ld] = Ax[p];
+  }
+  for (int p = Rp[j] + part; p < Rp[j + 1]; p += 8) {
+    const int gk = inv[Rj[p]];
+    if (gk > g) F[(int64_t)lp + (int64_t)local_pos(t, f, gk) * ld] = Rx[p];
   }
 }
 
@@ -653,8 +668,8 @@ struct Factors {
   std::vector<std::vector<int>> h_small, h_child[2];  // host copies (ascending ids) of small_lists / child_lists
   // tiles (64 x 16) before each item of child_lists (Schur complements) and of level_lists (P and
   // U panels): the flat grids of extend-add and compaction
-  std::vector<std::vector<int64_t>> h_ctile[2], h_ptile, h_utile;
-  std::vector<DBuf<int64_t>> ctile[2], ptile, utile;
+  std::vector<std::vector<int64_t>> h_ctile[2], h_ptile, h_utile, h_atile;  // h_atile: groups of 32 pivots (assembly)
+  std::vector<DBuf<int64_t>> ctile[2], ptile, utile, atile;
   int singular = 0;
   int big_solve = 0;  // fronts above this size are solved by many workgroups (kBigSolve; SPL_MF_BIGSOLVE)
   // those fronts, per depth, and the flat grids of their lockstep solve kernels: segments of
@@ -776,9 +791,11 @@ size_t mf_device_bytes(const mf::Tree &T) {  // resident part; the transient par
          ((size_t)T.bidx.size() + (size_t)T.rel_elems + 14 * (size_t)T.nfronts + (size_t)T.n) * sizeof(int64_t);
 }
 
-// numeric factorisation of P A P^T; d_Ap/d_Ai/d_Ax: CSC arrays of A on the device, d_inv: old -> new
+// numeric factorisation of P A P^T; d_Ap/d_Ai/d_Ax: CSC arrays of A on the device, d_Rp/d_Rj/d_Rx: its CSR
+// arrays, d_perm: new -> old, d_inv: old -> new
 mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, const int *d_Ai, const double *d_Ax,
-                       const int *d_inv, hipStream_t s) {
+                       const int *d_Rp, const int *d_Rj, const double *d_Rx, const int *d_perm, const int *d_inv,
+                       hipStream_t s) {
   const mf::Tree &T = *tree;
   const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // phase times on stderr (diagnostic)
   auto clock_now = [] { return std::chrono::steady_clock::now(); };
@@ -918,22 +935,27 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
     auto tiles = [](int64_t rows, int64_t cols) { return ((rows + 63) / 64) * ((cols + kTileCols - 1) / kTileCols); };
     F.h_ptile.assign((size_t)nd, std::vector<int64_t>());
     F.h_utile.assign((size_t)nd, std::vector<int64_t>());
+    F.h_atile.assign((size_t)nd, std::vector<int64_t>());
     F.ptile.resize((size_t)nd);
     F.utile.resize((size_t)nd);
+    F.atile.resize((size_t)nd);
     for (int sl = 0; sl < 2; ++sl) {
       F.h_ctile[sl].assign((size_t)nd, std::vector<int64_t>());
       F.ctile[sl].resize((size_t)nd);
     }
     for (int d = 0; d < nd; ++d) {
-      std::vector<int64_t> &pp = F.h_ptile[(size_t)d], &uu = F.h_utile[(size_t)d];
+      std::vector<int64_t> &pp = F.h_ptile[(size_t)d], &uu = F.h_utile[(size_t)d], &aa = F.h_atile[(size_t)d];
       pp.assign(1, 0);
       uu.assign(1, 0);
+      aa.assign(1, 0);
       for (int f : T.by_depth[(size_t)d]) {
         pp.push_back(pp.back() + tiles(T.fs(f), T.np[(size_t)f]));
         uu.push_back(uu.back() + tiles(T.np[(size_t)f], T.nb[(size_t)f]));
+        aa.push_back(aa.back() + (T.np[(size_t)f] + 31) / 32);
       }
       upload_vec(F.ptile[(size_t)d], pp, s);
       upload_vec(F.utile[(size_t)d], uu, s);
+      upload_vec(F.atile[(size_t)d], aa, s);
       for (int sl = 0; sl < 2; ++sl) {
         std::vector<int64_t> &cc = F.h_ctile[sl][(size_t)d];
         cc.assign(1, 0);
@@ -999,8 +1021,13 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
         extent = std::max(extent, plan.foff[(size_t)f] + (int64_t)T.ld[(size_t)f] * std::max(T.fs(f), 1));
       }
       SPL_HIP(hipMemsetAsync(region_of(d), 0, (size_t)extent * sizeof(double), s));
-      hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(((size_t)T.n * 8 + 255) / 256)), dim3(256), 0, s, T.n, d_Ap,
-                         d_Ai, d_Ax, d_inv, F.view, d, lo, hi);
+      {
+        const int64_t groups = F.h_atile[(size_t)d][(size_t)b1] - F.h_atile[(size_t)d][(size_t)b0];
+        if (groups > 0)
+          hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)groups), dim3(256), 0, s,
+                             F.level_lists[(size_t)d].get() + b0, F.atile[(size_t)d].get() + b0, b1 - b0, F.view, d_perm,
+                             d_inv, d_Ap, d_Ai, d_Ax, d_Rp, d_Rj, d_Rx);
+      }
       // ... and the Schur complements of the children, one child slot after the other (two children
       // of a parent may touch the same entry: a fixed order keeps the sums reproducible)
       if (d + 1 < nd) {

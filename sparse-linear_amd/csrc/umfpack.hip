@@ -464,7 +464,9 @@ void factor_multifrontal(Numeric *N, hipStream_t s) {
   const size_t free_b = device_free_bytes();
   if (mf_device_bytes(*N->tree) > free_b - free_b / 8) throw DeviceError{SPL_ERROR_out_of_memory};
   N->nopiv = 1;
-  N->mfact = mf_factor(N->tree, N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), N->inv.get(), s);
+  if (!N->A->rowptr.get()) throw DeviceError{SPL_ERROR_index_overflow};  // int32 row pointers at this seam
+  N->mfact = mf_factor(N->tree, N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), N->A->rowptr.get(),
+                       N->A->colidx.get(), N->A->val.get(), N->perm.get(), N->inv.get(), s);
   N->singular = mf_singular(N->mfact);
 }
 
