@@ -87,11 +87,20 @@ int band_nopiv_factor(int n, int kl, int ku, int ldab, double *d_AB, double *d_i
                      d_inv, b);
   DBuf<int> singular(1);
   SPL_HIP(hipMemsetAsync(singular.get(), 0, sizeof(int), s));
-  factor_loop(b, n, d_invs, singular.get(), s);
+  // wide bands: the look-ahead tile of every window on a helper stream (factor_loop)
+  hipStream_t helper = nullptr;
+  if (std::min(kl, ku) / 64 + 1 >= kSplitTiles) SPL_HIP(hipStreamCreateWithFlags(&helper, hipStreamNonBlocking));
   int h = 0;
-  SPL_HIP(hipMemcpyAsync(&h, singular.get(), sizeof(int), hipMemcpyDeviceToHost, s));
-  SPL_HIP(hipStreamSynchronize(s));
-  SPL_HIP(hipGetLastError());
+  try {
+    factor_loop(b, n, d_invs, singular.get(), s, helper);
+    SPL_HIP(hipMemcpyAsync(&h, singular.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipStreamSynchronize(s));
+    SPL_HIP(hipGetLastError());
+  } catch (...) {
+    if (helper) { (void)hipStreamSynchronize(helper); (void)hipStreamDestroy(helper); }
+    throw;
+  }
+  if (helper) (void)hipStreamDestroy(helper);  // joined into s by factor_loop's events, and s is idle
   return h;
 }
 

@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256) void trsm_gemm_kernel(Band b, int j0, int jb, 
 // invert it while the other tiles are still being updated, which takes the diagonal-block chain
 // off the critical path.
 constexpr int KS = 32;
+constexpr int kSplitTiles = 64;  // windows of at least this many tiles a side split off the look-ahead tile (factor_loop)
 struct Region {
   int rb, re, cb, ce, kb, klen, lshape, ntile_rows;
   int npiv;  // pivots of the (partial) factorisation: the look-ahead only factors blocks below it
@@ -413,6 +414,16 @@ __global__ __launch_bounds__(256) void gemm_update_kernel(Band b, Region g, int 
   }
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   update_tile<true>(b, g, tx, ty, singular, next_invL, next_invU, dsm);
+}
+
+// The same pass without tile (0,0) and without the look-ahead code: 168 registers instead of 172,
+// which is the step from two to three wavefronts per SIMD.  Large windows run this kernel on the
+// main stream and tile (0,0) with its look-ahead as a one-workgroup launch of gemm_update_kernel on a
+// helper stream beside it (factor_loop).
+__global__ __launch_bounds__(256) void gemm_update_bulk_kernel(Band b, Region g, int *__restrict__ singular) {
+  if (blockIdx.x == 0 && blockIdx.y == 0) return;
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  update_tile<false>(b, g, (int)blockIdx.x, (int)blockIdx.y, singular, nullptr, nullptr, dsm);
 }
 
 // The whole partial factorisation of one SMALL dense front by ONE workgroup (the multifrontal tree
@@ -661,6 +672,8 @@ inline void set_factor_attributes() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
   SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_update_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));  // uses less
+  SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_update_bulk_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
   attr_set = true;
 }
 
@@ -668,8 +681,26 @@ inline void set_factor_attributes() {
 // (npiv = b.n: the whole matrix); the trailing block is left holding the Schur complement.  The
 // inverses of the diagonal blocks go to d_invs (inverse_block_elems(npiv) doubles), a zero pivot sets
 // *d_singular.  Asynchronous on stream s.
-inline void factor_loop(const Band &b, int npiv, double *d_invs, int *d_singular, hipStream_t s) {
+// `helper`: a second stream for the look-ahead tile of large windows (nullptr: everything on s); the
+// two streams are joined by events inside, the caller only sees s.
+struct LookaheadFork {
+  hipStream_t helper = nullptr;
+  hipEvent_t ready = nullptr, done = nullptr;
+  explicit LookaheadFork(hipStream_t h) : helper(h) {
+    if (!helper) return;
+    SPL_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    SPL_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+  }
+  ~LookaheadFork() {
+    if (ready) (void)hipEventDestroy(ready);
+    if (done) (void)hipEventDestroy(done);
+  }
+};
+
+inline void factor_loop(const Band &b, int npiv, double *d_invs, int *d_singular, hipStream_t s,
+                        hipStream_t helper = nullptr) {
   set_factor_attributes();
+  LookaheadFork fork(helper);
   const int n = b.n, kl = b.kl, ku = b.ku;
   const size_t gemm_lds = kTileBytes + 2 * NB * sizeof(double);
   auto slot = [&](int j) { return d_invs + (size_t)(j / NB) * (2 * NB * NB); };
@@ -694,6 +725,19 @@ inline void factor_loop(const Band &b, int npiv, double *d_invs, int *d_singular
     if (re <= origin || ce <= origin) return false;
     const int ntr = (re - origin + 63) / 64, ntc = (ce - origin + 63) / 64;
     Region g{origin, re, origin, ce, kb, klen, lshape ? 1 : 0, ntr, npiv};
+    if (!lshape && fork.helper && ntr >= kSplitTiles && ntc >= kSplitTiles) {
+      // tile (0,0) and the next diagonal block on the helper stream, the rest of the window at three
+      // wavefronts per SIMD on this one; both start after the panel solves and meet again after
+      SPL_HIP(hipEventRecord(fork.ready, s));
+      SPL_HIP(hipStreamWaitEvent(fork.helper, fork.ready, 0));
+      hipLaunchKernelGGL(gemm_update_kernel, dim3(1, 1), dim3(256), gemm_lds, fork.helper, b, g, d_singular,
+                         slot(origin), slot(origin) + NB * NB);
+      SPL_HIP(hipEventRecord(fork.done, fork.helper));
+      hipLaunchKernelGGL(gemm_update_bulk_kernel, dim3((unsigned)ntr, (unsigned)ntc), dim3(256), gemm_lds, s, b, g,
+                         d_singular);
+      SPL_HIP(hipStreamWaitEvent(s, fork.done, 0));
+      return origin < npiv;
+    }
     const dim3 grid = lshape ? dim3((unsigned)(ntr + ntc - 1)) : dim3((unsigned)ntr, (unsigned)ntc);
     hipLaunchKernelGGL(gemm_update_kernel, grid, dim3(256), gemm_lds, s, b, g, d_singular, slot(origin),
                        slot(origin) + NB * NB);

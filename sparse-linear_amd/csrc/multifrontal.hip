@@ -703,8 +703,9 @@ struct Factors {
     std::lock_guard<std::mutex> lk(mu);
     std::unique_ptr<hipStream_t[]> &set = sets[device];
     if (!set) {
-      std::unique_ptr<hipStream_t[]> fresh(new hipStream_t[kStreams]);
-      for (int i = 0; i < kStreams; ++i) SPL_HIP(hipStreamCreateWithFlags(&fresh[i], hipStreamNonBlocking));
+      // kStreams for the fronts, kStreams beside them for the look-ahead tiles of their large windows
+      std::unique_ptr<hipStream_t[]> fresh(new hipStream_t[2 * kStreams]);
+      for (int i = 0; i < 2 * kStreams; ++i) SPL_HIP(hipStreamCreateWithFlags(&fresh[i], hipStreamNonBlocking));
       set = std::move(fresh);
     }
     side = set.get();
@@ -1116,7 +1117,8 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
         const int f = T.by_depth[(size_t)d][(size_t)i];
         if (T.np[(size_t)f] == 0 || T.fs(f) <= mid_limit) continue;
         const Band b = dense_view(region_of(d) + plan.foff[(size_t)f], T.fs(f), T.ld[(size_t)f]);
-        factor_loop(b, T.np[(size_t)f], F.invs.get() + T.ioff[(size_t)f], singular.get(), side[turn++ % kStreams]);
+        const int lane = turn++ % kStreams;
+        factor_loop(b, T.np[(size_t)f], F.invs.get() + T.ioff[(size_t)f], singular.get(), side[lane], side[kStreams + lane]);
       }
       if (turn > 0)
         for (int i = 0; i < kStreams && i < turn; ++i) SPL_HIP(hipStreamSynchronize(side[i]));
