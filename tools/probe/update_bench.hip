@@ -142,6 +142,20 @@ int main(int argc, char **argv) {
              2.0 * w * w * 128 / ms * 1e-9, 16.0 * w * w / ms * 1e-9);
     }
   }
+  {  // (2b) the same pass by the kernel without the look-ahead code (three wavefronts per SIMD)
+    const int origin = 128;
+    const int nt = (n - origin) / 64;
+    Region g2{origin, origin + nt * 64, origin, origin + nt * 64, 0, 128, 0, nt, 0};
+    for (int rep = 0; rep < 2; ++rep) {
+      SPL_HIP(hipEventRecord(e0, s));
+      for (int i = 0; i < 5; ++i)
+        hipLaunchKernelGGL(gemm_update_bulk_kernel, dim3(nt, nt), dim3(256), kTileBytes + 2 * NB * sizeof(double), s, b, g2, sing);
+      SPL_HIP(hipEventRecord(e1, s));
+      const float ms = elapsed(e0, e1) / 5;
+      const double w = (double)nt * 64;
+      printf("bulk (3 wavefronts per SIMD) update pass K=128 on %d^2: %.3f ms, %.1f TFLOP/s\n", nt * 64, ms, 2.0 * w * w * 128 / ms * 1e-9);
+    }
+  }
   {  // (3)
     hipLaunchKernelGGL(fill_kernel, dim3(n), dim3(256), 0, s, A, (size_t)n, ld);
     SPL_HIP(hipEventRecord(e0, s));
