@@ -203,37 +203,58 @@ __device__ __forceinline__ void zero_acc(double4v (&acc)[2][2]) {
 }
 
 // panel solves as GEMMs: tiles [0, ntile_l): L21 tile (64 rows) <- A21 tile * invU;
-// tiles [ntile_l, ...): U12 tile (64 columns) <- invL * A12 tile.  In place.
+// tiles [ntile_l, ...): U12 tile (64 columns) <- invL * A12 tile.  In place.  Both operands are
+// requested from memory at once (32 loads in flight per thread: the kernel is a latency chain
+// between the diagonal block and the update) and go through LDS in two K-halves of 32, so that
+// four workgroups fit a CU.
+constexpr size_t kTrsmLds = (size_t)2 * 32 * (NB + 1) * sizeof(double);
 __device__ __forceinline__ void trsm_tile(const Band &b, int j0, int jb, int nrows_below, int ncols_right,
                                           const double *__restrict__ invL, const double *__restrict__ invU,
                                           int tile, double *dsm) {
+  constexpr int KH = 32;
   double(*Cs)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);            // [k][output column]
-  double(*Rs)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + NB * LDP);  // [k][output row]
+  double(*Rs)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + KH * LDP);  // [k][output row]
   const int tid = threadIdx.x;
   const int ntile_l = (nrows_below + 63) / 64;
   const bool is_l = tile < ntile_l;
   const int rend = j0 + jb + nrows_below, cend = j0 + jb + ncols_right;
+  const int lo = tid % 64, hi = tid / 64;  // t = tid + 256 u  ->  t % 64 = lo, t / 64 = hi + 4 u
   int r0, c0;
+  double rv[16], cv[16];  // Rs[hi + 4 u][lo] and Cs[lo][hi + 4 u] of this thread
   if (is_l) {
     r0 = j0 + jb + tile * 64, c0 = j0;
-    for (int t = tid; t < NB * 64; t += 256) {  // Rs[k][r] = A21(r0 + r, j0 + k)
-      const int r = t % 64, k = t / 64;
-      Rs[k][r] = (k < jb && r0 + r < rend) ? b.get(r0 + r, j0 + k) : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = hi + 4 * u;  // Rs[k][r] = A21(r0 + r, j0 + k)
+      rv[u] = (k < jb && r0 + lo < rend) ? b.get(r0 + lo, j0 + k) : 0.0;
     }
-    for (int t = tid; t < NB * NB; t += 256) Cs[t % NB][t / NB] = invU[t];  // Cs[k][c] = invU(k, c)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) cv[u] = invU[tid + 256 * u];  // Cs[k][c] = invU(k, c), k = lo, c = hi + 4 u
   } else {
     r0 = j0, c0 = j0 + jb + (tile - ntile_l) * 64;
-    for (int t = tid; t < NB * NB; t += 256) Rs[t / NB][t % NB] = invL[t];  // Rs[k][r] = invL(r, k)
-    for (int t = tid; t < NB * 64; t += 256) {  // Cs[k][c] = A12(j0 + k, c0 + c)
-      const int k = t % NB, c = t / NB;
-      Cs[k][c] = (k < jb && c0 + c < cend) ? b.get(j0 + k, c0 + c) : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) rv[u] = invL[tid + 256 * u];  // Rs[k][r] = invL(r, k), r = lo, k = hi + 4 u
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int c = hi + 4 * u;  // Cs[k][c] = A12(j0 + k, c0 + c), k = lo
+      cv[u] = (lo < jb && c0 + c < cend) ? b.get(j0 + lo, c0 + c) : 0.0;
     }
   }
-  __syncthreads();
   const TilePos p;
   double4v acc[2][2];
   zero_acc(acc);
-  mfma_tile_64<NB>(Cs, Rs, p, acc);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) Rs[hi + 4 * u][lo] = rv[8 * h + u];  // k = hi + 4 (8 h + u) = 32 h + (hi + 4 u)
+    if (lo / KH == h) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) Cs[lo - KH * h][hi + 4 * u] = cv[u];
+    }
+    __syncthreads();
+    mfma_tile_64<KH>(Cs, Rs, p, acc);
+  }
   const int rlim = is_l ? rend : j0 + jb, clim = is_l ? j0 + jb : cend;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -714,7 +735,7 @@ inline void factor_loop(const Band &b, int npiv, double *d_invs, int *d_singular
     const int below = below_of(j0 + jb), right = right_of(j0 + jb);
     const int tiles = (below + 63) / 64 + (right + 63) / 64;
     if (tiles > 0)
-      hipLaunchKernelGGL(trsm_gemm_kernel, dim3((unsigned)tiles), dim3(256), 2 * kTileBytes, s, b, j0, jb, below,
+      hipLaunchKernelGGL(trsm_gemm_kernel, dim3((unsigned)tiles), dim3(256), kTrsmLds, s, b, j0, jb, below,
                          right, slot(j0), slot(j0) + NB * NB);
   };
   // trailing update of rows/cols from `origin` with the K range [kb, kb+klen); factors the diagonal

@@ -1103,7 +1103,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
             const size_t base = ((size_t)st * 2) * (size_t)(count + 1);
             const int64_t nt = hp[base + (size_t)count], nu = hp[base + (size_t)(count + 1) + (size_t)count];
             if (nt > 0)
-              hipLaunchKernelGGL(mid_trsm_kernel, dim3((unsigned)nt), dim3(256), 2 * kTileBytes, s, dl, dp + base, count,
+              hipLaunchKernelGGL(mid_trsm_kernel, dim3((unsigned)nt), dim3(256), kTrsmLds, s, dl, dp + base, count,
                                  st, F.view, F.invs.get());
             if (nu > 0)
               hipLaunchKernelGGL(mid_update_kernel, dim3((unsigned)nu), dim3(256),
