@@ -622,11 +622,13 @@ __device__ __forceinline__ void gemv_inv(const double *__restrict__ inv, const d
 }
 
 // NR right-hand sides at once: column r of in/out starts at r * stride
-// `tile`: which 64 rows outside the super block this workgroup updates (tile 0 also writes `out`)
+// `tile`: which rows outside the super block this workgroup updates: `tiles` consecutive blocks of 64
+// rows starting at block tile * tiles (workgroup 0 also writes `out`).  Every workgroup redoes the
+// in-super-block solve first, so large systems take several blocks per workgroup.
 template <int MODE, int NR>
 __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__restrict__ invs, int j0, int jbs,
                                                  double *in, double *__restrict__ out, size_t stride, int tile,
-                                                 double *dsm) {
+                                                 double *dsm, int tiles = 1) {
   double(*v)[NR] = reinterpret_cast<double(*)[NR]>(dsm);                          // [SB * NB]
   double(*w)[NR] = reinterpret_cast<double(*)[NR]>(dsm + SB * NB * NR);           // [NB]
   double(*res)[NR] = reinterpret_cast<double(*)[NR]>(dsm + (SB + 1) * NB * NR);   // [NB]
@@ -661,14 +663,19 @@ __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__
       const int t = o % jbs, r = o / jbs;
       out[(size_t)r * stride + j0 + t] = v[t][r];
     }
-  // the 64 rows of this workgroup outside the super block
-  const int rb = fwd ? j0 + jbs + tile * 64 : j0 - (tile + 1) * 64;
-  gemv64<MODE, NR>(b, rb, j0, jbs, v, res, part);
-  for (int o = tid; o < 64 * NR; o += SW * 64) {
-    const int l = o % 64, r = o / 64;
-    const int i = rb + l;
-    const bool ok = fwd ? (i < b.n) : (i >= 0);
-    if (ok) in[(size_t)r * stride + i] -= res[l][r];
+  // the rows of this workgroup outside the super block, 64 at a time
+  for (int q = 0; q < tiles; ++q) {
+    const int blk = tile * tiles + q;
+    const int rb = fwd ? j0 + jbs + blk * 64 : j0 - (blk + 1) * 64;
+    if (fwd ? rb >= b.n : rb + 64 <= 0) break;  // workgroup-uniform
+    gemv64<MODE, NR>(b, rb, j0, jbs, v, res, part);
+    for (int o = tid; o < 64 * NR; o += SW * 64) {
+      const int l = o % 64, r = o / 64;
+      const int i = rb + l;
+      const bool ok = fwd ? (i < b.n) : (i >= 0);
+      if (ok) in[(size_t)r * stride + i] -= res[l][r];
+    }
+    __syncthreads();  // res and part are reused by the next block
   }
 }
 

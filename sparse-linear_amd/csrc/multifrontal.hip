@@ -266,6 +266,7 @@ constexpr int kStreams = 8;        // larger fronts of a level are spread over t
 // NR right-hand sides travel through the tree together: every front has a work matrix W (fs x NR,
 // column-major), column r of the right-hand sides / solution is c + r * stride.
 constexpr int kSolveThreads = 1024;  // one workgroup per front, 16 wavefronts for the coupling loops
+constexpr int kSolveRowBlocks = 4;   // blocks of 64 rows per workgroup in the lockstep solve steps
 constexpr int kBigSolve = 256;       // fronts above this size are solved by many workgroups, in lockstep
 
 // The panels of a front as the solves see them.  M is the triangular system a front contributes:
@@ -506,7 +507,7 @@ template <int MODE, int NR>
 __global__ __launch_bounds__(SW * 64) void big_super_kernel(const int *__restrict__ list,
                                                             const int64_t *__restrict__ prefix, int count, int step,
                                                             TreeView t, const double *__restrict__ invs,
-                                                            double *work, double *zbuf) {
+                                                            double *work, double *zbuf, int row_blocks) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   constexpr bool fwd = (MODE == 0 || MODE == 2);
   const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(SW * 64) void big_super_kernel(const int *__restric
   const int n = MODE == 0 ? b.fs : b.np;
   const Band band{const_cast<double *>(b.P), n, n, n, b.ldp + 1, 0};
   solve_super_tile<MODE, NR>(band, invs + t.ioff[b.f], j0, jbs, fwd ? b.W : b.Z, fwd ? b.Z : b.W, (size_t)b.fs,
-                             b.blk, dsm);
+                             b.blk, dsm, row_blocks);
 }
 
 // boundary part of the solution into the front's work matrix: W[r * fs + np + k] = x[r * stride + bidx[k]]
@@ -678,6 +679,7 @@ struct Factors {
   // transposed forward pass, gather, gemv, scatter
   struct BigLevel {
     int count = 0, steps = 0;
+    int row_blocks = 1;  // blocks of 64 rows per workgroup in the super-block steps (levels that fill the chip: more)
     DBuf<int> list;
     std::vector<int64_t> h;
     DBuf<int64_t> d;
@@ -895,6 +897,12 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
       constexpr int span = SB * NB;
       for (int f : large) B.steps = std::max(B.steps, (T.np[(size_t)f] + span - 1) / span);
       if (B.count > 0) {
+        // every workgroup of a step redoes the in-super-block solve: where the first step alone
+        // would launch thousands of workgroups, each takes kSolveRowBlocks blocks of rows instead
+        int64_t first_step = 0;
+        for (int f : large) first_step += (T.fs(f) + 63) / 64;
+        B.row_blocks = first_step >= 4096 ? kSolveRowBlocks : 1;
+        const int rbk = B.row_blocks;
         B.h.assign((size_t)(3 * B.steps + 4) * (size_t)(B.count + 1), 0);
         auto fill = [&](int kind, int k, auto groups_of) {
           int64_t *pre = B.h.data() + B.seg(kind, k);
@@ -905,14 +913,14 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
             const int np = T.np[(size_t)f], j0 = k * span;
             if (j0 >= np) return 0;
             const int jbs = std::min(span, np - j0);
-            return std::max(1, (n - (j0 + jbs) + 63) / 64);
+            return std::max(1, ((n - (j0 + jbs) + 63) / 64 + rbk - 1) / rbk);
           };
           fill(0, k, [&](int f) { return fwd_rows(f, T.fs(f)); });
           fill(1, k, [&](int f) { return fwd_rows(f, T.np[(size_t)f]); });
           fill(2, k, [&](int f) -> int64_t {
             const int np = T.np[(size_t)f], nsup = (np + span - 1) / span;
             if (k >= nsup) return 0;
-            return std::max(1, ((nsup - 1 - k) * span + 63) / 64);
+            return std::max(1, (((nsup - 1 - k) * span + 63) / 64 + rbk - 1) / rbk);
           });
         }
         fill(3, 0, [&](int f) -> int64_t { return (T.nb[(size_t)f] + 3) / 4; });
@@ -1172,7 +1180,7 @@ static void launch_big_super(const mf::Factors &F, const mf::Factors::BigLevel &
   const unsigned groups = B.total(kind, step);
   if (groups > 0)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(big_super_kernel<MODE, NR>), dim3(groups), dim3(SW * 64), lds, s, B.list.get(),
-                       B.prefix(kind, step), B.count, step, F.view, F.invs.get(), work, zbuf);
+                       B.prefix(kind, step), B.count, step, F.view, F.invs.get(), work, zbuf, B.row_blocks);
 }
 
 template <bool TRANS, int NR>
