@@ -91,6 +91,7 @@ struct Shared {
   // (team_bfs); allocated only when the graph is large enough for a team
   std::vector<uint64_t> claim;
   int max_team = 1;
+  int team_region = kTeamRegion, team_frontier = kTeamFrontier;  // SPL_ND_TEAM_REGION / _FRONTIER (experiments)
   bool timing = false;
   std::atomic<int> stamp{0};
   Shared(int n_, const std::vector<int64_t> &xa, const std::vector<int> &ad, int leaf_)
@@ -100,7 +101,9 @@ struct Shared {
     max_team = (int)std::min<unsigned>(hw ? hw : 1, kMaxTeam);
     timing = getenv("SPL_MF_TIMING") != nullptr;
     if (const char *e = getenv("SPL_ND_TEAM")) max_team = std::max(1, std::min(atoi(e), 64));
-    if (n >= kTeamRegion && max_team > 1) claim.assign((size_t)n, 0);
+    if (const char *e = getenv("SPL_ND_TEAM_REGION")) team_region = std::max(1024, atoi(e));
+    if (const char *e = getenv("SPL_ND_TEAM_FRONTIER")) team_frontier = std::max(64, atoi(e));
+    if (n >= team_region && max_team > 1) claim.assign((size_t)n, 0);
   }
 };
 
@@ -190,12 +193,12 @@ struct Worker {
         // places marked (W); a barrier separates each of them from the reads of every thread on
         // either side, so all threads take the same branch here.
         if (!more) return;
-        if (hi - lo < (size_t)kTeamFrontier) {
+        if (hi - lo < (size_t)S.team_frontier) {
           // narrow levels are not worth a barrier each: the first thread expands them by itself,
           // as bfs() does, until the frontier is wide again or the traversal ends
           barrier.wait();  // everyone has read the state
           if (t == 0) {    // (W)
-            while (more && hi - lo < (size_t)kTeamFrontier) {
+            while (more && hi - lo < (size_t)S.team_frontier) {
               size_t end = hi;
               for (size_t i = lo; i < hi; ++i) {
                 const int v = queue[i];
@@ -279,7 +282,7 @@ struct Worker {
   int traverse(int root, int accept, int size) {
     // regions of one depth run side by side: each gets its share of the threads
     const int team = (int)(((int64_t)S.max_team * size + S.n / 2) / std::max(S.n, 1));
-    if (team >= 2 && size >= kTeamRegion && !S.claim.empty()) return team_bfs(root, accept, team, size);
+    if (team >= 2 && size >= S.team_region && !S.claim.empty()) return team_bfs(root, accept, team, size);
     return bfs(root, accept);
   }
 
