@@ -11,7 +11,7 @@ def grid(m):
     T = sp.diags([-np.ones(m - 1), 2 * np.ones(m), -np.ones(m - 1)], (-1, 0, 1)); I = sp.identity(m)
     return sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(T, I), I)
 rng = np.random.default_rng(3)
-for m in (30, 48):
+for m in ([int(t) for t in sys.argv[1].split(',')] if len(sys.argv) > 1 else (30, 48)):
     for sigma in (0.0, 0.37, 1.03, 3.1, 6.2):
         S = sp.csc_matrix(grid(m) - sigma * sp.identity(m ** 3)); S.sort_indices(); n = m ** 3
         A = pkg.Matrix(n, n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
