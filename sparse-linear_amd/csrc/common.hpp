@@ -7,6 +7,7 @@
 #include <string.h>
 #include <memory>
 #include <new>
+#include <vector>
 
 #include "../../include/sparse_linear_hip.h"
 
@@ -156,6 +157,9 @@ void segmented_sort_pairs_capped(const int64_t *d_ptr64, int64_t nseg, int *d_ke
 void segmented_sort_pairs64(const int64_t *d_ptr64, int64_t nseg, int64_t *d_key, double *d_val,
                             hipStream_t s);
 // finish a Matrix whose rowptr64/colidx/val are filled: int32 pointers, stats
+// the `zi` wrapper's note on a `di` Numeric object: which row pairs of the embedding it swapped
+void numeric_set_pair_swap(void *Numeric, std::vector<char> &&flags);
+const std::vector<char> *numeric_pair_swap(void *Numeric);  // nullptr: none
 void finalize_matrix(Matrix *m, hipStream_t s);
 void measure_locality(Matrix *m, hipStream_t s);  // fills new_line_fraction on first call
 

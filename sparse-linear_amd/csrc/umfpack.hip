@@ -74,6 +74,8 @@ struct Numeric {
   std::vector<int> band_perm, band_inv;
   Matrix *A = nullptr;   // rows of A   (residual b - A x)
   Matrix *At = nullptr;  // rows of A^T (residual b - A^T x)
+  // set by the `zi` wrapper (umfpack_zi.hip): rows 2r, 2r+1 of the real embedding were swapped
+  std::vector<char> pair_swap;
   ~Numeric() {
     delete A;
     delete At;
@@ -824,6 +826,20 @@ int spl_umfpack_di_solve_many(int sys, const int Ap[], const int Ai[], const dou
   if (sys != UMFPACK_A && sys != UMFPACK_At) return UMFPACK_ERROR_invalid_system;
   return solve_columns(N, sys, nrhs, X, B);
 }
+
+}  // extern "C"
+
+namespace spl {
+void numeric_set_pair_swap(void *NumericIn, std::vector<char> &&flags) {
+  if (Numeric *N = as_numeric(NumericIn)) N->pair_swap = std::move(flags);
+}
+const std::vector<char> *numeric_pair_swap(void *NumericIn) {
+  Numeric *N = as_numeric(NumericIn);
+  return N && !N->pair_swap.empty() ? &N->pair_swap : nullptr;
+}
+}  // namespace spl
+
+extern "C" {
 
 // dimension of the factored system (used by the `zi` wrappers in split-array mode); 0 if invalid
 int spl_umfpack_dimension(void *NumericIn) {

@@ -11,6 +11,8 @@
 // complex band kernel (half the index traffic) is the follow-up; values differ from a complex-
 // arithmetic LU only in rounding, and `ident <\> v == v` (suitesparse/tests/test-umfpack.hs:16-19,
 // on Vector (Complex Double)) holds exactly.
+#include <cmath>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -24,7 +26,9 @@ struct Embedded {
   std::vector<double> x;
 };
 
-bool embed(int n, const int *Ap, const int *Ai, const double *Ax, const double *Az, bool values, Embedded &E) {
+// swap[r] != 0: the two real rows of complex row r change places (static pivoting, see numeric)
+bool embed(int n, const int *Ap, const int *Ai, const double *Ax, const double *Az, bool values, Embedded &E,
+           const char *swap = nullptr) {
   const long nnz = Ap[n];
   if (4 * nnz >= 0x7fffffffL) return false;
   E.p.resize((size_t)2 * n + 1);
@@ -41,8 +45,10 @@ bool embed(int n, const int *Ap, const int *Ai, const double *Ax, const double *
         if (values) {
           const double re = Az ? Ax[p] : Ax[2 * (size_t)p];
           const double im = Az ? Az[p] : Ax[2 * (size_t)p + 1];
-          E.x[(size_t)q] = half == 0 ? re : -im;
-          E.x[(size_t)q + 1] = half == 0 ? im : re;
+          const double top = half == 0 ? re : -im, bottom = half == 0 ? im : re;
+          const bool sw = swap && swap[r];
+          E.x[(size_t)q] = sw ? bottom : top;
+          E.x[(size_t)q + 1] = sw ? top : bottom;
         }
         q += 2;
       }
@@ -50,6 +56,12 @@ bool embed(int n, const int *Ap, const int *Ai, const double *Ax, const double *
   }
   E.p[(size_t)2 * n] = (int)q;
   return true;
+}
+
+// v <- Q v: the entries 2r, 2r+1 of a packed complex vector change places where swap[r] is set
+void swap_pairs(const std::vector<char> &swap, double *v) {
+  for (size_t r = 0; r < swap.size(); ++r)
+    if (swap[r]) std::swap(v[2 * r], v[2 * r + 1]);
 }
 
 struct ZiSymbolic {  // remembers n so that numeric can rebuild the embedding
@@ -98,9 +110,26 @@ int umfpack_zi_numeric(const int Ap[], const int Ai[], const double Ax[], const 
   if (!S || S->magic != 0x5A53594Du) return UMFPACK_ERROR_invalid_Symbolic_object;
   if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;
   try {
+    // Static pivoting inside the 2 x 2 blocks of the diagonal.  The scalar factorisation of the
+    // embedding pivots on the REAL part of a complex diagonal entry first; where the imaginary part
+    // is the larger one (a shift z I - A close to the real axis of A's diagonal: pivot ~ 0), the two
+    // real equations of that complex row change places, so that the first pivot is the imaginary
+    // part.  A row permutation Q of the system: (Q E) x = Q b; E^T y = c is (Q E)^T (Q y) = c.  The
+    // pattern of the embedding does not change (every block is a full 2 x 2).
+    const int n = S->n;
+    std::vector<char> swap((size_t)n, 0);
+    bool any = false;
+    for (int j = 0; j < n; ++j)
+      for (int p = Ap[j]; p < Ap[j + 1]; ++p)
+        if (Ai[p] == j) {
+          const double re = Az ? Ax[p] : Ax[2 * (size_t)p], im = Az ? Az[p] : Ax[2 * (size_t)p + 1];
+          if (std::fabs(im) > std::fabs(re)) { swap[(size_t)j] = 1; any = true; }
+        }
     Embedded E;
-    if (!embed(S->n, Ap, Ai, Ax, Az, true, E)) return UMFPACK_ERROR_out_of_memory;
-    return umfpack_di_numeric(E.p.data(), E.i.data(), E.x.data(), S->di, Numeric, Control, Info);
+    if (!embed(n, Ap, Ai, Ax, Az, true, E, any ? swap.data() : nullptr)) return UMFPACK_ERROR_out_of_memory;
+    const int st = umfpack_di_numeric(E.p.data(), E.i.data(), E.x.data(), S->di, Numeric, Control, Info);
+    if (st >= 0 && any) spl::numeric_set_pair_swap(*Numeric, std::move(swap));
+    return st;
   } catch (const std::bad_alloc &) {
     return UMFPACK_ERROR_out_of_memory;
   }
@@ -113,17 +142,27 @@ int umfpack_zi_solve(int sys, const int Ap[], const int Ai[], const double Ax[],
   if (!Xx || !Bx) return UMFPACK_ERROR_argument_missing;
   if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;
   // the Numeric object holds device copies of E and E^T (residuals use those, like the `di` path)
-  if (!Xz && !Bz) return umfpack_di_solve(sys, Ap, Ai, Ax, Xx, Bx, Numeric, Control, Info);
-  // split real / imaginary arrays: interleave, solve, de-interleave
+  const std::vector<char> *swap = spl::numeric_pair_swap(Numeric);
+  if (!Xz && !Bz && !swap) return umfpack_di_solve(sys, Ap, Ai, Ax, Xx, Bx, Numeric, Control, Info);
+  // split real / imaginary arrays and / or swapped row pairs: interleave, solve, de-interleave
   try {
     // UMFPACK's solve takes no dimension argument: it lives in the Numeric object
     const int n2 = spl_umfpack_dimension(Numeric);
     if (n2 <= 0) return UMFPACK_ERROR_invalid_Numeric_object;
     const int n = n2 / 2;
+    const bool packed = !Xz && !Bz;
     std::vector<double> b((size_t)n2), x((size_t)n2);
-    for (int k = 0; k < n; ++k) { b[(size_t)2 * k] = Bx[k]; b[(size_t)2 * k + 1] = Bz ? Bz[k] : 0.0; }
+    for (int k = 0; k < n; ++k) {
+      b[(size_t)2 * k] = packed ? Bx[(size_t)2 * k] : Bx[k];
+      b[(size_t)2 * k + 1] = packed ? Bx[(size_t)2 * k + 1] : (Bz ? Bz[k] : 0.0);
+    }
+    if (swap && sys == UMFPACK_A) swap_pairs(*swap, b.data());          // (Q E) x = Q b
     const int st = umfpack_di_solve(sys, Ap, Ai, Ax, x.data(), b.data(), Numeric, Control, Info);
-    for (int k = 0; k < n; ++k) { Xx[k] = x[(size_t)2 * k]; if (Xz) Xz[k] = x[(size_t)2 * k + 1]; }
+    if (swap && sys != UMFPACK_A) swap_pairs(*swap, x.data());          // y = Q w
+    for (int k = 0; k < n; ++k) {
+      if (packed) { Xx[(size_t)2 * k] = x[(size_t)2 * k]; Xx[(size_t)2 * k + 1] = x[(size_t)2 * k + 1]; }
+      else { Xx[k] = x[(size_t)2 * k]; if (Xz) Xz[k] = x[(size_t)2 * k + 1]; }
+    }
     return st;
   } catch (const std::bad_alloc &) {
     return UMFPACK_ERROR_out_of_memory;
@@ -141,21 +180,27 @@ int spl_umfpack_zi_solve_many(int sys, const int Ap[], const int Ai[], const dou
   const int n2 = spl_umfpack_dimension(Numeric);
   if (n2 < 0 || (n2 == 0 && !Numeric)) return UMFPACK_ERROR_invalid_Numeric_object;
   if (nrhs > 0 && n2 > 0 && (!Xx || !Bx)) return UMFPACK_ERROR_argument_missing;
-  if (!Xz && !Bz) return spl_umfpack_di_solve_many(sys, Ap, Ai, Ax, nrhs, Xx, Bx, Numeric);
+  const std::vector<char> *swap = spl::numeric_pair_swap(Numeric);
+  if (!Xz && !Bz && !swap) return spl_umfpack_di_solve_many(sys, Ap, Ai, Ax, nrhs, Xx, Bx, Numeric);
   try {
     const size_t n = (size_t)n2 / 2, tot = (size_t)n2 * (size_t)nrhs;
+    const bool packed = !Xz && !Bz;
     std::vector<double> b(tot), x(tot);
-    for (size_t c = 0; c < (size_t)nrhs; ++c)
+    for (size_t c = 0; c < (size_t)nrhs; ++c) {
       for (size_t k = 0; k < n; ++k) {
-        b[c * n2 + 2 * k] = Bx[c * n + k];
-        b[c * n2 + 2 * k + 1] = Bz ? Bz[c * n + k] : 0.0;
+        b[c * n2 + 2 * k] = packed ? Bx[c * n2 + 2 * k] : Bx[c * n + k];
+        b[c * n2 + 2 * k + 1] = packed ? Bx[c * n2 + 2 * k + 1] : (Bz ? Bz[c * n + k] : 0.0);
       }
+      if (swap && sys == UMFPACK_A) swap_pairs(*swap, b.data() + c * n2);
+    }
     const int st = spl_umfpack_di_solve_many(sys, Ap, Ai, Ax, nrhs, x.data(), b.data(), Numeric);
-    for (size_t c = 0; c < (size_t)nrhs; ++c)
+    for (size_t c = 0; c < (size_t)nrhs; ++c) {
+      if (swap && sys != UMFPACK_A) swap_pairs(*swap, x.data() + c * n2);
       for (size_t k = 0; k < n; ++k) {
-        Xx[c * n + k] = x[c * n2 + 2 * k];
-        if (Xz) Xz[c * n + k] = x[c * n2 + 2 * k + 1];
+        if (packed) { Xx[c * n2 + 2 * k] = x[c * n2 + 2 * k]; Xx[c * n2 + 2 * k + 1] = x[c * n2 + 2 * k + 1]; }
+        else { Xx[c * n + k] = x[c * n2 + 2 * k]; if (Xz) Xz[c * n + k] = x[c * n2 + 2 * k + 1]; }
       }
+    }
     return st;
   } catch (const std::bad_alloc &) {
     return UMFPACK_ERROR_out_of_memory;

@@ -87,3 +87,38 @@ def test_complex_batched_solve(gpu, pkg, O):
         got = U.linearSolveMany_(fact, mode, M, [op @ x for x in xs])
         for x, g in zip(xs, got):
             assert np.max(np.abs(g - x)) / np.max(np.abs(x)) < 1e-10
+
+
+def test_complex_diagonal_with_dominant_imaginary_parts(gpu, pkg, O):
+    """rows whose diagonal entry has the larger imaginary part swap their two real equations in the
+    embedding (static pivoting in the zi wrapper): mixed rows, both systems, one and several
+    right-hand sides; then the shift z I - A with Re z on A's diagonal (real pivot exactly 0)"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(21)
+    n = 150
+    rows = list(rng.integers(0, n, 600)) + list(range(n))
+    cols = list(rng.integers(0, n, 600)) + list(range(n))
+    diag = [complex(0.0, 30.0) if k % 3 == 0 else complex(28.0, 2.0) if k % 3 == 1 else complex(-1.0, -26.0)
+            for k in range(n)]
+    vals = list(rng.normal(size=600) + 1j * rng.normal(size=600)) + diag
+    A = pkg.fromTriples(n, n, list(zip(map(int, rows), map(int, cols), vals)))
+    D = pkg.pack(A)
+    U = pkg.umfpack
+    fact = U.factor(A, U.analyze(A))
+    xs = [rng.normal(size=n) + 1j * rng.normal(size=n) for _ in range(9)]
+    for mode, op in ((U.UmfpackNormal, D), (U.UmfpackTrans, D.conj().T)):
+        x = U.linearSolve_(fact, mode, A, op @ xs[0])
+        assert np.max(np.abs(x - xs[0])) < 1e-10
+        for want, got in zip(xs, U.linearSolveMany_(fact, mode, A, [op @ x for x in xs])):
+            assert np.max(np.abs(got - want)) < 1e-10
+    m = 40
+    rp, ci, v = O.gen_poisson2d_csr(m)
+    S = ((4.0 + 0.01j) * sp.identity(m * m) - sp.csc_matrix((v, ci, rp), shape=(m * m, m * m))).tocsc()
+    S.sort_indices()
+    M = pkg.Matrix(m * m, m * m, S.indptr, S.indices, S.data)
+    fact = U.factor(M, U.analyze(M))
+    assert fact.path in (2, 4)  # not thrown back to partial pivoting by a zero real pivot
+    want = rng.uniform(0.5, 1.5, m * m) + 1j * rng.uniform(0.5, 1.5, m * m)
+    got = U.linearSolve_(fact, U.UmfpackNormal, M, S @ want)
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-9
+    assert fact.path in (2, 4)
