@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""The FEAST-style driver (sparse-linear_amd/feast.py) on a 2-D Laplacian whose eigenvalues are known
+in closed form: eigenvalues inside a window, their errors, and the time.  Every contour point is one
+complex factorisation (umfpack_zi_numeric, same analysis) and one batched solve of the subspace.
+python tools/bench_feast.py --grid 200 --m0 24"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", type=int, default=200)
+    ap.add_argument("--m0", type=int, default=24)
+    ap.add_argument("--lo", type=float, default=0.02)
+    ap.add_argument("--hi", type=float, default=0.035)
+    args = ap.parse_args()
+    import numpy as np
+    import scipy.sparse as sp
+    import torch
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    torch.cuda.set_device(0)
+    m = args.grid
+    n = m * m
+    T = sp.diags([-np.ones(m - 1), 2 * np.ones(m), -np.ones(m - 1)], (-1, 0, 1))
+    S = (sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m))).tocsc()
+    S.sort_indices()
+    A = pkg.Matrix(n, n, S.indptr, S.indices, S.data.astype(np.complex128))
+    k = np.arange(1, m + 1)
+    ev1 = 2.0 - 2.0 * np.cos(k * np.pi / (m + 1))
+    exact = np.sort((ev1[:, None] + ev1[None, :]).ravel())
+    inside = exact[(exact > args.lo) & (exact < args.hi)]
+    t = time.perf_counter()
+    lam, X = pkg.feast.eigSH(args.m0, (args.lo, args.hi), A)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    lam = np.sort(np.asarray(lam))
+    ok = len(lam) == len(inside)
+    err = float(np.max(np.abs(lam - inside) / inside)) if ok and len(lam) else None
+    print(json.dumps({"matrix": "2-D Laplacian %d^2" % m, "n": n, "window": [args.lo, args.hi], "m0": args.m0,
+                      "eigenvalues_exact_in_window": len(inside), "found": len(lam), "max_rel_error": err,
+                      "seconds": round(dt, 3)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
