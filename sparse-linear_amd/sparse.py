@@ -42,7 +42,7 @@ def _oops(fn, msg):
 class Matrix(object):
     """Matrix in compressed sparse column (CSC) format (Sparse.hs:67-76)."""
 
-    __slots__ = ("ncols", "nrows", "pointers", "indices", "values", "_handle", "__weakref__")
+    __slots__ = ("ncols", "nrows", "pointers", "indices", "values", "_handle", "_embedding", "__weakref__")
 
     def __init__(self, ncols, nrows, pointers, indices, values):
         self.ncols = int(ncols)
@@ -53,6 +53,7 @@ class Matrix(object):
         # Double, or Complex Double (the reference's two SPECIALIZE instances, Sparse.hs:456-457)
         self.values = np.ascontiguousarray(values, dtype=C128 if np.iscomplexobj(values) else F64)
         self._handle = None
+        self._embedding = None
 
     @property
     def is_complex(self):
@@ -113,7 +114,10 @@ class Matrix(object):
         """the real 2nrows x 2ncols matrix with interleaved (re, im) unknowns whose action on packed
         complex vectors equals this complex matrix's: block (i,j) = [[re, -im], [im, re]].  Complex
         arithmetic on the device goes through this embedding in round 1 (native complex kernels:
-        SURVEY.md §8f rank 3)."""
+        SURVEY.md §8f rank 3).  Built once per matrix (matrices are immutable values), so that its
+        device handle is uploaded once too."""
+        if self._embedding is not None:
+            return self._embedding
         p, i, x = self.pointers, self.indices, self.values
         lens = np.diff(p)
         nnz = int(p[-1])
@@ -126,7 +130,8 @@ class Matrix(object):
         b = newp[2 * col + 1] + 2 * t
         idx[a], idx[a + 1], idx[b], idx[b + 1] = 2 * i, 2 * i + 1, 2 * i, 2 * i + 1
         val[a], val[a + 1], val[b], val[b + 1] = x.real, x.imag, -x.imag, x.real
-        return Matrix(2 * self.ncols, 2 * self.nrows, newp, idx, val)
+        self._embedding = Matrix(2 * self.ncols, 2 * self.nrows, newp, idx, val)
+        return self._embedding
 
     def device_handle(self):
         """Upload once, reuse for every later SpMV (handle API)."""
