@@ -1257,7 +1257,11 @@ void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride,
   const mf::Tree &T = *F.tree;
   if (T.n == 0 || k == 0) return;
   const int nr = k == 1 ? 1 : kSolveGroup;
-  DBuf<double> work((size_t)T.work_elems * nr), zbuf((size_t)T.work_elems * nr);
+  DBuf<double> both((size_t)T.work_elems * nr * 2);  // work and z matrices of all fronts, one allocation
+  struct Span {
+    double *p;
+    double *get() const { return p; }
+  } work{both.get()}, zbuf{both.get() + (size_t)T.work_elems * nr};
   if (k == 1) {
     if (sys == 0) solve_columns_on_tree<false, 1>(F, d_c, stride, work.get(), zbuf.get(), s);
     else solve_columns_on_tree<true, 1>(F, d_c, stride, work.get(), zbuf.get(), s);

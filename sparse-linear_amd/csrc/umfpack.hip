@@ -714,10 +714,16 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B)
     const int kalloc = k == 1 ? 1 : (k + kSolveGroup - 1) / kSolveGroup * kSolveGroup;
     const size_t total = stride * (size_t)kalloc, used = stride * (size_t)k;
     const dim3 grid((unsigned)((n + 255) / 256), (unsigned)k);
-    DBuf<double> db(total), dx(total), dwork(total), dr(total), dd(total), dax(total), dabs(total), dxn(total),
-        drn(total);
-    DBuf<double> domega((size_t)k);
-    for (DBuf<double> *buf : {&db, &dx, &dwork, &dr, &dd, &dxn, &drn})
+    // one allocation for all work vectors of the call (each hipMalloc / hipFree is a device round trip)
+    struct Span {
+      double *p;
+      double *get() const { return p; }
+    };
+    DBuf<double> slab(9 * total + (size_t)k);
+    Span db{slab.get()}, dx{slab.get() + total}, dwork{slab.get() + 2 * total}, dr{slab.get() + 3 * total},
+        dd{slab.get() + 4 * total}, dax{slab.get() + 5 * total}, dabs{slab.get() + 6 * total},
+        dxn{slab.get() + 7 * total}, drn{slab.get() + 8 * total}, domega{slab.get() + 9 * total};
+    for (const Span *buf : {&db, &dx, &dwork, &dr, &dd, &dxn, &drn})
       if (kalloc > k) SPL_HIP(hipMemsetAsync(buf->get() + used, 0, (total - used) * sizeof(double), s));
     SPL_HIP(hipMemcpyAsync(db.get(), B, used * sizeof(double), hipMemcpyHostToDevice, s));
     // speculative factors may be replaced below: solves on such an object take turns
