@@ -122,3 +122,45 @@ def test_complex_diagonal_with_dominant_imaginary_parts(gpu, pkg, O):
     got = U.linearSolve_(fact, U.UmfpackNormal, M, S @ want)
     assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-9
     assert fact.path in (2, 4)
+
+
+def test_zi_split_arrays_through_the_c_abi(gpu, pkg):
+    """umfpack_zi_* with separate real and imaginary arrays (Az, Xz, Bz non-NULL) — the form the
+    reference does not use but UMFPACK's ABI defines —, on a matrix whose diagonal mixes dominant real
+    and dominant imaginary parts; both systems, one and several right-hand sides"""
+    import ctypes as C
+    import scipy.sparse as sp
+    L = pkg._ffi.lib()
+    pkg.umfpack._declare()
+    rng = np.random.default_rng(5)
+    n = 90
+    S = (sp.random(n, n, density=0.05, random_state=3) + 1j * sp.random(n, n, density=0.05, random_state=4)).tocsc()
+    w = np.asarray(abs(S).sum(axis=0)).ravel() + 1.0
+    S = sp.csc_matrix(S + sp.diags(np.where(np.arange(n) % 2 == 0, w, -1j * w)))
+    S.sort_indices()
+    ap, ai = S.indptr.astype(np.int32), S.indices.astype(np.int32)
+    ax, az = np.ascontiguousarray(S.data.real), np.ascontiguousarray(S.data.imag)
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    P = lambda a, t: a.ctypes.data_as(t)
+    sym, num = C.c_void_p(), C.c_void_p()
+    assert L.umfpack_zi_symbolic(n, n, P(ap, ip), P(ai, ip), P(ax, dp), P(az, dp), C.byref(sym), None, None) == 0
+    assert L.umfpack_zi_numeric(P(ap, ip), P(ai, ip), P(ax, dp), P(az, dp), sym, C.byref(num), None, None) == 0
+    D = S.toarray()
+    for sys_, op in ((0, D), (1, D.conj().T)):
+        xs = rng.normal(size=n) + 1j * rng.normal(size=n)
+        b = op @ xs
+        bx, bz = np.ascontiguousarray(b.real), np.ascontiguousarray(b.imag)
+        xx, xz = np.zeros(n), np.zeros(n)
+        assert L.umfpack_zi_solve(sys_, P(ap, ip), P(ai, ip), P(ax, dp), P(az, dp), P(xx, dp), P(xz, dp), P(bx, dp),
+                                  P(bz, dp), num, None, None) == 0
+        assert np.max(np.abs(xx + 1j * xz - xs)) < 1e-10
+        k = 3
+        Xs = rng.normal(size=(k, n)) + 1j * rng.normal(size=(k, n))
+        Bm = np.stack([op @ Xs[c] for c in range(k)])
+        bx, bz = np.ascontiguousarray(Bm.real), np.ascontiguousarray(Bm.imag)  # n x k column-major = k rows of n
+        xx, xz = np.zeros((k, n)), np.zeros((k, n))
+        assert L.spl_umfpack_zi_solve_many(sys_, P(ap, ip), P(ai, ip), P(ax, dp), P(az, dp), k, P(xx, dp), P(xz, dp),
+                                           P(bx, dp), P(bz, dp), num) == 0
+        assert np.max(np.abs(xx + 1j * xz - Xs)) < 1e-10
+    L.umfpack_zi_free_numeric(C.byref(num))
+    L.umfpack_zi_free_symbolic(C.byref(sym))
