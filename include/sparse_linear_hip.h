@@ -178,7 +178,8 @@ int spl_matrix_spmv_dev(void *H, const double *d_x, double *d_y, int accumulate,
 int spl_matrix_spmm_dev(void *H, const double *d_B, double *d_C, int k, int accumulate, void *stream);
 /* select a kernel variant for spl_matrix_spmv_dev (tuning / ablation only): 0 = default
  * (whatever spl_matrix_optimize chose), 1-6 CSR-stream shapes, 7 sub-wavefront kernel, 8
- * column-blocked image, 9-11 gather cache policies, 15 sliced-ELL image; 12-14 are timing-only
+ * column-blocked image, 9-11 gather cache policies, 15 sliced-ELL image, 16 column-sorted panel
+ * image (order-free sums, see spl_matrix_set_spmv_order); 12-14 are timing-only
  * ablations that do not compute A x and are refused unless SPL_ALLOW_ABLATION=1.
  * Returns SPL_ERROR_argument_missing for an unknown or refused variant. */
 int spl_matrix_set_variant(void *H, int variant);
@@ -193,6 +194,29 @@ int spl_matrix_optimize(void *H);
  * 0,0 = choose.  unroll: 0 default, {4,8,10,12} 64-entry chunks per register set of the
  * lockstep kernel; negative {-1,-2,-4,-8} selects the free-running baseline kernel. */
 int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unroll);
+
+/* Order of the floating-point sums of spl_matrix_spmv_dev / mulv / gaxpy on this handle.
+ * SPL_ORDER_REFERENCE (default): every y[r] receives a*x + y in ascending column order, each
+ * multiply and add separately rounded — the evaluation order of axpy_ (Sparse.hs:447-451); results
+ * are bit-identical to the reference's and the same on every run.
+ * SPL_ORDER_FREE: the products of a row may be added in any order (still separately rounded
+ * multiplies and adds): results agree with the reference to rounding level (1e-10 relative is
+ * north_star's contract; observed ~1e-16) but need not be bit-identical, nor identical from run to
+ * run.  Lets spl_matrix_optimize use the column-sorted panel image (csrc/spmv_panel.hip), which
+ * sends about a quarter fewer requests to the L2 on matrices without column locality. */
+#define SPL_ORDER_REFERENCE 0
+#define SPL_ORDER_FREE 1
+int spl_matrix_set_spmv_order(void *H, int order);
+/* build the column-sorted panel image with an explicit shape (tuning / ablation): panels of
+ * rows_per_panel rows (<= 20479: one workgroup's LDS), index blocks of 2^cols_log2 columns
+ * (<= 17); 0,0 = choose.  unroll: 0 default, {4,6,8,10,12} chunks per wavefront and register set;
+ * kblocks: index blocks per barrier phase (0 default, 1, 2); prefetch: 1 = touch the matrix stream
+ * two phases ahead through the scalar cache.  Used by variant 16, and by variant 0 once
+ * spl_matrix_set_spmv_order(H, SPL_ORDER_FREE) was called. */
+int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unroll, int kblocks, int prefetch);
+/* the kernel spl_matrix_spmv_dev launches for this handle now: 0 CSR-stream, 8 column-blocked
+ * lockstep, 15 sliced ELL, 16 column-sorted panels (other values: the forced ablation variant) */
+int spl_matrix_spmv_kernel(void *H);
 
 /* fill a device vector with the synthetic entries j in [j0,j1) */
 int spl_vector_synthetic_dev(uint64_t seed, int64_t j0, int64_t j1, double *d_x, void *stream);

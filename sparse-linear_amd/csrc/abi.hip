@@ -387,11 +387,16 @@ int spl_matrix_info(void *H, int64_t info[8]) {
   info[3] = m->nrows_local;
   info[4] = m->nnz;
   info[5] = m->device;
-  const bool sell = m->sell && (m->variant == 0 || m->variant == 15);
-  const bool blocked = !sell && m->blocked && (m->variant == 0 || m->variant == 8);
-  info[6] = blocked ? m->blocked->R : sell ? -64 : 0;  // -64: sliced-ELL image (64-row slices) in use
-  info[7] = blocked ? m->blocked->w : 0;
+  const int kern = spmv_kernel_in_use(m);
+  info[6] = kern == 8 ? m->blocked->R : kern == 16 ? m->panel->P : kern == 15 ? -64 : 0;  // -64: sliced-ELL image
+  info[7] = kern == 8 ? m->blocked->w : kern == 16 ? m->panel->w : 0;
   return SPL_OK;
+}
+
+int spl_matrix_spmv_kernel(void *H) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  return spmv_kernel_in_use(m);
 }
 
 int spl_matrix_export_csr(void *H, int64_t *rowptr, int *colidx, double *val) {
@@ -468,6 +473,10 @@ int spl_matrix_set_variant(void *H, int variant) {
     int st = spl_matrix_build_blocked(H, 0, 0, 0);
     if (st != SPL_OK) return st;
   }
+  if (variant == 16 && !m->panel) {
+    int st = spl_matrix_build_panel(H, 0, 0, 0, 0, 0);
+    if (st != SPL_OK) return st;
+  }
   if (variant == 15 && !m->sell) {
     int st = guarded([&]() -> int {
       DeviceGuard g(m->device);
@@ -519,6 +528,43 @@ int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unr
     if (const char *ev = getenv("SPL_BLOCKED_FOLD")) m->blocked->fold = atoi(ev);
     return SPL_OK;
   });
+}
+
+int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unroll, int kblocks, int prefetch) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  if (rows_per_panel == 0 && cols_log2 == 0) choose_panels(m, &rows_per_panel, &cols_log2);
+  if (rows_per_panel < 1 || rows_per_panel > 20479 || cols_log2 < 4 || cols_log2 > 17)
+    return SPL_ERROR_argument_missing;
+  if (kblocks != 0 && kblocks != 1 && kblocks != 2) return SPL_ERROR_argument_missing;
+  return guarded([&]() -> int {
+    DeviceGuard g(m->device);
+    build_panel_image(m, rows_per_panel, cols_log2, nullptr);
+    PanelImage *b = m->panel;
+    if (kblocks == 0) kblocks = cols_log2 >= 17 ? 2 : 1;  // a phase's x window: 2 MiB at most
+    if (const char *ev = getenv("SPL_PANEL_KBLOCKS")) kblocks = atoi(ev) == 1 ? 1 : 2;
+    b->kblocks = kblocks;
+    if (unroll == 0) {
+      // chunks per wavefront and phase: the mean number + 1 (the 16 wavefronts share the phase's chunks
+      // evenly, a phase's length varies by a chunk or two), from {4, 6, 8, 10, 12}
+      const double per_wave = (double)b->nchunks * kblocks / (double)(b->npanels * b->nib > 0 ? b->npanels * b->nib : 1) / 16.0;
+      const double want = per_wave + 0.9;
+      unroll = want <= 4 ? 4 : want <= 6 ? 6 : want <= 8 ? 8 : want <= 10 ? 10 : 12;
+    }
+    if (const char *ev = getenv("SPL_PANEL_UNROLL")) unroll = atoi(ev);
+    b->unroll = unroll;
+    if (const char *ev = getenv("SPL_PANEL_PREFETCH")) prefetch = atoi(ev);
+    b->prefetch = prefetch ? 1 : 0;
+    return SPL_OK;
+  });
+}
+
+int spl_matrix_set_spmv_order(void *H, int order) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  if (order != SPL_ORDER_REFERENCE && order != SPL_ORDER_FREE) return SPL_ERROR_argument_missing;
+  m->order_free = order == SPL_ORDER_FREE;
+  return SPL_OK;
 }
 
 int spl_matrix_optimize(void *H) {

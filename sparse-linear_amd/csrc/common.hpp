@@ -94,6 +94,19 @@ struct BlockedImage {
   int lockstep_waves = 16;        // wavefronts (= panels) per lockstep workgroup: 16 or 8; 0 = ablation kernel
 };
 
+// workgroup-wide column-sorted panels of a row block (spmv_panel.hip): the order-free SpMV mode
+struct PanelImage {
+  int P = 0, w = 0;               // panel = P rows (one workgroup's LDS), index block = 2^w columns (w <= 17)
+  int64_t npanels = 0, nib = 0, nchunks = 0;
+  DBuf<int> segc;                 // npanels*nib + 1 (+ padding): first 64-entry chunk of each segment
+  DBuf<unsigned> key;             // (local_col << 15) | local_row, segments padded to whole chunks
+  DBuf<double> val;
+  DBuf<unsigned> arrive;          // rendezvous counter between generations
+  int unroll = 10;                // chunks per wavefront and register set
+  int kblocks = 2;                // index blocks per phase (barrier to barrier)
+  int prefetch = 0;               // 1: touch the stream two phases ahead through the scalar cache
+};
+
 // sliced-ELL image of a row block (spmv_sell.hip)
 struct SellImage {
   int64_t nslices = 0, entries = 0;
@@ -118,11 +131,13 @@ struct Matrix {
   double new_line_fraction = -1.0;  // share of entries whose x line the previous row did not touch; < 0: not measured yet
   BlockedImage *blocked = nullptr;  // built on demand (spl_matrix_build_blocked / auto)
   SellImage *sell = nullptr;        // built on demand (spl_matrix_optimize on regular matrices)
+  PanelImage *panel = nullptr;      // built on demand (spl_matrix_build_panel / spl_matrix_set_spmv_order)
   int blocked_unroll = 0;  // 0 = default; < 0 selects the ablation kernel
+  bool order_free = false;  // spl_matrix_set_spmv_order: variant 0 may use the panel image (1e-10, order-free sums)
   Matrix() = default;
   Matrix(const Matrix &) = delete;
   Matrix &operator=(const Matrix &) = delete;
-  ~Matrix() { delete blocked; delete sell; }
+  ~Matrix() { delete blocked; delete sell; delete panel; }
 };
 
 inline Matrix *as_matrix(void *h) {
@@ -156,6 +171,8 @@ void segmented_sort_pairs_capped(const int64_t *d_ptr64, int64_t nseg, int *d_ke
                                  int64_t max_len, hipStream_t s);
 void segmented_sort_pairs64(const int64_t *d_ptr64, int64_t nseg, int64_t *d_key, double *d_val,
                             hipStream_t s);
+void segmented_sort_pairs_u32(const int64_t *d_ptr64, int64_t nseg, unsigned *d_key, double *d_val,
+                              hipStream_t s);
 // finish a Matrix whose rowptr64/colidx/val are filled: int32 pointers, stats
 // the `zi` wrapper's note on a `di` Numeric object: which row pairs of the embedding it swapped
 void numeric_set_pair_swap(void *Numeric, std::vector<char> &&flags);
@@ -225,11 +242,15 @@ int launch_spmm(const Matrix *m, const double *d_B, double *d_C, int k, int accu
 int64_t sell_padded_entries(const Matrix *m, hipStream_t s);
 void build_sell_image(Matrix *m, hipStream_t s);
 int launch_spmv_sell(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s);
-constexpr int kNumSpmvVariants = 16;  // 15 = sliced-ELL image;  // 12-14: timing-only ablations of the CSR-stream kernel (wrong results)  // 0 auto, 1-6 CSR-stream shapes, 7 sub-wavefront, 8 column-blocked
+constexpr int kNumSpmvVariants = 17;  // 16 = column-sorted workgroup panels (order-free);  // 15 = sliced-ELL image;  // 12-14: timing-only ablations of the CSR-stream kernel (wrong results)  // 0 auto, 1-6 CSR-stream shapes, 7 sub-wavefront, 8 column-blocked
 void build_blocked_image(Matrix *m, int rows_per_panel, int w, hipStream_t s);
 int launch_spmv_blocked(const Matrix *m, const double *d_x, double *d_y, int accumulate, int unroll,
                         hipStream_t s);
+void build_panel_image(Matrix *m, int rows_per_panel, int w, hipStream_t s);
+int launch_spmv_panel(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s);
 // choose the blocked image's shape for this matrix (0,0 = blocking would not help)
 void choose_blocking(const Matrix *m, int *rows_per_panel, int *w, int *waves);
+void choose_panels(const Matrix *m, int *rows_per_panel, int *w);
+int spmv_kernel_in_use(const Matrix *m);
 
 }  // namespace spl

@@ -74,6 +74,8 @@ template <>
 __device__ inline int key_max<int>() { return 0x7fffffff; }
 template <>
 __device__ inline int64_t key_max<int64_t>() { return 0x7fffffffffffffffLL; }
+template <>
+__device__ inline unsigned key_max<unsigned>() { return 0xffffffffu; }
 
 // len <= 64: one wavefront, registers + shuffles
 template <typename K>
@@ -271,6 +273,10 @@ void segmented_sort_pairs_capped(const int64_t *d_ptr64, int64_t nseg, int *d_ke
 void segmented_sort_pairs64(const int64_t *d_ptr64, int64_t nseg, int64_t *d_key, double *d_val,
                             hipStream_t s) {
   segmented_sort_impl<int64_t>(d_ptr64, nseg, d_key, d_val, s);
+}
+void segmented_sort_pairs_u32(const int64_t *d_ptr64, int64_t nseg, unsigned *d_key, double *d_val,
+                              hipStream_t s) {
+  segmented_sort_impl<unsigned>(d_ptr64, nseg, d_key, d_val, s);
 }
 
 void transpose_compressed(const int *d_ptr, const int *d_idx, const double *d_val, int64_t nmajor,

@@ -270,6 +270,10 @@ int launch_spmv(const Matrix *m, const double *d_x, double *d_y, int accumulate,
     if (!m->sell) return SPL_ERROR_argument_missing;
     return launch_spmv_sell(m, d_x, d_y, accumulate, s);
   }
+  if (m->variant == 16 || (m->variant == 0 && m->panel && m->order_free)) {
+    if (!m->panel) return SPL_ERROR_argument_missing;
+    return launch_spmv_panel(m, d_x, d_y, accumulate, s);
+  }
   if (m->variant == 8 || (m->variant == 0 && m->blocked)) {
     if (!m->blocked) return SPL_ERROR_argument_missing;
     return launch_spmv_blocked(m, d_x, d_y, accumulate, m->blocked_unroll, s);
@@ -302,6 +306,33 @@ int launch_spmv(const Matrix *m, const double *d_x, double *d_y, int accumulate,
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_last_error("spmv launch", e); return SPL_ERROR_device; }
   return SPL_OK;
+}
+
+// which kernel spl_matrix_spmv_dev launches for this handle now: 0 CSR-stream (variants 1-7, 9-14
+// report themselves), 8 column-blocked lockstep, 15 sliced ELL, 16 column-sorted panels
+int spmv_kernel_in_use(const Matrix *m) {
+  if ((m->variant == 15 || m->variant == 0) && m->sell) return 15;
+  if (m->variant == 16 || (m->variant == 0 && m->panel && m->order_free)) return m->panel ? 16 : 0;
+  if ((m->variant == 8 || m->variant == 0) && m->blocked) return 8;
+  return m->variant;
+}
+
+// Shape of the column-sorted panel image (spmv_panel.hip): one panel per workgroup, as tall as the
+// LDS allows, the generations of the persistent grid full; index blocks of 2^17 columns (the key's
+// 17 column bits) or fewer for narrow matrices.
+void choose_panels(const Matrix *m, int *rows_per_panel, int *w) {
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device);
+  const int64_t pmax = 20479;
+  int64_t ngen = (m->nrows_local + (int64_t)cus * pmax - 1) / ((int64_t)cus * pmax);
+  if (ngen < 1) ngen = 1;
+  int64_t P = (m->nrows_local + ngen * cus - 1) / (ngen * cus);
+  if (P < 64) P = 64;
+  if (P > pmax) P = pmax;
+  *rows_per_panel = (int)P;
+  int ww = 17;
+  while (ww > 4 && (1LL << ww) >= 2 * m->ncols) --ww;
+  *w = ww;
 }
 
 // Blocking pays when x does not fit the L2s and neighbouring rows do not share x lines

@@ -144,6 +144,8 @@ class Matrix(object):
 class DeviceMatrix(object):
     """Owner of a ``void *H`` from ``spl_matrix_create*`` (UMFPACK-style handle:
     callee-allocated, freed through ``void **``; Umfpack.hs:63-65)."""
+    ORDER_REFERENCE = 0
+    ORDER_FREE = 1
 
     def __init__(self, handle):
         self._h = C.c_void_p(handle)
@@ -252,6 +254,20 @@ class DeviceMatrix(object):
     def build_blocked(self, rows_per_panel=0, cols_log2=0, unroll=0):
         check("spl_matrix_build_blocked",
               lib().spl_matrix_build_blocked(self.handle, rows_per_panel, cols_log2, unroll))
+
+    def build_panel(self, rows_per_panel=0, cols_log2=0, unroll=0, kblocks=0, prefetch=0):
+        """the column-sorted panel image (csrc/spmv_panel.hip): order-free sums, 1e-10 contract"""
+        check("spl_matrix_build_panel",
+              lib().spl_matrix_build_panel(self.handle, rows_per_panel, cols_log2, unroll, kblocks, prefetch))
+
+    def set_spmv_order(self, order):
+        """ORDER_REFERENCE (0, default): sums in the reference's order, bit-identical; ORDER_FREE (1):
+        any order, rounding-level differences (include/sparse_linear_hip.h)"""
+        check("spl_matrix_set_spmv_order", lib().spl_matrix_set_spmv_order(self.handle, int(order)))
+
+    def spmv_kernel(self):
+        """0 CSR-stream, 8 column-blocked lockstep, 15 sliced ELL, 16 column-sorted panels"""
+        return int(lib().spl_matrix_spmv_kernel(self.handle))
 
     def mulv(self, x):
         x = as_f64(x)

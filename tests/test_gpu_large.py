@@ -84,3 +84,110 @@ def test_linearity_full_size_c2(gpu, pkg):
     H.spmv_dev(x.data_ptr(), y2.data_ptr(), stream=s)
     torch.cuda.synchronize()
     assert torch.equal(y2, yx)
+
+
+# ---- the configurations of BASELINE.json at FULL size (C2 banded variant, C4, C5) -------------------
+
+def test_c2_banded_full_size_sell(gpu, pkg, O):
+    """north_star's banded variant of C2 (1e7 rows, 20 diagonals within +-1000): the kernel
+    `optimize()` picks (sliced ELL) against the oracle on sampled row windows, bit for bit, and
+    y = A x recomputed by the CSR-stream kernel on the whole vector (1e-10, Sparse.hs:447-451)"""
+    torch = gpu
+    n = 10_000_000
+    H = pkg.DeviceMatrix.synthetic("banded", n, 20)
+    H.optimize()
+    assert H.info()["blocked_rows"] == -64  # the sliced-ELL image is in use
+    s = torch.cuda.current_stream().cuda_stream
+    x = _dev_vec(torch, pkg, n, 0xBEEF)
+    y = torch.zeros(n, dtype=torch.float64, device="cuda")
+    H.spmv_dev(x.data_ptr(), y.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    xh = x.cpu().numpy()
+    for row0 in (0, 999, 4_999_000, n - 2000):
+        rp, ci, v = O.gen_banded_csr(n, row0=row0, row1=row0 + 2000)
+        yo = np.zeros(2000)
+        O.csr_gaxpy32(rp.astype(np.int32), ci, v, xh, yo)
+        assert np.array_equal(y[row0:row0 + 2000].cpu().numpy(), yo)
+    H.set_variant(1)
+    y1 = torch.zeros_like(y)
+    H.spmv_dev(x.data_ptr(), y1.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    assert ((y - y1).abs() / (y + y1).abs()).max().item() < 1e-10
+    del H, x, y, y1
+    torch.cuda.empty_cache()
+
+
+def test_c4_spgemm_rmat20_full_size(gpu, pkg, O):
+    """config C4 at full size: A*A for the 2^20 x 2^20 R-MAT matrix, edge factor 32, Erdos-Renyi
+    quadrants (1.07e9 products).  The whole result is exported and checked for the
+    format invariants (Test/LinearAlgebra.hs:40-67) and the product count; 4 windows of 1024
+    sampled rows of C (= columns of C^T = A^T (A^T)[:, window] in the reference's CSC terms) are
+    recomputed by the oracle's mm (Sparse.hs:691-702): structure and values bit for bit."""
+    torch = gpu
+    scale, ef = 20, 32
+    n = 1 << scale
+    H = pkg.DeviceMatrix.rmat(scale, ef, (0.25, 0.25, 0.25))
+    nnzA = H.info()["nnz"]
+    assert 0.95 * n * ef < nnzA <= n * ef
+    HC, products = H.spgemm(H)
+    torch.cuda.synchronize()
+    rp, ci, v = H.export_csr()
+    lens = np.diff(rp)
+    assert products == int(np.sum(lens[ci]))  # sum over entries (k, j) of |A[:, k]|
+    assert 1.0e9 < products < 1.15e9
+    crp, cci, cv = HC.export_csr()
+    nnzC = HC.info()["nnz"]
+    assert crp[0] == 0 and crp[-1] == nnzC == len(cci) == len(cv) and nnzC <= products
+    # format invariants on all 1e9 entries: CSR(C) arrays are the CSC arrays of C^T
+    assert O.check_matrix((n, n, crp, cci, cv)) == 0
+    At = (n, n, rp, ci.astype(np.int64), v)  # CSR(A) arrays == CSC(A^T)
+    k = 1024
+    for r0 in (0, 300_001, 777_777, n - k):
+        a, b = rp[r0], rp[r0 + k]
+        Bs = (n, k, rp[r0:r0 + k + 1] - a, ci[a:b].astype(np.int64), v[a:b])
+        Cs = O.mm(At, Bs)
+        c0, c1 = crp[r0], crp[r0 + k]
+        assert np.array_equal(crp[r0:r0 + k + 1] - c0, Cs[2])
+        assert np.array_equal(cci[c0:c1], Cs[3])
+        assert np.array_equal(cv[c0:c1], Cs[4])
+    del HC, H
+    pkg._ffi.release_cached_memory()
+    torch.cuda.empty_cache()
+
+
+def test_c5_poisson3d_200_lu_full_size(gpu, pkg, O):
+    """config C5 at full size: sparse LU + triangular solves of the 7-point Poisson matrix on a
+    200^3 grid (8.0e6 unknowns, nnz 55 760 000 = 7 m^3 - 6 m^2) through umfpack_di_symbolic /
+    numeric / solve (Umfpack.hs:60-102), both `sys` codes, manufactured solution to 1e-10
+    (test-feast.hs:17-19) and the scaled residual.  Needs ~255 GB of HBM for panels + fronts."""
+    import scipy.sparse as sp
+    torch = gpu
+    pkg._ffi.release_cached_memory()
+    torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info()
+    if free < 260e9:
+        pytest.skip("C5 needs 260 GB of free HBM, %.0f GB are free" % (free / 1e9))
+    m = 200
+    n = m ** 3
+    H = pkg.DeviceMatrix.synthetic("poisson3d", m)
+    rp, ci, v = H.export_csr()  # symmetric: CSR arrays == CSC arrays
+    H.free()
+    assert int(rp[-1]) == 7 * m ** 3 - 6 * m ** 2 == 55_760_000
+    A = pkg.Matrix(n, n, rp, ci, v)
+    S = sp.csc_matrix((v, ci, rp), shape=(n, n))
+    xs = np.random.default_rng(0xBEEF).uniform(0.5, 1.5, n)
+    b = S @ xs
+    U = pkg.umfpack
+    fact = U.factor(A, U.analyze(A))
+    assert fact.path == 3  # multifrontal, no interchanges (diagonally dominant)
+    st = fact.stats
+    assert st["n"] == n and st["fronts"] > 1000 and st["flops"] > 1e14
+    for mode in (U.UmfpackNormal, U.UmfpackTrans):  # symmetric matrix: same system, different kernels
+        x = U.linearSolve_(fact, mode, A, b)
+        assert O.count_not_close(x, xs, 1e-10) == 0
+        res = float(np.max(np.abs(S @ x - b)) / (np.max(np.abs(b)) + 6 * np.max(np.abs(x))))
+        assert res < 1e-14
+    del fact
+    import gc
+    gc.collect()
+    pkg._ffi.release_cached_memory()

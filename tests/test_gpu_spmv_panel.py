@@ -1,0 +1,109 @@
+"""The order-free SpMV mode (csrc/spmv_panel.hip): workgroup-wide, column-sorted panels whose
+products are added with LDS atomics in whatever order the hardware executes them.  Contract:
+north_star's 1e-10 relative on values against the reference order (Sparse.hs:447-451) — checked
+here against the oracle with the reference's closeness predicate (feast/tests/test-feast.hs:17-19)
+and, much tighter, against a bound of a few ulps of sum |a x|; on exactly representable data
+(integers) the order cannot matter and the results must be bit-identical."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(torch, H, x):
+    n = H.info()["nrows_local"]
+    y = torch.zeros(n, dtype=torch.float64, device="cuda")
+    H.spmv_dev(x.data_ptr(), y.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,K,P,w,unroll,kblocks", [
+    (50_003, 20, 3000, 12, 4, 1), (50_003, 20, 3000, 12, 6, 2), (200_000, 20, 20479, 14, 0, 0),
+    (131_072, 7, 8192, 17, 12, 2), (70_001, 40, 5000, 10, 10, 2), (1000, 3, 64, 4, 4, 1),
+    (300_000, 20, 19000, 13, 8, 2)])
+def test_panel_matches_oracle(gpu, pkg, O, n, K, P, w, unroll, kblocks):
+    torch = gpu
+    H = pkg.DeviceMatrix.synthetic("random", n, K)
+    H.build_panel(P, w, unroll, kblocks)
+    H.set_variant(16)
+    assert H.spmv_kernel() == 16 and H.info()["blocked_rows"] == P
+    rp, ci, v = H.export_csr()
+    xh = O.gen_vector(n)
+    x = torch.from_numpy(xh).cuda()
+    y = _run(torch, H, x)
+    yo = np.zeros(n)
+    O.csr_gaxpy32(rp.astype(np.int32), ci, v, xh, yo)
+    assert O.count_not_close(y, yo, 1e-10) == 0
+    # rounding-level: |y - yo| <= 2 * len(row) * eps * sum |a x|  (values and x are positive here)
+    lens = np.diff(rp)
+    assert np.all(np.abs(y - yo) <= 2.0 * np.maximum(lens, 1) * np.finfo(float).eps * np.abs(yo))
+    # accumulate form: y <- A x + y
+    y0 = O.gen_vector(n, seed=7)
+    yd = torch.from_numpy(y0.copy()).cuda()
+    H.spmv_dev(x.data_ptr(), yd.data_ptr(), accumulate=True, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ya = y0.copy()
+    O.csr_gaxpy32(rp.astype(np.int32), ci, v, xh, ya)
+    assert O.count_not_close(yd.cpu().numpy(), ya, 1e-10) == 0
+
+
+def test_panel_exact_on_integers(gpu, pkg, O):
+    """integer-valued entries and vector: every partial sum is exact, so any order gives the same bits"""
+    torch = gpu
+    rng = np.random.default_rng(5)
+    n, k = 40_000, 700_000
+    A = O.compress(n, n, rng.integers(0, n, k), rng.integers(0, n, k), rng.integers(-9, 10, k).astype(float))
+    M = pkg.Matrix(n, n, A[2], A[3], A[4])
+    H = pkg.DeviceMatrix.from_csc(M)
+    H.build_panel(2500, 11, 0, 0)
+    H.set_variant(16)
+    xh = rng.integers(-5, 6, n).astype(float)
+    y = _run(torch, H, torch.from_numpy(xh).cuda())
+    assert np.array_equal(y, O.mulV(A, xh))
+
+
+def test_order_switch_and_optimize(gpu, pkg, O):
+    """spl_matrix_set_spmv_order: the default (reference order) never uses the panel image; ORDER_FREE
+    makes variant 0 use it once built; switching back restores bit-identical results"""
+    torch = gpu
+    n = 120_000
+    H = pkg.DeviceMatrix.synthetic("random", n, 20)
+    H.build_blocked(600, 12, 0)
+    H.build_panel(9000, 12, 0, 0)
+    assert H.spmv_kernel() == 8
+    rp, ci, v = H.export_csr()
+    xh = O.gen_vector(n)
+    x = torch.from_numpy(xh).cuda()
+    yo = np.zeros(n)
+    O.csr_gaxpy32(rp.astype(np.int32), ci, v, xh, yo)
+    assert np.array_equal(_run(torch, H, x), yo)
+    H.set_spmv_order(H.ORDER_FREE)
+    assert H.spmv_kernel() == 16
+    assert O.count_not_close(_run(torch, H, x), yo, 1e-10) == 0
+    H.set_spmv_order(H.ORDER_REFERENCE)
+    assert H.spmv_kernel() == 8
+    assert np.array_equal(_run(torch, H, x), yo)
+
+
+def test_panel_empty_rows_and_ragged_edges(gpu, pkg, O):
+    """rows without entries, a last panel with a few rows, a last index block with a few columns,
+    an all-empty matrix"""
+    torch = gpu
+    rng = np.random.default_rng(3)
+    nr, nc = 10_007, 4_099
+    rows = rng.integers(0, nr, 30_000)
+    rows = rows[(rows % 7 != 0) & (rows < nr - 5)]  # every 7th row and the last rows stay empty
+    cols = rng.integers(0, nc, len(rows))
+    A = O.compress(nr, nc, rows, cols, rng.uniform(0.5, 1.5, len(rows)))
+    H = pkg.DeviceMatrix.from_csc(pkg.Matrix(nc, nr, A[2], A[3], A[4]))
+    H.build_panel(1000, 10, 4, 2)
+    H.set_variant(16)
+    xh = rng.uniform(0.5, 1.5, nc)
+    y = _run(torch, H, torch.from_numpy(xh).cuda())
+    yo = O.mulV(A, xh)
+    assert O.count_not_close(y, yo, 1e-10) == 0 and np.all(y[::7] == 0.0)
+    Z = pkg.DeviceMatrix.from_csc(pkg.zeros(300, 200))
+    Z.build_panel(64, 4, 4, 1)
+    Z.set_variant(16)
+    assert np.array_equal(_run(torch, Z, torch.ones(200, dtype=torch.float64, device="cuda")), np.zeros(300))
