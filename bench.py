@@ -47,6 +47,10 @@ def main():
     ap.add_argument("--matrix", default="random", choices=["random", "banded"])
     ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (ablation)")
     ap.add_argument("--blocked", default="", help="force the column-blocked image: rows_per_panel,cols_log2[,unroll]")
+    ap.add_argument("--order", default="free", choices=["free", "reference"],
+                    help="order of the floating-point sums: free = any order (1e-10 contract, column-sorted panel "
+                         "kernel where it pays), reference = the reference's order, bit-identical (spl_matrix_set_spmv_order)")
+    ap.add_argument("--panel", default="", help="force the column-sorted panel image: rows_per_panel,cols_log2[,unroll[,kblocks]]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
     args = ap.parse_args()
@@ -92,10 +96,15 @@ def main():
     if args.blocked:
         H.build_blocked(*[int(t) for t in args.blocked.split(",")])
         H.set_variant(8)
+    elif args.panel:
+        H.build_panel(*[int(t) for t in args.panel.split(",")])
+        H.set_variant(16)
     elif args.variant:
         H.set_variant(args.variant)
     else:
-        H.optimize()  # one-time analysis (not timed): picks CSR-stream or the column-blocked image
+        if args.order == "free":
+            H.set_spmv_order(H.ORDER_FREE)
+        H.optimize()  # one-time analysis (not timed): picks CSR-stream, sliced ELL, column-blocked or panel image
     info = H.info()
     stream = torch.cuda.current_stream()
     x = torch.empty(n, dtype=torch.float64, device="cuda")
@@ -151,6 +160,8 @@ def main():
                 for c in range(C):
                     q = c * N + rank
                     h = pkg.DeviceMatrix.synthetic(args.matrix, n, args.draws, seed=0x5EED, row0=bnd[q], row1=bnd[q + 1])
+                    if args.order == "free":
+                        h.set_spmv_order(h.ORDER_FREE)
                     h.optimize()
                     hs.append(h)
                 cand = dist_mod.PipelinedRowBlockSpMV(
@@ -225,8 +236,8 @@ def main():
     torch.cuda.synchronize()
     kern_ms = ev0.elapsed_time(ev1) / args.steps
     achieved = B_local / (kern_ms * 1e-3) / 1e9
-    kernel = ("spmv_blocked_lockstep" if info["blocked_rows"] > 0 else
-              "spmv_sell" if info["blocked_rows"] < 0 else "spmv_stream")
+    kcode = handles[0].spmv_kernel()
+    kernel = {8: "spmv_blocked_lockstep", 15: "spmv_sell", 16: "spmv_panel"}.get(kcode, "spmv_stream")
     traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (N = 1, default sizes only)
     tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
     if N == 1 and n == 10_000_000 and args.draws == 20 and os.path.exists(tfile):
@@ -234,8 +245,10 @@ def main():
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "kernel": kernel, "kernel_ms": round(kern_ms, 4), "bytes_per_launch": B_local}
-    if info["blocked_rows"] > 0:
+    if kcode == 8:
         roofline["image"] = "column-blocked: %d rows/panel, 2^%d columns/block" % (info["blocked_rows"], info["blocked_cols_log2"])
+    elif kcode == 16:
+        roofline["image"] = "column-sorted panels: %d rows/workgroup, 2^%d columns/index block" % (info["blocked_rows"], info["blocked_cols_log2"])
 
     out = {
         "metric": "fp64 CSR SpMV effective GB/s", "value": round(value, 1), "unit": "GB/s",
@@ -246,7 +259,8 @@ def main():
                                % (args.matrix, n, n, args.draws, nnz_total,
                                   "" if N == 1 else ", %d row blocks + RCCL all-gather of y (%s)" % (N, exchange)),
                    "algorithmic_bytes": B_total, "hbm_frac_of_%dx8TBps" % N: round(value / (N * HBM_PEAK_GBPS), 4),
-                   "variant": args.variant, "blocked": args.blocked or "auto"},
+                   "variant": args.variant, "blocked": args.blocked or "auto", "panel": args.panel or "auto",
+                   "sum_order": args.order},
         "roofline": roofline,
     }
     # fingerprint of the whole y every rank holds after the last step: equal for every N and exchange

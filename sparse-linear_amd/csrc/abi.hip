@@ -536,11 +536,13 @@ int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unrol
   if (rows_per_panel == 0 && cols_log2 == 0) choose_panels(m, &rows_per_panel, &cols_log2);
   if (rows_per_panel < 1 || rows_per_panel > 20479 || cols_log2 < 4 || cols_log2 > 17)
     return SPL_ERROR_argument_missing;
-  if (kblocks != 0 && kblocks != 1 && kblocks != 2) return SPL_ERROR_argument_missing;
+  if (kblocks < 0 || kblocks > 3) return SPL_ERROR_argument_missing;
   return guarded([&]() -> int {
     DeviceGuard g(m->device);
     build_panel_image(m, rows_per_panel, cols_log2, nullptr);
     PanelImage *b = m->panel;
+    const bool three = kblocks == 3;
+    if (three) kblocks = 1;
     if (kblocks == 0) kblocks = cols_log2 >= 17 ? 2 : 1;  // a phase's x window: 2 MiB at most
     if (const char *ev = getenv("SPL_PANEL_KBLOCKS")) kblocks = atoi(ev) == 1 ? 1 : 2;
     b->kblocks = kblocks;
@@ -555,6 +557,14 @@ int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unrol
     b->unroll = unroll;
     if (const char *ev = getenv("SPL_PANEL_PREFETCH")) prefetch = atoi(ev);
     b->prefetch = prefetch ? 1 : 0;
+    // kblocks == 3 selects the three-stage kernel (one index block per phase)
+    b->stages = three ? 3 : 2;
+    b->ablate = 0;
+    {
+      const char *ok = getenv("SPL_ALLOW_ABLATION"), *ab = getenv("SPL_PANEL_ABLATE");
+      if (ok && ok[0] == '1' && ab) b->ablate = atoi(ab) & 7;
+    }
+    if (const char *ev = getenv("SPL_PANEL_STAGES")) b->stages = atoi(ev) == 3 ? 3 : 2;
     return SPL_OK;
   });
 }
@@ -589,6 +599,9 @@ int spl_matrix_optimize(void *H) {
     }
     return SPL_OK;  // the CSR-stream kernel is already the right one
   }
+  // order-free sums allowed (spl_matrix_set_spmv_order): the column-sorted panels send fewer requests
+  // to the L2 when a panel is tall enough for lines of x to meet several of its entries
+  if (m->order_free && panels_pay(m)) return spl_matrix_build_panel(H, 0, 0, 0, 0, 0);
   return spl_matrix_build_blocked(H, 0, 0, 0);  // 0,0: the same choice, including wavefronts per CU
 }
 

@@ -105,6 +105,8 @@ struct PanelImage {
   int unroll = 10;                // chunks per wavefront and register set
   int kblocks = 2;                // index blocks per phase (barrier to barrier)
   int prefetch = 0;               // 1: touch the stream two phases ahead through the scalar cache
+  int ablate = 0;                 // timing-only ablation bits (SPL_PANEL_ABLATE with SPL_ALLOW_ABLATION=1)
+  int stages = 2;                 // 3: three-stage kernel (gathers of phase i+1 issued before those of i are awaited)
 };
 
 // sliced-ELL image of a row block (spmv_sell.hip)
@@ -252,5 +254,6 @@ int launch_spmv_panel(const Matrix *m, const double *d_x, double *d_y, int accum
 void choose_blocking(const Matrix *m, int *rows_per_panel, int *w, int *waves);
 void choose_panels(const Matrix *m, int *rows_per_panel, int *w);
 int spmv_kernel_in_use(const Matrix *m);
+bool panels_pay(const Matrix *m);
 
 }  // namespace spl

@@ -335,6 +335,17 @@ void choose_panels(const Matrix *m, int *rows_per_panel, int *w) {
   *w = ww;
 }
 
+// The panel image beats the column-blocked one when a 128-byte line of x meets enough entries of a
+// panel for lanes to share requests: entries per line = 16 * nnz/nrows * P / ncols.
+// (measured on C2, P = 19 532: 0.63 per line, 0.99 ms vs 1.19 ms; tools/bench_spmv_variants.py)
+bool panels_pay(const Matrix *m) {
+  int P = 0, w = 0;
+  choose_panels(m, &P, &w);
+  if (m->nrows_local < 1 || m->ncols < 1) return false;
+  const double per_line = 16.0 * ((double)m->nnz / (double)m->nrows_local) * (double)P / (double)m->ncols;
+  return per_line >= 0.3;
+}
+
 // Blocking pays when x does not fit the L2s and neighbouring rows do not share x lines
 // (measured: random 1e7 gathers move 10x the algorithmic bytes; banded rows reuse lines).
 // Shape: 16 panels per CU fill its LDS; the panel height is chosen so that the generations of

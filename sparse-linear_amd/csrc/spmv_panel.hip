@@ -132,11 +132,14 @@ __device__ inline void pnl_fold(unsigned id, double prod, double *yp) {
 // u of wavefront i is chunk cs + i + 16 u of the panel's stream — while its chunks of the next
 // phase (which starts at ce) are loaded into (idN, aN).  mid[j] is the first chunk of index block
 // ib0 + j + 1 (K - 1 of them): the x block a chunk gathers from follows from its position.
-template <int U, int K, int PF>
+// ABL (timing-only ablations, wrong results; refused unless SPL_ALLOW_ABLATION=1): bit 0 every gather reads
+// x[lane] (no L2 requests beyond one line), bit 1 no value loads (a = 1), bit 2 no LDS fold
+template <int U, int K, int PF, int ABL = 0>
 __device__ inline void panel_phase(unsigned (&idC)[U], double (&aC)[U], unsigned (&idN)[U], double (&aN)[U],
                                    int cs, const int (&mid)[K > 1 ? K - 1 : 1], int ce, int64_t ib0, int w,
                                    const unsigned *__restrict__ key, const double *__restrict__ val,
-                                   const double *__restrict__ x, double *yp, int wave, int nextlen, unsigned &touch) {
+                                   const double *__restrict__ x, double *yp, int wave, int nextlen, unsigned &touch,
+                                   double &sink) {
   const int lane = threadIdx.x & 63;
   if (PF) pnl_touch_join(touch);  // the touches of the previous phase have returned
   double xv[U];
@@ -149,6 +152,7 @@ __device__ inline void panel_phase(unsigned (&idC)[U], double (&aC)[U], unsigned
     for (int j = 0; j + 1 < K; ++j) ib += (c >= mid[j]) ? 1 : 0;
     const bool ok = c < ce;  // wave-uniform
     xp[u] = x + (ok ? ((ib << w) + (int64_t)(idC[u] >> kRowBits)) : 0);
+    if (ABL & 1) xp[u] = x + lane;
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -159,7 +163,8 @@ __device__ inline void panel_phase(unsigned (&idC)[U], double (&aC)[U], unsigned
 #pragma unroll
   for (int u = 0; u < U; ++u) {  // ... then the next phase's stream, left in flight across the barrier
     idN[u] = __builtin_nontemporal_load(kn + (size_t)u * kPanelWaves * 64);
-    aN[u] = __builtin_nontemporal_load(vn + (size_t)u * kPanelWaves * 64);
+    if (ABL & 2) aN[u] = 1.0;
+    else aN[u] = __builtin_nontemporal_load(vn + (size_t)u * kPanelWaves * 64);
   }
   __builtin_amdgcn_sched_barrier(0);
   if (PF) {
@@ -174,7 +179,7 @@ __device__ inline void panel_phase(unsigned (&idC)[U], double (&aC)[U], unsigned
       pnl_touch_chunk(touch, kb + off * 256, vb + off * 512);
     }
   }
-  constexpr int Y = 3 * U - 1;  // younger than gather u here: U-1-u gathers + 2U stream loads
+  constexpr int Y = ((ABL & 2) ? 2 : 3) * U - 1;  // younger than gather u here: U-1-u gathers + 2U stream loads
   pnl_gather_wait<Y>(xv[0]);
   if (U > 1) pnl_gather_wait<Y - 1>(xv[U > 1 ? 1 : 0]);
   if (U > 2) pnl_gather_wait<Y - 2>(xv[U > 2 ? 2 : 0]);
@@ -190,7 +195,8 @@ __device__ inline void panel_phase(unsigned (&idC)[U], double (&aC)[U], unsigned
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (cs + wave + kPanelWaves * u >= ce) break;  // wave-uniform
-    pnl_fold(idC[u], aC[u] * xv[u], yp);
+    if (ABL & 4) sink += aC[u] * xv[u] + (double)(idC[u] & 1u);
+    else pnl_fold(idC[u], aC[u] * xv[u], yp);
   }
   for (int c = cs + wave + kPanelWaves * U; c < ce; c += kPanelWaves) {  // tail of an over-long phase
     int64_t ib = ib0;
@@ -203,7 +209,7 @@ __device__ inline void panel_phase(unsigned (&idC)[U], double (&aC)[U], unsigned
   __builtin_amdgcn_s_barrier();  // pacing only: no fence, vector memory stays in flight
 }
 
-template <int U, int K, int PF>
+template <int U, int K, int PF, int ABL = 0>
 __global__ __launch_bounds__(kPanelWaves * 64) void spmv_panel_kernel(
     int64_t nrows, int64_t npanels, int P, int w, int64_t nib, const int *__restrict__ segc,
     const unsigned *__restrict__ key, const double *__restrict__ val, const double *__restrict__ x,
@@ -223,6 +229,7 @@ __global__ __launch_bounds__(kPanelWaves * 64) void spmv_panel_kernel(
     unsigned idA[U], idB[U];
     double aA[U], aB[U];
     unsigned touch = 0;
+    double sink = 0.0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {  // prologue: this wavefront's first chunks of phase 0
       const int64_t k = (((int64_t)(c0 + wave + kPanelWaves * u)) << 6) + lane;
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(kPanelWaves * 64) void spmv_panel_kernel(
         const int cs = sp[ib0];
         int ce = sp[ib0 + K]; ce = (ib0 + K < nib) ? ce : cend;
         int cn = sp[ib0 + 2 * K]; cn = (ib0 + 2 * K < nib) ? cn : cend;
-        panel_phase<U, K, PF>(idA, aA, idB, aB, cs, mid, ce, ib0, w, key, val, x, ylds, wave, cn - ce, touch);
+        panel_phase<U, K, PF, ABL>(idA, aA, idB, aB, cs, mid, ce, ib0, w, key, val, x, ylds, wave, cn - ce, touch, sink);
       }
       if (ph + 1 < nph) {
         const int64_t ib0 = (ph + 1) * K;
@@ -252,11 +259,189 @@ __global__ __launch_bounds__(kPanelWaves * 64) void spmv_panel_kernel(
         const int cs = sp[ib0];
         int ce = sp[ib0 + K]; ce = (ib0 + K < nib) ? ce : cend;
         int cn = sp[ib0 + 2 * K]; cn = (ib0 + 2 * K < nib) ? cn : cend;
-        panel_phase<U, K, PF>(idB, aB, idA, aA, cs, mid, ce, ib0, w, key, val, x, ylds, wave, cn - ce, touch);
+        panel_phase<U, K, PF, ABL>(idB, aB, idA, aA, cs, mid, ce, ib0, w, key, val, x, ylds, wave, cn - ce, touch, sink);
       }
     }
     if (PF) pnl_touch_join(touch);
+    if (ABL && sink == 1.2345e-300) ylds[0] = sink;  // keeps the ablated arithmetic alive
     __syncthreads();  // every wavefront's LDS adds are done (s_barrier above does not wait for lgkmcnt)
+    for (int i = threadIdx.x; i < P; i += kPanelWaves * 64)
+      if (row_base + i < nrows) y[row_base + i] = ylds[i];
+    if (g + 1 < ngen) {  // re-align the CUs between generations (bounded, performance only)
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (unsigned)((g + 1) * nb);
+        const unsigned long long t0 = wall_clock64();  // 100 MHz
+        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          if (wall_clock64() - t0 > 20000ull) break;  // 200 us: give up, stay correct
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+
+// ---- three-stage form -----------------------------------------------------------------------------
+// The two-stage kernel above ends every phase with all of a CU's gathers drained: fold, barrier, key
+// wait and address arithmetic pass before the next gathers reach the L2, and because the CUs of an
+// XCD run in lockstep by design, its L2 — the unit whose request rate bounds this kernel
+// (profiles/r02_gather_probe2.txt) — idles with them.  Here a wavefront issues the gathers of phase
+// i+1 BEFORE it waits for those of phase i, and the stream of phase i+2 before that: three register
+// sets rotate through the roles load -> gather -> fold, gathers are in flight at all times, and the
+// barrier only keeps the wavefronts of a CU within one phase of each other (x window: two index
+// blocks).  Every load is inline asm with counted vmcnt waits (vmcnt retires in order); a register an
+// asm load is still going to write is tied ("+v") into the wait that precedes its first use, so the
+// compiler never sees it as free in between.  A phase = one index block (K = 1).
+__device__ inline unsigned pnl_ld_key(const unsigned *p) {
+  unsigned v;
+  asm volatile("global_load_dword %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ inline double pnl_ld_val(const double *p) {
+  double v;
+  asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+template <int N>
+__device__ inline void pnl_wait_kv(unsigned &k, double &a) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(k), "+v"(a) : "n"(N) : "memory");
+}
+template <int N>
+__device__ inline void pnl_wait_x(double &v) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
+}
+
+template <int U>
+struct PanelSet {
+  unsigned id[U];
+  double a[U];
+  double x[U];
+};
+
+template <int U>
+__device__ inline void pnl3_load(PanelSet<U> &L, int cs, int ce, int wave, int lane, const unsigned *__restrict__ key,
+                                 const double *__restrict__ val, int64_t dummy_entry) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int c = cs + wave + kPanelWaves * u;
+    const int64_t e = (c < ce ? ((int64_t)c << 6) : dummy_entry) + lane;  // wave-uniform select
+    L.id[u] = pnl_ld_key(key + e);
+    L.a[u] = pnl_ld_val(val + e);
+  }
+}
+
+template <int U>
+__device__ inline void pnl3_gather(PanelSet<U> &G, int cs, int ce, int wave, int64_t xbase,
+                                   const double *__restrict__ x) {
+  const double *xp[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const bool ok = cs + wave + kPanelWaves * u < ce;  // wave-uniform
+    xp[u] = x + (ok ? xbase + (int64_t)(G.id[u] >> kRowBits) : 0);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) G.x[u] = pnl_gather_issue(xp[u]);
+}
+
+// one phase i: F holds phase i (its gathers in flight), G phase i+1 (its stream in flight), L is free
+template <int U>
+__device__ inline void panel3_phase(PanelSet<U> &F, PanelSet<U> &G, PanelSet<U> &L, int csF, int ceF, int ceG, int ceL,
+                                    int64_t ibF, int w, const unsigned *__restrict__ key, const double *__restrict__ val,
+                                    const double *__restrict__ x, double *yp, int wave, int lane, int64_t dummy_entry) {
+  // a. the stream of phase i+2
+  pnl3_load<U>(L, ceG, ceL, wave, lane, key, val, dummy_entry);
+  // b. the keys of phase i+1: younger than them are gathers(i) [U] and stream(i+2) [2U]
+#pragma unroll
+  for (int u = 0; u < U; ++u) pnl_wait_kv<3 * U>(G.id[u], G.a[u]);
+  // c. the gathers of phase i+1
+  pnl3_gather<U>(G, ceF, ceG, wave, (ibF + 1) << w, x);
+  // d. fold phase i: younger than its gather u are U-1-u gathers(i), stream(i+2) [2U], gathers(i+1) [U]
+  if (U > 0) pnl_wait_x<4 * U - 1>(F.x[0]);
+  if (U > 1) pnl_wait_x<4 * U - 2>(F.x[U > 1 ? 1 : 0]);
+  if (U > 2) pnl_wait_x<4 * U - 3>(F.x[U > 2 ? 2 : 0]);
+  if (U > 3) pnl_wait_x<4 * U - 4>(F.x[U > 3 ? 3 : 0]);
+  if (U > 4) pnl_wait_x<4 * U - 5>(F.x[U > 4 ? 4 : 0]);
+  if (U > 5) pnl_wait_x<4 * U - 6>(F.x[U > 5 ? 5 : 0]);
+  if (U > 6) pnl_wait_x<4 * U - 7>(F.x[U > 6 ? 6 : 0]);
+  if (U > 7) pnl_wait_x<4 * U - 8>(F.x[U > 7 ? 7 : 0]);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (csF + wave + kPanelWaves * u >= ceF) break;  // wave-uniform
+    pnl_fold(F.id[u], F.a[u] * F.x[u], yp);
+  }
+  for (int c = csF + wave + kPanelWaves * U; c < ceF; c += kPanelWaves) {  // tail of an over-long phase
+    const unsigned id = pnl_ld_key(key + ((int64_t)c << 6) + lane);
+    double a = pnl_ld_val(val + ((int64_t)c << 6) + lane);
+    unsigned idw = id;
+    pnl_wait_kv<0>(idw, a);
+    double xv = pnl_gather_issue(x + (ibF << w) + (int64_t)(idw >> kRowBits));
+    pnl_wait_x<0>(xv);
+    pnl_fold(idw, a * xv, yp);
+  }
+  __builtin_amdgcn_s_barrier();  // pacing only
+}
+
+template <int U>
+__device__ inline void pnl3_drain(PanelSet<U> &S) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    pnl_wait_kv<0>(S.id[u], S.a[u]);
+    pnl_wait_x<0>(S.x[u]);
+  }
+}
+
+template <int U>
+__global__ __launch_bounds__(kPanelWaves * 64) void spmv_panel3_kernel(
+    int64_t nrows, int64_t npanels, int P, int w, int64_t nib, const int *__restrict__ segc,
+    const unsigned *__restrict__ key, const double *__restrict__ val, const double *__restrict__ x,
+    double *__restrict__ y, int accumulate, unsigned *__restrict__ arrive, int64_t dummy_entry) {
+  extern __shared__ __attribute__((aligned(16))) double ylds[];  // P + 1 doubles
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nb = gridDim.x;
+  const int64_t ngen = (npanels + nb - 1) / nb;
+  for (int64_t g = 0; g < ngen; ++g) {
+    const int64_t p = g * nb + blockIdx.x;
+    if (p >= npanels) break;  // only in the last generation: no rendezvous follows
+    const int64_t row_base = p * P;
+    const int *sp = segc + p * nib;
+    const int cend = sp[nib];
+    auto bound = [&](int64_t ib) -> int { const int t = sp[ib < nib ? ib : nib]; return ib < nib ? t : cend; };
+    PanelSet<U> A, B, C;
+    {  // prologue: stream(0) -> A, stream(1) -> B, then the gathers of phase 0
+      const int c0 = sp[0], c1 = bound(1), c2 = bound(2);
+      pnl3_load<U>(A, c0, c1, wave, lane, key, val, dummy_entry);
+      pnl3_load<U>(B, c1, c2, wave, lane, key, val, dummy_entry);
+#pragma unroll
+      for (int u = 0; u < U; ++u) pnl_wait_kv<2 * U>(A.id[u], A.a[u]);
+      pnl3_gather<U>(A, c0, c1, wave, 0, x);
+#pragma unroll
+      for (int u = 0; u < U; ++u) { C.id[u] = 0; C.a[u] = 0.0; C.x[u] = 0.0; B.x[u] = 0.0; }
+    }
+    for (int i = threadIdx.x; i <= P; i += kPanelWaves * 64)
+      ylds[i] = (accumulate && i < P && row_base + i < nrows) ? y[row_base + i] : 0.0;
+    __syncthreads();
+    for (int64_t ph = 0; ph < nib; ph += 3) {
+      {
+        const int cs = sp[ph], ce = bound(ph + 1), ceG = bound(ph + 2), ceL = bound(ph + 3);
+        panel3_phase<U>(A, B, C, cs, ce, ceG, ceL, ph, w, key, val, x, ylds, wave, lane, dummy_entry);
+      }
+      if (ph + 1 < nib) {
+        const int cs = sp[ph + 1], ce = bound(ph + 2), ceG = bound(ph + 3), ceL = bound(ph + 4);
+        panel3_phase<U>(B, C, A, cs, ce, ceG, ceL, ph + 1, w, key, val, x, ylds, wave, lane, dummy_entry);
+      }
+      if (ph + 2 < nib) {
+        const int cs = sp[ph + 2], ce = bound(ph + 3), ceG = bound(ph + 4), ceL = bound(ph + 5);
+        panel3_phase<U>(C, A, B, cs, ce, ceG, ceL, ph + 2, w, key, val, x, ylds, wave, lane, dummy_entry);
+      }
+    }
+    pnl3_drain<U>(A);  // loads past the last phase went to the dummy chunk / x[0]: wait before the registers die
+    pnl3_drain<U>(B);
+    pnl3_drain<U>(C);
+    __syncthreads();  // every wavefront's LDS adds are done
     for (int i = threadIdx.x; i < P; i += kPanelWaves * 64)
       if (row_base + i < nrows) y[row_base + i] = ylds[i];
     if (g + 1 < ngen) {  // re-align the CUs between generations (bounded, performance only)
@@ -338,18 +523,32 @@ void build_panel_image(Matrix *m, int P, int w, hipStream_t s) {
   m->panel = b.release();
 }
 
-template <int U, int K, int PF>
+template <int U, int K, int PF, int ABL = 0>
 static void launch_panel_as(const Matrix *m, const PanelImage *b, unsigned nb, size_t lds, const double *d_x,
                             double *d_y, int accumulate, hipStream_t s) {
   static bool set_ = false;
   if (!set_) {
-    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_panel_kernel<U, K, PF>),
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_panel_kernel<U, K, PF, ABL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     set_ = true;
   }
-  hipLaunchKernelGGL((spmv_panel_kernel<U, K, PF>), dim3(nb), dim3(kPanelWaves * 64), lds, s, m->nrows_local,
+  hipLaunchKernelGGL((spmv_panel_kernel<U, K, PF, ABL>), dim3(nb), dim3(kPanelWaves * 64), lds, s, m->nrows_local,
                      b->npanels, b->P, b->w, b->nib, b->segc.get(), b->key.get(), b->val.get(), d_x, d_y,
                      accumulate, b->arrive.get());
+}
+
+template <int U>
+static void launch_panel3_as(const Matrix *m, const PanelImage *b, unsigned nb, size_t lds, const double *d_x,
+                             double *d_y, int accumulate, hipStream_t s) {
+  static bool set_ = false;
+  if (!set_) {
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_panel3_kernel<U>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    set_ = true;
+  }
+  hipLaunchKernelGGL((spmv_panel3_kernel<U>), dim3(nb), dim3(kPanelWaves * 64), lds, s, m->nrows_local, b->npanels,
+                     b->P, b->w, b->nib, b->segc.get(), b->key.get(), b->val.get(), d_x, d_y, accumulate,
+                     b->arrive.get(), (int64_t)b->nchunks << 6);
 }
 
 int launch_spmv_panel(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s) {
@@ -368,6 +567,31 @@ int launch_spmv_panel(const Matrix *m, const double *d_x, double *d_y, int accum
   if (nb > b->npanels) nb = b->npanels;
   SPL_HIP(hipMemsetAsync(b->arrive.get(), 0, sizeof(unsigned), s));
   const int U = b->unroll, K = b->kblocks, PF = b->prefetch;
+  if (b->ablate) {  // timing-only (wrong results): the two-stage kernel, 12 chunks, 2 blocks per phase
+    switch (b->ablate) {
+      case 1: launch_panel_as<12, 2, 0, 1>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      case 2: launch_panel_as<12, 2, 0, 2>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      case 3: launch_panel_as<12, 2, 0, 3>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      case 4: launch_panel_as<12, 2, 0, 4>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      case 5: launch_panel_as<12, 2, 0, 5>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      case 6: launch_panel_as<12, 2, 0, 6>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      default: launch_panel_as<12, 2, 0, 7>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+    }
+    hipError_t ea = hipGetLastError();
+    if (ea != hipSuccess) { set_last_error("spmv_panel ablation launch", ea); return SPL_ERROR_device; }
+    return SPL_OK;
+  }
+  if (b->stages == 3) {
+    switch (U) {
+      case 4: launch_panel3_as<4>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      case 5: launch_panel3_as<5>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      case 7: launch_panel3_as<7>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      default: launch_panel3_as<6>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+    }
+    hipError_t e3 = hipGetLastError();
+    if (e3 != hipSuccess) { set_last_error("spmv_panel3 launch", e3); return SPL_ERROR_device; }
+    return SPL_OK;
+  }
 #define SPL_PNL(UU, KK)                                                                       \
   do {                                                                                        \
     if (PF) launch_panel_as<UU, KK, 1>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s);     \
