@@ -209,11 +209,12 @@ int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unr
 int spl_matrix_set_spmv_order(void *H, int order);
 /* build the column-sorted panel image with an explicit shape (tuning / ablation): panels of
  * rows_per_panel rows (<= 20479: one workgroup's LDS), index blocks of 2^cols_log2 columns
- * (<= 17); 0,0 = choose.  unroll: 0 default, {4,6,8,10,12} chunks per wavefront and register set;
- * kblocks: index blocks per barrier phase (0 default, 1, 2); prefetch: 1 = touch the matrix stream
- * two phases ahead through the scalar cache.  Used by variant 16, and by variant 0 once
+ * (<= 17); 0,0 = choose.  form: 0 default; 1 / 2 = one 64-entry chunk per load instruction with 1 / 2
+ * index blocks per barrier phase; 4 / 5 = paired storage (two chunks per 8-byte key / 16-byte value
+ * load) with 1 / 2 index blocks per phase.  unroll: 0 default, else chunks ({4,6,8,10,12}) or pairs
+ * ({2..6}) per wavefront and register set.  Used by variant 16, and by variant 0 once
  * spl_matrix_set_spmv_order(H, SPL_ORDER_FREE) was called. */
-int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unroll, int kblocks, int prefetch);
+int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unroll, int form);
 /* the kernel spl_matrix_spmv_dev launches for this handle now: 0 CSR-stream, 8 column-blocked
  * lockstep, 15 sliced ELL, 16 column-sorted panels (other values: the forced ablation variant) */
 int spl_matrix_spmv_kernel(void *H);

@@ -110,7 +110,7 @@ def _declare(L):
         "spl_matrix_set_variant": [C.c_void_p, i],
         "spl_matrix_optimize": [C.c_void_p],
         "spl_matrix_build_blocked": [C.c_void_p, i, i, i],
-        "spl_matrix_build_panel": [C.c_void_p, i, i, i, i, i],
+        "spl_matrix_build_panel": [C.c_void_p, i, i, i, i],
         "spl_matrix_set_spmv_order": [C.c_void_p, i],
         "spl_matrix_spmv_kernel": [C.c_void_p],
         "spl_vector_synthetic_dev": [u64, i64, i64, C.c_void_p, C.c_void_p],

@@ -474,7 +474,7 @@ int spl_matrix_set_variant(void *H, int variant) {
     if (st != SPL_OK) return st;
   }
   if (variant == 16 && !m->panel) {
-    int st = spl_matrix_build_panel(H, 0, 0, 0, 0, 0);
+    int st = spl_matrix_build_panel(H, 0, 0, 0, 0);
     if (st != SPL_OK) return st;
   }
   if (variant == 15 && !m->sell) {
@@ -530,41 +530,46 @@ int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unr
   });
 }
 
-int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unroll, int kblocks, int prefetch) {
+int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unroll, int form) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;
   if (rows_per_panel == 0 && cols_log2 == 0) choose_panels(m, &rows_per_panel, &cols_log2);
   if (rows_per_panel < 1 || rows_per_panel > 20479 || cols_log2 < 4 || cols_log2 > 17)
     return SPL_ERROR_argument_missing;
-  if (kblocks < 0 || kblocks > 3) return SPL_ERROR_argument_missing;
+  if (form != 0 && form != 1 && form != 2 && form != 4 && form != 5) return SPL_ERROR_argument_missing;
   return guarded([&]() -> int {
     DeviceGuard g(m->device);
-    build_panel_image(m, rows_per_panel, cols_log2, nullptr);
+    // form: 1 / 2 = one chunk per load, 1 / 2 index blocks per phase; 4 / 5 = paired storage (a pair of
+    // chunks per 8-byte key / 16-byte value load; unroll then counts pairs), 1 / 2 index blocks per phase.
+    // Default: paired, a phase's x window 2 MiB at most (measured on C2, tools/bench_spmv_variants.py:
+    // paired 0.90 ms, one chunk per load 0.96 ms)
+    if (form == 0) form = cols_log2 >= 17 ? 5 : 4;
+    const bool pair = form >= 4;
+    const int kblocks = (form == 2 || form == 5) ? 2 : 1;
+    build_panel_image(m, rows_per_panel, cols_log2, pair ? 1 : 0, nullptr);
     PanelImage *b = m->panel;
-    const bool three = kblocks == 3;
-    if (three) kblocks = 1;
-    if (kblocks == 0) kblocks = cols_log2 >= 17 ? 2 : 1;  // a phase's x window: 2 MiB at most
-    if (const char *ev = getenv("SPL_PANEL_KBLOCKS")) kblocks = atoi(ev) == 1 ? 1 : 2;
     b->kblocks = kblocks;
     if (unroll == 0) {
-      // chunks per wavefront and phase: the mean number + 1 (the 16 wavefronts share the phase's chunks
-      // evenly, a phase's length varies by a chunk or two), from {4, 6, 8, 10, 12}
+      // units (chunks or pairs) per wavefront and phase: the 16 wavefronts share a phase's units evenly and a
+      // phase's length varies by a unit or two.  More loads in flight than the mean needs cost time (the
+      // stream then queues in front of the gathers in the CU's L1): the nearest count, and the few longer
+      // phases take the un-pipelined tail loop (measured on C2: 5 pairs 0.90 ms, 6 pairs 0.97 ms).
       const double per_wave = (double)b->nchunks * kblocks / (double)(b->npanels * b->nib > 0 ? b->npanels * b->nib : 1) / 16.0;
-      const double want = per_wave + 0.9;
-      unroll = want <= 4 ? 4 : want <= 6 ? 6 : want <= 8 ? 8 : want <= 10 ? 10 : 12;
+      if (pair) {
+        unroll = (int)(per_wave / 2.0 + 0.5);
+        unroll = unroll < 2 ? 2 : unroll > 6 ? 6 : unroll;
+      } else {
+        const int want = (int)(per_wave + 0.5);
+        unroll = want <= 4 ? 4 : want <= 6 ? 6 : want <= 8 ? 8 : want <= 10 ? 10 : 12;
+      }
     }
     if (const char *ev = getenv("SPL_PANEL_UNROLL")) unroll = atoi(ev);
     b->unroll = unroll;
-    if (const char *ev = getenv("SPL_PANEL_PREFETCH")) prefetch = atoi(ev);
-    b->prefetch = prefetch ? 1 : 0;
-    // kblocks == 3 selects the three-stage kernel (one index block per phase)
-    b->stages = three ? 3 : 2;
     b->ablate = 0;
     {
       const char *ok = getenv("SPL_ALLOW_ABLATION"), *ab = getenv("SPL_PANEL_ABLATE");
-      if (ok && ok[0] == '1' && ab) b->ablate = atoi(ab) & 7;
+      if (ok && ok[0] == '1' && ab && !pair) b->ablate = atoi(ab) & 7;
     }
-    if (const char *ev = getenv("SPL_PANEL_STAGES")) b->stages = atoi(ev) == 3 ? 3 : 2;
     return SPL_OK;
   });
 }
@@ -601,7 +606,7 @@ int spl_matrix_optimize(void *H) {
   }
   // order-free sums allowed (spl_matrix_set_spmv_order): the column-sorted panels send fewer requests
   // to the L2 when a panel is tall enough for lines of x to meet several of its entries
-  if (m->order_free && panels_pay(m)) return spl_matrix_build_panel(H, 0, 0, 0, 0, 0);
+  if (m->order_free && panels_pay(m)) return spl_matrix_build_panel(H, 0, 0, 0, 0);
   return spl_matrix_build_blocked(H, 0, 0, 0);  // 0,0: the same choice, including wavefronts per CU
 }
 

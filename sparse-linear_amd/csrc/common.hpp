@@ -104,9 +104,8 @@ struct PanelImage {
   DBuf<unsigned> arrive;          // rendezvous counter between generations
   int unroll = 10;                // chunks per wavefront and register set
   int kblocks = 2;                // index blocks per phase (barrier to barrier)
-  int prefetch = 0;               // 1: touch the stream two phases ahead through the scalar cache
+  int pair = 0;                   // 1: paired storage (chunk pairs interleaved, 8-byte key / 16-byte value loads)
   int ablate = 0;                 // timing-only ablation bits (SPL_PANEL_ABLATE with SPL_ALLOW_ABLATION=1)
-  int stages = 2;                 // 3: three-stage kernel (gathers of phase i+1 issued before those of i are awaited)
 };
 
 // sliced-ELL image of a row block (spmv_sell.hip)
@@ -248,7 +247,7 @@ constexpr int kNumSpmvVariants = 17;  // 16 = column-sorted workgroup panels (or
 void build_blocked_image(Matrix *m, int rows_per_panel, int w, hipStream_t s);
 int launch_spmv_blocked(const Matrix *m, const double *d_x, double *d_y, int accumulate, int unroll,
                         hipStream_t s);
-void build_panel_image(Matrix *m, int rows_per_panel, int w, hipStream_t s);
+void build_panel_image(Matrix *m, int rows_per_panel, int w, int pair, hipStream_t s);
 int launch_spmv_panel(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s);
 // choose the blocked image's shape for this matrix (0,0 = blocking would not help)
 void choose_blocking(const Matrix *m, int *rows_per_panel, int *w, int *waves);

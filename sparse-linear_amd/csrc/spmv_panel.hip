@@ -61,9 +61,28 @@ __global__ __launch_bounds__(256) void pnl_count_kernel(int64_t nrows, const Ptr
 }
 
 __global__ __launch_bounds__(256) void pnl_chunks_kernel(int64_t nseg, const int *__restrict__ segcount,
-                                                         int *__restrict__ chunks) {
+                                                         int *__restrict__ chunks, int pair) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nseg) chunks[i] = (segcount[i] + 63) >> 6;
+  if (i < nseg) {
+    const int c = (segcount[i] + 63) >> 6;
+    chunks[i] = pair ? ((c + 1) & ~1) : c;  // paired storage: whole pairs of chunks
+  }
+}
+
+// paired storage: inside every 128-entry pair of chunks (A, B) the entries are stored A0 B0 A1 B1 ...,
+// so that one 16-byte load per lane brings lane l the values (A_l, B_l) and one 8-byte load the keys
+__global__ __launch_bounds__(128) void pnl_interleave_kernel(int64_t npairs, unsigned *__restrict__ key,
+                                                             double *__restrict__ val) {
+  const int64_t pr = blockIdx.x;
+  if (pr >= npairs) return;
+  const int t = threadIdx.x;
+  const int64_t base = pr << 7;
+  const unsigned k = key[base + t];
+  const double v = val[base + t];
+  __syncthreads();
+  const int dst = ((t & 63) << 1) | (t >> 6);
+  key[base + dst] = k;
+  val[base + dst] = v;
 }
 
 __global__ __launch_bounds__(256) void pnl_entryptr_kernel(int64_t n, const int *__restrict__ segc,
@@ -108,22 +127,6 @@ template <int N>
 __device__ inline void pnl_gather_wait(double &v) {
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
 }
-// Touch the six 128-byte lines of one chunk of the matrix stream (256 B of keys, 512 B of values)
-// through the scalar cache: the lines land in the XCD's L2 without taking a miss slot of the vector
-// L1.  The loads return at any later time into the ONE register `t`, which therefore stays reserved
-// (tied "+s" operand) from the first touch of a phase to the s_waitcnt lgkmcnt(0) at the start of the
-// next: the compiler must never be free to reuse a register a scalar load is still going to write.
-__device__ inline void pnl_touch_chunk(unsigned &t, const void *pk, const void *pv) {
-  asm volatile(
-      "s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x80\n\t"
-      "s_load_dword %0, %2, 0x0\n\ts_load_dword %0, %2, 0x80\n\t"
-      "s_load_dword %0, %2, 0x100\n\ts_load_dword %0, %2, 0x180"
-      : "+s"(t) : "s"(pk), "s"(pv) : "memory");
-}
-__device__ inline void pnl_touch_join(unsigned &t) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t) : : "memory");
-}
-
 __device__ inline void pnl_fold(unsigned id, double prod, double *yp) {
   __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)(yp + (id & kRowMask)), prod);
 }
@@ -134,14 +137,13 @@ __device__ inline void pnl_fold(unsigned id, double prod, double *yp) {
 // ib0 + j + 1 (K - 1 of them): the x block a chunk gathers from follows from its position.
 // ABL (timing-only ablations, wrong results; refused unless SPL_ALLOW_ABLATION=1): bit 0 every gather reads
 // x[lane] (no L2 requests beyond one line), bit 1 no value loads (a = 1), bit 2 no LDS fold
-template <int U, int K, int PF, int ABL = 0>
+template <int U, int K, int ABL = 0>
 __device__ inline void panel_phase(unsigned (&idC)[U], double (&aC)[U], unsigned (&idN)[U], double (&aN)[U],
                                    int cs, const int (&mid)[K > 1 ? K - 1 : 1], int ce, int64_t ib0, int w,
                                    const unsigned *__restrict__ key, const double *__restrict__ val,
-                                   const double *__restrict__ x, double *yp, int wave, int nextlen, unsigned &touch,
-                                   double &sink) {
+                                   const double *__restrict__ x, double *yp, int wave, int nextlen, double &sink,
+                                   int64_t dummy) {
   const int lane = threadIdx.x & 63;
-  if (PF) pnl_touch_join(touch);  // the touches of the previous phase have returned
   double xv[U];
   const double *xp[U];
 #pragma unroll
@@ -158,27 +160,17 @@ __device__ inline void panel_phase(unsigned (&idC)[U], double (&aC)[U], unsigned
 #pragma unroll
   for (int u = 0; u < U; ++u) xv[u] = pnl_gather_issue(xp[u]);  // gathers first ...
   __builtin_amdgcn_sched_barrier(0);
-  const unsigned *kn = key + (((int64_t)(ce + wave)) << 6) + lane;
-  const double *vn = val + (((int64_t)(ce + wave)) << 6) + lane;
 #pragma unroll
   for (int u = 0; u < U; ++u) {  // ... then the next phase's stream, left in flight across the barrier
-    idN[u] = __builtin_nontemporal_load(kn + (size_t)u * kPanelWaves * 64);
+    // a chunk past the next phase's end would be fetched again by the phase it belongs to: read the
+    // (L2-resident) dummy chunk behind the stream instead
+    const int c = ce + wave + kPanelWaves * u;
+    const int64_t e = (c < ce + nextlen ? ((int64_t)c << 6) : dummy) + lane;  // wave-uniform select
+    idN[u] = __builtin_nontemporal_load(key + e);
     if (ABL & 2) aN[u] = 1.0;
-    else aN[u] = __builtin_nontemporal_load(vn + (size_t)u * kPanelWaves * 64);
+    else aN[u] = __builtin_nontemporal_load(val + e);
   }
   __builtin_amdgcn_sched_barrier(0);
-  if (PF) {
-    // lines of the phase after next, this wavefront's share, through the scalar cache
-    const char *kb = reinterpret_cast<const char *>(key + (((int64_t)ce + nextlen) << 6));
-    const char *vb = reinterpret_cast<const char *>(val + (((int64_t)ce + nextlen) << 6));
-    // a chunk = 256 B of keys + 512 B of values = 2 + 4 lines of 128 B; wavefront i touches the
-    // lines of chunks i, i + 16, ... like the loads that will follow
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t off = (int64_t)(wave + kPanelWaves * u);
-      pnl_touch_chunk(touch, kb + off * 256, vb + off * 512);
-    }
-  }
   constexpr int Y = ((ABL & 2) ? 2 : 3) * U - 1;  // younger than gather u here: U-1-u gathers + 2U stream loads
   pnl_gather_wait<Y>(xv[0]);
   if (U > 1) pnl_gather_wait<Y - 1>(xv[U > 1 ? 1 : 0]);
@@ -209,11 +201,11 @@ __device__ inline void panel_phase(unsigned (&idC)[U], double (&aC)[U], unsigned
   __builtin_amdgcn_s_barrier();  // pacing only: no fence, vector memory stays in flight
 }
 
-template <int U, int K, int PF, int ABL = 0>
+template <int U, int K, int ABL = 0>
 __global__ __launch_bounds__(kPanelWaves * 64) void spmv_panel_kernel(
     int64_t nrows, int64_t npanels, int P, int w, int64_t nib, const int *__restrict__ segc,
     const unsigned *__restrict__ key, const double *__restrict__ val, const double *__restrict__ x,
-    double *__restrict__ y, int accumulate, unsigned *__restrict__ arrive) {
+    double *__restrict__ y, int accumulate, unsigned *__restrict__ arrive, int64_t dummy) {
   extern __shared__ __attribute__((aligned(16))) double ylds[];  // P + 1 doubles
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -228,11 +220,11 @@ __global__ __launch_bounds__(kPanelWaves * 64) void spmv_panel_kernel(
     const int c0 = sp[0];
     unsigned idA[U], idB[U];
     double aA[U], aB[U];
-    unsigned touch = 0;
     double sink = 0.0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {  // prologue: this wavefront's first chunks of phase 0
-      const int64_t k = (((int64_t)(c0 + wave + kPanelWaves * u)) << 6) + lane;
+      const int c = c0 + wave + kPanelWaves * u;
+      const int64_t k = (c < (K < nib ? sp[K] : sp[nib]) ? ((int64_t)c << 6) : dummy) + lane;
       idA[u] = __builtin_nontemporal_load(key + k);
       aA[u] = __builtin_nontemporal_load(val + k);
     }
@@ -249,7 +241,7 @@ __global__ __launch_bounds__(kPanelWaves * 64) void spmv_panel_kernel(
         const int cs = sp[ib0];
         int ce = sp[ib0 + K]; ce = (ib0 + K < nib) ? ce : cend;
         int cn = sp[ib0 + 2 * K]; cn = (ib0 + 2 * K < nib) ? cn : cend;
-        panel_phase<U, K, PF, ABL>(idA, aA, idB, aB, cs, mid, ce, ib0, w, key, val, x, ylds, wave, cn - ce, touch, sink);
+        panel_phase<U, K, ABL>(idA, aA, idB, aB, cs, mid, ce, ib0, w, key, val, x, ylds, wave, cn - ce, sink, dummy);
       }
       if (ph + 1 < nph) {
         const int64_t ib0 = (ph + 1) * K;
@@ -259,10 +251,9 @@ __global__ __launch_bounds__(kPanelWaves * 64) void spmv_panel_kernel(
         const int cs = sp[ib0];
         int ce = sp[ib0 + K]; ce = (ib0 + K < nib) ? ce : cend;
         int cn = sp[ib0 + 2 * K]; cn = (ib0 + 2 * K < nib) ? cn : cend;
-        panel_phase<U, K, PF, ABL>(idB, aB, idA, aA, cs, mid, ce, ib0, w, key, val, x, ylds, wave, cn - ce, touch, sink);
+        panel_phase<U, K, ABL>(idB, aB, idA, aA, cs, mid, ce, ib0, w, key, val, x, ylds, wave, cn - ce, sink, dummy);
       }
     }
-    if (PF) pnl_touch_join(touch);
     if (ABL && sink == 1.2345e-300) ylds[0] = sink;  // keeps the ablated arithmetic alive
     __syncthreads();  // every wavefront's LDS adds are done (s_barrier above does not wait for lgkmcnt)
     for (int i = threadIdx.x; i < P; i += kPanelWaves * 64)
@@ -284,174 +275,146 @@ __global__ __launch_bounds__(kPanelWaves * 64) void spmv_panel_kernel(
 }
 
 
-// ---- three-stage form -----------------------------------------------------------------------------
-// The two-stage kernel above ends every phase with all of a CU's gathers drained: fold, barrier, key
-// wait and address arithmetic pass before the next gathers reach the L2, and because the CUs of an
-// XCD run in lockstep by design, its L2 — the unit whose request rate bounds this kernel
-// (profiles/r02_gather_probe2.txt) — idles with them.  Here a wavefront issues the gathers of phase
-// i+1 BEFORE it waits for those of phase i, and the stream of phase i+2 before that: three register
-// sets rotate through the roles load -> gather -> fold, gathers are in flight at all times, and the
-// barrier only keeps the wavefronts of a CU within one phase of each other (x window: two index
-// blocks).  Every load is inline asm with counted vmcnt waits (vmcnt retires in order); a register an
-// asm load is still going to write is tied ("+v") into the wait that precedes its first use, so the
-// compiler never sees it as free in between.  A phase = one index block (K = 1).
-__device__ inline unsigned pnl_ld_key(const unsigned *p) {
-  unsigned v;
-  asm volatile("global_load_dword %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-__device__ inline double pnl_ld_val(const double *p) {
-  double v;
-  asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-template <int N>
-__device__ inline void pnl_wait_kv(unsigned &k, double &a) {
-  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(k), "+v"(a) : "n"(N) : "memory");
-}
-template <int N>
-__device__ inline void pnl_wait_x(double &v) {
-  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
-}
+// ---- paired form ------------------------------------------------------------------------------------
+// Same two-stage schedule on the paired storage: a wavefront's unit of work is a PAIR of chunks, read
+// with one 8-byte key load and one 16-byte value load per lane (half the stream instructions for the
+// same bytes: the HBM stream of a CU runs closer to its peak with fewer, wider requests in flight —
+// tools/probe/tcp_mix_probe.hip S rows), gathered with two instructions (chunk A, chunk B: each a run
+// of 64 column-sorted entries as before) and folded with two.  All units here are pairs.
+typedef unsigned pnl_u2 __attribute__((ext_vector_type(2)));
+typedef double pnl_d2 __attribute__((ext_vector_type(2)));
 
-template <int U>
-struct PanelSet {
-  unsigned id[U];
-  double a[U];
-  double x[U];
-};
-
-template <int U>
-__device__ inline void pnl3_load(PanelSet<U> &L, int cs, int ce, int wave, int lane, const unsigned *__restrict__ key,
-                                 const double *__restrict__ val, int64_t dummy_entry) {
+template <int U, int K>
+__device__ inline void panelw_phase(pnl_u2 (&idC)[U], pnl_d2 (&aC)[U], pnl_u2 (&idN)[U], pnl_d2 (&aN)[U], int cs,
+                                    const int (&mid)[K > 1 ? K - 1 : 1], int ce, int64_t ib0, int w,
+                                    const pnl_u2 *__restrict__ key2, const pnl_d2 *__restrict__ val2,
+                                    const double *__restrict__ x, double *yp, int wave, int cn, int64_t dummy) {
+  const int lane = threadIdx.x & 63;
+  double xa[U], xb[U];
+  const double *pa[U], *pb[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int c = cs + wave + kPanelWaves * u;
-    const int64_t e = (c < ce ? ((int64_t)c << 6) : dummy_entry) + lane;  // wave-uniform select
-    L.id[u] = pnl_ld_key(key + e);
-    L.a[u] = pnl_ld_val(val + e);
+    int64_t ib = ib0;
+#pragma unroll
+    for (int j = 0; j + 1 < K; ++j) ib += (c >= mid[j]) ? 1 : 0;
+    const bool ok = c < ce;  // wave-uniform
+    pa[u] = x + (ok ? ((ib << w) + (int64_t)(idC[u].x >> kRowBits)) : 0);
+    pb[u] = x + (ok ? ((ib << w) + (int64_t)(idC[u].y >> kRowBits)) : 0);
   }
-}
-
-template <int U>
-__device__ inline void pnl3_gather(PanelSet<U> &G, int cs, int ce, int wave, int64_t xbase,
-                                   const double *__restrict__ x) {
-  const double *xp[U];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {  // gathers first ...
+    xa[u] = pnl_gather_issue(pa[u]);
+    xb[u] = pnl_gather_issue(pb[u]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {  // ... then the next phase's stream, left in flight across the barrier
+    // a unit past the next phase's end [ce, cn) would be fetched again by the phase it belongs to: read
+    // the (L2-resident) dummy unit instead, so that U may exceed the mean count without costing HBM bytes
+    const int c = ce + wave + kPanelWaves * u;
+    const int64_t e = (c < cn ? ((int64_t)c << 6) : dummy) + lane;  // wave-uniform select
+    idN[u] = __builtin_nontemporal_load(key2 + e);
+    aN[u] = __builtin_nontemporal_load(val2 + e);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // younger than gather j (j = 2u for A, 2u + 1 for B) here: 2U-1-j gathers + 2U stream loads
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const bool ok = cs + wave + kPanelWaves * u < ce;  // wave-uniform
-    xp[u] = x + (ok ? xbase + (int64_t)(G.id[u] >> kRowBits) : 0);
+    if (u == 0) { pnl_gather_wait<4 * U - 1>(xa[u]); pnl_gather_wait<4 * U - 2>(xb[u]); }
+    if (u == 1) { pnl_gather_wait<4 * U - 3>(xa[u]); pnl_gather_wait<4 * U - 4>(xb[u]); }
+    if (u == 2) { pnl_gather_wait<(4 * U - 5 > 0 ? 4 * U - 5 : 0)>(xa[u]); pnl_gather_wait<(4 * U - 6 > 0 ? 4 * U - 6 : 0)>(xb[u]); }
+    if (u == 3) { pnl_gather_wait<(4 * U - 7 > 0 ? 4 * U - 7 : 0)>(xa[u]); pnl_gather_wait<(4 * U - 8 > 0 ? 4 * U - 8 : 0)>(xb[u]); }
+    if (u == 4) { pnl_gather_wait<(4 * U - 9 > 0 ? 4 * U - 9 : 0)>(xa[u]); pnl_gather_wait<(4 * U - 10 > 0 ? 4 * U - 10 : 0)>(xb[u]); }
+    if (u == 5) { pnl_gather_wait<(4 * U - 11 > 0 ? 4 * U - 11 : 0)>(xa[u]); pnl_gather_wait<(4 * U - 12 > 0 ? 4 * U - 12 : 0)>(xb[u]); }
+    if (u == 6) { pnl_gather_wait<(4 * U - 13 > 0 ? 4 * U - 13 : 0)>(xa[u]); pnl_gather_wait<(4 * U - 14 > 0 ? 4 * U - 14 : 0)>(xb[u]); }
+    if (u == 7) { pnl_gather_wait<(4 * U - 15 > 0 ? 4 * U - 15 : 0)>(xa[u]); pnl_gather_wait<(4 * U - 16 > 0 ? 4 * U - 16 : 0)>(xb[u]); }
   }
-#pragma unroll
-  for (int u = 0; u < U; ++u) G.x[u] = pnl_gather_issue(xp[u]);
-}
-
-// one phase i: F holds phase i (its gathers in flight), G phase i+1 (its stream in flight), L is free
-template <int U>
-__device__ inline void panel3_phase(PanelSet<U> &F, PanelSet<U> &G, PanelSet<U> &L, int csF, int ceF, int ceG, int ceL,
-                                    int64_t ibF, int w, const unsigned *__restrict__ key, const double *__restrict__ val,
-                                    const double *__restrict__ x, double *yp, int wave, int lane, int64_t dummy_entry) {
-  // a. the stream of phase i+2
-  pnl3_load<U>(L, ceG, ceL, wave, lane, key, val, dummy_entry);
-  // b. the keys of phase i+1: younger than them are gathers(i) [U] and stream(i+2) [2U]
-#pragma unroll
-  for (int u = 0; u < U; ++u) pnl_wait_kv<3 * U>(G.id[u], G.a[u]);
-  // c. the gathers of phase i+1
-  pnl3_gather<U>(G, ceF, ceG, wave, (ibF + 1) << w, x);
-  // d. fold phase i: younger than its gather u are U-1-u gathers(i), stream(i+2) [2U], gathers(i+1) [U]
-  if (U > 0) pnl_wait_x<4 * U - 1>(F.x[0]);
-  if (U > 1) pnl_wait_x<4 * U - 2>(F.x[U > 1 ? 1 : 0]);
-  if (U > 2) pnl_wait_x<4 * U - 3>(F.x[U > 2 ? 2 : 0]);
-  if (U > 3) pnl_wait_x<4 * U - 4>(F.x[U > 3 ? 3 : 0]);
-  if (U > 4) pnl_wait_x<4 * U - 5>(F.x[U > 4 ? 4 : 0]);
-  if (U > 5) pnl_wait_x<4 * U - 6>(F.x[U > 5 ? 5 : 0]);
-  if (U > 6) pnl_wait_x<4 * U - 7>(F.x[U > 6 ? 6 : 0]);
-  if (U > 7) pnl_wait_x<4 * U - 8>(F.x[U > 7 ? 7 : 0]);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    if (csF + wave + kPanelWaves * u >= ceF) break;  // wave-uniform
-    pnl_fold(F.id[u], F.a[u] * F.x[u], yp);
+    if (cs + wave + kPanelWaves * u >= ce) break;  // wave-uniform
+    pnl_fold(idC[u].x, aC[u].x * xa[u], yp);
+    pnl_fold(idC[u].y, aC[u].y * xb[u], yp);
   }
-  for (int c = csF + wave + kPanelWaves * U; c < ceF; c += kPanelWaves) {  // tail of an over-long phase
-    const unsigned id = pnl_ld_key(key + ((int64_t)c << 6) + lane);
-    double a = pnl_ld_val(val + ((int64_t)c << 6) + lane);
-    unsigned idw = id;
-    pnl_wait_kv<0>(idw, a);
-    double xv = pnl_gather_issue(x + (ibF << w) + (int64_t)(idw >> kRowBits));
-    pnl_wait_x<0>(xv);
-    pnl_fold(idw, a * xv, yp);
+  for (int c = cs + wave + kPanelWaves * U; c < ce; c += kPanelWaves) {  // tail of an over-long phase
+    int64_t ib = ib0;
+#pragma unroll
+    for (int j = 0; j + 1 < K; ++j) ib += (c >= mid[j]) ? 1 : 0;
+    const pnl_u2 id = __builtin_nontemporal_load(key2 + ((int64_t)c << 6) + lane);
+    const pnl_d2 a = __builtin_nontemporal_load(val2 + ((int64_t)c << 6) + lane);
+    pnl_fold(id.x, a.x * x[(ib << w) + (int64_t)(id.x >> kRowBits)], yp);
+    pnl_fold(id.y, a.y * x[(ib << w) + (int64_t)(id.y >> kRowBits)], yp);
   }
   __builtin_amdgcn_s_barrier();  // pacing only
 }
 
-template <int U>
-__device__ inline void pnl3_drain(PanelSet<U> &S) {
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    pnl_wait_kv<0>(S.id[u], S.a[u]);
-    pnl_wait_x<0>(S.x[u]);
-  }
-}
-
-template <int U>
-__global__ __launch_bounds__(kPanelWaves * 64) void spmv_panel3_kernel(
+template <int U, int K>
+__global__ __launch_bounds__(kPanelWaves * 64) void spmv_panelw_kernel(
     int64_t nrows, int64_t npanels, int P, int w, int64_t nib, const int *__restrict__ segc,
     const unsigned *__restrict__ key, const double *__restrict__ val, const double *__restrict__ x,
-    double *__restrict__ y, int accumulate, unsigned *__restrict__ arrive, int64_t dummy_entry) {
+    double *__restrict__ y, int accumulate, unsigned *__restrict__ arrive, int64_t dummy) {
   extern __shared__ __attribute__((aligned(16))) double ylds[];  // P + 1 doubles
+  const pnl_u2 *key2 = reinterpret_cast<const pnl_u2 *>(key);
+  const pnl_d2 *val2 = reinterpret_cast<const pnl_d2 *>(val);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nb = gridDim.x;
   const int64_t ngen = (npanels + nb - 1) / nb;
+  const int64_t nph = (nib + K - 1) / K;
   for (int64_t g = 0; g < ngen; ++g) {
     const int64_t p = g * nb + blockIdx.x;
-    if (p >= npanels) break;  // only in the last generation: no rendezvous follows
+    if (p >= npanels) break;
     const int64_t row_base = p * P;
-    const int *sp = segc + p * nib;
-    const int cend = sp[nib];
-    auto bound = [&](int64_t ib) -> int { const int t = sp[ib < nib ? ib : nib]; return ib < nib ? t : cend; };
-    PanelSet<U> A, B, C;
-    {  // prologue: stream(0) -> A, stream(1) -> B, then the gathers of phase 0
-      const int c0 = sp[0], c1 = bound(1), c2 = bound(2);
-      pnl3_load<U>(A, c0, c1, wave, lane, key, val, dummy_entry);
-      pnl3_load<U>(B, c1, c2, wave, lane, key, val, dummy_entry);
+    const int *sp = segc + p * nib;  // in chunks; every boundary is even (whole pairs)
+    const int c0 = sp[0] >> 1;
+    const int c1 = (K < nib ? sp[K] : sp[nib]) >> 1;
+    pnl_u2 idA[U], idB[U];
+    pnl_d2 aA[U], aB[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) pnl_wait_kv<2 * U>(A.id[u], A.a[u]);
-      pnl3_gather<U>(A, c0, c1, wave, 0, x);
-#pragma unroll
-      for (int u = 0; u < U; ++u) { C.id[u] = 0; C.a[u] = 0.0; C.x[u] = 0.0; B.x[u] = 0.0; }
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + wave + kPanelWaves * u;
+      const int64_t k = (c < c1 ? ((int64_t)c << 6) : dummy) + lane;
+      idA[u] = __builtin_nontemporal_load(key2 + k);
+      aA[u] = __builtin_nontemporal_load(val2 + k);
     }
     for (int i = threadIdx.x; i <= P; i += kPanelWaves * 64)
       ylds[i] = (accumulate && i < P && row_base + i < nrows) ? y[row_base + i] : 0.0;
     __syncthreads();
-    for (int64_t ph = 0; ph < nib; ph += 3) {
+    const int cend = sp[nib] >> 1;
+    for (int64_t ph = 0; ph < nph; ph += 2) {
       {
-        const int cs = sp[ph], ce = bound(ph + 1), ceG = bound(ph + 2), ceL = bound(ph + 3);
-        panel3_phase<U>(A, B, C, cs, ce, ceG, ceL, ph, w, key, val, x, ylds, wave, lane, dummy_entry);
+        const int64_t ib0 = ph * K;
+        int mid[K > 1 ? K - 1 : 1];
+#pragma unroll
+        for (int j = 0; j + 1 < K; ++j) { const int t = sp[ib0 + j + 1] >> 1; mid[j] = t < cend ? t : cend; }
+        const int cs = sp[ib0] >> 1;
+        int ce = sp[ib0 + K] >> 1; ce = (ib0 + K < nib) ? ce : cend;
+        int cn = sp[ib0 + 2 * K] >> 1; cn = (ib0 + 2 * K < nib) ? cn : cend;
+        panelw_phase<U, K>(idA, aA, idB, aB, cs, mid, ce, ib0, w, key2, val2, x, ylds, wave, cn, dummy);
       }
-      if (ph + 1 < nib) {
-        const int cs = sp[ph + 1], ce = bound(ph + 2), ceG = bound(ph + 3), ceL = bound(ph + 4);
-        panel3_phase<U>(B, C, A, cs, ce, ceG, ceL, ph + 1, w, key, val, x, ylds, wave, lane, dummy_entry);
-      }
-      if (ph + 2 < nib) {
-        const int cs = sp[ph + 2], ce = bound(ph + 3), ceG = bound(ph + 4), ceL = bound(ph + 5);
-        panel3_phase<U>(C, A, B, cs, ce, ceG, ceL, ph + 2, w, key, val, x, ylds, wave, lane, dummy_entry);
+      if (ph + 1 < nph) {
+        const int64_t ib0 = (ph + 1) * K;
+        int mid[K > 1 ? K - 1 : 1];
+#pragma unroll
+        for (int j = 0; j + 1 < K; ++j) { const int t = sp[ib0 + j + 1] >> 1; mid[j] = t < cend ? t : cend; }
+        const int cs = sp[ib0] >> 1;
+        int ce = sp[ib0 + K] >> 1; ce = (ib0 + K < nib) ? ce : cend;
+        int cn = sp[ib0 + 2 * K] >> 1; cn = (ib0 + 2 * K < nib) ? cn : cend;
+        panelw_phase<U, K>(idB, aB, idA, aA, cs, mid, ce, ib0, w, key2, val2, x, ylds, wave, cn, dummy);
       }
     }
-    pnl3_drain<U>(A);  // loads past the last phase went to the dummy chunk / x[0]: wait before the registers die
-    pnl3_drain<U>(B);
-    pnl3_drain<U>(C);
-    __syncthreads();  // every wavefront's LDS adds are done
+    __syncthreads();
     for (int i = threadIdx.x; i < P; i += kPanelWaves * 64)
       if (row_base + i < nrows) y[row_base + i] = ylds[i];
-    if (g + 1 < ngen) {  // re-align the CUs between generations (bounded, performance only)
+    if (g + 1 < ngen) {
       __syncthreads();
       if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = (unsigned)((g + 1) * nb);
-        const unsigned long long t0 = wall_clock64();  // 100 MHz
+        const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          if (wall_clock64() - t0 > 20000ull) break;  // 200 us: give up, stay correct
+          if (wall_clock64() - t0 > 20000ull) break;
           __builtin_amdgcn_s_sleep(8);
         }
       }
@@ -462,7 +425,7 @@ __global__ __launch_bounds__(kPanelWaves * 64) void spmv_panel3_kernel(
 
 }  // namespace
 
-void build_panel_image(Matrix *m, int P, int w, hipStream_t s) {
+void build_panel_image(Matrix *m, int P, int w, int pair, hipStream_t s) {
   auto b = std::make_unique<PanelImage>();
   b->P = P;
   b->w = w;
@@ -486,7 +449,7 @@ void build_panel_image(Matrix *m, int P, int w, hipStream_t s) {
                          m->rowptr64.get(), m->colidx.get(), P, w, b->nib, counts.get());
   }
   hipLaunchKernelGGL(pnl_chunks_kernel, dim3(blocks_for(nseg, 256)), dim3(256), 0, s, nseg, counts.get(),
-                     chunks.get());
+                     chunks.get(), pair);
   exclusive_scan_i32_to_i64(chunks.get(), off64.get(), nseg, s);
   int64_t nchunks = 0;
   SPL_HIP(hipMemcpyAsync(&nchunks, off64.get() + nseg, sizeof(int64_t), hipMemcpyDeviceToHost, s));
@@ -518,37 +481,41 @@ void build_panel_image(Matrix *m, int P, int w, hipStream_t s) {
   hipLaunchKernelGGL(pnl_entryptr_kernel, dim3(blocks_for(nseg + 1, 256)), dim3(256), 0, s, nseg + 1,
                      b->segc.get(), off64.get());
   segmented_sort_pairs_u32(off64.get(), nseg, b->key.get(), b->val.get(), s);
+  b->pair = pair ? 1 : 0;
+  if (pair && nchunks > 0)
+    hipLaunchKernelGGL(pnl_interleave_kernel, dim3((unsigned)(nchunks / 2)), dim3(128), 0, s, nchunks / 2,
+                       b->key.get(), b->val.get());
   SPL_HIP(hipStreamSynchronize(s));
   delete m->panel;
   m->panel = b.release();
 }
 
-template <int U, int K, int PF, int ABL = 0>
+template <int U, int K, int ABL = 0>
 static void launch_panel_as(const Matrix *m, const PanelImage *b, unsigned nb, size_t lds, const double *d_x,
                             double *d_y, int accumulate, hipStream_t s) {
   static bool set_ = false;
   if (!set_) {
-    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_panel_kernel<U, K, PF, ABL>),
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_panel_kernel<U, K, ABL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     set_ = true;
   }
-  hipLaunchKernelGGL((spmv_panel_kernel<U, K, PF, ABL>), dim3(nb), dim3(kPanelWaves * 64), lds, s, m->nrows_local,
+  hipLaunchKernelGGL((spmv_panel_kernel<U, K, ABL>), dim3(nb), dim3(kPanelWaves * 64), lds, s, m->nrows_local,
                      b->npanels, b->P, b->w, b->nib, b->segc.get(), b->key.get(), b->val.get(), d_x, d_y,
-                     accumulate, b->arrive.get());
+                     accumulate, b->arrive.get(), (int64_t)b->nchunks << 6);
 }
 
-template <int U>
-static void launch_panel3_as(const Matrix *m, const PanelImage *b, unsigned nb, size_t lds, const double *d_x,
+template <int U, int K>
+static void launch_panelw_as(const Matrix *m, const PanelImage *b, unsigned nb, size_t lds, const double *d_x,
                              double *d_y, int accumulate, hipStream_t s) {
   static bool set_ = false;
   if (!set_) {
-    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_panel3_kernel<U>),
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_panelw_kernel<U, K>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     set_ = true;
   }
-  hipLaunchKernelGGL((spmv_panel3_kernel<U>), dim3(nb), dim3(kPanelWaves * 64), lds, s, m->nrows_local, b->npanels,
+  hipLaunchKernelGGL((spmv_panelw_kernel<U, K>), dim3(nb), dim3(kPanelWaves * 64), lds, s, m->nrows_local, b->npanels,
                      b->P, b->w, b->nib, b->segc.get(), b->key.get(), b->val.get(), d_x, d_y, accumulate,
-                     b->arrive.get(), (int64_t)b->nchunks << 6);
+                     b->arrive.get(), (int64_t)(b->nchunks / 2) << 6);
 }
 
 int launch_spmv_panel(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s) {
@@ -566,37 +533,41 @@ int launch_spmv_panel(const Matrix *m, const double *d_x, double *d_y, int accum
   int64_t nb = cus;
   if (nb > b->npanels) nb = b->npanels;
   SPL_HIP(hipMemsetAsync(b->arrive.get(), 0, sizeof(unsigned), s));
-  const int U = b->unroll, K = b->kblocks, PF = b->prefetch;
+  const int U = b->unroll, K = b->kblocks;
   if (b->ablate) {  // timing-only (wrong results): the two-stage kernel, 12 chunks, 2 blocks per phase
     switch (b->ablate) {
-      case 1: launch_panel_as<12, 2, 0, 1>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
-      case 2: launch_panel_as<12, 2, 0, 2>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
-      case 3: launch_panel_as<12, 2, 0, 3>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
-      case 4: launch_panel_as<12, 2, 0, 4>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
-      case 5: launch_panel_as<12, 2, 0, 5>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
-      case 6: launch_panel_as<12, 2, 0, 6>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
-      default: launch_panel_as<12, 2, 0, 7>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      case 1: launch_panel_as<12, 2, 1>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      case 2: launch_panel_as<12, 2, 2>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      case 3: launch_panel_as<12, 2, 3>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      case 4: launch_panel_as<12, 2, 4>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      case 5: launch_panel_as<12, 2, 5>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      case 6: launch_panel_as<12, 2, 6>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      default: launch_panel_as<12, 2, 7>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
     }
     hipError_t ea = hipGetLastError();
     if (ea != hipSuccess) { set_last_error("spmv_panel ablation launch", ea); return SPL_ERROR_device; }
     return SPL_OK;
   }
-  if (b->stages == 3) {
-    switch (U) {
-      case 4: launch_panel3_as<4>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
-      case 5: launch_panel3_as<5>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
-      case 7: launch_panel3_as<7>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
-      default: launch_panel3_as<6>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+  if (b->pair) {  // paired storage: only the paired kernel reads it
+    if (K == 1) {
+      switch (U) {
+        case 2: launch_panelw_as<2, 1>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+        case 4: launch_panelw_as<4, 1>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+        default: launch_panelw_as<3, 1>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      }
+    } else {
+      switch (U) {
+        case 3: launch_panelw_as<3, 2>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+        case 4: launch_panelw_as<4, 2>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+        case 5: launch_panelw_as<5, 2>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+        default: launch_panelw_as<6, 2>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s); break;
+      }
     }
-    hipError_t e3 = hipGetLastError();
-    if (e3 != hipSuccess) { set_last_error("spmv_panel3 launch", e3); return SPL_ERROR_device; }
+    hipError_t ew = hipGetLastError();
+    if (ew != hipSuccess) { set_last_error("spmv_panelw launch", ew); return SPL_ERROR_device; }
     return SPL_OK;
   }
-#define SPL_PNL(UU, KK)                                                                       \
-  do {                                                                                        \
-    if (PF) launch_panel_as<UU, KK, 1>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s);     \
-    else launch_panel_as<UU, KK, 0>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s);        \
-  } while (0)
+#define SPL_PNL(UU, KK) launch_panel_as<UU, KK>(m, b, (unsigned)nb, lds, d_x, d_y, accumulate, s)
   if (K == 1) {
     switch (U) {
       case 4: SPL_PNL(4, 1); break;

@@ -255,10 +255,11 @@ class DeviceMatrix(object):
         check("spl_matrix_build_blocked",
               lib().spl_matrix_build_blocked(self.handle, rows_per_panel, cols_log2, unroll))
 
-    def build_panel(self, rows_per_panel=0, cols_log2=0, unroll=0, kblocks=0, prefetch=0):
-        """the column-sorted panel image (csrc/spmv_panel.hip): order-free sums, 1e-10 contract"""
+    def build_panel(self, rows_per_panel=0, cols_log2=0, unroll=0, form=0):
+        """the column-sorted panel image (csrc/spmv_panel.hip): order-free sums, 1e-10 contract;
+        form 1 / 2: one chunk per load, 1 / 2 index blocks per phase; 4 / 5: paired storage (default)"""
         check("spl_matrix_build_panel",
-              lib().spl_matrix_build_panel(self.handle, rows_per_panel, cols_log2, unroll, kblocks, prefetch))
+              lib().spl_matrix_build_panel(self.handle, rows_per_panel, cols_log2, unroll, form))
 
     def set_spmv_order(self, order):
         """ORDER_REFERENCE (0, default): sums in the reference's order, bit-identical; ORDER_FREE (1):

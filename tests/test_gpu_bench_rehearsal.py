@@ -31,7 +31,10 @@ def _run(nproc, extra, chunks=None):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")]
-    cmd += ["--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra
+    cmd += ["--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    if "--order" not in extra:
+        cmd += ["--order", "reference"]  # bit-identical sums: the SHA-1 of y must not depend on the rank count
+    cmd += extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -69,3 +72,13 @@ def test_pipelined_exchange_forced(gpu):
             assert out["roofline"]["launches_per_step"] == chunks
         else:
             assert "one all-gather of y after the kernel" in out["config"]["workload"]
+
+
+def test_two_ranks_order_free(gpu):
+    """--order free (the default of bench.py): sums may differ at rounding level between launches, so y is
+    compared through its sum and 2-norm instead of its SHA-1"""
+    args = ["--rows", "400000", "--order", "free"]
+    one, two = _run(1, args), _run(2, args)
+    assert one["config"]["sum_order"] == two["config"]["sum_order"] == "free"
+    for k in ("y_sum", "y_norm2"):
+        assert abs(one[k] - two[k]) <= 1e-12 * abs(one[k])

@@ -18,19 +18,20 @@ def _run(torch, H, x):
     return y.cpu().numpy()
 
 
-@pytest.mark.parametrize("n,K,P,w,unroll,kblocks", [
-    (50_003, 20, 3000, 12, 4, 1), (50_003, 20, 3000, 12, 6, 2), (200_000, 20, 20479, 14, 0, 0),
+@pytest.mark.parametrize("n,K,P,w,unroll,form", [
+    # form 1 / 2: one chunk per load instruction, 1 / 2 index blocks per phase
+    (50_003, 20, 3000, 12, 4, 1), (50_003, 20, 3000, 12, 6, 2), (200_000, 20, 20479, 14, 0, 2),
     (131_072, 7, 8192, 17, 12, 2), (70_001, 40, 5000, 10, 10, 2), (1000, 3, 64, 4, 4, 1),
     (300_000, 20, 19000, 13, 8, 2),
-    # kblocks = 3: the three-stage kernel (gathers of phase i+1 issued before those of phase i are awaited)
-    (50_003, 20, 3000, 12, 4, 3), (300_000, 20, 19000, 13, 6, 3), (131_072, 7, 8192, 17, 5, 3),
-    (200_000, 20, 20479, 14, 7, 3), (1000, 3, 64, 4, 4, 3),
+    # form 4 / 5: paired storage (16-byte value loads), 1 / 2 index blocks per phase; unroll counts pairs
+    (50_003, 20, 3000, 12, 2, 4), (300_000, 20, 19000, 13, 4, 5), (131_072, 7, 8192, 17, 3, 4),
+    (200_000, 20, 20479, 14, 6, 5), (1000, 3, 64, 4, 2, 4), (200_000, 20, 20479, 14, 0, 0),
     # phases far longer than the register pipeline: the un-pipelined tail loop
-    (70_001, 40, 5000, 13, 4, 3), (70_001, 40, 5000, 13, 4, 1)])
-def test_panel_matches_oracle(gpu, pkg, O, n, K, P, w, unroll, kblocks):
+    (70_001, 40, 5000, 13, 3, 5), (70_001, 40, 5000, 13, 4, 1)])
+def test_panel_matches_oracle(gpu, pkg, O, n, K, P, w, unroll, form):
     torch = gpu
     H = pkg.DeviceMatrix.synthetic("random", n, K)
-    H.build_panel(P, w, unroll, kblocks)
+    H.build_panel(P, w, unroll, form)
     H.set_variant(16)
     assert H.spmv_kernel() == 16 and H.info()["blocked_rows"] == P
     rp, ci, v = H.export_csr()

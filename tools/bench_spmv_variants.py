@@ -3,7 +3,7 @@
 same device-resident matrix (HIP events on the launch stream) and check each against the
 reference-order result of the column-blocked kernel.  Specs, comma separated fields:
   blocked[:R:w:unroll]            column-blocked lockstep (reference order)
-  panel[:P:w:unroll:kblocks:pf]   column-sorted workgroup panels (order-free)
+  panel[:P:w:unroll:form]         column-sorted workgroup panels (order-free); form 1/2 chunk per load, 4/5 paired
   variant:<k>                     any other spl_matrix_set_variant code
 """
 import argparse
@@ -46,7 +46,7 @@ def main():
                 H.build_blocked(*(ints + [0, 0, 0])[:3])
                 H.set_variant(8)
             elif f[0] == "panel":
-                H.build_panel(*(ints + [0, 0, 0, 0, 0])[:5])
+                H.build_panel(*(ints + [0, 0, 0, 0])[:4])
                 H.set_variant(16)
             else:
                 H.set_variant(ints[0])
