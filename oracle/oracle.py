@@ -206,6 +206,14 @@ def csr_spmv_omp(rowptr, colidx, val, x, y):
     return y
 
 
+def csr_spmv_omp_timed(rowptr, colidx, val, x, y, reps=5):
+    """the fair CPU line of bench.py: arrays re-placed by parallel first touch, best of `reps` runs (seconds)"""
+    f = lib().orc_csr_spmv_omp_timed
+    f.restype = C.c_double
+    return float(f(C.c_int64(len(rowptr) - 1), C.c_int64(len(x)), _i(rowptr), _i(colidx), _D(val), _D(x), _D(y),
+                   C.c_int(reps)))
+
+
 def omp_threads():
     return int(lib().orc_omp_threads())
 

@@ -49,6 +49,7 @@ struct Symbolic {
   std::vector<int> perm;  // new -> old (reverse Cuthill-McKee: the band paths)
   std::vector<int> inv;   // old -> new
   std::vector<int> Ap;    // pattern check in numeric (UMFPACK_ERROR_different_pattern)
+  uint64_t ai_hash = 0;   // ... together with a hash of the row indices
   // nested-dissection tree of the multifrontal path, present when that path is the cheaper one
   std::shared_ptr<const mf::Tree> tree;
 };
@@ -59,6 +60,9 @@ struct Numeric {
   int n = 0, kl = 0, ku = 0, ldab = 1;
   int singular = 0;
   int nopiv = 0;  // 1: blocked factorisation without interchanges
+  // set when a refactorisation failed after the previous factors were released: the object holds no
+  // usable factors any more and every later solve returns an error instead of launching kernels
+  std::atomic<int> broken{0};
   // 1: the matrix is NOT diagonally dominant by columns and the no-interchange factors are a
   // speculation; solve checks the backward error it computes anyway and, if it is not at
   // rounding level, refactors with partial pivoting (under `mu`) and solves again
@@ -82,6 +86,22 @@ struct Numeric {
     if (mfact) mf_free(mfact);
   }
 };
+
+// 64-bit hash of the row indices: the second half of the pattern check in numeric (the pointers are
+// compared exactly; a pattern with the same column counts but other rows would be scattered with a
+// stale ordering, out of the band / the fronts)
+uint64_t hash_indices(const int *Ai, int64_t nnz) {
+  uint64_t h[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+  int64_t p = 0;
+  for (; p + 4 <= nnz; p += 4)
+    for (int u = 0; u < 4; ++u) {
+      h[u] ^= (uint64_t)(uint32_t)Ai[p + u];
+      h[u] *= 0x100000001B3ull;
+      h[u] ^= h[u] >> 29;
+    }
+  for (; p < nnz; ++p) { h[0] ^= (uint64_t)(uint32_t)Ai[p]; h[0] *= 0x100000001B3ull; h[0] ^= h[0] >> 29; }
+  return (h[0] * 31 + h[1]) * 31 + (h[2] * 31 + h[3]) + (uint64_t)nnz;
+}
 
 // ---- reverse Cuthill-McKee on the pattern of A + A^T (host) --------------------------------
 void rcm_order(int n, const int *Ap, const int *Ai, std::vector<int> &perm) {
@@ -477,22 +497,35 @@ void factor_multifrontal(Numeric *N, hipStream_t s) {
 // partial pivoting.  Throws DeviceError; sets N->singular.
 void factor_band(Numeric *N, bool nopiv, hipStream_t s) {
   const int n = N->n;
-  if (N->mfact || N->tree) {  // leaving the multifrontal path: the band paths use the RCM ordering
-    if (N->mfact) { mf_free(N->mfact); N->mfact = nullptr; }
-    N->tree.reset();
-    set_ordering(N, N->band_perm, N->band_inv, s);
+  // Will the band fit?  Decided BEFORE anything of the current factors is released: a band that does not
+  // fit (a large 3-D matrix whose speculation failed) must leave the object as it was — its speculative
+  // factors still answer solves, which then report the error again instead of reading freed memory.
+  const int ldab_new = nopiv ? band_nopiv_ldab(N->kl, N->ku) : (2 * N->kl + N->ku + 1);
+  const size_t band_elems = (size_t)ldab_new * (size_t)n;
+  {
+    size_t held = (N->AB.n + N->blkinv.n) * sizeof(double);
+    if (N->mfact && N->tree) held += mf_device_bytes(*N->tree);
+    const size_t avail = device_free_bytes() + held;
+    if (band_elems * sizeof(double) > avail - avail / 8) throw DeviceError{SPL_ERROR_out_of_memory};  // too wide
   }
-  N->nopiv = nopiv ? 1 : 0;
-  N->ldab = nopiv ? band_nopiv_ldab(N->kl, N->ku) : (2 * N->kl + N->ku + 1);
-  const size_t band_elems = (size_t)N->ldab * (size_t)n;
-  N->AB.release();
-  N->blkinv.release();
-  const size_t free_b = device_free_bytes();
-  if (band_elems * sizeof(double) > free_b - free_b / 8) throw DeviceError{SPL_ERROR_out_of_memory};  // too wide
-  N->AB.alloc(band_elems);
-  SPL_HIP(hipMemsetAsync(N->AB.get(), 0, band_elems * sizeof(double), s));
+  try {
+    if (N->mfact || N->tree) {  // leaving the multifrontal path: the band paths use the RCM ordering
+      if (N->mfact) { mf_free(N->mfact); N->mfact = nullptr; }
+      N->tree.reset();
+      set_ordering(N, N->band_perm, N->band_inv, s);
+    }
+    N->nopiv = nopiv ? 1 : 0;
+    N->ldab = ldab_new;
+    N->AB.release();
+    N->blkinv.release();
+    N->AB.alloc(band_elems);
+    SPL_HIP(hipMemsetAsync(N->AB.get(), 0, band_elems * sizeof(double), s));
+    if (nopiv) N->blkinv.alloc(band_nopiv_inverse_elems(n));
+  } catch (...) {
+    N->broken = 1;  // the old factors are gone and the new ones could not be built
+    throw;
+  }
   if (nopiv) {
-    N->blkinv.alloc(band_nopiv_inverse_elems(n));
     N->singular = band_nopiv_factor(n, N->kl, N->ku, N->ldab, N->AB.get(), N->blkinv.get(), N->At->rowptr.get(),
                                     N->At->colidx.get(), N->At->val.get(), N->inv.get(), s);
     return;
@@ -545,10 +578,11 @@ int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
   int st = validate_host_csc(n_row, n_col, Ap, Ai);
   if (st != UMFPACK_OK) return st;
   try {
-    Symbolic *S = new Symbolic();
+    std::unique_ptr<Symbolic> S(new Symbolic());
     S->n = n_col;
     S->nnz = Ap[n_col];
     S->Ap.assign(Ap, Ap + n_col + 1);
+    S->ai_hash = hash_indices(Ai, S->nnz);
     // The two orderings are independent host work: for anything that is not tiny the nested
     // dissection runs on its own thread(s) while this one does the band ordering.
     // Multifrontal or band?  The band factorisation costs about 2 n kl ku flops and n (kl+ku+1)
@@ -601,10 +635,12 @@ int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
       const double t_tree = 2.5e-3 + T->flops / 2e13;
       if (force_mf || t_tree < t_band) S->tree = T;
     }
-    *SymbolicOut = S;
+    *SymbolicOut = S.release();
     return UMFPACK_OK;
   } catch (const std::bad_alloc &) {
     return UMFPACK_ERROR_out_of_memory;
+  } catch (...) {  // e.g. std::system_error from a thread that could not be started: never across the C ABI
+    return UMFPACK_ERROR_internal_error;
   }
 }
 
@@ -617,7 +653,8 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
   if (!S) return UMFPACK_ERROR_invalid_Symbolic_object;
   if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;
   const int n = S->n;
-  if (Ap[n] != S->nnz || !std::equal(S->Ap.begin(), S->Ap.end(), Ap)) return UMFPACK_ERROR_different_pattern;
+  if (Ap[n] != S->nnz || !std::equal(S->Ap.begin(), S->Ap.end(), Ap) || hash_indices(Ai, S->nnz) != S->ai_hash)
+    return UMFPACK_ERROR_different_pattern;
   Numeric *N = nullptr;
   try {
     int ndev = 0;
@@ -687,6 +724,9 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
   } catch (const std::bad_alloc &) {
     delete N;
     return UMFPACK_ERROR_out_of_memory;
+  } catch (...) {
+    delete N;
+    return UMFPACK_ERROR_internal_error;
   }
 }
 
@@ -697,6 +737,7 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
 // pass over the factors.
 static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B) {
   const int n = N->n;
+  if (N->broken) return UMFPACK_ERROR_invalid_Numeric_object;  // a failed refactorisation left no factors
   try {
     DeviceGuard g(N->device);
     hipStream_t s = nullptr;
@@ -807,6 +848,8 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B)
     return e.status == SPL_ERROR_out_of_memory ? UMFPACK_ERROR_out_of_memory : UMFPACK_ERROR_internal_error;
   } catch (const std::bad_alloc &) {
     return UMFPACK_ERROR_out_of_memory;
+  } catch (...) {
+    return UMFPACK_ERROR_internal_error;
   }
 }
 

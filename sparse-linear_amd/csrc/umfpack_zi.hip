@@ -99,6 +99,8 @@ int umfpack_zi_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
     return st;
   } catch (const std::bad_alloc &) {
     return UMFPACK_ERROR_out_of_memory;
+  } catch (...) {  // nothing may cross the C ABI
+    return UMFPACK_ERROR_internal_error;
   }
 }
 
@@ -132,6 +134,8 @@ int umfpack_zi_numeric(const int Ap[], const int Ai[], const double Ax[], const 
     return st;
   } catch (const std::bad_alloc &) {
     return UMFPACK_ERROR_out_of_memory;
+  } catch (...) {  // nothing may cross the C ABI
+    return UMFPACK_ERROR_internal_error;
   }
 }
 
@@ -166,6 +170,8 @@ int umfpack_zi_solve(int sys, const int Ap[], const int Ai[], const double Ax[],
     return st;
   } catch (const std::bad_alloc &) {
     return UMFPACK_ERROR_out_of_memory;
+  } catch (...) {  // nothing may cross the C ABI
+    return UMFPACK_ERROR_internal_error;
   }
 }
 
@@ -204,6 +210,8 @@ int spl_umfpack_zi_solve_many(int sys, const int Ap[], const int Ai[], const dou
     return st;
   } catch (const std::bad_alloc &) {
     return UMFPACK_ERROR_out_of_memory;
+  } catch (...) {  // nothing may cross the C ABI
+    return UMFPACK_ERROR_internal_error;
   }
 }
 

@@ -68,7 +68,10 @@ class RowBlockSpMV(object):
             self.pad = torch.zeros(world * self.maxlen, dtype=dtype, device=device)
 
     def step(self, x):
-        """one SpMV over the whole matrix; returns the full y on every rank"""
+        """one SpMV over the whole matrix; returns the full y on every rank.  x must not alias the returned
+        y (``x = op.step(x)`` does): the kernel / the gather would overwrite the x it is still reading —
+        pass a copy (``op.step(y.clone())``) or keep two operators."""
+        _refuse_alias(x, self.y_full)
         self.local_spmv(x, self.y_local)
         if self.world == 1:
             return self.y_full
@@ -81,6 +84,19 @@ class RowBlockSpMV(object):
                 self.y_full[self.bounds[p]:self.bounds[p + 1]] = \
                     self.pad[p * self.maxlen: p * self.maxlen + self.sizes[p]]
         return self.y_full
+
+
+def _refuse_alias(x, y_full):
+    """x sharing storage with the operator's own y would be overwritten while it is being read"""
+    if x is None:
+        return
+    try:
+        same = x.untyped_storage().data_ptr() == y_full.untyped_storage().data_ptr()
+    except AttributeError:  # not a torch tensor (CPU test doubles): compare the objects
+        same = x is y_full
+    if same:
+        raise ValueError("step(x): x aliases the operator's result vector y_full; pass a copy "
+                         "(x = op.step(x).clone()) — the product would overwrite the x it is reading")
 
 
 def pipelined_piece_bounds(n, world, chunks):
@@ -130,6 +146,9 @@ class PipelinedRowBlockSpMV(object):
         return self.bounds[q], self.bounds[q + 1]
 
     def step(self, x):
+        """as RowBlockSpMV.step; x must not alias the returned y either (the gather of chunk c would land in
+        y_full while later chunks still read it as x)"""
+        _refuse_alias(x, self.y_full)
         if self.world == 1:
             for c in range(self.chunks):
                 self.local_spmvs[c](x, self.y_local[c])

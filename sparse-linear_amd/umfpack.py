@@ -155,6 +155,13 @@ def linearSolve_(fact, mode, mat, b):
     """solve with existing factors (Umfpack.hs:87-102); returns the solution vector"""
     L = _declare()
     nr, nc, ap, ai, ax = mat._tuple32()
+    # the C side copies nrows (2 nrows) doubles out of b: a short vector would be a heap over-read, and real
+    # factors with a complex matrix (or the reverse) would be read with the wrong dimension
+    if np.shape(b) != (mat.nrows,):
+        raise UmfpackError("linearSolve_: right-hand side has shape %s, the matrix has %d rows" % (np.shape(b), mat.nrows))
+    if bool(fact.complex) != bool(mat.is_complex):
+        raise UmfpackError("linearSolve_: %s factors used with a %s matrix"
+                           % ("complex" if fact.complex else "real", "complex" if mat.is_complex else "real"))
     if mat.is_complex:
         b = np.ascontiguousarray(b, dtype=np.complex128)
         soln = np.zeros(mat.ncols, dtype=np.complex128)
@@ -179,6 +186,9 @@ def linearSolveMany_(fact, mode, mat, bs):
     if k == 0:
         return []
     nr, nc, ap, ai, ax = mat._tuple32()
+    if bool(fact.complex) != bool(mat.is_complex):
+        raise UmfpackError("linearSolveMany_: %s factors used with a %s matrix"
+                           % ("complex" if fact.complex else "real", "complex" if mat.is_complex else "real"))
     dt = np.complex128 if mat.is_complex else np.float64
     B = np.empty((k, mat.nrows), dtype=dt)  # row c = right-hand side c: column-major n x k for the C side
     for c, b in enumerate(bs):

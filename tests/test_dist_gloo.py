@@ -202,3 +202,13 @@ def test_bounds_helpers():
         pkg.dist.pipelined_piece_bounds(25, 2, 3)
     one = pkg.dist.PipelinedRowBlockSpMV(12, 0, 1, 3, [lambda x, y, c=c: y.fill_(c) for c in range(3)], "cpu")
     assert one.step(None).tolist() == [0.0] * 4 + [1.0] * 4 + [2.0] * 4  # a single rank writes y in place
+    # x = op.step(x) would hand the operator its own result vector as the next x: refused (the kernel, or
+    # the gather of an earlier chunk, would overwrite the x that is still being read)
+    with pytest.raises(ValueError):
+        one.step(one.y_full)
+    with pytest.raises(ValueError):
+        one.step(one.y_full[4:])
+    plain = pkg.dist.RowBlockSpMV(12, [0, 12], 0, 1, lambda x, y: y.fill_(1.0), "cpu")
+    with pytest.raises(ValueError):
+        plain.step(plain.step(None))
+    assert plain.step(plain.step(None).clone()).tolist() == [1.0] * 12

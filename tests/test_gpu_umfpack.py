@@ -379,3 +379,34 @@ def test_arrow_matrix_takes_the_tree(gpu, pkg, O):
     for mode, op in ((pkg.umfpack.UmfpackNormal, A), (pkg.umfpack.UmfpackTrans, A.T)):
         x = pkg.umfpack.linearSolve_(fact, mode, M, op @ xs)
         assert O.count_not_close(x, xs, 1e-10) == 0
+
+
+def test_numeric_rejects_other_row_indices(gpu, pkg):
+    """same column counts, different row indices: UMFPACK_ERROR_different_pattern (-11), not a scatter with
+    a stale ordering (only Ap used to be compared)"""
+    import ctypes as C
+    U = pkg.umfpack
+    L = U._declare()
+    ap = np.array([0, 2, 4, 6], dtype=np.int32)
+    ai = np.array([0, 1, 1, 2, 0, 2], dtype=np.int32)
+    ax = np.array([4.0, 1.0, 4.0, 1.0, 1.0, 4.0])
+    sym = C.c_void_p()
+    assert L.umfpack_di_symbolic(3, 3, U.p_i32(ap), U.p_i32(ai), U.p_f64(ax), C.byref(sym), None, None) == 0
+    num = C.c_void_p()
+    ai2 = np.array([0, 2, 0, 1, 1, 2], dtype=np.int32)  # same counts per column, other rows
+    assert L.umfpack_di_numeric(U.p_i32(ap), U.p_i32(ai2), U.p_f64(ax), sym, C.byref(num), None, None) == -11
+    assert not num.value
+    assert L.umfpack_di_numeric(U.p_i32(ap), U.p_i32(ai), U.p_f64(ax), sym, C.byref(num), None, None) == 0
+    L.umfpack_di_free_numeric(C.byref(num))
+    L.umfpack_di_free_symbolic(C.byref(sym))
+
+
+def test_linear_solve_checks_rhs_length_and_type(gpu, pkg):
+    U = pkg.umfpack
+    A = pkg.ident(5)
+    fact = U.factor(A, U.analyze(A))
+    with pytest.raises(U.UmfpackError):
+        U.linearSolve_(fact, U.UmfpackNormal, A, np.ones(4))
+    Z = pkg.Matrix(5, 5, A.pointers, A.indices, A.values.astype(np.complex128))
+    with pytest.raises(U.UmfpackError):
+        U.linearSolve_(fact, U.UmfpackNormal, Z, np.ones(5, dtype=np.complex128))
