@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void products_kernel(Csc A, Csc B, int64_t nco
                                                        int64_t *__restrict__ medium_list,
                                                        int64_t *__restrict__ xlarge_list,
                                                        int64_t *__restrict__ dense_list,
-                                                       int *__restrict__ list_counts) {
+                                                       int *__restrict__ list_counts, int ordered) {
   // 8 lanes per column of B: the extents of the selected columns of A are independent loads
   const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
   const int sub = threadIdx.x & 7;
@@ -91,6 +91,8 @@ __global__ __launch_bounds__(256) void products_kernel(Csc A, Csc B, int64_t nco
   if (owner) {
     nprod[j] = n;
     bin = bin_of(n, qe - qs);
+    // ordered form: columns its own kernel handles (<= 2048 products, <= 256 entries of B) are not listed
+    if (ordered && n <= 2048 && qe - qs <= 256) bin = n == 0 ? 0 : 1;
     if (bin >= 2) pos = atomicAdd(&local_count[bin - 2], 1);
   }
   __syncthreads();
@@ -446,6 +448,499 @@ __global__ __launch_bounds__(256) void compact_columns_kernel(int64_t ncols, con
   }
 }
 
+
+// ---- ordered single-pass form -------------------------------------------------------------------------
+// The single-pass form above writes every column at its upper-bound slot and compacts afterwards: one more
+// read and write of the whole result (15 % of C4 although only 0.05 % of its products merge).  Here every
+// column is written straight to its final place: the columns are handed out IN ORDER to persistent
+// workgroups (a ticket counter), a column's length is known once its keys are sorted, and its offset is the
+// sum of the lengths before it, obtained by a decoupled look-back over per-column status words
+// (flag + value in one 64-bit word; a column publishes its length at once, looks back until it meets a
+// predecessor that already knows its own inclusive prefix, then publishes its own).  A workgroup only ever
+// waits for columns with smaller tickets, all of which are held by resident workgroups.
+//
+// The rocprofv3 counters of the compacting form (profiles/r02_spgemm_c4_before_*) show its main kernel to
+// be bound by instruction issue, not by memory: 8 450 vector + 5 100 scalar instructions per wavefront
+// and column of 1 024 products, most of them in the five merge levels and in the binary search by which a
+// run head finds the operands of every product again.  Here
+//   * a thread expands a CONSECUTIVE run of products (one binary search, then a walk), a*b is computed
+//     then and kept in LDS, so the fold is a plain sum over LDS in sorted order;
+//   * the keys (row << 11 | t) are sorted by ONE counting pass over buckets of row ranges (CAP/2
+//     buckets, rank inside a bucket from the returning LDS atomic, exclusive scan, scatter) followed by an
+//     insertion sort inside each bucket (a thread per bucket; about two keys per bucket when the rows are
+//     spread evenly).  A bucket that outgrows kOrdBucketLimit (rows crowded into a narrow range) sends
+//     the column through the merge tree instead — same result, the old cost.
+// Order of the sums is unchanged: equal rows are adjacent in ascending t = ascending k, folded left to
+// right from 0 with separately rounded multiplies and adds (Sparse.hs:699) — bit-identical values.
+// Columns beyond the LDS budget of this kernel (more than 2 048 products or 256 entries in the column of
+// B) are computed beforehand by the kernels above into scratch slots; their owner here only copies them.
+constexpr int kOrdTB = 11;                         // tie-break bits of the packed key: t < 2048
+constexpr int kOrdCap = 2048, kOrdNb = 256;        // column handled by a whole workgroup
+constexpr int kOrdWaveCap = 256, kOrdWaveNb = 64;  // column handled by one wavefront (4 per workgroup)
+constexpr int kOrdBucketLimit = 24;
+constexpr int kOrdMaxRowBits = 32 - kOrdTB;        // rows must fit the packed (unsigned) 32-bit key
+
+template <int CAP, int NBCAP>
+struct OrdLds {
+  static constexpr int kBuckets = CAP / 2;
+  static constexpr size_t kb_bytes = NBCAP * sizeof(double);
+  static constexpr size_t val_bytes = CAP * sizeof(double);
+  static constexpr size_t key_bytes = CAP * sizeof(unsigned);
+  static constexpr size_t start_bytes = NBCAP * sizeof(int);
+  static constexpr size_t off_bytes = (NBCAP + 8) * sizeof(int);
+  static constexpr size_t hist_bytes = (kBuckets + 8) * sizeof(int);
+  static constexpr size_t scratch_bytes = 16 * sizeof(int);
+  static constexpr size_t total = kb_bytes + val_bytes + 2 * key_bytes + start_bytes + off_bytes + hist_bytes + scratch_bytes;
+};
+
+// status word of the look-back chain: bits 62-63 = 0 nothing yet, 1 the column's own length, 2 inclusive prefix
+constexpr unsigned long long kOrdFlagAgg = 1ull << 62, kOrdFlagPrefix = 2ull << 62, kOrdValueMask = (1ull << 62) - 1ull;
+
+// exclusive prefix of column j (sum of the lengths of all columns before it); called by ONE whole wavefront,
+// result wave-uniform.  Publishes the column's own length first and its inclusive prefix last.
+__device__ inline int64_t ord_chain(unsigned long long *__restrict__ status, int64_t j, int64_t count) {
+  const int lane = threadIdx.x & 63;
+  if (j == 0) {
+    if (lane == 0) __hip_atomic_store(status, kOrdFlagPrefix | (unsigned long long)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0;
+  }
+  if (lane == 0) __hip_atomic_store(status + j, kOrdFlagAgg | (unsigned long long)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int64_t sum = 0;
+  int64_t p = j - 1;  // nearest predecessor not yet accounted for
+  // The nearest predecessor took its ticket just before this column and is usually the last to publish: one
+  // lane polls it, asleep in between (64 lanes polling from a thousand waiting wavefronts take issue slots and
+  // L2 requests from the wavefronts they are waiting for); the wide look-back starts once it is there.
+  if (lane == 0) {
+    while ((__hip_atomic_load(status + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 62) == 0) __builtin_amdgcn_s_sleep(32);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (;;) {
+    const int64_t q = p - lane;
+    unsigned long long w = 0;
+    if (q >= 0) w = __hip_atomic_load(status + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned flag = (unsigned)(w >> 62);
+    const unsigned long long not_ready = __ballot(q >= 0 && flag == 0);
+    const unsigned long long is_prefix = __ballot(q >= 0 && flag == 2);
+    // lanes are ordered by distance: use everything up to the nearest prefix, provided nothing nearer is missing
+    const int first_missing = not_ready ? __builtin_ctzll(not_ready) : 64;
+    const int first_prefix = is_prefix ? __builtin_ctzll(is_prefix) : 64;
+    const int upto = first_prefix < first_missing ? first_prefix + 1 : first_missing;  // lanes [0, upto) are usable
+    long long part = (lane < upto && q >= 0) ? (long long)(w & kOrdValueMask) : 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+    sum += part;
+    if (first_prefix < first_missing) break;               // met a predecessor that knows everything before it
+    if (p - upto < 0 && first_missing == 64) break;        // ran past column 0 (cannot happen: column 0 publishes a prefix)
+    p -= upto;
+    if (first_missing < 64 && upto == 0) __builtin_amdgcn_s_sleep(16);  // the nearest one is not there yet
+  }
+  if (lane == 0)
+    __hip_atomic_store(status + j, kOrdFlagPrefix | (unsigned long long)(sum + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return sum;
+}
+
+// merge tree over the nb ascending runs laid out by the expansion (packed keys only): the fallback sort
+template <int NT, int CAP>
+__device__ inline unsigned *ord_merge_tree(unsigned *key, unsigned *key2, const int *koff, int nb, int np, int tid) {
+  constexpr int E = CAP / NT + 1;
+  unsigned *src = key, *dst = key2;
+  for (int width = 1; width < nb; width <<= 1) {
+    for (int c0 = tid * E; c0 < np; c0 += NT * E) {
+      int pos = c0;
+      const int end = min(np, c0 + E);
+      while (pos < end) {
+        int lq = 0, hq = nb - 1;
+        while (lq < hq) {
+          const int mid = (lq + hq + 1) >> 1;
+          if (koff[mid] <= pos) lq = mid; else hq = mid - 1;
+        }
+        const int g0 = lq & ~(2 * width - 1);
+        const int a0 = koff[g0], a1 = koff[min(nb, g0 + width)], b1 = koff[min(nb, g0 + 2 * width)];
+        const int d = pos - a0;
+        int lo = max(0, d - (b1 - a1)), hi = min(d, a1 - a0);
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (src[a0 + mid] <= src[a1 + d - mid - 1]) lo = mid + 1; else hi = mid;
+        }
+        int ia = a0 + lo, ib = a1 + d - lo;
+        const int stop = min(end, b1);
+        unsigned ka = ia < a1 ? src[ia] : 0xffffffffu, kb2 = ib < b1 ? src[ib] : 0xffffffffu;
+        for (; pos < stop; ++pos) {
+          if (ia < a1 && (ib >= b1 || ka <= kb2)) {
+            dst[pos] = ka;
+            ++ia;
+            ka = ia < a1 ? src[ia] : 0xffffffffu;
+          } else {
+            dst[pos] = kb2;
+            ++ib;
+            kb2 = ib < b1 ? src[ib] : 0xffffffffu;
+          }
+        }
+      }
+    }
+    group_sync<NT>();
+    unsigned *tmp = src;
+    src = dst;
+    dst = tmp;
+  }
+  return src;
+}
+
+// One column of C, written at its final place.  NT threads cooperate (64: one wavefront, wave-level
+// synchronisation only; 256: the workgroup); `chain_wave`: this thread belongs to the wavefront that
+// walks the look-back chain (NT = 256: wavefront 0; the result travels through `scratch`).
+template <int NT, int CAP, int NBCAP>
+__device__ inline void ord_column(const Csc &A, const Csc &B, int64_t j, int np, int bucket_shift, unsigned char *lds, int tid,
+                                  unsigned long long *__restrict__ status, int64_t *__restrict__ Cp, int *__restrict__ Ci,
+                                  double *__restrict__ Cx, unsigned long long *__restrict__ stamps) {
+  typedef OrdLds<CAP, NBCAP> L;
+  // SPL_SPGEMM_STAMPS=1 (diagnostic): cycles of thread 0 per phase, summed over columns
+  // (accumulated in registers of thread 0 and flushed once per workgroup: an atomic per phase would serialise
+  // a million columns on six addresses and distort what it measures)
+  unsigned long long t_prev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto stamp = [&](int phase) {
+    if (stamps && tid == 0) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      stamps[phase] += now - t_prev;
+      t_prev = now;
+    }
+  };
+  constexpr int NBK = L::kBuckets;
+  double *kb = reinterpret_cast<double *>(lds);
+  double *vals = kb + NBCAP;
+  unsigned *key = reinterpret_cast<unsigned *>(lds + L::kb_bytes + L::val_bytes);
+  unsigned *key2 = key + CAP;
+  int *kstart = reinterpret_cast<int *>(key2 + CAP);
+  int *koff = kstart + NBCAP;
+  int *hist = koff + NBCAP + 8;
+  int *scratch = hist + NBK + 8;
+  const int lane = tid & 63;
+  const int qs = B.p[j];
+  const int nb = B.p[j + 1] - qs;
+
+  // (1) stage the column of B and the extents of the selected columns of A; clear the histogram
+  for (int q = tid; q < nb; q += NT) {
+    const int k = B.i[qs + q];
+    const int s = A.p[k];
+    kstart[q] = s;
+    koff[q] = A.p[k + 1] - s;
+    kb[q] = B.x[qs + q];
+  }
+  for (int b = tid; b < NBK + 1; b += NT) hist[b] = 0;
+  if (tid == 0) scratch[8] = 0;  // overflow flag
+  group_sync<NT>();
+  {  // exclusive prefix sum of the extents
+    const int chunk = (nb + NT - 1) / NT;
+    const int lo = tid * chunk, hi = min(nb, lo + chunk);
+    int sum = 0;
+    for (int q = lo; q < hi; ++q) sum += koff[q];
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (NT > 64) {
+      if (lane == 63) scratch[tid >> 6] = incl;
+      __syncthreads();
+      int woff = 0;
+      for (int wv = 0; wv < (tid >> 6); ++wv) woff += scratch[wv];
+      incl += woff;
+      __syncthreads();
+    }
+    int run = incl - sum;
+    for (int q = lo; q < hi; ++q) {
+      const int l = koff[q];
+      koff[q] = run;
+      run += l;
+    }
+    if (tid == NT - 1) koff[nb] = run;  // == np
+  }
+  group_sync<NT>();
+  stamp(0);
+
+  // (2) expand a consecutive run of products per thread: one search, then a walk; all loads issued together
+  constexpr int PER = CAP / NT;
+  const int per = (np + NT - 1) / NT;  // <= PER
+  unsigned myk[PER];
+  int myrank[PER];
+  {
+    const int t0 = tid * per;
+    int q = 0;
+    if (t0 < np) {
+      int lo = 0, hi = nb - 1;  // largest q with koff[q] <= t0
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (koff[mid] <= t0) lo = mid; else hi = mid - 1;
+      }
+      q = lo;
+    }
+    int pp[PER], qq[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int t = t0 + u;
+      pp[u] = -1;
+      qq[u] = 0;
+      if (u < per && t < np) {
+        while (t >= koff[q + 1]) ++q;  // runs may be empty: skip them
+        pp[u] = kstart[q] + (t - koff[q]);
+        qq[u] = q;
+      }
+    }
+    int rows[PER];
+    double av[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      rows[u] = pp[u] >= 0 ? A.i[pp[u]] : 0;
+      av[u] = pp[u] >= 0 ? A.x[pp[u]] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      myk[u] = 0xffffffffu;
+      myrank[u] = 0;
+      if (pp[u] >= 0) {
+        const int t = t0 + u;
+        myk[u] = ((unsigned)rows[u] << kOrdTB) | (unsigned)t;
+        key[t] = myk[u];
+        vals[t] = av[u] * kb[qq[u]];  // a * b, rounded once (Sparse.hs:699)
+        myrank[u] = atomicAdd(&hist[rows[u] >> bucket_shift], 1);
+      }
+    }
+  }
+  group_sync<NT>();
+  stamp(1);
+
+  // (3) exclusive scan of the histogram (NBK buckets, NBK / NT consecutive ones per thread)
+  {
+    constexpr int BPT = (NBK + NT - 1) / NT;
+    const int b0 = tid * BPT;
+    int cnt[BPT], sum = 0, big = 0;
+#pragma unroll
+    for (int u = 0; u < BPT; ++u) {
+      cnt[u] = b0 + u < NBK ? hist[b0 + u] : 0;
+      sum += cnt[u];
+      big |= cnt[u] > kOrdBucketLimit;
+    }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (NT > 64) {
+      if (lane == 63) scratch[tid >> 6] = incl;
+      __syncthreads();
+      int woff = 0;
+      for (int wv = 0; wv < (tid >> 6); ++wv) woff += scratch[wv];
+      incl += woff;
+      __syncthreads();
+    }
+    int run = incl - sum;
+#pragma unroll
+    for (int u = 0; u < BPT; ++u)
+      if (b0 + u < NBK) { hist[b0 + u] = run; run += cnt[u]; }
+    if (tid == NT - 1) hist[NBK] = np;
+    if (big) scratch[8] = 1;
+  }
+  group_sync<NT>();
+  stamp(2);
+  const bool overflow = scratch[8] != 0;
+  const unsigned *skeys;
+  if (!overflow) {
+    // (4) scatter to the bucket ranges, then sort inside each bucket (a thread per bucket)
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+      if (myk[u] != 0xffffffffu) key2[hist[(myk[u] >> kOrdTB) >> bucket_shift] + myrank[u]] = myk[u];
+    group_sync<NT>();
+    for (int b = tid; b < NBK; b += NT) {
+      const int s = hist[b], e = hist[b + 1];
+      for (int i = s + 1; i < e; ++i) {
+        const unsigned k = key2[i];
+        int h = i - 1;
+        while (h >= s && key2[h] > k) { key2[h + 1] = key2[h]; --h; }
+        key2[h + 1] = k;
+      }
+    }
+    group_sync<NT>();
+    skeys = key2;
+  } else {
+    skeys = ord_merge_tree<NT, CAP>(key, key2, koff, nb, np, tid);
+  }
+  stamp(3);
+
+  // (5) run heads: count, chain, write
+  int count = 0;
+  for (int t0 = 0; t0 < np; t0 += NT) {
+    const int t = t0 + tid;
+    const bool head = t < np && (t == 0 || (skeys[t] >> kOrdTB) != (skeys[t - 1] >> kOrdTB));
+    count += __popcll(__ballot(head));
+  }
+  if (NT > 64) {  // per-wavefront counts -> workgroup total
+    if (lane == 0) scratch[tid >> 6] = count;
+    __syncthreads();
+    count = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    __syncthreads();
+  }
+  int64_t base;
+  if (NT > 64) {
+    if ((tid >> 6) == 0) {
+      const int64_t e = ord_chain(status, j, count);
+      if (lane == 0) { scratch[10] = (int)(e & 0xffffffffll); scratch[11] = (int)(e >> 32); }
+    }
+    __syncthreads();
+    base = ((int64_t)scratch[11] << 32) | (int64_t)(unsigned)scratch[10];
+  } else {
+    base = ord_chain(status, j, count);
+  }
+  if (tid == 0) Cp[j] = base;
+  stamp(4);
+  int running = 0;
+  for (int t0 = 0; t0 < np; t0 += NT) {
+    const int t = t0 + tid;
+    int row = 0;
+    bool head = false;
+    if (t < np) {
+      row = (int)(skeys[t] >> kOrdTB);
+      head = t == 0 || (int)(skeys[t - 1] >> kOrdTB) != row;
+    }
+    const unsigned long long m = __ballot(head);
+    int off = running + __popcll(m & ((1ull << lane) - 1ull));
+    int total = __popcll(m);
+    if (NT > 64) {
+      if (lane == 0) scratch[tid >> 6] = total;
+      __syncthreads();
+      total = 0;
+      for (int wv = 0; wv < NT / 64; ++wv) {
+        if (wv < (tid >> 6)) off += scratch[wv];
+        total += scratch[wv];
+      }
+      __syncthreads();
+    }
+    if (head) {
+      double acc = 0.0;  // SG.reset 0
+      for (int u = t; u < np; ++u) {
+        const unsigned k = skeys[u];
+        if ((int)(k >> kOrdTB) != row) break;
+        acc = acc + vals[k & ((1u << kOrdTB) - 1u)];  // c + a * b in ascending k
+      }
+      Ci[base + off] = row;
+      Cx[base + off] = acc;
+    }
+    running += total;
+  }
+  group_sync<NT>();  // the LDS image is reused by the next column
+  stamp(5);
+}
+
+// column classes of the ordered form
+__global__ __launch_bounds__(256) void ord_classify_kernel(Csc B, int64_t ncolsB, const int64_t *__restrict__ nprod,
+                                                           unsigned char *__restrict__ cls, int64_t *__restrict__ heavy_prod) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ncolsB) return;
+  const int64_t np = nprod[j];
+  const int nb = B.p[j + 1] - B.p[j];
+  const int c = np == 0 ? 0 : (np <= kOrdWaveCap && nb <= kOrdWaveNb) ? 1 : (np <= kOrdCap && nb <= kOrdNb) ? 2 : 3;
+  cls[j] = (unsigned char)c;
+  heavy_prod[j] = c == 3 ? np : 0;
+}
+
+// Tasks of the ordered kernel, in column order: an aligned tile of four light columns (classes 0 / 1: a
+// wavefront each, in parallel) is ONE task; every column of any other tile is a task of its own.  A
+// workgroup must never hold several chain elements that it processes one after the other: the length of
+// its last column would only be known after the earlier ones were WRITTEN, which waits for the columns
+// before them — the whole product would serialise along that chain.
+__global__ __launch_bounds__(256) void ord_task_count_kernel(int64_t ncolsB, const unsigned char *__restrict__ cls,
+                                                             int *__restrict__ ntasks) {
+  const int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t j0 = tile * 4;
+  if (j0 >= ncolsB) return;
+  bool light = true;
+  int n = 0;
+  for (int w = 0; w < 4 && j0 + w < ncolsB; ++w) { light = light && cls[j0 + w] <= 1; ++n; }
+  ntasks[tile] = light ? 1 : n;
+}
+__global__ __launch_bounds__(256) void ord_task_fill_kernel(int64_t ncolsB, const unsigned char *__restrict__ cls,
+                                                            const int64_t *__restrict__ task_off,
+                                                            int64_t *__restrict__ tasks) {
+  const int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t j0 = tile * 4;
+  if (j0 >= ncolsB) return;
+  const int64_t o = task_off[tile];
+  bool light = true;
+  int n = 0;
+  for (int w = 0; w < 4 && j0 + w < ncolsB; ++w) { light = light && cls[j0 + w] <= 1; ++n; }
+  if (light) { tasks[o] = ~j0; return; }  // a tile of light columns: one task
+  for (int w = 0; w < n; ++w) tasks[o + w] = j0 + w;
+}
+
+__global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64_t ncolsB, int bucket_shift_wave,
+                                                             int bucket_shift_group, const int64_t *__restrict__ nprod,
+                                                             const unsigned char *__restrict__ cls,
+                                                             const int64_t *__restrict__ heavy_slot,
+                                                             const int *__restrict__ heavy_count,
+                                                             const int *__restrict__ Ti, const double *__restrict__ Tx,
+                                                             unsigned long long *__restrict__ status,
+                                                             unsigned long long *__restrict__ ticket,
+                                                             const int64_t *__restrict__ tasks, int64_t ntasks,
+                                                             int64_t *__restrict__ Cp, int *__restrict__ Ci,
+                                                             double *__restrict__ Cx, unsigned long long *__restrict__ stamps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ long long s_tile;
+  __shared__ long long s_base;
+  typedef OrdLds<kOrdWaveCap, kOrdWaveNb> LW;
+  constexpr size_t wave_bytes = (LW::total + 15) / 16 * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long acc_stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long *const local_stamps = stamps ? acc_stamps : nullptr;
+  for (;;) {
+    if (tid == 0) s_tile = (long long)atomicAdd(ticket, 1ull);
+    __syncthreads();
+    const int64_t tk = s_tile;
+    __syncthreads();
+    if (tk >= ntasks) break;
+    const int64_t task = tasks[tk];
+    if (task < 0) {  // four light columns: one wavefront each, no workgroup barrier inside
+      const int64_t j = ~task + wave;
+      const int cw = j < ncolsB ? (int)cls[j] : -1;
+      if (cw == 0) {
+        const int64_t e = ord_chain(status, j, 0);
+        if (lane == 0) Cp[j] = e;
+      } else if (cw == 1) {
+        ord_column<64, kOrdWaveCap, kOrdWaveNb>(A, B, j, (int)nprod[j], bucket_shift_wave, smem + wave * wave_bytes, lane,
+                                                status, Cp, Ci, Cx, wave == 0 ? local_stamps : nullptr);
+      }
+    } else {
+      const int64_t j = task;
+      const int cw = (int)cls[j];
+      if (cw == 1 || cw == 2) {
+        ord_column<256, kOrdCap, kOrdNb>(A, B, j, (int)nprod[j], bucket_shift_group, smem, tid, status, Cp, Ci, Cx, local_stamps);
+      } else {  // empty, or computed beforehand into its scratch slot: publish the length, copy
+        const int cnt = cw == 3 ? heavy_count[j] : 0;
+        if (wave == 0) {
+          const int64_t e = ord_chain(status, j, cnt);
+          if (lane == 0) { s_base = e; Cp[j] = e; }
+        }
+        __syncthreads();
+        const int64_t base = s_base;
+        if (cw == 3) {
+          const int64_t src = heavy_slot[j];
+          for (int t = tid; t < cnt; t += 256) {
+            Ci[base + t] = Ti[src + t];
+            Cx[base + t] = Tx[src + t];
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (stamps && tid == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd(stamps + i, acc_stamps[i]);
+}
+
+__global__ void ord_total_kernel(const unsigned long long *__restrict__ status, int64_t ncolsB, int64_t *__restrict__ Cp) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) Cp[ncolsB] = (int64_t)(status[ncolsB - 1] & kOrdValueMask);
+}
+
 }  // namespace
 
 // C = A B; all pointers are device pointers.  Cp is 64-bit (nnz(C) may exceed 2^31).
@@ -468,12 +963,22 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
       dense_list((size_t)ncolsB);
   DBuf<int> list_counts(3), counts((size_t)ncolsB);
   SPL_HIP(hipMemsetAsync(list_counts.get(), 0, 3 * sizeof(int), s));
+  // SPL_SPGEMM_ORDERED=1 selects the ordered form (every column straight to its final place, no compaction;
+  // rows must fit its packed 32-bit keys).  It is NOT the default: measured on MI355X it ties with the
+  // compacting form on C4 (0.030 s vs 0.029 s: what the compaction costs, 17 %, the look-back chain costs
+  // in waiting, 25-30 % of its kernel — profiles/r02_spgemm_ordered_phases.txt) and loses on products of
+  // light columns (scale 20, edge factor 8: 7.4 ms vs 5.1 ms; its 32 KB of LDS per workgroup admit fewer
+  // wavefronts than the plain one-wavefront-per-column kernel).
+  const char *ord_env = getenv("SPL_SPGEMM_ORDERED");
+  const char *two_pass_env = getenv("SPL_SPGEMM_TWO_PASS"), *split_keys_env = getenv("SPL_SPGEMM_SPLIT_KEYS");
+  const bool ordered_ok = (ord_env && ord_env[0] == '1') && nrowsA <= (1LL << kOrdMaxRowBits) &&
+                          !(two_pass_env && two_pass_env[0] == '1') && !(split_keys_env && split_keys_env[0] == '1');
   hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 32)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
-                     medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get());
+                     medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), ordered_ok ? 1 : 0);
   int hc[3] = {0, 0, 0};
   SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 3 * sizeof(int), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
-  const int nmedium = hc[0], nxlarge = hc[1], ndense = hc[2];
+  const int nmedium0 = hc[0], nxlarge0 = hc[1], ndense0 = hc[2];
   DBuf<int64_t> pscan((size_t)ncolsB + 1);  // products before column j: its upper-bound output slot
   exclusive_scan_i64(nprod.get(), pscan.get(), ncolsB, s);
   int64_t total_products = 0;
@@ -490,6 +995,18 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     single_pass = !(force && force[0] == '1') && total_products > 0 &&
                   (double)total_products * 24.0 < 0.5 * (double)free_b;
   }
+  const bool ordered = ordered_ok && single_pass;
+  int nmedium_v = nmedium0, nxlarge_v = nxlarge0, ndense_v = ndense0;
+  if (ordered_ok && !single_pass) {  // the lists were filtered for the ordered form: build the full ones
+    SPL_HIP(hipMemsetAsync(list_counts.get(), 0, 3 * sizeof(int), s));
+    hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 32)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
+                       medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 0);
+    SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipStreamSynchronize(s));
+    nmedium_v = hc[0]; nxlarge_v = hc[1]; ndense_v = hc[2];
+  }
+  const int nmedium = nmedium_v, nxlarge = nxlarge_v, ndense = ndense_v;
+  (void)nmedium0; (void)nxlarge0; (void)ndense0;
   typedef EscLds<kMediumProducts, kMediumB, false> LMs;
   typedef EscLds<kLargeProducts, kLargeB, false> LXs;
   typedef EscLds<kLargeProducts, kLargeB, true, false> LXn;
@@ -531,7 +1048,26 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   int *out_i = nullptr;
   double *out_x = nullptr;
   int *numeric_counts = nullptr;
-  if (single_pass) {
+  DBuf<unsigned char> cls;
+  DBuf<int64_t> heavy_prod, heavy_slot;
+  int64_t total_heavy = 0;
+  if (ordered) {
+    // heavy columns (beyond the ordered kernel's LDS budget) go to scratch slots first, by the kernels above
+    cls.alloc((size_t)ncolsB);
+    heavy_prod.alloc((size_t)ncolsB);
+    heavy_slot.alloc((size_t)ncolsB + 1);
+    hipLaunchKernelGGL(ord_classify_kernel, dim3(blocks_for(ncolsB, 256)), dim3(256), 0, s, B, ncolsB, nprod.get(),
+                       cls.get(), heavy_prod.get());
+    exclusive_scan_i64(heavy_prod.get(), heavy_slot.get(), ncolsB, s);
+    SPL_HIP(hipMemcpyAsync(&total_heavy, heavy_slot.get() + ncolsB, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipStreamSynchronize(s));
+    Ti.alloc((size_t)total_heavy);
+    Tx.alloc((size_t)total_heavy);
+    slots = heavy_slot.get();
+    out_i = Ti.get();
+    out_x = Tx.get();
+    numeric_counts = counts.get();
+  } else if (single_pass) {
     Ti.alloc((size_t)total_products);
     Tx.alloc((size_t)total_products);
     slots = pscan.get();
@@ -575,7 +1111,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   hipLaunchKernelGGL((spgemm_block_kernel<CAP, NBCAP, true, K32>), dim3((unsigned)(COUNT)), dim3(256),         \
                      (EscLds<CAP, NBCAP, true, K32>::total), s, A, B, LIST.get(), nprod.get(), numeric_counts,   \
                      slots, out_i, out_x)
-  if (key32_s) SPL_NUMERIC_WAVE(true); else SPL_NUMERIC_WAVE(false);
+  if (!ordered) { if (key32_s) SPL_NUMERIC_WAVE(true); else SPL_NUMERIC_WAVE(false); }
   if (nmedium > 0) {
     if (key32_m) SPL_NUMERIC_BLOCK(kMediumProducts, kMediumB, true, medium_list, nmedium);
     else SPL_NUMERIC_BLOCK(kMediumProducts, kMediumB, false, medium_list, nmedium);
@@ -590,6 +1126,77 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     hipLaunchKernelGGL(spgemm_dense_kernel<true>, dim3((unsigned)pool), dim3(256), 0, s, A, B, nrowsA,
                        dense_list.get(), ndense, pool_flags.get(), pool_vals.get(), numeric_counts, slots, out_i,
                        out_x);
+  if (ordered) {
+    // ---- every column to its final place, in column order
+    Ci.alloc((size_t)total_products);  // upper bound; trimmed below when many products merged
+    Cx.alloc((size_t)total_products);
+    DBuf<unsigned long long> status((size_t)ncolsB + 1);
+    SPL_HIP(hipMemsetAsync(status.get(), 0, ((size_t)ncolsB + 1) * sizeof(unsigned long long), s));
+    unsigned long long *ticket = status.get() + ncolsB;
+    int rb = 0;
+    while ((1LL << rb) < nrowsA) ++rb;
+    const int sh_wave = rb > 7 ? rb - 7 : 0, sh_group = rb > 10 ? rb - 10 : 0;  // 128 / 1024 buckets
+    typedef OrdLds<kOrdWaveCap, kOrdWaveNb> LW;
+    typedef OrdLds<kOrdCap, kOrdNb> LG;
+    const size_t lds = std::max((LW::total + 15) / 16 * 16 * 4, (size_t)LG::total);
+    int cus = 256;
+    {
+      int dev = 0;
+      SPL_HIP(hipGetDevice(&dev));
+      SPL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 8) per_cu = 8;
+    const int64_t ntiles = (ncolsB + 3) / 4;
+    DBuf<int> tile_tasks((size_t)ntiles);
+    DBuf<int64_t> task_off((size_t)ntiles + 1);
+    hipLaunchKernelGGL(ord_task_count_kernel, dim3(blocks_for(ntiles, 256)), dim3(256), 0, s, ncolsB, cls.get(),
+                       tile_tasks.get());
+    exclusive_scan_i32_to_i64(tile_tasks.get(), task_off.get(), ntiles, s);
+    int64_t ntasks = 0;
+    SPL_HIP(hipMemcpyAsync(&ntasks, task_off.get() + ntiles, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipStreamSynchronize(s));
+    DBuf<int64_t> tasks((size_t)ntasks);
+    hipLaunchKernelGGL(ord_task_fill_kernel, dim3(blocks_for(ntiles, 256)), dim3(256), 0, s, ncolsB, cls.get(),
+                       task_off.get(), tasks.get());
+    int64_t grid = (int64_t)cus * per_cu;
+    if (grid > ntasks) grid = ntasks;
+    DBuf<unsigned long long> stamps;
+    if (const char *ev = getenv("SPL_SPGEMM_STAMPS")) {
+      if (ev[0] == '1') {
+        stamps.alloc(8);
+        SPL_HIP(hipMemsetAsync(stamps.get(), 0, 8 * sizeof(unsigned long long), s));
+      }
+    }
+    hipLaunchKernelGGL(spgemm_ordered_kernel, dim3((unsigned)grid), dim3(256), lds, s, A, B, ncolsB, sh_wave, sh_group,
+                       nprod.get(), cls.get(), heavy_slot.get(), counts.get(), Ti.get(), Tx.get(), status.get(), ticket,
+                       tasks.get(), ntasks, Cp.get(), Ci.get(), Cx.get(), stamps.get());
+    if (stamps.get()) {
+      unsigned long long h[8];
+      SPL_HIP(hipMemcpy(h, stamps.get(), sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[spgemm ordered] cycles of thread 0 per phase, summed over %lld tasks: stage+scan %llu | expand %llu | "
+              "histogram scan %llu | scatter+bucket sort %llu | count+chain %llu | fold+write %llu\n",
+              (long long)ntasks, h[0], h[1], h[2], h[3], h[4], h[5]);
+    }
+    hipLaunchKernelGGL(ord_total_kernel, dim3(1), dim3(64), 0, s, status.get(), ncolsB, Cp.get());
+    int64_t nz = 0;
+    SPL_HIP(hipMemcpyAsync(&nz, Cp.get() + ncolsB, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipStreamSynchronize(s));
+    SPL_HIP(hipGetLastError());
+    *nnzC = nz;
+    if ((double)nz < 0.75 * (double)total_products) {  // many products merged: give the surplus back
+      DBuf<int> Ci2((size_t)nz);
+      DBuf<double> Cx2((size_t)nz);
+      if (nz > 0) {
+        SPL_HIP(hipMemcpyAsync(Ci2.get(), Ci.get(), (size_t)nz * sizeof(int), hipMemcpyDeviceToDevice, s));
+        SPL_HIP(hipMemcpyAsync(Cx2.get(), Cx.get(), (size_t)nz * sizeof(double), hipMemcpyDeviceToDevice, s));
+        SPL_HIP(hipStreamSynchronize(s));
+      }
+      Ci = std::move(Ci2);
+      Cx = std::move(Cx2);
+    }
+    return;
+  }
   if (single_pass) {
     exclusive_scan_i32_to_i64(counts.get(), Cp.get(), ncolsB, s);
     int64_t nz = 0;

@@ -114,3 +114,35 @@ def test_colblock_spgemm_hip_blocks_concatenate_to_mm(gpu, pkg, O, nparts):
         assert blocks[-1].ncols == op.bounds[p + 1] - op.bounds[p]
     C = pkg.hcat(blocks)
     assert tuples_equal(mat_to_tuple(C), O.mm(A, B))
+
+
+def test_ordered_form_matches_oracle(gpu, pkg, O, monkeypatch):
+    """SPL_SPGEMM_ORDERED=1: every column written at its final offset through the look-back chain (no
+    compaction), counting sort over row buckets, bucket-overflow fallback to the merge tree, heavy columns
+    copied from scratch slots — same structure and values, bit for bit (Sparse.hs:691-702)"""
+    monkeypatch.setenv("SPL_SPGEMM_ORDERED", "1")
+    rng = np.random.default_rng(17)
+    for shape in ((40, 30, 50, 300), (2000, 1500, 1800, 30000), (200, 5000, 100, 8000), (300, 300, 300, 3000)):
+        m, n, p, k = shape
+        A, B = rand_csc(O, rng, m, n, k), rand_csc(O, rng, n, p, k)
+        C = pkg.mm(tuple_to_mat(pkg, A), tuple_to_mat(pkg, B))
+        assert tuples_equal(mat_to_tuple(C), O.mm(A, B))
+    # rows crowded into a narrow range (one bucket overflows) + columns of every class
+    n = 6000
+    rows = np.concatenate([rng.integers(0, 40, 30 * n), rng.integers(0, n, 10 * n)])
+    cols = np.concatenate([np.repeat(np.arange(n), 30), np.repeat(np.arange(n), 10)])
+    A = O.compress(n, n, rows, cols, rng.uniform(0.5, 1.5, len(rows)))
+    brow = np.concatenate([rng.integers(0, n, 3 * n), rng.choice(n, 60, replace=False), rng.choice(n, 300, replace=False)])
+    bcol = np.concatenate([rng.integers(4, n, 3 * n), np.full(60, 2), np.full(300, 3)])
+    B = O.compress(n, n, brow, bcol, rng.uniform(0.5, 1.5, len(brow)))
+    C = pkg.mm(tuple_to_mat(pkg, A), tuple_to_mat(pkg, B))
+    assert tuples_equal(mat_to_tuple(C), O.mm(A, B))
+    for scale, ef, abc in ((12, 16, (0.45, 0.22, 0.22)), (13, 32, (0.25, 0.25, 0.25))):
+        H = pkg.DeviceMatrix.rmat(scale, ef, abc)
+        HC, products = H.spgemm(H)
+        crp, cci, cv = HC.export_csr()
+        rp, ci, v = H.export_csr()
+        nn = 1 << scale
+        At = (nn, nn, rp, ci.astype(np.int64), v)
+        Cs = O.mm(At, At)
+        assert np.array_equal(crp, Cs[2]) and np.array_equal(cci, Cs[3]) and np.array_equal(cv, Cs[4])
