@@ -31,10 +31,16 @@
  * SPL_LU_FORCE_PIVOT=1, or a failed speculation).  solve (GPU): blocked substitution through the
  * band or up and down the tree, and SpMV-based iterative refinement with UMFPACK's stopping rules.
  * A speculation is checked by every solve: unless the refined solution is backward stable to
- * rounding level (componentwise backward error <= 1e-13), the object is refactored with partial
- * pivoting and the system solved again, so the caller sees pivoted-LU accuracy either way.
- * (A fallback whose band does not fit the HBM — a failed speculation on a large mesh — returns
- * UMFPACK_ERROR_out_of_memory from solve.)  SPL_LU_METHOD=band|mf forces the ordering.  Square matrices only (the reference's linearSolve_
+ * rounding level (componentwise backward error <= 1e-13), the object is refactored and the system
+ * solved again, so the caller sees pivoted-LU accuracy either way.  The refactorisation has two
+ * stages.  First STATIC PIVOTING (csrc/static_pivot.hpp), which stays on the tree: a
+ * maximum-product transversal with its scalings turns A into B = Dr P A Dc with |b_jj| = 1 >=
+ * |b_ij| (the pivots are chosen before the factorisation instead of during it — what UMFPACK's
+ * threshold pivoting with delayed pivots would do inside the fronts cannot be done on fronts whose
+ * sizes are planned ahead), B is ordered, factored without interchanges and checked like any
+ * speculation.  Only if that fails too: the band factorisation with partial pivoting (when its
+ * band does not fit the HBM — a large mesh — solve returns UMFPACK_ERROR_out_of_memory and the
+ * object keeps its previous factors).  SPL_LU_STATIC_PIVOT=0 skips the first stage.  SPL_LU_METHOD=band|mf forces the ordering.  Square matrices only (the reference's linearSolve_
  * assumes square, Umfpack.hs:93).
  * The complex (`zi`) entry points (Internal.hs:69-115) are served through the real 2n x 2n
  * embedding with interleaved unknowns (csrc/umfpack_zi.hip): packed complex arrays (imaginary
@@ -107,7 +113,8 @@ int spl_umfpack_dimension(void *Numeric);
 
 /* factorisation a Numeric object holds now: 0 band, partial pivoting; 1 band, no interchanges
  * (diagonally dominant matrix); 2 the same as a speculation; 3 multifrontal, no interchanges
- * (dominant); 4 the same as a speculation; -1 if invalid */
+ * (dominant); 4 the same as a speculation; 5 multifrontal with static pivoting (the
+ * maximum-product transversal on the diagonal, scaled; checked by every solve); -1 if invalid */
 int spl_umfpack_path(void *Numeric);
 
 /* figures of the factorisation a Numeric object holds now (diagnostics and benchmarks; UMFPACK

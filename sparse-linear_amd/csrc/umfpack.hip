@@ -32,6 +32,7 @@
 
 #include "common.hpp"
 #include "mf_symbolic.hpp"
+#include "static_pivot.hpp"
 #include "../../include/umfpack_hip.h"
 
 namespace spl {
@@ -80,9 +81,19 @@ struct Numeric {
   Matrix *At = nullptr;  // rows of A^T (residual b - A^T x)
   // set by the `zi` wrapper (umfpack_zi.hip): rows 2r, 2r+1 of the real embedding were swapped
   std::vector<char> pair_swap;
+  // Static pivoting (static_pivot.hpp): 0 not tried, 1 the factors held are those of B = Dr P A Dc on B's own
+  // tree (still a checked speculation), 2 tried and given up.  spA / spAt: rows of B / of B^T on the device
+  // (what mf_factor scatters); sp_idx / sp_scale: the permutations and scalings around a solve with B's factors,
+  // composed with B's nested-dissection ordering — [0] before, [1] after A x = b; [2] before, [3] after A^T x = b.
+  int sp_stage = 0;
+  Matrix *spA = nullptr, *spAt = nullptr;
+  DBuf<int> sp_idx[4];
+  DBuf<double> sp_scale[4];
   ~Numeric() {
     delete A;
     delete At;
+    delete spA;
+    delete spAt;
     if (mfact) mf_free(mfact);
   }
 };
@@ -309,6 +320,14 @@ __global__ void gather_perm_kernel(int n, const int *__restrict__ perm, const do
   if (k < n) out[col + k] = in[col + perm[k]];
 }
 
+// column blockIdx.y: out[k] = scale[k] * in[idx[k]]
+__global__ void gather_scale_kernel(int n, const int *__restrict__ idx, const double *__restrict__ scale,
+                                    const double *__restrict__ in, double *__restrict__ out, size_t stride) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t col = (size_t)blockIdx.y * stride;
+  if (k < n) out[col + k] = scale[k] * in[col + idx[k]];
+}
+
 // banded solves with the factors, one workgroup, vector c in HBM (L2-resident)
 __global__ __launch_bounds__(1024) void band_solve_kernel(int sys, int n, int kl, int ku, int ldab,
                                                           const double *__restrict__ AB,
@@ -464,6 +483,17 @@ void factor_solve(const Numeric *N, int sys, const double *d_b, double *d_x, dou
   const int n = N->n;
   if (n == 0 || k == 0) return;
   const dim3 g((unsigned)((n + 255) / 256), (unsigned)k);
+  if (N->sp_stage == 1) {
+    // factors of B = Dr P A Dc:  A x = b  <=>  B (Dc^-1 x) = Dr P b;  A^T x = b  <=>  B^T (Dr^-1 P x) = Dc b
+    // (the row permutation, the scalings and B's ordering are composed into one gather on either side)
+    const int a = sys == UMFPACK_A ? 0 : 2;
+    hipLaunchKernelGGL(gather_scale_kernel, g, dim3(256), 0, s, n, N->sp_idx[a].get(), N->sp_scale[a].get(), d_b, d_work,
+                       stride);
+    band_solve(N, sys, d_work, k, stride, s);
+    hipLaunchKernelGGL(gather_scale_kernel, g, dim3(256), 0, s, n, N->sp_idx[a + 1].get(), N->sp_scale[a + 1].get(), d_work,
+                       d_x, stride);
+    return;
+  }
   // B = P A P^T  =>  A x = b  <=>  B (P x) = P b ; (P v)[k] = v[perm[k]]
   hipLaunchKernelGGL(gather_perm_kernel, g, dim3(256), 0, s, n, N->perm.get(), d_b, d_work, stride);
   band_solve(N, sys, d_work, k, stride, s);
@@ -492,6 +522,83 @@ void factor_multifrontal(Numeric *N, hipStream_t s) {
   N->singular = mf_singular(N->mfact);
 }
 
+// Static pivoting (static_pivot.hpp): factor B = Dr P A Dc — the maximum-product transversal on the diagonal,
+// |b_jj| = 1 >= |b_ij| — without interchanges on B's own nested-dissection tree.  Returns false when it
+// cannot be done (structurally singular, scalings out of range, does not fit, zero pivot): the caller then
+// falls back to the band factorisation with partial pivoting.  The object is left consistent either way.
+bool factor_static_pivot(Numeric *N, const int *Ap, const int *Ai, const double *Ax, hipStream_t s) {
+  const int n = N->n;
+  if (N->sp_stage != 0 || n < 2) return false;
+  const char *off = getenv("SPL_LU_STATIC_PIVOT");
+  if (off && off[0] == '0') return false;
+  N->sp_stage = 2;  // whatever happens below, it is not tried twice
+  sp::Transversal T;
+  if (!sp::max_product_transversal(n, Ap, Ai, Ax, T)) return false;
+  std::vector<int> Bp, Bi;
+  std::vector<double> Bx;
+  sp::permuted_scaled_csc(n, Ap, Ai, Ax, T, Bp, Bi, Bx);
+  std::shared_ptr<mf::Tree> tree = std::make_shared<mf::Tree>();
+  mf::build_tree(n, Bp.data(), Bi.data(), 256, *tree);
+  {
+    size_t held = (N->AB.n + N->blkinv.n) * sizeof(double);
+    if (N->mfact && N->tree) held += mf_device_bytes(*N->tree);
+    const size_t avail = device_free_bytes() + held;
+    if (mf_device_bytes(*tree) + (size_t)Bp[(size_t)n] * 24 > avail - avail / 8) return false;
+  }
+  void *hBt = nullptr, *hB = nullptr;
+  if (spl_matrix_create_csr(n, n, 0, n, Bp.data(), Bi.data(), Bx.data(), &hBt) != SPL_OK) return false;
+  if (spl_matrix_create(n, n, Bp.data(), Bi.data(), Bx.data(), &hB) != SPL_OK) { spl_matrix_free(&hBt); return false; }
+  std::unique_ptr<Matrix> Bt(static_cast<Matrix *>(hBt)), B(static_cast<Matrix *>(hB));
+  if (!Bt->rowptr.get() || !B->rowptr.get()) return false;
+  // the gathers around a solve (see factor_solve): rowof[r] = the row of A that became row r of B
+  const std::vector<int> &pnd = tree->perm, &ind = tree->inv;
+  std::vector<int> idx[4];
+  std::vector<double> sc[4];
+  for (int a = 0; a < 4; ++a) { idx[a].resize((size_t)n); sc[a].resize((size_t)n); }
+  for (int k = 0; k < n; ++k) {
+    const int r = pnd[(size_t)k];                 // row / column of B at position k of the ordering
+    const int i = T.row_of_col[(size_t)r];        // row of A that became row r of B
+    idx[0][(size_t)k] = i;  sc[0][(size_t)k] = T.dr[(size_t)i];   // work[k] = dr_i b_i
+    idx[2][(size_t)k] = r;  sc[2][(size_t)k] = T.dc[(size_t)r];   // work[k] = dc_r b_r      (A^T x = b)
+  }
+  for (int j = 0; j < n; ++j) {
+    idx[1][(size_t)j] = ind[(size_t)j];  sc[1][(size_t)j] = T.dc[(size_t)j];                           // x_j = dc_j z[inv[j]]
+    idx[3][(size_t)j] = ind[(size_t)T.col_of_row[(size_t)j]];  sc[3][(size_t)j] = T.dr[(size_t)j];     // x_i = dr_i z[inv[newrow(i)]]
+  }
+  // from here on the old factors are released: failures leave the object without factors (broken)
+  try {
+    N->AB.release();
+    N->blkinv.release();
+    if (N->mfact) { mf_free(N->mfact); N->mfact = nullptr; }
+    N->tree = tree;
+    set_ordering(N, tree->perm, tree->inv, s);
+    for (int a = 0; a < 4; ++a) {
+      N->sp_idx[a].alloc((size_t)n);
+      N->sp_scale[a].alloc((size_t)n);
+      SPL_HIP(hipMemcpyAsync(N->sp_idx[a].get(), idx[a].data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+      SPL_HIP(hipMemcpyAsync(N->sp_scale[a].get(), sc[a].data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    SPL_HIP(hipStreamSynchronize(s));
+    delete N->spA;
+    delete N->spAt;
+    N->spA = B.release();
+    N->spAt = Bt.release();
+    N->nopiv = 1;
+    N->mfact = mf_factor(N->tree, N->spAt->rowptr.get(), N->spAt->colidx.get(), N->spAt->val.get(), N->spA->rowptr.get(),
+                         N->spA->colidx.get(), N->spA->val.get(), N->perm.get(), N->inv.get(), s);
+    if (mf_singular(N->mfact)) {  // a zero pivot: these factors are useless; the band fallback rebuilds everything
+      N->sp_stage = 2;
+      return false;
+    }
+    N->singular = 0;
+    N->sp_stage = 1;
+    return true;
+  } catch (...) {
+    N->broken = 1;
+    throw;
+  }
+}
+
 // (re)build the band factors of P A P^T from the device copy of A^T's rows (= the CSC arrays);
 // nopiv selects the blocked no-interchange factorisation (band_nopiv.hip) or LAPACK-style
 // partial pivoting.  Throws DeviceError; sets N->singular.
@@ -514,6 +621,9 @@ void factor_band(Numeric *N, bool nopiv, hipStream_t s) {
       N->tree.reset();
       set_ordering(N, N->band_perm, N->band_inv, s);
     }
+    if (N->sp_stage == 1) N->sp_stage = 2;  // the factors of B are gone: solves use the plain gathers again
+    delete N->spA; N->spA = nullptr;
+    delete N->spAt; N->spAt = nullptr;
     N->nopiv = nopiv ? 1 : 0;
     N->ldab = ldab_new;
     N->AB.release();
@@ -710,8 +820,10 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
       if (N->tree) factor_multifrontal(N, s); else factor_band(N, true, s);
       N->speculative = dominant ? 0 : 1;
       if (N->speculative && N->singular) {  // a zero pivot without interchanges proves nothing
-        N->speculative = 0;
-        factor_band(N, false, s);
+        if (!factor_static_pivot(N, Ap, Ai, Ax, s)) {
+          N->speculative = 0;
+          factor_band(N, false, s);
+        }
       }
     } else {
       factor_band(N, false, s);
@@ -735,7 +847,8 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
 // umf_solve): stop when the componentwise backward error is below machine epsilon, or when a
 // step does not at least halve it (a step that raises it is undone).  All columns share every
 // pass over the factors.
-static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B) {
+static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B, const int *Ap, const int *Ai,
+                         const double *Ax) {
   const int n = N->n;
   if (N->broken) return UMFPACK_ERROR_invalid_Numeric_object;  // a failed refactorisation left no factors
   try {
@@ -834,6 +947,9 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B)
       double worst = 0.0;
       for (int c = 0; c < k; ++c) worst = (omega[(size_t)c] <= worst) ? worst : omega[(size_t)c];  // NaN -> worst
       if (turn.owns_lock() && N->speculative && !(worst <= 1e-13)) {
+        // first the static-pivoting stage (stays on the tree, still checked by this very loop), then, if that
+        // fails too, the band factorisation with partial pivoting
+        if (factor_static_pivot(N, Ap, Ai, Ax, s)) goto again;
         factor_band(N, false, s);
         N->speculative = 0;  // only now may other threads use the object without taking turns
         goto again;
@@ -861,7 +977,7 @@ int umfpack_di_solve(int sys, const int Ap[], const int Ai[], const double Ax[],
   if (!X || !B) return UMFPACK_ERROR_argument_missing;
   if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;  // UMFPACK needs A for refinement
   if (sys != UMFPACK_A && sys != UMFPACK_At) return UMFPACK_ERROR_invalid_system;
-  return solve_columns(N, sys, 1, X, B);
+  return solve_columns(N, sys, 1, X, B, Ap, Ai, Ax);
 }
 
 // batched linearSolve: nrhs right-hand sides in one call (see umfpack_hip.h)
@@ -873,7 +989,7 @@ int spl_umfpack_di_solve_many(int sys, const int Ap[], const int Ai[], const dou
   if (nrhs > 0 && N->n > 0 && (!X || !B)) return UMFPACK_ERROR_argument_missing;
   if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;
   if (sys != UMFPACK_A && sys != UMFPACK_At) return UMFPACK_ERROR_invalid_system;
-  return solve_columns(N, sys, nrhs, X, B);
+  return solve_columns(N, sys, nrhs, X, B, Ap, Ai, Ax);
 }
 
 }  // extern "C"
@@ -898,10 +1014,11 @@ int spl_umfpack_dimension(void *NumericIn) {
 
 // which factorisation the object holds now: 0 band, partial pivoting; 1 band, no interchanges
 // (diagonally dominant matrix); 2 the same as a speculation; 3 / 4 multifrontal, no interchanges
-// (dominant / speculation) (see umfpack_hip.h); -1 if invalid
+// (dominant / speculation); 5 multifrontal with static pivoting (see umfpack_hip.h); -1 if invalid
 int spl_umfpack_path(void *NumericIn) {
   Numeric *N = as_numeric(NumericIn);
   if (!N) return -1;
+  if (N->mfact && N->sp_stage == 1) return 5;
   if (N->mfact) return N->speculative ? 4 : 3;
   return N->nopiv ? (N->speculative ? 2 : 1) : 0;
 }

@@ -103,7 +103,8 @@ class Factors(_Handle):
     def path(self):
         """factorisation held now: 0 band with partial pivoting, 1 band without interchanges
         (diagonally dominant), 2 the same as a speculation that every solve checks, 3 / 4
-        multifrontal without interchanges (dominant / speculation) (include/umfpack_hip.h)"""
+        multifrontal without interchanges (dominant / speculation), 5 multifrontal with static pivoting
+        (maximum-product transversal + scalings, csrc/static_pivot.hpp) (include/umfpack_hip.h)"""
         return int(_declare().spl_umfpack_path(self.value))
 
     @property

@@ -200,6 +200,7 @@ def test_speculation_that_fails_is_replaced_by_pivoting(gpu, pkg, O, monkeypatch
     M = pkg.Matrix(n, n, S.indptr, S.indices, S.data)
     xs = rng.uniform(0.5, 1.5, n)
     b = S @ xs
+    monkeypatch.setenv("SPL_LU_STATIC_PIVOT", "0")  # (the static-pivoting stage has its own tests below)
     fact = pkg.umfpack.factor(M, pkg.umfpack.analyze(M))
     assert fact.path in (2, 4)
     x = pkg.umfpack.linearSolve_(fact, pkg.umfpack.UmfpackNormal, M, b)
@@ -321,6 +322,17 @@ def test_multifrontal_unsymmetric_values_and_fallback(gpu, pkg, O, monkeypatch):
     fact = U.factor(M, U.analyze(M))
     assert fact.path == 4
     x = U.linearSolve_(fact, U.UmfpackNormal, M, B @ xs)
+    assert fact.path == 5  # static pivoting: the transversal takes the 3s, the factors stay on the tree
+    assert np.max(np.abs(x - xs)) / np.max(np.abs(xs)) < 1e-10
+    xt = U.linearSolve_(fact, U.UmfpackTrans, M, B.T @ xs)
+    assert fact.path == 5 and np.max(np.abs(xt - xs)) / np.max(np.abs(xs)) < 1e-10
+    many = U.linearSolveMany_(fact, U.UmfpackNormal, M, [B @ xs, 2.0 * (B @ xs)])
+    assert np.max(np.abs(many[1] - 2.0 * xs)) / np.max(np.abs(xs)) < 1e-10
+    # without that stage (SPL_LU_STATIC_PIVOT=0): band factorisation with partial pivoting, as before
+    monkeypatch.setenv("SPL_LU_STATIC_PIVOT", "0")
+    fact = U.factor(M, U.analyze(M))
+    assert fact.path == 4
+    x = U.linearSolve_(fact, U.UmfpackNormal, M, B @ xs)
     assert fact.path == 0
     assert np.max(np.abs(x - xs)) / np.max(np.abs(xs)) < 1e-8
     assert np.max(np.abs(x - spla.spsolve(B, B @ xs))) / np.max(np.abs(xs)) < 1e-8
@@ -410,3 +422,41 @@ def test_linear_solve_checks_rhs_length_and_type(gpu, pkg):
     Z = pkg.Matrix(5, 5, A.pointers, A.indices, A.values.astype(np.complex128))
     with pytest.raises(U.UmfpackError):
         U.linearSolve_(fact, U.UmfpackNormal, Z, np.ones(5, dtype=np.complex128))
+
+
+def _backward_error(S, x, b):
+    """componentwise backward error max_i |r_i| / (|A| |x| + |b|)_i (what umfpack_di_solve drives below 1e-13)"""
+    r = np.abs(S @ x - b)
+    den = abs(S) @ np.abs(x) + np.abs(b)
+    return float(np.max(r / np.where(den > 0, den, 1.0)))
+
+
+@pytest.mark.parametrize("m,dim,tiny_diag", [(58, 3, True), (300, 2, True), (58, 3, False)])
+def test_static_pivoting_random_unsymmetric_mesh(gpu, pkg, O, m, dim, tiny_diag):
+    """a random unsymmetric, non-dominant matrix with a mesh pattern (values uniform in [-1, 1]; 3-D:
+    195 112 unknowns).  With a diagonal of 1e-12 the factors without interchanges are useless, the
+    static-pivoting stage refactors on the tree (path 5) and both systems are solved to a backward error
+    <= 1e-13 — where the band fallback of round 1 did not fit the HBM and solve returned
+    UMFPACK_ERROR_out_of_memory.  With a random diagonal the plain speculation may already hold (path 4):
+    either way the answer is backward stable."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(m)
+    T = sp.diags([np.ones(m - 1), np.ones(m), np.ones(m - 1)], (-1, 0, 1))
+    I = sp.identity(m)
+    P = (sp.kron(I, T) + sp.kron(T, I)) if dim == 2 else (sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(T, I), I))
+    S = sp.csc_matrix(P)
+    S.data = rng.uniform(-1.0, 1.0, S.nnz)
+    if tiny_diag:
+        S.setdiag(1e-12 * rng.uniform(0.5, 1.0, S.shape[0]))
+    S = sp.csc_matrix(S)
+    S.sort_indices()
+    n = S.shape[0]
+    M = pkg.Matrix(n, n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
+    U = pkg.umfpack
+    fact = U.factor(M, U.analyze(M))
+    xs = rng.uniform(0.5, 1.5, n)
+    for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, sp.csc_matrix(S.T))):
+        b = np.asarray(op @ xs).ravel()
+        x = U.linearSolve_(fact, mode, M, b)
+        assert fact.path == 5 if tiny_diag else fact.path in (4, 5), fact.path
+        assert _backward_error(op, x, b) <= 1e-13
