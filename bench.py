@@ -142,7 +142,9 @@ def main():
     # under the kernel of the next).  A candidate must reproduce the plain step's y bit for bit on
     # every rank (to 1e-10 relative under --order free, whose sums may differ at rounding level between
     # launches) and is kept only if it is faster; SPL_BENCH_CHUNKS=k forces k (1 = plain).
-    exchange = "one all-gather of y after the kernel"
+    exchange = "one RCCL all-gather of y after the kernel"
+    H0 = H  # the rank's whole row block (the plain and the peer-store steps use it)
+    best_t = None
     handles = [H]
     kernels = [dist_mod.hip_local_spmv(H, lambda: stream.cuda_stream)]
     pieces = [(r0, r1)]
@@ -186,15 +188,57 @@ def main():
             if t_c < best_t or forced > 1:
                 best_t = t_c
                 for h in handles:
-                    h.free()
+                    if h is not H0:
+                        h.free()
                 op, handles, y_full = cand, hs, cand.y_full
                 kernels = list(cand.local_spmvs)
                 pieces = [cand.rows_of(c) for c in range(C)]
-                exchange = "%d chunks per rank, the all-gather of a chunk under the kernel of the next" % C
+                exchange = "%d chunks per rank, the RCCL all-gather of a chunk under the kernel of the next" % C
             else:
                 for h in hs:
                     h.free()
         del y_plain
+    # ---- a second kind of exchange: one-sided peer stores (csrc/peer.hip) instead of the RCCL collective.
+    # Measured like the candidates above and kept only if every rank finds the same y and it is faster;
+    # SPL_BENCH_EXCHANGE=rccl | peer forces one kind.
+    want = os.environ.get("SPL_BENCH_EXCHANGE", "")
+    if N > 1 and not args.blocked and not args.variant and want != "rccl" and (want == "peer" or not os.environ.get("SPL_BENCH_CHUNKS")):
+        peer, ok = None, 1.0
+        try:
+            peer = dist_mod.PeerStoreRowBlockSpMV(n, dist_mod.equal_row_bounds(n, N), rank, N,
+                                                  dist_mod.hip_local_spmv(H0, lambda: stream.cuda_stream), "cuda",
+                                                  lambda: stream.cuda_stream)
+        except Exception as e:
+            sys.stderr.write("rank %d: peer-store exchange not available: %s\n" % (rank, e))
+            ok = 0.0
+        if agree(ok, dist.ReduceOp.MIN) >= 1.0:
+            y_ref = op.step(x).clone()
+            y_p = peer.step(x)
+            torch.cuda.synchronize()
+            if args.order == "free":
+                same = float(((y_p - y_ref).abs() <= 1e-10 * (y_p + y_ref).abs()).all().item())
+            else:
+                same = float(torch.equal(y_p, y_ref))
+            same = min(same, 0.0 if peer.failed() else 1.0)
+            if agree(same, dist.ReduceOp.MIN) >= 1.0:
+                t_p = seconds_per_step(lambda: peer.step(x), 3, 10)
+                if tuning is None:
+                    tuning = {}
+                tuning["peer"] = round(t_p * 1e3, 4)
+                if t_p < best_t or want == "peer":
+                    for h in handles:
+                        if h is not H0:
+                            h.free()
+                    op, handles = peer, [H0]
+                    kernels = [dist_mod.hip_local_spmv(H0, lambda: stream.cuda_stream)]
+                    pieces = [(r0, r1)]
+                    exchange = "one-sided peer stores: a device-to-device copy per peer and stream, step flags"
+                    peer = None
+            elif rank == 0:
+                sys.stderr.write("peer-store exchange differs from the collective one: dropped\n")
+            del y_ref
+        if peer is not None:
+            peer.close()
     y_pieces = op.y_local if isinstance(op.y_local, list) else [op.y_local]
 
     def spmv():  # the kernel(s) of one step alone
@@ -287,7 +331,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s CSR %dx%d, %d draws/row, nnz=%d, y=A*x fp64, int32 indices%s"
                                % (args.matrix, n, n, args.draws, nnz_total,
-                                  "" if N == 1 else ", %d row blocks + RCCL all-gather of y (%s)" % (N, exchange)),
+                                  "" if N == 1 else ", %d row blocks, exchange of y: %s" % (N, exchange)),
                    "algorithmic_bytes": B_total, "hbm_frac_of_%dx8TBps" % N: round(value / (N * HBM_PEAK_GBPS), 4),
                    "variant": args.variant, "blocked": args.blocked or "auto", "panel": args.panel or "auto",
                    "sum_order": args.order},
@@ -297,7 +341,7 @@ def main():
     import hashlib
     step()
     torch.cuda.synchronize()
-    yh = y_full.cpu().numpy()
+    yh = op.y_full.cpu().numpy()
     out["y_sha1"] = hashlib.sha1(yh.tobytes()).hexdigest()  # equal for every N under --order reference
     out["y_sum"], out["y_norm2"] = float(yh.sum()), float(np.sqrt((yh * yh).sum()))  # equal to ~1e-15 under either order
     if tuning:

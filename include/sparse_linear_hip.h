@@ -219,6 +219,23 @@ int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unrol
  * lockstep, 15 sliced ELL, 16 column-sorted panels (other values: the forced ablation variant) */
 int spl_matrix_spmv_kernel(void *H);
 
+/* ---- one-sided exchange of y for the row-partitioned SpMV (one process per GPU; csrc/peer.hip) ----
+ * Every rank pushes its block of y straight into every peer's copy with device-to-device copies on one
+ * stream per peer (no collective kernel, no CU taken from the SpMV), then a 4-byte step flag; a one-thread
+ * kernel on the compute stream waits for the N - 1 flags.  Peers' buffers are reached through IPC memory
+ * handles that the caller passes between the processes (3 x 64 bytes per rank).
+ * create: rank q owns y[bounds[q], bounds[q+1]); handles_out = this rank's 192 bytes.
+ * connect: all_handles = world x 192 bytes in rank order.
+ * step: d_y_local was produced on `stream`; after the work enqueued here *y_full (n doubles, device, valid until
+ *   the step after next) is the whole y.  No host synchronisation.
+ * failed: 1 if a wait gave up after ~2 s (a peer did not deliver). */
+int spl_peer_exchange_create(int rank, int world, int64_t n, const int64_t *bounds, unsigned char *handles_out,
+                             void **X);
+int spl_peer_exchange_connect(void *X, const unsigned char *all_handles);
+int spl_peer_exchange_step(void *X, const double *d_y_local, void *stream, double **y_full);
+int spl_peer_exchange_failed(void *X);
+void spl_peer_exchange_free(void **X);
+
 /* fill a device vector with the synthetic entries j in [j0,j1) */
 int spl_vector_synthetic_dev(uint64_t seed, int64_t j0, int64_t j1, double *d_x, void *stream);
 

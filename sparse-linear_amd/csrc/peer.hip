@@ -1,0 +1,217 @@
+// peer.hip — one-sided exchange of the result blocks of a row-partitioned SpMV (last row of
+// §5: "direct peer stores on 7 links in parallel").
+//
+// The step of the multi-GPU path ends with every rank holding the whole y (so that y can be the next x).
+// With RCCL that is one all_gather: a ring over point-to-point xGMI links, whose kernels also take CUs from
+// an SpMV kernel that wants one resident workgroup on every CU.  The alternative built here uses no CU at
+// all for the data: every rank pushes its own block straight into every peer's copy of y with N - 1
+// device-to-device copies on N - 1 streams (one per peer = one per xGMI link, all links busy at once, the
+// copy engines do the work), followed on the same stream by a 4-byte store of the step number into the
+// peer's flag word for this rank; a one-thread kernel on the compute stream waits until all N - 1 flags of
+// the rank show the step.  One process per GPU: peers' buffers are reached through IPC memory handles
+// (hipIpcGetMemHandle / hipIpcOpenMemHandle), exchanged by the caller over its own channel
+// (torch.distributed in bench.py).
+//
+// Reuse: a peer may run ahead by at most one step — it starts step k + 1 only after it has seen this rank's
+// flag of step k — so two receive buffers alternate: step k lands in buffer k % 2 while the owner may still
+// be reading buffer (k - 1) % 2.
+#include "common.hpp"
+
+#include <vector>
+
+namespace spl {
+namespace {
+
+constexpr uint32_t kPeerMagic = 0x53504C58u;  // "SPLX"
+
+struct PeerExchange {
+  uint32_t magic = kPeerMagic;
+  int device = 0, rank = 0, world = 1;
+  int64_t n = 0;
+  std::vector<int64_t> bounds;
+  double *buf[2] = {nullptr, nullptr};  // this rank's two copies of y (hipMalloc: IPC needs whole allocations)
+  unsigned *flags = nullptr;            // world words: flags[q] = last step whose block of rank q has landed
+  unsigned *error = nullptr;            // set by the wait kernel when it gives up
+  std::vector<double *> peer_buf[2];    // the same of every peer (mapped); [rank] = own
+  std::vector<unsigned *> peer_flags;
+  std::vector<hipStream_t> streams;     // one per peer
+  hipEvent_t ready = nullptr;
+  unsigned step = 0;
+  bool connected = false;
+};
+
+inline PeerExchange *as_px(void *p) {
+  PeerExchange *x = static_cast<PeerExchange *>(p);
+  return (x && x->magic == kPeerMagic) ? x : nullptr;
+}
+
+// one thread: wait until every flag except `self` shows at least `step`; bounded (about 2 s at 100 MHz)
+__global__ void peer_wait_kernel(const unsigned *__restrict__ flags, int world, int self, unsigned step,
+                                 unsigned *__restrict__ error) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const unsigned long long t0 = wall_clock64();
+  for (int q = 0; q < world; ++q) {
+    if (q == self) continue;
+    while ((int)(__hip_atomic_load(flags + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) {
+      if (wall_clock64() - t0 > 200000000ull) { *error = 1; return; }
+      __builtin_amdgcn_s_sleep(16);
+    }
+  }
+}
+
+}  // namespace
+}  // namespace spl
+
+using namespace spl;
+
+extern "C" {
+
+// Allocate the exchange of rank `rank` of `world`: y has n entries, rank q owns [bounds[q], bounds[q+1]).
+// handles_out receives 3 x 64 bytes (the IPC handles of the two buffers and of the flag array) to be
+// passed to every peer.
+int spl_peer_exchange_create(int rank, int world, int64_t n, const int64_t *bounds, unsigned char *handles_out,
+                             void **X) {
+  if (!X || !bounds || !handles_out || world < 1 || rank < 0 || rank >= world || n < 0) return SPL_ERROR_argument_missing;
+  *X = nullptr;
+  PeerExchange *px = new (std::nothrow) PeerExchange();
+  if (!px) return SPL_ERROR_out_of_memory;
+  try {
+    SPL_HIP(hipGetDevice(&px->device));
+    px->rank = rank;
+    px->world = world;
+    px->n = n;
+    px->bounds.assign(bounds, bounds + world + 1);
+    const size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(double);
+    for (int b = 0; b < 2; ++b) {
+      SPL_HIP(hipMalloc(reinterpret_cast<void **>(&px->buf[b]), bytes));
+      SPL_HIP(hipMemset(px->buf[b], 0, bytes));
+    }
+    SPL_HIP(hipMalloc(reinterpret_cast<void **>(&px->flags), (size_t)(world + 1) * sizeof(unsigned)));
+    SPL_HIP(hipMemset(px->flags, 0, (size_t)(world + 1) * sizeof(unsigned)));
+    px->error = px->flags + world;
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    SPL_HIP(hipIpcGetMemHandle(&h, px->buf[0]));
+    memcpy(handles_out, &h, 64);
+    SPL_HIP(hipIpcGetMemHandle(&h, px->buf[1]));
+    memcpy(handles_out + 64, &h, 64);
+    SPL_HIP(hipIpcGetMemHandle(&h, px->flags));
+    memcpy(handles_out + 128, &h, 64);
+    SPL_HIP(hipEventCreateWithFlags(&px->ready, hipEventDisableTiming));
+  } catch (const DeviceError &e) {
+    if (px->buf[0]) (void)hipFree(px->buf[0]);
+    if (px->buf[1]) (void)hipFree(px->buf[1]);
+    if (px->flags) (void)hipFree(px->flags);
+    delete px;
+    return e.status;
+  }
+  *X = px;
+  return SPL_OK;
+}
+
+// all_handles: world x 192 bytes, entry q = what rank q's create returned
+int spl_peer_exchange_connect(void *X, const unsigned char *all_handles) {
+  PeerExchange *px = as_px(X);
+  if (!px || !all_handles) return SPL_ERROR_invalid_handle;
+  try {
+    DeviceGuard g(px->device);
+    px->peer_buf[0].assign((size_t)px->world, nullptr);
+    px->peer_buf[1].assign((size_t)px->world, nullptr);
+    px->peer_flags.assign((size_t)px->world, nullptr);
+    px->streams.assign((size_t)px->world, nullptr);
+    for (int q = 0; q < px->world; ++q) {
+      if (q == px->rank) {
+        px->peer_buf[0][(size_t)q] = px->buf[0];
+        px->peer_buf[1][(size_t)q] = px->buf[1];
+        px->peer_flags[(size_t)q] = px->flags;
+        continue;
+      }
+      hipIpcMemHandle_t h;
+      void *p = nullptr;
+      memcpy(&h, all_handles + (size_t)q * 192, 64);
+      SPL_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+      px->peer_buf[0][(size_t)q] = static_cast<double *>(p);
+      memcpy(&h, all_handles + (size_t)q * 192 + 64, 64);
+      SPL_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+      px->peer_buf[1][(size_t)q] = static_cast<double *>(p);
+      memcpy(&h, all_handles + (size_t)q * 192 + 128, 64);
+      SPL_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+      px->peer_flags[(size_t)q] = static_cast<unsigned *>(p);
+      SPL_HIP(hipStreamCreateWithFlags(&px->streams[(size_t)q], hipStreamNonBlocking));
+    }
+    px->connected = true;
+    return SPL_OK;
+  } catch (const DeviceError &e) {
+    return e.status;
+  }
+}
+
+// One step: this rank's block d_y_local (bounds[rank+1] - bounds[rank] doubles, produced on `stream`) goes to
+// every rank's y; when the work enqueued here has run, *y_full (device pointer, n doubles, valid until the
+// step after next) holds the whole y.  Nothing is synchronised on the host.
+int spl_peer_exchange_step(void *X, const double *d_y_local, void *stream, double **y_full) {
+  PeerExchange *px = as_px(X);
+  if (!px || !px->connected) return SPL_ERROR_invalid_handle;
+  if (!d_y_local || !y_full) return SPL_ERROR_argument_missing;
+  try {
+    DeviceGuard g(px->device);
+    hipStream_t s = as_stream(stream);
+    const unsigned step = ++px->step;
+    const int b = (int)(step & 1u);
+    const int64_t r0 = px->bounds[(size_t)px->rank], r1 = px->bounds[(size_t)px->rank + 1];
+    const size_t bytes = (size_t)(r1 - r0) * sizeof(double);
+    SPL_HIP(hipEventRecord(px->ready, s));  // the kernel that wrote d_y_local
+    for (int q = 0; q < px->world; ++q) {
+      if (q == px->rank) continue;
+      hipStream_t t = px->streams[(size_t)q];
+      SPL_HIP(hipStreamWaitEvent(t, px->ready, 0));
+      if (bytes) SPL_HIP(hipMemcpyAsync(px->peer_buf[b][(size_t)q] + r0, d_y_local, bytes, hipMemcpyDeviceToDevice, t));
+      // stream order: the flag lands after the block
+      SPL_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(px->peer_flags[(size_t)q] + px->rank), (int)step, 1, t));
+    }
+    if (bytes) SPL_HIP(hipMemcpyAsync(px->buf[b] + r0, d_y_local, bytes, hipMemcpyDeviceToDevice, s));
+    if (px->world > 1)
+      hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, px->flags, px->world, px->rank, step, px->error);
+    *y_full = px->buf[b];
+    SPL_HIP(hipGetLastError());
+    return SPL_OK;
+  } catch (const DeviceError &e) {
+    return e.status;
+  }
+}
+
+// 1 if a wait gave up (a peer did not deliver within ~2 s): the results since are incomplete
+int spl_peer_exchange_failed(void *X) {
+  PeerExchange *px = as_px(X);
+  if (!px) return SPL_ERROR_invalid_handle;
+  unsigned e = 0;
+  if (hipMemcpy(&e, px->error, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return SPL_ERROR_device;
+  return e ? 1 : 0;
+}
+
+void spl_peer_exchange_free(void **X) {
+  if (!X || !*X) return;
+  PeerExchange *px = as_px(*X);
+  *X = nullptr;
+  if (!px) return;
+  int prev = -1;
+  const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+  (void)hipSetDevice(px->device);
+  (void)hipDeviceSynchronize();
+  for (int q = 0; q < px->world && px->connected; ++q) {
+    if (q == px->rank) continue;
+    if (px->peer_buf[0][(size_t)q]) (void)hipIpcCloseMemHandle(px->peer_buf[0][(size_t)q]);
+    if (px->peer_buf[1][(size_t)q]) (void)hipIpcCloseMemHandle(px->peer_buf[1][(size_t)q]);
+    if (px->peer_flags[(size_t)q]) (void)hipIpcCloseMemHandle(px->peer_flags[(size_t)q]);
+    if (px->streams[(size_t)q]) (void)hipStreamDestroy(px->streams[(size_t)q]);
+  }
+  if (px->ready) (void)hipEventDestroy(px->ready);
+  (void)hipFree(px->buf[0]);
+  (void)hipFree(px->buf[1]);
+  (void)hipFree(px->flags);
+  px->magic = 0;
+  delete px;
+  if (have_prev) (void)hipSetDevice(prev);
+}
+
+}  // extern "C"

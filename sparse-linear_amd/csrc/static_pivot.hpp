@@ -61,18 +61,55 @@ inline bool max_product_transversal(int n, const int *Ap, const int *Ai, const d
     for (int p = Ap[j]; p < Ap[j + 1]; ++p) u[(size_t)Ai[p]] = std::min(u[(size_t)Ai[p]], c[(size_t)p]);
   for (int i = 0; i < n; ++i)
     if (u[(size_t)i] == inf) return false;  // an empty row
+  // column duals: v_j = min_i (c_ij - u_i), so that every column has a tight entry as well as every row
+  for (int j = 0; j < n; ++j) {
+    double m = inf;
+    for (int p = Ap[j]; p < Ap[j + 1]; ++p) m = std::min(m, c[(size_t)p] - u[(size_t)Ai[p]]);
+    v[(size_t)j] = m;
+  }
   T.row_of_col.assign((size_t)n, -1);
   T.col_of_row.assign((size_t)n, -1);
-  // greedy start: tight entries (reduced cost 0) of unmatched rows
+  auto tight = [&](int p, int i, int j) { return c[(size_t)p] - u[(size_t)i] - v[(size_t)j] <= 1e-14; };
+  // greedy start: tight entries of unmatched rows ...
   for (int j = 0; j < n; ++j)
     for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
       const int i = Ai[p];
-      if (T.col_of_row[(size_t)i] < 0 && c[(size_t)p] - u[(size_t)i] - v[(size_t)j] <= 0.0) {
+      if (T.col_of_row[(size_t)i] < 0 && tight(p, i, j)) {
         T.col_of_row[(size_t)i] = j;
         T.row_of_col[(size_t)j] = i;
         break;
       }
     }
+  // ... then augmenting paths of length two: a tight entry (i, j) whose row is taken by column j2, which has
+  // another tight entry in a free row (each column is rescanned from where its last scan stopped)
+  {
+    std::vector<int> next((size_t)n);
+    for (int j = 0; j < n; ++j) next[(size_t)j] = Ap[j];
+    for (int j = 0; j < n; ++j) {
+      if (T.row_of_col[(size_t)j] >= 0) continue;
+      for (int p = Ap[j]; p < Ap[j + 1] && T.row_of_col[(size_t)j] < 0; ++p) {
+        const int i = Ai[p];
+        if (!tight(p, i, j)) continue;
+        const int j2 = T.col_of_row[(size_t)i];
+        if (j2 < 0) {  // freed meanwhile
+          T.col_of_row[(size_t)i] = j;
+          T.row_of_col[(size_t)j] = i;
+          break;
+        }
+        for (int &q = next[(size_t)j2]; q < Ap[j2 + 1]; ++q) {
+          const int i2 = Ai[q];
+          if (T.col_of_row[(size_t)i2] < 0 && tight(q, i2, j2)) {
+            T.col_of_row[(size_t)i2] = j2;
+            T.row_of_col[(size_t)j2] = i2;
+            T.col_of_row[(size_t)i] = j;
+            T.row_of_col[(size_t)j] = i;
+            ++q;
+            break;
+          }
+        }
+      }
+    }
+  }
   // shortest augmenting paths for the rest
   std::vector<double> d((size_t)n, inf);
   std::vector<int> pred((size_t)n, -1);     // column from which row i was reached
@@ -87,11 +124,14 @@ inline bool max_product_transversal(int n, const int *Ap, const int *Ai, const d
     while (!heap.empty()) heap.pop();
     int j = j0, end_row = -1;
     double lowest = 0.0;  // distance at which column j was reached
+    double best_free = inf;  // shortest distance to a free row seen so far: nothing longer can be the answer
     for (;;) {
       for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
         const int i = Ai[p];
         if (done[(size_t)i] || c[(size_t)p] == inf) continue;
         const double dn = lowest + (c[(size_t)p] - u[(size_t)i] - v[(size_t)j]);
+        if (dn >= best_free) continue;
+        if (T.col_of_row[(size_t)i] < 0) best_free = dn;
         if (dn < d[(size_t)i]) {
           if (d[(size_t)i] == inf) touched.push_back(i);
           d[(size_t)i] = dn;

@@ -532,13 +532,18 @@ bool factor_static_pivot(Numeric *N, const int *Ap, const int *Ai, const double 
   const char *off = getenv("SPL_LU_STATIC_PIVOT");
   if (off && off[0] == '0') return false;
   N->sp_stage = 2;  // whatever happens below, it is not tried twice
+  const bool timing = getenv("SPL_MF_TIMING") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
   sp::Transversal T;
   if (!sp::max_product_transversal(n, Ap, Ai, Ax, T)) return false;
+  if (timing) fprintf(stderr, "[static pivot] transversal done at %.1f ms\n", since());
   std::vector<int> Bp, Bi;
   std::vector<double> Bx;
   sp::permuted_scaled_csc(n, Ap, Ai, Ax, T, Bp, Bi, Bx);
   std::shared_ptr<mf::Tree> tree = std::make_shared<mf::Tree>();
   mf::build_tree(n, Bp.data(), Bi.data(), 256, *tree);
+  if (timing) fprintf(stderr, "[static pivot] B and its tree (%d fronts, %.3g flops) at %.1f ms\n", tree->nfronts, tree->flops, since());
   {
     size_t held = (N->AB.n + N->blkinv.n) * sizeof(double);
     if (N->mfact && N->tree) held += mf_device_bytes(*N->tree);
@@ -592,6 +597,7 @@ bool factor_static_pivot(Numeric *N, const int *Ap, const int *Ai, const double 
     }
     N->singular = 0;
     N->sp_stage = 1;
+    if (timing) { (void)hipStreamSynchronize(s); fprintf(stderr, "[static pivot] factored at %.1f ms\n", since()); }
     return true;
   } catch (...) {
     N->broken = 1;

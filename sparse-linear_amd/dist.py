@@ -163,6 +163,79 @@ class PipelinedRowBlockSpMV(object):
         return self.y_full
 
 
+class _DevicePointerView(object):
+    """zero-copy torch view of library-owned device memory (``__cuda_array_interface__``)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 3}
+
+
+class PeerStoreRowBlockSpMV(object):
+    """The step of RowBlockSpMV with a ONE-SIDED exchange instead of the collective (csrc/peer.hip): every
+    rank pushes its block of y into every peer's copy with device-to-device copies on one stream per peer
+    (one per xGMI link, the copy engines move the data: no collective kernel takes CUs from the SpMV), then
+    a step flag; a one-thread kernel on the compute stream waits for the peers' flags.  Peers' buffers are
+    mapped through IPC handles exchanged once over the process group.  Two receive buffers alternate, so
+    the tensor a step returns stays valid until the step after next.  Results are those of RowBlockSpMV
+    (row sums never cross ranks)."""
+
+    def __init__(self, n, bounds, rank, world, local_spmv, device, stream_getter, group=None):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _ffi
+        self.torch, self._ffi, self._C = torch, _ffi, C
+        self.n, self.bounds, self.rank, self.world = int(n), [int(b) for b in bounds], int(rank), int(world)
+        assert len(self.bounds) == world + 1 and self.bounds[0] == 0 and self.bounds[-1] == n
+        self.local_spmv, self.stream_getter = local_spmv, stream_getter
+        r0, r1 = self.bounds[rank], self.bounds[rank + 1]
+        self.y_local = torch.zeros(r1 - r0, dtype=torch.float64, device=device)
+        L = _ffi.lib()
+        self._h = C.c_void_p()
+        mine = C.create_string_buffer(192)
+        b = (C.c_int64 * (world + 1))(*self.bounds)
+        _ffi.check("spl_peer_exchange_create", L.spl_peer_exchange_create(rank, world, self.n, b, mine, C.byref(self._h)))
+        handles = [None] * world
+        if world > 1:
+            dist.all_gather_object(handles, mine.raw, group=group)
+        else:
+            handles[0] = mine.raw
+        _ffi.check("spl_peer_exchange_connect", L.spl_peer_exchange_connect(self._h, b"".join(handles)))
+        if world > 1:
+            dist.barrier(group=group)  # every rank has mapped every peer before anyone stores
+        self._views = {}
+        self.y_full = None
+
+    def step(self, x):
+        C = self._C
+        self.local_spmv(x, self.y_local)
+        out = C.c_void_p()
+        self._ffi.check("spl_peer_exchange_step",
+                        self._ffi.lib().spl_peer_exchange_step(self._h, C.c_void_p(self.y_local.data_ptr()),
+                                                               C.c_void_p(self.stream_getter()), C.byref(out)))
+        v = self._views.get(out.value)
+        if v is None:
+            v = self.torch.as_tensor(_DevicePointerView(out.value, self.n), device=self.y_local.device)
+            self._views[out.value] = v
+        self.y_full = v
+        return v
+
+    def failed(self):
+        return bool(self._ffi.lib().spl_peer_exchange_failed(self._h))
+
+    def close(self):
+        if self._h.value:
+            self._views.clear()
+            self.y_full = None
+            self._ffi.lib().spl_peer_exchange_free(self._C.byref(self._h))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def hip_local_spmv(handle, stream_getter):
     """the product's local operator: the HIP CSR-stream kernel on the current stream"""
     def run(x, y_local):

@@ -22,10 +22,12 @@ def _free_port():
     return p
 
 
-def _run(nproc, extra, chunks=None):
+def _run(nproc, extra, chunks=None, exchange=None):
     env = dict(os.environ, SPL_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if chunks is not None:
         env["SPL_BENCH_CHUNKS"] = str(chunks)
+    if exchange is not None:
+        env["SPL_BENCH_EXCHANGE"] = exchange
     if nproc == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")]
     else:
@@ -55,7 +57,7 @@ def test_two_ranks_on_one_gpu(gpu, matrix):
     # the same matrix: identical nnz, hence identical algorithmic bytes, whatever the rank count
     assert one["config"]["algorithmic_bytes"] == two["config"]["algorithmic_bytes"]
     assert one["y_sha1"] == two["y_sha1"]  # the gathered y is the single-rank y, bit for bit
-    assert set(two["config"]["exchange_ms_per_step_by_chunks"]) == {"1", "2", "4"}  # all candidates were measured
+    assert set(two["config"]["exchange_ms_per_step_by_chunks"]) == {"1", "2", "4", "peer"}  # all candidates were measured
 
 
 def test_pipelined_exchange_forced(gpu):
@@ -71,7 +73,7 @@ def test_pipelined_exchange_forced(gpu):
             assert "%d chunks per rank" % chunks in out["config"]["workload"]
             assert out["roofline"]["launches_per_step"] == chunks
         else:
-            assert "one all-gather of y after the kernel" in out["config"]["workload"]
+            assert "one RCCL all-gather of y after the kernel" in out["config"]["workload"]
 
 
 def test_two_ranks_order_free(gpu):
@@ -82,3 +84,15 @@ def test_two_ranks_order_free(gpu):
     assert one["config"]["sum_order"] == two["config"]["sum_order"] == "free"
     for k in ("y_sum", "y_norm2"):
         assert abs(one[k] - two[k]) <= 1e-12 * abs(one[k])
+
+
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_peer_store_exchange_forced(gpu, nproc):
+    """the one-sided exchange (csrc/peer.hip: device-to-device copies into the peers' buffers through IPC
+    handles, step flags, a wait kernel) forced on: N = 2 and 3 give the y of one rank, bit for bit"""
+    args = ["--rows", "480000"]
+    one = _run(1, args)
+    out = _run(nproc, args, exchange="peer")
+    assert "one-sided peer stores" in out["config"]["workload"]
+    assert out["y_sha1"] == one["y_sha1"]
+    assert out["config"]["algorithmic_bytes"] == one["config"]["algorithmic_bytes"]
