@@ -136,109 +136,104 @@ def main():
         barrier()
         return agree((time.perf_counter() - t) / reps, dist.ReduceOp.MAX)
 
-    # ---- N > 1: how the exchange is scheduled is chosen by measurement before anything is timed.
-    # Candidates: the plain step (kernel, then one all-gather of y) and the pipelined step with the
-    # rank's rows cut into 2 or 4 chunks (dist.PipelinedRowBlockSpMV: the gather of one chunk runs
-    # under the kernel of the next).  A candidate must reproduce the plain step's y bit for bit on
-    # every rank (to 1e-10 relative under --order free, whose sums may differ at rounding level between
-    # launches) and is kept only if it is faster; SPL_BENCH_CHUNKS=k forces k (1 = plain).
+    # ---- N > 1: how y is exchanged is chosen by measurement before anything is timed.  Two kinds —
+    # "rccl": all_gather_into_tensor; "peer": one-sided device-to-device copies into the peers' buffers
+    # (csrc/peer.hip: no collective kernel takes CUs from the SpMV) — each with the rank's rows in one piece
+    # or cut into 2 or 4 chunks whose exchange runs under the kernel of the next chunk
+    # (dist.PipelinedRowBlockSpMV / dist.PeerStoreRowBlockSpMV).  A candidate must reproduce the plain step's y
+    # bit for bit on every rank (to 1e-10 relative under --order free, whose sums may differ at rounding level
+    # between launches) and is kept only if it is faster.  SPL_BENCH_CHUNKS=k forces the number of chunks
+    # (1 = one piece), SPL_BENCH_EXCHANGE=rccl|peer the kind.
     exchange = "one RCCL all-gather of y after the kernel"
-    H0 = H  # the rank's whole row block (the plain and the peer-store steps use it)
-    best_t = None
+    H0 = H  # the rank's whole row block
     handles = [H]
     kernels = [dist_mod.hip_local_spmv(H, lambda: stream.cuda_stream)]
     pieces = [(r0, r1)]
     tuning = None
     if N > 1 and not args.blocked and not args.variant:
         forced = int(os.environ.get("SPL_BENCH_CHUNKS", "0"))
-        candidates = [c for c in ([forced] if forced > 1 else [] if forced == 1 else [2, 4]) if n % (c * N) == 0]
+        want = os.environ.get("SPL_BENCH_EXCHANGE", "")
+        chunk_counts = [c for c in ([forced] if forced >= 1 else [1, 2, 4]) if n % (c * N) == 0]
+        kinds = [want] if want in ("rccl", "peer") else ["rccl", "peer"]
         y_plain = op.step(x).clone()
         best_t = seconds_per_step(lambda: op.step(x), 3, 10)
-        tuning = {"1": round(best_t * 1e3, 4)}
-        for C in candidates:
-            cand, ok = None, 1.0
-            try:
-                bnd = dist_mod.pipelined_piece_bounds(n, N, C)
-                hs = []
-                for c in range(C):
-                    q = c * N + rank
-                    h = pkg.DeviceMatrix.synthetic(args.matrix, n, args.draws, seed=0x5EED, row0=bnd[q], row1=bnd[q + 1])
-                    if args.order == "free":
-                        h.set_spmv_order(h.ORDER_FREE)
-                    h.optimize()
-                    hs.append(h)
-                cand = dist_mod.PipelinedRowBlockSpMV(
-                    n, rank, N, C, [dist_mod.hip_local_spmv(h, lambda: stream.cuda_stream) for h in hs], "cuda")
-            except Exception as e:  # e.g. out of memory on one rank: every rank drops the candidate
-                sys.stderr.write("rank %d: pipelined exchange with %d chunks not available: %s\n" % (rank, C, e))
-                ok = 0.0
-            if agree(ok, dist.ReduceOp.MIN) < 1.0:
-                continue
-            y_c = cand.step(x)
-            if args.order == "free":  # order-free sums: rounding-level differences between launches are legitimate
-                same = float(((y_c - y_plain).abs() <= 1e-10 * (y_c + y_plain).abs()).all().item())
-            else:
-                same = float(torch.equal(y_c, y_plain))
-            if agree(same, dist.ReduceOp.MIN) < 1.0:
-                if rank == 0:
-                    sys.stderr.write("pipelined exchange with %d chunks differs from the plain step: dropped\n" % C)
-                continue
-            t_c = seconds_per_step(lambda: cand.step(x), 3, 10)
-            tuning[str(C)] = round(t_c * 1e3, 4)
-            if t_c < best_t or forced > 1:
-                best_t = t_c
-                for h in handles:
-                    if h is not H0:
-                        h.free()
-                op, handles, y_full = cand, hs, cand.y_full
-                kernels = list(cand.local_spmvs)
-                pieces = [cand.rows_of(c) for c in range(C)]
-                exchange = "%d chunks per rank, the RCCL all-gather of a chunk under the kernel of the next" % C
-            else:
+        best_key = "rccl1"
+        tuning = {"rccl1": round(best_t * 1e3, 4)}
+        have_allowed = "rccl" in kinds and 1 in chunk_counts  # is the plain step itself a permitted choice?
+        piece_handles = {1: [H0]}  # per chunk count: the device matrices of this rank's pieces
+        winner_handles = [H0]
+
+        def describe(kind, C):
+            if kind == "rccl":
+                return ("one RCCL all-gather of y after the kernel" if C == 1 else
+                        "%d chunks per rank, the RCCL all-gather of a chunk under the kernel of the next" % C)
+            return ("one-sided peer stores after the kernel: a device-to-device copy per peer and stream, step flags" if C == 1 else
+                    "%d chunks per rank, one-sided peer stores of a chunk under the kernel of the next" % C)
+
+        for C in chunk_counts:
+            for kind in kinds:
+                key = "%s%d" % (kind, C)
+                if key == "rccl1":
+                    continue  # the plain step, measured above
+                cand, ok = None, 1.0
+                try:
+                    if C not in piece_handles:
+                        bnd = dist_mod.pipelined_piece_bounds(n, N, C)
+                        hs = []
+                        for c in range(C):
+                            q = c * N + rank
+                            h = pkg.DeviceMatrix.synthetic(args.matrix, n, args.draws, seed=0x5EED, row0=bnd[q], row1=bnd[q + 1])
+                            if args.order == "free":
+                                h.set_spmv_order(h.ORDER_FREE)
+                            h.optimize()
+                            hs.append(h)
+                        piece_handles[C] = hs
+                    hs = piece_handles[C]
+                    spmvs = [dist_mod.hip_local_spmv(h, lambda: stream.cuda_stream) for h in hs]
+                    if kind == "peer":
+                        cand = dist_mod.PeerStoreRowBlockSpMV(n, rank, N, C, spmvs, "cuda", lambda: stream.cuda_stream)
+                    elif C == 1:
+                        cand = op
+                    else:
+                        cand = dist_mod.PipelinedRowBlockSpMV(n, rank, N, C, spmvs, "cuda")
+                except Exception as e:  # e.g. out of memory or no peer access on one rank: every rank drops the candidate
+                    sys.stderr.write("rank %d: exchange %s not available: %s\n" % (rank, key, e))
+                    ok = 0.0
+                if agree(ok, dist.ReduceOp.MIN) < 1.0:
+                    continue
+                y_c = cand.step(x)
+                torch.cuda.synchronize()
+                if args.order == "free":  # order-free sums: rounding-level differences between launches are legitimate
+                    same = float(((y_c - y_plain).abs() <= 1e-10 * (y_c + y_plain).abs()).all().item())
+                else:
+                    same = float(torch.equal(y_c, y_plain))
+                if kind == "peer" and cand.failed():
+                    same = 0.0
+                if agree(same, dist.ReduceOp.MIN) < 1.0:
+                    if rank == 0:
+                        sys.stderr.write("exchange %s differs from the plain step: dropped\n" % key)
+                    if kind == "peer":
+                        cand.close()
+                    continue
+                t_c = seconds_per_step(lambda: cand.step(x), 3, 10)
+                tuning[key] = round(t_c * 1e3, 4)
+                if t_c < best_t or not have_allowed:  # (the plain step may be excluded by the forcing variables)
+                    have_allowed = True
+                    if hasattr(op, "close") and op is not cand:
+                        op.close()
+                    best_t, best_key = t_c, key
+                    op, winner_handles = cand, hs
+                    kernels = spmvs
+                    pieces = [cand.rows_of(c) for c in range(C)] if C > 1 else [(r0, r1)]
+                    exchange = describe(kind, C)
+                elif kind == "peer":
+                    cand.close()
+        for C, hs in piece_handles.items():  # free the pieces no schedule uses any more
+            if hs is not winner_handles and C != 1:
                 for h in hs:
                     h.free()
+        handles = winner_handles
         del y_plain
-    # ---- a second kind of exchange: one-sided peer stores (csrc/peer.hip) instead of the RCCL collective.
-    # Measured like the candidates above and kept only if every rank finds the same y and it is faster;
-    # SPL_BENCH_EXCHANGE=rccl | peer forces one kind.
-    want = os.environ.get("SPL_BENCH_EXCHANGE", "")
-    if N > 1 and not args.blocked and not args.variant and want != "rccl" and (want == "peer" or not os.environ.get("SPL_BENCH_CHUNKS")):
-        peer, ok = None, 1.0
-        try:
-            peer = dist_mod.PeerStoreRowBlockSpMV(n, dist_mod.equal_row_bounds(n, N), rank, N,
-                                                  dist_mod.hip_local_spmv(H0, lambda: stream.cuda_stream), "cuda",
-                                                  lambda: stream.cuda_stream)
-        except Exception as e:
-            sys.stderr.write("rank %d: peer-store exchange not available: %s\n" % (rank, e))
-            ok = 0.0
-        if agree(ok, dist.ReduceOp.MIN) >= 1.0:
-            y_ref = op.step(x).clone()
-            y_p = peer.step(x)
-            torch.cuda.synchronize()
-            if args.order == "free":
-                same = float(((y_p - y_ref).abs() <= 1e-10 * (y_p + y_ref).abs()).all().item())
-            else:
-                same = float(torch.equal(y_p, y_ref))
-            same = min(same, 0.0 if peer.failed() else 1.0)
-            if agree(same, dist.ReduceOp.MIN) >= 1.0:
-                t_p = seconds_per_step(lambda: peer.step(x), 3, 10)
-                if tuning is None:
-                    tuning = {}
-                tuning["peer"] = round(t_p * 1e3, 4)
-                if t_p < best_t or want == "peer":
-                    for h in handles:
-                        if h is not H0:
-                            h.free()
-                    op, handles = peer, [H0]
-                    kernels = [dist_mod.hip_local_spmv(H0, lambda: stream.cuda_stream)]
-                    pieces = [(r0, r1)]
-                    exchange = "one-sided peer stores: a device-to-device copy per peer and stream, step flags"
-                    peer = None
-            elif rank == 0:
-                sys.stderr.write("peer-store exchange differs from the collective one: dropped\n")
-            del y_ref
-        if peer is not None:
-            peer.close()
     y_pieces = op.y_local if isinstance(op.y_local, list) else [op.y_local]
 
     def spmv():  # the kernel(s) of one step alone

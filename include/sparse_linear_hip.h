@@ -224,15 +224,19 @@ int spl_matrix_spmv_kernel(void *H);
  * stream per peer (no collective kernel, no CU taken from the SpMV), then a 4-byte step flag; a one-thread
  * kernel on the compute stream waits for the N - 1 flags.  Peers' buffers are reached through IPC memory
  * handles that the caller passes between the processes (3 x 64 bytes per rank).
- * create: rank q owns y[bounds[q], bounds[q+1]); handles_out = this rank's 192 bytes.
+ * create: y is cut into chunks * world pieces, piece q = c * world + p = y[bounds[q], bounds[q+1]) belongs to
+ *   rank p (chunks = 1: one block per rank); handles_out = this rank's 192 bytes.
  * connect: all_handles = world x 192 bytes in rank order.
- * step: d_y_local was produced on `stream`; after the work enqueued here *y_full (n doubles, device, valid until
- *   the step after next) is the whole y.  No host synchronisation.
+ * A step = one push per chunk + finish.  push: the rank's piece of chunk c (produced on `stream`) goes to every
+ *   rank (the copies run on the per-peer streams, i.e. under whatever `stream` does next — the kernel of the
+ *   next chunk).  finish: after the work enqueued here *y_full (n doubles, device, valid until the step after
+ *   next) is the whole y.  No host synchronisation.
  * failed: 1 if a wait gave up after ~2 s (a peer did not deliver). */
-int spl_peer_exchange_create(int rank, int world, int64_t n, const int64_t *bounds, unsigned char *handles_out,
-                             void **X);
+int spl_peer_exchange_create(int rank, int world, int chunks, int64_t n, const int64_t *bounds,
+                             unsigned char *handles_out, void **X);
 int spl_peer_exchange_connect(void *X, const unsigned char *all_handles);
-int spl_peer_exchange_step(void *X, const double *d_y_local, void *stream, double **y_full);
+int spl_peer_exchange_push(void *X, int chunk, const double *d_piece, void *stream);
+int spl_peer_exchange_finish(void *X, void *stream, double **y_full);
 int spl_peer_exchange_failed(void *X);
 void spl_peer_exchange_free(void **X);
 

@@ -114,9 +114,10 @@ def _declare(L):
         "spl_matrix_set_spmv_order": [C.c_void_p, i],
         "spl_matrix_spmv_kernel": [C.c_void_p],
         "spl_vector_synthetic_dev": [u64, i64, i64, C.c_void_p, C.c_void_p],
-        "spl_peer_exchange_create": [i, i, i64, c_i64_p, C.c_char_p, c_void_pp],
+        "spl_peer_exchange_create": [i, i, i, i64, c_i64_p, C.c_char_p, c_void_pp],
         "spl_peer_exchange_connect": [C.c_void_p, C.c_char_p],
-        "spl_peer_exchange_step": [C.c_void_p, C.c_void_p, C.c_void_p, c_void_pp],
+        "spl_peer_exchange_push": [C.c_void_p, i, C.c_void_p, C.c_void_p],
+        "spl_peer_exchange_finish": [C.c_void_p, C.c_void_p, c_void_pp],
         "spl_peer_exchange_failed": [C.c_void_p],
     }
     for name, args in sigs.items():

@@ -26,11 +26,11 @@ constexpr uint32_t kPeerMagic = 0x53504C58u;  // "SPLX"
 
 struct PeerExchange {
   uint32_t magic = kPeerMagic;
-  int device = 0, rank = 0, world = 1;
+  int device = 0, rank = 0, world = 1, chunks = 1;
   int64_t n = 0;
-  std::vector<int64_t> bounds;
+  std::vector<int64_t> bounds;          // chunks * world + 1: piece q = c * world + p belongs to rank p, chunk c
   double *buf[2] = {nullptr, nullptr};  // this rank's two copies of y (hipMalloc: IPC needs whole allocations)
-  unsigned *flags = nullptr;            // world words: flags[q] = last step whose block of rank q has landed
+  unsigned *flags = nullptr;            // one word per piece: flags[q] = last step whose piece q has landed
   unsigned *error = nullptr;            // set by the wait kernel when it gives up
   std::vector<double *> peer_buf[2];    // the same of every peer (mapped); [rank] = own
   std::vector<unsigned *> peer_flags;
@@ -45,13 +45,13 @@ inline PeerExchange *as_px(void *p) {
   return (x && x->magic == kPeerMagic) ? x : nullptr;
 }
 
-// one thread: wait until every flag except `self` shows at least `step`; bounded (about 2 s at 100 MHz)
-__global__ void peer_wait_kernel(const unsigned *__restrict__ flags, int world, int self, unsigned step,
+// one thread: wait until the flag of every piece not owned by `self` shows at least `step`; bounded (about 2 s)
+__global__ void peer_wait_kernel(const unsigned *__restrict__ flags, int npieces, int world, int self, unsigned step,
                                  unsigned *__restrict__ error) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const unsigned long long t0 = wall_clock64();
-  for (int q = 0; q < world; ++q) {
-    if (q == self) continue;
+  for (int q = 0; q < npieces; ++q) {
+    if (q % world == self) continue;
     while ((int)(__hip_atomic_load(flags + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) {
       if (wall_clock64() - t0 > 200000000ull) { *error = 1; return; }
       __builtin_amdgcn_s_sleep(16);
@@ -66,12 +66,14 @@ using namespace spl;
 
 extern "C" {
 
-// Allocate the exchange of rank `rank` of `world`: y has n entries, rank q owns [bounds[q], bounds[q+1]).
-// handles_out receives 3 x 64 bytes (the IPC handles of the two buffers and of the flag array) to be
-// passed to every peer.
-int spl_peer_exchange_create(int rank, int world, int64_t n, const int64_t *bounds, unsigned char *handles_out,
-                             void **X) {
-  if (!X || !bounds || !handles_out || world < 1 || rank < 0 || rank >= world || n < 0) return SPL_ERROR_argument_missing;
+// Allocate the exchange of rank `rank` of `world`: y has n entries cut into chunks * world pieces, piece
+// q = c * world + p = [bounds[q], bounds[q+1]) belongs to rank p (chunks = 1: one block per rank; more: the
+// pieces of a chunk can be pushed while the kernel of the next chunk runs).  handles_out receives 3 x 64
+// bytes (the IPC handles of the two buffers and of the flag array) to be passed to every peer.
+int spl_peer_exchange_create(int rank, int world, int chunks, int64_t n, const int64_t *bounds,
+                             unsigned char *handles_out, void **X) {
+  if (!X || !bounds || !handles_out || world < 1 || chunks < 1 || rank < 0 || rank >= world || n < 0)
+    return SPL_ERROR_argument_missing;
   *X = nullptr;
   PeerExchange *px = new (std::nothrow) PeerExchange();
   if (!px) return SPL_ERROR_out_of_memory;
@@ -79,16 +81,18 @@ int spl_peer_exchange_create(int rank, int world, int64_t n, const int64_t *boun
     SPL_HIP(hipGetDevice(&px->device));
     px->rank = rank;
     px->world = world;
+    px->chunks = chunks;
     px->n = n;
-    px->bounds.assign(bounds, bounds + world + 1);
+    px->bounds.assign(bounds, bounds + (size_t)chunks * world + 1);
     const size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(double);
     for (int b = 0; b < 2; ++b) {
       SPL_HIP(hipMalloc(reinterpret_cast<void **>(&px->buf[b]), bytes));
       SPL_HIP(hipMemset(px->buf[b], 0, bytes));
     }
-    SPL_HIP(hipMalloc(reinterpret_cast<void **>(&px->flags), (size_t)(world + 1) * sizeof(unsigned)));
-    SPL_HIP(hipMemset(px->flags, 0, (size_t)(world + 1) * sizeof(unsigned)));
-    px->error = px->flags + world;
+    const size_t npieces = (size_t)chunks * world;
+    SPL_HIP(hipMalloc(reinterpret_cast<void **>(&px->flags), (npieces + 1) * sizeof(unsigned)));
+    SPL_HIP(hipMemset(px->flags, 0, (npieces + 1) * sizeof(unsigned)));
+    px->error = px->flags + npieces;
     hipIpcMemHandle_t h;
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
     SPL_HIP(hipIpcGetMemHandle(&h, px->buf[0]));
@@ -146,33 +150,50 @@ int spl_peer_exchange_connect(void *X, const unsigned char *all_handles) {
   }
 }
 
-// One step: this rank's block d_y_local (bounds[rank+1] - bounds[rank] doubles, produced on `stream`) goes to
-// every rank's y; when the work enqueued here has run, *y_full (device pointer, n doubles, valid until the
-// step after next) holds the whole y.  Nothing is synchronised on the host.
-int spl_peer_exchange_step(void *X, const double *d_y_local, void *stream, double **y_full) {
+// A step = `chunks` pushes + one finish.  push: this rank's piece of chunk c (d_piece, produced on `stream`)
+// goes into every rank's y of the current step; finish: the wait for every other rank's pieces is enqueued on
+// `stream`; when it has run, *y_full (device pointer, n doubles, valid until the step after next) holds the
+// whole y.  Nothing is synchronised on the host.
+int spl_peer_exchange_push(void *X, int chunk, const double *d_piece, void *stream) {
   PeerExchange *px = as_px(X);
   if (!px || !px->connected) return SPL_ERROR_invalid_handle;
-  if (!d_y_local || !y_full) return SPL_ERROR_argument_missing;
+  if (!d_piece || chunk < 0 || chunk >= px->chunks) return SPL_ERROR_argument_missing;
+  try {
+    DeviceGuard g(px->device);
+    hipStream_t s = as_stream(stream);
+    const unsigned step = px->step + 1;
+    const int b = (int)(step & 1u);
+    const size_t q = (size_t)chunk * px->world + px->rank;
+    const int64_t r0 = px->bounds[q], r1 = px->bounds[q + 1];
+    const size_t bytes = (size_t)(r1 - r0) * sizeof(double);
+    SPL_HIP(hipEventRecord(px->ready, s));  // the kernel that wrote d_piece
+    for (int p = 0; p < px->world; ++p) {
+      if (p == px->rank) continue;
+      hipStream_t t = px->streams[(size_t)p];
+      SPL_HIP(hipStreamWaitEvent(t, px->ready, 0));
+      if (bytes) SPL_HIP(hipMemcpyAsync(px->peer_buf[b][(size_t)p] + r0, d_piece, bytes, hipMemcpyDeviceToDevice, t));
+      // stream order: the flag lands after the piece
+      SPL_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(px->peer_flags[(size_t)p] + q), (int)step, 1, t));
+    }
+    if (bytes) SPL_HIP(hipMemcpyAsync(px->buf[b] + r0, d_piece, bytes, hipMemcpyDeviceToDevice, s));
+    return SPL_OK;
+  } catch (const DeviceError &e) {
+    return e.status;
+  }
+}
+
+int spl_peer_exchange_finish(void *X, void *stream, double **y_full) {
+  PeerExchange *px = as_px(X);
+  if (!px || !px->connected) return SPL_ERROR_invalid_handle;
+  if (!y_full) return SPL_ERROR_argument_missing;
   try {
     DeviceGuard g(px->device);
     hipStream_t s = as_stream(stream);
     const unsigned step = ++px->step;
-    const int b = (int)(step & 1u);
-    const int64_t r0 = px->bounds[(size_t)px->rank], r1 = px->bounds[(size_t)px->rank + 1];
-    const size_t bytes = (size_t)(r1 - r0) * sizeof(double);
-    SPL_HIP(hipEventRecord(px->ready, s));  // the kernel that wrote d_y_local
-    for (int q = 0; q < px->world; ++q) {
-      if (q == px->rank) continue;
-      hipStream_t t = px->streams[(size_t)q];
-      SPL_HIP(hipStreamWaitEvent(t, px->ready, 0));
-      if (bytes) SPL_HIP(hipMemcpyAsync(px->peer_buf[b][(size_t)q] + r0, d_y_local, bytes, hipMemcpyDeviceToDevice, t));
-      // stream order: the flag lands after the block
-      SPL_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(px->peer_flags[(size_t)q] + px->rank), (int)step, 1, t));
-    }
-    if (bytes) SPL_HIP(hipMemcpyAsync(px->buf[b] + r0, d_y_local, bytes, hipMemcpyDeviceToDevice, s));
     if (px->world > 1)
-      hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, px->flags, px->world, px->rank, step, px->error);
-    *y_full = px->buf[b];
+      hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, px->flags, px->chunks * px->world, px->world, px->rank,
+                         step, px->error);
+    *y_full = px->buf[step & 1u];
     SPL_HIP(hipGetLastError());
     return SPL_OK;
   } catch (const DeviceError &e) {

@@ -171,30 +171,36 @@ class _DevicePointerView(object):
 
 
 class PeerStoreRowBlockSpMV(object):
-    """The step of RowBlockSpMV with a ONE-SIDED exchange instead of the collective (csrc/peer.hip): every
-    rank pushes its block of y into every peer's copy with device-to-device copies on one stream per peer
-    (one per xGMI link, the copy engines move the data: no collective kernel takes CUs from the SpMV), then
-    a step flag; a one-thread kernel on the compute stream waits for the peers' flags.  Peers' buffers are
-    mapped through IPC handles exchanged once over the process group.  Two receive buffers alternate, so
-    the tensor a step returns stays valid until the step after next.  Results are those of RowBlockSpMV
-    (row sums never cross ranks)."""
+    """The step of RowBlockSpMV / PipelinedRowBlockSpMV with a ONE-SIDED exchange instead of the collective
+    (csrc/peer.hip): every rank pushes its piece of y into every peer's copy with device-to-device copies on
+    one stream per peer (one per xGMI link, the copy engines move the data: no collective kernel takes CUs
+    from the SpMV), then a step flag; a one-thread kernel on the compute stream waits for the peers' flags.
+    Peers' buffers are mapped through IPC handles exchanged once over the process group.  With `chunks` > 1
+    the rank owns pieces c * world + rank of pipelined_piece_bounds (one local product per chunk) and the
+    copies of chunk c run under the kernel of chunk c + 1.  Two receive buffers alternate, so the tensor a
+    step returns stays valid until the step after next.  Results are those of RowBlockSpMV (row sums never
+    cross ranks or chunks)."""
 
-    def __init__(self, n, bounds, rank, world, local_spmv, device, stream_getter, group=None):
+    def __init__(self, n, rank, world, chunks, local_spmvs, device, stream_getter, group=None):
         import ctypes as C
         import torch
         import torch.distributed as dist
         from . import _ffi
         self.torch, self._ffi, self._C = torch, _ffi, C
-        self.n, self.bounds, self.rank, self.world = int(n), [int(b) for b in bounds], int(rank), int(world)
-        assert len(self.bounds) == world + 1 and self.bounds[0] == 0 and self.bounds[-1] == n
-        self.local_spmv, self.stream_getter = local_spmv, stream_getter
-        r0, r1 = self.bounds[rank], self.bounds[rank + 1]
-        self.y_local = torch.zeros(r1 - r0, dtype=torch.float64, device=device)
+        self.n, self.rank, self.world, self.chunks = int(n), int(rank), int(world), int(chunks)
+        self.bounds = pipelined_piece_bounds(self.n, world, chunks) if chunks > 1 else equal_row_bounds(self.n, world)
+        self.local_spmvs, self.stream_getter = list(local_spmvs), stream_getter
+        assert len(self.local_spmvs) == self.chunks
+        self.y_local = []
+        for c in range(self.chunks):
+            a, b = self.rows_of(c)
+            self.y_local.append(torch.zeros(b - a, dtype=torch.float64, device=device))
         L = _ffi.lib()
         self._h = C.c_void_p()
         mine = C.create_string_buffer(192)
-        b = (C.c_int64 * (world + 1))(*self.bounds)
-        _ffi.check("spl_peer_exchange_create", L.spl_peer_exchange_create(rank, world, self.n, b, mine, C.byref(self._h)))
+        barr = (C.c_int64 * len(self.bounds))(*self.bounds)
+        _ffi.check("spl_peer_exchange_create",
+                   L.spl_peer_exchange_create(rank, world, self.chunks, self.n, barr, mine, C.byref(self._h)))
         handles = [None] * world
         if world > 1:
             dist.all_gather_object(handles, mine.raw, group=group)
@@ -206,16 +212,21 @@ class PeerStoreRowBlockSpMV(object):
         self._views = {}
         self.y_full = None
 
+    def rows_of(self, c):
+        q = c * self.world + self.rank
+        return self.bounds[q], self.bounds[q + 1]
+
     def step(self, x):
-        C = self._C
-        self.local_spmv(x, self.y_local)
+        C, L = self._C, self._ffi.lib()
+        s = C.c_void_p(self.stream_getter())
+        for c in range(self.chunks):
+            self.local_spmvs[c](x, self.y_local[c])
+            self._ffi.check("spl_peer_exchange_push", L.spl_peer_exchange_push(self._h, c, C.c_void_p(self.y_local[c].data_ptr()), s))
         out = C.c_void_p()
-        self._ffi.check("spl_peer_exchange_step",
-                        self._ffi.lib().spl_peer_exchange_step(self._h, C.c_void_p(self.y_local.data_ptr()),
-                                                               C.c_void_p(self.stream_getter()), C.byref(out)))
+        self._ffi.check("spl_peer_exchange_finish", L.spl_peer_exchange_finish(self._h, s, C.byref(out)))
         v = self._views.get(out.value)
         if v is None:
-            v = self.torch.as_tensor(_DevicePointerView(out.value, self.n), device=self.y_local.device)
+            v = self.torch.as_tensor(_DevicePointerView(out.value, self.n), device=self.y_local[0].device)
             self._views[out.value] = v
         self.y_full = v
         return v

@@ -57,7 +57,7 @@ def test_two_ranks_on_one_gpu(gpu, matrix):
     # the same matrix: identical nnz, hence identical algorithmic bytes, whatever the rank count
     assert one["config"]["algorithmic_bytes"] == two["config"]["algorithmic_bytes"]
     assert one["y_sha1"] == two["y_sha1"]  # the gathered y is the single-rank y, bit for bit
-    assert set(two["config"]["exchange_ms_per_step_by_chunks"]) == {"1", "2", "4", "peer"}  # all candidates were measured
+    assert set(two["config"]["exchange_ms_per_step_by_chunks"]) == {"rccl1", "rccl2", "rccl4", "peer1", "peer2", "peer4"}  # all candidates were measured
 
 
 def test_pipelined_exchange_forced(gpu):
@@ -66,7 +66,7 @@ def test_pipelined_exchange_forced(gpu):
     args = ["--rows", "480000"]
     one = _run(1, args)
     for nproc, chunks in ((2, 4), (3, 2), (2, 1)):
-        out = _run(nproc, args, chunks=chunks)
+        out = _run(nproc, args, chunks=chunks, exchange="rccl")
         assert out["y_sha1"] == one["y_sha1"], (nproc, chunks)
         assert out["config"]["algorithmic_bytes"] == one["config"]["algorithmic_bytes"]
         if chunks > 1:
@@ -86,13 +86,17 @@ def test_two_ranks_order_free(gpu):
         assert abs(one[k] - two[k]) <= 1e-12 * abs(one[k])
 
 
-@pytest.mark.parametrize("nproc", [2, 3])
-def test_peer_store_exchange_forced(gpu, nproc):
+@pytest.mark.parametrize("nproc,chunks", [(2, 1), (3, 1), (2, 4), (3, 2)])
+def test_peer_store_exchange_forced(gpu, nproc, chunks):
     """the one-sided exchange (csrc/peer.hip: device-to-device copies into the peers' buffers through IPC
-    handles, step flags, a wait kernel) forced on: N = 2 and 3 give the y of one rank, bit for bit"""
+    handles, step flags, a wait kernel) forced on, in one piece and pipelined over chunks: N = 2 and 3 give
+    the y of one rank, bit for bit"""
     args = ["--rows", "480000"]
     one = _run(1, args)
-    out = _run(nproc, args, exchange="peer")
+    out = _run(nproc, args, chunks=chunks, exchange="peer")
     assert "one-sided peer stores" in out["config"]["workload"]
+    if chunks > 1:
+        assert "%d chunks per rank" % chunks in out["config"]["workload"]
+        assert out["roofline"]["launches_per_step"] == chunks
     assert out["y_sha1"] == one["y_sha1"]
     assert out["config"]["algorithmic_bytes"] == one["config"]["algorithmic_bytes"]
