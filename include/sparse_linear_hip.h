@@ -114,6 +114,18 @@ int spl_kronecker(int nrowsA, int ncolsA, const int *Ap, const int *Ai, const do
                   int ncolsB, const int *Bp, const int *Bi, const double *Bx, int *nrowsC, int *ncolsC,
                   int **Cp, int **Ci, double **Cx);
 
+/* hcat / vcat / fromBlocks / fromBlocksDiag (Sparse.hs:500-595) in one call: nblocks CSC blocks (block b is
+ * nrows[b] x ncols[b] with arrays Ap[b], Ai[b], Ax[b]) are placed at (row_off[b], col_off[b]) of an
+ * nrowsC x ncolsC result.  Column c of the result is the concatenation, in list order, of the columns of the
+ * blocks that cover it, rows shifted by the block's row offset (vcat's copyWithOffset, Sparse.hs:551-559):
+ * blocks sharing columns must be listed by ascending row offset, as vcat stacks them.  hcat: row_off = 0,
+ * col_off = running widths; vcat: col_off = 0, row_off = running heights; fromBlocks: both.  value_width = 1
+ * (double) or 2 (packed Complex Double: the entries are moved, never combined).  Outputs malloc()'d as for
+ * spl_spgemm; SPL_ERROR_dimension_mismatch if a block leaves the result. */
+int spl_assemble_blocks(int nblocks, const int *nrows, const int *ncols, const int *const *Ap, const int *const *Ai,
+                        const double *const *Ax, int value_width, const int *row_off, const int *col_off, int nrowsC,
+                        int ncolsC, int **Cp, int **Ci, double **Cx);
+
 /* d[c] = A[c,c], or 0 where no entry is stored, c < min(nrows, ncols) (`takeDiag`, Sparse.hs:636-648) */
 int spl_take_diag(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax, double *d);
 

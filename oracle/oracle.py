@@ -378,6 +378,96 @@ def take_diag(m):
     return out
 
 
+def hcat(mats):
+    """hcat (Sparse.hs:504-522): pointers = scan of the concatenated column lengths, indices / values
+    concatenated; tuples (nrows, ncols, pointers, indices, values)"""
+    mats = [_matc(m) for m in mats]
+    if not mats:
+        raise OracleError("hcat: empty list")
+    if any(m[0] != mats[0][0] for m in mats):
+        raise OracleError("hcat: nrows mismatch")
+    lens = np.concatenate([np.diff(m[2][:m[1] + 1]) for m in mats])
+    ptrs = np.concatenate([[0], np.cumsum(lens)]).astype(I64)
+    return (mats[0][0], sum(m[1] for m in mats), ptrs, np.concatenate([m[3] for m in mats]).astype(I64),
+            np.concatenate([m[4] for m in mats]))
+
+
+def vcat(mats):
+    """vcat (Sparse.hs:528-559): pointers summed; column c = the blocks' columns c one after the other in list
+    order, row indices offset by the heights above (copyWithOffset)"""
+    mats = [_matc(m) for m in mats]
+    if not mats:
+        raise OracleError("vcat: empty list")
+    ncols = mats[0][1]
+    if any(m[1] != ncols for m in mats):
+        raise OracleError("vcat: ncols mismatch")
+    ptrs = np.sum([m[2][:ncols + 1] for m in mats], axis=0).astype(I64)
+    nz = int(ptrs[-1])
+    cplx = any(np.iscomplexobj(m[4]) for m in mats)
+    idx = np.zeros(nz, dtype=I64)
+    val = np.zeros(nz, dtype=np.complex128 if cplx else F64)
+    offs = np.concatenate([[0], np.cumsum([m[0] for m in mats])])
+    for c in range(ncols):
+        ix = int(ptrs[c])
+        for m, off in zip(mats, offs):
+            a, b = int(m[2][c]), int(m[2][c + 1])
+            idx[ix:ix + b - a] = m[3][a:b] + off
+            val[ix:ix + b - a] = m[4][a:b]
+            ix += b - a
+    return (int(offs[-1]), ncols, ptrs, idx, val)
+
+
+def zeros(nrows, ncols):
+    return (nrows, ncols, np.zeros(ncols + 1, dtype=I64), np.zeros(0, dtype=I64), np.zeros(0, dtype=F64))  # :671-677
+
+
+def fromBlocks(blocks):
+    """fromBlocks = vcat . map hcat . adjustDims (Sparse.hs:563-587): None = a zero block whose height / width
+    come from the other blocks of its block row / column"""
+    rows = [[None if m is None else _matc(m) for m in r] for r in blocks]
+    cols = [[r[c] for r in rows if c < len(r)] for c in range(max(len(r) for r in rows))]
+
+    def spec(groups, k, what):
+        out = []
+        for g in groups:
+            ds = [m[k] for m in g if m is not None]
+            if not ds:
+                raise OracleError("fromBlocks: underspecified " + what)
+            if any(d != ds[0] for d in ds):
+                raise OracleError("fromBlocks: incompatible " + what)
+            out.append(ds[0])
+        return out
+
+    heights, widths = spec(rows, 0, "heights"), spec(cols, 1, "widths")
+    return vcat([hcat([m if m is not None else zeros(heights[r], widths[c]) for c, m in enumerate(row)])
+                 for r, row in enumerate(rows)])
+
+
+def fromBlocksDiag(blocks):
+    """fromBlocksDiag (Sparse.hs:589-597): blocks listed by (super-)diagonals: transpose, pad, rotate row n by n"""
+    blocks = [list(b) for b in blocks]
+    n = len(blocks)
+    trans = [[b[i] for b in blocks if i < len(b)] for i in range(max(len(b) for b in blocks))]
+    out = []
+    for k, as_ in enumerate(trans):
+        as_ = as_ + [None] * (n - len(as_))
+        cut = len(as_) - k
+        out.append(as_[cut:] + as_[:cut])
+    return fromBlocks(out)
+
+
+def blockDiag(mats):
+    mats = list(mats)
+    return fromBlocksDiag([mats] + [[None] * len(mats) for _ in range(len(mats) - 1)])  # :659-665
+
+
+def _matc(m):
+    """like _mat, but complex values stay complex"""
+    nrows, ncols, p, i, x = m
+    x = np.asarray(x)
+    return (int(nrows), int(ncols), _c64(p), _c64(i), np.ascontiguousarray(x, dtype=np.complex128 if np.iscomplexobj(x) else F64))
+
+
 # -- solve --------------------------------------------------------------------------------
 
 def linear_solve(m, b, sys=0):

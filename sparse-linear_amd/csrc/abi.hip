@@ -835,6 +835,70 @@ int spl_spgemm(int nrowsA, int ncolsA, const int *Ap, const int *Ai, const doubl
   });
 }
 
+// hcat / vcat / fromBlocks / fromBlocksDiag (Sparse.hs:500-595): nblocks CSC blocks placed at (row_off, col_off)
+// of an nrowsC x ncolsC result; see include/sparse_linear_hip.h
+int spl_assemble_blocks(int nblocks, const int *nrows, const int *ncols, const int *const *Ap, const int *const *Ai,
+                        const double *const *Ax, int value_width, const int *row_off, const int *col_off, int nrowsC,
+                        int ncolsC, int **Cp, int **Ci, double **Cx) {
+  if (!Cp || !Ci || !Cx) return SPL_ERROR_argument_missing;
+  *Cp = nullptr; *Ci = nullptr; *Cx = nullptr;
+  if (nblocks < 0 || nrowsC < 0 || ncolsC < 0 || (value_width != 1 && value_width != 2)) return SPL_ERROR_argument_missing;
+  if (nblocks > 0 && (!nrows || !ncols || !Ap || !Ai || !Ax || !row_off || !col_off)) return SPL_ERROR_argument_missing;
+  for (int b = 0; b < nblocks; ++b) {
+    if (nrows[b] < 0 || ncols[b] < 0 || row_off[b] < 0 || col_off[b] < 0 || (int64_t)row_off[b] + nrows[b] > nrowsC ||
+        (int64_t)col_off[b] + ncols[b] > ncolsC)
+      return SPL_ERROR_dimension_mismatch;
+    if (!Ap[b]) return SPL_ERROR_argument_missing;
+  }
+  return guarded([&]() -> int {
+    (void)current_device();
+    hipStream_t s = nullptr;
+    std::vector<DBuf<int>> dp((size_t)nblocks), di((size_t)nblocks);
+    std::vector<DBuf<double>> dx((size_t)nblocks);
+    std::vector<const int *> pp((size_t)nblocks), pi((size_t)nblocks);
+    std::vector<const double *> px((size_t)nblocks);
+    for (int b = 0; b < nblocks; ++b) {
+      const int64_t nz = Ap[b][ncols[b]];
+      if (nz < 0 || (nz > 0 && (!Ai[b] || !Ax[b]))) return SPL_ERROR_argument_missing;
+      upload(dp[(size_t)b], Ap[b], (size_t)ncols[b] + 1, s);
+      upload(di[(size_t)b], Ai[b], (size_t)nz, s);
+      upload(dx[(size_t)b], Ax[b], (size_t)nz * (size_t)value_width, s);
+      int st = validate_compressed(dp[(size_t)b].get(), di[(size_t)b].get(), ncols[b], nrows[b], nz, s);
+      if (st != SPL_OK) return st;
+      pp[(size_t)b] = dp[(size_t)b].get();
+      pi[(size_t)b] = di[(size_t)b].get();
+      px[(size_t)b] = dx[(size_t)b].get();
+    }
+    DBuf<int64_t> dCp;
+    DBuf<int> dCi;
+    DBuf<double> dCx;
+    int64_t nnzC = 0;
+    blocks_assemble_device(nblocks, ncols, pp.data(), pi.data(), px.data(), value_width, row_off, col_off, ncolsC, dCp, dCi,
+                           dCx, &nnzC, s);
+    if (nnzC >= 0x7fffffffLL) return SPL_ERROR_index_overflow;
+    // download (values are value_width doubles per entry)
+    int *hp = (int *)malloc(((size_t)ncolsC + 1) * sizeof(int));
+    int *hi = (int *)malloc((size_t)(nnzC ? nnzC : 1) * sizeof(int));
+    double *hx = (double *)malloc((size_t)(nnzC ? nnzC : 1) * (size_t)value_width * sizeof(double));
+    if (!hp || !hi || !hx) { free(hp); free(hi); free(hx); return SPL_ERROR_out_of_memory; }
+    try {
+      DBuf<int> dCp32((size_t)ncolsC + 1);
+      narrow_i64_to_i32(dCp.get(), dCp32.get(), (int64_t)ncolsC + 1, s);
+      SPL_HIP(hipMemcpyAsync(hp, dCp32.get(), ((size_t)ncolsC + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+      if (nnzC) {
+        SPL_HIP(hipMemcpyAsync(hi, dCi.get(), (size_t)nnzC * sizeof(int), hipMemcpyDeviceToHost, s));
+        SPL_HIP(hipMemcpyAsync(hx, dCx.get(), (size_t)nnzC * (size_t)value_width * sizeof(double), hipMemcpyDeviceToHost, s));
+      }
+      SPL_HIP(hipStreamSynchronize(s));
+    } catch (...) {
+      free(hp); free(hi); free(hx);
+      throw;
+    }
+    *Cp = hp; *Ci = hi; *Cx = hx;
+    return SPL_OK;
+  });
+}
+
 int spl_lin(double alpha, int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Ax,
             double beta, int nrowsB, int ncolsB, const int *Bp, const int *Bi, const double *Bx,
             int *nrowsC, int *ncolsC, int **Cp, int **Ci, double **Cx) {

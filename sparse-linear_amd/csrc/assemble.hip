@@ -321,6 +321,64 @@ void kronecker_device(int nrowsB, const int *Ap, const int *Ai, const double *Ax
   SPL_HIP(hipStreamSynchronize(s));
 }
 
+// ---- block assembly: hcat / vcat / fromBlocks / fromBlocksDiag (Sparse.hs:500-595) -----------------------
+// The result's column c is the concatenation, in list order, of column c - col_off[b] of every block b that
+// covers it, row indices shifted by row_off[b] (vcat's copyWithOffset, Sparse.hs:551-559; hcat is the case of
+// disjoint column ranges, fromBlocks = vcat . map hcat places block (r, c) at the summed heights / widths).
+// Blocks that share columns must be listed by ascending row offset (they are: vcat stacks in list order), so
+// every result column ascends.
+__global__ __launch_bounds__(256) void blocks_count_kernel(int ncols_b, const int *__restrict__ Bp, int col_off,
+                                                          int *__restrict__ len) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < ncols_b) len[col_off + c] += Bp[c + 1] - Bp[c];  // one launch per block, in stream order: no race
+}
+
+// one wavefront per column of the block: copy it behind what earlier blocks put into that result column
+__global__ __launch_bounds__(256) void blocks_copy_kernel(int ncols_b, const int *__restrict__ Bp, const int *__restrict__ Bi,
+                                                         const double *__restrict__ Bx, int vw, int row_off, int col_off,
+                                                         int64_t *__restrict__ cursor, int *__restrict__ Ci,
+                                                         double *__restrict__ Cx) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= ncols_b) return;
+  const int s = Bp[c], n = Bp[c + 1] - s;
+  const int64_t dst = cursor[col_off + c];
+  for (int t = lane; t < n; t += 64) {
+    Ci[dst + t] = Bi[s + t] + row_off;
+    for (int k = 0; k < vw; ++k) Cx[(dst + t) * vw + k] = Bx[(size_t)(s + t) * vw + k];
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) cursor[col_off + c] = dst + n;
+}
+
+void blocks_assemble_device(int nblocks, const int *ncols_b, const int *const *d_Bp, const int *const *d_Bi,
+                            const double *const *d_Bx, int vw, const int *row_off, const int *col_off, int64_t ncolsC,
+                            DBuf<int64_t> &Cp, DBuf<int> &Ci, DBuf<double> &Cx, int64_t *nnzC, hipStream_t s) {
+  DBuf<int> len((size_t)ncolsC + 1);
+  SPL_HIP(hipMemsetAsync(len.get(), 0, ((size_t)ncolsC + 1) * sizeof(int), s));
+  for (int b = 0; b < nblocks; ++b)
+    if (ncols_b[b] > 0)
+      hipLaunchKernelGGL(blocks_count_kernel, dim3((unsigned)((ncols_b[b] + 255) / 256)), dim3(256), 0, s, ncols_b[b], d_Bp[b],
+                         col_off[b], len.get());
+  Cp.alloc((size_t)ncolsC + 1);
+  exclusive_scan_i32_to_i64(len.get(), Cp.get(), ncolsC, s);
+  int64_t nz = 0;
+  SPL_HIP(hipMemcpyAsync(&nz, Cp.get() + ncolsC, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  SPL_HIP(hipStreamSynchronize(s));
+  *nnzC = nz;
+  Ci.alloc((size_t)nz);
+  Cx.alloc((size_t)nz * (size_t)vw);
+  if (nz == 0) return;
+  DBuf<int64_t> cursor((size_t)ncolsC + 1);
+  SPL_HIP(hipMemcpyAsync(cursor.get(), Cp.get(), ((size_t)ncolsC + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+  for (int b = 0; b < nblocks; ++b)
+    if (ncols_b[b] > 0)
+      hipLaunchKernelGGL(blocks_copy_kernel, dim3((unsigned)((ncols_b[b] + 3) / 4)), dim3(256), 0, s, ncols_b[b], d_Bp[b], d_Bi[b],
+                         d_Bx[b], vw, row_off[b], col_off[b], cursor.get(), Ci.get(), Cx.get());
+  SPL_HIP(hipGetLastError());
+  SPL_HIP(hipStreamSynchronize(s));
+}
+
 void take_diag_device(const int *Ap, const int *Ai, const double *Ax, int n, double *d, hipStream_t s) {
   if (n > 0)
     hipLaunchKernelGGL(take_diag_kernel, dim3((unsigned)(((size_t)n * 8 + 255) / 256)), dim3(256), 0, s, Ap, Ai, Ax,

@@ -194,6 +194,10 @@ void kronecker_device(int nrowsB, const int *Ap, const int *Ai, const double *Ax
                       const int *Bi, const double *Bx, int64_t ncolsB, DBuf<int64_t> &Cp, DBuf<int> &Ci,
                       DBuf<double> &Cx, int64_t *nnzC, hipStream_t s);
 void take_diag_device(const int *Ap, const int *Ai, const double *Ax, int n, double *d, hipStream_t s);
+// place blocks at (row_off, col_off) of a result with ncolsC columns; vw = doubles per value (1 real, 2 complex)
+void blocks_assemble_device(int nblocks, const int *ncols_b, const int *const *d_Bp, const int *const *d_Bi,
+                            const double *const *d_Bx, int vw, const int *row_off, const int *col_off, int64_t ncolsC,
+                            DBuf<int64_t> &Cp, DBuf<int> &Ci, DBuf<double> &Cx, int64_t *nnzC, hipStream_t s);
 
 // ---- multifrontal LU without interchanges (multifrontal.hip, mf_symbolic.hpp) ------------------
 namespace mf {

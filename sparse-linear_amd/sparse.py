@@ -547,16 +547,46 @@ def takeDiag(mat):
     return out
 
 
+def _assemble(blocks, row_off, col_off, nrows, ncols):
+    """place CSC blocks at (row_off, col_off) of an nrows x ncols result on the device (spl_assemble_blocks,
+    csrc/assemble.hip): the one kernel pair behind hcat / vcat / fromBlocks / fromBlocksDiag"""
+    _ffi.require_gpu()
+    k = len(blocks)
+    cplx = any(m.is_complex for m in blocks)
+    keep = []  # the int32 / float64 copies must outlive the call
+    nr, nc = (C.c_int * k)(), (C.c_int * k)()
+    ro, co = (C.c_int * k)(*[int(v) for v in row_off]), (C.c_int * k)(*[int(v) for v in col_off])
+    ap, ai, ax = (C.c_void_p * k)(), (C.c_void_p * k)(), (C.c_void_p * k)()
+    for b, m in enumerate(blocks):
+        vals = m.values.astype(C128) if cplx else m.values
+        t = (as_i32(m.pointers), as_i32(m.indices), as_f64(vals.view(F64) if cplx else vals))
+        keep.append(t)
+        nr[b], nc[b] = m.nrows, m.ncols
+        ap[b], ai[b], ax[b] = t[0].ctypes.data, t[1].ctypes.data, t[2].ctypes.data
+    cp, ci, cx = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    fn = lib().spl_assemble_blocks
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                   C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int,
+                   C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    st = fn(k, nr, nc, ap, ai, ax, 2 if cplx else 1, ro, co, int(nrows), int(ncols), C.byref(cp), C.byref(ci), C.byref(cx))
+    check("spl_assemble_blocks", st)
+    ptrs = _ffi.take_malloced(cp, ncols + 1, C.c_int, np.int32)
+    nz = int(ptrs[-1])
+    idx = _ffi.take_malloced(ci, max(nz, 1), C.c_int, np.int32)[:nz]
+    val = _ffi.take_malloced(cx, max(nz, 1) * (2 if cplx else 1), C.c_double, F64)[:nz * (2 if cplx else 1)]
+    return Matrix(ncols, nrows, ptrs, idx, val.view(C128) if cplx else val)
+
+
 def hcat(mats):
+    """hcat (Sparse.hs:504-522), assembled on the device"""
     mats = list(mats)
     if not mats:
         _oops("hcat", "empty list")
     if any(m.nrows != mats[0].nrows for m in mats):
         _oops("hcat", "nrows mismatch")
-    lens = np.concatenate([_lengths(m) for m in mats])
-    ptrs = np.concatenate([[0], np.cumsum(lens)]).astype(I64)
-    return Matrix(sum(m.ncols for m in mats), mats[0].nrows, ptrs, np.concatenate([m.indices for m in mats]),
-                  np.concatenate([m.values for m in mats]))  # :504-522
+    widths = [m.ncols for m in mats]
+    return _assemble(mats, [0] * len(mats), np.concatenate([[0], np.cumsum(widths)])[:-1], mats[0].nrows, sum(widths))
 
 
 def hjoin(a, b):
@@ -564,27 +594,15 @@ def hjoin(a, b):
 
 
 def vcat(mats):
+    """vcat (Sparse.hs:528-559), assembled on the device: blocks stacked in list order inside every column"""
     mats = list(mats)
     if not mats:
         _oops("vcat", "empty list")
     ncols = mats[0].ncols
     if any(m.ncols != ncols for m in mats):
         _oops("vcat", "ncols mismatch")
-    ptrs = np.sum([m.pointers for m in mats], axis=0).astype(I64)  # :545
-    nz = int(ptrs[-1])
-    idx = np.zeros(nz, dtype=I64)
-    val = np.zeros(nz, dtype=F64)
-    offs = np.concatenate([[0], np.cumsum([m.nrows for m in mats])])
-    cursor = ptrs[:-1].copy()
-    for m, off in zip(mats, offs):  # column c: blocks stacked in list order (:551-559)
-        ln = _lengths(m)
-        if int(m.pointers[-1]) == 0:
-            continue
-        dst = np.repeat(cursor - m.pointers[:-1], ln) + np.arange(int(m.pointers[-1]))
-        idx[dst] = m.indices + off
-        val[dst] = m.values
-        cursor = cursor + ln
-    return Matrix(ncols, int(offs[-1]), ptrs, idx, val)
+    heights = [m.nrows for m in mats]
+    return _assemble(mats, np.concatenate([[0], np.cumsum(heights)])[:-1], [0] * len(mats), sum(heights), ncols)
 
 
 def vjoin(a, b):
@@ -592,7 +610,9 @@ def vjoin(a, b):
 
 
 def fromBlocks(blocks):
-    """[[Maybe Matrix]] -> Matrix, None = zero block (Sparse.hs:563-587)."""
+    """[[Maybe Matrix]] -> Matrix, None = zero block (Sparse.hs:563-587): vcat . map hcat . adjustDims in one
+    device assembly — block (r, c) sits at (sum of the heights above, sum of the widths to the left), listed
+    row-major so that blocks sharing columns come by ascending row offset."""
     rows = [list(r) for r in blocks]
     ncb = max(len(r) for r in rows)
     cols = [[r[c] for r in rows if c < len(r)] for c in range(ncb)]
@@ -610,8 +630,22 @@ def fromBlocks(blocks):
 
     heights = spec(rows, "nrows", "heights")
     widths = spec(cols, "ncols", "widths")
-    return vcat([hcat([m if m is not None else zeros(heights[r], widths[c]) for c, m in enumerate(row)])
-                 for r, row in enumerate(rows)])
+    roff = np.concatenate([[0], np.cumsum(heights)])
+    # hcat of a block row fails in the reference when the rows' widths differ in total (vcat: ncols mismatch)
+    totals = [sum(widths[:len(r)]) for r in rows]
+    if any(t != totals[0] for t in totals):
+        _oops("vcat", "ncols mismatch")
+    coff = np.concatenate([[0], np.cumsum(widths)])
+    placed, ro, co = [], [], []
+    for r, row in enumerate(rows):
+        for c, m in enumerate(row):
+            if m is not None:
+                placed.append(m)
+                ro.append(roff[r])
+                co.append(coff[c])
+    if not placed:  # every block a zero block cannot happen: heights would be underspecified
+        return zeros(int(roff[-1]), totals[0])
+    return _assemble(placed, ro, co, int(roff[-1]), totals[0])
 
 
 def fromBlocksDiag(blocks):

@@ -235,3 +235,74 @@ def test_kronecker_large_and_edges(gpu, pkg, O):
     Kc = pkg.kronecker(Cm, Cm)
     assert np.array_equal(pkg.pack(Kc), np.kron(pkg.pack(Cm), pkg.pack(Cm)))
     assert np.array_equal(pkg.takeDiag(Cm), np.array([1 + 2j, 3 - 1j]))
+
+
+# ---- hcat / vcat / fromBlocks / fromBlocksDiag on the device (spl_assemble_blocks) against the oracle's
+# restatement of Sparse.hs:500-595 ----------------------------------------------------------------------
+def _rand_mat(pkg, O, rng, nr, nc, k, cplx=False):
+    A = O.compress(nr, nc, rng.integers(0, nr, k), rng.integers(0, nc, k), rng.integers(-9, 10, k).astype(float))
+    vals = A[4] + 1j * rng.integers(-9, 10, len(A[4])) if cplx else A[4]
+    return pkg.Matrix(nc, nr, A[2], A[3], vals)
+
+
+def _same(M, t):
+    return (M.nrows, M.ncols) == (t[0], t[1]) and np.array_equal(M.pointers, t[2]) and np.array_equal(M.indices, t[3]) \
+        and np.array_equal(M.values, t[4])
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_hcat_vcat_match_oracle(gpu, pkg, O, cplx):
+    rng = np.random.default_rng(11 + cplx)
+    for _ in range(6):
+        nr = int(rng.integers(1, 40))
+        mats = [_rand_mat(pkg, O, rng, nr, int(rng.integers(1, 30)), int(rng.integers(0, 80)), cplx and i % 2 == 0)
+                for i in range(int(rng.integers(1, 6)))]
+        H = pkg.hcat(mats)
+        assert _same(H, O.hcat([mat_to_tuple(m) for m in mats]))
+        assert O.check_matrix((H.nrows, H.ncols, H.pointers, H.indices, np.abs(H.values))) == 0
+        nc = int(rng.integers(1, 40))
+        mats = [_rand_mat(pkg, O, rng, int(rng.integers(1, 30)), nc, int(rng.integers(0, 80)), cplx and i % 2 == 1)
+                for i in range(int(rng.integers(1, 6)))]
+        V = pkg.vcat(mats)
+        assert _same(V, O.vcat([mat_to_tuple(m) for m in mats]))
+        assert O.check_matrix((V.nrows, V.ncols, V.pointers, V.indices, np.abs(V.values))) == 0
+    A, B = _rand_mat(pkg, O, rng, 7, 5, 20), _rand_mat(pkg, O, rng, 7, 3, 9)
+    assert pkg.hjoin(A, B) == pkg.hcat([A, B]) and pkg.transpose(pkg.hjoin(A, B)) == pkg.vjoin(pkg.transpose(A), pkg.transpose(B))
+    with pytest.raises(pkg.SparseError):
+        pkg.hcat([])
+    with pytest.raises(pkg.SparseError):
+        pkg.hcat([A, pkg.transpose(A)])  # nrows mismatch
+    with pytest.raises(pkg.SparseError):
+        pkg.vcat([A, B])  # ncols mismatch
+
+
+def test_fromBlocks_matches_oracle(gpu, pkg, O):
+    rng = np.random.default_rng(5)
+    hs, ws = [4, 9, 1, 6], [3, 8, 5]
+    blocks = [[None if rng.random() < 0.3 else _rand_mat(pkg, O, rng, h, w, int(rng.integers(0, 30))) for w in ws] for h in hs]
+    for r in range(len(hs)):  # every block row and column keeps one block: dimensions stay specified
+        if all(b is None for b in blocks[r]):
+            blocks[r][0] = _rand_mat(pkg, O, rng, hs[r], ws[0], 5)
+    for c in range(len(ws)):
+        if all(blocks[r][c] is None for r in range(len(hs))):
+            blocks[0][c] = _rand_mat(pkg, O, rng, hs[0], ws[c], 5)
+    M = pkg.fromBlocks(blocks)
+    ref = O.fromBlocks([[None if b is None else mat_to_tuple(b) for b in row] for row in blocks])
+    assert _same(M, ref) and (M.nrows, M.ncols) == (sum(hs), sum(ws))
+    # == vcat . map hcat with explicit zero blocks (Sparse.hs:564)
+    full = pkg.vcat([pkg.hcat([b if b is not None else pkg.zeros(hs[r], ws[c]) for c, b in enumerate(row)])
+                     for r, row in enumerate(blocks)])
+    assert M == full
+    D = pkg.fromBlocksDiag([[blocks[0][0], blocks[1][1], blocks[2][2]], [blocks[0][1], blocks[1][2], None], [None, None, None]])
+    refD = O.fromBlocksDiag([[mat_to_tuple(blocks[0][0]) if blocks[0][0] is not None else None,
+                              mat_to_tuple(blocks[1][1]) if blocks[1][1] is not None else None,
+                              mat_to_tuple(blocks[2][2]) if blocks[2][2] is not None else None],
+                             [mat_to_tuple(blocks[0][1]) if blocks[0][1] is not None else None,
+                              mat_to_tuple(blocks[1][2]) if blocks[1][2] is not None else None, None],
+                             [None, None, None]]) if all(blocks[i][i] is not None for i in range(3)) else None
+    if refD is not None:
+        assert _same(D, refD)
+    with pytest.raises(pkg.SparseError):
+        pkg.fromBlocks([[None, blocks[0][1]], [None, blocks[1][1]]])  # underspecified widths
+    with pytest.raises(pkg.SparseError):
+        pkg.fromBlocks([[pkg.ident(2), pkg.ident(3)], [pkg.ident(3), pkg.ident(3)]])  # incompatible widths / heights
