@@ -536,7 +536,9 @@ bool factor_static_pivot(Numeric *N, const int *Ap, const int *Ai, const double 
   const auto t_begin = std::chrono::steady_clock::now();
   auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
   sp::Transversal T;
-  if (!sp::max_product_transversal(n, Ap, Ai, Ax, T)) return false;
+  double match_seconds = 180.0;  // SPL_LU_MATCH_SECONDS: how long the (sequential, host) matching may take
+  if (const char *ev = getenv("SPL_LU_MATCH_SECONDS")) match_seconds = atof(ev);
+  if (!sp::max_product_transversal(n, Ap, Ai, Ax, T, match_seconds)) return false;
   if (timing) fprintf(stderr, "[static pivot] transversal done at %.1f ms\n", since());
   std::vector<int> Bp, Bi;
   std::vector<double> Bx;
