@@ -91,8 +91,9 @@ __global__ __launch_bounds__(256) void products_kernel(Csc A, Csc B, int64_t nco
   if (owner) {
     nprod[j] = n;
     bin = bin_of(n, qe - qs);
-    // ordered form: columns its own kernel handles (<= 2048 products, <= 256 entries of B) are not listed
-    if (ordered && n <= 2048 && qe - qs <= 256) bin = n == 0 ? 0 : 1;
+    // ordered form: the columns its own kernel handles (<= 2048 products, <= 128 entries of B) are not listed;
+    // every other column must be, also a light one with a long column of B (bin S has no list: it goes with M)
+    if (ordered && n > 0) bin = (n <= 2048 && qe - qs <= 128) ? 1 : (bin < 2 ? 2 : bin);
     if (bin >= 2) pos = atomicAdd(&local_count[bin - 2], 1);
   }
   __syncthreads();
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(256) void compact_columns_kernel(int64_t ncols, con
 // Columns beyond the LDS budget of this kernel (more than 2 048 products or 256 entries in the column of
 // B) are computed beforehand by the kernels above into scratch slots; their owner here only copies them.
 constexpr int kOrdTB = 11;                         // tie-break bits of the packed key: t < 2048
-constexpr int kOrdCap = 2048, kOrdNb = 256;        // column handled by a whole workgroup
+constexpr int kOrdCap = 2048;                      // products of a column handled by a whole workgroup
 constexpr int kOrdWaveCap = 256, kOrdWaveNb = 64;  // column handled by one wavefront (4 per workgroup)
 constexpr int kOrdBucketLimit = 24;
 constexpr int kOrdMaxRowBits = 32 - kOrdTB;        // rows must fit the packed (unsigned) 32-bit key
@@ -496,15 +497,18 @@ struct OrdLds {
 // status word of the look-back chain: bits 62-63 = 0 nothing yet, 1 the column's own length, 2 inclusive prefix
 constexpr unsigned long long kOrdFlagAgg = 1ull << 62, kOrdFlagPrefix = 2ull << 62, kOrdValueMask = (1ull << 62) - 1ull;
 
-// exclusive prefix of column j (sum of the lengths of all columns before it); called by ONE whole wavefront,
-// result wave-uniform.  Publishes the column's own length first and its inclusive prefix last.
-__device__ inline int64_t ord_chain(unsigned long long *__restrict__ status, int64_t j, int64_t count) {
+// The chain.  publish: the column's own length, as soon as it is known (column 0 publishes its inclusive prefix
+// at once).  look-back: exclusive prefix of column j (sum of the lengths of all columns before it), then the
+// column's inclusive prefix is published.  Both are called by ONE whole wavefront; results are wave-uniform.
+__device__ inline void ord_publish(unsigned long long *__restrict__ status, int64_t j, int64_t count) {
+  if ((threadIdx.x & 63) == 0)
+    __hip_atomic_store(status + j, (j == 0 ? kOrdFlagPrefix : kOrdFlagAgg) | (unsigned long long)count, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ inline int64_t ord_lookback(unsigned long long *__restrict__ status, int64_t j, int64_t count) {
   const int lane = threadIdx.x & 63;
-  if (j == 0) {
-    if (lane == 0) __hip_atomic_store(status, kOrdFlagPrefix | (unsigned long long)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return 0;
-  }
-  if (lane == 0) __hip_atomic_store(status + j, kOrdFlagAgg | (unsigned long long)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (j == 0) return 0;
   int64_t sum = 0;
   int64_t p = j - 1;  // nearest predecessor not yet accounted for
   // The nearest predecessor took its ticket just before this column and is usually the last to publish: one
@@ -537,6 +541,11 @@ __device__ inline int64_t ord_chain(unsigned long long *__restrict__ status, int
   if (lane == 0)
     __hip_atomic_store(status + j, kOrdFlagPrefix | (unsigned long long)(sum + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return sum;
+}
+
+__device__ inline int64_t ord_chain(unsigned long long *__restrict__ status, int64_t j, int64_t count) {
+  ord_publish(status, j, count);
+  return ord_lookback(status, j, count);
 }
 
 // merge tree over the nb ascending runs laid out by the expansion (packed keys only): the fallback sort
@@ -832,6 +841,225 @@ __device__ inline void ord_column(const Csc &A, const Csc &B, int64_t j, int np,
   stamp(5);
 }
 
+// ---- the workgroup path, pipelined over two columns -----------------------------------------------------------
+// ord_column above waits in the look-back right after it has published its length: measured on C4, 25-30 % of
+// the kernel's cycles.  Here the workgroup keeps the sorted keys and the products of a column in one of TWO
+// result buffers and goes on to expand and sort its next column; the earlier column is finished (look-back,
+// fold, write) after that — one whole column of work later, when its predecessors have long published.  A
+// workgroup still only ever waits for columns with smaller tickets.
+constexpr int kOrdPNb = 128;           // entries of B's column a pipelined column may have
+constexpr int kOrdPBuckets = 512;
+
+struct OrdPipeLds {  // workspace + two result buffers
+  static constexpr size_t kb_bytes = kOrdPNb * sizeof(double);
+  static constexpr size_t start_bytes = kOrdPNb * sizeof(int);
+  static constexpr size_t off_bytes = (kOrdPNb + 8) * sizeof(int);
+  static constexpr size_t hist_bytes = (kOrdPBuckets + 8) * sizeof(int);
+  static constexpr size_t scratch_bytes = 32 * sizeof(int);
+  static constexpr size_t work_bytes = kb_bytes + start_bytes + off_bytes + hist_bytes + scratch_bytes;
+  static constexpr size_t vals_bytes = kOrdCap * sizeof(double), keys_bytes = kOrdCap * sizeof(unsigned);
+  static constexpr size_t total = work_bytes + 2 * (vals_bytes + keys_bytes);
+};
+
+struct OrdPending {
+  int64_t j = 0;
+  int np = 0, count = 0;
+  int keys_in = 0, vals_in = 0;  // which key / value buffer holds the column
+  bool valid = false;
+};
+
+// finish a column whose sorted keys and products wait in LDS: look-back, fold, write (scratch: 16 ints of its own)
+__device__ inline void ordp_finish(const OrdPending &P, const unsigned *skeys, const double *vals, int *scratch, int tid,
+                                   unsigned long long *__restrict__ status, int64_t *__restrict__ Cp,
+                                   int *__restrict__ Ci, double *__restrict__ Cx) {
+  const int lane = tid & 63;
+  if ((tid >> 6) == 0) {
+    const int64_t e = ord_lookback(status, P.j, P.count);
+    if (lane == 0) { scratch[10] = (int)(e & 0xffffffffll); scratch[11] = (int)(e >> 32); }
+  }
+  __syncthreads();
+  const int64_t base = ((int64_t)scratch[11] << 32) | (int64_t)(unsigned)scratch[10];
+  if (tid == 0) Cp[P.j] = base;
+  const int np = P.np;
+  int running = 0;
+  for (int t0 = 0; t0 < np; t0 += 256) {
+    const int t = t0 + tid;
+    int row = 0;
+    bool head = false;
+    if (t < np) {
+      row = (int)(skeys[t] >> kOrdTB);
+      head = t == 0 || (int)(skeys[t - 1] >> kOrdTB) != row;
+    }
+    const unsigned long long m = __ballot(head);
+    int off = running + __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) scratch[tid >> 6] = __popcll(m);
+    __syncthreads();
+    int total = 0;
+    for (int wv = 0; wv < 4; ++wv) {
+      if (wv < (tid >> 6)) off += scratch[wv];
+      total += scratch[wv];
+    }
+    __syncthreads();
+    if (head) {
+      double acc = 0.0;  // SG.reset 0
+      for (int u = t; u < np; ++u) {
+        const unsigned k = skeys[u];
+        if ((int)(k >> kOrdTB) != row) break;
+        acc = acc + vals[k & ((1u << kOrdTB) - 1u)];  // c + a * b in ascending k
+      }
+      Ci[base + off] = row;
+      Cx[base + off] = acc;
+    }
+    running += total;
+  }
+}
+
+// expand + sort column j into (keys, vals); returns the number of distinct rows, or -1 when a bucket overflowed:
+// then `keys` holds the expanded keys in their original order (nb ascending runs) for the merge tree
+__device__ inline int ordp_sort(const Csc &A, const Csc &B, int64_t j, int np, int bucket_shift, unsigned char *work,
+                                unsigned *keys, double *vals, int tid) {
+  constexpr int NT = 256, CAP = kOrdCap, NBCAP = kOrdPNb, NBK = kOrdPBuckets;
+  double *kb = reinterpret_cast<double *>(work);
+  int *kstart = reinterpret_cast<int *>(work + OrdPipeLds::kb_bytes);
+  int *koff = kstart + NBCAP;
+  int *hist = koff + NBCAP + 8;
+  int *scratch = hist + NBK + 8;
+  const int lane = tid & 63;
+  const int qs = B.p[j];
+  const int nb = B.p[j + 1] - qs;
+  for (int q = tid; q < nb; q += NT) {
+    const int k = B.i[qs + q];
+    const int s = A.p[k];
+    kstart[q] = s;
+    koff[q] = A.p[k + 1] - s;
+    kb[q] = B.x[qs + q];
+  }
+  for (int b = tid; b < NBK + 1; b += NT) hist[b] = 0;
+  if (tid == 0) scratch[8] = 0;
+  __syncthreads();
+  {  // exclusive prefix sum of the extents (nb <= 128: the first two wavefronts hold one entry per lane)
+    const int v = tid < nb ? koff[tid] : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) scratch[tid >> 6] = incl;
+    __syncthreads();
+    if ((tid >> 6) == 1) incl += scratch[0];
+    if (tid < nb) koff[tid] = incl - v;
+    if (tid == 0) koff[nb] = np;
+    __syncthreads();
+  }
+  constexpr int PER = CAP / NT;
+  const int per = (np + NT - 1) / NT;
+  unsigned myk[PER];
+  int myrank[PER];
+  {
+    const int t0 = tid * per;
+    int q = 0;
+    if (t0 < np) {
+      int lo = 0, hi = nb - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (koff[mid] <= t0) lo = mid; else hi = mid - 1;
+      }
+      q = lo;
+    }
+    int pp[PER], qq[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int t = t0 + u;
+      pp[u] = -1;
+      qq[u] = 0;
+      if (u < per && t < np) {
+        while (t >= koff[q + 1]) ++q;
+        pp[u] = kstart[q] + (t - koff[q]);
+        qq[u] = q;
+      }
+    }
+    int rows[PER];
+    double av[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      rows[u] = pp[u] >= 0 ? A.i[pp[u]] : 0;
+      av[u] = pp[u] >= 0 ? A.x[pp[u]] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      myk[u] = 0xffffffffu;
+      myrank[u] = 0;
+      if (pp[u] >= 0) {
+        const int t = t0 + u;
+        myk[u] = ((unsigned)rows[u] << kOrdTB) | (unsigned)t;
+        vals[t] = av[u] * kb[qq[u]];  // a * b, rounded once (Sparse.hs:699)
+        myrank[u] = atomicAdd(&hist[rows[u] >> bucket_shift], 1);
+      }
+    }
+  }
+  __syncthreads();
+  {  // exclusive scan of the histogram: two consecutive buckets per thread
+    const int b0 = tid * 2;
+    const int c0 = hist[b0], c1 = hist[b0 + 1];
+    const int sum = c0 + c1;
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) scratch[tid >> 6] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int wv = 0; wv < (tid >> 6); ++wv) woff += scratch[wv];
+    __syncthreads();
+    const int run = incl + woff - sum;
+    hist[b0] = run;
+    hist[b0 + 1] = run + c0;
+    if (tid == NT - 1) hist[NBK] = np;
+    if (c0 > kOrdBucketLimit || c1 > kOrdBucketLimit) scratch[8] = 1;
+  }
+  __syncthreads();
+  if (scratch[8] != 0) {  // a crowded bucket: hand the keys over in run order, the caller merges them
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+      if (myk[u] != 0xffffffffu) keys[myk[u] & ((1u << kOrdTB) - 1u)] = myk[u];
+    __syncthreads();
+    return -1;
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u)
+    if (myk[u] != 0xffffffffu) keys[hist[(myk[u] >> kOrdTB) >> bucket_shift] + myrank[u]] = myk[u];
+  __syncthreads();
+  for (int b = tid; b < NBK; b += NT) {
+    const int s = hist[b], e = hist[b + 1];
+    for (int i = s + 1; i < e; ++i) {
+      const unsigned k = keys[i];
+      int h = i - 1;
+      while (h >= s && keys[h] > k) { keys[h + 1] = keys[h]; --h; }
+      keys[h + 1] = k;
+    }
+  }
+  __syncthreads();
+  return 0;
+}
+
+// distinct rows of a sorted column (workgroup-wide)
+__device__ inline int ordp_count(const unsigned *skeys, int np, int *scratch, int tid) {
+  int count = 0;
+  for (int t0 = 0; t0 < np; t0 += 256) {
+    const int t = t0 + tid;
+    const bool head = t < np && (t == 0 || (skeys[t] >> kOrdTB) != (skeys[t - 1] >> kOrdTB));
+    count += __popcll(__ballot(head));
+  }
+  if ((tid & 63) == 0) scratch[4 + (tid >> 6)] = count;
+  __syncthreads();
+  count = scratch[4] + scratch[5] + scratch[6] + scratch[7];
+  __syncthreads();
+  return count;
+}
+
 // column classes of the ordered form
 __global__ __launch_bounds__(256) void ord_classify_kernel(Csc B, int64_t ncolsB, const int64_t *__restrict__ nprod,
                                                            unsigned char *__restrict__ cls, int64_t *__restrict__ heavy_prod) {
@@ -839,7 +1067,7 @@ __global__ __launch_bounds__(256) void ord_classify_kernel(Csc B, int64_t ncolsB
   if (j >= ncolsB) return;
   const int64_t np = nprod[j];
   const int nb = B.p[j + 1] - B.p[j];
-  const int c = np == 0 ? 0 : (np <= kOrdWaveCap && nb <= kOrdWaveNb) ? 1 : (np <= kOrdCap && nb <= kOrdNb) ? 2 : 3;
+  const int c = np == 0 ? 0 : (np <= kOrdWaveCap && nb <= kOrdWaveNb) ? 1 : (np <= kOrdCap && nb <= kOrdPNb) ? 2 : 3;
   cls[j] = (unsigned char)c;
   heavy_prod[j] = c == 3 ? np : 0;
 }
@@ -892,6 +1120,22 @@ __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned long long acc_stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long *const local_stamps = stamps ? acc_stamps : nullptr;
+  // pipelined workgroup path: workspace, then the two (values, keys) result buffers
+  unsigned char *work = smem;
+  auto pvals = [&](int i) { return reinterpret_cast<double *>(smem + OrdPipeLds::work_bytes + (size_t)i * OrdPipeLds::vals_bytes); };
+  auto pkeys = [&](int i) {
+    return reinterpret_cast<unsigned *>(smem + OrdPipeLds::work_bytes + 2 * OrdPipeLds::vals_bytes + (size_t)i * OrdPipeLds::keys_bytes);
+  };
+  int *scratch_a = reinterpret_cast<int *>(smem + OrdPipeLds::work_bytes) - 32;  // the workspace's scratch: [0,16) sort, [16,32) finish
+  int *scratch_b = scratch_a + 16;
+  OrdPending pend;
+  auto finish_pending = [&]() {
+    if (pend.valid) {
+      ordp_finish(pend, pkeys(pend.keys_in), pvals(pend.vals_in), scratch_b, tid, status, Cp, Ci, Cx);
+      pend.valid = false;
+      __syncthreads();
+    }
+  };
   for (;;) {
     if (tid == 0) s_tile = (long long)atomicAdd(ticket, 1ull);
     __syncthreads();
@@ -900,6 +1144,7 @@ __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64
     if (tk >= ntasks) break;
     const int64_t task = tasks[tk];
     if (task < 0) {  // four light columns: one wavefront each, no workgroup barrier inside
+      finish_pending();  // (their LDS image overlaps the result buffers)
       const int64_t j = ~task + wave;
       const int cw = j < ncolsB ? (int)cls[j] : -1;
       if (cw == 0) {
@@ -913,7 +1158,22 @@ __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64
       const int64_t j = task;
       const int cw = (int)cls[j];
       if (cw == 1 || cw == 2) {
-        ord_column<256, kOrdCap, kOrdNb>(A, B, j, (int)nprod[j], bucket_shift_group, smem, tid, status, Cp, Ci, Cx, local_stamps);
+        // sort this column into the buffers the pending one does not use, publish its length, THEN finish the
+        // pending column: its look-back has had a whole column of work to become a formality
+        const int kin = pend.valid ? 1 - pend.keys_in : 0, vin = pend.valid ? 1 - pend.vals_in : 0;
+        const int np = (int)nprod[j];
+        int keys_in = kin;
+        const int st = ordp_sort(A, B, j, np, bucket_shift_group, work, pkeys(kin), pvals(vin), tid);
+        if (st < 0) {  // crowded bucket: merge tree over the runs; needs the other key buffer, so finish what waits there
+          finish_pending();
+          const int *koff = reinterpret_cast<const int *>(work + OrdPipeLds::kb_bytes + OrdPipeLds::start_bytes);
+          const unsigned *sorted = ord_merge_tree<256, kOrdCap>(pkeys(kin), pkeys(1 - kin), koff, (int)(B.p[j + 1] - B.p[j]), np, tid);
+          keys_in = sorted == pkeys(kin) ? kin : 1 - kin;
+        }
+        const int count = ordp_count(pkeys(keys_in), np, scratch_a, tid);
+        if (wave == 0) ord_publish(status, j, count);
+        finish_pending();
+        pend.j = j; pend.np = np; pend.count = count; pend.keys_in = keys_in; pend.vals_in = vin; pend.valid = true;
       } else {  // empty, or computed beforehand into its scratch slot: publish the length, copy
         const int cnt = cw == 3 ? heavy_count[j] : 0;
         if (wave == 0) {
@@ -933,8 +1193,32 @@ __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64
       }
     }
   }
+  finish_pending();
   if (stamps && tid == 0)
     for (int i = 0; i < 6; ++i) atomicAdd(stamps + i, acc_stamps[i]);
+}
+
+// products in the columns where the ordered kernel's workgroup path pays (513 ... 2048 products, <= 128 entries of B)
+__global__ __launch_bounds__(256) void ord_share_kernel(Csc B, int64_t ncolsB, const int64_t *__restrict__ nprod,
+                                                        unsigned long long *__restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v = 0;
+  if (j < ncolsB) {
+    const int64_t np = nprod[j];
+    const int nb = B.p[j + 1] - B.p[j];
+    if (np > 2 * kOrdWaveCap && np <= kOrdCap && nb <= kOrdPNb) v = (unsigned long long)np;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
+// upper bound of a column's length in the result: exact for the columns computed beforehand, its products otherwise
+__global__ __launch_bounds__(256) void ord_bound_kernel(int64_t ncolsB, const unsigned char *__restrict__ cls,
+                                                        const int64_t *__restrict__ nprod, const int *__restrict__ heavy_count,
+                                                        int64_t *__restrict__ bound) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < ncolsB) bound[j] = cls[j] == 3 ? (int64_t)heavy_count[j] : nprod[j];
 }
 
 __global__ void ord_total_kernel(const unsigned long long *__restrict__ status, int64_t ncolsB, int64_t *__restrict__ Cp) {
@@ -963,22 +1247,22 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
       dense_list((size_t)ncolsB);
   DBuf<int> list_counts(3), counts((size_t)ncolsB);
   SPL_HIP(hipMemsetAsync(list_counts.get(), 0, 3 * sizeof(int), s));
-  // SPL_SPGEMM_ORDERED=1 selects the ordered form (every column straight to its final place, no compaction;
-  // rows must fit its packed 32-bit keys).  It is NOT the default: measured on MI355X it ties with the
-  // compacting form on C4 (0.030 s vs 0.029 s: what the compaction costs, 17 %, the look-back chain costs
-  // in waiting, 25-30 % of its kernel — profiles/r02_spgemm_ordered_phases.txt) and loses on products of
-  // light columns (scale 20, edge factor 8: 7.4 ms vs 5.1 ms; its 32 KB of LDS per workgroup admit fewer
-  // wavefronts than the plain one-wavefront-per-column kernel).
+  // Which single-pass form?  The ordered form (every column straight to its final place, no compaction, the
+  // pipelined workgroup path) wins where the products sit in columns of about a thousand products — C4: 0.023 s
+  // vs 0.030 s — and loses where they sit in light columns (64 products per column: 8.2 ms vs 5.4 ms; 256 per
+  // column: 47 ms vs 32 ms; its LDS image admits 12 wavefronts per CU where the plain one-wavefront-per-column
+  // kernel runs 32; profiles/r02_spgemm_ordered_phases.txt).  It is taken when at least half of the products
+  // belong to columns of 513 ... 2048 products; SPL_SPGEMM_ORDERED=1 / 0 forces / forbids it.  Its packed 32-bit keys need
+  // nrows <= 2^21.
   const char *ord_env = getenv("SPL_SPGEMM_ORDERED");
   const char *two_pass_env = getenv("SPL_SPGEMM_TWO_PASS"), *split_keys_env = getenv("SPL_SPGEMM_SPLIT_KEYS");
-  const bool ordered_ok = (ord_env && ord_env[0] == '1') && nrowsA <= (1LL << kOrdMaxRowBits) &&
-                          !(two_pass_env && two_pass_env[0] == '1') && !(split_keys_env && split_keys_env[0] == '1');
+  const bool ordered_possible = !(ord_env && ord_env[0] == '0') && nrowsA <= (1LL << kOrdMaxRowBits) &&
+                                !(two_pass_env && two_pass_env[0] == '1') && !(split_keys_env && split_keys_env[0] == '1');
   hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 32)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
-                     medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), ordered_ok ? 1 : 0);
+                     medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 0);
   int hc[3] = {0, 0, 0};
   SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 3 * sizeof(int), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
-  const int nmedium0 = hc[0], nxlarge0 = hc[1], ndense0 = hc[2];
   DBuf<int64_t> pscan((size_t)ncolsB + 1);  // products before column j: its upper-bound output slot
   exclusive_scan_i64(nprod.get(), pscan.get(), ncolsB, s);
   int64_t total_products = 0;
@@ -995,18 +1279,28 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     single_pass = !(force && force[0] == '1') && total_products > 0 &&
                   (double)total_products * 24.0 < 0.5 * (double)free_b;
   }
-  const bool ordered = ordered_ok && single_pass;
-  int nmedium_v = nmedium0, nxlarge_v = nxlarge0, ndense_v = ndense0;
-  if (ordered_ok && !single_pass) {  // the lists were filtered for the ordered form: build the full ones
+  bool ordered = false;
+  if (ordered_possible && single_pass) {
+    if (ord_env && ord_env[0] == '1') {
+      ordered = true;
+    } else {  // the share of the products in columns of the workgroup class
+      DBuf<unsigned long long> share(1);
+      SPL_HIP(hipMemsetAsync(share.get(), 0, sizeof(unsigned long long), s));
+      hipLaunchKernelGGL(ord_share_kernel, dim3(blocks_for(ncolsB, 256)), dim3(256), 0, s, B, ncolsB, nprod.get(), share.get());
+      unsigned long long h = 0;
+      SPL_HIP(hipMemcpyAsync(&h, share.get(), sizeof(h), hipMemcpyDeviceToHost, s));
+      SPL_HIP(hipStreamSynchronize(s));
+      ordered = 2.0 * (double)h >= (double)total_products;
+    }
+  }
+  if (ordered) {  // the columns the ordered kernel handles itself leave the bin lists
     SPL_HIP(hipMemsetAsync(list_counts.get(), 0, 3 * sizeof(int), s));
     hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 32)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
-                       medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 0);
+                       medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 1);
     SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 3 * sizeof(int), hipMemcpyDeviceToHost, s));
     SPL_HIP(hipStreamSynchronize(s));
-    nmedium_v = hc[0]; nxlarge_v = hc[1]; ndense_v = hc[2];
   }
-  const int nmedium = nmedium_v, nxlarge = nxlarge_v, ndense = ndense_v;
-  (void)nmedium0; (void)nxlarge0; (void)ndense0;
+  const int nmedium = hc[0], nxlarge = hc[1], ndense = hc[2];
   typedef EscLds<kMediumProducts, kMediumB, false> LMs;
   typedef EscLds<kLargeProducts, kLargeB, false> LXs;
   typedef EscLds<kLargeProducts, kLargeB, true, false> LXn;
@@ -1128,17 +1422,27 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
                        out_x);
   if (ordered) {
     // ---- every column to its final place, in column order
-    Ci.alloc((size_t)total_products);  // upper bound; trimmed below when many products merged
-    Cx.alloc((size_t)total_products);
+    // capacity of the result: the exact lengths of the columns computed beforehand + the products of the others
+    // (an upper bound; trimmed below when many products merged)
+    int64_t capacity = total_products;
+    if (total_heavy > 0) {
+      hipLaunchKernelGGL(ord_bound_kernel, dim3(blocks_for(ncolsB, 256)), dim3(256), 0, s, ncolsB, cls.get(), nprod.get(),
+                         counts.get(), heavy_prod.get());
+      DBuf<int64_t> bscan((size_t)ncolsB + 1);
+      exclusive_scan_i64(heavy_prod.get(), bscan.get(), ncolsB, s);
+      SPL_HIP(hipMemcpyAsync(&capacity, bscan.get() + ncolsB, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+      SPL_HIP(hipStreamSynchronize(s));
+    }
+    Ci.alloc((size_t)capacity);
+    Cx.alloc((size_t)capacity);
     DBuf<unsigned long long> status((size_t)ncolsB + 1);
     SPL_HIP(hipMemsetAsync(status.get(), 0, ((size_t)ncolsB + 1) * sizeof(unsigned long long), s));
     unsigned long long *ticket = status.get() + ncolsB;
     int rb = 0;
     while ((1LL << rb) < nrowsA) ++rb;
-    const int sh_wave = rb > 7 ? rb - 7 : 0, sh_group = rb > 10 ? rb - 10 : 0;  // 128 / 1024 buckets
+    const int sh_wave = rb > 7 ? rb - 7 : 0, sh_group = rb > 9 ? rb - 9 : 0;  // 128 / 512 buckets
     typedef OrdLds<kOrdWaveCap, kOrdWaveNb> LW;
-    typedef OrdLds<kOrdCap, kOrdNb> LG;
-    const size_t lds = std::max((LW::total + 15) / 16 * 16 * 4, (size_t)LG::total);
+    const size_t lds = std::max((LW::total + 15) / 16 * 16 * 4, (size_t)OrdPipeLds::total);
     int cus = 256;
     {
       int dev = 0;
@@ -1184,7 +1488,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     SPL_HIP(hipStreamSynchronize(s));
     SPL_HIP(hipGetLastError());
     *nnzC = nz;
-    if ((double)nz < 0.75 * (double)total_products) {  // many products merged: give the surplus back
+    if ((double)nz < 0.75 * (double)capacity) {  // many products merged: give the surplus back
       DBuf<int> Ci2((size_t)nz);
       DBuf<double> Cx2((size_t)nz);
       if (nz > 0) {

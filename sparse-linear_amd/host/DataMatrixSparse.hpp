@@ -211,6 +211,84 @@ inline std::vector<double> takeDiag(const Matrix &a) {
   return d;
 }
 
+// hcat / vcat / fromBlocks (Sparse.hs:504-587): one device assembly (spl_assemble_blocks); nullptr = Nothing
+namespace detail {
+inline Matrix assemble(const std::vector<const Matrix *> &blocks, const std::vector<int> &row_off,
+                       const std::vector<int> &col_off, Int nrows, Int ncols) {
+  const int k = (int)blocks.size();
+  std::vector<Const> cs;
+  cs.reserve((size_t)k);
+  for (const Matrix *m : blocks) cs.emplace_back(*m);
+  std::vector<int> nr((size_t)k), nc((size_t)k);
+  std::vector<const int *> ap((size_t)k), ai((size_t)k);
+  std::vector<const double *> ax((size_t)k);
+  for (int b = 0; b < k; ++b) {
+    nr[(size_t)b] = cs[(size_t)b].nrows; nc[(size_t)b] = cs[(size_t)b].ncols;
+    ap[(size_t)b] = cs[(size_t)b].p.data(); ai[(size_t)b] = cs[(size_t)b].i.data(); ax[(size_t)b] = cs[(size_t)b].x;
+  }
+  int *cp = nullptr, *ci = nullptr;
+  double *cx = nullptr;
+  check("assemble", spl_assemble_blocks(k, nr.data(), nc.data(), ap.data(), ai.data(), ax.data(), 1, row_off.data(),
+                                        col_off.data(), (int)nrows, (int)ncols, &cp, &ci, &cx));
+  return adopt((int)nrows, (int)ncols, cp, ci, cx);
+}
+}  // namespace detail
+
+inline Matrix hcat(const std::vector<Matrix> &mats) {
+  if (mats.empty()) detail::oops("hcat", "empty list");
+  std::vector<const Matrix *> bs;
+  std::vector<int> ro, co;
+  Int w = 0;
+  for (const Matrix &m : mats) {
+    if (m.nrows != mats[0].nrows) detail::oops("hcat", "nrows mismatch");
+    bs.push_back(&m); ro.push_back(0); co.push_back((int)w);
+    w += m.ncols;
+  }
+  return detail::assemble(bs, ro, co, mats[0].nrows, w);
+}
+inline Matrix hjoin(const Matrix &a, const Matrix &b) { return hcat({a, b}); }
+
+inline Matrix vcat(const std::vector<Matrix> &mats) {
+  if (mats.empty()) detail::oops("vcat", "empty list");
+  std::vector<const Matrix *> bs;
+  std::vector<int> ro, co;
+  Int h = 0;
+  for (const Matrix &m : mats) {
+    if (m.ncols != mats[0].ncols) detail::oops("vcat", "ncols mismatch");
+    bs.push_back(&m); ro.push_back((int)h); co.push_back(0);
+    h += m.nrows;
+  }
+  return detail::assemble(bs, ro, co, h, mats[0].ncols);
+}
+inline Matrix vjoin(const Matrix &a, const Matrix &b) { return vcat({a, b}); }
+
+// fromBlocks (Sparse.hs:563-587): rectangular list of lists, nullptr = a zero block
+inline Matrix fromBlocks(const std::vector<std::vector<const Matrix *>> &rows) {
+  size_t ncb = 0;
+  for (const auto &r : rows) ncb = std::max(ncb, r.size());
+  std::vector<Int> heights(rows.size(), -1), widths(ncb, -1);
+  for (size_t r = 0; r < rows.size(); ++r)
+    for (size_t c = 0; c < rows[r].size(); ++c)
+      if (const Matrix *m = rows[r][c]) {
+        if (heights[r] >= 0 && heights[r] != m->nrows) detail::oops("fromBlocks", "incompatible heights");
+        if (widths[c] >= 0 && widths[c] != m->ncols) detail::oops("fromBlocks", "incompatible widths");
+        heights[r] = m->nrows;
+        widths[c] = m->ncols;
+      }
+  for (Int h : heights) if (h < 0) detail::oops("fromBlocks", "underspecified heights");
+  for (Int w : widths) if (w < 0) detail::oops("fromBlocks", "underspecified widths");
+  std::vector<Int> roff(rows.size() + 1, 0), coff(ncb + 1, 0);
+  for (size_t r = 0; r < rows.size(); ++r) roff[r + 1] = roff[r] + heights[r];
+  for (size_t c = 0; c < ncb; ++c) coff[c + 1] = coff[c] + widths[c];
+  for (const auto &r : rows) if (coff[r.size()] != coff[rows[0].size()]) detail::oops("vcat", "ncols mismatch");
+  std::vector<const Matrix *> bs;
+  std::vector<int> ro, co;
+  for (size_t r = 0; r < rows.size(); ++r)
+    for (size_t c = 0; c < rows[r].size(); ++c)
+      if (rows[r][c]) { bs.push_back(rows[r][c]); ro.push_back((int)roff[r]); co.push_back((int)coff[c]); }
+  return detail::assemble(bs, ro, co, roff.back(), coff[rows[0].size()]);
+}
+
 }}}  // namespace Data::Matrix::Sparse
 
 namespace Numeric { namespace LinearAlgebra { namespace Umfpack {

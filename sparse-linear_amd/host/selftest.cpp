@@ -120,6 +120,11 @@ int main() {
     EXPECT(A.nrows == n * n && nonZero(A) == 5 * n * n - 4 * n);
     EXPECT(takeDiag(A) == std::vector<double>((size_t)(n * n), 4.0));
     EXPECT(kronecker(ident(3), ident(4)) == ident(12));
+    // hcat / vcat / fromBlocks on the device: [[I2, 0], [0, I3]] == I5; (A | A)^T == A^T over A^T
+    const Matrix i2 = ident(2), i3 = ident(3);
+    EXPECT(fromBlocks({{&i2, nullptr}, {nullptr, &i3}}) == ident(5));
+    EXPECT(transpose(hjoin(A, A)) == vjoin(transpose(A), transpose(A)));
+    EXPECT(nonZero(vcat({A, A, A})) == 3 * nonZero(A));
     std::vector<std::vector<double>> xs, bs;
     for (int j = 0; j < 3; ++j) {
       std::vector<double> x((size_t)(n * n));

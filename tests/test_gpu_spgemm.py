@@ -137,6 +137,15 @@ def test_ordered_form_matches_oracle(gpu, pkg, O, monkeypatch):
     B = O.compress(n, n, brow, bcol, rng.uniform(0.5, 1.5, len(brow)))
     C = pkg.mm(tuple_to_mat(pkg, A), tuple_to_mat(pkg, B))
     assert tuples_equal(mat_to_tuple(C), O.mm(A, B))
+    # very sparse A (one entry per column) times columns of B with 130 ... 300 entries: few products, but more
+    # entries of B than the ordered kernel's own classes take: these columns go through the listed kernels
+    n = 4000
+    A = O.compress(n, n, rng.permutation(n), np.arange(n), rng.uniform(0.5, 1.5, n))
+    brow = np.concatenate([rng.choice(n, k, replace=False) for k in (130, 200, 300, 5, 64, 128, 129)])
+    bcol = np.concatenate([np.full(k, c) for c, k in enumerate((130, 200, 300, 5, 64, 128, 129))])
+    B = O.compress(n, 7, brow, bcol, rng.uniform(0.5, 1.5, len(brow)))
+    C = pkg.mm(tuple_to_mat(pkg, A), tuple_to_mat(pkg, B))
+    assert tuples_equal(mat_to_tuple(C), O.mm(A, B))
     for scale, ef, abc in ((12, 16, (0.45, 0.22, 0.22)), (13, 32, (0.25, 0.25, 0.25))):
         H = pkg.DeviceMatrix.rmat(scale, ef, abc)
         HC, products = H.spgemm(H)
