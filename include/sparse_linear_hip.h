@@ -199,7 +199,10 @@ int spl_matrix_set_variant(void *H, int variant);
 /* Analyse the matrix once (like umfpack_*_symbolic) and build the image variant 0 then uses:
  * the column-blocked image when columns have no locality and x exceeds the L2s
  * (csrc/spmv_blocked.hip), the sliced-ELL image for regular rows with locality
- * (csrc/spmv_sell.hip), or nothing (CSR-stream kernel).  Results are bit-identical either way. */
+ * (csrc/spmv_sell.hip), or nothing (CSR-stream kernel).  Results are bit-identical either way.
+ * After spl_matrix_set_spmv_order(H, SPL_ORDER_FREE) the column-sorted panel image (csrc/spmv_panel.hip) takes
+ * the place of the column-blocked one where it pays; its two launch parameters are then timed against their
+ * neighbours on a scratch vector (about a hundred launches, once) and the fastest pair kept. */
 int spl_matrix_optimize(void *H);
 /* build that image with an explicit shape (tuning / ablation): panels of rows_per_panel rows,
  * column blocks of 2^cols_log2 columns (rows_per_panel << cols_log2 must fit 31 bits);

@@ -533,6 +533,7 @@ int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unr
 int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unroll, int form) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;
+  const bool auto_shape = rows_per_panel == 0 && cols_log2 == 0, form_was_default = form == 0, unroll_was_default = unroll == 0;
   if (rows_per_panel == 0 && cols_log2 == 0) choose_panels(m, &rows_per_panel, &cols_log2);
   if (rows_per_panel < 1 || rows_per_panel > 20479 || cols_log2 < 4 || cols_log2 > 17)
     return SPL_ERROR_argument_missing;
@@ -563,8 +564,55 @@ int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unrol
         unroll = want <= 4 ? 4 : want <= 6 ? 6 : want <= 8 ? 8 : want <= 10 ? 10 : 12;
       }
     }
+    const bool autotune = auto_shape && form_was_default && unroll_was_default && pair && m->nnz > (int64_t)1 << 22;
     if (const char *ev = getenv("SPL_PANEL_UNROLL")) unroll = atoi(ev);
     b->unroll = unroll;
+    if (autotune && !getenv("SPL_PANEL_UNROLL") && !(getenv("SPL_PANEL_TUNE") && getenv("SPL_PANEL_TUNE")[0] == '0')) {
+      // The register sets per wavefront and the index blocks per phase are worth 5-10 % either way and the
+      // best pair sits next to the heuristic one (C2: 5 pairs, 2 blocks: 0.90 ms; 6 pairs: 0.97; 4: 0.98;
+      // 3 pairs, 1 block: 0.96): time the neighbours once (the image is the same for all of them; about a
+      // hundred launches on a scratch vector) and keep the fastest.  SPL_PANEL_TUNE=0 keeps the heuristic.
+      DBuf<double> tx((size_t)m->ncols), ty((size_t)m->nrows_local);
+      SPL_HIP(hipMemsetAsync(tx.get(), 0, (size_t)m->ncols * sizeof(double), nullptr));
+      hipEvent_t e0, e1;
+      SPL_HIP(hipEventCreate(&e0));
+      SPL_HIP(hipEventCreate(&e1));
+      struct Cand { int k, u; };
+      std::vector<Cand> cands;
+      for (int du = -1; du <= 1; ++du) {
+        const int u2 = unroll + du;
+        if (kblocks == 2 && u2 >= 3 && u2 <= 6) cands.push_back({2, u2});
+        if (kblocks == 1 && u2 >= 2 && u2 <= 4) cands.push_back({1, u2});
+      }
+      if (kblocks == 2) {
+        for (int u1 = (unroll + 1) / 2; u1 <= (unroll + 1) / 2 + 1; ++u1)
+          if (u1 >= 2 && u1 <= 4) cands.push_back({1, u1});
+      }
+      float best = 0.f;
+      int best_k = kblocks, best_u = unroll;
+      float heur = 0.f;
+      for (const Cand &c : cands) {
+        b->kblocks = c.k;
+        b->unroll = c.u;
+        for (int w = 0; w < 2; ++w) (void)launch_spmv_panel(m, tx.get(), ty.get(), 0, nullptr);
+        SPL_HIP(hipEventRecord(e0, nullptr));
+        for (int r = 0; r < 8; ++r) (void)launch_spmv_panel(m, tx.get(), ty.get(), 0, nullptr);
+        SPL_HIP(hipEventRecord(e1, nullptr));
+        SPL_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        SPL_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (c.k == kblocks && c.u == unroll) heur = ms;
+        if (best == 0.f || ms < best) { best = ms; best_k = c.k; best_u = c.u; }
+      }
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      if (heur > 0.f && best > 0.99f * heur) { best_k = kblocks; best_u = unroll; }  // within noise: keep the heuristic
+      if (getenv("SPL_PANEL_VERBOSE"))
+        fprintf(stderr, "[panel] heuristic %d pairs x %d blocks: %.4f ms; chosen %d x %d: %.4f ms\n", unroll, kblocks,
+                heur / 8.f, best_u, best_k, best / 8.f);
+      b->kblocks = best_k;
+      b->unroll = best_u;
+    }
     b->ablate = 0;
     {
       const char *ok = getenv("SPL_ALLOW_ABLATION"), *ab = getenv("SPL_PANEL_ABLATE");
