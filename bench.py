@@ -336,6 +336,7 @@ def main():
     import hashlib
     step()
     torch.cuda.synchronize()
+    barrier()  # one-sided exchange: no rank may release its receive buffers while a peer is still storing
     yh = op.y_full.cpu().numpy()
     out["y_sha1"] = hashlib.sha1(yh.tobytes()).hexdigest()  # equal for every N under --order reference
     out["y_sum"], out["y_norm2"] = float(yh.sum()), float(np.sqrt((yh * yh).sum()))  # equal to ~1e-15 under either order
@@ -380,6 +381,9 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if N > 1:
+        if hasattr(op, "close"):
+            barrier()
+            op.close()
         dist.destroy_process_group()
 
 
