@@ -142,6 +142,15 @@ int spl_compress(int nrows, int ncols, int64_t nnz, const int *rows, const int *
  * kernels read.  The inputs may be freed as soon as the call returns. */
 int spl_matrix_create(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax,
                       void **H);
+/* The same for Complex Double: Az holds packed (re, im) pairs, 2 * Ap[ncols] doubles (the form the reference
+ * passes for its complex instance, Umfpack/Internal.hs:124-132).  On such a handle spl_matrix_mulv / _gaxpy /
+ * _spmv_dev take packed complex vectors (2 * ncols and 2 * nrows doubles; xlen, ylen still count entries) and
+ * compute  y <- a * x + y  per stored entry in ascending column order with Data.Complex's arithmetic, every
+ * real operation separately rounded (csrc/spmv_z.hip: 20 bytes per stored entry instead of the 48 of the real
+ * 2n x 2n embedding).  Other handle operations (spgemm, export, spmm, images) are for real handles. */
+int spl_matrix_create_z(int nrows, int ncols, const int *Ap, const int *Ai, const double *Az, void **H);
+/* 1 for a handle made by spl_matrix_create_z, 0 for a real one */
+int spl_matrix_is_complex(void *H);
 /* Same, but keep only the rows of the part-th of nparts nnz-balanced
  * contiguous row blocks (1-D row partition). */
 int spl_matrix_create_rowblock(int nrows, int ncols, const int *Ap, const int *Ai,

@@ -158,6 +158,26 @@ def axpy_(m, x, y):
         raise OracleError("axpy_: dimension mismatch")
 
 
+def axpy_z(m, x, y):
+    """in place y <- A x + y on Complex Double (Sparse.hs:433-453 under the SPECIALIZE of :456-457): the
+    matrix tuple carries complex values; x, y complex128 arrays"""
+    nrows, ncols, p, i, v = m
+    p, i = _c64(p), _c64(i)
+    v = np.ascontiguousarray(v, dtype=np.complex128)
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    assert y.dtype == np.complex128 and y.flags.c_contiguous
+    st = lib().orc_axpy_z(C.c_int64(nrows), C.c_int64(ncols), _I(p), _I(i), _D(v.view(F64)), C.c_int64(len(x)),
+                          _D(x.view(F64)), C.c_int64(len(y)), _D(y.view(F64)))
+    if st != 0:
+        raise OracleError("axpy_: dimension mismatch")
+
+
+def mulV_z(m, x):
+    y = np.zeros(int(m[0]), dtype=np.complex128)
+    axpy_z(m, x, y)
+    return y
+
+
 def mulV(m, x):
     nrows, ncols, p, i, v = _mat(m)
     x = _cf(x)

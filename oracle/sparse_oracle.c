@@ -201,6 +201,28 @@ int orc_axpy_(Int nrows, Int ncols, const Int *ptrs, const Int *idx, const doubl
   return ORC_OK;
 }
 
+/* axpy_ on Complex Double — the reference's second SPECIALIZE instance (Sparse.hs:456-457, 465-466).
+ * Values, x and y are packed (re, im) pairs.  `a * x + y` with base's Data.Complex instance
+ *   (x :+ y) * (x' :+ y') = (x*x' - y*y') :+ (x*y' + y*x')      (+) componentwise
+ * every real operation separately rounded (this file is built with -ffp-contract=off). */
+int orc_axpy_z(Int nrows, Int ncols, const Int *ptrs, const Int *idx, const double *val,
+               Int xlen, const double *x, Int ylen, double *y) {
+  if (xlen != ncols) return ORC_ERR_DIM;
+  if (ylen != nrows) return ORC_ERR_DIM;
+  for (Int c = 0; c < ncols; ++c) {
+    for (Int k = ptrs[c]; k < ptrs[c + 1]; ++k) {
+      const double xr = x[2 * c], xi = x[2 * c + 1];
+      const double ar = val[2 * k], ai = val[2 * k + 1];
+      const Int r = idx[k];
+      const double pr = ar * xr - ai * xi;
+      const double pi = ar * xi + ai * xr;
+      y[2 * r] = pr + y[2 * r];
+      y[2 * r + 1] = pi + y[2 * r + 1];
+    }
+  }
+  return ORC_OK;
+}
+
 /* mulV — Sparse.hs:464-471: thaw (copy) x, zero y, axpy_, freeze (copy) y. */
 int orc_mulv(Int nrows, Int ncols, const Int *ptrs, const Int *idx, const double *val,
              Int xlen, const double *x, double *y_out) {

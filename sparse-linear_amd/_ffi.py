@@ -96,6 +96,8 @@ def _declare(L):
         "spl_compress": [i, i, i64, c_int_p, c_int_p, c_dbl_p, c_int_p, c_void_pp, c_void_pp, c_i64_p],
         "spl_matrix_create": tup + [c_void_pp],
         "spl_matrix_create_rowblock": tup + [i, i, c_void_pp],
+        "spl_matrix_create_z": tup + [c_void_pp],
+        "spl_matrix_is_complex": [C.c_void_p],
         "spl_matrix_create_csr": [i64, i64, i64, i64, c_int_p, c_int_p, c_dbl_p, c_void_pp],
         "spl_matrix_create_synthetic": [i, i64, i, u64, i64, i64, c_void_pp],
         "spl_matrix_create_rmat": [i, i, d, d, d, u64, c_void_pp],

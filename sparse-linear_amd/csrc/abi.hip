@@ -153,11 +153,12 @@ int host_spmv(Matrix *m, int xlen, const double *x, int ylen, double *y, int acc
   DeviceGuard g(m->device);
   hipStream_t s = nullptr;
   DBuf<double> dx, dy;
-  upload(dx, x, (size_t)xlen, s);
-  if (accumulate) upload(dy, y, (size_t)ylen, s); else dy.alloc((size_t)ylen);
+  const size_t vw = (size_t)m->vw;  // packed complex vectors carry two doubles per entry
+  upload(dx, x, (size_t)xlen * vw, s);
+  if (accumulate) upload(dy, y, (size_t)ylen * vw, s); else dy.alloc((size_t)ylen * vw);
   int st = launch_spmv(m, dx.get(), dy.get(), accumulate, s);
   if (st != SPL_OK) return st;
-  if (ylen) SPL_HIP(hipMemcpyAsync(y, dy.get(), (size_t)ylen * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (ylen) SPL_HIP(hipMemcpyAsync(y, dy.get(), (size_t)ylen * vw * sizeof(double), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
   return SPL_OK;
 }
@@ -213,6 +214,55 @@ int spl_matrix_create_rowblock(int nrows, int ncols, const int *Ap, const int *A
     if (st == SPL_OK) *H = m;
     return st;
   });
+}
+
+// Complex Double: the CSC 5-tuple with packed (re, im) values (what the reference passes for its complex
+// instance, Umfpack/Internal.hs:124-132).  The row-major image is built by transposing the PATTERN with the
+// entry positions as payload and gathering the 16-byte values along the permutation.
+int spl_matrix_create_z(int nrows, int ncols, const int *Ap, const int *Ai, const double *Az, void **H) {
+  if (!H) return SPL_ERROR_argument_missing;
+  *H = nullptr;
+  return guarded([&]() -> int {
+    int st = check_tuple(nrows, ncols, Ap, Ai, Az);
+    if (st != SPL_OK) return st;
+    const int64_t nnz = Ap[ncols];
+    const int dev = current_device();
+    hipStream_t s = nullptr;
+    DBuf<int> dAp, dAi;
+    DBuf<double> dAz, dpos, dperm;
+    upload(dAp, Ap, (size_t)ncols + 1, s);
+    upload(dAi, Ai, (size_t)nnz, s);
+    upload(dAz, Az, (size_t)nnz * 2, s);
+    st = validate_compressed(dAp.get(), dAi.get(), ncols, nrows, nnz, s);
+    if (st != SPL_OK) return st;
+    dpos.alloc((size_t)nnz);
+    dperm.alloc((size_t)nnz);
+    fill_positions(nnz, dpos.get(), s);
+    std::unique_ptr<Matrix> m(new Matrix());
+    m->device = dev;
+    m->nrows_global = nrows;
+    m->ncols = ncols;
+    m->row0 = 0;
+    m->nrows_local = nrows;
+    m->nnz = nnz;
+    m->vw = 2;
+    m->rowptr64.alloc((size_t)nrows + 1);
+    m->colidx.alloc((size_t)nnz);
+    m->val.alloc((size_t)nnz * 2);
+    transpose_compressed(dAp.get(), dAi.get(), dpos.get(), ncols, nrows, nnz, m->rowptr64.get(), m->colidx.get(),
+                         dperm.get(), s);
+    gather_complex_values(nnz, dperm.get(), dAz.get(), m->val.get(), s);
+    SPL_HIP(hipStreamSynchronize(s));
+    finalize_matrix(m.get(), s);
+    *H = m.release();
+    return SPL_OK;
+  });
+}
+
+int spl_matrix_is_complex(void *H) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  return m->vw == 2 ? 1 : 0;
 }
 
 int spl_matrix_create_csr(int64_t nrows_global, int64_t ncols, int64_t row0, int64_t nrows_local,
@@ -336,6 +386,7 @@ int spl_matrix_spgemm(void *HA, void *HB, void **HC, int64_t *products) {
   if (!A || !B) return SPL_ERROR_invalid_handle;
   if (!HC) return SPL_ERROR_argument_missing;
   *HC = nullptr;
+  if (A->vw != 1 || B->vw != 1) return SPL_ERROR_argument_missing;  // complex products: through the host mirror
   if (A->ncols != B->nrows_global || B->row0 != 0 || B->nrows_local != B->nrows_global)
     return SPL_ERROR_dimension_mismatch;  // Sparse.hs:694 (B must be whole; A may be a row block)
   if (!A->rowptr.get() || !B->rowptr.get()) return SPL_ERROR_index_overflow;
@@ -402,6 +453,7 @@ int spl_matrix_spmv_kernel(void *H) {
 int spl_matrix_export_csr(void *H, int64_t *rowptr, int *colidx, double *val) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;
+  if (m->vw != 1) return SPL_ERROR_argument_missing;  // complex handles: SpMV only
   if (!rowptr || (m->nnz > 0 && (!colidx || !val))) return SPL_ERROR_argument_missing;
   return guarded([&]() -> int {
     DeviceGuard g(m->device);
@@ -418,6 +470,7 @@ int spl_matrix_export_csr(void *H, int64_t *rowptr, int *colidx, double *val) {
 int spl_matrix_export_csc(void *H, int64_t *colptr, int *rowidx, double *val) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;
+  if (m->vw != 1) return SPL_ERROR_argument_missing;  // complex handles: SpMV only
   if (!colptr || (m->nnz > 0 && (!rowidx || !val))) return SPL_ERROR_argument_missing;
   if (!m->rowptr.get()) return SPL_ERROR_index_overflow;
   return guarded([&]() -> int {
@@ -462,6 +515,7 @@ int spl_matrix_spmv_dev(void *H, const double *d_x, double *d_y, int accumulate,
 int spl_matrix_set_variant(void *H, int variant) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;
+  if (m->vw != 1) return variant == 0 ? SPL_OK : SPL_ERROR_argument_missing;  // complex: the one native kernel
   if (variant < 0 || variant >= kNumSpmvVariants) return SPL_ERROR_argument_missing;
   if (variant >= 12 && variant <= 14) {
     // timing-only ablations of the CSR-stream kernel (they do NOT compute A x): refuse them unless
@@ -492,6 +546,7 @@ int spl_matrix_set_variant(void *H, int variant) {
 int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unroll) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;
+  if (m->vw != 1) return SPL_ERROR_argument_missing;
   int waves = 16;
   if (rows_per_panel == 0 && cols_log2 == 0) {
     {
@@ -533,6 +588,7 @@ int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unr
 int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unroll, int form) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;
+  if (m->vw != 1) return SPL_ERROR_argument_missing;
   const bool auto_shape = rows_per_panel == 0 && cols_log2 == 0, form_was_default = form == 0, unroll_was_default = unroll == 0;
   if (rows_per_panel == 0 && cols_log2 == 0) choose_panels(m, &rows_per_panel, &cols_log2);
   if (rows_per_panel < 1 || rows_per_panel > 20479 || cols_log2 < 4 || cols_log2 > 17)
@@ -633,6 +689,7 @@ int spl_matrix_set_spmv_order(void *H, int order) {
 int spl_matrix_optimize(void *H) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;
+  if (m->vw != 1) return SPL_OK;  // complex: the CSR-stream kernel of spmv_z.hip is the one there is
   int R = 0, w = 0, waves = 16;
   {
     int st = guarded([&]() -> int { DeviceGuard g(m->device); measure_locality(m, nullptr); return SPL_OK; });
@@ -753,6 +810,7 @@ int spl_mulm(int nrows, int ncols, const int *Ap, const int *Ai, const double *A
 int spl_matrix_spmm_dev(void *H, const double *d_B, double *d_C, int k, int accumulate, void *stream) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;
+  if (m->vw != 1) return SPL_ERROR_argument_missing;
   if (k < 0) return SPL_ERROR_n_nonpositive;
   if (k > 0 && ((m->ncols > 0 && !d_B) || (m->nrows_local > 0 && !d_C))) return SPL_ERROR_argument_missing;
   return guarded([&]() -> int {

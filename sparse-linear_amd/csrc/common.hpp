@@ -127,6 +127,7 @@ struct Matrix {
   DBuf<int> rowptr;        // nrows_local+1, present iff nnz < 2^31
   DBuf<int> colidx;        // nnz
   DBuf<double> val;        // nnz
+  int vw = 1;              // doubles per stored value: 1 Double, 2 packed Complex Double (csrc/spmv_z.hip)
   int variant = 0;
   int64_t max_row_len = 0;
   double new_line_fraction = -1.0;  // share of entries whose x line the previous row did not touch; < 0: not measured yet
@@ -244,6 +245,10 @@ void generate_vector(uint64_t seed, int64_t j0, int64_t j1, double *d_x, hipStre
 int launch_spmv(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s);
 // C (nrows_local x k, row-major) = A B (+ C) for a row-major dense B (ncols x k): one pass over A
 int launch_spmm(const Matrix *m, const double *d_B, double *d_C, int k, int accumulate, hipStream_t s);
+// Complex Double (spmv_z.hip): d_x, d_y packed (re, im) pairs
+int launch_spmv_z(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s);
+void fill_positions(int64_t n, double *d_out, hipStream_t s);
+void gather_complex_values(int64_t n, const double *d_pos, const double *d_in, double *d_out, hipStream_t s);
 int64_t sell_padded_entries(const Matrix *m, hipStream_t s);
 void build_sell_image(Matrix *m, hipStream_t s);
 int launch_spmv_sell(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s);

@@ -265,6 +265,7 @@ int launch_spmm(const Matrix *m, const double *d_B, double *d_C, int k, int accu
 
 int launch_spmv(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s) {
   if (m->nrows_local == 0) return SPL_OK;
+  if (m->vw == 2) return launch_spmv_z(m, d_x, d_y, accumulate, s);
   int st = SPL_OK;
   if (m->variant == 15 || (m->variant == 0 && m->sell)) {
     if (!m->sell) return SPL_ERROR_argument_missing;

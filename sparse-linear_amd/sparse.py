@@ -136,8 +136,11 @@ class Matrix(object):
     def device_handle(self):
         """Upload once, reuse for every later SpMV (handle API)."""
         if self._handle is None:
-            self._handle = DeviceMatrix.from_csc(self)
-            self._handle.optimize()  # one-time analysis, like umfpack_*_symbolic
+            if self.is_complex:
+                self._handle = DeviceMatrix.from_csc_complex(self)
+            else:
+                self._handle = DeviceMatrix.from_csc(self)
+                self._handle.optimize()  # one-time analysis, like umfpack_*_symbolic
         return self._handle
 
 
@@ -176,6 +179,19 @@ class DeviceMatrix(object):
               lib().spl_matrix_create_rowblock(nr, nc, p_i32(ap), p_i32(ai), p_f64(ax), part, nparts,
                                                C.byref(h)))
         return cls(h.value)
+
+    @classmethod
+    def from_csc_complex(cls, mat):
+        """Complex Double handle (spl_matrix_create_z): packed (re, im) values, native SpMV (csrc/spmv_z.hip)"""
+        _ffi.require_gpu()
+        nr, nc, ap, ai, az = mat._tuple32()  # complex values cross as packed pairs
+        h = C.c_void_p()
+        check("spl_matrix_create_z", lib().spl_matrix_create_z(nr, nc, p_i32(ap), p_i32(ai), p_f64(az), C.byref(h)))
+        return cls(h.value)
+
+    @property
+    def is_complex(self):
+        return int(lib().spl_matrix_is_complex(self.handle)) == 1
 
     @classmethod
     def from_csr(cls, nrows_global, ncols, rowptr, colidx, val, row0=0):
@@ -271,6 +287,14 @@ class DeviceMatrix(object):
         return int(lib().spl_matrix_spmv_kernel(self.handle))
 
     def mulv(self, x):
+        if self.is_complex:  # packed complex vectors; the lengths count entries
+            x = np.ascontiguousarray(x, dtype=C128)
+            y = np.zeros(self.info()["nrows_local"], dtype=C128)
+            st = lib().spl_matrix_mulv(self.handle, len(x), p_f64(x.view(F64)), p_f64(y.view(F64)))
+            if st == SPL_ERROR_dimension_mismatch:
+                _oops("axpy_", "column dimension does not match operand dimension %d" % len(x))
+            check("spl_matrix_mulv", st)
+            return y
         x = as_f64(x)
         y = np.zeros(self.info()["nrows_local"], dtype=F64)
         st = lib().spl_matrix_mulv(self.handle, len(x), p_f64(x), p_f64(y))
@@ -280,6 +304,14 @@ class DeviceMatrix(object):
         return y
 
     def gaxpy(self, x, y):
+        if self.is_complex:
+            x = np.ascontiguousarray(x, dtype=C128)
+            assert y.dtype == C128 and y.flags.c_contiguous
+            st = lib().spl_matrix_gaxpy(self.handle, len(x), p_f64(x.view(F64)), len(y), p_f64(y.view(F64)))
+            if st == SPL_ERROR_dimension_mismatch:
+                _oops("axpy_", "dimension does not match operand dimension")
+            check("spl_matrix_gaxpy", st)
+            return y
         x = as_f64(x)
         assert y.dtype == F64 and y.flags.c_contiguous
         st = lib().spl_matrix_gaxpy(self.handle, len(x), p_f64(x), len(y), p_f64(y))
@@ -404,24 +436,28 @@ def axpy_(mat, xs, ys):
         _oops("axpy_", "column dimension %d does not match operand dimension %d" % (mat.ncols, len(xs)))
     if len(ys) != mat.nrows:
         _oops("axpy_", "row dimension %d does not match result dimension %d" % (mat.nrows, len(ys)))
-    if not (isinstance(ys, np.ndarray) and ys.dtype == F64 and ys.flags.c_contiguous):
-        raise TypeError("axpy_: ys must be a contiguous float64 array (it is updated in place)")
-    mat.device_handle().gaxpy(xs, ys)
+    want = C128 if mat.is_complex else F64
+    if not (isinstance(ys, np.ndarray) and ys.dtype == want and ys.flags.c_contiguous):
+        raise TypeError("axpy_: ys must be a contiguous %s array (it is updated in place)" % np.dtype(want).name)
+    mat.device_handle().gaxpy(xs, ys)  # Complex Double: the native kernel of csrc/spmv_z.hip
 
 
 def axpy(mat, x, y):
-    y = np.array(y, dtype=F64)  # U.thaw _y (Sparse.hs:459)
-    axpy_(mat, np.asarray(x, dtype=F64), y)
+    dt = C128 if mat.is_complex else F64
+    y = np.array(y, dtype=dt)  # U.thaw _y (Sparse.hs:459)
+    axpy_(mat, np.asarray(x, dtype=dt), y)
     return y
 
 
 def mulV(mat, x):
     if mat.is_complex or np.iscomplexobj(x):
+        # Complex Double (Sparse.hs:465-466): native packed-complex kernel (csrc/spmv_z.hip); a real matrix
+        # applied to a complex vector is promoted as the reference's types would demand
         x = np.ascontiguousarray(x, dtype=C128)
         if len(x) != mat.ncols:
             _oops("axpy_", "column dimension %d does not match operand dimension %d" % (mat.ncols, len(x)))
         m = mat if mat.is_complex else cmap(lambda v: v.astype(C128), mat)
-        return mulV(m._embedded(), x.view(F64)).view(C128)
+        return m.device_handle().mulv(x)
     x = np.asarray(x, dtype=F64)
     if len(x) != mat.ncols:
         _oops("axpy_", "column dimension %d does not match operand dimension %d" % (mat.ncols, len(x)))

@@ -164,3 +164,60 @@ def test_zi_split_arrays_through_the_c_abi(gpu, pkg):
         assert np.max(np.abs(xx + 1j * xz - Xs)) < 1e-10
     L.umfpack_zi_free_numeric(C.byref(num))
     L.umfpack_zi_free_symbolic(C.byref(sym))
+
+
+# ---- native Complex Double SpMV (csrc/spmv_z.hip) against the oracle's complex restatement of axpy_ -------------
+def _rand_complex(O, rng, nr, nc, k, ints=False):
+    A = O.compress(nr, nc, rng.integers(0, nr, k), rng.integers(0, nc, k), rng.normal(size=k))
+    if ints:
+        vals = rng.integers(-9, 10, len(A[4])) + 1j * rng.integers(-9, 10, len(A[4]))
+    else:
+        vals = A[4] + 1j * rng.normal(size=len(A[4]))
+    return (nr, nc, A[2], A[3], vals.astype(np.complex128))
+
+
+@pytest.mark.parametrize("nr,nc,k", [(1, 1, 1), (7, 5, 20), (300, 200, 5000), (5000, 7000, 90000), (64, 64, 4096), (20000, 20000, 400000)])
+def test_native_complex_mulv_matches_oracle_bitwise(gpu, pkg, O, nr, nc, k):
+    """mulV / axpy_ / axpy on Complex Double: y <- a * x + y per stored entry in ascending column order with
+    Data.Complex's (a :+ b) * (c :+ d) = (a*c - b*d) :+ (a*d + b*c) — bit-identical to the oracle's restatement
+    (oracle/sparse_oracle.c orc_axpy_z, Sparse.hs:433-453 under the SPECIALIZE of :456-457)"""
+    rng = np.random.default_rng(nr + nc + k)
+    A = _rand_complex(O, rng, nr, nc, k)
+    M = pkg.Matrix(nc, nr, A[2], A[3], A[4])
+    assert M.device_handle().is_complex
+    x = rng.normal(size=nc) + 1j * rng.normal(size=nc)
+    y = pkg.mulV(M, x)
+    assert y.dtype == np.complex128 and np.array_equal(y, O.mulV_z(A, x))
+    y0 = rng.normal(size=nr) + 1j * rng.normal(size=nr)
+    ya = pkg.axpy(M, x, y0)
+    yo = y0.copy()
+    O.axpy_z(A, x, yo)
+    assert np.array_equal(ya, yo)
+    yin = y0.copy()
+    pkg.axpy_(M, x, yin)
+    assert np.array_equal(yin, yo)
+    with pytest.raises(pkg.SparseError):
+        pkg.mulV(M, np.ones(nc + 1, dtype=complex))
+
+
+def test_native_complex_fixtures_and_long_rows(gpu, pkg, O):
+    # sigma_y (Sparse.hs:70-72): [[0, -i], [i, 0]] (1, i) = (1, i)
+    sy = pkg.Matrix(2, 2, [0, 1, 2], [1, 0], np.array([1j, -1j]))
+    assert np.array_equal(pkg.mulV(sy, np.array([1.0, 1j])), np.array([1.0 + 0j, 1j]))
+    # a real matrix applied to a complex vector == componentwise real products
+    rng = np.random.default_rng(8)
+    n = 3000
+    R = O.compress(n, n, rng.integers(0, n, 40000), rng.integers(0, n, 40000), rng.integers(-5, 6, 40000).astype(float))
+    Mr = pkg.Matrix(n, n, R[2], R[3], R[4])
+    xr, xi = rng.integers(-5, 6, n).astype(float), rng.integers(-5, 6, n).astype(float)
+    y = pkg.mulV(Mr, xr + 1j * xi)
+    assert np.array_equal(y.real, O.mulV(R, xr)) and np.array_equal(y.imag, O.mulV(R, xi))
+    # one row far longer than an LDS chunk: wavefront tree sum, the reference's closeness predicate
+    k = 2500
+    cols = rng.choice(n, k, replace=False)
+    A = O.compress(3, n, np.concatenate([np.zeros(k, dtype=int), [1, 2]]), np.concatenate([cols, [5, 7]]), rng.normal(size=k + 2))
+    Az = (3, n, A[2], A[3], (A[4] + 1j * rng.normal(size=len(A[4]))).astype(np.complex128))
+    x = rng.normal(size=n) + 1j * rng.normal(size=n)
+    y = pkg.mulV(pkg.Matrix(n, 3, Az[2], Az[3], Az[4]), x)
+    yo = O.mulV_z(Az, x)
+    assert np.max(np.abs(y - yo)) <= 1e-10 * np.max(np.abs(yo)) and np.array_equal(y[1:], yo[1:])
