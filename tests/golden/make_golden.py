@@ -86,6 +86,56 @@ def main():
                "banded_1e7_row5000000": {"colidx": [int(t) for t in cb], "val": vec(vb)},
                "x_1e7_first4": vec(O.gen_vector(10_000_000, j0=0, j1=4))},
               open(os.path.join(OUT, "synthetic.json"), "w"), indent=0)
+    # combinators (Sparse.hs:504-597) and Complex Double axpy_ (Sparse.hs:433-457): cross-checked against
+    # scipy's bmat / complex product before being frozen
+    import scipy.sparse as sp
+
+    def cmat(m):
+        d = mat((m[0], m[1], m[2], m[3], np.real(m[4])))
+        d["values_im"] = [float(t) for t in np.imag(m[4])]
+        return d
+
+    def rnd(nr, nc, k, cplx=False):
+        v = np.round(rng.normal(size=k), 3)
+        if cplx:
+            v = v + 1j * np.round(rng.normal(size=k), 3)
+        return O.compress(nr, nc, rng.integers(0, nr, k), rng.integers(0, nc, k), v) if not cplx else \
+            _compress_z(nr, nc, rng.integers(0, nr, k), rng.integers(0, nc, k), v)
+
+    def _compress_z(nr, nc, r, c, v):
+        re = O.compress(nr, nc, r, c, np.real(v))
+        im = O.compress(nr, nc, r, c, np.imag(v))
+        assert np.array_equal(re[2], im[2]) and np.array_equal(re[3], im[3])
+        return (nr, nc, re[2], re[3], re[4] + 1j * im[4])
+
+    hs, ws = (3, 5, 2), (4, 1, 6)
+    blocks = [[rnd(h, w, 2 * max(h, w)) for w in ws] for h in hs]
+    blocks[0][2] = None
+    blocks[1][0] = None
+    blocks[2][1] = None
+    fb = O.fromBlocks(blocks)
+    dense = sp.bmat([[None if b is None else scipy_of(b) for b in row] for row in blocks]).toarray()
+    assert np.array_equal(scipy_of(fb).toarray(), dense)
+    hc = O.hcat(blocks[1][1:])
+    vc = O.vcat([blocks[0][0], blocks[2][0]])
+    assert np.array_equal(scipy_of(hc).toarray(), np.hstack([scipy_of(b).toarray() for b in blocks[1][1:]]))
+    assert np.array_equal(scipy_of(vc).toarray(), np.vstack([scipy_of(blocks[0][0]).toarray(), scipy_of(blocks[2][0]).toarray()]))
+    fd = O.fromBlocksDiag([[blocks[0][0], blocks[1][1], blocks[2][2]], [blocks[0][1], blocks[1][2], None], [None, None, None]])
+    dd = sp.bmat([[scipy_of(blocks[0][0]), scipy_of(blocks[0][1]), None], [None, scipy_of(blocks[1][1]), scipy_of(blocks[1][2])],
+                  [None, None, scipy_of(blocks[2][2])]]).toarray()
+    assert np.array_equal(scipy_of(fd).toarray(), dd)
+    Z = rnd(9, 7, 30, cplx=True)
+    xz = np.round(rng.normal(size=7), 3) + 1j * np.round(rng.normal(size=7), 3)
+    yz = np.round(rng.normal(size=9), 3) + 1j * np.round(rng.normal(size=9), 3)
+    out = yz.copy()
+    O.axpy_z(Z, xz, out)
+    assert np.allclose(out, sp.csc_matrix((Z[4], Z[3], Z[2]), shape=(9, 7)) @ xz + yz, rtol=1e-13, atol=1e-13)
+    json.dump({"blocks": [[None if b is None else mat(b) for b in row] for row in blocks],
+               "fromBlocks": mat(fb), "hcat_row1_cols12": mat(hc), "vcat_col0_rows02": mat(vc), "fromBlocksDiag": mat(fd),
+               "complex": {"A": cmat(Z), "x": [[float(t.real), float(t.imag)] for t in xz],
+                           "y0": [[float(t.real), float(t.imag)] for t in yz],
+                           "axpy": [[float(t.real), float(t.imag)] for t in out]}},
+              open(os.path.join(OUT, "combinators_complex.json"), "w"), indent=0)
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".json")))
 
 

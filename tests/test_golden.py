@@ -69,3 +69,44 @@ def test_hip_path_reproduces_golden(gpu, pkg, O):
     rp, ci, v = H.export_csr()
     assert rp.tolist() == g["random_1e7_k20_rows0_3"]["rowptr"] and ci.tolist() == g["random_1e7_k20_rows0_3"]["colidx"]
     assert v.tolist() == g["random_1e7_k20_rows0_3"]["val"]
+
+
+def _cplx(pairs):
+    return np.array([complex(a, b) for a, b in pairs], dtype=np.complex128)
+
+
+def _ctup(d):
+    t = tup(d)
+    return (t[0], t[1], t[2], t[3], t[4] + 1j * np.array(d["values_im"], dtype=np.float64))
+
+
+def test_oracle_reproduces_combinators_and_complex(O):
+    g = load("combinators_complex.json")
+    blocks = [[None if b is None else tup(b) for b in row] for row in g["blocks"]]
+    assert tuples_equal(O.fromBlocks(blocks), tup(g["fromBlocks"]))
+    assert tuples_equal(O.hcat(blocks[1][1:]), tup(g["hcat_row1_cols12"]))
+    assert tuples_equal(O.vcat([blocks[0][0], blocks[2][0]]), tup(g["vcat_col0_rows02"]))
+    assert tuples_equal(O.fromBlocksDiag([[blocks[0][0], blocks[1][1], blocks[2][2]], [blocks[0][1], blocks[1][2], None],
+                                          [None, None, None]]), tup(g["fromBlocksDiag"]))
+    c = g["complex"]
+    y = _cplx(c["y0"])
+    O.axpy_z(_ctup(c["A"]), _cplx(c["x"]), y)
+    assert np.array_equal(y, _cplx(c["axpy"]))
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_combinators_and_complex(gpu, pkg):
+    def M(d, cplx=False):
+        v = np.array(d["values"]) + (1j * np.array(d["values_im"]) if cplx else 0.0)
+        return pkg.Matrix(d["ncols"], d["nrows"], d["pointers"], d["indices"], v)
+    g = load("combinators_complex.json")
+    blocks = [[None if b is None else M(b) for b in row] for row in g["blocks"]]
+    assert pkg.fromBlocks(blocks) == M(g["fromBlocks"])
+    assert pkg.hcat(blocks[1][1:]) == M(g["hcat_row1_cols12"])
+    assert pkg.vcat([blocks[0][0], blocks[2][0]]) == M(g["vcat_col0_rows02"])
+    assert pkg.fromBlocksDiag([[blocks[0][0], blocks[1][1], blocks[2][2]], [blocks[0][1], blocks[1][2], None],
+                               [None, None, None]]) == M(g["fromBlocksDiag"])
+    c = g["complex"]
+    A = M(c["A"], cplx=True)
+    assert A.is_complex
+    assert np.array_equal(pkg.axpy(A, _cplx(c["x"]), _cplx(c["y0"])), _cplx(c["axpy"]))
