@@ -108,6 +108,17 @@ int spl_umfpack_zi_solve_many(int sys, const int Ap[], const int Ai[], const dou
                               int nrhs, double Xx[], double Xz[], const double Bx[], const double Bz[],
                               void *Numeric);
 
+/* The same with the right-hand sides and the solutions in DEVICE memory (n x nrhs doubles, column-major;
+ * complex ones packed (re, im) pairs: 2 n x nrhs doubles), for callers that keep a whole subspace in HBM
+ * between the solves, the SpMVs and the dense products of an iteration (the FEAST-style loop,
+ * Feast.hs:197-233).  The call returns when the solutions are written.  Ap/Ai/Ax stay HOST arrays — the
+ * arguments umfpack_*_solve ignores on the way to the factors are what a failed speculation is refactored
+ * from — and may be NULL, which rules that refactoring out (the band fallback remains). */
+int spl_umfpack_di_solve_many_dev(int sys, const int Ap[], const int Ai[], const double Ax[], int nrhs, double *d_X,
+                                  const double *d_B, void *Numeric);
+int spl_umfpack_zi_solve_many_dev(int sys, const int Ap[], const int Ai[], const double Ax[], int nrhs, double *d_X,
+                                  const double *d_B, void *Numeric);
+
 /* dimension of the system a Numeric object factors (0 if invalid); helper of the zi wrappers */
 int spl_umfpack_dimension(void *Numeric);
 

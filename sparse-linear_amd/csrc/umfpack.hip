@@ -855,8 +855,24 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
 // umf_solve): stop when the componentwise backward error is below machine epsilon, or when a
 // step does not at least halve it (a step that raises it is undone).  All columns share every
 // pass over the factors.
+// Static pivoting from a solve: the matrix is taken from the object's own device copy (the columns of A are the
+// rows of N->At), not from the caller's Ap / Ai / Ax — a `zi` caller passes the complex matrix there, whose arrays
+// are not those of the embedding this object factors (umfpack_zi.hip).
+static bool factor_static_pivot_of_copy(Numeric *N, hipStream_t s) {
+  if (N->sp_stage != 0 || !N->At || !N->At->rowptr.get() || N->At->nnz <= 0) return false;
+  const size_t n = (size_t)N->n, nnz = (size_t)N->At->nnz;
+  std::vector<int> p(n + 1), i(nnz);
+  std::vector<double> x(nnz);
+  SPL_HIP(hipMemcpyAsync(p.data(), N->At->rowptr.get(), (n + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+  SPL_HIP(hipMemcpyAsync(i.data(), N->At->colidx.get(), nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+  SPL_HIP(hipMemcpyAsync(x.data(), N->At->val.get(), nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+  SPL_HIP(hipStreamSynchronize(s));
+  return factor_static_pivot(N, p.data(), i.data(), x.data(), s);
+}
+
+// device_io: X and B are device pointers (spl_umfpack_*_solve_many_dev), else host
 static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B, const int *Ap, const int *Ai,
-                         const double *Ax) {
+                         const double *Ax, bool device_io = false) {
   const int n = N->n;
   if (N->broken) return UMFPACK_ERROR_invalid_Numeric_object;  // a failed refactorisation left no factors
   try {
@@ -887,7 +903,8 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B,
         dxn{slab.get() + 7 * total}, drn{slab.get() + 8 * total}, domega{slab.get() + 9 * total};
     for (const Span *buf : {&db, &dx, &dwork, &dr, &dd, &dxn, &drn})
       if (kalloc > k) SPL_HIP(hipMemsetAsync(buf->get() + used, 0, (total - used) * sizeof(double), s));
-    SPL_HIP(hipMemcpyAsync(db.get(), B, used * sizeof(double), hipMemcpyHostToDevice, s));
+    SPL_HIP(hipMemcpyAsync(db.get(), B, used * sizeof(double),
+                           device_io ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     // speculative factors may be replaced below: solves on such an object take turns
     std::unique_lock<std::mutex> turn(N->mu, std::defer_lock);
     if (N->speculative) turn.lock();
@@ -957,13 +974,14 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B,
       if (turn.owns_lock() && N->speculative && !(worst <= 1e-13)) {
         // first the static-pivoting stage (stays on the tree, still checked by this very loop), then, if that
         // fails too, the band factorisation with partial pivoting
-        if (factor_static_pivot(N, Ap, Ai, Ax, s)) goto again;
+        if (factor_static_pivot_of_copy(N, s)) goto again;
         factor_band(N, false, s);
         N->speculative = 0;  // only now may other threads use the object without taking turns
         goto again;
       }
     }
-    SPL_HIP(hipMemcpyAsync(X, dx.get(), used * sizeof(double), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipMemcpyAsync(X, dx.get(), used * sizeof(double),
+                           device_io ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     SPL_HIP(hipStreamSynchronize(s));
     SPL_HIP(hipGetLastError());
     lap("download of x");
@@ -998,6 +1016,17 @@ int spl_umfpack_di_solve_many(int sys, const int Ap[], const int Ai[], const dou
   if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;
   if (sys != UMFPACK_A && sys != UMFPACK_At) return UMFPACK_ERROR_invalid_system;
   return solve_columns(N, sys, nrhs, X, B, Ap, Ai, Ax);
+}
+
+// the same with X and B in device memory (see umfpack_hip.h)
+int spl_umfpack_di_solve_many_dev(int sys, const int Ap[], const int Ai[], const double Ax[], int nrhs, double *d_X,
+                                  const double *d_B, void *NumericIn) {
+  Numeric *N = as_numeric(NumericIn);
+  if (!N) return UMFPACK_ERROR_invalid_Numeric_object;
+  if (nrhs < 0) return UMFPACK_ERROR_argument_missing;
+  if (nrhs > 0 && N->n > 0 && (!d_X || !d_B)) return UMFPACK_ERROR_argument_missing;
+  if (sys != UMFPACK_A && sys != UMFPACK_At) return UMFPACK_ERROR_invalid_system;
+  return solve_columns(N, sys, nrhs, d_X, d_B, Ap, Ai, Ax, true);
 }
 
 }  // extern "C"

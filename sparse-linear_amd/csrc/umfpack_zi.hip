@@ -64,6 +64,16 @@ void swap_pairs(const std::vector<char> &swap, double *v) {
     if (swap[r]) std::swap(v[2 * r], v[2 * r + 1]);
 }
 
+// device form of swap_pairs: one thread per complex entry of n x k packed vectors
+__global__ __launch_bounds__(256) void swap_pairs_kernel(const char *__restrict__ flags, double *__restrict__ v,
+                                                         size_t n, size_t total) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total || !flags[t % n]) return;
+  const double a = v[2 * t], b = v[2 * t + 1];
+  v[2 * t] = b;
+  v[2 * t + 1] = a;
+}
+
 struct ZiSymbolic {  // remembers n so that numeric can rebuild the embedding
   unsigned magic = 0x5A53594Du;
   int n = 0;
@@ -208,6 +218,41 @@ int spl_umfpack_zi_solve_many(int sys, const int Ap[], const int Ai[], const dou
       }
     }
     return st;
+  } catch (const std::bad_alloc &) {
+    return UMFPACK_ERROR_out_of_memory;
+  } catch (...) {  // nothing may cross the C ABI
+    return UMFPACK_ERROR_internal_error;
+  }
+}
+
+// packed complex right-hand sides and solutions in device memory (see umfpack_hip.h)
+int spl_umfpack_zi_solve_many_dev(int sys, const int Ap[], const int Ai[], const double Ax[], int nrhs, double *d_X,
+                                  const double *d_B, void *Numeric) {
+  if (nrhs < 0) return UMFPACK_ERROR_argument_missing;
+  const int n2 = spl_umfpack_dimension(Numeric);
+  if (n2 < 0 || (n2 == 0 && !Numeric)) return UMFPACK_ERROR_invalid_Numeric_object;
+  if (nrhs > 0 && n2 > 0 && (!d_X || !d_B)) return UMFPACK_ERROR_argument_missing;
+  const std::vector<char> *swap = spl::numeric_pair_swap(Numeric);
+  if (!swap || nrhs == 0 || n2 == 0) return spl_umfpack_di_solve_many_dev(sys, Ap, Ai, Ax, nrhs, d_X, d_B, Numeric);
+  try {
+    const size_t n = (size_t)n2 / 2, total = n * (size_t)nrhs;
+    spl::DBuf<char> flags(n);
+    SPL_HIP(hipMemcpy(flags.get(), swap->data(), n, hipMemcpyHostToDevice));
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (sys == UMFPACK_A) {  // (Q E) x = Q b
+      spl::DBuf<double> b(2 * total);
+      SPL_HIP(hipMemcpy(b.get(), d_B, 2 * total * sizeof(double), hipMemcpyDeviceToDevice));
+      hipLaunchKernelGGL(swap_pairs_kernel, grid, dim3(256), 0, nullptr, flags.get(), b.get(), n, total);
+      SPL_HIP(hipDeviceSynchronize());
+      return spl_umfpack_di_solve_many_dev(sys, Ap, Ai, Ax, nrhs, d_X, b.get(), Numeric);
+    }
+    const int st = spl_umfpack_di_solve_many_dev(sys, Ap, Ai, Ax, nrhs, d_X, d_B, Numeric);
+    if (st < 0) return st;
+    hipLaunchKernelGGL(swap_pairs_kernel, grid, dim3(256), 0, nullptr, flags.get(), d_X, n, total);  // y = Q w
+    SPL_HIP(hipDeviceSynchronize());
+    return st;
+  } catch (const spl::DeviceError &e) {
+    return e.status == SPL_ERROR_out_of_memory ? UMFPACK_ERROR_out_of_memory : UMFPACK_ERROR_internal_error;
   } catch (const std::bad_alloc &) {
     return UMFPACK_ERROR_out_of_memory;
   } catch (...) {  // nothing may cross the C ABI

@@ -32,9 +32,49 @@ def _as_complex(m):
     return m if m.is_complex else cmap(lambda v: v.astype(np.complex128), m)
 
 
+def _positions(union, part):
+    """index in `union`'s entry arrays of every entry of `part` (same shape, pattern a subset, both with
+    ascending rows inside ascending columns)"""
+    def keys(m):
+        cols = np.repeat(np.arange(m.ncols, dtype=np.int64), np.diff(m.pointers))
+        return cols * m.nrows + m.indices
+    ku, kp = keys(union), keys(part)
+    pos = np.searchsorted(ku, kp)
+    if len(kp) and (pos.max() >= len(ku) or not np.array_equal(ku[pos], kp)):
+        raise ValueError("geigSH_: pattern of an operand is not inside the pattern of ze*B - A")
+    return pos
+
+
+def _apply(mat, V):
+    """rows of the result = mat * rows of V (ijob 30 / 40, Feast.hs:203-208): one SpMV of the hot path per
+    subspace vector, device pointers in and out (spl_matrix_spmv_dev), nothing leaves HBM"""
+    import torch
+    out = torch.empty_like(V)
+    h = mat.device_handle()
+    stream = torch.cuda.current_stream(V.device).cuda_stream
+    for j in range(V.shape[0]):
+        h.spmv_dev(V[j].data_ptr(), out[j].data_ptr(), False, stream)
+    return out
+
+
 def geigSH_(params, m0, interval, matA, matB=None, guess=None):
     """(eigenvalues, eigenvectors, residuals) of A x = lambda B x inside (emin, emax); A (and B)
-    Hermitian.  m0 = subspace size, must be >= the number of eigenvalues in the interval."""
+    Hermitian.  m0 = subspace size, must be >= the number of eigenvalues in the interval.
+
+    Contour: `feastContourPoints` points on the UPPER half circle, as in libfeast (fpm(2) counts the
+    half contour): the lower half is served by the same factors — (conj(ze) B - A)^-1 = ((ze B - A)^-1)^H
+    for Hermitian A, B — through `UmfpackTrans` solves (ijob 21, Feast.hs:228), or, when A, B and the
+    subspace are real, by complex conjugation of the upper half's solutions (the real-symmetric
+    driver of libfeast never issues ijob 21).
+
+    The subspace lives in HBM for the whole iteration (torch tensors of shape (m0, n), one vector per row):
+    the SpMVs, the batched solves (spl_umfpack_*_solve_many_dev) and the dense products Q^H A Q, Q^H B Q
+    read and write device memory; only the m0 x m0 reduced problem and the values of ze*B - A for the
+    next factorisation pass through the host."""
+    import time
+    import torch
+    from . import _ffi
+    _ffi.require_gpu()
     n = matA.ncols
     if matA.nrows != n:
         raise ValueError("geigSH_: matrix not square")
@@ -43,53 +83,116 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
     if matB is not None and not hermitian(matB):  # Feast.hs:130
         raise ValueError("geigSH_: matrix B not hermitian")
     emin, emax = interval
+    dev = torch.device("cuda", torch.cuda.current_device())
+    real_problem = (not matA.is_complex or not np.any(matA.values.imag)) and \
+                   (matB is None or not matB.is_complex or not np.any(matB.values.imag)) and \
+                   (guess is None or not np.any(np.imag(guess)))
     A = _as_complex(matA)
     B = _as_complex(matB) if matB is not None else diag(np.ones(n, dtype=np.complex128))
+    # SpMV operands: a real problem keeps a real subspace and real SpMVs (half the bytes)
+    opA = cmap(lambda v: np.ascontiguousarray(v.real), A) if real_problem else A
+    opB = cmap(lambda v: np.ascontiguousarray(v.real), B) if real_problem else B
+    sub_t = torch.float64 if real_problem else torch.complex128
     c, r = 0.5 * (emin + emax), 0.5 * (emax - emin)
-    ne = 2 * params.feastContourPoints            # full circle, trapezoidal rule
-    thetas = 2.0 * np.pi * (np.arange(ne) + 0.5) / ne
+    nh = params.feastContourPoints                # points on the half contour
+    ne = 2 * nh                                   # full circle, trapezoidal rule
+    thetas = np.pi * (np.arange(nh) + 0.5) / nh   # upper half; the lower half is its mirror image
     rng = np.random.default_rng(0)
-    Y = guess if guess is not None else rng.normal(size=(n, m0)) + 0j
-    # ONE symbolic analysis for every contour point: the pattern of ze*B - A never changes (Feast.hs:212)
-    analysis = U.analyze(lin(-1.0, A, 1.0, B))
+
+    def random_rows(k):
+        return torch.from_numpy(rng.normal(size=(k, n))).to(dev).to(sub_t)
+
+    if guess is not None:
+        g = np.ascontiguousarray(np.asarray(guess).T)   # (n, m0) columns -> rows
+        Y = torch.from_numpy(g.real.copy() if real_problem else g.astype(np.complex128)).to(dev).to(sub_t)
+    else:
+        Y = random_rows(m0)
+    # ONE symbolic analysis for every contour point: the pattern of ze*B - A never changes (Feast.hs:212).
+    # The pattern (union of the two, Sparse.hs:385-399) and the places of A's and B's entries in it are
+    # found once; a contour point only recomputes the values  ze * b - a.
+    shifted = lin(-1.0, A, 1.0, B)
+    analysis = U.analyze(shifted)
+    a_u = np.zeros(len(shifted.values), dtype=np.complex128)
+    b_u = np.zeros(len(shifted.values), dtype=np.complex128)
+    a_u[_positions(shifted, A)] = A.values
+    b_u[_positions(shifted, B)] = B.values
     tol = 10.0 ** (-params.feastTolerance)
     lam, X, res = np.zeros(0), np.zeros((n, 0), dtype=complex), np.zeros(0)
+    last_trace = None
+    clock = {"values": 0.0, "factor": 0.0, "solve": 0.0, "spmv": 0.0, "dense": 0.0}
+
+    def tick(key, t0):
+        torch.cuda.synchronize(dev)
+        clock[key] += time.perf_counter() - t0
+        return time.perf_counter()
+
     for it in range(20):
-        BY = np.stack([mulV(B, np.ascontiguousarray(Y[:, j])) for j in range(m0)], axis=1)  # ijob 40
-        Q = np.zeros((n, m0), dtype=complex)
+        t0 = time.perf_counter()
+        BY = _apply(opB, Y)                                                    # ijob 40
+        rhs = BY if BY.dtype == torch.complex128 else BY.to(torch.complex128)
+        t0 = tick("spmv", t0)
+        Q = torch.zeros((m0, n), dtype=sub_t, device=dev)
         for th in thetas:
             ze = c + r * np.exp(1j * th)
-            mat = lin(-1.0, A, 1.0, cmap(lambda v: v * ze, B))    # ijob 10: ze*B - A, sparse add on the GPU
-            fact = U.factor(mat, analysis)                          #          numeric LU, same analysis
-            # ijob 11 (Feast.hs:197-201 solves one subspace column at a time): all m0 columns in
-            # one pass through the factors
-            qs = U.linearSolveMany_(fact, U.UmfpackNormal, mat, [BY[:, j] for j in range(m0)])
-            for j in range(m0):
-                Q[:, j] += (r * np.exp(1j * th) / ne) * qs[j]
+            w = complex(r * np.exp(1j * th) / ne)
+            mat = type(shifted)(n, n, shifted.pointers, shifted.indices, ze * b_u - a_u)   # ijob 10: ze*B - A
+            t0 = tick("values", t0)
+            fact = U.factor(mat, analysis)                                     #          numeric LU, same analysis
+            t0 = tick("factor", t0)
+            # ijob 11 (Feast.hs:197-201 solves one subspace column at a time): all m0 vectors in one pass
+            # through the factors
+            qs = U.linearSolveManyDevice_(fact, U.UmfpackNormal, mat, rhs)
+            if real_problem:
+                Q += 2.0 * (qs * w).real
+            else:
+                qh = U.linearSolveManyDevice_(fact, U.UmfpackTrans, mat, rhs)  # ijob 21: the mirrored point
+                Q += qs * w + qh * w.conjugate()
+                del qh
+            del fact, qs
+            t0 = tick("solve", t0)
         # Rayleigh-Ritz on the filtered subspace (dense, m0 x m0)
-        AQ = np.stack([mulV(A, np.ascontiguousarray(Q[:, j])) for j in range(m0)], axis=1)        # ijob 30
-        BQ = np.stack([mulV(B, np.ascontiguousarray(Q[:, j])) for j in range(m0)], axis=1)        # ijob 40
-        Aq, Bq = Q.conj().T @ AQ, Q.conj().T @ BQ
+        AQ = _apply(opA, Q)                                                    # ijob 30
+        BQ = _apply(opB, Q)                                                    # ijob 40
+        t0 = tick("spmv", t0)
+        Aq = (Q.conj() @ AQ.T).cpu().numpy()
+        Bq = (Q.conj() @ BQ.T).cpu().numpy()
         # drop numerically dependent directions of the subspace
-        w, V = np.linalg.eigh(0.5 * (Bq + Bq.conj().T))
-        keep = w > 1e-12 * w.max()
-        T = V[:, keep] / np.sqrt(w[keep])
-        ev, Z = np.linalg.eigh(0.5 * ((T.conj().T @ Aq @ T) + (T.conj().T @ Aq @ T).conj().T))
-        Xs = Q @ (T @ Z)
+        w_, V = np.linalg.eigh(0.5 * (Bq + Bq.conj().T))
+        keep = w_ > 1e-12 * w_.max()
+        T = V[:, keep] / np.sqrt(w_[keep])
+        Ar_ = T.conj().T @ Aq @ T
+        ev, Z = np.linalg.eigh(0.5 * (Ar_ + Ar_.conj().T))
+        TZ = T @ Z                                                              # m0 x (kept directions)
+        TZd = torch.from_numpy(np.ascontiguousarray(TZ.T)).to(dev).to(sub_t)   # rows = Ritz vectors' coefficients
+        Xs = TZd @ Q
         inside = (ev > emin) & (ev < emax)
-        lam, X = ev[inside], Xs[:, inside]
-        if X.shape[1]:
-            AX = np.stack([mulV(A, np.ascontiguousarray(X[:, j])) for j in range(X.shape[1])], axis=1)
-            BX = np.stack([mulV(B, np.ascontiguousarray(X[:, j])) for j in range(X.shape[1])], axis=1)
-            res = np.linalg.norm(AX - BX * lam, axis=0) / (np.linalg.norm(BX, axis=0) * max(abs(emin), abs(emax)))
+        lam = ev[inside]
+        sel = torch.from_numpy(np.nonzero(inside)[0]).to(dev)
+        t0 = tick("dense", t0)
+        if len(lam):
+            # A X and B X are linear images of what was already multiplied: (T Z)^T (A Q), (T Z)^T (B Q)
+            AX, BX = (TZd @ AQ)[sel], (TZd @ BQ)[sel]
+            lam_d = torch.from_numpy(lam).to(dev).to(sub_t)[:, None]
+            res = (torch.linalg.vector_norm(AX - BX * lam_d, dim=1) /
+                   (torch.linalg.vector_norm(BX, dim=1) * max(abs(emin), abs(emax)))).cpu().numpy()
+            t0 = tick("dense", t0)
             if params.feastDebug:
                 print("feast iteration %d: %d eigenvalues, max residual %.3e" % (it, len(lam), res.max()))
-            if res.max() < tol:
+            # libfeast's default stopping test (fpm(6) = 0 in its documentation): the relative change of the
+            # trace — the sum of the eigenvalues inside — between two iterations; the residual test is the
+            # alternative (fpm(6) = 1) and ends the loop here as well
+            trace = float(np.sum(lam))
+            if res.max() < tol or (last_trace is not None and abs(trace - last_trace) / max(abs(emin), abs(emax)) < tol):
                 break
-        Y = np.zeros((n, m0), dtype=complex)
-        Y[:, :Xs.shape[1]] = Xs
-        if Xs.shape[1] < m0:
-            Y[:, Xs.shape[1]:] = rng.normal(size=(n, m0 - Xs.shape[1]))
+            last_trace = trace
+        else:
+            last_trace = None
+        Y = Xs if Xs.shape[0] == m0 else torch.cat([Xs, random_rows(m0 - Xs.shape[0])], dim=0)
+        Y = Y.contiguous()
+    X = Xs[sel].cpu().numpy().T.astype(np.complex128) if len(lam) else np.zeros((n, 0), dtype=complex)
+    if params.feastDebug:
+        print("feast seconds: " + ", ".join("%s %.3f" % kv for kv in sorted(clock.items())))
+    geigSH_.last_clock = dict(clock, iterations=it + 1)
     return lam, X, res
 
 

@@ -56,6 +56,10 @@ def _declare():
     L.spl_umfpack_di_solve_many.argtypes = [i, ip, ip, dp, i, dp, dp, vp]
     L.spl_umfpack_zi_solve_many.restype = i
     L.spl_umfpack_zi_solve_many.argtypes = [i, ip, ip, dp, dp, i, dp, dp, dp, dp, vp]
+    L.spl_umfpack_di_solve_many_dev.restype = i
+    L.spl_umfpack_di_solve_many_dev.argtypes = [i, ip, ip, dp, i, vp, vp, vp]
+    L.spl_umfpack_zi_solve_many_dev.restype = i
+    L.spl_umfpack_zi_solve_many_dev.argtypes = [i, ip, ip, dp, i, vp, vp, vp]
     L.spl_umfpack_path.restype = i
     L.spl_umfpack_path.argtypes = [vp]
     L.spl_umfpack_stats.restype = C.c_int
@@ -218,3 +222,30 @@ def linearSolve(mat, bs):
 def solve(mat, b):
     """the reference's (<\\>) (Umfpack.hs:48-50)"""
     return linearSolve(mat, [b])[0]
+
+
+def linearSolveManyDevice_(fact, mode, mat, B):
+    """`linearSolveMany_` with the right-hand sides and the solutions in device memory: B is a torch tensor on
+    the GPU of shape (k, nrows) — row c = right-hand side c, float64 for real factors, complex128 for complex
+    ones — and the result is a new tensor of the same shape and device (spl_umfpack_{di,zi}_solve_many_dev)."""
+    import torch
+    L = _declare()
+    want = torch.complex128 if mat.is_complex else torch.float64
+    if bool(fact.complex) != bool(mat.is_complex):
+        raise UmfpackError("linearSolveManyDevice_: %s factors used with a %s matrix"
+                           % ("complex" if fact.complex else "real", "complex" if mat.is_complex else "real"))
+    if not (isinstance(B, torch.Tensor) and B.is_cuda and B.dtype == want and B.dim() == 2 and B.shape[1] == mat.nrows
+            and B.is_contiguous()):
+        raise UmfpackError("linearSolveManyDevice_: B must be a contiguous %s GPU tensor of shape (k, %d)" % (want, mat.nrows))
+    k = int(B.shape[0])
+    X = torch.zeros((k, mat.ncols), dtype=want, device=B.device)
+    if k == 0:
+        return X
+    nr, nc, ap, ai, ax = mat._tuple32()
+    torch.cuda.current_stream(B.device).synchronize()  # the library works on the null stream of the device
+    fn = L.spl_umfpack_zi_solve_many_dev if mat.is_complex else L.spl_umfpack_di_solve_many_dev
+    with torch.cuda.device(B.device):
+        st = fn(int(mode), p_i32(ap), p_i32(ai), p_f64(ax), k, C.c_void_p(X.data_ptr()), C.c_void_p(B.data_ptr()), fact.value)
+    _report("linearSolveManyDevice_: umfpack_solve", st)
+    return X
+

@@ -49,3 +49,39 @@ def test_feast_generalized(gpu, pkg):
     ref = np.linalg.eigvalsh(pkg.pack(A)) / 2.0
     inside = ref[(ref > 2.2) & (ref < 4.3)]
     assert close_enough(np.sort(lam), inside, 1e-9)
+
+
+def test_feast_complex_hermitian_uses_transposed_solves(gpu, pkg):
+    """A genuinely complex Hermitian matrix: the lower half of the contour comes from UmfpackTrans solves with
+    the upper half's factors (ijob 21, Feast.hs:228); eigenvalues against numpy's dense eigvalsh"""
+    rng = np.random.default_rng(12)
+    n = 50
+    tri = [(i, i, float(i + 1)) for i in range(n)]
+    for i in range(n - 1):
+        z = complex(0.3 * rng.normal(), 0.3 * rng.normal())
+        tri += [(i, i + 1, z), (i + 1, i, z.conjugate())]
+    A = pkg.fromTriples(n, n, [(r, c, complex(v)) for r, c, v in tri])
+    assert A.is_complex and pkg.hermitian(A)
+    ref = np.linalg.eigvalsh(pkg.pack(A))
+    lo, hi = 0.5 * (ref[11] + ref[12]), 0.5 * (ref[16] + ref[17])
+    lam, X = pkg.feast.eigSH(8, (lo, hi), A)
+    assert close_enough(np.sort(lam), ref[12:17], 1e-9)
+    assert pkg.feast.geigSH_.last_clock["iterations"] <= 12
+    D = pkg.pack(A)
+    for l, v in zip(lam, X.T):
+        assert np.linalg.norm(D @ v - l * v) < 1e-8 * np.linalg.norm(v)
+
+
+def test_feast_real_and_complex_paths_agree(gpu, pkg):
+    """a real symmetric matrix given as Double and as Complex Double with a complex start: conjugation of the
+    upper half contour and the transposed solves give the same eigenvalues"""
+    n = 30
+    tri = [(i, i, 2.0) for i in range(n)] + [(i, i + 1, -1.0) for i in range(n - 1)] + [(i + 1, i, -1.0) for i in range(n - 1)]
+    A = pkg.fromTriples(n, n, tri)
+    exact = 2 - 2 * np.cos(np.arange(1, n + 1) * np.pi / (n + 1))
+    lo, hi = 0.5 * (exact[4] + exact[5]), 0.5 * (exact[8] + exact[9])
+    lam_r, _, _ = pkg.feast.geigSH_(pkg.feast.defaultFeastParams, 8, (lo, hi), A)
+    rng = np.random.default_rng(5)
+    guess = rng.normal(size=(n, 8)) + 1j * rng.normal(size=(n, 8))
+    lam_c, _, _ = pkg.feast.geigSH_(pkg.feast.defaultFeastParams, 8, (lo, hi), A, guess=guess)
+    assert close_enough(np.sort(lam_r), exact[5:9], 1e-9) and close_enough(np.sort(lam_c), exact[5:9], 1e-9)

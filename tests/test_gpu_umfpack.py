@@ -460,3 +460,60 @@ def test_static_pivoting_random_unsymmetric_mesh(gpu, pkg, O, m, dim, tiny_diag)
         x = U.linearSolve_(fact, mode, M, b)
         assert fact.path == 5 if tiny_diag else fact.path in (4, 5), fact.path
         assert _backward_error(op, x, b) <= 1e-13
+
+
+def test_solve_many_device_pointers_match_host(gpu, pkg, O):
+    """spl_umfpack_{di,zi}_solve_many_dev: right-hand sides and solutions in HBM (torch tensors) — the same
+    numbers as the host-array entry points, both systems, real and complex"""
+    import scipy.sparse as sp
+    import torch
+    rng = np.random.default_rng(77)
+    m = 24
+    T = sp.diags([-np.ones(m - 1), 2.5 * np.ones(m), -np.ones(m - 1)], (-1, 0, 1))
+    S = sp.csc_matrix(sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m)))
+    S.data = S.data * rng.uniform(0.8, 1.2, S.nnz)
+    S.sort_indices()
+    n = S.shape[0]
+    U = pkg.umfpack
+    for cplx in (False, True):
+        vals = S.data + (0.3j * rng.uniform(-1, 1, S.nnz) if cplx else 0.0)
+        M = pkg.Matrix(n, n, S.indptr, S.indices, vals)
+        fact = U.factor(M, U.analyze(M))
+        B = rng.normal(size=(5, n)) + (1j * rng.normal(size=(5, n)) if cplx else 0.0)
+        for mode in (U.UmfpackNormal, U.UmfpackTrans):
+            host = U.linearSolveMany_(fact, mode, M, [B[c] for c in range(5)])
+            devX = U.linearSolveManyDevice_(fact, mode, M, torch.from_numpy(np.ascontiguousarray(B)).cuda())
+            assert devX.is_cuda and devX.shape == (5, n)
+            assert np.array_equal(devX.cpu().numpy(), np.stack(host))
+    with pytest.raises(U.UmfpackError):
+        U.linearSolveManyDevice_(fact, U.UmfpackNormal, M, torch.zeros((2, n + 1), dtype=torch.complex128, device="cuda"))
+    with pytest.raises(U.UmfpackError):
+        U.linearSolveManyDevice_(fact, U.UmfpackNormal, M, torch.zeros((2, n), dtype=torch.float64, device="cuda"))
+
+
+def test_static_pivoting_complex_mesh(gpu, pkg):
+    """the `zi` path with a useless diagonal: the solve refactors the EMBEDDING the object holds (its own device
+    copy, not the caller's complex arrays) with static pivoting and stays on the tree; both systems, packed and
+    device-pointer right-hand sides"""
+    import scipy.sparse as sp
+    import torch
+    rng = np.random.default_rng(5)
+    m = 40
+    T = sp.diags([np.ones(m - 1), np.ones(m), np.ones(m - 1)], (-1, 0, 1))
+    S = sp.csc_matrix(sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m)), dtype=np.complex128)
+    S.data = rng.uniform(-1, 1, S.nnz) + 1j * rng.uniform(-1, 1, S.nnz)
+    S.setdiag(1e-12 * (rng.uniform(0.5, 1.0, S.shape[0]) + 0j))
+    S = sp.csc_matrix(S)
+    S.sort_indices()
+    n = S.shape[0]
+    M = pkg.Matrix(n, n, S.indptr, S.indices, S.data)
+    U = pkg.umfpack
+    fact = U.factor(M, U.analyze(M))
+    xs = rng.uniform(0.5, 1.5, n) + 1j * rng.uniform(-1, 1, n)
+    for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, sp.csc_matrix(S.conj().T))):
+        b = np.asarray(op @ xs).ravel()
+        x = U.linearSolve_(fact, mode, M, b)
+        assert fact.path in (0, 5), fact.path
+        assert _backward_error(op, x, b) <= 1e-12
+        xd = U.linearSolveManyDevice_(fact, mode, M, torch.from_numpy(b[None, :].copy()).cuda()).cpu().numpy()[0]
+        assert _backward_error(op, xd, b) <= 1e-12

@@ -45,7 +45,8 @@ def main():
     err = float(np.max(np.abs(lam - inside) / inside)) if ok and len(lam) else None
     print(json.dumps({"matrix": "2-D Laplacian %d^2" % m, "n": n, "window": [args.lo, args.hi], "m0": args.m0,
                       "eigenvalues_exact_in_window": len(inside), "found": len(lam), "max_rel_error": err,
-                      "seconds": round(dt, 3)}), flush=True)
+                      "seconds": round(dt, 3),
+                      "stage_seconds": {k: round(v, 3) for k, v in pkg.feast.geigSH_.last_clock.items()}}), flush=True)
 
 
 if __name__ == "__main__":
