@@ -100,6 +100,13 @@ int spl_spgemm(int nrowsA, int ncolsA, const int *Ap, const int *Ai, const doubl
 int spl_lin(double alpha, int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Ax,
             double beta, int nrowsB, int ncolsB, const int *Bp, const int *Bi, const double *Bx,
             int *nrowsC, int *ncolsC, int **Cp, int **Ci, double **Cx);
+/* The same on `Matrix U.Vector (Complex Double)` (the second SPECIALIZE instance, Sparse.hs:456-457; what
+ * Feast.hs:216 calls with a complex contour point: `lin (-1) matA _ze matB`): values and the two scalars are
+ * (re, im) pairs, products and sums evaluated in Data.Complex's order, so the result is bit-identical to the
+ * Haskell code.  *Cz is malloc()'d with 2 * nnz doubles. */
+int spl_lin_z(const double alpha[2], int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Az,
+              const double beta[2], int nrowsB, int ncolsB, const int *Bp, const int *Bi, const double *Bz,
+              int *nrowsC, int *ncolsC, int **Cp, int **Ci, double **Cz);
 
 /* transpose (Sparse.hs:301-329): CSC(A) -> CSC(A^T) == CSR(A).  Caller
  * allocates Tp[nrows+1], Ti[nnz], Tx[nnz]. */

@@ -268,6 +268,26 @@ def lin(alpha, a, beta, b):
     return (ar, ac, ptrs, _take(ci, nz, I64), _take(cx, nz, F64))
 
 
+def lin_z(alpha, a, beta, b):
+    """lin on Complex Double (orc_lin_z): complex scalars, matrix tuples with complex values (real ones are
+    promoted, as the reference's types would demand)"""
+    ar, ac, ap, ai, ax = _matc(a)
+    br, bc, bp, bi, bx = _matc(b)
+    ax = np.ascontiguousarray(ax, dtype=np.complex128)
+    bx = np.ascontiguousarray(bx, dtype=np.complex128)
+    al = np.array([complex(alpha).real, complex(alpha).imag], dtype=F64)
+    be = np.array([complex(beta).real, complex(beta).imag], dtype=F64)
+    cp, ci, cx = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    st = lib().orc_lin_z(_D(al), C.c_int64(ar), C.c_int64(ac), _I(ap), _I(ai), _D(ax.view(F64)),
+                         _D(be), C.c_int64(br), C.c_int64(bc), _I(bp), _I(bi), _D(bx.view(F64)),
+                         C.byref(cp), C.byref(ci), C.byref(cx))
+    if st != 0:
+        raise OracleError("glin: dimension mismatch")
+    ptrs = _take(cp, ac + 1, I64)
+    nz = int(ptrs[ac])
+    return (ar, ac, ptrs, _take(ci, nz, I64), _take(cx, 2 * nz, F64).view(np.complex128))
+
+
 def add(a, b):
     return lin(1.0, a, 1.0, b)
 

@@ -440,6 +440,88 @@ int orc_lin(double alpha, Int nrowsA, Int ncolsA, const Int *Ap, const Int *Ai, 
   return ORC_OK;
 }
 
+/* lin on Complex Double (Sparse.hs:426-431 over glin :401-424 at a = Complex Double; the call of
+ * feast/src/Numeric/LinearAlgebra/Feast.hs:216, `lin (-1) matA _ze matB`).  Values and the scalars are packed
+ * (re, im) pairs; `r + alpha * a` with Data.Complex's instance: the product (x*x' - y*y') :+ (x*y' + y*x'),
+ * the sum componentwise.  The same three cases as orc_lin; the scatter-gather workspace holds a complex number
+ * per row (two planes here). */
+int orc_lin_z(const double *alpha, Int nrowsA, Int ncolsA, const Int *Ap, const Int *Ai, const double *Ax,
+              const double *beta, Int nrowsB, Int ncolsB, const Int *Bp, const Int *Bi, const double *Bx,
+              Int **Cp_out, Int **Ci_out, double **Cx_out) {
+  if (nrowsA != nrowsB) return ORC_ERR_DIM; /* :408 */
+  if (ncolsA != ncolsB) return ORC_ERR_DIM; /* :409 */
+  orc_sg sg;
+  if (sg_run(&sg, nrowsA) != ORC_OK) return ORC_ERR_ALLOC;
+  double *im = (double *)malloc((size_t)(nrowsA > 0 ? nrowsA : 1) * sizeof(double));
+  Int cap = 16, nnz = 0;
+  Int *idx = (Int *)malloc((size_t)cap * sizeof(Int));
+  double *val = (double *)malloc((size_t)cap * 2 * sizeof(double));
+  Int *Cp = (Int *)malloc((size_t)(ncolsA + 1) * sizeof(Int));
+  if (!im || !idx || !val || !Cp) return ORC_ERR_ALLOC;
+  Cp[0] = 0;
+  const double ar = alpha[0], ai = alpha[1], br = beta[0], bi = beta[1];
+  for (Int j = 0; j < ncolsA; ++j) {
+    const Int na = Ap[j + 1] - Ap[j], nb = Bp[j + 1] - Bp[j];
+    if (nnz + na + nb > cap) {
+      while (nnz + na + nb > cap) cap *= 2;
+      idx = (Int *)realloc(idx, (size_t)cap * sizeof(Int));
+      val = (double *)realloc(val, (size_t)cap * 2 * sizeof(double));
+      if (!idx || !val) return ORC_ERR_ALLOC;
+    }
+    Int *ci = idx + nnz;
+    double *cx = val + 2 * nnz;
+    Int pop;
+    if (na == 0) { /* S.cmap (fB 0) colB */
+      for (Int t = 0; t < nb; ++t) {
+        const double xr = Bx[2 * (Bp[j] + t)], xi = Bx[2 * (Bp[j] + t) + 1];
+        ci[t] = Bi[Bp[j] + t];
+        cx[2 * t] = 0.0 + (br * xr - bi * xi);
+        cx[2 * t + 1] = 0.0 + (br * xi + bi * xr);
+      }
+      pop = nb;
+    } else if (nb == 0) { /* S.cmap (fA 0) colA */
+      for (Int t = 0; t < na; ++t) {
+        const double xr = Ax[2 * (Ap[j] + t)], xi = Ax[2 * (Ap[j] + t) + 1];
+        ci[t] = Ai[Ap[j] + t];
+        cx[2 * t] = 0.0 + (ar * xr - ai * xi);
+        cx[2 * t + 1] = 0.0 + (ar * xi + ai * xr);
+      }
+      pop = na;
+    } else {
+      sg_reset(&sg, 0.0);
+      for (Int i = 0; i < nrowsA; ++i) im[i] = 0.0;
+      sg_scatter_indices(&sg, na, Ai + Ap[j]);
+      for (Int p = Ap[j]; p < Ap[j + 1]; ++p) {
+        const double xr = Ax[2 * p], xi = Ax[2 * p + 1];
+        sg.values[Ai[p]] = sg.values[Ai[p]] + (ar * xr - ai * xi);
+        im[Ai[p]] = im[Ai[p]] + (ar * xi + ai * xr);
+      }
+      sg_scatter_indices(&sg, nb, Bi + Bp[j]);
+      for (Int p = Bp[j]; p < Bp[j + 1]; ++p) {
+        const double xr = Bx[2 * p], xi = Bx[2 * p + 1];
+        sg.values[Bi[p]] = sg.values[Bi[p]] + (br * xr - bi * xi);
+        im[Bi[p]] = im[Bi[p]] + (br * xi + bi * xr);
+      }
+      pop = 0;
+      for (Int i = 0; i < nrowsA; ++i)
+        if (sg.pattern[i]) {
+          ci[pop] = i;
+          cx[2 * pop] = sg.values[i];
+          cx[2 * pop + 1] = im[i];
+          ++pop;
+        }
+    }
+    nnz += pop;
+    Cp[j + 1] = nnz;
+  }
+  sg_done(&sg);
+  free(im);
+  *Cp_out = Cp;
+  *Ci_out = idx;
+  *Cx_out = val;
+  return ORC_OK;
+}
+
 /* ------------------------------------------------------------------------
  * checkMatrix — sparse-linear/tests/Test/LinearAlgebra.hs:40-67.
  * Returns 0 if all format invariants hold, else the 1-based number of the

@@ -1034,6 +1034,77 @@ int spl_lin(double alpha, int nrowsA, int ncolsA, const int *Ap, const int *Ai, 
   });
 }
 
+// upload + validate a packed-complex CSC 5-tuple; unsorted columns are sorted by row with the values following
+// their positions
+static int upload_csc_z(int nrows, int ncols, const int *Ap, const int *Ai, const double *Az, DeviceCsc &d,
+                        hipStream_t s) {
+  int st = check_tuple(nrows, ncols, Ap, Ai, Az);
+  if (st != SPL_OK) return st;
+  d.nnz = Ap[ncols];
+  upload(d.p, Ap, (size_t)ncols + 1, s);
+  upload(d.i, Ai, (size_t)d.nnz, s);
+  upload(d.x, Az, (size_t)d.nnz * 2, s);
+  st = validate_compressed(d.p.get(), d.i.get(), ncols, nrows, d.nnz, s);
+  if (st != SPL_OK) return st;
+  if (!columns_sorted(d.p.get(), d.i.get(), ncols, s)) {
+    DBuf<int64_t> p64((size_t)ncols + 1);
+    DBuf<double> pos((size_t)d.nnz), sorted((size_t)d.nnz * 2);
+    widen_i32_to_i64(d.p.get(), p64.get(), (int64_t)ncols + 1, s);
+    fill_positions(d.nnz, pos.get(), s);
+    segmented_sort_pairs(p64.get(), ncols, d.i.get(), pos.get(), s);
+    gather_complex_values(d.nnz, pos.get(), d.x.get(), sorted.get(), s);
+    SPL_HIP(hipStreamSynchronize(s));
+    d.x = std::move(sorted);
+  }
+  return SPL_OK;
+}
+
+int spl_lin_z(const double alpha[2], int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Az,
+              const double beta[2], int nrowsB, int ncolsB, const int *Bp, const int *Bi, const double *Bz,
+              int *nrowsC, int *ncolsC, int **Cp, int **Ci, double **Cz) {
+  if (!nrowsC || !ncolsC || !Cp || !Ci || !Cz || !alpha || !beta) return SPL_ERROR_argument_missing;
+  *Cp = nullptr; *Ci = nullptr; *Cz = nullptr;
+  if (nrowsA >= 0 && ncolsA >= 0 && nrowsB >= 0 && ncolsB >= 0 && (nrowsA != nrowsB || ncolsA != ncolsB))
+    return SPL_ERROR_dimension_mismatch;  // Sparse.hs:408-409
+  return guarded([&]() -> int {
+    (void)current_device();
+    hipStream_t s = nullptr;
+    DeviceCsc A, B;
+    int st = upload_csc_z(nrowsA, ncolsA, Ap, Ai, Az, A, s);
+    if (st != SPL_OK) return st;
+    st = upload_csc_z(nrowsB, ncolsB, Bp, Bi, Bz, B, s);
+    if (st != SPL_OK) return st;
+    DBuf<int64_t> dCp;
+    DBuf<int> dCi;
+    DBuf<double> dCz;
+    int64_t nnzC = 0;
+    lin_device_z(alpha, A.p.get(), A.i.get(), A.x.get(), beta, B.p.get(), B.i.get(), B.x.get(), ncolsA, dCp, dCi,
+                 dCz, &nnzC, s);
+    if (nnzC >= 0x7fffffffLL) return SPL_ERROR_index_overflow;
+    int *hp = (int *)malloc(((size_t)ncolsA + 1) * sizeof(int));
+    int *hi = (int *)malloc((size_t)(nnzC ? nnzC : 1) * sizeof(int));
+    double *hz = (double *)malloc((size_t)(nnzC ? nnzC : 1) * 2 * sizeof(double));
+    if (!hp || !hi || !hz) { free(hp); free(hi); free(hz); return SPL_ERROR_out_of_memory; }
+    try {
+      DBuf<int> dCp32((size_t)ncolsA + 1);
+      narrow_i64_to_i32(dCp.get(), dCp32.get(), (int64_t)ncolsA + 1, s);
+      SPL_HIP(hipMemcpyAsync(hp, dCp32.get(), ((size_t)ncolsA + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+      if (nnzC) {
+        SPL_HIP(hipMemcpyAsync(hi, dCi.get(), (size_t)nnzC * sizeof(int), hipMemcpyDeviceToHost, s));
+        SPL_HIP(hipMemcpyAsync(hz, dCz.get(), (size_t)nnzC * 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+      }
+      SPL_HIP(hipStreamSynchronize(s));
+    } catch (...) {
+      free(hp); free(hi); free(hz);
+      throw;
+    }
+    *Cp = hp; *Ci = hi; *Cz = hz;
+    *nrowsC = nrowsA;
+    *ncolsC = ncolsA;
+    return SPL_OK;
+  });
+}
+
 int spl_kronecker(int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Ax, int nrowsB,
                   int ncolsB, const int *Bp, const int *Bi, const double *Bx, int *nrowsC, int *ncolsC,
                   int **Cp, int **Ci, double **Cx) {

@@ -115,12 +115,14 @@ __global__ __launch_bounds__(256) void sorted_check_kernel(const int *__restrict
   if (bad) atomicOr(flag, 1);
 }
 
-template <bool FILL>
+// VW = 1: Double.  VW = 2: Complex Double, values and scalars as (re, im) pairs; products and sums in
+// Data.Complex's order — (x:+y)*(x':+y') = (x*x' - y*y') :+ (x*y' + y*x'), sums componentwise.
+template <bool FILL, int VW>
 __global__ __launch_bounds__(256) void lin_merge_kernel(
-    double alpha, const int *__restrict__ Ap, const int *__restrict__ Ai, const double *__restrict__ Ax,
-    double beta, const int *__restrict__ Bp, const int *__restrict__ Bi, const double *__restrict__ Bx,
-    int64_t ncols, int *__restrict__ counts, const int64_t *__restrict__ Cp, int *__restrict__ Ci,
-    double *__restrict__ Cx) {
+    double alpha, double alpha_im, const int *__restrict__ Ap, const int *__restrict__ Ai,
+    const double *__restrict__ Ax, double beta, double beta_im, const int *__restrict__ Bp,
+    const int *__restrict__ Bi, const double *__restrict__ Bx, int64_t ncols, int *__restrict__ counts,
+    const int64_t *__restrict__ Cp, int *__restrict__ Ci, double *__restrict__ Cx) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncols) return;
   int a = Ap[c], b = Bp[c];
@@ -131,11 +133,27 @@ __global__ __launch_bounds__(256) void lin_merge_kernel(
     const int ra = a < ae ? Ai[a] : 0x7fffffff;
     const int rb = b < be ? Bi[b] : 0x7fffffff;
     if (FILL) {
-      double w = 0.0;                       // SG.reset 0
-      if (ra <= rb) w = w + alpha * Ax[a];  // fA: \r a -> r + alpha * a
-      if (rb <= ra) w = w + beta * Bx[b];   // fB: \r b -> r + beta * b
       Ci[o] = ra < rb ? ra : rb;
-      Cx[o] = w;
+      if (VW == 1) {
+        double w = 0.0;                       // SG.reset 0
+        if (ra <= rb) w = w + alpha * Ax[a];  // fA: \r a -> r + alpha * a
+        if (rb <= ra) w = w + beta * Bx[b];   // fB: \r b -> r + beta * b
+        Cx[o] = w;
+      } else {
+        double wr = 0.0, wi = 0.0;
+        if (ra <= rb) {
+          const double xr = Ax[2 * (size_t)a], xi = Ax[2 * (size_t)a + 1];
+          wr = wr + (alpha * xr - alpha_im * xi);
+          wi = wi + (alpha * xi + alpha_im * xr);
+        }
+        if (rb <= ra) {
+          const double xr = Bx[2 * (size_t)b], xi = Bx[2 * (size_t)b + 1];
+          wr = wr + (beta * xr - beta_im * xi);
+          wi = wi + (beta * xi + beta_im * xr);
+        }
+        Cx[2 * (size_t)o] = wr;
+        Cx[2 * (size_t)o + 1] = wi;
+      }
       ++o;
     }
     ++n;
@@ -221,27 +239,46 @@ bool columns_sorted(const int *d_ptr, const int *d_idx, int64_t ncols, hipStream
   return h == 0;
 }
 
-// C = alpha A + beta B on device CSC arrays with sorted columns.
-void lin_device(double alpha, const int *Ap, const int *Ai, const double *Ax, double beta, const int *Bp,
-                const int *Bi, const double *Bx, int64_t ncols, DBuf<int64_t> &Cp, DBuf<int> &Ci,
-                DBuf<double> &Cx, int64_t *nnzC, hipStream_t s) {
+// C = alpha A + beta B on device CSC arrays with sorted columns; vw = 2: packed complex values, scalars
+// (alpha, alpha_im), (beta, beta_im)
+static void lin_device_any(int vw, double alpha, double alpha_im, const int *Ap, const int *Ai, const double *Ax,
+                           double beta, double beta_im, const int *Bp, const int *Bi, const double *Bx, int64_t ncols,
+                           DBuf<int64_t> &Cp, DBuf<int> &Ci, DBuf<double> &Cx, int64_t *nnzC, hipStream_t s) {
   Cp.alloc((size_t)ncols + 1);
   DBuf<int> counts((size_t)ncols);
   const unsigned grid = blocks_for(ncols, 256);
   if (ncols > 0)
-    hipLaunchKernelGGL(lin_merge_kernel<false>, dim3(grid), dim3(256), 0, s, alpha, Ap, Ai, Ax, beta, Bp, Bi,
-                       Bx, ncols, counts.get(), (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
+    hipLaunchKernelGGL((lin_merge_kernel<false, 1>), dim3(grid), dim3(256), 0, s, alpha, alpha_im, Ap, Ai, Ax, beta,
+                       beta_im, Bp, Bi, Bx, ncols, counts.get(), (const int64_t *)nullptr, (int *)nullptr,
+                       (double *)nullptr);
   exclusive_scan_i32_to_i64(counts.get(), Cp.get(), ncols, s);
   int64_t nz = 0;
   SPL_HIP(hipMemcpyAsync(&nz, Cp.get() + ncols, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
   Ci.alloc((size_t)nz);
-  Cx.alloc((size_t)nz);
-  if (ncols > 0 && nz > 0)
-    hipLaunchKernelGGL(lin_merge_kernel<true>, dim3(grid), dim3(256), 0, s, alpha, Ap, Ai, Ax, beta, Bp, Bi,
-                       Bx, ncols, (int *)nullptr, Cp.get(), Ci.get(), Cx.get());
+  Cx.alloc((size_t)nz * (size_t)vw);
+  if (ncols > 0 && nz > 0) {
+    if (vw == 1)
+      hipLaunchKernelGGL((lin_merge_kernel<true, 1>), dim3(grid), dim3(256), 0, s, alpha, alpha_im, Ap, Ai, Ax, beta,
+                         beta_im, Bp, Bi, Bx, ncols, (int *)nullptr, Cp.get(), Ci.get(), Cx.get());
+    else
+      hipLaunchKernelGGL((lin_merge_kernel<true, 2>), dim3(grid), dim3(256), 0, s, alpha, alpha_im, Ap, Ai, Ax, beta,
+                         beta_im, Bp, Bi, Bx, ncols, (int *)nullptr, Cp.get(), Ci.get(), Cx.get());
+  }
   SPL_HIP(hipStreamSynchronize(s));
   *nnzC = nz;
+}
+
+void lin_device(double alpha, const int *Ap, const int *Ai, const double *Ax, double beta, const int *Bp,
+                const int *Bi, const double *Bx, int64_t ncols, DBuf<int64_t> &Cp, DBuf<int> &Ci,
+                DBuf<double> &Cx, int64_t *nnzC, hipStream_t s) {
+  lin_device_any(1, alpha, 0.0, Ap, Ai, Ax, beta, 0.0, Bp, Bi, Bx, ncols, Cp, Ci, Cx, nnzC, s);
+}
+
+void lin_device_z(const double alpha[2], const int *Ap, const int *Ai, const double *Az, const double beta[2],
+                  const int *Bp, const int *Bi, const double *Bz, int64_t ncols, DBuf<int64_t> &Cp, DBuf<int> &Ci,
+                  DBuf<double> &Cz, int64_t *nnzC, hipStream_t s) {
+  lin_device_any(2, alpha[0], alpha[1], Ap, Ai, Az, beta[0], beta[1], Bp, Bi, Bz, ncols, Cp, Ci, Cz, nnzC, s);
 }
 
 // ---- kronecker / takeDiag (Sparse.hs:597-648) --------------------------------------------------

@@ -190,6 +190,9 @@ bool columns_sorted(const int *d_ptr, const int *d_idx, int64_t ncols, hipStream
 void lin_device(double alpha, const int *Ap, const int *Ai, const double *Ax, double beta, const int *Bp,
                 const int *Bi, const double *Bx, int64_t ncols, DBuf<int64_t> &Cp, DBuf<int> &Ci,
                 DBuf<double> &Cx, int64_t *nnzC, hipStream_t s);
+void lin_device_z(const double alpha[2], const int *Ap, const int *Ai, const double *Az, const double beta[2],
+                  const int *Bp, const int *Bi, const double *Bz, int64_t ncols, DBuf<int64_t> &Cp, DBuf<int> &Ci,
+                  DBuf<double> &Cz, int64_t *nnzC, hipStream_t s);
 
 void kronecker_device(int nrowsB, const int *Ap, const int *Ai, const double *Ax, int64_t ncolsA, const int *Bp,
                       const int *Bi, const double *Bx, int64_t ncolsB, DBuf<int64_t> &Cp, DBuf<int> &Ci,

@@ -530,14 +530,25 @@ def lin(alpha, matA, beta, matB):
         _oops("glin", "row number mismatch")
     if matA.ncols != matB.ncols:
         _oops("glin", "column number mismatch")
-    if matA.is_complex or matB.is_complex:
-        if np.iscomplexobj(alpha) and complex(alpha).imag != 0 or np.iscomplexobj(beta) and complex(beta).imag != 0:
-            raise NotImplementedError("lin: complex scalars need the native complex kernels (SURVEY.md §8f rank 3)")
-        al, be = float(np.real(alpha)), float(np.real(beta))
-        ar, ai = (matA if matA.is_complex else cmap(lambda v: v.astype(C128), matA))._parts()
-        br, bi = (matB if matB.is_complex else cmap(lambda v: v.astype(C128), matB))._parts()
-        re, im = lin(al, ar, be, br), lin(al, ai, be, bi)  # real scalars act componentwise: exact
-        return Matrix(re.ncols, re.nrows, re.pointers, re.indices, re.values + 1j * im.values)
+    if matA.is_complex or matB.is_complex or np.iscomplexobj(alpha) or np.iscomplexobj(beta):
+        # Complex Double (what Feast.hs:216 calls: `lin (-1) matA _ze matB`): the native packed-complex kernel,
+        # Data.Complex's evaluation order (spl_lin_z)
+        _ffi.require_gpu()
+        a = (matA if matA.is_complex else cmap(lambda v: v.astype(C128), matA))._tuple32()
+        b = (matB if matB.is_complex else cmap(lambda v: v.astype(C128), matB))._tuple32()
+        al = np.array([complex(alpha).real, complex(alpha).imag], dtype=F64)
+        be = np.array([complex(beta).real, complex(beta).imag], dtype=F64)
+        nr, nc = C.c_int(), C.c_int()
+        cp, ci, cz = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        st = lib().spl_lin_z(p_f64(al), a[0], a[1], p_i32(a[2]), p_i32(a[3]), p_f64(a[4].view(F64)),
+                             p_f64(be), b[0], b[1], p_i32(b[2]), p_i32(b[3]), p_f64(b[4].view(F64)),
+                             C.byref(nr), C.byref(nc), C.byref(cp), C.byref(ci), C.byref(cz))
+        check("spl_lin_z", st)
+        ncols = nc.value
+        ptrs = _ffi.take_malloced(cp, ncols + 1, C.c_int, I64)
+        nz = int(ptrs[ncols])
+        return Matrix(ncols, nr.value, ptrs, _ffi.take_malloced(ci, nz, C.c_int, I64),
+                      _ffi.take_malloced(cz, 2 * nz, C.c_double, F64).view(C128))
     _ffi.require_gpu()
     a, b = matA._tuple32(), matB._tuple32()
     nr, nc = C.c_int(), C.c_int()

@@ -7,6 +7,8 @@ import pytest
 from hypothesis import HealthCheck, given, settings
 from hypothesis import strategies as st
 
+from helpers import mat_to_tuple, tuple_to_mat, tuples_equal
+
 pytestmark = pytest.mark.gpu
 
 cval = st.builds(complex, st.integers(-20, 20), st.integers(-20, 20))
@@ -221,3 +223,42 @@ def test_native_complex_fixtures_and_long_rows(gpu, pkg, O):
     y = pkg.mulV(pkg.Matrix(n, 3, Az[2], Az[3], Az[4]), x)
     yo = O.mulV_z(Az, x)
     assert np.max(np.abs(y - yo)) <= 1e-10 * np.max(np.abs(yo)) and np.array_equal(y[1:], yo[1:])
+
+
+def test_native_complex_lin_matches_oracle_bitwise(gpu, pkg, O):
+    """lin with complex scalars (what Feast.hs:216 calls: `lin (-1) matA _ze matB`) on the packed-complex kernel
+    (spl_lin_z) against the oracle's restatement of glin at Complex Double: structure and values bit for bit —
+    columns present in one operand only, overlapping entries, exact cancellation (stored 0), real operands
+    promoted, the `+` / `-` of the Num instance"""
+    rng = np.random.default_rng(23)
+    for nr, nc, k in ((1, 1, 1), (7, 5, 12), (60, 40, 300), (300, 500, 4000)):
+        A, B = _rand_complex(O, rng, nr, nc, k), _rand_complex(O, rng, nr, nc, k)
+        # empty columns on either side
+        for M in (A, B):
+            c = int(rng.integers(0, nc))
+            lo, hi = int(M[2][c]), int(M[2][c + 1])
+            M[2][c + 1:] -= hi - lo
+            keep = np.r_[0:lo, hi:len(M[3])]
+            A_or_B = (M[0], M[1], M[2], M[3][keep], M[4][keep])
+            if M is A:
+                A = A_or_B
+            else:
+                B = A_or_B
+        for alpha, beta in ((-1.0, 0.3 + 0.7j), (2.5 - 1j, -0.5j), (1.0, 1.0), (1.0, -1.0)):
+            got = pkg.lin(alpha, tuple_to_mat(pkg, A), beta, tuple_to_mat(pkg, B))
+            ref = O.lin_z(alpha, A, beta, B)
+            assert got.is_complex and tuples_equal(mat_to_tuple(got), ref)
+        # cancellation keeps the entry
+        Z = pkg.lin(1.0 + 0j, tuple_to_mat(pkg, A), -1.0 + 0j, tuple_to_mat(pkg, A))
+        assert np.array_equal(Z.indices, A[3]) and not np.any(Z.values)
+        # Num instance
+        Am, Bm = tuple_to_mat(pkg, A), tuple_to_mat(pkg, B)
+        assert tuples_equal(mat_to_tuple(Am + Bm), O.lin_z(1.0, A, 1.0, B))
+        assert tuples_equal(mat_to_tuple(Am - Bm), O.lin_z(1.0, A, -1.0, B))
+    # a real matrix with a complex scalar is promoted; unsorted input columns are tolerated
+    R = pkg.Matrix(2, 3, [0, 2, 3], [2, 0, 1], [1.0, 2.0, 3.0])
+    Rs = (3, 2, np.array([0, 2, 3]), np.array([0, 2, 1]), np.array([2.0, 1.0, 3.0]))
+    got = pkg.lin(1j, R, 2.0, R)
+    assert tuples_equal(mat_to_tuple(got), O.lin_z(1j, Rs, 2.0, Rs))
+    with pytest.raises(Exception):
+        pkg.lin(1j, R, 1.0, pkg.transpose(R))

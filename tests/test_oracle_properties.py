@@ -322,3 +322,33 @@ def test_oracle_kronecker_and_take_diag_against_dense():
 
         assert np.array_equal(dense(K), np.kron(dense(A), dense(B)))
         assert np.array_equal(O.take_diag(K), np.diag(dense(K))[:min(K[0], K[1])])
+
+
+def test_lin_complex_restatement_against_dense(O):
+    """orc_lin_z (glin at Complex Double, Sparse.hs:401-431): against dense numpy arithmetic, union pattern with
+    cancellations kept, and equal to the real restatement when everything is real"""
+    rng = np.random.default_rng(8)
+    for nr, nc, k in ((4, 3, 6), (30, 20, 150)):
+        def rnd():
+            r, c = rng.integers(0, nr, k), rng.integers(0, nc, k)
+            re = O.compress(nr, nc, r, c, rng.integers(-3, 4, k).astype(float))
+            im = O.compress(nr, nc, r, c, rng.integers(-3, 4, k).astype(float))
+            return (nr, nc, re[2], re[3], re[4] + 1j * im[4])
+        A, B = rnd(), rnd()
+        for alpha, beta in ((-1.0, 0.5 + 2j), (1j, 1.0), (2.0, -3.0)):
+            Cm = O.lin_z(alpha, A, beta, B)
+            assert O.check_matrix((Cm[0], Cm[1], Cm[2], Cm[3], np.real(Cm[4]))) == 0
+
+            def dense(m):
+                d = np.zeros((m[0], m[1]), dtype=complex)
+                cols = np.repeat(np.arange(m[1]), np.diff(m[2]))
+                d[m[3], cols] = m[4]
+                return d
+            assert np.array_equal(dense(Cm), alpha * dense(A) + beta * dense(B))  # small integers: exact
+            union = (dense(A) != 0) | (dense(B) != 0)
+            assert int(Cm[2][-1]) >= int(union.sum())  # explicit zeros of the operands stay, too
+        real = lambda m: (m[0], m[1], m[2], m[3], np.ascontiguousarray(np.real(m[4])))
+        Cr = O.lin(2.0, real(A), -0.5, real(B))
+        Cz = O.lin_z(2.0, real(A), -0.5, real(B))
+        assert np.array_equal(Cr[2], Cz[2]) and np.array_equal(Cr[3], Cz[3])
+        assert np.array_equal(Cr[4], np.real(Cz[4])) and not np.any(np.imag(Cz[4]))
