@@ -179,6 +179,8 @@ void segmented_sort_pairs_u32(const int64_t *d_ptr64, int64_t nseg, unsigned *d_
 // the `zi` wrapper's note on a `di` Numeric object: which row pairs of the embedding it swapped
 void numeric_set_pair_swap(void *Numeric, std::vector<char> &&flags);
 const std::vector<char> *numeric_pair_swap(void *Numeric);  // nullptr: none
+// symbolic analysis of the real embedding of a complex matrix, ordered on the complex pattern (umfpack.hip)
+int symbolic_of_embedding(int n, const int *Ap, const int *Ai, const int *Ep, const int *Ei, void **Symbolic);
 void finalize_matrix(Matrix *m, hipStream_t s);
 void measure_locality(Matrix *m, hipStream_t s);  // fills new_line_fraction on first call
 

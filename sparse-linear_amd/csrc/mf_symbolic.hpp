@@ -462,7 +462,11 @@ struct Worker {
 }  // namespace detail
 
 // Pattern of A given as CSC arrays (n x n); leaf = largest region that is not dissected further.
-inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T) {
+// mult > 1: (Ap, Ai) is the pattern of an n x n matrix of dense mult x mult blocks — the complex matrix behind
+// the real embedding of umfpack_zi.hip, mult = 2, unknowns interleaved — and the tree is the one of the expanded
+// (n mult) x (n mult) matrix: ordered on the small graph (a half of the vertices, a quarter of the edges), every
+// vertex then replaced by its mult unknowns, which stay together in their front.  `leaf` counts small vertices.
+inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, int mult = 1) {
   T = Tree();
   T.n = n;
   const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // phase times on stderr (diagnostic)
@@ -582,6 +586,30 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T) {
     for (int f = 0; f < nf; ++f) std::copy(bnd[(size_t)f].begin(), bnd[(size_t)f].end(), T.bidx.begin() + T.bptr[(size_t)f]);
   }
   lap("boundaries");
+  if (mult > 1) {
+    const size_t m = (size_t)mult;
+    std::vector<int> perm((size_t)n * m), inv((size_t)n * m), front_of((size_t)n * m), bidx(T.bidx.size() * m);
+    for (size_t k = 0; k < (size_t)n; ++k)
+      for (size_t h = 0; h < m; ++h) {
+        perm[k * m + h] = (int)((size_t)T.perm[k] * m + h);
+        front_of[k * m + h] = T.front_of[k];
+      }
+    for (size_t k = 0; k < (size_t)n * m; ++k) inv[(size_t)perm[k]] = (int)k;
+    for (size_t k = 0; k < T.bidx.size(); ++k)
+      for (size_t h = 0; h < m; ++h) bidx[k * m + h] = (int)((size_t)T.bidx[k] * m + h);
+    T.perm.swap(perm);
+    T.inv.swap(inv);
+    T.front_of.swap(front_of);
+    T.bidx.swap(bidx);
+    for (int f = 0; f < nf; ++f) {
+      T.p0[(size_t)f] *= mult;
+      T.np[(size_t)f] *= mult;
+      T.nb[(size_t)f] *= mult;
+    }
+    for (int f = 0; f <= nf; ++f) T.bptr[(size_t)f] *= mult;
+    T.n = n * mult;
+    lap("expansion");
+  }
   // storage layout and work estimate
   T.ld.assign((size_t)nf, 0);
   T.foff.assign((size_t)nf, 0);

@@ -684,23 +684,17 @@ using namespace spl;
 
 extern "C" {
 
-int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], const double Ax[],
-                        void **SymbolicOut, const double Control[], double Info[]) {
-  (void)Ax; (void)Control; (void)Info;
-  if (!SymbolicOut) return UMFPACK_ERROR_argument_missing;
-  *SymbolicOut = nullptr;
-  if (!Ap || (!Ai && n_col > 0 && Ap[n_col] > 0)) return UMFPACK_ERROR_argument_missing;
-  if (n_row <= 0 || n_col <= 0) return UMFPACK_ERROR_n_nonpositive;
-  if (n_row != n_col) return UMFPACK_ERROR_invalid_system;  // square systems only (Umfpack.hs:93)
-  if (Ap[n_col] < 0) return UMFPACK_ERROR_invalid_matrix;
-  int st = validate_host_csc(n_row, n_col, Ap, Ai);
-  if (st != UMFPACK_OK) return st;
+// The analysis behind umfpack_di_symbolic and, with mult = 2, umfpack_zi_symbolic: (Ap, Ai) is the n x n pattern
+// that is ORDERED; the object describes the (n mult) x (n mult) matrix of dense mult x mult blocks whose CSC
+// pattern is (Ep, Ei) — what numeric will be handed and checks against.  mult = 1: Ep = Ap, Ei = Ai.
+static int symbolic_common(int n, const int *Ap, const int *Ai, int mult, const int *Ep, const int *Ei,
+                           void **SymbolicOut) {
   try {
     std::unique_ptr<Symbolic> S(new Symbolic());
-    S->n = n_col;
-    S->nnz = Ap[n_col];
-    S->Ap.assign(Ap, Ap + n_col + 1);
-    S->ai_hash = hash_indices(Ai, S->nnz);
+    S->n = n * mult;
+    S->nnz = Ep[S->n];
+    S->Ap.assign(Ep, Ep + S->n + 1);
+    S->ai_hash = hash_indices(Ei, S->nnz);
     // The two orderings are independent host work: for anything that is not tiny the nested
     // dissection runs on its own thread(s) while this one does the band ordering.
     // Multifrontal or band?  The band factorisation costs about 2 n kl ku flops and n (kl+ku+1)
@@ -708,33 +702,44 @@ int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
     // SPL_LU_METHOD=mf / band forces the choice (tests).
     const char *method = getenv("SPL_LU_METHOD");
     const bool force_mf = method && method[0] == 'm', force_band = method && method[0] == 'b';
-    const int n = S->n;
     std::future<std::shared_ptr<mf::Tree>> tree_job;
-    if (!force_band && (force_mf || n >= 1024))
-      tree_job = std::async(std::launch::async, [n, Ap, Ai] {
+    if (!force_band && (force_mf || S->n >= 1024))
+      tree_job = std::async(std::launch::async, [n, Ap, Ai, mult] {
         std::shared_ptr<mf::Tree> T = std::make_shared<mf::Tree>();
-        mf::build_tree(n, Ap, Ai, 256, *T);
+        mf::build_tree(n, Ap, Ai, 256 / mult, *T, mult);
         return T;
       });
     const bool timing = getenv("SPL_MF_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     try {
-      rcm_order(S->n, Ap, Ai, S->perm);
+      std::vector<int> perm, inv((size_t)n, 0);
+      rcm_order(n, Ap, Ai, perm);
       if (timing) fprintf(stderr, "[symbolic] RCM done at %.1f ms\n", since());
-      S->inv.assign((size_t)S->n, 0);
-      for (int k = 0; k < S->n; ++k) S->inv[(size_t)S->perm[(size_t)k]] = k;
+      for (int k = 0; k < n; ++k) inv[(size_t)perm[(size_t)k]] = k;
       int kl = 0, ku = 0;
-      for (int j = 0; j < S->n; ++j) {
-        const int nj = S->inv[(size_t)j];
+      for (int j = 0; j < n; ++j) {
+        const int nj = inv[(size_t)j];
         for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
-          const int ni = S->inv[(size_t)Ai[p]];
+          const int ni = inv[(size_t)Ai[p]];
           kl = std::max(kl, ni - nj);
           ku = std::max(ku, nj - ni);
         }
       }
-      S->kl = kl;
-      S->ku = ku;
+      if (mult == 1) {
+        S->perm.swap(perm);
+        S->inv.swap(inv);
+        S->kl = kl;
+        S->ku = ku;
+      } else {  // block (i, j) covers rows mult i .. mult i + mult - 1, columns mult j .. mult j + mult - 1
+        S->perm.resize((size_t)S->n);
+        S->inv.resize((size_t)S->n);
+        for (int k = 0; k < n; ++k)
+          for (int h = 0; h < mult; ++h) S->perm[(size_t)k * mult + h] = perm[(size_t)k] * mult + h;
+        for (int k = 0; k < S->n; ++k) S->inv[(size_t)S->perm[(size_t)k]] = k;
+        S->kl = mult * kl + (mult - 1);
+        S->ku = mult * ku + (mult - 1);
+      }
     } catch (...) {
       if (tree_job.valid()) tree_job.wait();  // Ap / Ai are borrowed: nobody may outlive this call
       throw;
@@ -762,6 +767,32 @@ int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
   }
 }
 
+int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], const double Ax[],
+                        void **SymbolicOut, const double Control[], double Info[]) {
+  (void)Ax; (void)Control; (void)Info;
+  if (!SymbolicOut) return UMFPACK_ERROR_argument_missing;
+  *SymbolicOut = nullptr;
+  if (!Ap || (!Ai && n_col > 0 && Ap[n_col] > 0)) return UMFPACK_ERROR_argument_missing;
+  if (n_row <= 0 || n_col <= 0) return UMFPACK_ERROR_n_nonpositive;
+  if (n_row != n_col) return UMFPACK_ERROR_invalid_system;  // square systems only (Umfpack.hs:93)
+  if (Ap[n_col] < 0) return UMFPACK_ERROR_invalid_matrix;
+  int st = validate_host_csc(n_row, n_col, Ap, Ai);
+  if (st != UMFPACK_OK) return st;
+  return symbolic_common(n_col, Ap, Ai, 1, Ap, Ai, SymbolicOut);
+}
+
+}  // extern "C"
+
+namespace spl {
+// analysis of the real embedding of an n x n complex matrix from the complex pattern itself (umfpack_zi.hip);
+// (Ep, Ei): the pattern of the embedding, 2n x 2n, interleaved unknowns
+int symbolic_of_embedding(int n, const int *Ap, const int *Ai, const int *Ep, const int *Ei, void **SymbolicOut) {
+  return symbolic_common(n, Ap, Ai, 2, Ep, Ei, SymbolicOut);
+}
+}  // namespace spl
+
+extern "C" {
+
 int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *SymbolicIn,
                        void **NumericOut, const double Control[], double Info[]) {
   (void)Control; (void)Info;
@@ -783,6 +814,15 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
     N = new Numeric();
     SPL_HIP(hipGetDevice(&N->device));
     hipStream_t s = nullptr;
+    const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // phase times on stderr (diagnostic)
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+      if (!timing) return;
+      (void)hipStreamSynchronize(s);
+      const auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "[numeric] %-26s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+      t_last = now;
+    };
     N->n = n;
     N->kl = S->kl;
     N->ku = S->ku;
@@ -798,6 +838,7 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
     }
     N->At = static_cast<Matrix *>(hAt);
     if (!N->At->rowptr.get()) { delete N; return UMFPACK_ERROR_out_of_memory; }
+    lap("rows of A^T (upload)");
     N->ipiv.alloc((size_t)n);
     N->perm.alloc((size_t)n);
     N->inv.alloc((size_t)n);
@@ -816,6 +857,7 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
              : st == SPL_ERROR_invalid_matrix ? UMFPACK_ERROR_invalid_matrix : UMFPACK_ERROR_internal_error;
     }
     N->A = static_cast<Matrix *>(hA);
+    lap("ordering, rows of A");
     // Path: SPL_LU_FORCE_PIVOT=1 -> partial pivoting; =0 -> only provably safe no-interchange
     // factors (column diagonal dominance); default -> no-interchange factors for every matrix,
     // as a speculation when dominance does not hold (checked by every solve, see Numeric).
@@ -836,6 +878,7 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
     } else {
       factor_band(N, false, s);
     }
+    lap("factorisation");
     *NumericOut = N;
     return N->singular ? UMFPACK_WARNING_singular_matrix : UMFPACK_OK;
   } catch (const DeviceError &e) {

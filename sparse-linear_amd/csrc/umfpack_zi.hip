@@ -11,7 +11,9 @@
 // complex band kernel (half the index traffic) is the follow-up; values differ from a complex-
 // arithmetic LU only in rounding, and `ident <\> v == v` (suitesparse/tests/test-umfpack.hs:16-19,
 // on Vector (Complex Double)) holds exactly.
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <utility>
 #include <vector>
 
@@ -103,7 +105,9 @@ int umfpack_zi_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
     if (!embed(n_col, Ap, Ai, nullptr, nullptr, false, E)) return UMFPACK_ERROR_out_of_memory;
     ZiSymbolic *S = new ZiSymbolic();
     S->n = n_col;
-    const int st = umfpack_di_symbolic(2 * n_row, 2 * n_col, E.p.data(), E.i.data(), nullptr, &S->di, Control, Info);
+    (void)Control; (void)Info;
+    // ordered on the complex pattern (half the vertices, a quarter of the edges of the embedding), then expanded
+    const int st = spl::symbolic_of_embedding(n_col, Ap, Ai, E.p.data(), E.i.data(), &S->di);
     if (st < 0) { delete S; return st; }
     *Symbolic = S;
     return st;
@@ -137,8 +141,13 @@ int umfpack_zi_numeric(const int Ap[], const int Ai[], const double Ax[], const 
           const double re = Az ? Ax[p] : Ax[2 * (size_t)p], im = Az ? Az[p] : Ax[2 * (size_t)p + 1];
           if (std::fabs(im) > std::fabs(re)) { swap[(size_t)j] = 1; any = true; }
         }
+    const bool timing = getenv("SPL_MF_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     Embedded E;
     if (!embed(n, Ap, Ai, Ax, Az, true, E, any ? swap.data() : nullptr)) return UMFPACK_ERROR_out_of_memory;
+    if (timing)
+      fprintf(stderr, "[zi numeric] embedding built on the host %8.2f ms\n",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     const int st = umfpack_di_numeric(E.p.data(), E.i.data(), E.x.data(), S->di, Numeric, Control, Info);
     if (st >= 0 && any) spl::numeric_set_pair_swap(*Numeric, std::move(swap));
     return st;

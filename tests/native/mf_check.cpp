@@ -15,9 +15,22 @@ int main(int argc, char **argv) {
   std::vector<int> Ap((size_t)n + 1), Ai((size_t)nnz);
   for (int &v : Ap) if (scanf("%d", &v) != 1) return 2;
   for (int &v : Ai) if (scanf("%d", &v) != 1) return 2;
+  const int mult = argc > 2 ? atoi(argv[2]) : 1;
   Tree T;
-  build_tree(n, Ap.data(), Ai.data(), leaf, T);
-  long bad = 0;
+  build_tree(n, Ap.data(), Ai.data(), leaf, T, mult);
+  if (mult > 1) {  // the invariants are checked against the expanded pattern: a dense mult x mult block per entry
+    std::vector<int> Ep((size_t)n * mult + 1, 0), Ei;
+    for (int j = 0; j < n; ++j)
+      for (int h = 0; h < mult; ++h) {
+        for (int q = Ap[(size_t)j]; q < Ap[(size_t)j + 1]; ++q)
+          for (int a = 0; a < mult; ++a) Ei.push_back(Ai[(size_t)q] * mult + a);
+        Ep[(size_t)j * mult + h + 1] = (int)Ei.size();
+      }
+    n *= mult;
+    Ap.swap(Ep);
+    Ai.swap(Ei);
+  }
+  long bad = T.n == n ? 0 : 1;
   // perm / inv are inverse permutations
   std::vector<char> hit((size_t)n, 0);
   for (int g = 0; g < n; ++g) {

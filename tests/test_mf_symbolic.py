@@ -20,12 +20,12 @@ def checker(tmp_path_factory):
     return exe
 
 
-def run(checker, S, leaf, team=None):
+def run(checker, S, leaf, team=None, mult=1):
     S = sp.csc_matrix(S)
     S.sort_indices()
     text = "%d %d\n%s\n%s\n" % (S.shape[0], S.nnz, " ".join(map(str, S.indptr)), " ".join(map(str, S.indices)))
     env = dict(os.environ) if team is None else dict(os.environ, SPL_ND_TEAM=str(team))
-    r = subprocess.run([checker, str(leaf)], input=text, capture_output=True, text=True, env=env, timeout=300)
+    r = subprocess.run([checker, str(leaf), str(mult)], input=text, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     return dict(kv.split("=") for kv in r.stdout.split())
 
@@ -91,3 +91,21 @@ def test_dense_row_and_column_do_not_make_a_dense_front(checker):
     # a dense block stays one leaf
     out = run(checker, np.ones((300, 300)), 64)
     assert int(out["bad"]) == 0 and int(out["fronts"]) == 1
+
+
+@pytest.mark.parametrize("m,dim,leaf", [(40, 2, 32), (14, 3, 128)])
+def test_expanded_tree_of_block_matrices(checker, m, dim, leaf):
+    """mult = 2 (the real embedding of a complex matrix, umfpack_zi.hip): ordered on the small pattern, every
+    vertex replaced by its two unknowns — all invariants hold against the expanded pattern, the fronts are
+    exactly twice as large and there are as many of them"""
+    S = poisson(m, dim)
+    small = run(checker, S, leaf)
+    big = run(checker, S, leaf, mult=2)
+    assert int(big["bad"]) == 0 and int(big["n"]) == 2 * int(small["n"])
+    assert int(big["fronts"]) == int(small["fronts"]) and int(big["maxfront"]) == 2 * int(small["maxfront"])
+    # an unsymmetric pattern without a stored diagonal
+    rng = np.random.default_rng(9)
+    n = 800
+    R = sp.coo_matrix((np.ones(4000), (rng.integers(0, n, 4000), rng.integers(0, n, 4000))), shape=(n, n))
+    assert int(run(checker, R, 16, mult=2)["bad"]) == 0
+
