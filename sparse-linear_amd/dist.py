@@ -199,16 +199,27 @@ class PeerStoreRowBlockSpMV(object):
         self._h = C.c_void_p()
         mine = C.create_string_buffer(192)
         barr = (C.c_int64 * len(self.bounds))(*self.bounds)
-        _ffi.check("spl_peer_exchange_create",
-                   L.spl_peer_exchange_create(rank, world, self.chunks, self.n, barr, mine, C.byref(self._h)))
+        # Both stages can fail on ONE rank (no memory, IPC mapping refused): the outcome is shared through the
+        # process group before anyone raises, so that no rank is left waiting in a collective the failing rank
+        # never enters — every rank raises, or none.
+        st = L.spl_peer_exchange_create(rank, world, self.chunks, self.n, barr, mine, C.byref(self._h))
         handles = [None] * world
         if world > 1:
-            dist.all_gather_object(handles, mine.raw, group=group)
+            dist.all_gather_object(handles, mine.raw if st == 0 else None, group=group)
         else:
-            handles[0] = mine.raw
-        _ffi.check("spl_peer_exchange_connect", L.spl_peer_exchange_connect(self._h, b"".join(handles)))
+            handles[0] = mine.raw if st == 0 else None
+        if any(h is None for h in handles):
+            self.close()
+            raise RuntimeError("spl_peer_exchange_create failed on rank(s) %s (status %d here)"
+                               % ([r for r, h in enumerate(handles) if h is None], st))
+        st = L.spl_peer_exchange_connect(self._h, b"".join(handles))
+        oks = [st == 0] * world
         if world > 1:
-            dist.barrier(group=group)  # every rank has mapped every peer before anyone stores
+            dist.all_gather_object(oks, st == 0, group=group)  # also: every rank has mapped every peer before anyone stores
+        if not all(oks):
+            self.close()
+            raise RuntimeError("spl_peer_exchange_connect failed on rank(s) %s (status %d here)"
+                               % ([r for r, o in enumerate(oks) if not o], st))
         self._views = {}
         self.y_full = None
 
@@ -236,7 +247,7 @@ class PeerStoreRowBlockSpMV(object):
 
     def close(self):
         if self._h.value:
-            self._views.clear()
+            getattr(self, "_views", {}).clear()
             self.y_full = None
             self._ffi.lib().spl_peer_exchange_free(self._C.byref(self._h))
 
