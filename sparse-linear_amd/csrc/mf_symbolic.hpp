@@ -133,6 +133,23 @@ struct Worker {
   int region_stamp = 0, bfs_stamp = 0;
   explicit Worker(Shared &s) : S(s) {}
 
+  // The traversals are bound by memory latency (on a mesh in its natural order the frontier strides through the
+  // arrays: every vertex is a miss in xadj, adj, mark and level).  Three software-prefetch stages ahead of the
+  // scan position i of a frontier q[0, end): the pointers of q[i + 24], the adjacency of q[i + 16], the marks
+  // of the neighbours of q[i + 8].
+  inline void prefetch_ahead(const int *q, size_t i, size_t end) const {
+    if (i + 24 < end) __builtin_prefetch(&S.xadj[(size_t)q[i + 24]]);
+    if (i + 16 < end) __builtin_prefetch(&S.adj[(size_t)S.xadj[(size_t)q[i + 16]]]);
+    if (i + 8 < end) {
+      const int v = q[i + 8];
+      const int64_t a = S.xadj[(size_t)v], b = std::min(S.xadj[(size_t)v + 1], a + 8);
+      for (int64_t p = a; p < b; ++p) {
+        __builtin_prefetch(&S.mark[(size_t)S.adj[(size_t)p]]);
+        __builtin_prefetch(&S.level[(size_t)S.adj[(size_t)p]], 1);
+      }
+    }
+  }
+
   // BFS over the vertices whose mark is `accept`; they get this BFS's stamp.  Fills queue (BFS
   // order), level[], level_ptr; returns #reached
   int bfs(int root, int accept) {
@@ -146,6 +163,7 @@ struct Worker {
     size_t head = 0;
     int cur = 0;
     while (head < queue.size()) {
+      prefetch_ahead(queue.data(), head, queue.size());
       const int v = queue[head];
       if (S.level[(size_t)v] != cur) {
         cur = S.level[(size_t)v];
@@ -201,6 +219,7 @@ struct Worker {
             while (more && hi - lo < (size_t)S.team_frontier) {
               size_t end = hi;
               for (size_t i = lo; i < hi; ++i) {
+                prefetch_ahead(queue.data(), i, hi);
                 const int v = queue[i];
                 for (int64_t p = S.xadj[(size_t)v]; p < S.xadj[(size_t)v + 1]; ++p) {
                   const int u = S.adj[(size_t)p];
