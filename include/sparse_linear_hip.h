@@ -95,6 +95,13 @@ int spl_mulm(int nrows, int ncols, const int *Ap, const int *Ai, const double *A
 int spl_spgemm(int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Ax,
                int nrowsB, int ncolsB, const int *Bp, const int *Bi, const double *Bx,
                int *nrowsC, int *ncolsC, int **Cp, int **Ci, double **Cx);
+/* mm on `Matrix U.Vector (Complex Double)` (Sparse.hs:691-702 under the SPECIALIZE of :456-457): values as packed
+ * (re, im) pairs; the pattern is that of the real product of the two patterns, every value the sum over ascending k
+ * of A[i,k] * B[k,j] in Data.Complex's arithmetic, started from 0 — bit-identical to the Haskell code.  *Cz is
+ * malloc()'d with 2 * nnz doubles. */
+int spl_spgemm_z(int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Az, int nrowsB, int ncolsB,
+                 const int *Bp, const int *Bi, const double *Bz, int *nrowsC, int *ncolsC, int **Cp, int **Ci,
+                 double **Cz);
 
 /* lin (Sparse.hs:426-431):  C = alpha A + beta B, union pattern. malloc()'d outputs. */
 int spl_lin(double alpha, int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Ax,

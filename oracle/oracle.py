@@ -254,6 +254,22 @@ def mm(a, b, literal=False):
     return (ar, bc, ptrs, _take(ci, nz, I64), _take(cx, nz, F64))
 
 
+def mm_z(a, b):
+    """mm on Complex Double (orc_mm_z): matrix tuples with complex values (real ones are promoted)"""
+    ar, ac, ap, ai, ax = _matc(a)
+    br, bc, bp, bi, bx = _matc(b)
+    ax = np.ascontiguousarray(ax, dtype=np.complex128)
+    bx = np.ascontiguousarray(bx, dtype=np.complex128)
+    cp, ci, cx = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    st = lib().orc_mm_z(C.c_int64(ar), C.c_int64(ac), _I(ap), _I(ai), _D(ax.view(F64)), C.c_int64(br), C.c_int64(bc),
+                        _I(bp), _I(bi), _D(bx.view(F64)), C.byref(cp), C.byref(ci), C.byref(cx))
+    if st != 0:
+        raise OracleError("mm: inner dimension mismatch")
+    ptrs = _take(cp, bc + 1, I64)
+    nz = int(ptrs[bc])
+    return (ar, bc, ptrs, _take(ci, nz, I64), _take(cx, 2 * nz, F64).view(np.complex128))
+
+
 def lin(alpha, a, beta, b):
     ar, ac, ap, ai, ax = _mat(a)
     br, bc, bp, bi, bx = _mat(b)

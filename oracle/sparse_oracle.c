@@ -392,6 +392,65 @@ int orc_mm(Int nrowsA, Int ncolsA, const Int *Ap, const Int *Ai, const double *A
   return ORC_OK;
 }
 
+/* mm on Complex Double (Sparse.hs:691-702 at the SPECIALIZE instance of :456-457).  The same loop as orc_mm
+ * (touched-list form: identical results to the literal O(nrows) reset / gather sweeps, see there) with a complex
+ * accumulator per row: w[i] = w[i] + a * b, Data.Complex's product (x*x' - y*y') :+ (x*y' + y*x'), componentwise
+ * sum.  Values are packed (re, im) pairs. */
+int orc_mm_z(Int nrowsA, Int ncolsA, const Int *Ap, const Int *Ai, const double *Ax,
+             Int nrowsB, Int ncolsB, const Int *Bp, const Int *Bi, const double *Bx,
+             Int **Cp_out, Int **Ci_out, double **Cx_out) {
+  if (ncolsA != nrowsB) return ORC_ERR_DIM; /* :694 */
+  const size_t nr = (size_t)(nrowsA > 0 ? nrowsA : 1);
+  unsigned char *pattern = (unsigned char *)calloc(nr, 1);
+  double *wr = (double *)calloc(nr, sizeof(double)), *wi = (double *)calloc(nr, sizeof(double));
+  Int *touched = (Int *)malloc(nr * sizeof(Int));
+  Int *Cp = (Int *)malloc((size_t)(ncolsB + 1) * sizeof(Int));
+  Int cap = 16, nnz = 0;
+  Int *idx = (Int *)malloc((size_t)cap * sizeof(Int));
+  double *val = (double *)malloc((size_t)cap * 2 * sizeof(double));
+  if (!pattern || !wr || !wi || !touched || !Cp || !idx || !val) return ORC_ERR_ALLOC;
+  Cp[0] = 0;
+  for (Int j = 0; j < ncolsB; ++j) {
+    Int ntouched = 0; /* SG.reset 0 :697 */
+    for (Int q = Bp[j]; q < Bp[j + 1]; ++q) { /* iforM_ colB :698 */
+      const Int k = Bi[q];
+      const double br = Bx[2 * q], bi = Bx[2 * q + 1];
+      for (Int p = Ap[k]; p < Ap[k + 1]; ++p) { /* add = \c a -> c + a*b :699 */
+        const Int i = Ai[p];
+        if (!pattern[i]) { pattern[i] = 1; touched[ntouched++] = i; }
+        const double ar = Ax[2 * p], ai = Ax[2 * p + 1];
+        const double pr = ar * br - ai * bi;
+        const double pi = ar * bi + ai * br;
+        wr[i] = wr[i] + pr;
+        wi[i] = wi[i] + pi;
+      }
+    }
+    if (nnz + ntouched > cap) {
+      while (nnz + ntouched > cap) cap *= 2;
+      idx = (Int *)realloc(idx, (size_t)cap * sizeof(Int));
+      val = (double *)realloc(val, (size_t)cap * 2 * sizeof(double));
+      if (!idx || !val) return ORC_ERR_ALLOC;
+    }
+    qsort(touched, (size_t)ntouched, sizeof(Int), cmp_int);
+    for (Int t = 0; t < ntouched; ++t) {
+      const Int i = touched[t];
+      idx[nnz + t] = i;
+      val[2 * (nnz + t)] = wr[i];
+      val[2 * (nnz + t) + 1] = wi[i];
+      pattern[i] = 0;
+      wr[i] = 0.0;
+      wi[i] = 0.0;
+    }
+    nnz += ntouched;
+    Cp[j + 1] = nnz;
+  }
+  free(pattern); free(wr); free(wi); free(touched);
+  *Cp_out = Cp;
+  *Ci_out = idx;
+  *Cx_out = val;
+  return ORC_OK;
+}
+
 /* ------------------------------------------------------------------------
  * lin — Sparse.hs:426-431 on top of glin :401-424:
  *   glin 0 (\r a -> r + alpha*a) A (\r b -> r + beta*b) B

@@ -90,6 +90,7 @@ def _declare(L):
         "spl_mulm": tup + [i, i, c_dbl_p, c_dbl_p],
         "spl_transpose": tup + [c_int_p, c_int_p, c_dbl_p],
         "spl_spgemm": tup + tup + [c_int_p, c_int_p, c_void_pp, c_void_pp, c_void_pp],
+        "spl_spgemm_z": tup + tup + [c_int_p, c_int_p, c_void_pp, c_void_pp, c_void_pp],
         "spl_lin": [d] + tup + [d] + tup + [c_int_p, c_int_p, c_void_pp, c_void_pp, c_void_pp],
         "spl_lin_z": [c_dbl_p] + tup + [c_dbl_p] + tup + [c_int_p, c_int_p, c_void_pp, c_void_pp, c_void_pp],
         "spl_kronecker": tup + tup + [c_int_p, c_int_p, c_void_pp, c_void_pp, c_void_pp],

@@ -1059,6 +1059,60 @@ static int upload_csc_z(int nrows, int ncols, const int *Ap, const int *Ai, cons
   return SPL_OK;
 }
 
+// copy a packed-complex device result into malloc()'d host arrays
+static int download_result_z(int64_t ncols, int64_t nnz, const int64_t *dCp64, const int *dCi, const double *dCz,
+                             int **Cp, int **Ci, double **Cz, hipStream_t s) {
+  if (nnz >= 0x7fffffffLL) return SPL_ERROR_index_overflow;
+  int *hp = (int *)malloc(((size_t)ncols + 1) * sizeof(int));
+  int *hi = (int *)malloc((size_t)(nnz ? nnz : 1) * sizeof(int));
+  double *hz = (double *)malloc((size_t)(nnz ? nnz : 1) * 2 * sizeof(double));
+  if (!hp || !hi || !hz) { free(hp); free(hi); free(hz); return SPL_ERROR_out_of_memory; }
+  try {
+    DBuf<int> dCp32((size_t)ncols + 1);
+    narrow_i64_to_i32(dCp64, dCp32.get(), ncols + 1, s);
+    SPL_HIP(hipMemcpyAsync(hp, dCp32.get(), ((size_t)ncols + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (nnz) {
+      SPL_HIP(hipMemcpyAsync(hi, dCi, (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+      SPL_HIP(hipMemcpyAsync(hz, dCz, (size_t)nnz * 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    SPL_HIP(hipStreamSynchronize(s));
+  } catch (...) {
+    free(hp); free(hi); free(hz);
+    throw;
+  }
+  *Cp = hp; *Ci = hi; *Cz = hz;
+  return SPL_OK;
+}
+
+int spl_spgemm_z(int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Az, int nrowsB, int ncolsB,
+                 const int *Bp, const int *Bi, const double *Bz, int *nrowsC, int *ncolsC, int **Cp, int **Ci,
+                 double **Cz) {
+  if (!nrowsC || !ncolsC || !Cp || !Ci || !Cz) return SPL_ERROR_argument_missing;
+  *Cp = nullptr; *Ci = nullptr; *Cz = nullptr;
+  if (nrowsA >= 0 && ncolsA >= 0 && nrowsB >= 0 && ncolsB >= 0 && ncolsA != nrowsB)
+    return SPL_ERROR_dimension_mismatch;  // Sparse.hs:694
+  return guarded([&]() -> int {
+    (void)current_device();
+    hipStream_t s = nullptr;
+    DeviceCsc A, B;
+    int st = upload_csc_z(nrowsA, ncolsA, Ap, Ai, Az, A, s);
+    if (st != SPL_OK) return st;
+    st = upload_csc_z(nrowsB, ncolsB, Bp, Bi, Bz, B, s);
+    if (st != SPL_OK) return st;
+    DBuf<int64_t> dCp;
+    DBuf<int> dCi;
+    DBuf<double> dCz;
+    int64_t nnzC = 0;
+    spgemm_device_z(nrowsA, ncolsA, A.p.get(), A.i.get(), A.x.get(), ncolsB, B.p.get(), B.i.get(), B.x.get(), dCp, dCi,
+                    dCz, &nnzC, s);
+    st = download_result_z(ncolsB, nnzC, dCp.get(), dCi.get(), dCz.get(), Cp, Ci, Cz, s);
+    if (st != SPL_OK) return st;
+    *nrowsC = nrowsA;
+    *ncolsC = ncolsB;
+    return SPL_OK;
+  });
+}
+
 int spl_lin_z(const double alpha[2], int nrowsA, int ncolsA, const int *Ap, const int *Ai, const double *Az,
               const double beta[2], int nrowsB, int ncolsB, const int *Bp, const int *Bi, const double *Bz,
               int *nrowsC, int *ncolsC, int **Cp, int **Ci, double **Cz) {
@@ -1080,25 +1134,8 @@ int spl_lin_z(const double alpha[2], int nrowsA, int ncolsA, const int *Ap, cons
     int64_t nnzC = 0;
     lin_device_z(alpha, A.p.get(), A.i.get(), A.x.get(), beta, B.p.get(), B.i.get(), B.x.get(), ncolsA, dCp, dCi,
                  dCz, &nnzC, s);
-    if (nnzC >= 0x7fffffffLL) return SPL_ERROR_index_overflow;
-    int *hp = (int *)malloc(((size_t)ncolsA + 1) * sizeof(int));
-    int *hi = (int *)malloc((size_t)(nnzC ? nnzC : 1) * sizeof(int));
-    double *hz = (double *)malloc((size_t)(nnzC ? nnzC : 1) * 2 * sizeof(double));
-    if (!hp || !hi || !hz) { free(hp); free(hi); free(hz); return SPL_ERROR_out_of_memory; }
-    try {
-      DBuf<int> dCp32((size_t)ncolsA + 1);
-      narrow_i64_to_i32(dCp.get(), dCp32.get(), (int64_t)ncolsA + 1, s);
-      SPL_HIP(hipMemcpyAsync(hp, dCp32.get(), ((size_t)ncolsA + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
-      if (nnzC) {
-        SPL_HIP(hipMemcpyAsync(hi, dCi.get(), (size_t)nnzC * sizeof(int), hipMemcpyDeviceToHost, s));
-        SPL_HIP(hipMemcpyAsync(hz, dCz.get(), (size_t)nnzC * 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-      }
-      SPL_HIP(hipStreamSynchronize(s));
-    } catch (...) {
-      free(hp); free(hi); free(hz);
-      throw;
-    }
-    *Cp = hp; *Ci = hi; *Cz = hz;
+    st = download_result_z(ncolsA, nnzC, dCp.get(), dCi.get(), dCz.get(), Cp, Ci, Cz, s);
+    if (st != SPL_OK) return st;
     *nrowsC = nrowsA;
     *ncolsC = ncolsA;
     return SPL_OK;

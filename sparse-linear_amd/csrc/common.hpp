@@ -223,6 +223,11 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
                    int64_t ncolsB, const int *Bp, const int *Bi, const double *Bx, DBuf<int64_t> &Cp,
                    DBuf<int> &Ci, DBuf<double> &Cx, int64_t *nnzC, int64_t *products, hipStream_t s);
 
+// mm on packed Complex Double (spgemm_z.hip): pattern from the real kernels, values in the reference's order
+void spgemm_device_z(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai, const double *Az, int64_t ncolsB,
+                     const int *Bp, const int *Bi, const double *Bz, DBuf<int64_t> &Cp, DBuf<int> &Ci,
+                     DBuf<double> &Cz, int64_t *nnzC, hipStream_t s);
+
 // ---- blocked band LU without interchanges (band_nopiv.hip) --------------------------------------
 bool band_is_column_dominant(int n, const int *d_Ap, const int *d_Ai, const double *d_Ax, hipStream_t s);
 // leading dimension of the band storage: >= kl+ku+1, padded so that the stride between the same row

@@ -42,7 +42,7 @@ def _oops(fn, msg):
 class Matrix(object):
     """Matrix in compressed sparse column (CSC) format (Sparse.hs:67-76)."""
 
-    __slots__ = ("ncols", "nrows", "pointers", "indices", "values", "_handle", "_embedding", "__weakref__")
+    __slots__ = ("ncols", "nrows", "pointers", "indices", "values", "_handle", "__weakref__")
 
     def __init__(self, ncols, nrows, pointers, indices, values):
         self.ncols = int(ncols)
@@ -53,7 +53,6 @@ class Matrix(object):
         # Double, or Complex Double (the reference's two SPECIALIZE instances, Sparse.hs:456-457)
         self.values = np.ascontiguousarray(values, dtype=C128 if np.iscomplexobj(values) else F64)
         self._handle = None
-        self._embedding = None
 
     @property
     def is_complex(self):
@@ -109,29 +108,6 @@ class Matrix(object):
         """real and imaginary parts as two real matrices with the same pattern"""
         return (Matrix(self.ncols, self.nrows, self.pointers, self.indices, self.values.real.copy()),
                 Matrix(self.ncols, self.nrows, self.pointers, self.indices, self.values.imag.copy()))
-
-    def _embedded(self):
-        """the real 2nrows x 2ncols matrix with interleaved (re, im) unknowns whose action on packed
-        complex vectors equals this complex matrix's: block (i,j) = [[re, -im], [im, re]].  Complex
-        arithmetic on the device goes through this embedding in round 1 (native complex kernels:
-        SURVEY.md §8f rank 3).  Built once per matrix (matrices are immutable values), so that its
-        device handle is uploaded once too."""
-        if self._embedding is not None:
-            return self._embedding
-        p, i, x = self.pointers, self.indices, self.values
-        lens = np.diff(p)
-        nnz = int(p[-1])
-        newp = np.concatenate([[0], np.cumsum(np.repeat(2 * lens, 2))]).astype(I64)
-        col = np.repeat(np.arange(self.ncols), lens)
-        t = np.arange(nnz) - p[col]
-        idx = np.zeros(4 * nnz, dtype=I64)
-        val = np.zeros(4 * nnz, dtype=F64)
-        a = newp[2 * col] + 2 * t
-        b = newp[2 * col + 1] + 2 * t
-        idx[a], idx[a + 1], idx[b], idx[b + 1] = 2 * i, 2 * i + 1, 2 * i, 2 * i + 1
-        val[a], val[a + 1], val[b], val[b + 1] = x.real, x.imag, -x.imag, x.real
-        self._embedding = Matrix(2 * self.ncols, 2 * self.nrows, newp, idx, val)
-        return self._embedding
 
     def device_handle(self):
         """Upload once, reuse for every later SpMV (handle API)."""
@@ -506,14 +482,22 @@ def mm(matA, matB):
     if matA.ncols != matB.nrows:
         _oops("mm", "inner dimension mismatch")
     if matA.is_complex or matB.is_complex:
-        a = matA if matA.is_complex else cmap(lambda v: v.astype(C128), matA)
-        b = matB if matB.is_complex else cmap(lambda v: v.astype(C128), matB)
-        e = mm(a._embedded(), b._embedded())  # embedding of the product: 2x2 blocks [[re,-im],[im,re]]
-        even = e.pointers[0:-1:2]
-        lens = np.diff(e.pointers)[0::2] // 2
-        ptrs = np.concatenate([[0], np.cumsum(lens)]).astype(I64)
-        take = np.repeat(even - 2 * ptrs[:-1], lens) + 2 * np.arange(int(ptrs[-1]))
-        return Matrix(matB.ncols, matA.nrows, ptrs, e.indices[take] // 2, e.values[take] + 1j * e.values[take + 1])
+        # Complex Double: pattern from the real kernels, values accumulated in the reference's order with
+        # Data.Complex's arithmetic (csrc/spgemm_z.hip, spl_spgemm_z)
+        _ffi.require_gpu()
+        a = (matA if matA.is_complex else cmap(lambda v: v.astype(C128), matA))._tuple32()
+        b = (matB if matB.is_complex else cmap(lambda v: v.astype(C128), matB))._tuple32()
+        nr, nc = C.c_int(), C.c_int()
+        cp, ci, cz = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        st = lib().spl_spgemm_z(a[0], a[1], p_i32(a[2]), p_i32(a[3]), p_f64(a[4]), b[0], b[1], p_i32(b[2]),
+                                p_i32(b[3]), p_f64(b[4]), C.byref(nr), C.byref(nc), C.byref(cp), C.byref(ci),
+                                C.byref(cz))
+        check("spl_spgemm_z", st)
+        ncols = nc.value
+        ptrs = _ffi.take_malloced(cp, ncols + 1, C.c_int, I64)
+        nz = int(ptrs[ncols])
+        return Matrix(ncols, nr.value, ptrs, _ffi.take_malloced(ci, nz, C.c_int, I64),
+                      _ffi.take_malloced(cz, 2 * nz, C.c_double, F64).view(C128))
     _ffi.require_gpu()
     a, b = matA._tuple32(), matB._tuple32()
     nr, nc = C.c_int(), C.c_int()

@@ -1,7 +1,8 @@
 """Complex Double (the reference's second SPECIALIZE instance): the complex fixtures of
 sparse-linear/tests/Sparse.hs:61-73 and the reference's only UMFPACK test
 (suitesparse/tests/test-umfpack.hs:16-19, `ident <\\> v == v` on Vector (Complex Double)).
-Round 1 serves complex arithmetic through the real embedding / componentwise real kernels."""
+Since round 2 mulV / axpy_, lin and mm run on native packed-complex kernels (bit-identical to the oracle's
+complex restatements); the LU factors the real embedding (csrc/umfpack_zi.hip)."""
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings
@@ -262,3 +263,48 @@ def test_native_complex_lin_matches_oracle_bitwise(gpu, pkg, O):
     assert tuples_equal(mat_to_tuple(got), O.lin_z(1j, Rs, 2.0, Rs))
     with pytest.raises(Exception):
         pkg.lin(1j, R, 1.0, pkg.transpose(R))
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (40, 30, 50, 300), (300, 300, 300, 3000), (2000, 1500, 1800, 30000),
+                                   (200, 5000, 100, 8000)])
+def test_native_complex_mm_matches_oracle_bitwise(gpu, pkg, O, shape):
+    """mm on Complex Double (spl_spgemm_z): pattern of the real product, every value accumulated over ascending k
+    with Data.Complex's arithmetic — structure and values bit-identical to the oracle's restatement (orc_mm_z,
+    Sparse.hs:691-702)"""
+    m, n, p, k = shape
+    rng = np.random.default_rng(sum(shape))
+    A, B = _rand_complex(O, rng, m, n, k), _rand_complex(O, rng, n, p, k)
+    C = pkg.mm(tuple_to_mat(pkg, A), tuple_to_mat(pkg, B))
+    assert C.is_complex and tuples_equal(mat_to_tuple(C), O.mm_z(A, B))
+    assert O.check_matrix((C.nrows, C.ncols, C.pointers, C.indices, C.values.real)) == 0
+
+
+def test_native_complex_mm_long_columns_and_cancellation(gpu, pkg, O):
+    """columns of C longer than one 512-entry chunk (several chunks per column, bisection into A's columns),
+    dense-ish operands, exact cancellation (the entry stays, as 0), a real operand promoted, dense numpy check"""
+    rng = np.random.default_rng(41)
+    n = 3000
+    # B column 0 picks 400 columns of A with ~20 entries each: ~2500 distinct rows (5 chunks); column 1 is tiny
+    A = _rand_complex(O, rng, n, n, 20 * n)
+    brow = np.concatenate([rng.choice(n, 400, replace=False), [5], rng.choice(n, 1500, replace=False)])
+    bcol = np.concatenate([np.zeros(400, dtype=int), [1], np.full(1500, 2)])
+    Bre = O.compress(n, 3, brow, bcol, rng.normal(size=len(brow)))
+    B = (n, 3, Bre[2], Bre[3], Bre[4] + 1j * rng.normal(size=len(Bre[4])))
+    C = pkg.mm(tuple_to_mat(pkg, A), tuple_to_mat(pkg, B))
+    ref = O.mm_z(A, B)
+    assert tuples_equal(mat_to_tuple(C), ref)
+    assert np.diff(ref[2]).max() > 4 * 512
+    # cancellation: [[1, -1]] * [[z], [z]] = stored 0
+    a = pkg.fromTriples(1, 2, [(0, 0, 1 + 0j), (0, 1, -1 + 0j)])
+    b = pkg.fromTriples(2, 1, [(0, 0, 2 + 3j), (1, 0, 2 + 3j)])
+    c = a * b
+    assert c.pointers.tolist() == [0, 1] and c.indices.tolist() == [0] and c.values.tolist() == [0j]
+    # small integers: exact against dense numpy; real x complex promoted
+    Ai_, Bi_ = _rand_complex(O, rng, 60, 50, 400, ints=True), _rand_complex(O, rng, 50, 70, 400, ints=True)
+    Cm = pkg.mm(tuple_to_mat(pkg, Ai_), tuple_to_mat(pkg, Bi_))
+    assert np.array_equal(pkg.pack(Cm), pkg.pack(tuple_to_mat(pkg, Ai_)) @ pkg.pack(tuple_to_mat(pkg, Bi_)))
+    R = pkg.Matrix(50, 60, Ai_[2], Ai_[3], np.real(Ai_[4]))
+    Cr = pkg.mm(R, tuple_to_mat(pkg, Bi_))
+    assert Cr.is_complex and np.array_equal(pkg.pack(Cr), pkg.pack(R) @ pkg.pack(tuple_to_mat(pkg, Bi_)))
+    with pytest.raises(Exception):
+        pkg.mm(tuple_to_mat(pkg, Ai_), tuple_to_mat(pkg, Ai_))

@@ -352,3 +352,33 @@ def test_lin_complex_restatement_against_dense(O):
         Cz = O.lin_z(2.0, real(A), -0.5, real(B))
         assert np.array_equal(Cr[2], Cz[2]) and np.array_equal(Cr[3], Cz[3])
         assert np.array_equal(Cr[4], np.real(Cz[4])) and not np.any(np.imag(Cz[4]))
+
+
+def test_mm_complex_restatement_against_dense(O):
+    """orc_mm_z (mm at Complex Double, Sparse.hs:691-702): exact against dense numpy on small integers, equal to the
+    real restatement on real data, format invariants"""
+    rng = np.random.default_rng(15)
+
+    def rnd(nr, nc, k):
+        r, c = rng.integers(0, nr, k), rng.integers(0, nc, k)
+        re = O.compress(nr, nc, r, c, rng.integers(-3, 4, k).astype(float))
+        im = O.compress(nr, nc, r, c, rng.integers(-3, 4, k).astype(float))
+        return (nr, nc, re[2], re[3], re[4] + 1j * im[4])
+
+    def dense(m):
+        d = np.zeros((m[0], m[1]), dtype=complex)
+        d[m[3], np.repeat(np.arange(m[1]), np.diff(m[2]))] = m[4]
+        return d
+    for m, n, p, k in ((3, 4, 2, 8), (25, 30, 20, 200)):
+        A, B = rnd(m, n, k), rnd(n, p, k)
+        Cm = O.mm_z(A, B)
+        assert O.check_matrix((Cm[0], Cm[1], Cm[2], Cm[3], np.real(Cm[4]))) == 0
+        assert np.array_equal(dense(Cm), dense(A) @ dense(B))
+        real = lambda t: (t[0], t[1], t[2], t[3], np.ascontiguousarray(np.real(t[4])))
+        Cr, Cz = O.mm(real(A), real(B)), O.mm_z(real(A), real(B))
+        assert np.array_equal(Cr[2], Cz[2]) and np.array_equal(Cr[3], Cz[3]) and np.array_equal(Cr[4], np.real(Cz[4]))
+    try:
+        O.mm_z(rnd(3, 4, 5), rnd(3, 4, 5))
+        raise AssertionError("inner dimension mismatch not reported")
+    except O.OracleError:
+        pass

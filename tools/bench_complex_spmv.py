@@ -10,6 +10,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def embedded(pkg, M):
+    """the real 2n x 2n matrix with interleaved (re, im) unknowns whose action on packed complex vectors equals
+    the complex matrix's: block (i, j) = [[re, -im], [im, re]] — what round 1 multiplied with"""
+    import numpy as np
+    p, i, x = M.pointers, M.indices, M.values
+    lens = np.diff(p)
+    nnz = int(p[-1])
+    newp = np.concatenate([[0], np.cumsum(np.repeat(2 * lens, 2))]).astype(np.int64)
+    col = np.repeat(np.arange(M.ncols), lens)
+    t = np.arange(nnz) - p[col]
+    idx = np.zeros(4 * nnz, dtype=np.int64)
+    val = np.zeros(4 * nnz, dtype=np.float64)
+    a = newp[2 * col] + 2 * t
+    b = newp[2 * col + 1] + 2 * t
+    idx[a], idx[a + 1], idx[b], idx[b + 1] = 2 * i, 2 * i + 1, 2 * i, 2 * i + 1
+    val[a], val[a + 1], val[b], val[b + 1] = x.real, x.imag, -x.imag, x.real
+    return pkg.Matrix(2 * M.ncols, 2 * M.nrows, newp, idx, val)
+
+
 def main():
     import numpy as np
     import torch
@@ -28,7 +47,7 @@ def main():
     dx = torch.from_numpy(x.view(np.float64).copy()).cuda()
     out = {"n": n, "nnz": int(A[2][-1])}
     for name, H, xdev, ylen in (("native", pkg.DeviceMatrix.from_csc_complex(M), dx, 2 * n),
-                                ("embedding", pkg.DeviceMatrix.from_csc(M._embedded()), dx, 2 * n)):
+                                ("embedding", pkg.DeviceMatrix.from_csc(embedded(pkg, M)), dx, 2 * n)):
         if name == "embedding":
             H.optimize()
         y = torch.zeros(ylen, dtype=torch.float64, device="cuda")
