@@ -308,3 +308,26 @@ def test_native_complex_mm_long_columns_and_cancellation(gpu, pkg, O):
     assert Cr.is_complex and np.array_equal(pkg.pack(Cr), pkg.pack(R) @ pkg.pack(tuple_to_mat(pkg, Bi_)))
     with pytest.raises(Exception):
         pkg.mm(tuple_to_mat(pkg, Ai_), tuple_to_mat(pkg, Ai_))
+
+
+def test_native_complex_edge_shapes(gpu, pkg, O):
+    """empty and degenerate operands of the packed-complex entry points: no entries at all, no columns, a single
+    column, operands whose product is empty — structure as the oracle's, nothing read out of bounds"""
+    z = np.zeros(0, dtype=np.complex128)
+    E = pkg.Matrix(4, 3, [0, 0, 0, 0, 0], [], z)            # 3 x 4, no entries
+    F = pkg.Matrix(2, 4, [0, 0, 0], [], z)                  # 4 x 2, no entries
+    A = pkg.fromTriples(3, 4, [(0, 1, 1 + 2j), (2, 3, -1j)])
+    B = pkg.fromTriples(4, 2, [(1, 0, 2 - 1j), (0, 1, 5 + 0j)])
+    for X, Y in ((E, F), (A, F), (E, B), (A, B)):
+        C = pkg.mm(X, Y)
+        ref = O.mm_z(mat_to_tuple(X), mat_to_tuple(Y))
+        assert C.is_complex and tuples_equal(mat_to_tuple(C), ref)
+    for X, Y in ((E, E), (A, E), (E, A)):
+        L = pkg.lin(2 - 1j, X, 1j, Y)
+        assert tuples_equal(mat_to_tuple(L), O.lin_z(2 - 1j, mat_to_tuple(X), 1j, mat_to_tuple(Y)))
+    N0 = pkg.Matrix(0, 3, [0], [], z)                       # 3 x 0
+    assert pkg.lin(1j, N0, 1.0, N0).ncols == 0
+    C0 = pkg.mm(A, pkg.Matrix(0, 4, [0], [], z))            # (3 x 4)(4 x 0) = 3 x 0
+    assert (C0.nrows, C0.ncols, C0.pointers.tolist()) == (3, 0, [0])
+    y = pkg.mulV(E, np.ones(4, dtype=np.complex128))
+    assert y.shape == (3,) and not np.any(y)
