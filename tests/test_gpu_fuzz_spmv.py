@@ -17,3 +17,13 @@ def test_fuzz_spmv_kernels(gpu):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "60 cases" in r.stdout and ", 0 failures" in r.stdout.splitlines()[-1]
+
+
+def test_fuzz_spgemm_forms(gpu):
+    """tools/fuzz_spgemm.py: hub columns, heavy / empty columns, crowded rows, rectangular shapes, real and complex
+    values through the automatic, ordered, compacting, two-pass and split-key forms of mm — bit-identical to the
+    oracle in every form"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_spgemm.py"), "4", "40"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "40 cases, 200 products, 0 failures" in r.stdout
