@@ -234,9 +234,13 @@ int spl_matrix_optimize(void *H);
 int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unroll);
 
 /* Order of the floating-point sums of spl_matrix_spmv_dev / mulv / gaxpy on this handle.
+ * The CONTRACT of both modes is north_star's: every value within 1e-10 relative of the reference's.
  * SPL_ORDER_REFERENCE (default): every y[r] receives a*x + y in ascending column order, each
- * multiply and add separately rounded — the evaluation order of axpy_ (Sparse.hs:447-451); results
- * are bit-identical to the reference's and the same on every run.
+ * multiply and add separately rounded — the evaluation order of axpy_ (Sparse.hs:447-451).  On gfx950
+ * this reproduces the reference's bits, run after run (what the parity tests check), with two caveats that
+ * keep bit-identity an observation rather than a promise: the column-blocked kernel relies on same-address
+ * lanes of one LDS atomic being applied in lane order (pinned by tests/test_gpu_spmv_blocked.py, not by an
+ * ISA document), and the CSR-stream kernel sums a row longer than one 512-entry chunk with a wavefront tree.
  * SPL_ORDER_FREE: the products of a row may be added in any order (still separately rounded
  * multiplies and adds): results agree with the reference to rounding level (1e-10 relative is
  * north_star's contract; observed ~1e-16) but need not be bit-identical, nor identical from run to
