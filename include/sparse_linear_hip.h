@@ -249,6 +249,15 @@ int spl_matrix_build_blocked(void *H, int rows_per_panel, int cols_log2, int unr
 #define SPL_ORDER_REFERENCE 0
 #define SPL_ORDER_FREE 1
 int spl_matrix_set_spmv_order(void *H, int order);
+/* CUs to leave free for a kernel that runs beside the SpMV (the collective of a multi-GPU step): the images
+ * spl_matrix_optimize / _build_* lay out afterwards have one panel (group) per remaining CU when the row block
+ * takes one generation, so the persistent grid is that much smaller.  Call before spl_matrix_optimize.
+ * Default 0, or the environment variable SPL_SPMV_RESERVED_CUS. */
+int spl_matrix_set_reserved_cus(void *H, int reserved);
+/* Diagnostics only: `blocks` workgroups of `threads` threads copy d_buf (count doubles) onto itself for
+ * `milliseconds` (at most 2000) on `stream` — a stand-in for a collective's channel kernels when measuring what
+ * reserved CUs are worth on one GPU (tools/bench_reserved_cus.py). */
+int spl_debug_occupy(int blocks, int threads, double milliseconds, double *d_buf, size_t count, void *stream);
 /* build the column-sorted panel image with an explicit shape (tuning / ablation): panels of
  * rows_per_panel rows (<= 20479: one workgroup's LDS), index blocks of 2^cols_log2 columns
  * (<= 17); 0,0 = choose.  form: 0 default; 1 / 2 = one 64-entry chunk per load instruction with 1 / 2

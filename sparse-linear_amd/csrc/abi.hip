@@ -686,6 +686,14 @@ int spl_matrix_set_spmv_order(void *H, int order) {
   return SPL_OK;
 }
 
+int spl_matrix_set_reserved_cus(void *H, int reserved) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  if (reserved < 0) return SPL_ERROR_argument_missing;
+  m->reserved_cus = reserved;
+  return SPL_OK;
+}
+
 int spl_matrix_optimize(void *H) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;

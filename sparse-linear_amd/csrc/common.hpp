@@ -135,6 +135,7 @@ struct Matrix {
   SellImage *sell = nullptr;        // built on demand (spl_matrix_optimize on regular matrices)
   PanelImage *panel = nullptr;      // built on demand (spl_matrix_build_panel / spl_matrix_set_spmv_order)
   int blocked_unroll = 0;  // 0 = default; < 0 selects the ablation kernel
+  int reserved_cus = -1;    // spl_matrix_set_reserved_cus: CUs left to a communication kernel; < 0: SPL_SPMV_RESERVED_CUS or 0
   bool order_free = false;  // spl_matrix_set_spmv_order: variant 0 may use the panel image (1e-10, order-free sums)
   Matrix() = default;
   Matrix(const Matrix &) = delete;
@@ -182,6 +183,7 @@ const std::vector<char> *numeric_pair_swap(void *Numeric);  // nullptr: none
 // symbolic analysis of the real embedding of a complex matrix, ordered on the complex pattern (umfpack.hip)
 int symbolic_of_embedding(int n, const int *Ap, const int *Ai, const int *Ep, const int *Ei, void **Symbolic);
 void finalize_matrix(Matrix *m, hipStream_t s);
+int spmv_cus(const Matrix *m);  // CUs the persistent SpMV images are laid out for: the device's minus the reserved ones
 void measure_locality(Matrix *m, hipStream_t s);  // fills new_line_fraction on first call
 
 // ---- assembly (assemble.hip) ------------------------------------------------------------

@@ -318,12 +318,30 @@ int spmv_kernel_in_use(const Matrix *m) {
   return m->variant;
 }
 
+// CUs the persistent images are laid out for.  In a multi-GPU step a communication kernel (RCCL's all-gather
+// when its chunks run under the SpMV of the next chunk) wants CUs of its own: the lockstep kernels pace
+// themselves by equal work per resident workgroup, so a workgroup that shares its CU falls behind and holds up
+// its generation.  With r CUs reserved (spl_matrix_set_reserved_cus / SPL_SPMV_RESERVED_CUS) the images of a
+// one-generation row block have exactly CUs - r panels (groups of wavefront panels), the grid is that much
+// smaller, and the dispatcher has free CUs for the other kernel (tools/bench_reserved_cus.py).
+int spmv_cus(const Matrix *m) {
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device);
+  int r = m->reserved_cus;
+  if (r < 0) {
+    const char *e = getenv("SPL_SPMV_RESERVED_CUS");
+    r = e ? atoi(e) : 0;
+  }
+  if (r < 0) r = 0;
+  if (r > cus - 8) r = cus - 8;
+  return cus - r;
+}
+
 // Shape of the column-sorted panel image (spmv_panel.hip): one panel per workgroup, as tall as the
 // LDS allows, the generations of the persistent grid full; index blocks of 2^17 columns (the key's
 // 17 column bits) or fewer for narrow matrices.
 void choose_panels(const Matrix *m, int *rows_per_panel, int *w) {
-  int cus = 256;
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device);
+  const int cus = spmv_cus(m);
   const int64_t pmax = 20479;
   int64_t ngen = (m->nrows_local + (int64_t)cus * pmax - 1) / ((int64_t)cus * pmax);
   if (ngen < 1) ngen = 1;
@@ -359,8 +377,7 @@ void choose_blocking(const Matrix *m, int *rows_per_panel, int *w, int *waves) {
   if (x_bytes <= (32LL << 20)) return;       // x fits the aggregate L2: gathers already hit
   if (m->new_line_fraction < 0.5) return;    // rows reuse their neighbours' lines (banded, stencil)
   if (m->nnz < 4 * m->nrows_local) return;   // too sparse for 64-entry chunks per segment
-  int cus = 256;
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device);
+  const int cus = spmv_cus(m);
   const int64_t rmax = (160 * 1024 / 8) / 16;  // 1280 rows of y per wavefront (16 wavefronts fill the LDS)
   // Small row blocks (one rank of a multi-GPU run): fewer, fuller wavefronts per CU amortise the
   // fixed cost of a phase better than 16 nearly empty ones (measured at 1/8 of C2: 0.197 ms with

@@ -258,6 +258,10 @@ class DeviceMatrix(object):
         any order, rounding-level differences (include/sparse_linear_hip.h)"""
         check("spl_matrix_set_spmv_order", lib().spl_matrix_set_spmv_order(self.handle, int(order)))
 
+    def set_reserved_cus(self, reserved):
+        """CUs left free for a kernel beside the SpMV (call before optimize(); include/sparse_linear_hip.h)"""
+        check("spl_matrix_set_reserved_cus", lib().spl_matrix_set_reserved_cus(self.handle, int(reserved)))
+
     def spmv_kernel(self):
         """0 CSR-stream, 8 column-blocked lockstep, 15 sliced ELL, 16 column-sorted panels"""
         return int(lib().spl_matrix_spmv_kernel(self.handle))
