@@ -40,6 +40,12 @@ namespace {
 constexpr int kSmallProducts = 256;
 constexpr int kMediumProducts = 2048, kMediumB = 256;
 constexpr int kLargeProducts = 4096, kLargeB = 2048;
+// Columns the ordered form's own kernel takes (the others are computed beforehand by the listed kernels): at most
+// kOrdCap products and kOrdPNb entries of B.  The two sizes fix its LDS image — workspace + two (values, keys)
+// buffers = 40 640 bytes — at FOUR workgroups per CU; with 2048 / 128 (53 440 bytes) three fit, and the kernel, which
+// lives on overlapping the latencies of its resident workgroups, ran C4 in 19.5 ms instead of 15.2 ms.
+constexpr int kOrdCap = 1536;
+constexpr int kOrdPNb = 96;
 constexpr int kMaxPool = 512;
 
 inline unsigned blocks_for(int64_t n, int per_block) {
@@ -91,9 +97,9 @@ __global__ __launch_bounds__(256) void products_kernel(Csc A, Csc B, int64_t nco
   if (owner) {
     nprod[j] = n;
     bin = bin_of(n, qe - qs);
-    // ordered form: the columns its own kernel handles (<= 2048 products, <= 128 entries of B) are not listed;
+    // ordered form: the columns its own kernel handles (<= kOrdCap products, <= kOrdPNb entries of B) are not listed;
     // every other column must be, also a light one with a long column of B (bin S has no list: it goes with M)
-    if (ordered && n > 0) bin = (n <= 2048 && qe - qs <= 128) ? 1 : (bin < 2 ? 2 : bin);
+    if (ordered && n > 0) bin = (n <= kOrdCap && qe - qs <= kOrdPNb) ? 1 : (bin < 2 ? 2 : bin);
     if (bin >= 2) pos = atomicAdd(&local_count[bin - 2], 1);
   }
   __syncthreads();
@@ -476,7 +482,6 @@ __global__ __launch_bounds__(256) void compact_columns_kernel(int64_t ncols, con
 // Columns beyond the LDS budget of this kernel (more than 2 048 products or 256 entries in the column of
 // B) are computed beforehand by the kernels above into scratch slots; their owner here only copies them.
 constexpr int kOrdTB = 11;                         // tie-break bits of the packed key: t < 2048
-constexpr int kOrdCap = 2048;                      // products of a column handled by a whole workgroup
 constexpr int kOrdWaveCap = 256, kOrdWaveNb = 64;  // column handled by one wavefront (4 per workgroup)
 constexpr int kOrdBucketLimit = 24;
 constexpr int kOrdMaxRowBits = 32 - kOrdTB;        // rows must fit the packed (unsigned) 32-bit key
@@ -847,7 +852,6 @@ __device__ inline void ord_column(const Csc &A, const Csc &B, int64_t j, int np,
 // result buffers and goes on to expand and sort its next column; the earlier column is finished (look-back,
 // fold, write) after that — one whole column of work later, when its predecessors have long published.  A
 // workgroup still only ever waits for columns with smaller tickets.
-constexpr int kOrdPNb = 128;           // entries of B's column a pipelined column may have
 constexpr int kOrdPBuckets = 512;
 
 struct OrdPipeLds {  // workspace + two result buffers
@@ -916,8 +920,36 @@ __device__ inline void ordp_finish(const OrdPending &P, const unsigned *skeys, c
 
 // expand + sort column j into (keys, vals); returns the number of distinct rows, or -1 when a bucket overflowed:
 // then `keys` holds the expanded keys in their original order (nb ascending runs) for the merge tree
-__device__ inline int ordp_sort(const Csc &A, const Csc &B, int64_t j, int np, int bucket_shift, unsigned char *work,
-                                unsigned *keys, double *vals, int tid) {
+// one entry (k, b) of B as the ordered kernel wants it: where A[:, k] starts, how long it is, and b — 16 bytes,
+// one load, no dependent chain B.p -> B.i -> A.p in front of the gathers (ord_bmeta_kernel)
+struct __attribute__((aligned(16))) OrdBMeta {
+  int start, len;
+  double b;
+};
+
+__global__ __launch_bounds__(256) void ord_bmeta_kernel(Csc A, Csc B, int64_t nnzB, OrdBMeta *__restrict__ out) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nnzB) return;
+  const int k = B.i[q];
+  const int s0 = A.p[k];
+  OrdBMeta m;
+  m.start = s0;
+  m.len = A.p[k + 1] - s0;
+  m.b = B.x[q];
+  out[q] = m;
+}
+
+__device__ inline int ordp_sort(const Csc &A, const OrdBMeta *__restrict__ bmeta, int qs, int nb, int np, int bucket_shift,
+                                unsigned char *work, unsigned *keys, double *vals, int tid,
+                                unsigned long long *stamps = nullptr) {
+  unsigned long long t_prev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto stamp = [&](int phase) {  // SPL_SPGEMM_STAMPS=1 (diagnostic): cycles of thread 0 per phase
+    if (stamps) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      stamps[phase] += now - t_prev;
+      t_prev = now;
+    }
+  };
   constexpr int NT = 256, CAP = kOrdCap, NBCAP = kOrdPNb, NBK = kOrdPBuckets;
   double *kb = reinterpret_cast<double *>(work);
   int *kstart = reinterpret_cast<int *>(work + OrdPipeLds::kb_bytes);
@@ -925,19 +957,16 @@ __device__ inline int ordp_sort(const Csc &A, const Csc &B, int64_t j, int np, i
   int *hist = koff + NBCAP + 8;
   int *scratch = hist + NBK + 8;
   const int lane = tid & 63;
-  const int qs = B.p[j];
-  const int nb = B.p[j + 1] - qs;
   for (int q = tid; q < nb; q += NT) {
-    const int k = B.i[qs + q];
-    const int s = A.p[k];
-    kstart[q] = s;
-    koff[q] = A.p[k + 1] - s;
-    kb[q] = B.x[qs + q];
+    const OrdBMeta m = bmeta[(int64_t)qs + q];
+    kstart[q] = m.start;
+    koff[q] = m.len;
+    kb[q] = m.b;
   }
   for (int b = tid; b < NBK + 1; b += NT) hist[b] = 0;
   if (tid == 0) scratch[8] = 0;
   __syncthreads();
-  {  // exclusive prefix sum of the extents (nb <= 128: the first two wavefronts hold one entry per lane)
+  {  // exclusive prefix sum of the extents (nb <= kOrdPNb <= 128: the first two wavefronts hold one entry per lane)
     const int v = tid < nb ? koff[tid] : 0;
     int incl = v;
 #pragma unroll
@@ -952,6 +981,7 @@ __device__ inline int ordp_sort(const Csc &A, const Csc &B, int64_t j, int np, i
     if (tid == 0) koff[nb] = np;
     __syncthreads();
   }
+  stamp(1);
   constexpr int PER = CAP / NT;
   const int per = (np + NT - 1) / NT;
   unsigned myk[PER];
@@ -999,6 +1029,7 @@ __device__ inline int ordp_sort(const Csc &A, const Csc &B, int64_t j, int np, i
     }
   }
   __syncthreads();
+  stamp(2);
   {  // exclusive scan of the histogram: two consecutive buckets per thread
     const int b0 = tid * 2;
     const int c0 = hist[b0], c1 = hist[b0 + 1];
@@ -1021,6 +1052,7 @@ __device__ inline int ordp_sort(const Csc &A, const Csc &B, int64_t j, int np, i
     if (c0 > kOrdBucketLimit || c1 > kOrdBucketLimit) scratch[8] = 1;
   }
   __syncthreads();
+  stamp(3);
   if (scratch[8] != 0) {  // a crowded bucket: hand the keys over in run order, the caller merges them
 #pragma unroll
     for (int u = 0; u < PER; ++u)
@@ -1028,20 +1060,40 @@ __device__ inline int ordp_sort(const Csc &A, const Csc &B, int64_t j, int np, i
     __syncthreads();
     return -1;
   }
+  // Every key goes to its bucket in arrival order; then each thread RANKS its own keys (still in registers)
+  // inside their buckets — the number of smaller keys there; keys are unique, so the ranks are a permutation —
+  // and stores them at bucket start + rank.  The reads of a bucket are independent LDS loads (no
+  // data-dependent chain of load, compare, move as in an insertion sort: that chain, in the slowest lane,
+  // was 30 % of the kernel on C4).
+  int bs[PER], be[PER];
 #pragma unroll
-  for (int u = 0; u < PER; ++u)
-    if (myk[u] != 0xffffffffu) keys[hist[(myk[u] >> kOrdTB) >> bucket_shift] + myrank[u]] = myk[u];
-  __syncthreads();
-  for (int b = tid; b < NBK; b += NT) {
-    const int s = hist[b], e = hist[b + 1];
-    for (int i = s + 1; i < e; ++i) {
-      const unsigned k = keys[i];
-      int h = i - 1;
-      while (h >= s && keys[h] > k) { keys[h + 1] = keys[h]; --h; }
-      keys[h + 1] = k;
+  for (int u = 0; u < PER; ++u) {
+    bs[u] = 0;
+    be[u] = 0;
+    if (myk[u] != 0xffffffffu) {
+      const int b = (int)((myk[u] >> kOrdTB) >> bucket_shift);
+      bs[u] = hist[b];
+      be[u] = hist[b + 1];
+      keys[bs[u] + myrank[u]] = myk[u];
     }
   }
   __syncthreads();
+  int rank[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    rank[u] = 0;
+    for (int i = bs[u]; i < be[u]; i += 4) {  // four independent loads per wait; the index is clamped, the test masks
+      const unsigned k0 = keys[i], k1 = keys[min(i + 1, CAP - 1)], k2 = keys[min(i + 2, CAP - 1)], k3 = keys[min(i + 3, CAP - 1)];
+      rank[u] += (k0 < myk[u] ? 1 : 0) + ((i + 1 < be[u] && k1 < myk[u]) ? 1 : 0) + ((i + 2 < be[u] && k2 < myk[u]) ? 1 : 0) +
+                 ((i + 3 < be[u] && k3 < myk[u]) ? 1 : 0);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < PER; ++u)
+    if (myk[u] != 0xffffffffu) keys[bs[u] + rank[u]] = myk[u];
+  __syncthreads();
+  stamp(4);
   return 0;
 }
 
@@ -1087,9 +1139,13 @@ __global__ __launch_bounds__(256) void ord_task_count_kernel(int64_t ncolsB, con
   for (int w = 0; w < 4 && j0 + w < ncolsB; ++w) { light = light && cls[j0 + w] <= 1; ++n; }
   ntasks[tile] = light ? 1 : n;
 }
-__global__ __launch_bounds__(256) void ord_task_fill_kernel(int64_t ncolsB, const unsigned char *__restrict__ cls,
+// A task record is everything the kernel needs to start on a column, in ONE 16-byte load after the ticket:
+// x = the column (or ~first column of a tile of light columns), y = its products, z = its first entry in B,
+// w = entries of B | class << 16.  (Before: ticket -> task -> class, products, B.p — three dependent round trips.)
+__global__ __launch_bounds__(256) void ord_task_fill_kernel(Csc B, int64_t ncolsB, const unsigned char *__restrict__ cls,
+                                                            const int64_t *__restrict__ nprod,
                                                             const int64_t *__restrict__ task_off,
-                                                            int64_t *__restrict__ tasks) {
+                                                            int4 *__restrict__ tasks) {
   const int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t j0 = tile * 4;
   if (j0 >= ncolsB) return;
@@ -1097,8 +1153,14 @@ __global__ __launch_bounds__(256) void ord_task_fill_kernel(int64_t ncolsB, cons
   bool light = true;
   int n = 0;
   for (int w = 0; w < 4 && j0 + w < ncolsB; ++w) { light = light && cls[j0 + w] <= 1; ++n; }
-  if (light) { tasks[o] = ~j0; return; }  // a tile of light columns: one task
-  for (int w = 0; w < n; ++w) tasks[o + w] = j0 + w;
+  if (light) { tasks[o] = make_int4((int)~j0, 0, 0, 0); return; }  // a tile of light columns: one task
+  for (int w = 0; w < n; ++w) {
+    const int64_t j = j0 + w;
+    const int c = cls[j];
+    const int qs = B.p[j], nb = B.p[j + 1] - qs;
+    // classes 1 / 2 have at most kOrdCap products and kOrdPNb entries of B; the others do not use y / w's low half
+    tasks[o + w] = make_int4((int)j, c == 1 || c == 2 ? (int)nprod[j] : 0, qs, (nb & 0xffff) | (c << 16));
+  }
 }
 
 __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64_t ncolsB, int bucket_shift_wave,
@@ -1109,7 +1171,8 @@ __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64
                                                              const int *__restrict__ Ti, const double *__restrict__ Tx,
                                                              unsigned long long *__restrict__ status,
                                                              unsigned long long *__restrict__ ticket,
-                                                             const int64_t *__restrict__ tasks, int64_t ntasks,
+                                                             const int4 *__restrict__ tasks, int64_t ntasks,
+                                                             const OrdBMeta *__restrict__ bmeta,
                                                              int64_t *__restrict__ Cp, int *__restrict__ Ci,
                                                              double *__restrict__ Cx, unsigned long long *__restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1136,16 +1199,27 @@ __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64
       __syncthreads();
     }
   };
+  unsigned long long t_mark = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto mark = [&](int phase) {
+    if (stamps) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      acc_stamps[phase] += now - t_mark;
+      t_mark = now;
+    }
+  };
   for (;;) {
+    mark(7);  // (whatever is not covered below)
     if (tid == 0) s_tile = (long long)atomicAdd(ticket, 1ull);
     __syncthreads();
     const int64_t tk = s_tile;
     __syncthreads();
     if (tk >= ntasks) break;
-    const int64_t task = tasks[tk];
-    if (task < 0) {  // four light columns: one wavefront each, no workgroup barrier inside
+    int4 rec = tasks[tk];
+    if (stamps) rec.x = __builtin_amdgcn_readfirstlane(rec.x);  // wait for the record here, so that the stamp sees it
+    mark(0);
+    if (rec.x < 0) {  // four light columns: one wavefront each, no workgroup barrier inside
       finish_pending();  // (their LDS image overlaps the result buffers)
-      const int64_t j = ~task + wave;
+      const int64_t j = (int64_t)~rec.x + wave;
       const int cw = j < ncolsB ? (int)cls[j] : -1;
       if (cw == 0) {
         const int64_t e = ord_chain(status, j, 0);
@@ -1155,24 +1229,28 @@ __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64
                                                 status, Cp, Ci, Cx, wave == 0 ? local_stamps : nullptr);
       }
     } else {
-      const int64_t j = task;
-      const int cw = (int)cls[j];
+      const int64_t j = rec.x;
+      const int cw = rec.w >> 16, nbj = rec.w & 0xffff;
       if (cw == 1 || cw == 2) {
         // sort this column into the buffers the pending one does not use, publish its length, THEN finish the
         // pending column: its look-back has had a whole column of work to become a formality
         const int kin = pend.valid ? 1 - pend.keys_in : 0, vin = pend.valid ? 1 - pend.vals_in : 0;
-        const int np = (int)nprod[j];
+        const int np = rec.y;
         int keys_in = kin;
-        const int st = ordp_sort(A, B, j, np, bucket_shift_group, work, pkeys(kin), pvals(vin), tid);
+        const int st = ordp_sort(A, bmeta, rec.z, nbj, np, bucket_shift_group, work, pkeys(kin), pvals(vin), tid,
+                                 tid == 0 ? local_stamps : nullptr);
+        if (stamps) t_mark = __builtin_amdgcn_s_memtime();
         if (st < 0) {  // crowded bucket: merge tree over the runs; needs the other key buffer, so finish what waits there
           finish_pending();
           const int *koff = reinterpret_cast<const int *>(work + OrdPipeLds::kb_bytes + OrdPipeLds::start_bytes);
-          const unsigned *sorted = ord_merge_tree<256, kOrdCap>(pkeys(kin), pkeys(1 - kin), koff, (int)(B.p[j + 1] - B.p[j]), np, tid);
+          const unsigned *sorted = ord_merge_tree<256, kOrdCap>(pkeys(kin), pkeys(1 - kin), koff, nbj, np, tid);
           keys_in = sorted == pkeys(kin) ? kin : 1 - kin;
         }
         const int count = ordp_count(pkeys(keys_in), np, scratch_a, tid);
         if (wave == 0) ord_publish(status, j, count);
+        mark(5);
         finish_pending();
+        mark(6);
         pend.j = j; pend.np = np; pend.count = count; pend.keys_in = keys_in; pend.vals_in = vin; pend.valid = true;
       } else {  // empty, or computed beforehand into its scratch slot: publish the length, copy
         const int cnt = cw == 3 ? heavy_count[j] : 0;
@@ -1195,10 +1273,10 @@ __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64
   }
   finish_pending();
   if (stamps && tid == 0)
-    for (int i = 0; i < 6; ++i) atomicAdd(stamps + i, acc_stamps[i]);
+    for (int i = 0; i < 8; ++i) atomicAdd(stamps + i, acc_stamps[i]);
 }
 
-// products in the columns where the ordered kernel's workgroup path pays (513 ... 2048 products, <= 128 entries of B)
+// products in the columns where the ordered kernel's workgroup path pays (513 ... kOrdCap products, <= kOrdPNb entries of B)
 __global__ __launch_bounds__(256) void ord_share_kernel(Csc B, int64_t ncolsB, const int64_t *__restrict__ nprod,
                                                         unsigned long long *__restrict__ out) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1458,11 +1536,16 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
                        tile_tasks.get());
     exclusive_scan_i32_to_i64(tile_tasks.get(), task_off.get(), ntiles, s);
     int64_t ntasks = 0;
+    int nnzB_h = 0;
     SPL_HIP(hipMemcpyAsync(&ntasks, task_off.get() + ntiles, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipMemcpyAsync(&nnzB_h, Bp + ncolsB, sizeof(int), hipMemcpyDeviceToHost, s));
     SPL_HIP(hipStreamSynchronize(s));
-    DBuf<int64_t> tasks((size_t)ntasks);
-    hipLaunchKernelGGL(ord_task_fill_kernel, dim3(blocks_for(ntiles, 256)), dim3(256), 0, s, ncolsB, cls.get(),
-                       task_off.get(), tasks.get());
+    DBuf<int4> tasks((size_t)ntasks);
+    hipLaunchKernelGGL(ord_task_fill_kernel, dim3(blocks_for(ntiles, 256)), dim3(256), 0, s, B, ncolsB, cls.get(),
+                       nprod.get(), task_off.get(), tasks.get());
+    DBuf<OrdBMeta> bmeta((size_t)nnzB_h);
+    if (nnzB_h > 0)
+      hipLaunchKernelGGL(ord_bmeta_kernel, dim3(blocks_for(nnzB_h, 256)), dim3(256), 0, s, A, B, (int64_t)nnzB_h, bmeta.get());
     int64_t grid = (int64_t)cus * per_cu;
     if (grid > ntasks) grid = ntasks;
     DBuf<unsigned long long> stamps;
@@ -1474,13 +1557,15 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     }
     hipLaunchKernelGGL(spgemm_ordered_kernel, dim3((unsigned)grid), dim3(256), lds, s, A, B, ncolsB, sh_wave, sh_group,
                        nprod.get(), cls.get(), heavy_slot.get(), counts.get(), Ti.get(), Tx.get(), status.get(), ticket,
-                       tasks.get(), ntasks, Cp.get(), Ci.get(), Cx.get(), stamps.get());
+                       tasks.get(), ntasks, bmeta.get(), Cp.get(), Ci.get(), Cx.get(), stamps.get());
     if (stamps.get()) {
       unsigned long long h[8];
       SPL_HIP(hipMemcpy(h, stamps.get(), sizeof(h), hipMemcpyDeviceToHost));
-      fprintf(stderr, "[spgemm ordered] cycles of thread 0 per phase, summed over %lld tasks: stage+scan %llu | expand %llu | "
-              "histogram scan %llu | scatter+bucket sort %llu | count+chain %llu | fold+write %llu\n",
-              (long long)ntasks, h[0], h[1], h[2], h[3], h[4], h[5]);
+      // (the wavefront path of light columns adds its own phases to slots 0-5: meaningful for one class at a time)
+      fprintf(stderr, "[spgemm ordered] s_memtime ticks of thread 0 per phase, summed over %lld tasks: ticket+record %llu | "
+              "stage+scan %llu | expand %llu | histogram scan %llu | scatter+bucket sort %llu | count+publish %llu | "
+              "finish of the pending column %llu | rest %llu\n",
+              (long long)ntasks, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     }
     hipLaunchKernelGGL(ord_total_kernel, dim3(1), dim3(64), 0, s, status.get(), ncolsB, Cp.get());
     int64_t nz = 0;
