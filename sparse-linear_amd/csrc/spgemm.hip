@@ -31,6 +31,7 @@
 // One pass when 24 B x products fits in half of the free HBM (every column is written at its
 // upper-bound slot, one copy compacts); otherwise symbolic (count distinct) + scan + numeric.
 // HBM/latency-bound integer + fp64 work; no MFMA (no dense contraction).
+#include <chrono>
 #include "common.hpp"
 
 namespace spl {
@@ -1310,6 +1311,15 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
                    int64_t ncolsB, const int *Bp, const int *Bi, const double *Bx, DBuf<int64_t> &Cp,
                    DBuf<int> &Ci, DBuf<double> &Cx, int64_t *nnzC, int64_t *products, hipStream_t s) {
   (void)ncolsA;
+  const bool timing = getenv("SPL_SPGEMM_TIMING") != nullptr;  // host laps on stderr (diagnostic; each lap synchronises)
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(s);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[spgemm] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   Csc A{Ap, Ai, Ax}, B{Bp, Bi, Bx};
   Cp.alloc((size_t)ncolsB + 1);
   *nnzC = 0;
@@ -1346,6 +1356,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   int64_t total_products = 0;
   SPL_HIP(hipMemcpy(&total_products, pscan.get() + ncolsB, sizeof(int64_t), hipMemcpyDeviceToHost));
   if (products) *products = total_products;
+  lap("products, scan, totals");
   // Single pass when the upper bound nnz(C) <= products fits comfortably in HBM: the numeric
   // kernels write every column at its slot and report its length, one copy compacts.  This
   // skips the symbolic pass (a second expand + sort of every column).  SPL_SPGEMM_TWO_PASS=1
@@ -1371,6 +1382,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
       ordered = 2.0 * (double)h >= (double)total_products;
     }
   }
+  lap("form chosen (share)");
   if (ordered) {  // the columns the ordered kernel handles itself leave the bin lists
     SPL_HIP(hipMemsetAsync(list_counts.get(), 0, 3 * sizeof(int), s));
     hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 32)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
@@ -1378,6 +1390,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 3 * sizeof(int), hipMemcpyDeviceToHost, s));
     SPL_HIP(hipStreamSynchronize(s));
   }
+  lap("ordered bin lists");
   const int nmedium = hc[0], nxlarge = hc[1], ndense = hc[2];
   typedef EscLds<kMediumProducts, kMediumB, false> LMs;
   typedef EscLds<kLargeProducts, kLargeB, false> LXs;
@@ -1511,8 +1524,10 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
       SPL_HIP(hipMemcpyAsync(&capacity, bscan.get() + ncolsB, sizeof(int64_t), hipMemcpyDeviceToHost, s));
       SPL_HIP(hipStreamSynchronize(s));
     }
+    lap("listed kernels (heavy columns)");
     Ci.alloc((size_t)capacity);
     Cx.alloc((size_t)capacity);
+    lap("result buffers");
     DBuf<unsigned long long> status((size_t)ncolsB + 1);
     SPL_HIP(hipMemsetAsync(status.get(), 0, ((size_t)ncolsB + 1) * sizeof(unsigned long long), s));
     unsigned long long *ticket = status.get() + ncolsB;
@@ -1546,6 +1561,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     DBuf<OrdBMeta> bmeta((size_t)nnzB_h);
     if (nnzB_h > 0)
       hipLaunchKernelGGL(ord_bmeta_kernel, dim3(blocks_for(nnzB_h, 256)), dim3(256), 0, s, A, B, (int64_t)nnzB_h, bmeta.get());
+    lap("status, tasks, B metadata");
     int64_t grid = (int64_t)cus * per_cu;
     if (grid > ntasks) grid = ntasks;
     DBuf<unsigned long long> stamps;
@@ -1567,6 +1583,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
               "finish of the pending column %llu | rest %llu\n",
               (long long)ntasks, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     }
+    lap("ordered kernel");
     hipLaunchKernelGGL(ord_total_kernel, dim3(1), dim3(64), 0, s, status.get(), ncolsB, Cp.get());
     int64_t nz = 0;
     SPL_HIP(hipMemcpyAsync(&nz, Cp.get() + ncolsB, sizeof(int64_t), hipMemcpyDeviceToHost, s));

@@ -147,7 +147,9 @@ int main() {
     const U::Factors::Stats st = f.stats();
     EXPECT(st.n == 5 && st.path == 1 && st.kl == 0 && st.ku == 0 && st.fronts == 0 && st.device_bytes > 0);
   }
-  EXPECT(U::releaseCachedMemory() == 0);  // nothing of 1 GiB was ever allocated here
+  // work arrays of 256 KiB and more are kept for reuse (at most 2 GiB of them); releasing gives them back once
+  EXPECT(U::releaseCachedMemory() <= (size_t)2 << 30);
+  EXPECT(U::releaseCachedMemory() == 0);
   std::printf(failures ? "selftest: %d FAILED\n" : "selftest: all passed\n", failures);
   return failures ? 1 : 0;
 }
