@@ -137,7 +137,7 @@ struct Worker {
   // arrays: every vertex is a miss in xadj, adj, mark and level).  Three software-prefetch stages ahead of the
   // scan position i of a frontier q[0, end): the pointers of q[i + 24], the adjacency of q[i + 16], the marks
   // of the neighbours of q[i + 8].
-  inline void prefetch_ahead(const int *q, size_t i, size_t end) const {
+  inline void prefetch_ahead(const int *q, size_t i, size_t end, bool claims = false) const {
     if (i + 24 < end) __builtin_prefetch(&S.xadj[(size_t)q[i + 24]]);
     if (i + 16 < end) __builtin_prefetch(&S.adj[(size_t)S.xadj[(size_t)q[i + 16]]]);
     if (i + 8 < end) {
@@ -145,7 +145,8 @@ struct Worker {
       const int64_t a = S.xadj[(size_t)v], b = std::min(S.xadj[(size_t)v + 1], a + 8);
       for (int64_t p = a; p < b; ++p) {
         __builtin_prefetch(&S.mark[(size_t)S.adj[(size_t)p]]);
-        __builtin_prefetch(&S.level[(size_t)S.adj[(size_t)p]], 1);
+        if (claims) __builtin_prefetch(&S.claim[(size_t)S.adj[(size_t)p]], 1);  // team traversal: the claim words
+        else __builtin_prefetch(&S.level[(size_t)S.adj[(size_t)p]], 1);
       }
     }
   }
@@ -243,6 +244,7 @@ struct Worker {
         }
         const size_t len = hi - lo, a = lo + len * (size_t)t / (size_t)team, b = lo + len * (size_t)(t + 1) / (size_t)team;
         for (size_t i = a; i < b; ++i) {
+          prefetch_ahead(queue.data(), i, b, true);
           const int v = queue[i];
           const uint64_t mine = tag | (uint32_t)~(uint32_t)i;
           for (int64_t p = S.xadj[(size_t)v]; p < S.xadj[(size_t)v + 1]; ++p) {
@@ -257,6 +259,7 @@ struct Worker {
         std::vector<int> &out = found[(size_t)t];
         out.clear();
         for (size_t i = a; i < b; ++i) {
+          prefetch_ahead(queue.data(), i, b, true);
           const int v = queue[i];
           const uint64_t mine = tag | (uint32_t)~(uint32_t)i;
           for (int64_t p = S.xadj[(size_t)v]; p < S.xadj[(size_t)v + 1]; ++p) {
