@@ -182,6 +182,8 @@ void numeric_set_pair_swap(void *Numeric, std::vector<char> &&flags);
 const std::vector<char> *numeric_pair_swap(void *Numeric);  // nullptr: none
 // symbolic analysis of the real embedding of a complex matrix, ordered on the complex pattern (umfpack.hip)
 int symbolic_of_embedding(int n, const int *Ap, const int *Ai, const int *Ep, const int *Ei, void **Symbolic);
+int numeric_of_embedding(const int *Ep, const int *Ei, const double *Ex, void *Symbolic, void **Numeric);
+uint64_t pattern_hash(const int *Ai, int64_t nnz);
 void finalize_matrix(Matrix *m, hipStream_t s);
 int spmv_cus(const Matrix *m);  // CUs the persistent SpMV images are laid out for: the device's minus the reserved ones
 void measure_locality(Matrix *m, hipStream_t s);  // fills new_line_fraction on first call

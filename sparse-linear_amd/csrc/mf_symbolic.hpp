@@ -22,6 +22,8 @@
 #include <cstdlib>
 #include <atomic>
 #include <future>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -66,6 +68,25 @@ struct Tree {
   double flops = 0.0;
   std::vector<std::vector<int>> by_depth;  // fronts of each tree level
   int fs(int f) const { return np[(size_t)f] + nb[(size_t)f]; }
+  // What a numeric factorisation derives from the tree alone — its arrays on the device, the positions of every
+  // boundary index inside the parent's front — is built by the first factorisation and kept here for the later
+  // ones with the same analysis (a FEAST-style caller refactors once per contour point): opaque to this header,
+  // owned by multifrontal.hip.
+  mutable std::shared_ptr<void> device_cache;
+  mutable std::mutex device_cache_mu;
+  Tree() = default;
+  Tree(const Tree &) = delete;
+  Tree &operator=(const Tree &o) {  // (build_tree starts from `T = Tree()`; the cache never travels)
+    n = o.n; nfronts = o.nfronts; maxdepth = o.maxdepth;
+    perm = o.perm; inv = o.inv; parent = o.parent; slot = o.slot; depth = o.depth; p0 = o.p0; np = o.np; nb = o.nb;
+    bptr = o.bptr; bidx = o.bidx; front_of = o.front_of; ld = o.ld; foff = o.foff; poff = o.poff; uoff = o.uoff;
+    ldp = o.ldp; ldu = o.ldu; ioff = o.ioff; woff = o.woff; roff = o.roff; level_elems = o.level_elems;
+    region_elems[0] = o.region_elems[0]; region_elems[1] = o.region_elems[1];
+    front_elems = o.front_elems; panel_elems = o.panel_elems; inv_elems = o.inv_elems; work_elems = o.work_elems;
+    rel_elems = o.rel_elems; flops = o.flops; by_depth = o.by_depth;
+    device_cache.reset();
+    return *this;
+  }
 };
 
 namespace detail {

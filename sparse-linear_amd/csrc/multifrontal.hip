@@ -35,9 +35,10 @@ namespace spl {
 
 namespace {
 
-struct DeviceTree {
+struct DeviceTree {  // depends on the tree only (cached in mf::Tree::device_cache); foff / cboff: per factorisation
+  int device = 0;
   DBuf<int> p0, np, nb, ld, parent, front_of, bidx, rel, depth, ldp, ldu;
-  DBuf<int64_t> bptr, foff, ioff, woff, roff, poff, uoff, cboff;
+  DBuf<int64_t> bptr, ioff, woff, roff, poff, uoff;
 };
 
 struct TreeView {  // raw pointers for kernels
@@ -656,7 +657,8 @@ namespace mf {
 
 struct Factors {
   std::shared_ptr<const Tree> tree;
-  DeviceTree D;
+  std::shared_ptr<DeviceTree> D;     // the tree's own arrays and `rel`: shared by every factorisation of this tree
+  DBuf<int64_t> d_foff, d_cboff;     // where this factorisation's memory plan puts the fronts
   TreeView view;
   DBuf<double> arena, invs;  // factor panels, inverses of the diagonal blocks
   std::vector<DBuf<int>> level_lists;                // fronts of each depth
@@ -832,27 +834,49 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
       fprintf(stderr, "[mf_factor] panels %.1f GB, transient %.1f GB at cut depth %d (free %.1f GB)\n",
               T.panel_elems * 8e-9, plan.transient_elems() * 8e-9, plan.cut, free_b * 1e-9);
   }
-  DeviceTree &D = F.D;
-  upload_vec(D.p0, T.p0, s);
-  upload_vec(D.np, T.np, s);
-  upload_vec(D.nb, T.nb, s);
-  upload_vec(D.ld, T.ld, s);
-  upload_vec(D.parent, T.parent, s);
-  upload_vec(D.front_of, T.front_of, s);
-  upload_vec(D.bidx, T.bidx, s);
-  upload_vec(D.bptr, T.bptr, s);
-  upload_vec(D.foff, plan.foff, s);
-  upload_vec(D.cboff, plan.cboff, s);
-  upload_vec(D.ioff, T.ioff, s);
-  upload_vec(D.woff, T.woff, s);
-  upload_vec(D.roff, T.roff, s);
-  upload_vec(D.depth, T.depth, s);
-  upload_vec(D.ldp, T.ldp, s);
-  upload_vec(D.ldu, T.ldu, s);
-  upload_vec(D.poff, T.poff, s);
-  upload_vec(D.uoff, T.uoff, s);
+  // the device copy of the tree and the relative indices: built once per tree and device, then shared
+  {
+    std::lock_guard<std::mutex> lk(T.device_cache_mu);
+    int dev = 0;
+    SPL_HIP(hipGetDevice(&dev));
+    std::shared_ptr<DeviceTree> cached = std::static_pointer_cast<DeviceTree>(T.device_cache);
+    if (!cached || cached->device != dev) {
+      std::shared_ptr<DeviceTree> fresh = std::make_shared<DeviceTree>();
+      DeviceTree &N = *fresh;
+      N.device = dev;
+      upload_vec(N.p0, T.p0, s);
+      upload_vec(N.np, T.np, s);
+      upload_vec(N.nb, T.nb, s);
+      upload_vec(N.ld, T.ld, s);
+      upload_vec(N.parent, T.parent, s);
+      upload_vec(N.front_of, T.front_of, s);
+      upload_vec(N.bidx, T.bidx, s);
+      upload_vec(N.bptr, T.bptr, s);
+      upload_vec(N.ioff, T.ioff, s);
+      upload_vec(N.woff, T.woff, s);
+      upload_vec(N.roff, T.roff, s);
+      upload_vec(N.depth, T.depth, s);
+      upload_vec(N.ldp, T.ldp, s);
+      upload_vec(N.ldu, T.ldu, s);
+      upload_vec(N.poff, T.poff, s);
+      upload_vec(N.uoff, T.uoff, s);
+      N.rel.alloc((size_t)T.rel_elems);
+      const TreeView v{N.p0.get(),   N.np.get(),   N.nb.get(),   N.ld.get(),   N.parent.get(), N.front_of.get(),
+                       N.bidx.get(), N.rel.get(),  N.depth.get(), N.ldp.get(), N.ldu.get(),    N.bptr.get(),
+                       nullptr,      N.ioff.get(), N.woff.get(), N.roff.get(), N.poff.get(),   N.uoff.get(),
+                       {nullptr, nullptr}, nullptr, nullptr, nullptr};
+      if (nf > 0) hipLaunchKernelGGL(rel_kernel, dim3((unsigned)nf), dim3(256), 0, s, nf, v, N.rel.get());
+      SPL_HIP(hipStreamSynchronize(s));  // the host vectors of the tree may go away with it
+      SPL_HIP(hipGetLastError());
+      T.device_cache = fresh;
+      cached = fresh;
+    }
+    F.D = cached;
+  }
+  DeviceTree &D = *F.D;
+  upload_vec(F.d_foff, plan.foff, s);
+  upload_vec(F.d_cboff, plan.cboff, s);
   lap("tree uploads (queued)");
-  D.rel.alloc((size_t)T.rel_elems);
   F.arena.alloc((size_t)T.panel_elems);
   F.invs.alloc((size_t)T.inv_elems);
   DBuf<double> region0((size_t)plan.region_elems[0]), region1((size_t)plan.region_elems[1]),
@@ -860,8 +884,8 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   lap("hipMalloc");
   F.view = TreeView{D.p0.get(),    D.np.get(),   D.nb.get(),   D.ld.get(),   D.parent.get(), D.front_of.get(),
                     D.bidx.get(),  D.rel.get(),  D.depth.get(), D.ldp.get(), D.ldu.get(),    D.bptr.get(),
-                    D.foff.get(),  D.ioff.get(), D.woff.get(), D.roff.get(), D.poff.get(),   D.uoff.get(),
-                    {region0.get(), region1.get()}, F.arena.get(), D.cboff.get(), cutbuf.get()};
+                    F.d_foff.get(), D.ioff.get(), D.woff.get(), D.roff.get(), D.poff.get(),  D.uoff.get(),
+                    {region0.get(), region1.get()}, F.arena.get(), F.d_cboff.get(), cutbuf.get()};
   F.level_lists.resize((size_t)nd);
   F.small_lists.resize((size_t)nd);
   F.small_counts.assign((size_t)nd, 0);
@@ -976,7 +1000,6 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   SPL_HIP(hipStreamSynchronize(s));
   staged.clear();
   lap("level lists");
-  if (nf > 0) hipLaunchKernelGGL(rel_kernel, dim3((unsigned)nf), dim3(256), 0, s, nf, F.view, D.rel.get());
   DBuf<int> singular(1);
   SPL_HIP(hipMemsetAsync(singular.get(), 0, sizeof(int), s));
   set_factor_attributes();

@@ -98,6 +98,8 @@ struct Numeric {
   }
 };
 
+thread_local bool t_pattern_vouched = false;  // set around umfpack_di_numeric by spl::numeric_of_embedding
+
 // 64-bit hash of the row indices: the second half of the pattern check in numeric (the pointers are
 // compared exactly; a pattern with the same column counts but other rows would be scattered with a
 // stale ordering, out of the band / the fronts)
@@ -784,6 +786,17 @@ int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
 }  // extern "C"
 
 namespace spl {
+uint64_t pattern_hash(const int *Ai, int64_t nnz) { return hash_indices(Ai, nnz); }
+
+// numeric factorisation of an embedding whose pattern the caller has already checked against its own record
+int numeric_of_embedding(const int *Ep, const int *Ei, const double *Ex, void *Symbolic, void **Numeric) {
+  struct Vouch {
+    Vouch() { t_pattern_vouched = true; }
+    ~Vouch() { t_pattern_vouched = false; }
+  } vouch;
+  return umfpack_di_numeric(Ep, Ei, Ex, Symbolic, Numeric, nullptr, nullptr);
+}
+
 // analysis of the real embedding of an n x n complex matrix from the complex pattern itself (umfpack_zi.hip);
 // (Ep, Ei): the pattern of the embedding, 2n x 2n, interleaved unknowns
 int symbolic_of_embedding(int n, const int *Ap, const int *Ai, const int *Ep, const int *Ei, void **SymbolicOut) {
@@ -802,7 +815,9 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
   if (!S) return UMFPACK_ERROR_invalid_Symbolic_object;
   if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;
   const int n = S->n;
-  if (Ap[n] != S->nnz || !std::equal(S->Ap.begin(), S->Ap.end(), Ap) || hash_indices(Ai, S->nnz) != S->ai_hash)
+  // (the `zi` wrapper has compared the complex pattern — a quarter of the embedding's — and vouches for the rest)
+  if (!t_pattern_vouched &&
+      (Ap[n] != S->nnz || !std::equal(S->Ap.begin(), S->Ap.end(), Ap) || hash_indices(Ai, S->nnz) != S->ai_hash))
     return UMFPACK_ERROR_different_pattern;
   Numeric *N = nullptr;
   try {

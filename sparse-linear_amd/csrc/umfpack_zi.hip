@@ -12,8 +12,11 @@
 // arithmetic LU only in rounding, and `ident <\> v == v` (suitesparse/tests/test-umfpack.hs:16-19,
 // on Vector (Complex Double)) holds exactly.
 #include <chrono>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <memory>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -24,8 +27,17 @@ namespace {
 
 // CSC arrays of the embedding E (2n x 2n, 4 entries per complex entry, rows ascending)
 struct Embedded {
-  std::vector<int> p, i;
-  std::vector<double> x;
+  // plain arrays, NOT std::vector: resize() would zero 240 MB on one thread (40 ms at 10^6 unknowns) before the
+  // threads of embed() write every element anyway
+  template <typename T>
+  struct Raw {
+    std::unique_ptr<T[]> mem;
+    void resize(size_t n) { mem.reset(new T[n ? n : 1]); }
+    T *data() const { return mem.get(); }
+    T &operator[](size_t k) const { return mem[k]; }
+  };
+  Raw<int> p, i;
+  Raw<double> x;
 };
 
 // swap[r] != 0: the two real rows of complex row r change places (static pivoting, see numeric)
@@ -36,27 +48,50 @@ bool embed(int n, const int *Ap, const int *Ai, const double *Ax, const double *
   E.p.resize((size_t)2 * n + 1);
   E.i.resize((size_t)4 * nnz);
   if (values) E.x.resize((size_t)4 * nnz);
-  long q = 0;
-  for (int j = 0; j < n; ++j) {
-    for (int half = 0; half < 2; ++half) {
-      E.p[(size_t)2 * j + half] = (int)q;
-      for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
-        const int r = Ai[p];
-        E.i[(size_t)q] = 2 * r;
-        E.i[(size_t)q + 1] = 2 * r + 1;
-        if (values) {
-          const double re = Az ? Ax[p] : Ax[2 * (size_t)p];
-          const double im = Az ? Az[p] : Ax[2 * (size_t)p + 1];
-          const double top = half == 0 ? re : -im, bottom = half == 0 ? im : re;
-          const bool sw = swap && swap[r];
-          E.x[(size_t)q] = sw ? bottom : top;
-          E.x[(size_t)q + 1] = sw ? top : bottom;
+  // column 2j starts at 4 Ap[j], column 2j + 1 one block column (2 entries per stored entry) further: no running
+  // counter, so the columns are shared out among threads (20 million entries at 10^6 unknowns: 48 ms on one core,
+  // a third of a FEAST-style refactorisation)
+  auto fill = [&](int j0, int j1) {
+    for (int j = j0; j < j1; ++j) {
+      const long len = Ap[j + 1] - Ap[j];
+      for (int half = 0; half < 2; ++half) {
+        long q = 4 * (long)Ap[j] + 2 * len * half;
+        E.p[(size_t)2 * j + half] = (int)q;
+        for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
+          const int r = Ai[p];
+          E.i[(size_t)q] = 2 * r;
+          E.i[(size_t)q + 1] = 2 * r + 1;
+          if (values) {
+            const double re = Az ? Ax[p] : Ax[2 * (size_t)p];
+            const double im = Az ? Az[p] : Ax[2 * (size_t)p + 1];
+            const double top = half == 0 ? re : -im, bottom = half == 0 ? im : re;
+            const bool sw = swap && swap[r];
+            E.x[(size_t)q] = sw ? bottom : top;
+            E.x[(size_t)q + 1] = sw ? top : bottom;
+          }
+          q += 2;
         }
-        q += 2;
       }
     }
+  };
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt ? (nt > 8 ? 8 : nt) : 1;
+  if (nnz < 200000 || nt < 2) {
+    fill(0, n);
+  } else {
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; ++t) {
+      const int j0 = (int)((long)n * t / nt), j1 = (int)((long)n * (t + 1) / nt);
+      try {
+        pool.emplace_back(fill, j0, j1);
+      } catch (...) {  // a thread could not be started: its columns are done here
+        fill(j0, j1);
+      }
+    }
+    fill(0, (int)((long)n / nt));
+    for (std::thread &th : pool) th.join();
   }
-  E.p[(size_t)2 * n] = (int)q;
+  E.p[(size_t)2 * n] = (int)(4 * nnz);
   return true;
 }
 
@@ -76,10 +111,12 @@ __global__ __launch_bounds__(256) void swap_pairs_kernel(const char *__restrict_
   v[2 * t + 1] = a;
 }
 
-struct ZiSymbolic {  // remembers n so that numeric can rebuild the embedding
+struct ZiSymbolic {  // remembers n so that numeric can rebuild the embedding, and the complex pattern it analysed
   unsigned magic = 0x5A53594Du;
   int n = 0;
   void *di = nullptr;
+  std::vector<int> Ap;
+  uint64_t ai_hash = 0;
 };
 
 }  // namespace
@@ -105,6 +142,8 @@ int umfpack_zi_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
     if (!embed(n_col, Ap, Ai, nullptr, nullptr, false, E)) return UMFPACK_ERROR_out_of_memory;
     ZiSymbolic *S = new ZiSymbolic();
     S->n = n_col;
+    S->Ap.assign(Ap, Ap + n_col + 1);
+    S->ai_hash = spl::pattern_hash(Ai, Ap[n_col]);
     (void)Control; (void)Info;
     // ordered on the complex pattern (half the vertices, a quarter of the edges of the embedding), then expanded
     const int st = spl::symbolic_of_embedding(n_col, Ap, Ai, E.p.data(), E.i.data(), &S->di);
@@ -133,6 +172,9 @@ int umfpack_zi_numeric(const int Ap[], const int Ai[], const double Ax[], const 
     // part.  A row permutation Q of the system: (Q E) x = Q b; E^T y = c is (Q E)^T (Q y) = c.  The
     // pattern of the embedding does not change (every block is a full 2 x 2).
     const int n = S->n;
+    // UMFPACK_ERROR_different_pattern, decided on the complex pattern (the embedding's is four times as long)
+    if (!std::equal(S->Ap.begin(), S->Ap.end(), Ap) || spl::pattern_hash(Ai, Ap[n]) != S->ai_hash)
+      return UMFPACK_ERROR_different_pattern;
     std::vector<char> swap((size_t)n, 0);
     bool any = false;
     for (int j = 0; j < n; ++j)
@@ -148,7 +190,8 @@ int umfpack_zi_numeric(const int Ap[], const int Ai[], const double Ax[], const 
     if (timing)
       fprintf(stderr, "[zi numeric] embedding built on the host %8.2f ms\n",
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    const int st = umfpack_di_numeric(E.p.data(), E.i.data(), E.x.data(), S->di, Numeric, Control, Info);
+    (void)Control; (void)Info;
+    const int st = spl::numeric_of_embedding(E.p.data(), E.i.data(), E.x.data(), S->di, Numeric);
     if (st >= 0 && any) spl::numeric_set_pair_swap(*Numeric, std::move(swap));
     return st;
   } catch (const std::bad_alloc &) {

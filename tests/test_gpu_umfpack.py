@@ -413,6 +413,34 @@ def test_numeric_rejects_other_row_indices(gpu, pkg):
     L.umfpack_di_free_symbolic(C.byref(sym))
 
 
+def test_zi_numeric_rejects_other_pattern_and_vouching_does_not_leak(gpu, pkg):
+    """the complex numeric phase compares the COMPLEX pattern with the one it analysed (-11 on other rows or other
+    column counts) and only then lets the embedding skip its own, four times longer comparison; that licence must
+    not outlive the call: a real numeric call right after still checks its pattern"""
+    import ctypes as C
+    U = pkg.umfpack
+    L = U._declare()
+    ap = np.array([0, 2, 4, 6], dtype=np.int32)
+    ai = np.array([0, 1, 1, 2, 0, 2], dtype=np.int32)
+    az = np.array([4.0, 1.0, 1.0, 0.5, 4.0, -1.0, 1.0, 0.0, 1.0, 2.0, 4.0, 0.0])  # packed (re, im)
+    sym = C.c_void_p()
+    assert L.umfpack_zi_symbolic(3, 3, U.p_i32(ap), U.p_i32(ai), U.p_f64(az), None, C.byref(sym), None, None) == 0
+    num = C.c_void_p()
+    ai2 = np.array([0, 2, 0, 1, 1, 2], dtype=np.int32)
+    assert L.umfpack_zi_numeric(U.p_i32(ap), U.p_i32(ai2), U.p_f64(az), None, sym, C.byref(num), None, None) == -11
+    assert not num.value
+    ap3 = np.array([0, 1, 4, 6], dtype=np.int32)
+    assert L.umfpack_zi_numeric(U.p_i32(ap3), U.p_i32(ai), U.p_f64(az), None, sym, C.byref(num), None, None) == -11
+    assert L.umfpack_zi_numeric(U.p_i32(ap), U.p_i32(ai), U.p_f64(az), None, sym, C.byref(num), None, None) == 0
+    L.umfpack_zi_free_numeric(C.byref(num))
+    L.umfpack_zi_free_symbolic(C.byref(sym))
+    # the real path right after: still checked
+    ax = np.array([4.0, 1.0, 4.0, 1.0, 1.0, 4.0])
+    assert L.umfpack_di_symbolic(3, 3, U.p_i32(ap), U.p_i32(ai), U.p_f64(ax), C.byref(sym), None, None) == 0
+    assert L.umfpack_di_numeric(U.p_i32(ap), U.p_i32(ai2), U.p_f64(ax), sym, C.byref(num), None, None) == -11
+    L.umfpack_di_free_symbolic(C.byref(sym))
+
+
 def test_linear_solve_checks_rhs_length_and_type(gpu, pkg):
     U = pkg.umfpack
     A = pkg.ident(5)
