@@ -42,11 +42,14 @@ constexpr int kSmallProducts = 256;
 constexpr int kMediumProducts = 2048, kMediumB = 256;
 constexpr int kLargeProducts = 4096, kLargeB = 2048;
 // Columns the ordered form's own kernel takes (the others are computed beforehand by the listed kernels): at most
-// kOrdCap products and kOrdPNb entries of B.  The two sizes fix its LDS image — workspace + two (values, keys)
-// buffers = 40 640 bytes — at FOUR workgroups per CU; with 2048 / 128 (53 440 bytes) three fit, and the kernel, which
-// lives on overlapping the latencies of its resident workgroups, ran C4 in 19.5 ms instead of 15.2 ms.
-constexpr int kOrdCap = 1536;
-constexpr int kOrdPNb = 96;
+// `cap` products and `nbcap` entries of B.  The two sizes fix its LDS image — workspace + two (values, keys)
+// buffers.  Two shapes are compiled: 1536 / 96 (40 640 bytes: FOUR workgroups per CU; the kernel lives on
+// overlapping the latencies of its resident workgroups — C4: 13.8 ms against 19.5 ms at three) and 2048 / 128
+// (53 440 bytes, three per CU) for products whose columns sit between 1537 and 2048 products, which the small shape
+// would send to the listed kernels (scale 20, edge factor 44: 0.119 s against 0.044 s).  The host picks per product.
+constexpr int kOrdCapSmall = 1536, kOrdPNbSmall = 96;
+constexpr int kOrdPBuckets = 512;
+constexpr int kOrdCapLarge = 2048, kOrdPNbLarge = 128;
 constexpr int kMaxPool = 512;
 
 inline unsigned blocks_for(int64_t n, int per_block) {
@@ -74,7 +77,8 @@ __global__ __launch_bounds__(256) void products_kernel(Csc A, Csc B, int64_t nco
                                                        int64_t *__restrict__ medium_list,
                                                        int64_t *__restrict__ xlarge_list,
                                                        int64_t *__restrict__ dense_list,
-                                                       int *__restrict__ list_counts, int ordered) {
+                                                       int *__restrict__ list_counts, int ordered, int ord_cap,
+                                                       int ord_nb) {
   // 8 lanes per column of B: the extents of the selected columns of A are independent loads
   const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
   const int sub = threadIdx.x & 7;
@@ -98,9 +102,9 @@ __global__ __launch_bounds__(256) void products_kernel(Csc A, Csc B, int64_t nco
   if (owner) {
     nprod[j] = n;
     bin = bin_of(n, qe - qs);
-    // ordered form: the columns its own kernel handles (<= kOrdCap products, <= kOrdPNb entries of B) are not listed;
+    // ordered form: the columns its own kernel handles (<= ord_cap products, <= ord_nb entries of B) are not listed;
     // every other column must be, also a light one with a long column of B (bin S has no list: it goes with M)
-    if (ordered && n > 0) bin = (n <= kOrdCap && qe - qs <= kOrdPNb) ? 1 : (bin < 2 ? 2 : bin);
+    if (ordered && n > 0) bin = (n <= ord_cap && qe - qs <= ord_nb) ? 1 : (bin < 2 ? 2 : bin);
     if (bin >= 2) pos = atomicAdd(&local_count[bin - 2], 1);
   }
   __syncthreads();
@@ -853,16 +857,16 @@ __device__ inline void ord_column(const Csc &A, const Csc &B, int64_t j, int np,
 // result buffers and goes on to expand and sort its next column; the earlier column is finished (look-back,
 // fold, write) after that — one whole column of work later, when its predecessors have long published.  A
 // workgroup still only ever waits for columns with smaller tickets.
-constexpr int kOrdPBuckets = 512;
 
+template <int CAP, int NBCAP>
 struct OrdPipeLds {  // workspace + two result buffers
-  static constexpr size_t kb_bytes = kOrdPNb * sizeof(double);
-  static constexpr size_t start_bytes = kOrdPNb * sizeof(int);
-  static constexpr size_t off_bytes = (kOrdPNb + 8) * sizeof(int);
+  static constexpr size_t kb_bytes = NBCAP * sizeof(double);
+  static constexpr size_t start_bytes = NBCAP * sizeof(int);
+  static constexpr size_t off_bytes = (NBCAP + 8) * sizeof(int);
   static constexpr size_t hist_bytes = (kOrdPBuckets + 8) * sizeof(int);
   static constexpr size_t scratch_bytes = 32 * sizeof(int);
   static constexpr size_t work_bytes = kb_bytes + start_bytes + off_bytes + hist_bytes + scratch_bytes;
-  static constexpr size_t vals_bytes = kOrdCap * sizeof(double), keys_bytes = kOrdCap * sizeof(unsigned);
+  static constexpr size_t vals_bytes = CAP * sizeof(double), keys_bytes = CAP * sizeof(unsigned);
   static constexpr size_t total = work_bytes + 2 * (vals_bytes + keys_bytes);
 };
 
@@ -940,6 +944,7 @@ __global__ __launch_bounds__(256) void ord_bmeta_kernel(Csc A, Csc B, int64_t nn
   out[q] = m;
 }
 
+template <int CAP, int NBCAP>
 __device__ inline int ordp_sort(const Csc &A, const OrdBMeta *__restrict__ bmeta, int qs, int nb, int np, int bucket_shift,
                                 unsigned char *work, unsigned *keys, double *vals, int tid,
                                 unsigned long long *stamps = nullptr) {
@@ -951,9 +956,10 @@ __device__ inline int ordp_sort(const Csc &A, const OrdBMeta *__restrict__ bmeta
       t_prev = now;
     }
   };
-  constexpr int NT = 256, CAP = kOrdCap, NBCAP = kOrdPNb, NBK = kOrdPBuckets;
+  constexpr int NT = 256, NBK = kOrdPBuckets;
+  typedef OrdPipeLds<CAP, NBCAP> PL;
   double *kb = reinterpret_cast<double *>(work);
-  int *kstart = reinterpret_cast<int *>(work + OrdPipeLds::kb_bytes);
+  int *kstart = reinterpret_cast<int *>(work + PL::kb_bytes);
   int *koff = kstart + NBCAP;
   int *hist = koff + NBCAP + 8;
   int *scratch = hist + NBK + 8;
@@ -967,7 +973,7 @@ __device__ inline int ordp_sort(const Csc &A, const OrdBMeta *__restrict__ bmeta
   for (int b = tid; b < NBK + 1; b += NT) hist[b] = 0;
   if (tid == 0) scratch[8] = 0;
   __syncthreads();
-  {  // exclusive prefix sum of the extents (nb <= kOrdPNb <= 128: the first two wavefronts hold one entry per lane)
+  {  // exclusive prefix sum of the extents (nb <= NBCAP <= 128: the first two wavefronts hold one entry per lane)
     const int v = tid < nb ? koff[tid] : 0;
     int incl = v;
 #pragma unroll
@@ -1115,12 +1121,13 @@ __device__ inline int ordp_count(const unsigned *skeys, int np, int *scratch, in
 
 // column classes of the ordered form
 __global__ __launch_bounds__(256) void ord_classify_kernel(Csc B, int64_t ncolsB, const int64_t *__restrict__ nprod,
-                                                           unsigned char *__restrict__ cls, int64_t *__restrict__ heavy_prod) {
+                                                           unsigned char *__restrict__ cls, int64_t *__restrict__ heavy_prod,
+                                                           int ord_cap, int ord_nb) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= ncolsB) return;
   const int64_t np = nprod[j];
   const int nb = B.p[j + 1] - B.p[j];
-  const int c = np == 0 ? 0 : (np <= kOrdWaveCap && nb <= kOrdWaveNb) ? 1 : (np <= kOrdCap && nb <= kOrdPNb) ? 2 : 3;
+  const int c = np == 0 ? 0 : (np <= kOrdWaveCap && nb <= kOrdWaveNb) ? 1 : (np <= ord_cap && nb <= ord_nb) ? 2 : 3;
   cls[j] = (unsigned char)c;
   heavy_prod[j] = c == 3 ? np : 0;
 }
@@ -1159,11 +1166,12 @@ __global__ __launch_bounds__(256) void ord_task_fill_kernel(Csc B, int64_t ncols
     const int64_t j = j0 + w;
     const int c = cls[j];
     const int qs = B.p[j], nb = B.p[j + 1] - qs;
-    // classes 1 / 2 have at most kOrdCap products and kOrdPNb entries of B; the others do not use y / w's low half
+    // classes 1 / 2 have at most 2048 products and 128 entries of B; the others do not use y / w's low half
     tasks[o + w] = make_int4((int)j, c == 1 || c == 2 ? (int)nprod[j] : 0, qs, (nb & 0xffff) | (c << 16));
   }
 }
 
+template <int CAP, int NBCAP>
 __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64_t ncolsB, int bucket_shift_wave,
                                                              int bucket_shift_group, const int64_t *__restrict__ nprod,
                                                              const unsigned char *__restrict__ cls,
@@ -1180,17 +1188,18 @@ __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64
   __shared__ long long s_tile;
   __shared__ long long s_base;
   typedef OrdLds<kOrdWaveCap, kOrdWaveNb> LW;
+  typedef OrdPipeLds<CAP, NBCAP> PL;
   constexpr size_t wave_bytes = (LW::total + 15) / 16 * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned long long acc_stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long *const local_stamps = stamps ? acc_stamps : nullptr;
   // pipelined workgroup path: workspace, then the two (values, keys) result buffers
   unsigned char *work = smem;
-  auto pvals = [&](int i) { return reinterpret_cast<double *>(smem + OrdPipeLds::work_bytes + (size_t)i * OrdPipeLds::vals_bytes); };
+  auto pvals = [&](int i) { return reinterpret_cast<double *>(smem + PL::work_bytes + (size_t)i * PL::vals_bytes); };
   auto pkeys = [&](int i) {
-    return reinterpret_cast<unsigned *>(smem + OrdPipeLds::work_bytes + 2 * OrdPipeLds::vals_bytes + (size_t)i * OrdPipeLds::keys_bytes);
+    return reinterpret_cast<unsigned *>(smem + PL::work_bytes + 2 * PL::vals_bytes + (size_t)i * PL::keys_bytes);
   };
-  int *scratch_a = reinterpret_cast<int *>(smem + OrdPipeLds::work_bytes) - 32;  // the workspace's scratch: [0,16) sort, [16,32) finish
+  int *scratch_a = reinterpret_cast<int *>(smem + PL::work_bytes) - 32;  // the workspace's scratch: [0,16) sort, [16,32) finish
   int *scratch_b = scratch_a + 16;
   OrdPending pend;
   auto finish_pending = [&]() {
@@ -1238,13 +1247,13 @@ __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64
         const int kin = pend.valid ? 1 - pend.keys_in : 0, vin = pend.valid ? 1 - pend.vals_in : 0;
         const int np = rec.y;
         int keys_in = kin;
-        const int st = ordp_sort(A, bmeta, rec.z, nbj, np, bucket_shift_group, work, pkeys(kin), pvals(vin), tid,
+        const int st = ordp_sort<CAP, NBCAP>(A, bmeta, rec.z, nbj, np, bucket_shift_group, work, pkeys(kin), pvals(vin), tid,
                                  tid == 0 ? local_stamps : nullptr);
         if (stamps) t_mark = __builtin_amdgcn_s_memtime();
         if (st < 0) {  // crowded bucket: merge tree over the runs; needs the other key buffer, so finish what waits there
           finish_pending();
-          const int *koff = reinterpret_cast<const int *>(work + OrdPipeLds::kb_bytes + OrdPipeLds::start_bytes);
-          const unsigned *sorted = ord_merge_tree<256, kOrdCap>(pkeys(kin), pkeys(1 - kin), koff, nbj, np, tid);
+          const int *koff = reinterpret_cast<const int *>(work + PL::kb_bytes + PL::start_bytes);
+          const unsigned *sorted = ord_merge_tree<256, CAP>(pkeys(kin), pkeys(1 - kin), koff, nbj, np, tid);
           keys_in = sorted == pkeys(kin) ? kin : 1 - kin;
         }
         const int count = ordp_count(pkeys(keys_in), np, scratch_a, tid);
@@ -1277,19 +1286,25 @@ __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64
     for (int i = 0; i < 8; ++i) atomicAdd(stamps + i, acc_stamps[i]);
 }
 
-// products in the columns where the ordered kernel's workgroup path pays (513 ... kOrdCap products, <= kOrdPNb entries of B)
+// products in the columns where the ordered kernel's workgroup path pays: out[0] with the large shape
+// (513 ... 2048 products, <= 128 entries of B), out[1] with the small one (... 1536, <= 96)
 __global__ __launch_bounds__(256) void ord_share_kernel(Csc B, int64_t ncolsB, const int64_t *__restrict__ nprod,
                                                         unsigned long long *__restrict__ out) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long v = 0;
+  unsigned long long v = 0, w = 0;
   if (j < ncolsB) {
     const int64_t np = nprod[j];
     const int nb = B.p[j + 1] - B.p[j];
-    if (np > 2 * kOrdWaveCap && np <= kOrdCap && nb <= kOrdPNb) v = (unsigned long long)np;
+    if (np > 2 * kOrdWaveCap && np <= kOrdCapLarge && nb <= kOrdPNbLarge) v = (unsigned long long)np;
+    if (np > 2 * kOrdWaveCap && np <= kOrdCapSmall && nb <= kOrdPNbSmall) w = (unsigned long long)np;
   }
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  for (int d = 32; d > 0; d >>= 1) {
+    v += __shfl_xor(v, d, 64);
+    w += __shfl_xor(w, d, 64);
+  }
   if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+  if ((threadIdx.x & 63) == 0 && w) atomicAdd(out + 1, w);
 }
 
 // upper bound of a column's length in the result: exact for the columns computed beforehand, its products otherwise
@@ -1347,7 +1362,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   const bool ordered_possible = !(ord_env && ord_env[0] == '0') && nrowsA <= (1LL << kOrdMaxRowBits) &&
                                 !(two_pass_env && two_pass_env[0] == '1') && !(split_keys_env && split_keys_env[0] == '1');
   hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 32)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
-                     medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 0);
+                     medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 0, 0, 0);
   int hc[3] = {0, 0, 0};
   SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 3 * sizeof(int), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
@@ -1369,24 +1384,27 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
                   (double)total_products * 24.0 < 0.5 * (double)free_b;
   }
   bool ordered = false;
+  // shape of the ordered kernel's columns: the small one (four workgroups per CU) unless a good part of the products
+  // sits in columns only the large one takes (1537 ... 2048 products, or 97 ... 128 entries of B);
+  // SPL_SPGEMM_ORDERED_SHAPE=small|large forces it (tests)
+  bool large_shape = false;
   if (ordered_possible && single_pass) {
-    if (ord_env && ord_env[0] == '1') {
-      ordered = true;
-    } else {  // the share of the products in columns of the workgroup class
-      DBuf<unsigned long long> share(1);
-      SPL_HIP(hipMemsetAsync(share.get(), 0, sizeof(unsigned long long), s));
-      hipLaunchKernelGGL(ord_share_kernel, dim3(blocks_for(ncolsB, 256)), dim3(256), 0, s, B, ncolsB, nprod.get(), share.get());
-      unsigned long long h = 0;
-      SPL_HIP(hipMemcpyAsync(&h, share.get(), sizeof(h), hipMemcpyDeviceToHost, s));
-      SPL_HIP(hipStreamSynchronize(s));
-      ordered = 2.0 * (double)h >= (double)total_products;
-    }
+    DBuf<unsigned long long> share(2);
+    SPL_HIP(hipMemsetAsync(share.get(), 0, 2 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(ord_share_kernel, dim3(blocks_for(ncolsB, 256)), dim3(256), 0, s, B, ncolsB, nprod.get(), share.get());
+    unsigned long long h[2] = {0, 0};
+    SPL_HIP(hipMemcpyAsync(h, share.get(), sizeof(h), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipStreamSynchronize(s));
+    ordered = (ord_env && ord_env[0] == '1') || 2.0 * (double)h[0] >= (double)total_products;
+    large_shape = (double)(h[0] - h[1]) > 0.08 * (double)total_products;
+    if (const char *e = getenv("SPL_SPGEMM_ORDERED_SHAPE")) large_shape = e[0] == 'l';
   }
+  const int ord_cap = large_shape ? kOrdCapLarge : kOrdCapSmall, ord_nb = large_shape ? kOrdPNbLarge : kOrdPNbSmall;
   lap("form chosen (share)");
   if (ordered) {  // the columns the ordered kernel handles itself leave the bin lists
     SPL_HIP(hipMemsetAsync(list_counts.get(), 0, 3 * sizeof(int), s));
     hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 32)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
-                       medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 1);
+                       medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 1, ord_cap, ord_nb);
     SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 3 * sizeof(int), hipMemcpyDeviceToHost, s));
     SPL_HIP(hipStreamSynchronize(s));
   }
@@ -1442,7 +1460,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     heavy_prod.alloc((size_t)ncolsB);
     heavy_slot.alloc((size_t)ncolsB + 1);
     hipLaunchKernelGGL(ord_classify_kernel, dim3(blocks_for(ncolsB, 256)), dim3(256), 0, s, B, ncolsB, nprod.get(),
-                       cls.get(), heavy_prod.get());
+                       cls.get(), heavy_prod.get(), ord_cap, ord_nb);
     exclusive_scan_i64(heavy_prod.get(), heavy_slot.get(), ncolsB, s);
     SPL_HIP(hipMemcpyAsync(&total_heavy, heavy_slot.get() + ncolsB, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     SPL_HIP(hipStreamSynchronize(s));
@@ -1535,7 +1553,9 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     while ((1LL << rb) < nrowsA) ++rb;
     const int sh_wave = rb > 7 ? rb - 7 : 0, sh_group = rb > 9 ? rb - 9 : 0;  // 128 / 512 buckets
     typedef OrdLds<kOrdWaveCap, kOrdWaveNb> LW;
-    const size_t lds = std::max((LW::total + 15) / 16 * 16 * 4, (size_t)OrdPipeLds::total);
+    const size_t pipe_lds = large_shape ? (size_t)OrdPipeLds<kOrdCapLarge, kOrdPNbLarge>::total
+                                        : (size_t)OrdPipeLds<kOrdCapSmall, kOrdPNbSmall>::total;
+    const size_t lds = std::max((LW::total + 15) / 16 * 16 * 4, pipe_lds);
     int cus = 256;
     {
       int dev = 0;
@@ -1571,9 +1591,14 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
         SPL_HIP(hipMemsetAsync(stamps.get(), 0, 8 * sizeof(unsigned long long), s));
       }
     }
-    hipLaunchKernelGGL(spgemm_ordered_kernel, dim3((unsigned)grid), dim3(256), lds, s, A, B, ncolsB, sh_wave, sh_group,
-                       nprod.get(), cls.get(), heavy_slot.get(), counts.get(), Ti.get(), Tx.get(), status.get(), ticket,
-                       tasks.get(), ntasks, bmeta.get(), Cp.get(), Ci.get(), Cx.get(), stamps.get());
+    if (large_shape)
+      hipLaunchKernelGGL((spgemm_ordered_kernel<kOrdCapLarge, kOrdPNbLarge>), dim3((unsigned)grid), dim3(256), lds, s, A, B,
+                         ncolsB, sh_wave, sh_group, nprod.get(), cls.get(), heavy_slot.get(), counts.get(), Ti.get(), Tx.get(),
+                         status.get(), ticket, tasks.get(), ntasks, bmeta.get(), Cp.get(), Ci.get(), Cx.get(), stamps.get());
+    else
+      hipLaunchKernelGGL((spgemm_ordered_kernel<kOrdCapSmall, kOrdPNbSmall>), dim3((unsigned)grid), dim3(256), lds, s, A, B,
+                         ncolsB, sh_wave, sh_group, nprod.get(), cls.get(), heavy_slot.get(), counts.get(), Ti.get(), Tx.get(),
+                         status.get(), ticket, tasks.get(), ntasks, bmeta.get(), Cp.get(), Ci.get(), Cx.get(), stamps.get());
     if (stamps.get()) {
       unsigned long long h[8];
       SPL_HIP(hipMemcpy(h, stamps.get(), sizeof(h), hipMemcpyDeviceToHost));

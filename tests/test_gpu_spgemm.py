@@ -116,11 +116,13 @@ def test_colblock_spgemm_hip_blocks_concatenate_to_mm(gpu, pkg, O, nparts):
     assert tuples_equal(mat_to_tuple(C), O.mm(A, B))
 
 
-def test_ordered_form_matches_oracle(gpu, pkg, O, monkeypatch):
+@pytest.mark.parametrize("shape_name", ["small", "large"])
+def test_ordered_form_matches_oracle(gpu, pkg, O, monkeypatch, shape_name):
     """SPL_SPGEMM_ORDERED=1: every column written at its final offset through the look-back chain (no
     compaction), counting sort over row buckets, bucket-overflow fallback to the merge tree, heavy columns
     copied from scratch slots — same structure and values, bit for bit (Sparse.hs:691-702)"""
     monkeypatch.setenv("SPL_SPGEMM_ORDERED", "1")
+    monkeypatch.setenv("SPL_SPGEMM_ORDERED_SHAPE", shape_name)  # 1536 / 96 (four workgroups per CU) or 2048 / 128
     rng = np.random.default_rng(17)
     for shape in ((40, 30, 50, 300), (2000, 1500, 1800, 30000), (200, 5000, 100, 8000), (300, 300, 300, 3000)):
         m, n, p, k = shape

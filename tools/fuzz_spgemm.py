@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fuzz of mm (Sparse.hs:691-702) on structures the R-MAT generator never makes: hub columns in A, heavy and empty
 columns in B, rows crowded into narrow ranges, rectangular shapes, real and complex values — through every form of
-the SpGEMM (automatic choice, ordered single pass, compacting single pass, symbolic + numeric two-pass, split sort
+the SpGEMM (automatic choice, ordered single pass in both column shapes, compacting single pass, symbolic + numeric two-pass, split sort
 keys), each compared with the oracle bit for bit (structure and values).
 python tools/fuzz_spgemm.py [seed] [cases]"""
 import os
@@ -12,9 +12,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-FORMS = ({}, {"SPL_SPGEMM_ORDERED": "1"}, {"SPL_SPGEMM_ORDERED": "0"}, {"SPL_SPGEMM_TWO_PASS": "1"},
-         {"SPL_SPGEMM_SPLIT_KEYS": "1"})
-KEYS = ("SPL_SPGEMM_ORDERED", "SPL_SPGEMM_TWO_PASS", "SPL_SPGEMM_SPLIT_KEYS")
+FORMS = ({}, {"SPL_SPGEMM_ORDERED": "1", "SPL_SPGEMM_ORDERED_SHAPE": "small"},
+         {"SPL_SPGEMM_ORDERED": "1", "SPL_SPGEMM_ORDERED_SHAPE": "large"}, {"SPL_SPGEMM_ORDERED": "0"},
+         {"SPL_SPGEMM_TWO_PASS": "1"}, {"SPL_SPGEMM_SPLIT_KEYS": "1"})
+KEYS = ("SPL_SPGEMM_ORDERED", "SPL_SPGEMM_ORDERED_SHAPE", "SPL_SPGEMM_TWO_PASS", "SPL_SPGEMM_SPLIT_KEYS")
 
 
 def pattern(rng, kind, nr, nc, k):
