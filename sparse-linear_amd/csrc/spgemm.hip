@@ -66,7 +66,9 @@ struct Csc {
 // bins: 0 empty, 1 S, 2 M, 3 X, 4 L
 __device__ inline int bin_of(int64_t np, int nb) {
   if (np == 0) return 0;
-  if (np <= kSmallProducts) return 1;
+  // (a column of B may be long and still have few products — most of the columns of A it selects empty: the
+  // one-wavefront kernel stages at most kSmallProducts entries of B, such a column goes to a bin that holds it)
+  if (np <= kSmallProducts && nb <= kSmallProducts) return 1;
   if (np <= kMediumProducts && nb <= kMediumB) return 2;
   if (np <= kLargeProducts && nb <= kLargeB) return 3;
   return 4;
@@ -371,6 +373,7 @@ __global__ __launch_bounds__(256) void spgemm_wave_kernel(Csc A, Csc B, int64_t 
     if (counts && lane == 0) counts[j] = 0;
     return;
   }
+  if (B.p[j + 1] - B.p[j] > kSmallProducts) return;  // listed in another bin (bin_of)
   esc_column<64, kSmallProducts, kSmallProducts, NUMERIC, KEY32>(A, B, j, (int)np, lds_all[wave], lane, counts,
                                                                 Cp, Ci, Cx);
 }
@@ -395,52 +398,118 @@ __global__ __launch_bounds__(256) void spgemm_dense_kernel(Csc A, Csc B, int64_t
                                                            double *__restrict__ pool_vals,
                                                            int *__restrict__ counts,
                                                            const int64_t *__restrict__ Cp,
-                                                           int *__restrict__ Ci, double *__restrict__ Cx) {
+                                                           int *__restrict__ Ci, double *__restrict__ Cx,
+                                                           unsigned long long *__restrict__ stamps = nullptr) {
   __shared__ int wave_counts[4];
   __shared__ int64_t running;
+  unsigned long long t_acc = 0, t_gather = 0, t_max = 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned char *flags = pool_flags + (size_t)blockIdx.x * (size_t)nrowsA;
+  const int64_t npad = (nrowsA + 15) & ~(int64_t)15;  // stride of a flag slot: whole 16-byte vectors (see the gather)
+  unsigned char *flags = pool_flags + (size_t)blockIdx.x * (size_t)npad;
   double *w = NUMERIC ? pool_vals + (size_t)blockIdx.x * (size_t)nrowsA : nullptr;
   for (int li = blockIdx.x; li < nlist; li += gridDim.x) {
     const int64_t j = list[li];
     if (threadIdx.x == 0) running = 0;
+    const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     const int qs = B.p[j], qe = B.p[j + 1];
     for (int q = qs; q < qe; ++q) {
       const int k = B.i[q];
       const double b = NUMERIC ? B.x[q] : 0.0;
       const int ps = A.p[k], pe = A.p[k + 1];
-      for (int p = ps + (int)threadIdx.x; p < pe; p += 256) {
-        const int r = A.i[p];
-        flags[r] = 1;
-        if (NUMERIC) w[r] = w[r] + A.x[p] * b;
+      // The rows of one column of A are distinct, so the read-modify-writes of one pass over it are independent:
+      // four per thread are in flight at a time (loads of the indices, then of the accumulators, then the stores).
+      // A thread that did them one after the other (each store before the next load, as the compiler must assume
+      // they alias) ran a hub column of 10^8 products alone for most of a second.
+      for (int p0 = ps + (int)threadIdx.x; p0 < pe; p0 += 4 * 256) {
+        int r[4];
+        double a[4], acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int p = p0 + u * 256;
+          r[u] = p < pe ? A.i[p] : -1;
+          a[u] = (NUMERIC && p < pe) ? A.x[p] : 0.0;
+        }
+        if (NUMERIC) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[u] = r[u] >= 0 ? w[r[u]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (r[u] >= 0) {
+            flags[r[u]] = 1;
+            if (NUMERIC) w[r[u]] = acc[u] + a[u] * b;
+          }
       }
       __syncthreads();
     }
     // gather in row order (ScatterGather.hs:97-147), clearing the accumulator as we go
+    const unsigned long long t1 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    // A step covers 256 x 16 rows: every thread reads the flags of 16 consecutive rows as one 16-byte vector (a flag
+    // is 0 or 1, so the population count of a word is its number of used rows) and the vector of the next step is
+    // requested before this one is consumed.  (Row by row — 256 rows, three barriers and a dependent load per
+    // step — the sweep of all nrowsA flags cost every dense column 2 ms, ten times its accumulation, whatever
+    // the number of rows it had touched: profiles/r02_spgemm_dense_stamps.txt.)
     const int64_t base = NUMERIC ? Cp[j] : 0;
-    for (int64_t r0 = 0; r0 < nrowsA; r0 += 256) {
-      const int64_t r = r0 + threadIdx.x;
-      const bool used = r < nrowsA && flags[r] != 0;
-      const unsigned long long m = __ballot(used);
-      if (lane == 0) wave_counts[wave] = __popcll(m);
+    uint4 *f4 = reinterpret_cast<uint4 *>(flags);
+    const int64_t nvec = npad >> 4;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 cur = (int64_t)threadIdx.x < nvec ? f4[threadIdx.x] : zero4;
+    for (int64_t v0 = 0; v0 < nvec; v0 += 256) {
+      const int64_t v = v0 + threadIdx.x;
+      const uint4 nxt = v + 256 < nvec ? f4[v + 256] : zero4;
+      const int c = __popc(cur.x) + __popc(cur.y) + __popc(cur.z) + __popc(cur.w);
+      int incl = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+      }
+      if (lane == 63) wave_counts[wave] = incl;
       __syncthreads();
-      int64_t off = running;
+      int64_t off = running + (incl - c);
       for (int ww = 0; ww < wave; ++ww) off += wave_counts[ww];
-      if (used) {
+      if (c) {
         if (NUMERIC) {
-          off += __popcll(m & ((1ull << lane) - 1ull));
-          Ci[base + off] = (int)r;
-          Cx[base + off] = w[r];
-          w[r] = 0.0;
+          const unsigned words[4] = {cur.x, cur.y, cur.z, cur.w};
+          const double *wrow = w + (v << 4);
+          double got[16];  // all the accumulators of the used rows first (independent loads), then the stores
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int bidx = 0; bidx < 4; ++bidx)
+              got[4 * q + bidx] = ((words[q] >> (8 * bidx)) & 1u) ? wrow[4 * q + bidx] : 0.0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int bidx = 0; bidx < 4; ++bidx)
+              if ((words[q] >> (8 * bidx)) & 1u) {
+                const int64_t r = (v << 4) + 4 * q + bidx;
+                Ci[base + off] = (int)r;
+                Cx[base + off] = got[4 * q + bidx];
+                w[r] = 0.0;
+                ++off;
+              }
         }
-        flags[r] = 0;
+        f4[v] = zero4;
       }
       __syncthreads();
       if (threadIdx.x == 0) running += wave_counts[0] + wave_counts[1] + wave_counts[2] + wave_counts[3];
       __syncthreads();
+      cur = nxt;
     }
     if (counts && threadIdx.x == 0) counts[j] = (int)running;
     __syncthreads();
+    if (stamps) {
+      const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+      t_acc += t1 - t0;
+      t_gather += t2 - t1;
+      t_max = t2 - t0 > t_max ? t2 - t0 : t_max;
+    }
+  }
+  if (stamps && threadIdx.x == 0) {  // SPL_SPGEMM_STAMPS=1: ticks of accumulation / gather summed over columns, the longest column
+    atomicAdd(stamps, t_acc);
+    atomicAdd(stamps + 1, t_gather);
+    atomicMax(stamps + 2, t_max);
   }
 }
 
@@ -1439,9 +1508,10 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   DBuf<unsigned char> pool_flags;
   DBuf<double> pool_vals;
   if (ndense > 0) {
-    pool_flags.alloc((size_t)pool * (size_t)nrowsA);
+    const size_t flag_stride = ((size_t)nrowsA + 15) & ~(size_t)15;  // spgemm_dense_kernel reads flags 16 at a time
+    pool_flags.alloc((size_t)pool * flag_stride);
     pool_vals.alloc((size_t)pool * (size_t)nrowsA);
-    SPL_HIP(hipMemsetAsync(pool_flags.get(), 0, (size_t)pool * (size_t)nrowsA, s));
+    SPL_HIP(hipMemsetAsync(pool_flags.get(), 0, (size_t)pool * flag_stride, s));
     SPL_HIP(hipMemsetAsync(pool_vals.get(), 0, (size_t)pool * (size_t)nrowsA * sizeof(double), s));
   }
 
@@ -1525,10 +1595,22 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   }
 #undef SPL_NUMERIC_WAVE
 #undef SPL_NUMERIC_BLOCK
-  if (ndense > 0)
+  if (ndense > 0) {
+    DBuf<unsigned long long> dstamps;
+    if (getenv("SPL_SPGEMM_STAMPS")) {
+      dstamps.alloc(4);
+      SPL_HIP(hipMemsetAsync(dstamps.get(), 0, 4 * sizeof(unsigned long long), s));
+    }
     hipLaunchKernelGGL(spgemm_dense_kernel<true>, dim3((unsigned)pool), dim3(256), 0, s, A, B, nrowsA,
                        dense_list.get(), ndense, pool_flags.get(), pool_vals.get(), numeric_counts, slots, out_i,
-                       out_x);
+                       out_x, dstamps.get());
+    if (dstamps.get()) {
+      unsigned long long h[4];
+      SPL_HIP(hipMemcpy(h, dstamps.get(), sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[spgemm dense] %d columns on %d workgroups: accumulate %llu ticks, gather %llu ticks (summed), longest "
+              "column %llu ticks; medium %d, xlarge %d columns\n", ndense, pool, h[0], h[1], h[2], nmedium, nxlarge);
+    }
+  }
   if (ordered) {
     // ---- every column to its final place, in column order
     // capacity of the result: the exact lengths of the columns computed beforehand + the products of the others

@@ -157,3 +157,21 @@ def test_ordered_form_matches_oracle(gpu, pkg, O, monkeypatch, shape_name):
         At = (nn, nn, rp, ci.astype(np.int64), v)
         Cs = O.mm(At, At)
         assert np.array_equal(crp, Cs[2]) and np.array_equal(cci, Cs[3]) and np.array_equal(cv, Cs[4])
+
+
+@pytest.mark.parametrize("form", [{}, {"SPL_SPGEMM_ORDERED": "1"}, {"SPL_SPGEMM_ORDERED": "0"}, {"SPL_SPGEMM_TWO_PASS": "1"}])
+def test_long_columns_of_b_with_few_products(gpu, pkg, O, monkeypatch, form):
+    """a column of B with hundreds to thousands of entries that selects mostly EMPTY columns of A has few products:
+    it must not go to the one-wavefront kernel, whose LDS stages at most 256 entries of B (found by
+    tools/fuzz_spgemm.py: 2049 x 4000 with 1 187 entries times a 4000 x 1 column of 1 899 entries hung the kernel)"""
+    for k, v in form.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(29)
+    for m, n, ka, nbs in ((2049, 4000, 1187, (1899,)), (3000, 4000, 100, (2000, 257, 3000, 5)), (500, 9000, 40, (8000, 300))):
+        A = O.compress(m, n, rng.integers(0, m, ka), rng.integers(0, n, ka), rng.normal(size=ka))
+        brow = np.concatenate([rng.choice(n, k, replace=False) for k in nbs])
+        bcol = np.concatenate([np.full(k, c) for c, k in enumerate(nbs)])
+        B = O.compress(n, len(nbs), brow, bcol, rng.normal(size=len(brow)))
+        C = pkg.mm(tuple_to_mat(pkg, A), tuple_to_mat(pkg, B))
+        assert tuples_equal(mat_to_tuple(C), O.mm(A, B))
+

@@ -6,6 +6,7 @@ keys), each compared with the oracle bit for bit (structure and values).
 python tools/fuzz_spgemm.py [seed] [cases]"""
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -64,7 +65,14 @@ def main():
             for k_ in KEYS:
                 os.environ.pop(k_, None)
             os.environ.update(form)
+            if os.environ.get("SPL_FUZZ_VERBOSE"):
+                print("case %d form %s: %dx%d * %dx%d nnz %d %d complex=%d" % (case, form, m, n, n, p, len(A[3]), len(B[3]), cplx),
+                      flush=True)
+            t_call = time.perf_counter()
             C = pkg.mm(Am, Bm)
+            if time.perf_counter() - t_call > 2.0:
+                print("slow: case %d form %s: %dx%d * %dx%d nnz %d %d: %.1f s" %
+                      (case, form, m, n, n, p, len(A[3]), len(B[3]), time.perf_counter() - t_call), flush=True)
             calls += 1
             ok = (C.nrows, C.ncols) == (ref[0], ref[1]) and np.array_equal(C.pointers, ref[2]) and \
                 np.array_equal(C.indices, ref[3]) and np.array_equal(C.values, ref[4])
