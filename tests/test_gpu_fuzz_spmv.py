@@ -27,3 +27,12 @@ def test_fuzz_spgemm_forms(gpu):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "40 cases, 240 products, 0 failures" in r.stdout
+
+
+def test_fuzz_assembly_operations(gpu):
+    """tools/fuzz_assembly.py: compress, transpose, lin / + / - (real and complex), mulM, mulVT, takeDiag, kronecker,
+    hcat / vcat / fromBlocks on irregular random inputs — every result bit-identical to the oracle"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_assembly.py"), "6", "60"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "60 cases" in r.stdout and ", 0 failures" in r.stdout.splitlines()[-1]
