@@ -101,6 +101,14 @@ class Matrix(object):
         """withConstMatrix's marshalling (Foreign.hs:24-41): fresh int32 copies.  Complex values
         cross as packed (re, im) pairs, the form the reference passes to umfpack_zi_* with the
         imaginary pointer NULL (Umfpack/Internal.hs:124-132)."""
+        # the 5-tuple carries no lengths: the C side reads pointers[ncols] indices and values, so a last pointer
+        # beyond the arrays (or a pointer array shorter than ncols + 1) would be a heap over-read before any
+        # validation on the device could refuse the matrix
+        if len(self.pointers) != self.ncols + 1:
+            _oops("withConstMatrix", "pointers has %d entries for %d columns" % (len(self.pointers), self.ncols))
+        nz = int(self.pointers[-1]) if len(self.pointers) else 0
+        if nz < 0 or nz > len(self.indices) or nz > len(self.values):
+            _oops("withConstMatrix", "last pointer %d, but %d indices and %d values" % (nz, len(self.indices), len(self.values)))
         vals = self.values.view(F64) if self.is_complex else self.values
         return (self.nrows, self.ncols, as_i32(self.pointers), as_i32(self.indices), as_f64(vals))
 

@@ -60,3 +60,21 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "libsparse_oracle" not in text, f
+
+
+def test_marshalling_refuses_arrays_shorter_than_the_pointers_say():
+    """the 5-tuple of withConstMatrix carries no lengths (Foreign.hs:24-41): the Python mirror checks them before the
+    C side would read pointers[ncols] indices and values out of shorter arrays (no GPU needed: the check is host side)"""
+    import numpy as np
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    for M in (pkg.Matrix(3, 3, [0, 2, 3, 9], [0, 2, 1, 2], [1.0, 2.0, 3.0, 4.0]),
+              pkg.Matrix(3, 3, [0, 2, 3], [0, 2, 1], [1.0, 2.0, 3.0]),
+              pkg.Matrix(3, 3, [0, 2, 3, 4], [0, 2, 1, 2], np.array([1.0, 2.0, 3.0]))):
+        try:
+            M._tuple32()
+        except pkg.SparseError:
+            continue
+        raise AssertionError("short arrays were marshalled")
+    ok = pkg.Matrix(3, 3, [0, 2, 3, 4], [0, 2, 1, 2], [1.0, 2.0, 3.0, 4.0])
+    assert ok._tuple32()[0] == 3
