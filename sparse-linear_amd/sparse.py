@@ -181,6 +181,8 @@ class DeviceMatrix(object):
     def from_csr(cls, nrows_global, ncols, rowptr, colidx, val, row0=0):
         _ffi.require_gpu()
         rp, ci, v = as_i32(rowptr), as_i32(colidx), as_f64(val)
+        if len(rp) < 1 or int(rp[-1]) < 0 or int(rp[-1]) > len(ci) or int(rp[-1]) > len(v):
+            _oops("from_csr", "last row pointer %s, but %d column indices and %d values" % (rp[-1] if len(rp) else None, len(ci), len(v)))
         h = C.c_void_p()
         check("spl_matrix_create_csr",
               lib().spl_matrix_create_csr(nrows_global, ncols, row0, len(rp) - 1, p_i32(rp), p_i32(ci),
