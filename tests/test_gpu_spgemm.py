@@ -1,5 +1,7 @@
 """SpGEMM (mm, Sparse.hs:691-702) on the HIP path: structure bit-exact, values bit-exact
 (the kernels keep the reference's ascending-k accumulation order), every size bin."""
+import os
+
 import numpy as np
 import pytest
 
@@ -175,3 +177,31 @@ def test_long_columns_of_b_with_few_products(gpu, pkg, O, monkeypatch, form):
         C = pkg.mm(tuple_to_mat(pkg, A), tuple_to_mat(pkg, B))
         assert tuples_equal(mat_to_tuple(C), O.mm(A, B))
 
+
+
+@pytest.mark.parametrize("m", [70001, 4097, 16])
+def test_dense_accumulator_columns_any_row_count(gpu, pkg, O, m):
+    """columns beyond every LDS bin (tens of thousands of products, or thousands of entries of B) go through the
+    dense accumulator in HBM, whose flags are swept 16 rows per thread: row counts that are not multiples of 16,
+    rows touched at the very end of the range, several dense columns per workgroup slot, both single-pass forms"""
+    rng = np.random.default_rng(m)
+    n = 3000
+    ka = min(40 * n, m * n // 2)
+    rows, cols = rng.integers(0, m, ka), rng.integers(0, n, ka)
+    rows[:50] = m - 1  # the last row, in many columns
+    A = O.compress(m, n, rows, cols, rng.normal(size=ka))
+    nbs = (2500, 2100, 30, 2999, 1)
+    brow = np.concatenate([rng.choice(n, k, replace=False) for k in nbs])
+    bcol = np.concatenate([np.full(k, c) for c, k in enumerate(nbs)])
+    B = O.compress(n, len(nbs), brow, bcol, rng.normal(size=len(brow)))
+    ref = O.mm(A, B)
+    for env in ({}, {"SPL_SPGEMM_ORDERED": "1"}, {"SPL_SPGEMM_TWO_PASS": "1"}):
+        for k in ("SPL_SPGEMM_ORDERED", "SPL_SPGEMM_TWO_PASS"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            C = pkg.mm(tuple_to_mat(pkg, A), tuple_to_mat(pkg, B))
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert tuples_equal(mat_to_tuple(C), ref), env
