@@ -96,26 +96,34 @@ __global__ __launch_bounds__(256) void products_kernel(Csc A, Csc B, int64_t nco
   n += __shfl_xor(n, 4, 64);
   // bin lists: one global atomic per workgroup and bin (a million columns of one bin would
   // otherwise serialise on one address), positions inside the workgroup from LDS counters
-  __shared__ int local_count[3], base[3];
-  if (threadIdx.x < 3) local_count[threadIdx.x] = 0;
+  // (bin X is listed in two halves of one array: columns with at most kMediumB entries of B from the front — they run
+  // with the small staging area, four workgroups per CU instead of two —, the others from the back: slot 3)
+  __shared__ int local_count[4], base[4];
+  if (threadIdx.x < 4) local_count[threadIdx.x] = 0;
   __syncthreads();
   const bool owner = g < ncolsB && sub == 0;
   int bin = 0, pos = 0;
+  bool xback = false;
   if (owner) {
     nprod[j] = n;
     bin = bin_of(n, qe - qs);
     // ordered form: the columns its own kernel handles (<= ord_cap products, <= ord_nb entries of B) are not listed;
     // every other column must be, also a light one with a long column of B (bin S has no list: it goes with M)
     if (ordered && n > 0) bin = (n <= ord_cap && qe - qs <= ord_nb) ? 1 : (bin < 2 ? 2 : bin);
-    if (bin >= 2) pos = atomicAdd(&local_count[bin - 2], 1);
+    xback = bin == 3 && qe - qs > kMediumB;
+    if (bin >= 2) pos = atomicAdd(&local_count[xback ? 3 : bin - 2], 1);
   }
   __syncthreads();
-  if (threadIdx.x < 3 && local_count[threadIdx.x] > 0)
+  if (threadIdx.x < 4 && local_count[threadIdx.x] > 0)
     base[threadIdx.x] = atomicAdd(&list_counts[threadIdx.x], local_count[threadIdx.x]);
   __syncthreads();
   if (owner && bin >= 2) {
-    int64_t *list = bin == 2 ? medium_list : bin == 3 ? xlarge_list : dense_list;
-    list[base[bin - 2] + pos] = j;
+    if (xback) {
+      xlarge_list[ncolsB - 1 - (base[3] + pos)] = j;
+    } else {
+      int64_t *list = bin == 2 ? medium_list : bin == 3 ? xlarge_list : dense_list;
+      list[base[bin - 2] + pos] = j;
+    }
   }
 }
 
@@ -1417,8 +1425,8 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   }
   DBuf<int64_t> nprod((size_t)ncolsB), medium_list((size_t)ncolsB), xlarge_list((size_t)ncolsB),
       dense_list((size_t)ncolsB);
-  DBuf<int> list_counts(3), counts((size_t)ncolsB);
-  SPL_HIP(hipMemsetAsync(list_counts.get(), 0, 3 * sizeof(int), s));
+  DBuf<int> list_counts(4), counts((size_t)ncolsB);
+  SPL_HIP(hipMemsetAsync(list_counts.get(), 0, 4 * sizeof(int), s));
   // Which single-pass form?  The ordered form (every column straight to its final place, no compaction, the
   // pipelined workgroup path) wins where the products sit in columns of about a thousand products — C4: 0.023 s
   // vs 0.030 s — and loses where they sit in light columns (64 products per column: 8.2 ms vs 5.4 ms; 256 per
@@ -1432,8 +1440,8 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
                                 !(two_pass_env && two_pass_env[0] == '1') && !(split_keys_env && split_keys_env[0] == '1');
   hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 32)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
                      medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 0, 0, 0);
-  int hc[3] = {0, 0, 0};
-  SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+  int hc[4] = {0, 0, 0, 0};
+  SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
   DBuf<int64_t> pscan((size_t)ncolsB + 1);  // products before column j: its upper-bound output slot
   exclusive_scan_i64(nprod.get(), pscan.get(), ncolsB, s);
@@ -1471,16 +1479,18 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   const int ord_cap = large_shape ? kOrdCapLarge : kOrdCapSmall, ord_nb = large_shape ? kOrdPNbLarge : kOrdPNbSmall;
   lap("form chosen (share)");
   if (ordered) {  // the columns the ordered kernel handles itself leave the bin lists
-    SPL_HIP(hipMemsetAsync(list_counts.get(), 0, 3 * sizeof(int), s));
+    SPL_HIP(hipMemsetAsync(list_counts.get(), 0, 4 * sizeof(int), s));
     hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 32)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
                        medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 1, ord_cap, ord_nb);
-    SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     SPL_HIP(hipStreamSynchronize(s));
   }
   lap("ordered bin lists");
-  const int nmedium = hc[0], nxlarge = hc[1], ndense = hc[2];
+  const int nmedium = hc[0], nxlarge = hc[1], ndense = hc[2], nxback = hc[3];
+  const int64_t *xback_list = xlarge_list.get() + (ncolsB - nxback);  // the columns of bin X with a long column of B
   typedef EscLds<kMediumProducts, kMediumB, false> LMs;
   typedef EscLds<kLargeProducts, kLargeB, false> LXs;
+  typedef EscLds<kLargeProducts, kMediumB, false> LXsShort;
   typedef EscLds<kLargeProducts, kLargeB, true, false> LXn;
   typedef EscLds<kLargeProducts, kLargeB, true, true> LXn32;
   // 32-bit packed sort keys need row + tie-break bits to fit 31 bits in every bin
@@ -1557,8 +1567,12 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
                          dim3(256), LMs::total, s, A, B, medium_list.get(), nprod.get(), counts.get(),
                          (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
     if (nxlarge > 0)
-      hipLaunchKernelGGL((spgemm_block_kernel<kLargeProducts, kLargeB, false, false>), dim3((unsigned)nxlarge),
-                         dim3(256), LXs::total, s, A, B, xlarge_list.get(), nprod.get(), counts.get(),
+      hipLaunchKernelGGL((spgemm_block_kernel<kLargeProducts, kMediumB, false, false>), dim3((unsigned)nxlarge),
+                         dim3(256), LXsShort::total, s, A, B, xlarge_list.get(), nprod.get(), counts.get(),
+                         (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
+    if (nxback > 0)
+      hipLaunchKernelGGL((spgemm_block_kernel<kLargeProducts, kLargeB, false, false>), dim3((unsigned)nxback),
+                         dim3(256), LXs::total, s, A, B, xback_list, nprod.get(), counts.get(),
                          (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
     if (ndense > 0)
       hipLaunchKernelGGL(spgemm_dense_kernel<false>, dim3((unsigned)pool), dim3(256), 0, s, A, B, nrowsA,
@@ -1582,16 +1596,20 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
                      nprod.get(), numeric_counts, slots, out_i, out_x)
 #define SPL_NUMERIC_BLOCK(CAP, NBCAP, K32, LIST, COUNT)                                                        \
   hipLaunchKernelGGL((spgemm_block_kernel<CAP, NBCAP, true, K32>), dim3((unsigned)(COUNT)), dim3(256),         \
-                     (EscLds<CAP, NBCAP, true, K32>::total), s, A, B, LIST.get(), nprod.get(), numeric_counts,   \
+                     (EscLds<CAP, NBCAP, true, K32>::total), s, A, B, LIST, nprod.get(), numeric_counts,         \
                      slots, out_i, out_x)
   if (!ordered) { if (key32_s) SPL_NUMERIC_WAVE(true); else SPL_NUMERIC_WAVE(false); }
   if (nmedium > 0) {
-    if (key32_m) SPL_NUMERIC_BLOCK(kMediumProducts, kMediumB, true, medium_list, nmedium);
-    else SPL_NUMERIC_BLOCK(kMediumProducts, kMediumB, false, medium_list, nmedium);
+    if (key32_m) SPL_NUMERIC_BLOCK(kMediumProducts, kMediumB, true, medium_list.get(), nmedium);
+    else SPL_NUMERIC_BLOCK(kMediumProducts, kMediumB, false, medium_list.get(), nmedium);
   }
-  if (nxlarge > 0) {
-    if (key32_x) SPL_NUMERIC_BLOCK(kLargeProducts, kLargeB, true, xlarge_list, nxlarge);
-    else SPL_NUMERIC_BLOCK(kLargeProducts, kLargeB, false, xlarge_list, nxlarge);
+  if (nxlarge > 0) {  // bin X, short columns of B: 36 KB of LDS, four workgroups per CU
+    if (key32_x) SPL_NUMERIC_BLOCK(kLargeProducts, kMediumB, true, xlarge_list.get(), nxlarge);
+    else SPL_NUMERIC_BLOCK(kLargeProducts, kMediumB, false, xlarge_list.get(), nxlarge);
+  }
+  if (nxback > 0) {   // bin X, long columns of B (up to kLargeB entries): 64 KB, two per CU
+    if (key32_x) SPL_NUMERIC_BLOCK(kLargeProducts, kLargeB, true, xback_list, nxback);
+    else SPL_NUMERIC_BLOCK(kLargeProducts, kLargeB, false, xback_list, nxback);
   }
 #undef SPL_NUMERIC_WAVE
 #undef SPL_NUMERIC_BLOCK
@@ -1608,7 +1626,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
       unsigned long long h[4];
       SPL_HIP(hipMemcpy(h, dstamps.get(), sizeof(h), hipMemcpyDeviceToHost));
       fprintf(stderr, "[spgemm dense] %d columns on %d workgroups: accumulate %llu ticks, gather %llu ticks (summed), longest "
-              "column %llu ticks; medium %d, xlarge %d columns\n", ndense, pool, h[0], h[1], h[2], nmedium, nxlarge);
+              "column %llu ticks; medium %d, xlarge %d + %d columns\n", ndense, pool, h[0], h[1], h[2], nmedium, nxlarge, nxback);
     }
   }
   if (ordered) {
