@@ -50,7 +50,7 @@ constexpr int kLargeProducts = 4096, kLargeB = 2048;
 constexpr int kOrdCapSmall = 1536, kOrdPNbSmall = 96;
 constexpr int kOrdPBuckets = 512;
 constexpr int kOrdCapLarge = 2048, kOrdPNbLarge = 128;
-constexpr int kMaxPool = 512;
+constexpr int kMaxPool = 2048;  // dense-accumulator slots = resident workgroups of spgemm_dense_kernel: eight per CU (it lives on latency overlap)
 
 inline unsigned blocks_for(int64_t n, int per_block) {
   int64_t b = (n + per_block - 1) / per_block;
@@ -1511,8 +1511,8 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     attr_set = true;
   }
   int pool = ndense < kMaxPool ? ndense : kMaxPool;
-  {  // keep the accumulator pool under ~8 GB
-    const int64_t cap = (int64_t)8e9 / (9 * (nrowsA > 0 ? nrowsA : 1));
+  {  // keep the accumulator pool under ~32 GB (of 288)
+    const int64_t cap = (int64_t)32e9 / (9 * (nrowsA > 0 ? nrowsA : 1));
     if (pool > cap) pool = (int)(cap < 1 ? 1 : cap);
   }
   DBuf<unsigned char> pool_flags;
