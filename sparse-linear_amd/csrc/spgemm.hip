@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void spgemm_dense_kernel(Csc A, Csc B, int64_t
     }
     // gather in row order (ScatterGather.hs:97-147), clearing the accumulator as we go
     const unsigned long long t1 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    // A step covers 256 x 16 rows: every thread reads the flags of 16 consecutive rows as one 16-byte vector (a flag
+    // A step covers 256 x 64 rows: every thread reads the flags of 64 consecutive rows as four 16-byte vectors (a flag
     // is 0 or 1, so the population count of a word is its number of used rows) and the vector of the next step is
     // requested before this one is consumed.  (Row by row — 256 rows, three barriers and a dependent load per
     // step — the sweep of all nrowsA flags cost every dense column 2 ms, ten times its accumulation, whatever
@@ -461,11 +461,22 @@ __global__ __launch_bounds__(256) void spgemm_dense_kernel(Csc A, Csc B, int64_t
     uint4 *f4 = reinterpret_cast<uint4 *>(flags);
     const int64_t nvec = npad >> 4;
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    uint4 cur = (int64_t)threadIdx.x < nvec ? f4[threadIdx.x] : zero4;
-    for (int64_t v0 = 0; v0 < nvec; v0 += 256) {
-      const int64_t v = v0 + threadIdx.x;
-      const uint4 nxt = v + 256 < nvec ? f4[v + 256] : zero4;
-      const int c = __popc(cur.x) + __popc(cur.y) + __popc(cur.z) + __popc(cur.w);
+    constexpr int VPT = 4;  // vectors per thread and step: 64 consecutive rows per thread, 16 384 rows per step
+    uint4 cur[VPT], nxt[VPT];
+#pragma unroll
+    for (int e = 0; e < VPT; ++e) {
+      const int64_t v = (int64_t)threadIdx.x * VPT + e;
+      cur[e] = v < nvec ? f4[v] : zero4;
+    }
+    for (int64_t v0 = 0; v0 < nvec; v0 += 256 * VPT) {
+      const int64_t vb = v0 + (int64_t)threadIdx.x * VPT;
+      int c = 0;
+#pragma unroll
+      for (int e = 0; e < VPT; ++e) {
+        const int64_t vn = vb + 256 * VPT + e;
+        nxt[e] = vn < nvec ? f4[vn] : zero4;
+        c += __popc(cur[e].x) + __popc(cur[e].y) + __popc(cur[e].z) + __popc(cur[e].w);
+      }
       int incl = c;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -477,33 +488,39 @@ __global__ __launch_bounds__(256) void spgemm_dense_kernel(Csc A, Csc B, int64_t
       int64_t off = running + (incl - c);
       for (int ww = 0; ww < wave; ++ww) off += wave_counts[ww];
       if (c) {
-        if (NUMERIC) {
-          const unsigned words[4] = {cur.x, cur.y, cur.z, cur.w};
-          const double *wrow = w + (v << 4);
-          double got[16];  // all the accumulators of the used rows first (independent loads), then the stores
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+        for (int e = 0; e < VPT; ++e) {
+          const unsigned words[4] = {cur[e].x, cur[e].y, cur[e].z, cur[e].w};
+          if ((words[0] | words[1] | words[2] | words[3]) == 0u) continue;
+          const int64_t v = vb + e;
+          if (NUMERIC) {
+            const double *wrow = w + (v << 4);
+            double got[16];  // all the accumulators of the used rows first (independent loads), then the stores
 #pragma unroll
-            for (int bidx = 0; bidx < 4; ++bidx)
-              got[4 * q + bidx] = ((words[q] >> (8 * bidx)) & 1u) ? wrow[4 * q + bidx] : 0.0;
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+              for (int bidx = 0; bidx < 4; ++bidx)
+                got[4 * q + bidx] = ((words[q] >> (8 * bidx)) & 1u) ? wrow[4 * q + bidx] : 0.0;
 #pragma unroll
-            for (int bidx = 0; bidx < 4; ++bidx)
-              if ((words[q] >> (8 * bidx)) & 1u) {
-                const int64_t r = (v << 4) + 4 * q + bidx;
-                Ci[base + off] = (int)r;
-                Cx[base + off] = got[4 * q + bidx];
-                w[r] = 0.0;
-                ++off;
-              }
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int bidx = 0; bidx < 4; ++bidx)
+                if ((words[q] >> (8 * bidx)) & 1u) {
+                  const int64_t r = (v << 4) + 4 * q + bidx;
+                  Ci[base + off] = (int)r;
+                  Cx[base + off] = got[4 * q + bidx];
+                  w[r] = 0.0;
+                  ++off;
+                }
+          }
+          f4[v] = zero4;
         }
-        f4[v] = zero4;
       }
       __syncthreads();
       if (threadIdx.x == 0) running += wave_counts[0] + wave_counts[1] + wave_counts[2] + wave_counts[3];
       __syncthreads();
-      cur = nxt;
+#pragma unroll
+      for (int e = 0; e < VPT; ++e) cur[e] = nxt[e];
     }
     if (counts && threadIdx.x == 0) counts[j] = (int)running;
     __syncthreads();
