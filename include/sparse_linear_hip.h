@@ -263,9 +263,15 @@ int spl_debug_occupy(int blocks, int threads, double milliseconds, double *d_buf
  * (<= 17); 0,0 = choose.  form: 0 default; 1 / 2 = one 64-entry chunk per load instruction with 1 / 2
  * index blocks per barrier phase; 4 / 5 = paired storage (two chunks per 8-byte key / 16-byte value
  * load) with 1 / 2 index blocks per phase.  unroll: 0 default, else chunks ({4,6,8,10,12}) or pairs
- * ({2..6}) per wavefront and register set.  Used by variant 16, and by variant 0 once
- * spl_matrix_set_spmv_order(H, SPL_ORDER_FREE) was called. */
+ * ({2..6}) per wavefront and register set.  6 / 7 = ring form on the paired storage (a few wavefronts of
+ * the workgroup only stream the image and hand it to the others, which only gather and fold, through
+ * 1.5 KiB slots in LDS; 1 / 2 index blocks per phase; unroll = units in flight per loader, 0 = 6;
+ * rows_per_panel then has to leave room for the slots: 19 700 with the default 4 loaders).  Used by
+ * variant 16, and by variant 0 once spl_matrix_set_spmv_order(H, SPL_ORDER_FREE) was called. */
 int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unroll, int form);
+/* Diagnostics: synchronises the device and returns 1 when a bounded wait of the ring form's hand-over gave
+ * up during the last panel SpMV of this handle (its result is then invalid), 0 otherwise, < 0 on error. */
+int spl_matrix_panel_errors(void *H);
 /* the kernel spl_matrix_spmv_dev launches for this handle now: 0 CSR-stream, 8 column-blocked
  * lockstep, 15 sliced ELL, 16 column-sorted panels (other values: the forced ablation variant) */
 int spl_matrix_spmv_kernel(void *H);

@@ -115,6 +115,7 @@ def _declare(L):
         "spl_matrix_optimize": [C.c_void_p],
         "spl_matrix_build_blocked": [C.c_void_p, i, i, i],
         "spl_matrix_build_panel": [C.c_void_p, i, i, i, i],
+        "spl_matrix_panel_errors": [C.c_void_p],
         "spl_matrix_set_spmv_order": [C.c_void_p, i],
         "spl_matrix_set_reserved_cus": [C.c_void_p, i],
         "spl_debug_occupy": [i, i, C.c_double, C.c_void_p, C.c_size_t, C.c_void_p],

@@ -593,19 +593,38 @@ int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unrol
   if (rows_per_panel == 0 && cols_log2 == 0) choose_panels(m, &rows_per_panel, &cols_log2);
   if (rows_per_panel < 1 || rows_per_panel > 20479 || cols_log2 < 4 || cols_log2 > 17)
     return SPL_ERROR_argument_missing;
-  if (form != 0 && form != 1 && form != 2 && form != 4 && form != 5) return SPL_ERROR_argument_missing;
+  if (form != 0 && form != 1 && form != 2 && form != 4 && form != 5 && form != 6 && form != 7) return SPL_ERROR_argument_missing;
   return guarded([&]() -> int {
     DeviceGuard g(m->device);
     // form: 1 / 2 = one chunk per load, 1 / 2 index blocks per phase; 4 / 5 = paired storage (a pair of
     // chunks per 8-byte key / 16-byte value load; unroll then counts pairs), 1 / 2 index blocks per phase.
     // Default: paired, a phase's x window 2 MiB at most (measured on C2, tools/bench_spmv_variants.py:
     // paired 0.90 ms, one chunk per load 0.96 ms)
+    // 6 / 7 = ring form on the paired storage (loader + gather wavefronts, csrc/spmv_panel.hip), 1 / 2 index
+    // blocks per phase; unroll then counts the units a loader keeps in flight (0: 6)
     if (form == 0) form = cols_log2 >= 17 ? 5 : 4;
     const bool pair = form >= 4;
-    const int kblocks = (form == 2 || form == 5) ? 2 : 1;
+    const bool ring = form >= 6;
+    const int kblocks = (form == 2 || form == 5 || form == 7) ? 2 : 1;
+    if (ring) {
+      int nl = 4, slots = 1;
+      if (const char *ev = getenv("SPL_PANEL_RING_NL")) nl = atoi(ev);
+      if (const char *ev = getenv("SPL_PANEL_RING_SLOTS")) slots = atoi(ev);
+      if (nl < 1 || slots < 1 || panel_ring_lds_bytes(rows_per_panel, nl, slots) > 160 * 1024) return SPL_ERROR_argument_missing;
+    }
     build_panel_image(m, rows_per_panel, cols_log2, pair ? 1 : 0, nullptr);
     PanelImage *b = m->panel;
     b->kblocks = kblocks;
+    if (ring) {
+      b->ring = 1;
+      b->ring_depth = unroll > 0 ? unroll : 6;
+      if (const char *ev = getenv("SPL_PANEL_RING_NL")) b->ring_nl = atoi(ev);
+      if (const char *ev = getenv("SPL_PANEL_RING_SLOTS")) b->ring_slots = atoi(ev);
+      if (const char *ev = getenv("SPL_PANEL_RING_GD")) b->ring_gather = atoi(ev);
+      b->unroll = 0;
+      b->ablate = 0;
+      return SPL_OK;
+    }
     if (unroll == 0) {
       // units (chunks or pairs) per wavefront and phase: the 16 wavefronts share a phase's units evenly and a
       // phase's length varies by a unit or two.  More loads in flight than the mean needs cost time (the
@@ -676,6 +695,14 @@ int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unrol
     }
     return SPL_OK;
   });
+}
+
+int spl_matrix_panel_errors(void *H) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  int out = 0;
+  int st = guarded([&]() -> int { DeviceGuard g(m->device); out = panel_ring_errors(m, nullptr); return SPL_OK; });
+  return st != SPL_OK ? st : out;
 }
 
 int spl_matrix_set_spmv_order(void *H, int order) {

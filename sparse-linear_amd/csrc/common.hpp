@@ -106,6 +106,8 @@ struct PanelImage {
   int kblocks = 2;                // index blocks per phase (barrier to barrier)
   int pair = 0;                   // 1: paired storage (chunk pairs interleaved, 8-byte key / 16-byte value loads)
   int ablate = 0;                 // timing-only ablation bits (SPL_PANEL_ABLATE with SPL_ALLOW_ABLATION=1)
+  int ring = 0;                   // 1: ring form (loader wavefronts hand units to gather wavefronts through LDS slots)
+  int ring_nl = 4, ring_depth = 6, ring_gather = 4, ring_slots = 1;  // loaders, units in flight per loader / per gatherer, slots per loader
 };
 
 // sliced-ELL image of a row block (spmv_sell.hip)
@@ -272,6 +274,8 @@ int launch_spmv_blocked(const Matrix *m, const double *d_x, double *d_y, int acc
                         hipStream_t s);
 void build_panel_image(Matrix *m, int rows_per_panel, int w, int pair, hipStream_t s);
 int launch_spmv_panel(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s);
+size_t panel_ring_lds_bytes(int P, int nl, int slots);
+int panel_ring_errors(const Matrix *m, hipStream_t s);
 // choose the blocked image's shape for this matrix (0,0 = blocking would not help)
 void choose_blocking(const Matrix *m, int *rows_per_panel, int *w, int *waves);
 void choose_panels(const Matrix *m, int *rows_per_panel, int *w);

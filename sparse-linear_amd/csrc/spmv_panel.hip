@@ -34,6 +34,7 @@
 // gather from together), wavefront i takes chunks i, i+16, ... of the phase, keeps U of them in
 // registers, and the stream of the next phase is requested before the barrier that ends this one.
 #include "common.hpp"
+#include <atomic>
 
 namespace spl {
 
@@ -423,6 +424,210 @@ __global__ __launch_bounds__(kPanelWaves * 64) void spmv_panelw_kernel(
   }
 }
 
+
+// ---- ring form (round 3): loader wavefronts + gather wavefronts ---------------------------------------
+// What the probes say (tools/probe/lds_dma_mix_probe.hip, profiles/r03_tcp_mix_lds_dma.txt): when every
+// wavefront carries both the HBM stream and the L2 gathers, the two times ADD (vmcnt retires in order, so a
+// wavefront's gathers wait behind its own stream loads, and the stream arrives in bursts of a whole phase);
+// when a few wavefronts do nothing but keep ~32 KiB of 16-byte stream loads in flight and the others do
+// nothing but gather, the mix takes 0.82x the sum.  LDS-DMA for the stream does not help (it adds up like
+// the register loads do, and more).  So: NL loader wavefronts stream the paired image into registers (D
+// units of 1.5 KiB each in flight per loader) and hand every unit through a 1.5 KiB slot in LDS to one of
+// its R = (16 - NL) / NL gather wavefronts, which keeps GD units (2 GD gather instructions) in flight and
+// folds with ds_add_f64 as before.  The panel keeps (almost) the whole LDS: the hand-over slots are NL * S
+// units (6 KiB for NL = 4, S = 1).
+//   slot header {seq, ib}: seq = t + 1 while the loader's t-th unit waits in the slot, 0 = free.  LDS
+//   operations of one wavefront execute in program order, so data written before the header is visible
+//   to whoever sees the header, and a header cleared after the reads have returned frees the slot.
+//   Phase barriers (pacing only, as in the other forms): a gather wavefront crosses barrier p before it
+//   gathers its first unit beyond phase p (it has taken that unit out of its slot by then); a loader
+//   crosses it once each of its gather wavefronts has been handed a unit beyond phase p (its last R
+//   deliveries are all beyond p), or at the end of the stream.  Nobody waits at a barrier for something
+//   that only a wavefront behind that barrier can provide.  Every wait is bounded (spin limit -> error
+//   word, results then wrong but the grid drains).
+constexpr int kRingUnitBytes = 1536;
+constexpr unsigned kRingSpinLimit = 1u << 22;
+
+// a wave-uniform int through the scalar cache: a vector load here would sit on vmcnt behind the loader's stream
+__device__ inline int ring_sload(const int *p) {
+  int v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+
+// the loader's stream loads, outside the compiler's wait bookkeeping (it drains vmcnt to 0 at every loop
+// header): issued here, awaited with a counted vmcnt by ring_stream_wait
+__device__ inline void ring_stream_issue(pnl_u2 &k, pnl_d2 &v, const pnl_u2 *kp, const pnl_d2 *vp) {
+  asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(k) : "v"(kp) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(vp) : "memory");
+}
+template <int N>
+__device__ inline void ring_stream_wait(pnl_u2 &k, pnl_d2 &v) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(k), "+v"(v) : "n"(N) : "memory");
+}
+
+__device__ inline void ring_fail(unsigned *err) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int NL, int D, int GD, int K, int S>
+__global__ __launch_bounds__(kPanelWaves * 64) void spmv_panelr_kernel(
+    int64_t nrows, int64_t npanels, int P, int w, int64_t nib, const int *__restrict__ segc,
+    const unsigned *__restrict__ key, const double *__restrict__ val, const double *__restrict__ x,
+    double *__restrict__ y, int accumulate, unsigned *__restrict__ arrive, int64_t dummy) {
+  extern __shared__ __attribute__((aligned(16))) double ylds[];  // P + 1 doubles, then the slots, then their headers
+  constexpr int R = (kPanelWaves - NL) / NL;
+  static_assert(NL * (R + 1) == kPanelWaves, "NL must divide 16");
+  const pnl_u2 *key2 = reinterpret_cast<const pnl_u2 *>(key);
+  const pnl_d2 *val2 = reinterpret_cast<const pnl_d2 *>(val);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // explicit LDS pointers: a generic pointer would turn every access into a flat_ instruction (vmcnt + lgkmcnt)
+  typedef __attribute__((address_space(3))) char lds_char;
+  typedef __attribute__((address_space(3))) pnl_u2 lds_u2;
+  typedef __attribute__((address_space(3))) pnl_d2 lds_d2;
+  lds_char *ring = (lds_char *)ylds + ((((size_t)P + 1) * sizeof(double) + 15) & ~(size_t)15);
+  volatile lds_u2 *hdr = (volatile lds_u2 *)(ring + NL * S * kRingUnitBytes);
+  const int64_t nb = gridDim.x;
+  const int64_t ngen = (npanels + nb - 1) / nb;
+  const int nph = (int)((nib + K - 1) / K);
+  for (int64_t g = 0; g < ngen; ++g) {
+    const int64_t p = g * nb + blockIdx.x;
+    if (p >= npanels) break;
+    const int64_t row_base = p * P;
+    const int *sp = segc + p * nib;  // in chunks; every boundary is even (whole pairs)
+    const int c0 = sp[0] >> 1;
+    const int nu = (sp[nib] >> 1) - c0;  // units (pairs of chunks) of this panel
+    for (int i = threadIdx.x; i <= P; i += kPanelWaves * 64)
+      ylds[i] = (accumulate && i < P && row_base + i < nrows) ? y[row_base + i] : 0.0;
+    if (threadIdx.x < NL * S) { pnl_u2 z = {0u, 0u}; hdr[threadIdx.x] = z; }
+    __syncthreads();
+    int bar_done = 0;
+    if (wave < NL) {
+      // ---- loader ----
+      const int L = wave;
+      const int nt = nu > L ? (nu - L + NL - 1) / NL : 0;
+      pnl_u2 kr[D];
+      pnl_d2 vr[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int m = L + NL * d;
+        const int64_t e = (m < nu ? ((int64_t)(c0 + m) << 6) : dummy) + lane;
+        ring_stream_issue(kr[d], vr[d], key2 + e, val2 + e);
+      }
+      int ibc = 0;
+      int hist[R];  // phases of the last R units handed over, oldest first
+#pragma unroll
+      for (int r = 0; r < R; ++r) hist[r] = 0;
+      for (int t0 = 0; t0 < nt; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const int t = t0 + d;
+          if (t >= nt) break;  // wave-uniform
+          const int c = c0 + L + NL * t;
+          while (ibc + 1 < (int)nib && c >= (ring_sload(sp + ibc + 1) >> 1)) ++ibc;
+          const int sl = L * S + (S > 1 ? t % S : 0);
+          unsigned spins = 0;
+          while (__builtin_amdgcn_readfirstlane(hdr[sl].x) != 0u) {  // the slot still holds an earlier unit
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kRingSpinLimit) { ring_fail(arrive + 1); break; }
+          }
+          lds_char *slot = ring + sl * kRingUnitBytes;
+          ring_stream_wait<2 * (D - 1)>(kr[d], vr[d]);  // D - 1 younger units stay in flight
+          ((lds_u2 *)slot)[lane] = kr[d];
+          ((lds_d2 *)(slot + 512))[lane] = vr[d];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == 0) { pnl_u2 h = {(unsigned)(t + 1), (unsigned)ibc}; hdr[sl] = h; }
+          {  // refill this register set: the unit D places further down this loader's sequence
+            const int m = L + NL * (t + D);
+            const int64_t e = (m < nu ? ((int64_t)(c0 + m) << 6) : dummy) + lane;
+            ring_stream_issue(kr[d], vr[d], key2 + e, val2 + e);
+          }
+#pragma unroll
+          for (int r = 0; r + 1 < R; ++r) hist[r] = hist[r + 1];
+          hist[R - 1] = ibc / K;
+          while (bar_done < hist[0]) { __builtin_amdgcn_s_barrier(); ++bar_done; }
+        }
+      }
+    } else {
+      // ---- gather wavefront ----
+      const int j = wave - NL;
+      const int L = j % NL, q = j / NL;
+      const int nt = nu > L ? (nu - L + NL - 1) / NL : 0;  // units of my loader; mine are q, q + R, ...
+      pnl_u2 id[GD];
+      pnl_d2 a[GD];
+      double xa[GD], xb[GD];
+      bool first = true;
+      int t = q;
+      int live = 0;  // units issued and not yet folded at loop exit
+      while (t < nt) {
+        live = 0;
+#pragma unroll
+        for (int u = 0; u < GD; ++u) {
+          if (t >= nt) break;  // wave-uniform
+          if (!first) {
+            pnl_gather_wait<2 * (GD - 1) + 1>(xa[u]);
+            pnl_gather_wait<2 * (GD - 1)>(xb[u]);
+            pnl_fold(id[u].x, a[u].x * xa[u], ylds);
+            pnl_fold(id[u].y, a[u].y * xb[u], ylds);
+          }
+          const int sl = L * S + (S > 1 ? t % S : 0);
+          unsigned spins = 0;
+          pnl_u2 h;
+          for (;;) {
+            h = hdr[sl];
+            if (__builtin_amdgcn_readfirstlane(h.x) == (unsigned)(t + 1)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kRingSpinLimit) { ring_fail(arrive + 1); break; }
+          }
+          const int ib = __builtin_amdgcn_readfirstlane(h.y);
+          const lds_char *slot = ring + sl * kRingUnitBytes;
+          id[u] = ((const lds_u2 *)slot)[lane];
+          a[u] = ((const lds_d2 *)(slot + 512))[lane];
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(id[u]), "+v"(a[u]) : : "memory");
+          if (lane == 0) { pnl_u2 z = {0u, 0u}; hdr[sl] = z; }
+          const int ph = ib / K;
+          while (bar_done < ph) { __builtin_amdgcn_s_barrier(); ++bar_done; }
+          const double *xw = x + ((int64_t)ib << w);
+          xa[u] = pnl_gather_issue(xw + (id[u].x >> kRowBits));
+          xb[u] = pnl_gather_issue(xw + (id[u].y >> kRowBits));
+          t += R;
+          ++live;
+        }
+        if (live == GD) first = false;
+        else break;
+      }
+      // drain: everything still in flight (the last full round's units that were not re-used + the partial round)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < GD; ++u) {
+        const bool pending = first ? (u < live) : true;  // after a full round every set holds an unfolded unit
+        if (pending) {
+          pnl_gather_wait<0>(xa[u]);
+          pnl_gather_wait<0>(xb[u]);
+          pnl_fold(id[u].x, a[u].x * xa[u], ylds);
+          pnl_fold(id[u].y, a[u].y * xb[u], ylds);
+        }
+      }
+    }
+    while (bar_done < nph) { __builtin_amdgcn_s_barrier(); ++bar_done; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += kPanelWaves * 64)
+      if (row_base + i < nrows) y[row_base + i] = ylds[i];
+    if (g + 1 < ngen) {
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (unsigned)((g + 1) * nb);
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          if (wall_clock64() - t0 > 20000ull) break;
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace
 
 void build_panel_image(Matrix *m, int P, int w, int pair, hipStream_t s) {
@@ -465,7 +670,7 @@ void build_panel_image(Matrix *m, int P, int w, int pair, hipStream_t s) {
   // padding: column 0 of the block, the dummy row P, value 0
   SPL_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->key.get()), P, entries, s));
   SPL_HIP(hipMemsetAsync(b->val.get(), 0, entries * sizeof(double), s));
-  b->arrive.alloc(1);
+  b->arrive.alloc(2);  // [0] generation rendezvous, [1] ring form: a bounded wait gave up
   SPL_HIP(hipMemsetAsync(counts.get(), 0, ((size_t)nseg + 1) * sizeof(int), s));
   if (m->nrows_local > 0) {
     if (m->rowptr.get())
@@ -493,11 +698,11 @@ void build_panel_image(Matrix *m, int P, int w, int pair, hipStream_t s) {
 template <int U, int K, int ABL = 0>
 static void launch_panel_as(const Matrix *m, const PanelImage *b, unsigned nb, size_t lds, const double *d_x,
                             double *d_y, int accumulate, hipStream_t s) {
-  static bool set_ = false;
-  if (!set_) {
+  static std::atomic<uint64_t> set_{0};  // bit d: attribute set on device d (it is per device)
+  if (!(set_.load(std::memory_order_acquire) >> (m->device & 63) & 1u)) {
     SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_panel_kernel<U, K, ABL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    set_ = true;
+    set_.fetch_or(1ull << (m->device & 63), std::memory_order_release);
   }
   hipLaunchKernelGGL((spmv_panel_kernel<U, K, ABL>), dim3(nb), dim3(kPanelWaves * 64), lds, s, m->nrows_local,
                      b->npanels, b->P, b->w, b->nib, b->segc.get(), b->key.get(), b->val.get(), d_x, d_y,
@@ -507,15 +712,63 @@ static void launch_panel_as(const Matrix *m, const PanelImage *b, unsigned nb, s
 template <int U, int K>
 static void launch_panelw_as(const Matrix *m, const PanelImage *b, unsigned nb, size_t lds, const double *d_x,
                              double *d_y, int accumulate, hipStream_t s) {
-  static bool set_ = false;
-  if (!set_) {
+  static std::atomic<uint64_t> set_{0};
+  if (!(set_.load(std::memory_order_acquire) >> (m->device & 63) & 1u)) {
     SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_panelw_kernel<U, K>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    set_ = true;
+    set_.fetch_or(1ull << (m->device & 63), std::memory_order_release);
   }
   hipLaunchKernelGGL((spmv_panelw_kernel<U, K>), dim3(nb), dim3(kPanelWaves * 64), lds, s, m->nrows_local, b->npanels,
                      b->P, b->w, b->nib, b->segc.get(), b->key.get(), b->val.get(), d_x, d_y, accumulate,
                      b->arrive.get(), (int64_t)(b->nchunks / 2) << 6);
+}
+
+
+size_t panel_ring_lds_bytes(int P, int nl, int slots) {
+  return ((((size_t)P + 1) * sizeof(double) + 15) & ~(size_t)15) + (size_t)nl * slots * (kRingUnitBytes + 8);
+}
+
+template <int NL, int D, int GD, int K, int S>
+static void launch_panelr_as(const Matrix *m, const PanelImage *b, unsigned nb, const double *d_x, double *d_y,
+                             int accumulate, hipStream_t s) {
+  static std::atomic<uint64_t> set_{0};
+  if (!(set_.load(std::memory_order_acquire) >> (m->device & 63) & 1u)) {
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_panelr_kernel<NL, D, GD, K, S>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    set_.fetch_or(1ull << (m->device & 63), std::memory_order_release);
+  }
+  hipLaunchKernelGGL((spmv_panelr_kernel<NL, D, GD, K, S>), dim3(nb), dim3(kPanelWaves * 64),
+                     panel_ring_lds_bytes(b->P, NL, S), s, m->nrows_local, b->npanels, b->P, b->w, b->nib, b->segc.get(),
+                     b->key.get(), b->val.get(), d_x, d_y, accumulate, b->arrive.get(), (int64_t)(b->nchunks / 2) << 6);
+}
+
+static int launch_panel_ring(const Matrix *m, const PanelImage *b, unsigned nb, const double *d_x, double *d_y,
+                             int accumulate, hipStream_t s) {
+  if (!b->pair) return SPL_ERROR_internal;
+  const int nl = b->ring_nl, S = b->ring_slots, D = b->ring_depth, GD = b->ring_gather, K = b->kblocks;
+  if (panel_ring_lds_bytes(b->P, nl, S) > 160 * 1024) return SPL_ERROR_argument_missing;
+  SPL_HIP(hipMemsetAsync(b->arrive.get() + 1, 0, sizeof(unsigned), s));
+#define SPL_RING(NLv, Dv, GDv, Kv, Sv) \
+  if (nl == NLv && D == Dv && GD == GDv && K == Kv && S == Sv) { launch_panelr_as<NLv, Dv, GDv, Kv, Sv>(m, b, nb, d_x, d_y, accumulate, s); launched = true; }
+  bool launched = false;
+  // only shapes that compile without scratch: a spilled register with a gather still in flight would be stale
+  SPL_RING(4, 4, 4, 2, 1) SPL_RING(4, 6, 4, 2, 1) SPL_RING(4, 8, 4, 2, 1) SPL_RING(4, 6, 3, 2, 1)
+  SPL_RING(4, 6, 4, 1, 1) SPL_RING(4, 6, 4, 2, 3) SPL_RING(4, 4, 3, 2, 1) SPL_RING(4, 5, 4, 2, 1)
+  SPL_RING(2, 8, 2, 2, 1) SPL_RING(8, 3, 4, 2, 1) SPL_RING(8, 4, 4, 2, 1)
+#undef SPL_RING
+  if (!launched) return SPL_ERROR_argument_missing;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_last_error("spmv_panelr launch", e); return SPL_ERROR_device; }
+  return SPL_OK;
+}
+
+int panel_ring_errors(const Matrix *m, hipStream_t s) {
+  const PanelImage *b = m->panel;
+  if (!b || !b->arrive.get()) return 0;
+  unsigned e = 0;
+  SPL_HIP(hipMemcpyAsync(&e, b->arrive.get() + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  SPL_HIP(hipStreamSynchronize(s));
+  return (int)e;
 }
 
 int launch_spmv_panel(const Matrix *m, const double *d_x, double *d_y, int accumulate, hipStream_t s) {
@@ -533,6 +786,7 @@ int launch_spmv_panel(const Matrix *m, const double *d_x, double *d_y, int accum
   int64_t nb = cus;
   if (nb > b->npanels) nb = b->npanels;
   SPL_HIP(hipMemsetAsync(b->arrive.get(), 0, sizeof(unsigned), s));
+  if (b->ring) return launch_panel_ring(m, b, (unsigned)nb, d_x, d_y, accumulate, s);
   const int U = b->unroll, K = b->kblocks;
   if (b->ablate) {  // timing-only (wrong results): the two-stage kernel, 12 chunks, 2 blocks per phase
     switch (b->ablate) {

@@ -263,6 +263,13 @@ class DeviceMatrix(object):
         check("spl_matrix_build_panel",
               lib().spl_matrix_build_panel(self.handle, rows_per_panel, cols_log2, unroll, form))
 
+    def panel_errors(self):
+        """1 when a bounded wait of the ring form gave up during the last panel SpMV (diagnostics)"""
+        r = lib().spl_matrix_panel_errors(self.handle)
+        if r < 0:
+            check("spl_matrix_panel_errors", r)
+        return r
+
     def set_spmv_order(self, order):
         """ORDER_REFERENCE (0, default): sums in the reference's order, bit-identical; ORDER_FREE (1):
         any order, rounding-level differences (include/sparse_linear_hip.h)"""

@@ -27,7 +27,11 @@ def _run(torch, H, x):
     (50_003, 20, 3000, 12, 2, 4), (300_000, 20, 19000, 13, 4, 5), (131_072, 7, 8192, 17, 3, 4),
     (200_000, 20, 20479, 14, 6, 5), (1000, 3, 64, 4, 2, 4), (200_000, 20, 20479, 14, 0, 0),
     # phases far longer than the register pipeline: the un-pipelined tail loop
-    (70_001, 40, 5000, 13, 3, 5), (70_001, 40, 5000, 13, 4, 1)])
+    (70_001, 40, 5000, 13, 3, 5), (70_001, 40, 5000, 13, 4, 1),
+    # form 6 / 7: ring form (loader wavefronts hand units to gather wavefronts), 1 / 2 index blocks per phase;
+    # unroll counts the units a loader keeps in flight
+    (50_003, 20, 3000, 12, 6, 6), (300_000, 20, 19000, 13, 6, 7), (131_072, 7, 8192, 17, 4, 7), (1000, 3, 64, 4, 6, 6),
+    (70_001, 40, 5000, 13, 8, 7), (200_000, 20, 19700, 14, 0, 7), (64, 1, 64, 4, 5, 7), (5_000_000, 3, 19700, 17, 6, 7)])
 def test_panel_matches_oracle(gpu, pkg, O, n, K, P, w, unroll, form):
     torch = gpu
     H = pkg.DeviceMatrix.synthetic("random", n, K)
@@ -52,6 +56,7 @@ def test_panel_matches_oracle(gpu, pkg, O, n, K, P, w, unroll, form):
     ya = y0.copy()
     O.csr_gaxpy32(rp.astype(np.int32), ci, v, xh, ya)
     assert O.count_not_close(yd.cpu().numpy(), ya, 1e-10) == 0
+    assert H.panel_errors() == 0
 
 
 def test_panel_exact_on_integers(gpu, pkg, O):
