@@ -18,8 +18,15 @@ at N > 1).  Inputs are generated in HBM by counter-based generators
               Sparse.hs:433-471) on the same matrix, 1 core; its result is also
               compared element-wise with the GPU's y (1e-10 relative).
 
-Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under
-python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  secondary (N = 1 only, after the timed region; --no-secondary skips it) = the other configurations of
+              BASELINE.json the driver's one line can carry: the banded variant of C2, C4 (SpGEMM A*A, R-MAT
+              scale 20) and the C5 ladder (sparse LU + solves, 100^3 and, memory permitting, 200^3), each with
+              its own roofline and parity fields (tools/bench_secondary.py).
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 either under
+python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ... (one rank per GPU), or plainly as
+python bench.py --gpus N: without WORLD_SIZE in the environment the script starts that launcher itself, as a
+child process and before anything touches a GPU, and exits with its status.
 """
 import argparse
 import json
@@ -53,7 +60,24 @@ def main():
     ap.add_argument("--panel", default="", help="force the column-sorted panel image: rows_per_panel,cols_log2[,unroll[,form]]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the banded / C4 / C5 block after the timed region")
+    ap.add_argument("--secondary", default="banded,c4,c5:100,c5:200",
+                    help="which secondary configurations to run (comma separated: banded, c4, c5:<m>)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start one rank per GPU ourselves.  A fresh child process runs the
+        # launcher; this parent has not imported torch or touched a GPU, and only passes the child's status on.
+        import socket
+        import subprocess
+        port = os.environ.get("MASTER_PORT")
+        if not port:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = str(sk.getsockname()[1])
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
 
     import numpy as np
     import torch
@@ -64,11 +88,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
-        if world > 1:
-            sys.exit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+        sys.exit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # SPL_BENCH_REHEARSAL=1 (tests only): every rank on cuda:0 and the gloo backend, so that the whole
@@ -267,6 +287,11 @@ def main():
     if N > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
+    # one-sided exchange: a bounded wait that gave up during the warm-up or the timed steps leaves an incomplete y
+    # behind; its flag is sticky, and a line measured on such a run is not a result
+    exchange_failed = 0.0
+    if N > 1:
+        exchange_failed = agree(1.0 if (hasattr(op, "failed") and op.failed()) else 0.0, dist.ReduceOp.MAX)
     ms_per_step = 1e3 * elapsed / args.steps
     value = B_total / (elapsed / args.steps) / 1e9
 
@@ -378,8 +403,48 @@ def main():
                                       "cores": O.omp_threads(), "bit_identical_to_reference_order": bool(np.array_equal(yo, y_cpu)),
                                       "note": "not the reference: OpenMP CSR gather, int32, NUMA first-touch placement, best of 5"}
 
+    if exchange_failed:
+        out["invalid"] = "the one-sided exchange of y timed out on at least one rank: y is incomplete, the figures mean nothing"
+
+    # ---- the other configurations of BASELINE.json (N = 1): banded C2, C4 SpGEMM, C5 LU ladder
+    if N == 1 and rank == 0 and not args.no_secondary and args.secondary:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_secondary as sec
+        for h in handles:
+            h.free()
+        del x, op, y_local, y_full, y_pieces
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        ffi.release_cached_memory()
+        secondary = {}
+        for item in args.secondary.split(","):
+            t_item = time.perf_counter()
+            try:
+                if item == "banded":
+                    secondary["c2_banded_spmv"] = sec.banded_c2(pkg, torch, n=n, draws=args.draws, steps=args.steps)
+                elif item == "c4":
+                    secondary["c4_spgemm_rmat20"] = sec.spgemm_c4(pkg, torch)
+                elif item.startswith("c5:"):
+                    m = int(item[3:])
+                    torch.cuda.empty_cache()
+                    free, _tot = torch.cuda.mem_get_info()
+                    need = 262e9 * (m / 200.0) ** 4  # panels + transient fronts grow like m^4
+                    if free + 0 < need:
+                        secondary["c5_lu_poisson3d_%d" % m] = {"skipped": "needs %.0f GB of free HBM, %.0f GB are free" % (need / 1e9, free / 1e9)}
+                    else:
+                        secondary["c5_lu_poisson3d_%d" % m] = sec.lu_c5(pkg, torch, m)
+            except Exception as e:  # a secondary configuration must never cost the headline line
+                secondary[item] = {"error": "%s: %s" % (type(e).__name__, e)}
+            for v in secondary.values():
+                if isinstance(v, dict) and "wall_s" not in v:
+                    v["wall_s"] = round(time.perf_counter() - t_item, 2)
+        out["secondary"] = secondary
+
     if rank == 0:
         print(json.dumps(out))
+    if exchange_failed:
+        sys.exit(3)
     if N > 1:
         if hasattr(op, "close"):
             barrier()

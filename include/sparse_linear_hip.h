@@ -195,6 +195,12 @@ int spl_matrix_info(void *H, int64_t info[8]);
 /* copy the device CSR image back: rowptr[nrows_local+1] (relative to the block,
  * rowptr[0]=0), colidx[nnz_local], val[nnz_local] */
 int spl_matrix_export_csr(void *H, int64_t *rowptr, int *colidx, double *val);
+/* the same for rows [row0, row1) of the block only (a window of a result too large to copy whole):
+ * rowptr[row1-row0+1] keeps the block's offsets (rowptr[0] = first entry of row0, not 0); colidx / val
+ * receive the rowptr[row1-row0] - rowptr[0] entries of those rows and must hold `capacity` entries
+ * (SPL_ERROR_argument_missing if they do not: call once with capacity 0 to learn the count from rowptr) */
+int spl_matrix_export_csr_rows(void *H, int64_t row0, int64_t row1, int64_t *rowptr, int64_t capacity, int *colidx,
+                               double *val);
 /* transpose the block on the device (Sparse.hs:301-329) and copy out its
  * column-major image: colptr[ncols+1], rowidx[nnz_local] (LOCAL row ids, ascending
  * inside a column), val[nnz_local] — i.e. the reference's own CSC Matrix fields */

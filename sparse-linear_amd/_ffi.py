@@ -107,6 +107,7 @@ def _declare(L):
         "spl_matrix_info": [C.c_void_p, c_i64_p],
         "spl_matrix_export_csr": [C.c_void_p, c_i64_p, c_int_p, c_dbl_p],
         "spl_matrix_export_csc": [C.c_void_p, c_i64_p, c_int_p, c_dbl_p],
+        "spl_matrix_export_csr_rows": [C.c_void_p, i64, i64, c_i64_p, i64, c_int_p, c_dbl_p],
         "spl_matrix_mulv": [C.c_void_p, i, c_dbl_p, c_dbl_p],
         "spl_matrix_gaxpy": [C.c_void_p, i, c_dbl_p, i, c_dbl_p],
         "spl_matrix_spmv_dev": [C.c_void_p, C.c_void_p, C.c_void_p, i, C.c_void_p],

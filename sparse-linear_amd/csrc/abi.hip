@@ -467,6 +467,26 @@ int spl_matrix_export_csr(void *H, int64_t *rowptr, int *colidx, double *val) {
   });
 }
 
+int spl_matrix_export_csr_rows(void *H, int64_t row0, int64_t row1, int64_t *rowptr, int64_t capacity, int *colidx,
+                               double *val) {
+  Matrix *m = as_matrix(H);
+  if (!m) return SPL_ERROR_invalid_handle;
+  if (m->vw != 1) return SPL_ERROR_argument_missing;
+  if (!rowptr || row0 < 0 || row1 < row0 || row1 > m->nrows_local || capacity < 0) return SPL_ERROR_argument_missing;
+  return guarded([&]() -> int {
+    DeviceGuard g(m->device);
+    SPL_HIP(hipMemcpy(rowptr, m->rowptr64.get() + row0, ((size_t)(row1 - row0) + 1) * sizeof(int64_t),
+                      hipMemcpyDeviceToHost));
+    const int64_t a = rowptr[0], b = rowptr[row1 - row0];
+    if (b - a > capacity || (b > a && (!colidx || !val))) return SPL_ERROR_argument_missing;
+    if (b > a) {
+      SPL_HIP(hipMemcpy(colidx, m->colidx.get() + a, (size_t)(b - a) * sizeof(int), hipMemcpyDeviceToHost));
+      SPL_HIP(hipMemcpy(val, m->val.get() + a, (size_t)(b - a) * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return SPL_OK;
+  });
+}
+
 int spl_matrix_export_csc(void *H, int64_t *colptr, int *rowidx, double *val) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;

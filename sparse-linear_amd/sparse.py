@@ -231,6 +231,20 @@ class DeviceMatrix(object):
         check("spl_matrix_export_csr", lib().spl_matrix_export_csr(self.handle, _ffi.p_i64(rp), p_i32(ci), p_f64(v)))
         return rp, ci[:inf["nnz"]], v[:inf["nnz"]]
 
+    def export_csr_rows(self, row0, row1):
+        """rows [row0, row1) of the device CSR image: (rowptr relative to the window, colidx, val)"""
+        rp = np.zeros(row1 - row0 + 1, dtype=I64)
+        st = lib().spl_matrix_export_csr_rows(self.handle, row0, row1, _ffi.p_i64(rp), 0, None, None)
+        cnt = int(rp[-1] - rp[0])
+        if cnt == 0:
+            check("spl_matrix_export_csr_rows", st)
+            return rp - rp[0], np.zeros(0, dtype=np.int32), np.zeros(0, dtype=F64)
+        ci = np.zeros(cnt, dtype=np.int32)
+        v = np.zeros(cnt, dtype=F64)
+        check("spl_matrix_export_csr_rows",
+              lib().spl_matrix_export_csr_rows(self.handle, row0, row1, _ffi.p_i64(rp), cnt, p_i32(ci), p_f64(v)))
+        return rp - rp[0], ci, v
+
     def export_csc(self):
         """the block as the reference's CSC fields (device transpose, Sparse.hs:301-329)"""
         inf = self.info()

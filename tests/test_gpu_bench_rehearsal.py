@@ -22,18 +22,20 @@ def _free_port():
     return p
 
 
-def _run(nproc, extra, chunks=None, exchange=None):
+def _run(nproc, extra, chunks=None, exchange=None, plain=False):
     env = dict(os.environ, SPL_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if chunks is not None:
         env["SPL_BENCH_CHUNKS"] = str(chunks)
     if exchange is not None:
         env["SPL_BENCH_EXCHANGE"] = exchange
-    if nproc == 1:
+    if nproc == 1 or plain:  # plain: bench.py starts the launcher itself (no WORLD_SIZE in the environment)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")]
-    cmd += ["--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    cmd += ["--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"]
     if "--order" not in extra:
         cmd += ["--order", "reference"]  # bit-identical sums: the SHA-1 of y must not depend on the rank count
     cmd += extra
@@ -100,3 +102,22 @@ def test_peer_store_exchange_forced(gpu, nproc, chunks):
         assert out["roofline"]["launches_per_step"] == chunks
     assert out["y_sha1"] == one["y_sha1"]
     assert out["config"]["algorithmic_bytes"] == one["config"]["algorithmic_bytes"]
+
+
+def test_plain_launch_starts_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` without torchrun (the shape of the driver's 1-GPU command): the script starts
+    the launcher as a child before touching a GPU and hands its status on; same y as one rank"""
+    args = ["--rows", "400000"]
+    one = _run(1, args)
+    two = _run(2, args, plain=True)
+    assert two["n_gpus"] == 2 and two["y_sha1"] == one["y_sha1"]
+
+
+def test_six_ranks_all_schedules(gpu):
+    """the widest rehearsal a one-GPU box admits (6 processes on the card): 5 IPC peers and 5 copy streams per
+    rank, 6-way all-gather, all six schedules measured and each equal to the single-rank y"""
+    args = ["--rows", "480000"]
+    one = _run(1, args)
+    six = _run(6, args)
+    assert six["n_gpus"] == 6 and six["y_sha1"] == one["y_sha1"]
+    assert set(six["config"]["exchange_ms_per_step_by_chunks"]) == {"rccl1", "rccl2", "rccl4", "peer1", "peer2", "peer4"}
