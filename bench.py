@@ -212,6 +212,11 @@ def main():
                     spmvs = [dist_mod.hip_local_spmv(h, lambda: stream.cuda_stream) for h in hs]
                     if kind == "peer":
                         cand = dist_mod.PeerStoreRowBlockSpMV(n, rank, N, C, spmvs, "cuda", lambda: stream.cuda_stream)
+                        if not cand.flags_finegrained() and want != "peer":
+                            # flags a kernel polls while a peer's copy engine writes them belong in fine-grained
+                            # memory; without it the one-sided exchange only runs when asked for by name
+                            cand.close()
+                            raise RuntimeError("no fine-grained device memory for the step flags")
                     elif C == 1:
                         cand = op
                     else:
@@ -273,25 +278,47 @@ def main():
     B_local = sum(spmv_bytes(h.info()["nnz"], b - a, n) for h, (a, b) in zip(handles, pieces))
 
     # ---- timed region: W warm-ups, then exactly K steps between barrier+sync pairs
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
-    if N > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+    def timed_region():
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        el = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+        if N > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item())
+
+    elapsed = timed_region()
     # one-sided exchange: a bounded wait that gave up during the warm-up or the timed steps leaves an incomplete y
-    # behind; its flag is sticky, and a line measured on such a run is not a result
+    # behind (its flag is sticky).  Such a run is not a result: every rank goes back to the plain step — the whole
+    # row block, one RCCL all-gather — and the region is timed again.
     exchange_failed = 0.0
     if N > 1:
         exchange_failed = agree(1.0 if (hasattr(op, "failed") and op.failed()) else 0.0, dist.ReduceOp.MAX)
+        if exchange_failed:
+            if rank == 0:
+                sys.stderr.write("the one-sided exchange timed out during the timed region: falling back to the RCCL all-gather\n")
+            barrier()
+            op.close()
+            if handles[0] is not H0:
+                for h in handles:
+                    h.free()
+            handles, pieces = [H0], [(r0, r1)]
+            kernels = [dist_mod.hip_local_spmv(H0, lambda: stream.cuda_stream)]
+            op = dist_mod.RowBlockSpMV(n, dist_mod.equal_row_bounds(n, N), rank, N, kernels[0], "cuda")
+            y_pieces = [op.y_local]
+            exchange = "one RCCL all-gather of y after the kernel (fallback: the one-sided exchange timed out)"
+            nnz_local = H0.info()["nnz"]
+            B_local = spmv_bytes(nnz_local, r1 - r0, n)
+            info = H0.info()
+            elapsed = timed_region()
+            exchange_failed = 0.0
     ms_per_step = 1e3 * elapsed / args.steps
     value = B_total / (elapsed / args.steps) / 1e9
 

@@ -301,6 +301,9 @@ int spl_peer_exchange_connect(void *X, const unsigned char *all_handles);
 int spl_peer_exchange_push(void *X, int chunk, const double *d_piece, void *stream);
 int spl_peer_exchange_finish(void *X, void *stream, double **y_full);
 int spl_peer_exchange_failed(void *X);
+/* 1 when the step flags live in fine-grained device memory (polled by a kernel while a peer's copy engine
+ * writes them: csrc/peer.hip), 0 when the runtime refused it and plain device memory is used */
+int spl_peer_exchange_flags_finegrained(void *X);
 void spl_peer_exchange_free(void **X);
 
 /* fill a device vector with the synthetic entries j in [j0,j1) */

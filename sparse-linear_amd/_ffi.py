@@ -127,6 +127,7 @@ def _declare(L):
         "spl_peer_exchange_push": [C.c_void_p, i, C.c_void_p, C.c_void_p],
         "spl_peer_exchange_finish": [C.c_void_p, C.c_void_p, c_void_pp],
         "spl_peer_exchange_failed": [C.c_void_p],
+        "spl_peer_exchange_flags_finegrained": [C.c_void_p],
     }
     for name, args in sigs.items():
         fn = getattr(L, name, None)

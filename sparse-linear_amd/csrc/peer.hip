@@ -12,6 +12,16 @@
 // (hipIpcGetMemHandle / hipIpcOpenMemHandle), exchanged by the caller over its own channel
 // (torch.distributed in bench.py).
 //
+// Visibility: the flag words are polled by a kernel while a peer's copy engine writes them, so they
+// live in FINE-GRAINED device memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained): system-scope loads
+// are not served from a stale L2 line); plain hipMalloc is the fallback when the runtime refuses such memory or
+// its IPC handle, and spl_peer_exchange_flags_finegrained() tells which one is in use so that a caller can keep
+// the fallback out of an unattended run.  The y buffers stay coarse-grained (they are the next x of the SpMV,
+// whose gathers live on L2 hits): they are only ever read by kernels launched after the wait kernel has
+// finished, i.e. behind a kernel boundary, which is where coarse-grained memory is made coherent.
+// SPL_PEER_FINEGRAINED_DATA=1 puts them in fine-grained memory as well (for a box where that boundary proves
+// not to be enough).
+//
 // Reuse: a peer may run ahead by at most one step — it starts step k + 1 only after it has seen this rank's
 // flag of step k — so two receive buffers alternate: step k lands in buffer k % 2 while the owner may still
 // be reading buffer (k - 1) % 2.
@@ -38,7 +48,17 @@ struct PeerExchange {
   hipEvent_t ready = nullptr;
   unsigned step = 0;
   bool connected = false;
+  bool flags_fine = false, data_fine = false;
 };
+
+// fine-grained device memory whose IPC handle can be taken, or nullptr
+void *alloc_finegrained_ipc(size_t bytes) {
+  void *p = nullptr;
+  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  hipIpcMemHandle_t h;
+  if (hipIpcGetMemHandle(&h, p) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+  return p;
+}
 
 inline PeerExchange *as_px(void *p) {
   PeerExchange *x = static_cast<PeerExchange *>(p);
@@ -85,12 +105,22 @@ int spl_peer_exchange_create(int rank, int world, int chunks, int64_t n, const i
     px->n = n;
     px->bounds.assign(bounds, bounds + (size_t)chunks * world + 1);
     const size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(double);
+    const char *fd = getenv("SPL_PEER_FINEGRAINED_DATA");
+    const bool want_fine_data = fd && fd[0] == '1';
+    px->data_fine = want_fine_data;
     for (int b = 0; b < 2; ++b) {
-      SPL_HIP(hipMalloc(reinterpret_cast<void **>(&px->buf[b]), bytes));
+      if (want_fine_data) px->buf[b] = static_cast<double *>(alloc_finegrained_ipc(bytes));
+      if (!px->buf[b]) {
+        px->data_fine = false;
+        SPL_HIP(hipMalloc(reinterpret_cast<void **>(&px->buf[b]), bytes));
+      }
       SPL_HIP(hipMemset(px->buf[b], 0, bytes));
     }
     const size_t npieces = (size_t)chunks * world;
-    SPL_HIP(hipMalloc(reinterpret_cast<void **>(&px->flags), (npieces + 1) * sizeof(unsigned)));
+    const char *ff = getenv("SPL_PEER_FINEGRAINED_FLAGS");
+    if (!(ff && ff[0] == '0')) px->flags = static_cast<unsigned *>(alloc_finegrained_ipc((npieces + 1) * sizeof(unsigned)));
+    px->flags_fine = px->flags != nullptr;
+    if (!px->flags) SPL_HIP(hipMalloc(reinterpret_cast<void **>(&px->flags), (npieces + 1) * sizeof(unsigned)));
     SPL_HIP(hipMemset(px->flags, 0, (npieces + 1) * sizeof(unsigned)));
     px->error = px->flags + npieces;
     hipIpcMemHandle_t h;
@@ -199,6 +229,13 @@ int spl_peer_exchange_finish(void *X, void *stream, double **y_full) {
   } catch (const DeviceError &e) {
     return e.status;
   }
+}
+
+// 1: the flag words are in fine-grained device memory; 0: plain hipMalloc (fallback, see the header comment)
+int spl_peer_exchange_flags_finegrained(void *X) {
+  PeerExchange *px = as_px(X);
+  if (!px) return SPL_ERROR_invalid_handle;
+  return px->flags_fine ? 1 : 0;
 }
 
 // 1 if a wait gave up (a peer did not deliver within ~2 s): the results since are incomplete

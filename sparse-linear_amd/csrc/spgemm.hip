@@ -1450,10 +1450,10 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   // column: 47 ms vs 32 ms; its LDS image admits 12 wavefronts per CU where the plain one-wavefront-per-column
   // kernel runs 32; profiles/r02_spgemm_ordered_phases.txt).  It is taken when at least half of the products
   // belong to columns of 513 ... 2048 products; SPL_SPGEMM_ORDERED=1 / 0 forces / forbids it.  Its packed 32-bit keys need
-  // nrows <= 2^21.
+  // nrows < 2^21 (strictly: the key of row 2^21 - 1 with the last tie-break position is the 0xffffffff "no product" sentinel).
   const char *ord_env = getenv("SPL_SPGEMM_ORDERED");
   const char *two_pass_env = getenv("SPL_SPGEMM_TWO_PASS"), *split_keys_env = getenv("SPL_SPGEMM_SPLIT_KEYS");
-  const bool ordered_possible = !(ord_env && ord_env[0] == '0') && nrowsA <= (1LL << kOrdMaxRowBits) &&
+  const bool ordered_possible = !(ord_env && ord_env[0] == '0') && nrowsA < (1LL << kOrdMaxRowBits) &&
                                 !(two_pass_env && two_pass_env[0] == '1') && !(split_keys_env && split_keys_env[0] == '1');
   hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 32)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
                      medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 0, 0, 0);
@@ -1528,8 +1528,13 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     attr_set = true;
   }
   int pool = ndense < kMaxPool ? ndense : kMaxPool;
-  {  // keep the accumulator pool under ~32 GB (of 288)
-    const int64_t cap = (int64_t)32e9 / (9 * (nrowsA > 0 ? nrowsA : 1));
+  {  // keep the accumulator pool under ~32 GB (of 288) and under a quarter of what is free right now (the result
+     // buffers of a single pass are budgeted against half of it below; a busy device gets a smaller pool, not an error)
+    const int64_t per_slot = 9 * (nrowsA > 0 ? nrowsA : 1);
+    int64_t budget = (int64_t)32e9;
+    const int64_t quarter = (int64_t)(device_free_bytes() / 4);
+    if (ndense > 0 && quarter < budget) budget = quarter;
+    const int64_t cap = budget / per_slot;
     if (pool > cap) pool = (int)(cap < 1 ? 1 : cap);
   }
   DBuf<unsigned char> pool_flags;

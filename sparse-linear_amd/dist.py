@@ -245,6 +245,10 @@ class PeerStoreRowBlockSpMV(object):
     def failed(self):
         return bool(self._ffi.lib().spl_peer_exchange_failed(self._h))
 
+    def flags_finegrained(self):
+        """True when the step flags live in fine-grained device memory (csrc/peer.hip, 'Visibility')"""
+        return self._ffi.lib().spl_peer_exchange_flags_finegrained(self._h) == 1
+
     def close(self):
         if self._h.value:
             getattr(self, "_views", {}).clear()

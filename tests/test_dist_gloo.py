@@ -80,7 +80,7 @@ def _pipelined_worker(rank, world, port, chunks, out_dir):
         import __graft_entry__ as g
         pkg = g.load_package()
         from oracle import oracle as O
-        n = 3000  # divisible by chunks * world for every case below
+        n = 4800  # divisible by chunks * world for every case below
         rp, ci, v = O.gen_random_csr(n, 20)
         bounds = pkg.dist.pipelined_piece_bounds(n, world, chunks)
         calls = []
@@ -166,18 +166,18 @@ def test_colblock_spgemm_gloo(tmp_path, world):
         assert ok == "1" and ok_off == "1" and bal == "1" and ragged == "1"
 
 
-@pytest.mark.parametrize("world,balanced", [(2, False), (2, True), (3, False)])
+@pytest.mark.parametrize("world,balanced", [(2, False), (2, True), (3, False), (8, False), (8, True)])  # 8 = config C3's rank count
 def test_rowblock_spmv_gloo(tmp_path, world, balanced):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, balanced, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         ok, cover, bal, equal = open(tmp_path / ("rank%d" % r)).read().split()
         assert ok == "1" and cover == "1" and bal == "1"
-        if balanced or world == 3:
+        if balanced or world in (3, 8):
             assert equal == "0"  # the ragged (padded) gather path was exercised
 
 
-@pytest.mark.parametrize("world,chunks", [(2, 1), (2, 4), (3, 2)])
+@pytest.mark.parametrize("world,chunks", [(2, 1), (2, 4), (3, 2), (8, 2)])
 def test_pipelined_rowblock_spmv_gloo(tmp_path, world, chunks):
     """chunked ownership + one asynchronous all-gather per chunk == the serial product, bit for bit"""
     port = _free_port()

@@ -113,11 +113,13 @@ def test_plain_launch_starts_its_own_ranks(gpu):
     assert two["n_gpus"] == 2 and two["y_sha1"] == one["y_sha1"]
 
 
-def test_six_ranks_all_schedules(gpu):
-    """the widest rehearsal a one-GPU box admits (6 processes on the card): 5 IPC peers and 5 copy streams per
-    rank, 6-way all-gather, all six schedules measured and each equal to the single-rank y"""
+def test_four_ranks_all_schedules(gpu):
+    """the widest rehearsal a one-GPU box admits (its process guard allows 6 processes on the card: this test
+    runner, the launcher's agent and 4 ranks): 3 IPC peers and 3 copy streams per rank, 4-way all-gather, all six
+    schedules measured and each equal to the single-rank y.  The 8-rank shape of config C3 is rehearsed on CPU
+    ranks (tests/test_dist_gloo.py)."""
     args = ["--rows", "480000"]
     one = _run(1, args)
-    six = _run(6, args)
-    assert six["n_gpus"] == 6 and six["y_sha1"] == one["y_sha1"]
-    assert set(six["config"]["exchange_ms_per_step_by_chunks"]) == {"rccl1", "rccl2", "rccl4", "peer1", "peer2", "peer4"}
+    four = _run(4, args)
+    assert four["n_gpus"] == 4 and four["y_sha1"] == one["y_sha1"]
+    assert set(four["config"]["exchange_ms_per_step_by_chunks"]) == {"rccl1", "rccl2", "rccl4", "peer1", "peer2", "peer4"}

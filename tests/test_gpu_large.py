@@ -86,6 +86,83 @@ def test_linearity_full_size_c2(gpu, pkg):
     assert torch.equal(y2, yx)
 
 
+def _check_windows(torch, O, H, x, y, n, K, rows, order_free, y0=None):
+    """windows of 1000 rows recomputed by the oracle from the counter-based generators: bit for bit in the
+    reference order; in the order-free mode the reference's closeness predicate at 1e-10 and the rounding bound
+    2 * len * eps * sum |a x| per row (values and x are positive: sum |a x| = y)"""
+    xh = x.cpu().numpy()
+    row_off = H.info()["row0"]
+    for row0 in rows:
+        rp, ci, v = O.gen_random_csr(n, K, row0=row_off + row0, row1=row_off + row0 + 1000)
+        yo = np.zeros(1000) if y0 is None else y0[row0:row0 + 1000].cpu().numpy().copy()
+        O.csr_gaxpy32(rp.astype(np.int32), ci, v, xh, yo)
+        got = y[row0:row0 + 1000].cpu().numpy()
+        if order_free:
+            assert O.count_not_close(got, yo, 1e-10) == 0
+            lens = np.diff(rp) + (0 if y0 is None else 1)
+            assert np.all(np.abs(got - yo) <= 2.0 * np.maximum(lens, 1) * np.finfo(float).eps * np.abs(yo))
+        else:
+            assert np.array_equal(got, yo)
+
+
+def test_c2_full_size_order_free_is_the_benchmarked_kernel(gpu, pkg, O):
+    """config C2 at full size through the path bench.py times: set_spmv_order(ORDER_FREE) + optimize() must pick
+    the column-sorted panel kernel (512 panels, two generations with their rendezvous, 77 index blocks), y = A x
+    and the accumulate form y <- A x + y checked on four 1000-row windows against the oracle (Sparse.hs:447-451)"""
+    torch = gpu
+    n, K = 10_000_000, 20
+    H = pkg.DeviceMatrix.synthetic("random", n, K)
+    H.set_spmv_order(H.ORDER_FREE)
+    H.optimize()
+    assert H.spmv_kernel() == 16
+    s = torch.cuda.current_stream().cuda_stream
+    x = _dev_vec(torch, pkg, n, 0xBEEF)
+    y = torch.zeros(n, dtype=torch.float64, device="cuda")
+    H.spmv_dev(x.data_ptr(), y.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    rows = (0, 3_333_333, 9_765_500, n - 1000)  # 9_765_500: around the boundary of the two generations' panels
+    _check_windows(torch, O, H, x, y, n, K, rows, True)
+    assert float(y.min()) >= 0.25 and float(y.max()) <= 2.25 * K * 1.5
+    y0 = _dev_vec(torch, pkg, n, 7)
+    ya = y0.clone()
+    H.spmv_dev(x.data_ptr(), ya.data_ptr(), accumulate=True, stream=s)
+    torch.cuda.synchronize()
+    _check_windows(torch, O, H, x, ya, n, K, rows, True, y0=y0)
+    assert H.panel_errors() == 0
+    # the whole vector against the reference-order kernel on the same handle (1e-10, every entry)
+    H.set_spmv_order(H.ORDER_REFERENCE)
+    H.build_blocked(0, 0, 0)
+    assert H.spmv_kernel() == 8
+    yr = torch.zeros_like(y)
+    H.spmv_dev(x.data_ptr(), yr.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    assert ((y - yr).abs() / (y + yr).abs()).max().item() < 1e-10
+    _check_windows(torch, O, H, x, yr, n, K, rows[:2], False)
+    del H, x, y, ya, y0, yr
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("order_free", [False, True])
+def test_c3_row_block_of_one_rank_in_both_orders(gpu, pkg, O, order_free):
+    """the row block a rank owns at N = 8 (config C3: rows [5 000 000, 6 250 000) of the 1e7 x 1e7 matrix, all
+    columns), optimized the way bench.py does it per rank, in the reference order and order-free"""
+    torch = gpu
+    n, K = 10_000_000, 20
+    r0, r1 = 5_000_000, 6_250_000
+    H = pkg.DeviceMatrix.synthetic("random", n, K, row0=r0, row1=r1)
+    if order_free:
+        H.set_spmv_order(H.ORDER_FREE)
+    H.optimize()
+    assert H.spmv_kernel() in (8, 16)
+    x = _dev_vec(torch, pkg, n, 0xBEEF)
+    y = torch.zeros(r1 - r0, dtype=torch.float64, device="cuda")
+    H.spmv_dev(x.data_ptr(), y.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    _check_windows(torch, O, H, x, y, n, K, (0, 612_345, r1 - r0 - 1000), order_free or H.spmv_kernel() == 16)
+    del H, x, y
+    torch.cuda.empty_cache()
+
+
 # ---- the configurations of BASELINE.json at FULL size (C2 banded variant, C4, C5) -------------------
 
 def test_c2_banded_full_size_sell(gpu, pkg, O):

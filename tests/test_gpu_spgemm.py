@@ -161,6 +161,28 @@ def test_ordered_form_matches_oracle(gpu, pkg, O, monkeypatch, shape_name):
         assert np.array_equal(crp, Cs[2]) and np.array_equal(cci, Cs[3]) and np.array_equal(cv, Cs[4])
 
 
+@pytest.mark.parametrize("nrows", [(1 << 21) - 1, 1 << 21, (1 << 21) + 1])
+def test_ordered_form_last_row_last_tiebreak(gpu, pkg, O, monkeypatch, nrows):
+    """the ordered form packs key = row << 11 | t and uses 0xffffffff as "no product"; with 2^21 rows
+    a column of exactly 2048 products whose last product hits the last row would produce that very key.  The
+    ordered form is now refused from 2^21 rows on; around the bound, forced on with the 2048-product shape, such
+    a column must come out right (and C keep its format invariants)"""
+    monkeypatch.setenv("SPL_SPGEMM_ORDERED", "1")
+    monkeypatch.setenv("SPL_SPGEMM_ORDERED_SHAPE", "large")
+    rng = np.random.default_rng(3)
+    # A: nrows x 2; column 0 has 2047 entries, column 1 one entry in the last row.  B: 2 x 3, column 0 selects
+    # both (2048 products, the last with t = 2047 in row nrows - 1), columns 1, 2 ordinary
+    r0 = np.sort(rng.choice(nrows - 1, 2047, replace=False))
+    A = O.compress(nrows, 2, np.concatenate([r0, [nrows - 1]]), np.concatenate([np.zeros(2047, dtype=np.int64), [1]]),
+                   rng.uniform(0.5, 1.5, 2048))
+    B = O.compress(2, 3, np.array([0, 1, 0, 1]), np.array([0, 0, 1, 2]), rng.uniform(0.5, 1.5, 4))
+    C = pkg.mm(tuple_to_mat(pkg, A), tuple_to_mat(pkg, B))
+    Co = O.mm(A, B)
+    assert tuples_equal(mat_to_tuple(C), Co)
+    assert np.diff(Co[2])[0] == 2048 and Co[3][2047] == nrows - 1
+    assert O.check_matrix(mat_to_tuple(C)) == 0
+
+
 @pytest.mark.parametrize("form", [{}, {"SPL_SPGEMM_ORDERED": "1"}, {"SPL_SPGEMM_ORDERED": "0"}, {"SPL_SPGEMM_TWO_PASS": "1"}])
 def test_long_columns_of_b_with_few_products(gpu, pkg, O, monkeypatch, form):
     """a column of B with hundreds to thousands of entries that selects mostly EMPTY columns of A has few products:
