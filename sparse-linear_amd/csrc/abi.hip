@@ -610,10 +610,12 @@ int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unrol
   if (!m) return SPL_ERROR_invalid_handle;
   if (m->vw != 1) return SPL_ERROR_argument_missing;
   const bool auto_shape = rows_per_panel == 0 && cols_log2 == 0, form_was_default = form == 0, unroll_was_default = unroll == 0;
-  if (rows_per_panel == 0 && cols_log2 == 0) choose_panels(m, &rows_per_panel, &cols_log2);
+  int nslices = 1;
+  if (rows_per_panel == 0 && cols_log2 == 0) choose_panels(m, &rows_per_panel, &cols_log2, (form == 0 || form == 4 || form == 5) ? &nslices : nullptr);
+  else if (const char *ev = getenv("SPL_PANEL_SLICES")) { if (form == 4 || form == 5) nslices = atoi(ev) >= 1 ? atoi(ev) : 1; }
   if (rows_per_panel < 1 || rows_per_panel > 20479 || cols_log2 < 4 || cols_log2 > 17)
     return SPL_ERROR_argument_missing;
-  if (form != 0 && form != 1 && form != 2 && form != 4 && form != 5 && form != 6 && form != 7) return SPL_ERROR_argument_missing;
+  if (form != 0 && form != 1 && form != 2 && form != 4 && form != 5 && (form < 6 || form > 10)) return SPL_ERROR_argument_missing;
   return guarded([&]() -> int {
     DeviceGuard g(m->device);
     // form: 1 / 2 = one chunk per load, 1 / 2 index blocks per phase; 4 / 5 = paired storage (a pair of
@@ -625,7 +627,8 @@ int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unrol
     if (form == 0) form = cols_log2 >= 17 ? 5 : 4;
     const bool pair = form >= 4;
     const bool ring = form >= 6;
-    const int kblocks = (form == 2 || form == 5 || form == 7) ? 2 : 1;
+    // ring forms: 6 / 7 / 8 / 9 / 10 = 1 / 2 / 3 / 4 / 8 index blocks per phase
+    const int kblocks = form == 10 ? 8 : form >= 8 ? form - 5 : (form == 2 || form == 5 || form == 7) ? 2 : 1;
     if (ring) {
       int nl = 4, slots = 1;
       if (const char *ev = getenv("SPL_PANEL_RING_NL")) nl = atoi(ev);
@@ -635,6 +638,7 @@ int spl_matrix_build_panel(void *H, int rows_per_panel, int cols_log2, int unrol
     build_panel_image(m, rows_per_panel, cols_log2, pair ? 1 : 0, nullptr);
     PanelImage *b = m->panel;
     b->kblocks = kblocks;
+    b->nslices = pair && !ring ? nslices : 1;
     if (ring) {
       b->ring = 1;
       b->ring_depth = unroll > 0 ? unroll : 6;

@@ -106,6 +106,7 @@ struct PanelImage {
   int kblocks = 2;                // index blocks per phase (barrier to barrier)
   int pair = 0;                   // 1: paired storage (chunk pairs interleaved, 8-byte key / 16-byte value loads)
   int ablate = 0;                 // timing-only ablation bits (SPL_PANEL_ABLATE with SPL_ALLOW_ABLATION=1)
+  int nslices = 1;                // paired form: column slices per panel (8 = one per XCD; csrc/spmv_panel.hip)
   int ring = 0;                   // 1: ring form (loader wavefronts hand units to gather wavefronts through LDS slots)
   int ring_nl = 4, ring_depth = 6, ring_gather = 4, ring_slots = 1;  // loaders, units in flight per loader / per gatherer, slots per loader
 };
@@ -279,6 +280,7 @@ int panel_ring_errors(const Matrix *m, hipStream_t s);
 // choose the blocked image's shape for this matrix (0,0 = blocking would not help)
 void choose_blocking(const Matrix *m, int *rows_per_panel, int *w, int *waves);
 void choose_panels(const Matrix *m, int *rows_per_panel, int *w);
+void choose_panels(const Matrix *m, int *rows_per_panel, int *w, int *nslices);
 int spmv_kernel_in_use(const Matrix *m);
 bool panels_pay(const Matrix *m);
 

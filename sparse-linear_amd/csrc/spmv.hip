@@ -340,7 +340,7 @@ int spmv_cus(const Matrix *m) {
 // Shape of the column-sorted panel image (spmv_panel.hip): one panel per workgroup, as tall as the
 // LDS allows, the generations of the persistent grid full; index blocks of 2^17 columns (the key's
 // 17 column bits) or fewer for narrow matrices.
-void choose_panels(const Matrix *m, int *rows_per_panel, int *w) {
+void choose_panels(const Matrix *m, int *rows_per_panel, int *w, int *nslices) {
   const int cus = spmv_cus(m);
   const int64_t pmax = 20479;
   int64_t ngen = (m->nrows_local + (int64_t)cus * pmax - 1) / ((int64_t)cus * pmax);
@@ -348,18 +348,50 @@ void choose_panels(const Matrix *m, int *rows_per_panel, int *w) {
   int64_t P = (m->nrows_local + ngen * cus - 1) / (ngen * cus);
   if (P < 64) P = 64;
   if (P > pmax) P = pmax;
-  *rows_per_panel = (int)P;
   int ww = 17;
   while (ww > 4 && (1LL << ww) >= 2 * m->ncols) --ww;
   *w = ww;
+  int ns = 1;
+  // A row block too short to give every CU a tall panel (a rank's block at N = 4, 8): ns column slices per panel
+  // (csrc/spmv_panel.hip "Column slices"), the largest power of two that still leaves ONE generation of
+  // full-height panels — more slices mean more generations and more atomic adds into y (measured on the block of
+  // a rank at N = 8: 1 / 2 / 4 / 8 slices 0.201 / 0.158 / 0.151 / 0.195 ms; at N = 4: 1 / 2 / 4: 0.286 / 0.260 / 0.310)
+  const int64_t nib = (m->ncols + (1LL << ww) - 1) >> ww;
+  if (nslices && ngen == 1 && P * 5 < pmax * 3 && nib >= 32) {
+    int best = 1;
+    for (int f = 2; f <= 8; f *= 2)
+      if (cus % f == 0 && (int64_t)(cus / f) * pmax >= m->nrows_local) best = f;
+    if (best > 1) {
+      const int64_t ppg = cus / best;
+      P = (m->nrows_local + ppg - 1) / ppg;
+      if (P > pmax) P = pmax;
+      ns = best;
+    }
+  }
+  if (const char *ev = getenv("SPL_PANEL_SLICES")) {
+    const int f = atoi(ev);
+    if (nslices && f >= 1 && f != ns) {  // forced (experiments): panels sized for cus / f workgroups per generation
+      ns = f;
+      const int64_t ppg = cus / f > 0 ? cus / f : 1;
+      int64_t ng = (m->nrows_local + ppg * pmax - 1) / (ppg * pmax);
+      if (ng < 1) ng = 1;
+      P = (m->nrows_local + ng * ppg - 1) / (ng * ppg);
+      if (P < 64) P = 64;
+      if (P > pmax) P = pmax;
+    }
+  }
+  *rows_per_panel = (int)P;
+  if (nslices) *nslices = ns;
 }
+
+void choose_panels(const Matrix *m, int *rows_per_panel, int *w) { choose_panels(m, rows_per_panel, w, nullptr); }
 
 // The panel image beats the column-blocked one when a 128-byte line of x meets enough entries of a
 // panel for lanes to share requests: entries per line = 16 * nnz/nrows * P / ncols.
 // (measured on C2, P = 19 532: 0.63 per line, 0.99 ms vs 1.19 ms; tools/bench_spmv_variants.py)
 bool panels_pay(const Matrix *m) {
-  int P = 0, w = 0;
-  choose_panels(m, &P, &w);
+  int P = 0, w = 0, ns = 1;
+  choose_panels(m, &P, &w, &ns);
   if (m->nrows_local < 1 || m->ncols < 1) return false;
   const double per_line = 16.0 * ((double)m->nnz / (double)m->nrows_local) * (double)P / (double)m->ncols;
   return per_line >= 0.3;

@@ -350,26 +350,41 @@ __device__ inline void panelw_phase(pnl_u2 (&idC)[U], pnl_d2 (&aC)[U], pnl_u2 (&
   __builtin_amdgcn_s_barrier();  // pacing only
 }
 
+// Column slices (round 3): with `ns` > 1 the index blocks are dealt to ns slices and workgroup b works on slice
+// b % ns (workgroups go round-robin to the 8 XCDs, so with ns = 8 a slice is what ONE XCD's L2 has to hold) of
+// panel slot b / ns: a panel's row sums are then completed by ns workgroups, which add their parts into y with
+// global_atomic_add_f64 (y zeroed by the launcher unless accumulating).  Why: every XCD that works on a panel
+// pulls the x lines that panel touches through its own L2 once per generation, so x costs (rows / (panels per
+// generation of one XCD * P)) * 8 bytes * ncols of fabric traffic per product — a row block too short to give
+// every CU a full-height panel (a rank's block at N = 4, 8) would otherwise pay with short panels (fewer lanes
+// per line of x, more passes over x): 640 MB of x for 300 MB of matrix at N = 8.  With slices the panels keep
+// the full LDS height and each XCD reads an eighth of x per generation.
 template <int U, int K>
 __global__ __launch_bounds__(kPanelWaves * 64) void spmv_panelw_kernel(
     int64_t nrows, int64_t npanels, int P, int w, int64_t nib, const int *__restrict__ segc,
     const unsigned *__restrict__ key, const double *__restrict__ val, const double *__restrict__ x,
-    double *__restrict__ y, int accumulate, unsigned *__restrict__ arrive, int64_t dummy) {
+    double *__restrict__ y, int accumulate, unsigned *__restrict__ arrive, int64_t dummy, int ns) {
   extern __shared__ __attribute__((aligned(16))) double ylds[];  // P + 1 doubles
   const pnl_u2 *key2 = reinterpret_cast<const pnl_u2 *>(key);
   const pnl_d2 *val2 = reinterpret_cast<const pnl_d2 *>(val);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t nb = gridDim.x;
-  const int64_t ngen = (npanels + nb - 1) / nb;
-  const int64_t nph = (nib + K - 1) / K;
+  const int64_t ppg = gridDim.x / ns;          // panels per generation
+  const int slice = (int)(blockIdx.x % ns);
+  const int64_t slot = blockIdx.x / ns;
+  if (slot >= ppg) return;                      // grid not a multiple of ns: the extra workgroups idle
+  const int64_t nb = ppg * ns;                  // workgroups that take part in the rendezvous
+  const int64_t ngen = (npanels + ppg - 1) / ppg;
+  const int64_t ibs = nib * slice / ns, ibe = nib * (slice + 1) / ns;  // this slice's index blocks
+  const int64_t nph = (ibe - ibs + K - 1) / K;
   for (int64_t g = 0; g < ngen; ++g) {
-    const int64_t p = g * nb + blockIdx.x;
+    const int64_t p = g * ppg + slot;
     if (p >= npanels) break;
     const int64_t row_base = p * P;
     const int *sp = segc + p * nib;  // in chunks; every boundary is even (whole pairs)
-    const int c0 = sp[0] >> 1;
-    const int c1 = (K < nib ? sp[K] : sp[nib]) >> 1;
+    const int c0 = sp[ibs] >> 1;
+    const int cend = sp[ibe] >> 1;
+    const int c1 = (ibs + K < ibe ? sp[ibs + K] >> 1 : cend);
     pnl_u2 idA[U], idB[U];
     pnl_d2 aA[U], aB[U];
 #pragma unroll
@@ -380,34 +395,38 @@ __global__ __launch_bounds__(kPanelWaves * 64) void spmv_panelw_kernel(
       aA[u] = __builtin_nontemporal_load(val2 + k);
     }
     for (int i = threadIdx.x; i <= P; i += kPanelWaves * 64)
-      ylds[i] = (accumulate && i < P && row_base + i < nrows) ? y[row_base + i] : 0.0;
+      ylds[i] = (ns == 1 && accumulate && i < P && row_base + i < nrows) ? y[row_base + i] : 0.0;
     __syncthreads();
-    const int cend = sp[nib] >> 1;
     for (int64_t ph = 0; ph < nph; ph += 2) {
       {
-        const int64_t ib0 = ph * K;
+        const int64_t ib0 = ibs + ph * K;
         int mid[K > 1 ? K - 1 : 1];
 #pragma unroll
-        for (int j = 0; j + 1 < K; ++j) { const int t = sp[ib0 + j + 1] >> 1; mid[j] = t < cend ? t : cend; }
+        for (int j = 0; j + 1 < K; ++j) { const int t = (ib0 + j + 1 < ibe) ? sp[ib0 + j + 1] >> 1 : cend; mid[j] = t < cend ? t : cend; }
         const int cs = sp[ib0] >> 1;
-        int ce = sp[ib0 + K] >> 1; ce = (ib0 + K < nib) ? ce : cend;
-        int cn = sp[ib0 + 2 * K] >> 1; cn = (ib0 + 2 * K < nib) ? cn : cend;
+        const int ce = (ib0 + K < ibe) ? sp[ib0 + K] >> 1 : cend;
+        const int cn = (ib0 + 2 * K < ibe) ? sp[ib0 + 2 * K] >> 1 : cend;
         panelw_phase<U, K>(idA, aA, idB, aB, cs, mid, ce, ib0, w, key2, val2, x, ylds, wave, cn, dummy);
       }
       if (ph + 1 < nph) {
-        const int64_t ib0 = (ph + 1) * K;
+        const int64_t ib0 = ibs + (ph + 1) * K;
         int mid[K > 1 ? K - 1 : 1];
 #pragma unroll
-        for (int j = 0; j + 1 < K; ++j) { const int t = sp[ib0 + j + 1] >> 1; mid[j] = t < cend ? t : cend; }
+        for (int j = 0; j + 1 < K; ++j) { const int t = (ib0 + j + 1 < ibe) ? sp[ib0 + j + 1] >> 1 : cend; mid[j] = t < cend ? t : cend; }
         const int cs = sp[ib0] >> 1;
-        int ce = sp[ib0 + K] >> 1; ce = (ib0 + K < nib) ? ce : cend;
-        int cn = sp[ib0 + 2 * K] >> 1; cn = (ib0 + 2 * K < nib) ? cn : cend;
+        const int ce = (ib0 + K < ibe) ? sp[ib0 + K] >> 1 : cend;
+        const int cn = (ib0 + 2 * K < ibe) ? sp[ib0 + 2 * K] >> 1 : cend;
         panelw_phase<U, K>(idB, aB, idA, aA, cs, mid, ce, ib0, w, key2, val2, x, ylds, wave, cn, dummy);
       }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < P; i += kPanelWaves * 64)
-      if (row_base + i < nrows) y[row_base + i] = ylds[i];
+    if (ns == 1) {
+      for (int i = threadIdx.x; i < P; i += kPanelWaves * 64)
+        if (row_base + i < nrows) y[row_base + i] = ylds[i];
+    } else {
+      for (int i = threadIdx.x; i < P; i += kPanelWaves * 64)
+        if (row_base + i < nrows) unsafeAtomicAdd(y + row_base + i, ylds[i]);  // global_atomic_add_f64, no return
+    }
     if (g + 1 < ngen) {
       __syncthreads();
       if (threadIdx.x == 0) {
@@ -423,7 +442,6 @@ __global__ __launch_bounds__(kPanelWaves * 64) void spmv_panelw_kernel(
     }
   }
 }
-
 
 // ---- ring form (round 3): loader wavefronts + gather wavefronts ---------------------------------------
 // What the probes say (tools/probe/lds_dma_mix_probe.hip, profiles/r03_tcp_mix_lds_dma.txt): when every
@@ -718,9 +736,11 @@ static void launch_panelw_as(const Matrix *m, const PanelImage *b, unsigned nb, 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     set_.fetch_or(1ull << (m->device & 63), std::memory_order_release);
   }
+  const int ns = b->nslices > 1 ? b->nslices : 1;
+  if (ns > 1 && !accumulate) SPL_HIP(hipMemsetAsync(d_y, 0, (size_t)m->nrows_local * sizeof(double), s));
   hipLaunchKernelGGL((spmv_panelw_kernel<U, K>), dim3(nb), dim3(kPanelWaves * 64), lds, s, m->nrows_local, b->npanels,
                      b->P, b->w, b->nib, b->segc.get(), b->key.get(), b->val.get(), d_x, d_y, accumulate,
-                     b->arrive.get(), (int64_t)(b->nchunks / 2) << 6);
+                     b->arrive.get(), (int64_t)(b->nchunks / 2) << 6, ns);
 }
 
 
@@ -755,6 +775,9 @@ static int launch_panel_ring(const Matrix *m, const PanelImage *b, unsigned nb, 
   SPL_RING(4, 4, 4, 2, 1) SPL_RING(4, 6, 4, 2, 1) SPL_RING(4, 8, 4, 2, 1) SPL_RING(4, 6, 3, 2, 1)
   SPL_RING(4, 6, 4, 1, 1) SPL_RING(4, 6, 4, 2, 3) SPL_RING(4, 4, 3, 2, 1) SPL_RING(4, 5, 4, 2, 1)
   SPL_RING(2, 8, 2, 2, 1) SPL_RING(8, 3, 4, 2, 1) SPL_RING(8, 4, 4, 2, 1)
+  SPL_RING(4, 6, 4, 3, 1) SPL_RING(4, 6, 4, 4, 1) SPL_RING(4, 6, 4, 3, 3) SPL_RING(4, 6, 4, 4, 3) SPL_RING(4, 4, 4, 2, 3)
+  SPL_RING(4, 6, 3, 2, 3) SPL_RING(4, 6, 4, 1, 3) SPL_RING(4, 4, 4, 4, 1) SPL_RING(4, 4, 4, 3, 1) SPL_RING(8, 4, 4, 4, 1)
+  SPL_RING(8, 4, 4, 2, 2) SPL_RING(4, 4, 4, 8, 1) SPL_RING(4, 6, 4, 8, 1)
 #undef SPL_RING
   if (!launched) return SPL_ERROR_argument_missing;
   hipError_t e = hipGetLastError();
@@ -784,7 +807,8 @@ int launch_spmv_panel(const Matrix *m, const double *d_x, double *d_y, int accum
   int cus = 0;
   SPL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
   int64_t nb = cus;
-  if (nb > b->npanels) nb = b->npanels;
+  const int64_t tasks = b->npanels * (b->nslices > 1 && b->pair && !b->ring ? b->nslices : 1);
+  if (nb > tasks) nb = tasks;
   SPL_HIP(hipMemsetAsync(b->arrive.get(), 0, sizeof(unsigned), s));
   if (b->ring) return launch_panel_ring(m, b, (unsigned)nb, d_x, d_y, accumulate, s);
   const int U = b->unroll, K = b->kblocks;

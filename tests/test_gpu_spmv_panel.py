@@ -118,3 +118,51 @@ def test_panel_empty_rows_and_ragged_edges(gpu, pkg, O):
     Z.build_panel(64, 4, 4, 1)
     Z.set_variant(16)
     assert np.array_equal(_run(torch, Z, torch.ones(200, dtype=torch.float64, device="cuda")), np.zeros(300))
+
+
+@pytest.mark.parametrize("slices", [2, 4, 8])
+def test_panel_column_slices(gpu, pkg, O, monkeypatch, slices):
+    """column slices (csrc/spmv_panel.hip): a panel's index blocks dealt to `slices` workgroups that add their parts
+    of the row sums into y with atomics — y = A x and y <- A x + y to the order-free contract, exact on integers"""
+    torch = gpu
+    monkeypatch.setenv("SPL_PANEL_SLICES", str(slices))
+    n, K = 600_000, 20
+    H = pkg.DeviceMatrix.synthetic("random", n, K, row0=100_000, row1=400_000)  # a row block: 300 000 rows, all columns
+    H.build_panel(9000, 12, 0, 5)
+    H.set_variant(16)
+    rp, ci, v = H.export_csr()
+    xh = O.gen_vector(n)
+    x = torch.from_numpy(xh).cuda()
+    y = _run(torch, H, x)
+    yo = np.zeros(300_000)
+    O.csr_gaxpy32(rp.astype(np.int32), ci, v, xh, yo)
+    assert O.count_not_close(y, yo, 1e-10) == 0
+    lens = np.diff(rp)
+    assert np.all(np.abs(y - yo) <= 2.0 * np.maximum(lens, 1) * np.finfo(float).eps * np.abs(yo))
+    y0 = O.gen_vector(300_000, seed=7)
+    yd = torch.from_numpy(y0.copy()).cuda()
+    H.spmv_dev(x.data_ptr(), yd.data_ptr(), accumulate=True, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ya = y0.copy()
+    O.csr_gaxpy32(rp.astype(np.int32), ci, v, xh, ya)
+    assert O.count_not_close(yd.cpu().numpy(), ya, 1e-10) == 0
+    # the automatic choice on the same block picks slices by itself (one generation of tall panels)
+    monkeypatch.delenv("SPL_PANEL_SLICES")
+    H2 = pkg.DeviceMatrix.synthetic("random", 10_000_000, K, row0=0, row1=1_250_000)
+    H2.set_spmv_order(H2.ORDER_FREE)
+    H2.optimize()
+    assert H2.spmv_kernel() == 16 and H2.info()["blocked_rows"] > 15_000
+
+
+def test_panel_column_slices_exact_on_integers(gpu, pkg, O, monkeypatch):
+    torch = gpu
+    monkeypatch.setenv("SPL_PANEL_SLICES", "4")
+    rng = np.random.default_rng(6)
+    n, k = 40_000, 700_000
+    A = O.compress(n, n, rng.integers(0, n, k), rng.integers(0, n, k), rng.integers(-9, 10, k).astype(float))
+    H = pkg.DeviceMatrix.from_csc(pkg.Matrix(n, n, A[2], A[3], A[4]))
+    H.build_panel(2500, 8, 0, 4)
+    H.set_variant(16)
+    xh = rng.integers(-5, 6, n).astype(float)
+    y = _run(torch, H, torch.from_numpy(xh).cuda())
+    assert np.array_equal(y, O.mulV(A, xh))

@@ -20,6 +20,7 @@ pkg._ffi.check("v", pkg._ffi.lib().spl_vector_synthetic_dev(0xBEEF, 0, n, x.data
 import argparse  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--ranks", default="1,2,4,8")
+ap.add_argument("--order", default="free", choices=["free", "reference"])
 ap.add_argument("--blocked", default="", help="R,w,u;R,w,u;... shapes to try instead of the automatic one")
 args = ap.parse_args()
 shapes = [tuple(int(t) for t in b.split(",")) for b in args.blocked.split(";") if b] or [None]
@@ -30,6 +31,8 @@ for N, shape in [(int(t), sh) for t in args.ranks.split(",") for sh in shapes]:
         H.build_blocked(*shape)
         H.set_variant(8)
     else:
+        if args.order == "free":
+            H.set_spmv_order(H.ORDER_FREE)
         H.optimize()
     y = torch.empty(r1 - r0, dtype=torch.float64, device="cuda")
     for _ in range(5):
@@ -43,6 +46,6 @@ for N, shape in [(int(t), sh) for t in args.ranks.split(",") for sh in shapes]:
     ms = e0.elapsed_time(e1) / 50
     inf = H.info()
     print(json.dumps({"ranks": N, "rows": r1 - r0, "nnz": inf["nnz"], "kernel_ms": round(ms, 4),
-                      "panel_rows": inf["blocked_rows"], "cols_log2": inf["blocked_cols_log2"],
-                      "ideal_ms_from_1gpu": None}), flush=True)
+                      "kernel": H.spmv_kernel(), "sum_order": args.order,
+                      "panel_rows": inf["blocked_rows"], "cols_log2": inf["blocked_cols_log2"]}), flush=True)
     del H
