@@ -193,7 +193,7 @@ void spl_matrix_free(void **H);
  * image in use), its cols_log2 */
 int spl_matrix_info(void *H, int64_t info[8]);
 /* copy the device CSR image back: rowptr[nrows_local+1] (relative to the block,
- * rowptr[0]=0), colidx[nnz_local], val[nnz_local] */
+ * rowptr[0]=0), colidx[nnz_local], val[nnz_local] (2 nnz_local doubles, packed (re, im), for a complex handle) */
 int spl_matrix_export_csr(void *H, int64_t *rowptr, int *colidx, double *val);
 /* the same for rows [row0, row1) of the block only (a window of a result too large to copy whole):
  * rowptr[row1-row0+1] keeps the block's offsets (rowptr[0] = first entry of row0, not 0); colidx / val
@@ -201,6 +201,20 @@ int spl_matrix_export_csr(void *H, int64_t *rowptr, int *colidx, double *val);
  * (SPL_ERROR_argument_missing if they do not: call once with capacity 0 to learn the count from rowptr) */
 int spl_matrix_export_csr_rows(void *H, int64_t row0, int64_t row1, int64_t *rowptr, int64_t capacity, int *colidx,
                                double *val);
+
+/* ---- device-resident forms of lin / transpose / compress: handle in, handle out, nothing crosses PCIe ----
+ * spl_matrix_lin: C = alpha A + beta B (Sparse.hs:401-431) for two handles of the same shape, row block and
+ *   scalar kind; alpha / beta are (re, im) pairs, the imaginary parts must be 0 for real handles (complex scalars
+ *   on real matrices: spl_matrix_to_complex first, as the reference's `cmap (:+ 0)` does, Feast.hs:214).
+ * spl_matrix_to_complex: the Complex Double handle (x :+ 0) of a real one.
+ * spl_matrix_transpose: handle of A^T (Sparse.hs:301-329); whole real matrices.
+ * spl_matrix_compress_dev: COO triples in DEVICE memory -> handle (compress / fromTriples, Sparse.hs:184-280):
+ *   bounds checked rows first, then columns (*bad = first offending position, may be NULL), duplicates summed. */
+int spl_matrix_lin(void *HA, const double alpha[2], void *HB, const double beta[2], void **HC);
+int spl_matrix_to_complex(void *H, void **HZ);
+int spl_matrix_transpose(void *H, void **HT);
+int spl_matrix_compress_dev(int nrows, int ncols, int64_t ntriples, const int *d_rows, const int *d_cols,
+                            const double *d_vals, void **H, int64_t *bad);
 /* transpose the block on the device (Sparse.hs:301-329) and copy out its
  * column-major image: colptr[ncols+1], rowidx[nnz_local] (LOCAL row ids, ascending
  * inside a column), val[nnz_local] — i.e. the reference's own CSC Matrix fields */

@@ -104,6 +104,10 @@ def _declare(L):
         "spl_matrix_create_synthetic": [i, i64, i, u64, i64, i64, c_void_pp],
         "spl_matrix_create_rmat": [i, i, d, d, d, u64, c_void_pp],
         "spl_matrix_spgemm": [C.c_void_p, C.c_void_p, c_void_pp, c_i64_p],
+        "spl_matrix_lin": [C.c_void_p, c_dbl_p, C.c_void_p, c_dbl_p, c_void_pp],
+        "spl_matrix_to_complex": [C.c_void_p, c_void_pp],
+        "spl_matrix_transpose": [C.c_void_p, c_void_pp],
+        "spl_matrix_compress_dev": [i, i, i64, C.c_void_p, C.c_void_p, C.c_void_p, c_void_pp, c_i64_p],
         "spl_matrix_info": [C.c_void_p, c_i64_p],
         "spl_matrix_export_csr": [C.c_void_p, c_i64_p, c_int_p, c_dbl_p],
         "spl_matrix_export_csc": [C.c_void_p, c_i64_p, c_int_p, c_dbl_p],

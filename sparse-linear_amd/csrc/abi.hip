@@ -415,6 +415,152 @@ int spl_matrix_spgemm(void *HA, void *HB, void **HC, int64_t *products) {
   });
 }
 
+
+// ---- device-resident forms of lin / transpose / compress (round 3) -----------------------------------------
+// The host 5-tuple entry points (spl_lin, spl_transpose, spl_compress) pay PCIe and marshalling for kernels that
+// take a few milliseconds; these work handle to handle.  A handle holds the ROW-major image; `lin` merges along
+// the major index whichever it is (Sparse.hs:401-431 applied to the transposes), so the same kernels serve.
+int spl_matrix_lin(void *HA, const double alpha[2], void *HB, const double beta[2], void **HC) {
+  Matrix *A = as_matrix(HA), *B = as_matrix(HB);
+  if (!A || !B) return SPL_ERROR_invalid_handle;
+  if (!HC || !alpha || !beta) return SPL_ERROR_argument_missing;
+  *HC = nullptr;
+  if (A->nrows_global != B->nrows_global || A->ncols != B->ncols || A->row0 != B->row0 || A->nrows_local != B->nrows_local)
+    return SPL_ERROR_dimension_mismatch;  // Sparse.hs:408-409
+  if (A->vw != B->vw || A->device != B->device) return SPL_ERROR_argument_missing;
+  if (A->vw == 1 && (alpha[1] != 0.0 || beta[1] != 0.0)) return SPL_ERROR_argument_missing;  // complex scalars: spl_matrix_to_complex first
+  if (!A->rowptr.get() || !B->rowptr.get()) return SPL_ERROR_index_overflow;
+  return guarded([&]() -> int {
+    DeviceGuard g(A->device);
+    hipStream_t s = nullptr;
+    std::unique_ptr<Matrix> C(new Matrix());
+    C->device = A->device;
+    C->nrows_global = A->nrows_global;
+    C->ncols = A->ncols;
+    C->row0 = A->row0;
+    C->nrows_local = A->nrows_local;
+    C->vw = A->vw;
+    if (A->vw == 1)
+      lin_device(alpha[0], A->rowptr.get(), A->colidx.get(), A->val.get(), beta[0], B->rowptr.get(), B->colidx.get(),
+                 B->val.get(), A->nrows_local, C->rowptr64, C->colidx, C->val, &C->nnz, s);
+    else
+      lin_device_z(alpha, A->rowptr.get(), A->colidx.get(), A->val.get(), beta, B->rowptr.get(), B->colidx.get(),
+                   B->val.get(), A->nrows_local, C->rowptr64, C->colidx, C->val, &C->nnz, s);
+    finalize_matrix(C.get(), s);
+    *HC = C.release();
+    return SPL_OK;
+  });
+}
+
+namespace {
+__global__ __launch_bounds__(256) void promote_complex_kernel(const double *__restrict__ x, int64_t n, double *__restrict__ z) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) { z[2 * i] = x[i]; z[2 * i + 1] = 0.0; }  // cmap (:+ 0)
+}
+}  // namespace
+
+// the Complex Double handle of a real one: same pattern, values (x :+ 0)
+int spl_matrix_to_complex(void *H, void **HZ) {
+  Matrix *A = as_matrix(H);
+  if (!A) return SPL_ERROR_invalid_handle;
+  if (!HZ) return SPL_ERROR_argument_missing;
+  *HZ = nullptr;
+  if (A->vw != 1) return SPL_ERROR_argument_missing;
+  return guarded([&]() -> int {
+    DeviceGuard g(A->device);
+    hipStream_t s = nullptr;
+    std::unique_ptr<Matrix> C(new Matrix());
+    C->device = A->device;
+    C->nrows_global = A->nrows_global;
+    C->ncols = A->ncols;
+    C->row0 = A->row0;
+    C->nrows_local = A->nrows_local;
+    C->nnz = A->nnz;
+    C->vw = 2;
+    C->rowptr64.alloc((size_t)A->nrows_local + 1);
+    SPL_HIP(hipMemcpyAsync(C->rowptr64.get(), A->rowptr64.get(), ((size_t)A->nrows_local + 1) * sizeof(int64_t),
+                           hipMemcpyDeviceToDevice, s));
+    C->colidx.alloc((size_t)A->nnz);
+    C->val.alloc((size_t)A->nnz * 2);
+    if (A->nnz) {
+      SPL_HIP(hipMemcpyAsync(C->colidx.get(), A->colidx.get(), (size_t)A->nnz * sizeof(int), hipMemcpyDeviceToDevice, s));
+      int64_t blocks = (A->nnz + 255) / 256;
+      if (blocks > 65536) blocks = 65536;
+      hipLaunchKernelGGL(promote_complex_kernel, dim3((unsigned)blocks), dim3(256), 0, s, A->val.get(), A->nnz, C->val.get());
+    }
+    finalize_matrix(C.get(), s);
+    *HZ = C.release();
+    return SPL_OK;
+  });
+}
+
+// handle of the transpose (Sparse.hs:301-329 on the device, no host round trip); whole matrices only
+int spl_matrix_transpose(void *H, void **HT) {
+  Matrix *A = as_matrix(H);
+  if (!A) return SPL_ERROR_invalid_handle;
+  if (!HT) return SPL_ERROR_argument_missing;
+  *HT = nullptr;
+  if (A->vw != 1 || A->row0 != 0 || A->nrows_local != A->nrows_global) return SPL_ERROR_argument_missing;
+  if (!A->rowptr.get()) return SPL_ERROR_index_overflow;
+  return guarded([&]() -> int {
+    DeviceGuard g(A->device);
+    hipStream_t s = nullptr;
+    std::unique_ptr<Matrix> C(new Matrix());
+    C->device = A->device;
+    C->nrows_global = C->nrows_local = A->ncols;
+    C->ncols = A->nrows_global;
+    C->nnz = A->nnz;
+    C->rowptr64.alloc((size_t)A->ncols + 1);
+    C->colidx.alloc((size_t)A->nnz);
+    C->val.alloc((size_t)A->nnz);
+    transpose_compressed(A->rowptr.get(), A->colidx.get(), A->val.get(), A->nrows_local, A->ncols, A->nnz,
+                         C->rowptr64.get(), C->colidx.get(), C->val.get(), s);
+    finalize_matrix(C.get(), s);
+    *HT = C.release();
+    return SPL_OK;
+  });
+}
+
+// COO triples in device memory -> handle (compress / fromTriples, Sparse.hs:184-280: bounds checked rows first,
+// then columns; duplicates summed in input order).  *bad receives the first offending position on
+// SPL_ERROR_index_out_of_bounds (may be NULL).
+int spl_matrix_compress_dev(int nrows, int ncols, int64_t ntriples, const int *d_rows, const int *d_cols,
+                            const double *d_vals, void **H, int64_t *bad) {
+  if (!H) return SPL_ERROR_argument_missing;
+  *H = nullptr;
+  if (nrows < 0 || ncols < 0) return SPL_ERROR_n_nonpositive;
+  if (ntriples < 0 || (ntriples > 0 && (!d_rows || !d_cols || !d_vals))) return SPL_ERROR_argument_missing;
+  return guarded([&]() -> int {
+    const int dev = current_device();
+    hipStream_t s = nullptr;
+    // the row-major image of A is the column-major image of A^T: compress with the roles of rows and columns
+    // exchanged.  The reference checks rows before columns (Sparse.hs:196-212): keep its order of complaints.
+    {
+      DBuf<int> none_i;
+      DBuf<double> none_v;
+      DBuf<int> probe((size_t)ncols + 1);
+      int64_t nz = 0, where = -1;
+      int st = compress_device(nrows, ncols, ntriples, d_rows, d_cols, d_vals, probe.get(), none_i, none_v, &nz, &where, s,
+                               /*check_only=*/true);
+      if (st != SPL_OK) { if (bad) *bad = where; return st; }
+    }
+    std::unique_ptr<Matrix> C(new Matrix());
+    C->device = dev;
+    C->nrows_global = C->nrows_local = nrows;
+    C->ncols = ncols;
+    DBuf<int> ptr32((size_t)nrows + 1);
+    int64_t where = -1;
+    int st = compress_device(ncols, nrows, ntriples, d_cols, d_rows, d_vals, ptr32.get(), C->colidx, C->val, &C->nnz, &where, s, false);
+    if (st != SPL_OK) { if (bad) *bad = where; return st; }
+    C->rowptr64.alloc((size_t)nrows + 1);
+    widen_i32_to_i64(ptr32.get(), C->rowptr64.get(), (int64_t)nrows + 1, s);
+    finalize_matrix(C.get(), s);
+    *H = C.release();
+    return SPL_OK;
+  });
+}
+
 void spl_matrix_free(void **H) {
   if (!H || !*H) return;
   Matrix *m = as_matrix(*H);
@@ -453,7 +599,6 @@ int spl_matrix_spmv_kernel(void *H) {
 int spl_matrix_export_csr(void *H, int64_t *rowptr, int *colidx, double *val) {
   Matrix *m = as_matrix(H);
   if (!m) return SPL_ERROR_invalid_handle;
-  if (m->vw != 1) return SPL_ERROR_argument_missing;  // complex handles: SpMV only
   if (!rowptr || (m->nnz > 0 && (!colidx || !val))) return SPL_ERROR_argument_missing;
   return guarded([&]() -> int {
     DeviceGuard g(m->device);
@@ -461,7 +606,7 @@ int spl_matrix_export_csr(void *H, int64_t *rowptr, int *colidx, double *val) {
                       hipMemcpyDeviceToHost));
     if (m->nnz) {
       SPL_HIP(hipMemcpy(colidx, m->colidx.get(), (size_t)m->nnz * sizeof(int), hipMemcpyDeviceToHost));
-      SPL_HIP(hipMemcpy(val, m->val.get(), (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToHost));
+      SPL_HIP(hipMemcpy(val, m->val.get(), (size_t)m->nnz * (size_t)m->vw * sizeof(double), hipMemcpyDeviceToHost));
     }
     return SPL_OK;
   });

@@ -13,6 +13,7 @@
 // evaluated exactly as the reference's SPA does: (0 + alpha*a) + beta*b, each
 // operation separately rounded (-ffp-contract=off).
 #include "common.hpp"
+#include <atomic>
 
 namespace spl {
 
@@ -163,13 +164,178 @@ __global__ __launch_bounds__(256) void lin_merge_kernel(
   if (!FILL) counts[c] = n;
 }
 
+
+// Tiled form (round 3): the merge itself is unchanged — one thread walks the two sorted columns exactly as above,
+// so the values are the same bits — but a workgroup of kLinCols threads takes kLinCols CONSECUTIVE columns, whose
+// entries are one contiguous range of each operand, stages those ranges in LDS with coalesced loads, merges out of
+// LDS into an LDS image of the result range and writes that image back with coalesced stores.  The thread-per-column
+// kernel above reads and writes a 12-byte entry per lane and instruction at addresses a column apart (330 GB/s at
+// 4e7 entries, profiles/r02_assembly_kernel_stats.txt); here every global access is a full line.  Tiles whose two
+// ranges exceed the LDS image (very long columns) fall back to the walk in global memory, tile by tile.
+constexpr int kLinCols = 64;
+
+template <int VW>
+struct LinTile {
+  static constexpr int kCap = VW == 1 ? 3072 : 2048;  // staged entries of A + B; the result range has at most as many
+};
+
+// n elements global -> LDS (or LDS -> global) by one workgroup, eight independent loads in flight per thread: a
+// plain loop would wait for every load before it issues the next (one HBM latency per 64 elements)
+template <typename T, typename D, typename S>
+__device__ inline void lin_copy(D dst, S src, int n) {
+  for (int i0 = 0; i0 < n; i0 += kLinCols * 8) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * kLinCols + (int)threadIdx.x;
+      v[u] = src[i < n ? i : n - 1];  // branch-free: lanes past the end re-read the last element
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * kLinCols + (int)threadIdx.x;
+      if (i < n) dst[i] = v[u];
+    }
+  }
+}
+
+template <bool FILL, int VW>
+__global__ __launch_bounds__(kLinCols) void lin_tile_kernel(
+    double alpha, double alpha_im, const int *__restrict__ Ap, const int *__restrict__ Ai,
+    const double *__restrict__ Ax, double beta, double beta_im, const int *__restrict__ Bp,
+    const int *__restrict__ Bi, const double *__restrict__ Bx, int64_t ncols, int *__restrict__ counts,
+    const int64_t *__restrict__ Cp, int *__restrict__ Ci, double *__restrict__ Cx) {
+  constexpr int CAP = LinTile<VW>::kCap;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lin_lds[];
+  int *sI = reinterpret_cast<int *>(lin_lds);                       // CAP: rows of A's range, then B's
+  int *sO = sI + CAP;                                               // CAP: rows of the result range (FILL)
+  double *sX = reinterpret_cast<double *>(sO + (FILL ? CAP : 0));   // CAP * VW values in, then CAP * VW out
+  double *sY = sX + (size_t)CAP * VW;
+  const int64_t c0 = (int64_t)blockIdx.x * kLinCols;
+  const int64_t c1 = c0 + kLinCols < ncols ? c0 + kLinCols : ncols;
+  const int64_t c = c0 + threadIdx.x;
+  const int a0 = Ap[c0], a1 = Ap[c1], b0 = Bp[c0], b1 = Bp[c1];
+  const int nA = a1 - a0, nB = b1 - b0;
+  const bool staged = nA + nB <= CAP;
+  int64_t o0 = 0;
+  int nC = 0;
+  if (FILL) { o0 = Cp[c0]; nC = (int)(Cp[c1] - o0); }
+  if (staged) {
+    // rows and values of both ranges in ONE sweep, sixteen entries per thread in flight (a tile costs three HBM
+    // round trips instead of one per array and batch)
+    const int nT = nA + nB;
+    for (int i0 = 0; i0 < nT; i0 += kLinCols * 16) {
+      int vi[16];
+      double vx[16][VW];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        // no branch around a load (the compiler drains vmcnt at every join): lanes past the end re-read the last entry
+        int i = i0 + u * kLinCols + (int)threadIdx.x;
+        i = i < nT ? i : nT - 1;
+        const bool in_a = i < nA;
+        const int k = in_a ? a0 + i : b0 + (i - nA);
+        const int *pi = in_a ? Ai : Bi;        // one load with a per-lane address, not two predicated ones
+        const double *px = in_a ? Ax : Bx;
+        vi[u] = pi[k];
+        if (FILL) {
+#pragma unroll
+          for (int q = 0; q < VW; ++q) vx[u][q] = px[(size_t)k * VW + q];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int i = i0 + u * kLinCols + (int)threadIdx.x;
+        if (i < nT) {
+          sI[i] = vi[u];
+          if (FILL) {
+#pragma unroll
+            for (int q = 0; q < VW; ++q) sX[(size_t)i * VW + q] = vx[u][q];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (c < ncols) {
+    const int as = Ap[c], bs = Bp[c];
+    const int ae = Ap[c + 1], be = Bp[c + 1];
+    const int64_t oc = FILL ? Cp[c] : 0;
+    // The walk of Sparse.hs:401-431 with the head of each column held in registers: per step ONE round trip to
+    // the staged image (the entry behind the one just consumed), the result written without waiting.  get_* /
+    // put are the staged (LDS) or the global accessors; the arithmetic and its order are those of lin_merge_kernel.
+    auto walk = [&](auto get_ai, auto get_ax, auto get_bi, auto get_bx, auto put) {
+      constexpr int kEnd = 0x7fffffff;
+      int a = as, b = bs, n = 0;
+      int ra = a < ae ? get_ai(a) : kEnd, rb = b < be ? get_bi(b) : kEnd;
+      double xa0 = 0.0, xa1 = 0.0, xb0 = 0.0, xb1 = 0.0;
+      if (FILL) {
+        if (a < ae) get_ax(a, xa0, xa1);
+        if (b < be) get_bx(b, xb0, xb1);
+      }
+      while (ra != kEnd || rb != kEnd) {
+        const bool ta = ra <= rb, tb = rb <= ra;
+        if (FILL) {
+          const int r = ta ? ra : rb;
+          if (VW == 1) {
+            double w = 0.0;                  // SG.reset 0
+            if (ta) w = w + alpha * xa0;     // fA: \r a -> r + alpha * a
+            if (tb) w = w + beta * xb0;      // fB: \r b -> r + beta * b
+            put(n, r, w, 0.0);
+          } else {
+            double wr = 0.0, wi = 0.0;
+            if (ta) { wr = wr + (alpha * xa0 - alpha_im * xa1); wi = wi + (alpha * xa1 + alpha_im * xa0); }
+            if (tb) { wr = wr + (beta * xb0 - beta_im * xb1); wi = wi + (beta * xb1 + beta_im * xb0); }
+            put(n, r, wr, wi);
+          }
+        }
+        ++n;
+        if (ta) { ++a; ra = a < ae ? get_ai(a) : kEnd; if (FILL && a < ae) get_ax(a, xa0, xa1); }
+        if (tb) { ++b; rb = b < be ? get_bi(b) : kEnd; if (FILL && b < be) get_bx(b, xb0, xb1); }
+      }
+      return n;
+    };
+    int n;
+    if (staged)
+      n = walk([&](int k) { return sI[k - a0]; },
+               [&](int k, double &re, double &im) { if (VW == 1) re = sX[k - a0]; else { re = sX[2 * (k - a0)]; im = sX[2 * (k - a0) + 1]; } },
+               [&](int k) { return sI[nA + (k - b0)]; },
+               [&](int k, double &re, double &im) { if (VW == 1) re = sX[nA + (k - b0)]; else { re = sX[2 * (nA + (k - b0))]; im = sX[2 * (nA + (k - b0)) + 1]; } },
+               [&](int k, int r, double re, double im) {
+                 const int q = (int)(oc - o0) + k;
+                 sO[q] = r;
+                 if (VW == 1) sY[q] = re; else { sY[2 * q] = re; sY[2 * q + 1] = im; }
+               });
+    else
+      n = walk([&](int k) { return Ai[k]; },
+               [&](int k, double &re, double &im) { if (VW == 1) re = Ax[k]; else { re = Ax[2 * (size_t)k]; im = Ax[2 * (size_t)k + 1]; } },
+               [&](int k) { return Bi[k]; },
+               [&](int k, double &re, double &im) { if (VW == 1) re = Bx[k]; else { re = Bx[2 * (size_t)k]; im = Bx[2 * (size_t)k + 1]; } },
+               [&](int k, int r, double re, double im) {
+                 const int64_t q = oc + k;
+                 Ci[q] = r;
+                 if (VW == 1) Cx[q] = re; else { Cx[2 * (size_t)q] = re; Cx[2 * (size_t)q + 1] = im; }
+               });
+    if (!FILL) counts[c] = n;
+  }
+  if (FILL && staged) {
+    __syncthreads();
+    lin_copy<int>(Ci + o0, sO, nC);
+    lin_copy<double>(Cx + (size_t)o0 * VW, sY, nC * VW);
+  }
+}
+
+template <bool FILL, int VW>
+size_t lin_tile_lds_bytes() {
+  constexpr size_t CAP = LinTile<VW>::kCap;
+  return FILL ? CAP * 4 * 2 + CAP * VW * 8 * 2 : CAP * 4;
+}
+
 }  // namespace
 
 // COO (device arrays) -> CSC.  Returns SPL_OK / SPL_ERROR_index_out_of_bounds.
 // Outputs: d_newptr[ncols+1] (int32), out_idx/out_val allocated with nnz_out entries.
 int compress_device(int nrows, int ncols, int64_t nnz, const int *d_rows, const int *d_cols,
                     const double *d_vals, int *d_newptr, DBuf<int> &out_idx, DBuf<double> &out_val,
-                    int64_t *nnz_out, int64_t *bad, hipStream_t s) {
+                    int64_t *nnz_out, int64_t *bad, hipStream_t s, bool check_only) {
   *nnz_out = 0;
   if (nnz == 0) {
     SPL_HIP(hipMemsetAsync(d_newptr, 0, ((size_t)ncols + 1) * sizeof(int), s));
@@ -191,6 +357,7 @@ int compress_device(int nrows, int ncols, int64_t nnz, const int *d_rows, const 
       return SPL_ERROR_index_out_of_bounds;
     }
   }
+  if (check_only) return SPL_OK;  // bounds only (spl_matrix_compress_dev keeps the reference's order of complaints)
   DBuf<int> counts((size_t)ncols);
   DBuf<int64_t> colptr((size_t)ncols + 1);
   SPL_HIP(hipMemsetAsync(counts.get(), 0, (size_t)(ncols ? ncols : 1) * sizeof(int), s));
@@ -246,11 +413,31 @@ static void lin_device_any(int vw, double alpha, double alpha_im, const int *Ap,
                            DBuf<int64_t> &Cp, DBuf<int> &Ci, DBuf<double> &Cx, int64_t *nnzC, hipStream_t s) {
   Cp.alloc((size_t)ncols + 1);
   DBuf<int> counts((size_t)ncols);
-  const unsigned grid = blocks_for(ncols, 256);
-  if (ncols > 0)
-    hipLaunchKernelGGL((lin_merge_kernel<false, 1>), dim3(grid), dim3(256), 0, s, alpha, alpha_im, Ap, Ai, Ax, beta,
-                       beta_im, Bp, Bi, Bx, ncols, counts.get(), (const int64_t *)nullptr, (int *)nullptr,
-                       (double *)nullptr);
+  const char *tile_env = getenv("SPL_LIN_TILED");
+  const bool tiled = !(tile_env && tile_env[0] == '0');  // SPL_LIN_TILED=0: the thread-per-column kernels (ablation)
+  const unsigned grid = tiled ? blocks_for(ncols, kLinCols) : blocks_for(ncols, 256);
+  static std::atomic<uint64_t> lds_set{0};
+  const size_t lds_count = lin_tile_lds_bytes<false, 1>(), lds_fill1 = lin_tile_lds_bytes<true, 1>(),
+               lds_fill2 = lin_tile_lds_bytes<true, 2>();
+  int lin_dev = 0;
+  SPL_HIP(hipGetDevice(&lin_dev));
+  if (tiled && !(lds_set.load(std::memory_order_acquire) >> (lin_dev & 63) & 1u)) {
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lin_tile_kernel<true, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fill1));
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lin_tile_kernel<true, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fill2));
+    lds_set.fetch_or(1ull << (lin_dev & 63), std::memory_order_release);
+  }
+  if (ncols > 0) {
+    if (tiled)
+      hipLaunchKernelGGL((lin_tile_kernel<false, 1>), dim3(grid), dim3(kLinCols), lds_count, s, alpha,
+                         alpha_im, Ap, Ai, Ax, beta, beta_im, Bp, Bi, Bx, ncols, counts.get(), (const int64_t *)nullptr,
+                         (int *)nullptr, (double *)nullptr);
+    else
+      hipLaunchKernelGGL((lin_merge_kernel<false, 1>), dim3(grid), dim3(256), 0, s, alpha, alpha_im, Ap, Ai, Ax, beta,
+                         beta_im, Bp, Bi, Bx, ncols, counts.get(), (const int64_t *)nullptr, (int *)nullptr,
+                         (double *)nullptr);
+  }
   exclusive_scan_i32_to_i64(counts.get(), Cp.get(), ncols, s);
   int64_t nz = 0;
   SPL_HIP(hipMemcpyAsync(&nz, Cp.get() + ncols, sizeof(int64_t), hipMemcpyDeviceToHost, s));
@@ -258,7 +445,13 @@ static void lin_device_any(int vw, double alpha, double alpha_im, const int *Ap,
   Ci.alloc((size_t)nz);
   Cx.alloc((size_t)nz * (size_t)vw);
   if (ncols > 0 && nz > 0) {
-    if (vw == 1)
+    if (tiled && vw == 1)
+      hipLaunchKernelGGL((lin_tile_kernel<true, 1>), dim3(grid), dim3(kLinCols), lds_fill1, s, alpha,
+                         alpha_im, Ap, Ai, Ax, beta, beta_im, Bp, Bi, Bx, ncols, (int *)nullptr, Cp.get(), Ci.get(), Cx.get());
+    else if (tiled)
+      hipLaunchKernelGGL((lin_tile_kernel<true, 2>), dim3(grid), dim3(kLinCols), lds_fill2, s, alpha,
+                         alpha_im, Ap, Ai, Ax, beta, beta_im, Bp, Bi, Bx, ncols, (int *)nullptr, Cp.get(), Ci.get(), Cx.get());
+    else if (vw == 1)
       hipLaunchKernelGGL((lin_merge_kernel<true, 1>), dim3(grid), dim3(256), 0, s, alpha, alpha_im, Ap, Ai, Ax, beta,
                          beta_im, Bp, Bi, Bx, ncols, (int *)nullptr, Cp.get(), Ci.get(), Cx.get());
     else

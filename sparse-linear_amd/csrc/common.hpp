@@ -194,7 +194,7 @@ void measure_locality(Matrix *m, hipStream_t s);  // fills new_line_fraction on 
 // ---- assembly (assemble.hip) ------------------------------------------------------------
 int compress_device(int nrows, int ncols, int64_t nnz, const int *d_rows, const int *d_cols,
                     const double *d_vals, int *d_newptr, DBuf<int> &out_idx, DBuf<double> &out_val,
-                    int64_t *nnz_out, int64_t *bad, hipStream_t s);
+                    int64_t *nnz_out, int64_t *bad, hipStream_t s, bool check_only = false);
 bool columns_sorted(const int *d_ptr, const int *d_idx, int64_t ncols, hipStream_t s);
 void lin_device(double alpha, const int *Ap, const int *Ai, const double *Ax, double beta, const int *Bp,
                 const int *Bi, const double *Bx, int64_t ncols, DBuf<int64_t> &Cp, DBuf<int> &Ci,

@@ -217,6 +217,37 @@ class DeviceMatrix(object):
         check("spl_matrix_spgemm", lib().spl_matrix_spgemm(self.handle, other.handle, C.byref(h), C.byref(prod)))
         return DeviceMatrix(h.value), int(prod.value)
 
+    def lin(self, alpha, other, beta):
+        """device-resident alpha * self + beta * other (Sparse.hs:401-431): handle in, handle out"""
+        h = C.c_void_p()
+        a = (C.c_double * 2)(complex(alpha).real, complex(alpha).imag)
+        b = (C.c_double * 2)(complex(beta).real, complex(beta).imag)
+        check("spl_matrix_lin", lib().spl_matrix_lin(self.handle, a, other.handle, b, C.byref(h)))
+        return DeviceMatrix(h.value)
+
+    def to_complex(self):
+        """the Complex Double handle (x :+ 0) of a real one"""
+        h = C.c_void_p()
+        check("spl_matrix_to_complex", lib().spl_matrix_to_complex(self.handle, C.byref(h)))
+        return DeviceMatrix(h.value)
+
+    def transpose(self):
+        """device-resident transpose (Sparse.hs:301-329)"""
+        h = C.c_void_p()
+        check("spl_matrix_transpose", lib().spl_matrix_transpose(self.handle, C.byref(h)))
+        return DeviceMatrix(h.value)
+
+    @classmethod
+    def compress_dev(cls, nrows, ncols, ntriples, rows_ptr, cols_ptr, vals_ptr):
+        """COO triples in device memory (int32, int32, float64 device pointers) -> handle (Sparse.hs:184-280)"""
+        _ffi.require_gpu()
+        h = C.c_void_p()
+        bad = C.c_int64(-1)
+        st = lib().spl_matrix_compress_dev(nrows, ncols, ntriples, C.c_void_p(rows_ptr), C.c_void_p(cols_ptr),
+                                           C.c_void_p(vals_ptr), C.byref(h), C.byref(bad))
+        check("spl_matrix_compress_dev", st)
+        return cls(h.value)
+
     def info(self):
         buf = (C.c_int64 * 8)()
         check("spl_matrix_info", lib().spl_matrix_info(self.handle, buf))
@@ -227,8 +258,11 @@ class DeviceMatrix(object):
         inf = self.info()
         rp = np.zeros(inf["nrows_local"] + 1, dtype=I64)
         ci = np.zeros(max(inf["nnz"], 1), dtype=np.int32)
-        v = np.zeros(max(inf["nnz"], 1), dtype=F64)
+        vw = 2 if self.is_complex else 1
+        v = np.zeros(max(inf["nnz"], 1) * vw, dtype=F64)
         check("spl_matrix_export_csr", lib().spl_matrix_export_csr(self.handle, _ffi.p_i64(rp), p_i32(ci), p_f64(v)))
+        if vw == 2:
+            return rp, ci[:inf["nnz"]], v[:2 * inf["nnz"]].view(np.complex128)
         return rp, ci[:inf["nnz"]], v[:inf["nnz"]]
 
     def export_csr_rows(self, row0, row1):

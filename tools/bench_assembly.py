@@ -43,6 +43,34 @@ def main():
     L = timed("lin", lambda: pkg.lin(2.0, M, -0.5, T), 2 * 12 * nnz + 12 * 2 * nnz)
     # spot checks against the oracle on a small instance happen in tests/; here only the shapes
     out["nnz_compress"], out["nnz_lin"] = int(C.pointers[-1]), int(L.pointers[-1])
+    # the device-resident forms (round 3): handle in, handle out, HIP events around the calls
+    import torch
+    HM, HT = pkg.DeviceMatrix.from_csc(M), pkg.DeviceMatrix.from_csc(T)
+    s = torch.cuda.current_stream()
+
+    def timed_dev(name, fn, bytes_, reps=5):
+        fn().free()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        hs = [fn() for _ in range(reps)]
+        e1.record(s)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        for h in hs[1:]:
+            h.free()
+        out[name] = {"ms": round(ms, 3), "algorithmic_MB": round(bytes_ / 1e6, 1), "GBps_algorithmic": round(bytes_ / ms / 1e6, 1),
+                     "hbm_frac": round(bytes_ / ms / 1e6 / 8000.0, 4)}
+        return hs[0]
+    HL = timed_dev("lin_on_handles", lambda: HM.lin(2.0, HT, -0.5), 2 * 12 * nnz + 12 * 2 * nnz)
+    out["nnz_lin_on_handles"] = HL.info()["nnz"]
+    timed_dev("transpose_on_handles", lambda: HM.transpose(), 2 * (12 * nnz + 4 * n))
+    dr = torch.from_numpy(rows_c.astype(np.int32)).cuda()
+    dc = torch.from_numpy(cols_c.astype(np.int32)).cuda()
+    dv = torch.from_numpy(vals_c).cuda()
+    HC = timed_dev("compress_on_device_triples", lambda: pkg.DeviceMatrix.compress_dev(n, n, k, dr.data_ptr(), dc.data_ptr(), dv.data_ptr()),
+                   16 * k + 12 * nnz)
+    out["nnz_compress_dev"] = HC.info()["nnz"]
     print(json.dumps(out))
 
 
