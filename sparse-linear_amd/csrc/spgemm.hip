@@ -31,7 +31,9 @@
 // One pass when 24 B x products fits in half of the free HBM (every column is written at its
 // upper-bound slot, one copy compacts); otherwise symbolic (count distinct) + scan + numeric.
 // HBM/latency-bound integer + fp64 work; no MFMA (no dense contraction).
+#include <atomic>
 #include <chrono>
+#include <type_traits>
 #include "common.hpp"
 
 namespace spl {
@@ -535,6 +537,295 @@ __global__ __launch_bounds__(256) void spgemm_dense_kernel(Csc A, Csc B, int64_t
     atomicAdd(stamps, t_acc);
     atomicAdd(stamps + 1, t_gather);
     atomicMax(stamps + 2, t_max);
+  }
+}
+
+// bin L, row-range form (round 3).  The dense accumulator above is the reference's own structure: 9 bytes of HBM
+// per row of A and column in flight, random read-modify-writes per product and a sweep of all nrowsA flags per column
+// — 409 019 such columns cost 1.2 of the 1.44 s of a scale-20 product with skewed quadrants.  Here a heavy column
+// is cut into RANGES of rows with at most kRngCap products each, and every range goes through expand - sort -
+// compress in LDS like a column of its own:
+//   (1) the column of B and the extents of the columns of A it selects are staged and prefix-summed (as in esc_column);
+//   (2) all products are enumerated once to count them over 4096 buckets of rows; consecutive buckets are grouped
+//       into ranges (a serial scan by one thread: 4096 additions);
+//   (3) all products are enumerated again and dealt to their ranges in a scratch area in HBM (8 bytes per product:
+//       the key (row - first row of the range) << 11 | q and the position of the entry of A; q, the position of
+//       (k, b) in the column of B, is the tie-break: a column of A has a row at most once, so (row, q) is unique and
+//       ascending q is ascending k) — every load of (2) and (3) is independent of every other, a thread keeps eight
+//       in flight;
+//   (4) a range at a time: its keys are read back, counted into monotone buckets of rows, placed at bucket start +
+//       arrival rank and then at bucket start + number of smaller keys of the bucket (the ordered kernel's rank
+//       sort), run heads fold their run left to right — c + a * b in ascending k, separately rounded multiplies and
+//       adds (Sparse.hs:699): the same bits as every other path — and write row and sum.  Ranges ascend, so the
+//       column comes out in ascending row order with no further pass.
+// (A first version walked a cursor per entry of B through the columns of A range by range: chains of dependent
+// loads, 0.52 s where the dense accumulators take 0.41 s on scale 19.)
+// Not taken (the column is appended to `fallback` and goes to the dense kernel): more than kRngNb entries in the
+// column of B, more than kRngMaxProducts products, a single bucket of rows with more than kRngCap products (hub
+// rows), or more than kRngMaxRanges ranges.
+constexpr int kRngNb = 2048, kRngCap = 2048, kRngBuckets = 4096, kRngTB = 11, kRngSortBuckets = 2048;
+constexpr int kRngMaxRanges = 1024, kRngMaxProducts = 1 << 19;
+constexpr int kRngThreads = 512;  // 8 wavefronts per workgroup, two workgroups per CU: the kernel lives on loads in flight
+constexpr size_t kRngLdsBytes =
+    (size_t)(2 * kRngNb + 8 + kRngBuckets + 8 + 3 * kRngMaxRanges + 16 + 2 * kRngCap + kRngSortBuckets + 8) * 4;
+
+template <bool NUMERIC>
+__global__ __launch_bounds__(kRngThreads) void spgemm_range_kernel(Csc A, Csc B, int64_t nrowsA, const int64_t *__restrict__ list,
+                                                           int nlist, int *__restrict__ counts,
+                                                           const int64_t *__restrict__ Cp, int *__restrict__ Ci,
+                                                           double *__restrict__ Cx, int64_t *__restrict__ fallback,
+                                                           int *__restrict__ nfallback, unsigned *__restrict__ scratch_key,
+                                                           double *__restrict__ scratch_val) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rng_lds[];  // kRngLdsBytes: 72 KB, two workgroups per CU
+  int *cur = reinterpret_cast<int *>(rng_lds), *off = cur + kRngNb;
+  int *hist = off + kRngNb + 8;                 // products per bucket of rows, then (in place) the range of every bucket
+  int *rstart = hist + kRngBuckets + 8;         // first product of range r in the scratch area (kRngMaxRanges + 8)
+  int *rlo = rstart + kRngMaxRanges + 8;        // first row of range r (kRngMaxRanges + 8)
+  int *rfill = rlo + kRngMaxRanges + 8;         // products dealt to range r so far
+  unsigned *keys = reinterpret_cast<unsigned *>(rfill + kRngMaxRanges);
+  int *ppos = reinterpret_cast<int *>(keys + kRngCap);  // where the product of a sorted key sits in the range's scratch segment
+  int *bcount = ppos + kRngCap;                 // kRngSortBuckets + 8
+  constexpr int NT = kRngThreads, NW = NT / 64, PT = kRngCap / NT;  // threads, wavefronts, products per thread and batch
+  __shared__ int wsum[2 * NW], sh_nr, sh_bad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned *gkey = scratch_key + (size_t)blockIdx.x * kRngMaxProducts;
+  double *gval = NUMERIC ? scratch_val + (size_t)blockIdx.x * kRngMaxProducts : nullptr;
+  int shift = 0;
+  while (((int64_t)kRngBuckets << shift) < nrowsA) ++shift;
+  // exclusive prefix sum of arr[0 .. n) in place, arr[n] = total; PER entries per thread (n <= NT * PER)
+  auto scan_arr = [&](int *arr, int n, auto per_tag) {
+    constexpr int PER = decltype(per_tag)::value;
+    int v[PER], sum = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { const int q = tid * PER + u; v[u] = q < n ? arr[q] : 0; sum += v[u]; }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { const int q = tid * PER + u; if (q < n) arr[q] = run; run += v[u]; }
+    if (tid == NT - 1) arr[n] = run;
+    __syncthreads();
+  };
+  typedef std::integral_constant<int, kRngNb / NT> PerNb;            // scans of kRngNb = kRngSortBuckets entries
+  typedef std::integral_constant<int, kRngBuckets / NT> PerBuckets;  // scan of the bucket counts
+  auto find_q = [&](int t, int nb) {  // largest q with off[q] <= t
+    int lo = 0, hi = nb - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (off[mid] <= t) lo = mid; else hi = mid - 1; }
+    return lo;
+  };
+  for (int li = blockIdx.x; li < nlist; li += gridDim.x) {
+    const int64_t j = list[li];
+    const int qs = B.p[j], nb = B.p[j + 1] - qs;
+    if (nb > kRngNb) {
+      if (tid == 0) fallback[atomicAdd(nfallback, 1)] = j;
+      continue;
+    }
+    // (1) the column of B: where each selected column of A starts, how long it is
+    for (int q = tid; q < nb; q += NT) {
+      const int k = B.i[qs + q];
+      const int s0 = A.p[k];
+      cur[q] = s0;
+      off[q] = A.p[k + 1] - s0;
+    }
+    for (int b = tid; b < kRngBuckets; b += NT) hist[b] = 0;
+    for (int r = tid; r < kRngMaxRanges; r += NT) rfill[r] = 0;
+    __syncthreads();
+    scan_arr(off, nb, PerNb());
+    const int np = off[nb];
+    if (np > kRngMaxProducts) {  // (uniform: every thread reads the same total)
+      if (tid == 0) fallback[atomicAdd(nfallback, 1)] = j;
+      __syncthreads();
+      continue;
+    }
+    // (2) products per bucket of rows.  A thread takes PT CONSECUTIVE products of the k-then-row enumeration: one
+    // search for the first, a walk for the others, PT independent loads in flight
+    auto locate8 = [&](int tfirst, int (&pp)[PT], int (&qq)[PT]) {
+      int q = find_q(tfirst < np ? tfirst : np - 1, nb);
+      int nxt = off[q + 1];
+#pragma unroll
+      for (int u = 0; u < PT; ++u) {
+        int t = tfirst + u;
+        t = t < np ? t : np - 1;
+        while (t >= nxt) { ++q; nxt = off[q + 1]; }  // (empty columns of A are skipped)
+        qq[u] = q;
+        pp[u] = cur[q] + (t - off[q]);
+      }
+    };
+    for (int t0 = 0; t0 < np; t0 += NT * PT) {
+      int pp[PT], qq[PT], rr[PT];
+      locate8(t0 + tid * PT, pp, qq);
+#pragma unroll
+      for (int u = 0; u < PT; ++u) rr[u] = A.i[pp[u]];
+#pragma unroll
+      for (int u = 0; u < PT; ++u)
+        if (t0 + tid * PT + u < np) atomicAdd(&hist[rr[u] >> shift], 1);
+    }
+    __syncthreads();
+    // (3a) ranges: consecutive buckets while their products fit kRngCap.  Prefix sums of the bucket counts (all
+    // threads), then one thread finds the end of every range by bisection (a dozen ranges, twelve steps each); a
+    // bucket with more than kRngCap products cannot be taken
+    {
+      int over = 0;
+      for (int b = tid; b < kRngBuckets; b += NT) over |= hist[b] > kRngCap ? 1 : 0;
+      if (tid == 0) sh_bad = 0;
+      __syncthreads();
+      if (over) sh_bad = 1;
+      __syncthreads();
+    }
+    if (sh_bad) {
+      if (tid == 0) fallback[atomicAdd(nfallback, 1)] = j;
+      __syncthreads();
+      continue;
+    }
+    scan_arr(hist, kRngBuckets, PerBuckets());  // hist[b] = products in front of bucket b, hist[kRngBuckets] = np
+    if (tid == 0) {
+      int nr = 0, start = 0, bad = 0;
+      while (start < kRngBuckets) {
+        if (nr >= kRngMaxRanges) { bad = 1; break; }
+        const int p0 = hist[start];
+        int lo = start + 1, hi = kRngBuckets;  // largest e with hist[e] - p0 <= kRngCap (e = start + 1 always fits)
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (hist[mid] - p0 <= kRngCap) lo = mid; else hi = mid - 1; }
+        rstart[nr] = p0;
+        rlo[nr] = start;  // bucket for now, row below
+        ++nr;
+        start = lo;
+      }
+      rstart[nr] = np;
+      rlo[nr] = kRngBuckets;
+      sh_nr = nr;
+      sh_bad = bad;
+    }
+    __syncthreads();
+    if (sh_bad) {
+      if (tid == 0) fallback[atomicAdd(nfallback, 1)] = j;
+      __syncthreads();
+      continue;
+    }
+    for (int b = tid; b < kRngBuckets; b += NT) {  // hist[b] <- range of bucket b: largest r with rlo[r] <= b
+      int lo = 0, hi = sh_nr - 1;
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (rlo[mid] <= b) lo = mid; else hi = mid - 1; }
+      hist[b] = lo;
+    }
+    __syncthreads();
+    for (int r = tid; r <= sh_nr; r += NT) {
+      const int64_t row = (int64_t)rlo[r] << shift;
+      rlo[r] = (int)(row < nrowsA ? row : nrowsA);
+    }
+    __syncthreads();
+    const int nr = sh_nr;
+    // (3b) every product to its range in the scratch area
+    for (int t0 = 0; t0 < np; t0 += NT * PT) {
+      int pp[PT], qq[PT], rr[PT];
+      locate8(t0 + tid * PT, pp, qq);
+#pragma unroll
+      for (int u = 0; u < PT; ++u) rr[u] = A.i[pp[u]];
+      double prod[PT];
+      if (NUMERIC) {  // the product itself travels with the key: a * b, rounded once, here (the fold only adds)
+        double av[PT], bv[PT];
+#pragma unroll
+        for (int u = 0; u < PT; ++u) { av[u] = A.x[pp[u]]; bv[u] = B.x[qs + qq[u]]; }
+#pragma unroll
+        for (int u = 0; u < PT; ++u) prod[u] = av[u] * bv[u];
+      }
+#pragma unroll
+      for (int u = 0; u < PT; ++u)
+        if (t0 + tid * PT + u < np) {
+          const int rid = hist[rr[u] >> shift];
+          const int slot = rstart[rid] + atomicAdd(&rfill[rid], 1);
+          gkey[slot] = ((unsigned)(rr[u] - rlo[rid]) << kRngTB) | (unsigned)qq[u];
+          if (NUMERIC) gval[slot] = prod[u];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int64_t base = NUMERIC ? Cp[j] : 0;
+    int running = 0;
+    // (4) a range at a time
+    for (int r = 0; r < nr; ++r) {
+      const int s0 = rstart[r], npr = rstart[r + 1] - s0;  // <= kRngCap
+      if (npr == 0) continue;  // (uniform)
+      const int lo_row = rlo[r];
+      int bshift = 0;
+      {
+        const int64_t span = (int64_t)rlo[r + 1] - lo_row;
+        while ((span >> bshift) >= kRngSortBuckets) ++bshift;
+      }
+      for (int b = tid; b < kRngSortBuckets; b += NT) bcount[b] = 0;
+      __syncthreads();
+      unsigned mykey[PT];
+      int mypp[PT], mybkt[PT], myarr[PT];
+#pragma unroll
+      for (int u = 0; u < PT; ++u) {
+        const int t = u * NT + tid;
+        const int tc = t < npr ? t : npr - 1;
+        mykey[u] = gkey[s0 + tc];
+        mypp[u] = tc;
+      }
+#pragma unroll
+      for (int u = 0; u < PT; ++u) {
+        mybkt[u] = -1;
+        if (u * NT + tid < npr) {
+          mybkt[u] = (int)((mykey[u] >> kRngTB) >> bshift);
+          myarr[u] = atomicAdd(&bcount[mybkt[u]], 1);
+        }
+      }
+      __syncthreads();
+      scan_arr(bcount, kRngSortBuckets, PerNb());
+#pragma unroll
+      for (int u = 0; u < PT; ++u)
+        if (mybkt[u] >= 0) keys[bcount[mybkt[u]] + myarr[u]] = mykey[u];
+      __syncthreads();
+      int mypos[PT];
+#pragma unroll
+      for (int u = 0; u < PT; ++u) {
+        mypos[u] = -1;
+        if (mybkt[u] >= 0) {
+          const int b0 = bcount[mybkt[u]], b1 = bcount[mybkt[u] + 1];
+          int c = 0;
+          for (int i = b0; i < b1; ++i) c += keys[i] < mykey[u] ? 1 : 0;
+          mypos[u] = b0 + c;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < PT; ++u)
+        if (mypos[u] >= 0) { keys[mypos[u]] = mykey[u]; ppos[mypos[u]] = mypp[u]; }
+      __syncthreads();
+      // compress: run heads in ascending row order; a head folds its run left to right (ascending q = ascending k)
+      for (int t0 = 0; t0 < npr; t0 += NT) {
+        const int t = t0 + tid;
+        bool head = false;
+        unsigned rowl = 0;
+        if (t < npr) {
+          rowl = keys[t] >> kRngTB;
+          head = t == 0 || (keys[t - 1] >> kRngTB) != rowl;
+        }
+        const unsigned long long m = __ballot(head);
+        int offp = running + __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[NW + wave] = __popcll(m);
+        __syncthreads();
+        int total = 0;
+        for (int w = 0; w < NW; ++w) { if (w < wave) offp += wsum[NW + w]; total += wsum[NW + w]; }
+        __syncthreads();
+        if (NUMERIC && head) {
+          double acc = 0.0;  // SG.reset 0
+          for (int u = t; u < npr; ++u) {
+            const unsigned ku = keys[u];
+            if ((ku >> kRngTB) != rowl) break;
+            acc = acc + gval[s0 + ppos[u]];  // c + a * b, the product as rounded in (3)
+          }
+          Ci[base + offp] = (int)rowl + lo_row;
+          Cx[base + offp] = acc;
+        }
+        running += total;
+      }
+    }
+    if (counts && tid == 0) counts[j] = running;
+    __syncthreads();
   }
 }
 
@@ -1527,25 +1818,69 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LXn32::total));
     attr_set = true;
   }
-  int pool = ndense < kMaxPool ? ndense : kMaxPool;
-  {  // keep the accumulator pool under ~32 GB (of 288) and under a quarter of what is free right now (the result
-     // buffers of a single pass are budgeted against half of it below; a busy device gets a smaller pool, not an error)
+  // Heavy columns (bin L): the row-range kernel takes those it can keep in LDS (spgemm_range_kernel), the others —
+  // appended to a second list — go to the dense accumulators, whose pool is only allocated when that list is not empty.
+  int pool = 0;
+  DBuf<unsigned char> pool_flags;
+  DBuf<double> pool_vals;
+  auto ensure_pool = [&](int ncolumns) {
+    if (pool > 0) return;
+    pool = ncolumns < kMaxPool ? ncolumns : kMaxPool;
+    // keep the accumulator pool under ~32 GB (of 288) and under a quarter of what is free right now (the result
+    // buffers of a single pass are budgeted against half of it; a busy device gets a smaller pool, not an error)
     const int64_t per_slot = 9 * (nrowsA > 0 ? nrowsA : 1);
     int64_t budget = (int64_t)32e9;
     const int64_t quarter = (int64_t)(device_free_bytes() / 4);
-    if (ndense > 0 && quarter < budget) budget = quarter;
+    if (quarter < budget) budget = quarter;
     const int64_t cap = budget / per_slot;
     if (pool > cap) pool = (int)(cap < 1 ? 1 : cap);
-  }
-  DBuf<unsigned char> pool_flags;
-  DBuf<double> pool_vals;
-  if (ndense > 0) {
     const size_t flag_stride = ((size_t)nrowsA + 15) & ~(size_t)15;  // spgemm_dense_kernel reads flags 16 at a time
     pool_flags.alloc((size_t)pool * flag_stride);
     pool_vals.alloc((size_t)pool * (size_t)nrowsA);
     SPL_HIP(hipMemsetAsync(pool_flags.get(), 0, (size_t)pool * flag_stride, s));
     SPL_HIP(hipMemsetAsync(pool_vals.get(), 0, (size_t)pool * (size_t)nrowsA * sizeof(double), s));
+  };
+  DBuf<int64_t> fallback_list;
+  DBuf<int> fallback_count;
+  DBuf<unsigned> range_key;
+  DBuf<double> range_val;
+  unsigned range_grid = 0;
+  const char *range_env = getenv("SPL_SPGEMM_RANGE");
+  const bool use_range = ndense > 0 && !(range_env && range_env[0] == '0') && nrowsA <= (1LL << 21);
+  const int64_t *dense_run_list = dense_list.get();
+  if (use_range) {
+    fallback_list.alloc((size_t)ndense);
+    fallback_count.alloc(1);
+    range_grid = (unsigned)(ndense < 512 ? ndense : 512);  // two resident workgroups per CU
+    range_key.alloc((size_t)range_grid * kRngMaxProducts);  // 6 MB of scratch per workgroup: key + product
+    range_val.alloc((size_t)range_grid * kRngMaxProducts);
+    dense_run_list = fallback_list.get();
+    static std::atomic<uint64_t> rng_set{0};
+    int dev = 0;
+    SPL_HIP(hipGetDevice(&dev));
+    if (!(rng_set.load(std::memory_order_acquire) >> (dev & 63) & 1u)) {
+      SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spgemm_range_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRngLdsBytes));
+      SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spgemm_range_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRngLdsBytes));
+      rng_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
   }
+  // runs the row-range kernel over the heavy columns; returns how many are left for the dense accumulators
+  auto run_range = [&](bool numeric, int *cnt, const int64_t *where, int *oi, double *ox) -> int {
+    if (!use_range) return ndense;
+    SPL_HIP(hipMemsetAsync(fallback_count.get(), 0, sizeof(int), s));
+    if (numeric)
+      hipLaunchKernelGGL(spgemm_range_kernel<true>, dim3(range_grid), dim3(kRngThreads), kRngLdsBytes, s, A, B, nrowsA, dense_list.get(),
+                         ndense, cnt, where, oi, ox, fallback_list.get(), fallback_count.get(), range_key.get(), range_val.get());
+    else
+      hipLaunchKernelGGL(spgemm_range_kernel<false>, dim3(range_grid), dim3(kRngThreads), kRngLdsBytes, s, A, B, nrowsA, dense_list.get(),
+                         ndense, cnt, where, oi, ox, fallback_list.get(), fallback_count.get(), range_key.get(), range_val.get());
+    int nfb = 0;
+    SPL_HIP(hipMemcpyAsync(&nfb, fallback_count.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipStreamSynchronize(s));
+    return nfb;
+  };
 
   DBuf<int> Ti;
   DBuf<double> Tx;
@@ -1584,6 +1919,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     hipLaunchKernelGGL((spgemm_wave_kernel<false, false>), dim3(blocks_for(ncolsB, 4)), dim3(256), 0, s, A, B,
                        ncolsB, nprod.get(), counts.get(), (const int64_t *)nullptr, (int *)nullptr,
                        (double *)nullptr);
+    lap("symbolic: one wavefront per column");
     if (nmedium > 0)
       hipLaunchKernelGGL((spgemm_block_kernel<kMediumProducts, kMediumB, false, false>), dim3((unsigned)nmedium),
                          dim3(256), LMs::total, s, A, B, medium_list.get(), nprod.get(), counts.get(),
@@ -1596,10 +1932,18 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
       hipLaunchKernelGGL((spgemm_block_kernel<kLargeProducts, kLargeB, false, false>), dim3((unsigned)nxback),
                          dim3(256), LXs::total, s, A, B, xback_list, nprod.get(), counts.get(),
                          (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
-    if (ndense > 0)
-      hipLaunchKernelGGL(spgemm_dense_kernel<false>, dim3((unsigned)pool), dim3(256), 0, s, A, B, nrowsA,
-                         dense_list.get(), ndense, pool_flags.get(), (double *)nullptr, counts.get(),
-                         (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
+    lap("symbolic: workgroup bins");
+    if (ndense > 0) {
+      const int nfb = run_range(false, counts.get(), (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
+      lap("symbolic: heavy columns, row ranges");
+      if (nfb > 0) {
+        ensure_pool(nfb);
+        hipLaunchKernelGGL(spgemm_dense_kernel<false>, dim3((unsigned)pool), dim3(256), 0, s, A, B, nrowsA,
+                           dense_run_list, nfb, pool_flags.get(), (double *)nullptr, counts.get(),
+                           (const int64_t *)nullptr, (int *)nullptr, (double *)nullptr);
+      }
+    }
+    lap("symbolic: heavy columns, dense accumulators");
     exclusive_scan_i32_to_i64(counts.get(), Cp.get(), ncolsB, s);
     int64_t nz = 0;
     SPL_HIP(hipMemcpyAsync(&nz, Cp.get() + ncolsB, sizeof(int64_t), hipMemcpyDeviceToHost, s));
@@ -1610,6 +1954,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     if (nz == 0) return;
     out_i = Ci.get();
     out_x = Cx.get();
+    lap("scan, result buffers");
   }
 
   // ---- numeric: every path writes its column already sorted by row
@@ -1635,15 +1980,23 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   }
 #undef SPL_NUMERIC_WAVE
 #undef SPL_NUMERIC_BLOCK
+  lap("numeric: wavefront and workgroup bins");
   if (ndense > 0) {
     DBuf<unsigned long long> dstamps;
     if (getenv("SPL_SPGEMM_STAMPS")) {
       dstamps.alloc(4);
       SPL_HIP(hipMemsetAsync(dstamps.get(), 0, 4 * sizeof(unsigned long long), s));
     }
-    hipLaunchKernelGGL(spgemm_dense_kernel<true>, dim3((unsigned)pool), dim3(256), 0, s, A, B, nrowsA,
-                       dense_list.get(), ndense, pool_flags.get(), pool_vals.get(), numeric_counts, slots, out_i,
-                       out_x, dstamps.get());
+    const int nfb = run_range(true, numeric_counts, slots, out_i, out_x);
+    lap("numeric: heavy columns, row ranges");
+    if (nfb > 0) {
+      ensure_pool(nfb);
+      hipLaunchKernelGGL(spgemm_dense_kernel<true>, dim3((unsigned)pool), dim3(256), 0, s, A, B, nrowsA,
+                         dense_run_list, nfb, pool_flags.get(), pool_vals.get(), numeric_counts, slots, out_i,
+                         out_x, dstamps.get());
+    }
+    lap("numeric: heavy columns, dense accumulators");
+    if (getenv("SPL_SPGEMM_TIMING")) fprintf(stderr, "[spgemm] heavy columns: %d, of them %d through the dense accumulators\n", ndense, nfb);
     if (dstamps.get()) {
       unsigned long long h[4];
       SPL_HIP(hipMemcpy(h, dstamps.get(), sizeof(h), hipMemcpyDeviceToHost));
