@@ -61,8 +61,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--no-secondary", action="store_true", help="skip the banded / C4 / C5 block after the timed region")
-    ap.add_argument("--secondary", default="banded,c4,c5:100,c5:200",
-                    help="which secondary configurations to run (comma separated: banded, c4, c5:<m>)")
+    ap.add_argument("--secondary", default="banded,c5:200,c4,c5:100",
+                    help="which secondary configurations to run, in this order (comma separated: banded, c4, c5:<m>); the 200^3 "
+                         "factorisation comes early: it asks the driver for 255 GB, and memory other configurations have just "
+                         "released is still being wiped in the background (DESIGN.md, Device memory)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
