@@ -490,6 +490,34 @@ def test_static_pivoting_random_unsymmetric_mesh(gpu, pkg, O, m, dim, tiny_diag)
         assert _backward_error(op, x, b) <= 1e-13
 
 
+def test_rows_in_random_order_end_on_static_pivoting(gpu, pkg, monkeypatch):
+    """a mesh matrix whose rows arrive in random order: the pattern of A + A^T has no separators, the tree of the
+    speculation can grow beyond the device (tools/fuzz_lu_scale.py, family perm2d: 195 364 unknowns used to return
+    UMFPACK_ERROR_out_of_memory from umfpack_di_numeric where SuperLU solves).  numeric now hands such a matrix to
+    static pivoting, whose transversal undoes the permutation.  The refusal of the speculation is simulated here
+    (SPL_LU_TEST_SPECULATION_OOM) so that the test stays small."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(12)
+    m = 150
+    T = sp.diags([np.ones(m - 1), np.ones(m), np.ones(m - 1)], (-1, 0, 1))
+    P = (sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m))).tocoo()
+    v = 10.0 ** rng.uniform(-3, 3, P.nnz) * rng.choice([-1.0, 1.0], P.nnz)
+    perm = rng.permutation(m * m)
+    S = sp.csc_matrix((v, (perm[P.row], P.col)), shape=(m * m, m * m))
+    S.sort_indices()
+    n = S.shape[0]
+    M = pkg.Matrix(n, n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
+    U = pkg.umfpack
+    monkeypatch.setenv("SPL_LU_TEST_SPECULATION_OOM", "1")
+    fact = U.factor(M, U.analyze(M))
+    assert fact.path == 5
+    xs = rng.uniform(0.5, 1.5, n)
+    for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, sp.csc_matrix(S.T))):
+        b = np.asarray(op @ xs).ravel()
+        x = U.linearSolve_(fact, mode, M, b)
+        assert _backward_error(op, x, b) <= 1e-13
+
+
 def test_solve_many_device_pointers_match_host(gpu, pkg, O):
     """spl_umfpack_{di,zi}_solve_many_dev: right-hand sides and solutions in HBM (torch tensors) — the same
     numbers as the host-array entry points, both systems, real and complex"""
