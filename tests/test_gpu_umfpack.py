@@ -498,7 +498,7 @@ def test_rows_in_random_order_end_on_static_pivoting(gpu, pkg, monkeypatch):
     (SPL_LU_TEST_SPECULATION_OOM) so that the test stays small."""
     import scipy.sparse as sp
     rng = np.random.default_rng(12)
-    m = 150
+    m = 280  # large enough for the refinement with the static-pivoting factors to stall: the FGMRES polish takes over
     T = sp.diags([np.ones(m - 1), np.ones(m), np.ones(m - 1)], (-1, 0, 1))
     P = (sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m))).tocoo()
     v = 10.0 ** rng.uniform(-3, 3, P.nnz) * rng.choice([-1.0, 1.0], P.nnz)
@@ -516,6 +516,34 @@ def test_rows_in_random_order_end_on_static_pivoting(gpu, pkg, monkeypatch):
         b = np.asarray(op @ xs).ravel()
         x = U.linearSolve_(fact, mode, M, b)
         assert _backward_error(op, x, b) <= 1e-13
+
+
+def test_stalled_static_pivoting_is_polished_by_fgmres(gpu, pkg, monkeypatch):
+    """299 209 unknowns of the perm2d family of tools/fuzz_lu_scale.py (5-point mesh, values 10^U(-3, 3) with random
+    signs, rows in random order): the speculation does not fit, static pivoting factors, its refinement stops at a
+    backward error of 5e-10 and the pivoted band does not fit — this used to be status -1.  The FGMRES polish
+    preconditioned by the factors held takes the backward error to rounding level; without it (SPL_LU_GMRES=0) the
+    refined solution is still returned (<= 1e-9)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    m = 547
+    T = sp.diags([np.ones(m - 1), np.ones(m - 1)], (-1, 1))
+    P = (sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m)) + sp.identity(m * m)).tocoo()
+    v = 10.0 ** rng.uniform(-3, 3, P.nnz) * rng.choice([-1.0, 1.0], P.nnz)
+    perm = rng.permutation(m * m)
+    S = sp.csc_matrix((v, (perm[P.row], P.col)), shape=(m * m, m * m))
+    S.sort_indices()
+    n = S.shape[0]
+    M = pkg.Matrix(n, n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
+    U = pkg.umfpack
+    xs = rng.uniform(0.5, 1.5, n)
+    b = np.asarray(S @ xs).ravel()
+    fact = U.factor(M, U.analyze(M))
+    x = U.linearSolve_(fact, U.UmfpackNormal, M, b)
+    assert fact.path == 5 and _backward_error(S, x, b) <= 1e-13
+    monkeypatch.setenv("SPL_LU_GMRES", "0")
+    x0 = U.linearSolve_(fact, U.UmfpackNormal, M, b)
+    assert 1e-13 < _backward_error(S, x0, b) <= 1e-9
 
 
 def test_solve_many_device_pointers_match_host(gpu, pkg, O):
