@@ -11,7 +11,7 @@ mkdir -p "$out"
 run() {  # name, rocprofv3 args...
   local name=$1; shift
   echo "[profile] $name" | tee -a "$out/progress.log"
-  timeout -k 10 300 rocprofv3 "$@" --output-format csv -d "$out/$name" -- python3 bench.py --no-cpu-baseline "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1
+  timeout -k 10 300 rocprofv3 "$@" --output-format csv -d "$out/$name" -- python3 bench.py --no-cpu-baseline --no-secondary "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1
   echo "[profile] $name rc=$?" | tee -a "$out/progress.log"
 }
 BENCH_ARGS=(--steps 20 --warmup 3 "$@")
