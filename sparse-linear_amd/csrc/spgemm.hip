@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void products_kernel(Csc A, Csc B, int64_t nco
                                                        int64_t *__restrict__ xlarge_list,
                                                        int64_t *__restrict__ dense_list,
                                                        int *__restrict__ list_counts, int ordered, int ord_cap,
-                                                       int ord_nb) {
+                                                       int ord_nb, int x_heavy) {
   // 8 lanes per column of B: the extents of the selected columns of A are independent loads
   const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
   const int sub = threadIdx.x & 7;
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void products_kernel(Csc A, Csc B, int64_t nco
   if (owner) {
     nprod[j] = n;
     bin = bin_of(n, qe - qs);
+    if (x_heavy && bin == 3) bin = 4;  // columns of 2049 .. 4096 products with the heavy ones (row-range kernel)
     // ordered form: the columns its own kernel handles (<= ord_cap products, <= ord_nb entries of B) are not listed;
     // every other column must be, also a light one with a long column of B (bin S has no list: it goes with M)
     if (ordered && n > 0) bin = (n <= ord_cap && qe - qs <= ord_nb) ? 1 : (bin < 2 ? 2 : bin);
@@ -1742,12 +1743,17 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   // kernel runs 32; profiles/r02_spgemm_ordered_phases.txt).  It is taken when at least half of the products
   // belong to columns of 513 ... 2048 products; SPL_SPGEMM_ORDERED=1 / 0 forces / forbids it.  Its packed 32-bit keys need
   // nrows < 2^21 (strictly: the key of row 2^21 - 1 with the last tie-break position is the 0xffffffff "no product" sentinel).
+  const char *xh_env = getenv("SPL_SPGEMM_X_AS_HEAVY");
+  // Columns of 2049 .. 4096 products (bin X) go with the heavy ones through the row-range kernel: its counting + rank
+  // sort beats the merge tree of the workgroup kernels there (scale 20, edge factor 44: 0.0616 -> 0.0527 s, 48: 0.0885 ->
+  // 0.0691 s).  SPL_SPGEMM_X_AS_HEAVY=0 keeps them in bin X.
+  const int x_heavy = (!(xh_env && xh_env[0] == '0') && nrowsA <= (1LL << 21)) ? 1 : 0;
   const char *ord_env = getenv("SPL_SPGEMM_ORDERED");
   const char *two_pass_env = getenv("SPL_SPGEMM_TWO_PASS"), *split_keys_env = getenv("SPL_SPGEMM_SPLIT_KEYS");
   const bool ordered_possible = !(ord_env && ord_env[0] == '0') && nrowsA < (1LL << kOrdMaxRowBits) &&
                                 !(two_pass_env && two_pass_env[0] == '1') && !(split_keys_env && split_keys_env[0] == '1');
   hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 32)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
-                     medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 0, 0, 0);
+                     medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 0, 0, 0, x_heavy);
   int hc[4] = {0, 0, 0, 0};
   SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   SPL_HIP(hipStreamSynchronize(s));
@@ -1789,7 +1795,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   if (ordered) {  // the columns the ordered kernel handles itself leave the bin lists
     SPL_HIP(hipMemsetAsync(list_counts.get(), 0, 4 * sizeof(int), s));
     hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 32)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
-                       medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 1, ord_cap, ord_nb);
+                       medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 1, ord_cap, ord_nb, x_heavy);
     SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     SPL_HIP(hipStreamSynchronize(s));
   }
