@@ -452,8 +452,9 @@ def main():
             try:
                 if item == "banded":
                     secondary["c2_banded_spmv"] = sec.banded_c2(pkg, torch, n=n, draws=args.draws, steps=args.steps)
-                elif item == "c4":
-                    secondary["c4_spgemm_rmat20"] = sec.spgemm_c4(pkg, torch)
+                elif item == "c4" or item.startswith("c4:"):  # c4:<scale> (tests): a smaller R-MAT matrix, same code
+                    scale = int(item[3:]) if item.startswith("c4:") else 20
+                    secondary["c4_spgemm_rmat%d" % scale] = sec.spgemm_c4(pkg, torch, scale=scale, cpu_rows=min(2048, 1 << scale))
                 elif item.startswith("c5:"):
                     m = int(item[3:])
                     torch.cuda.empty_cache()
