@@ -134,7 +134,31 @@ def spgemm_c4(pkg, torch, scale=20, edge_factor=32, abc=(0.25, 0.25, 0.25), reps
     return out
 
 
-def lu_c5(pkg, torch, m=100):
+def _superlu_sample(pkg, ms=32):
+    """CPU stand-in on a bounded sample: scipy's SuperLU on the ms^3 grid (its fill makes larger grids take minutes:
+    48^3 43.8 s, profiles/r02_solve_ladder_poisson3d.json).  No libumfpack exists in this pipeline."""
+    import numpy as np
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    H = pkg.DeviceMatrix.synthetic("poisson3d", ms)
+    rp, ci, v = H.export_csr()
+    H.free()
+    n = ms ** 3
+    S = sp.csc_matrix((v, ci, rp), shape=(n, n))
+    xs = np.random.default_rng(0xBEEF).uniform(0.5, 1.5, n)
+    b = S @ xs
+    t = time.perf_counter()
+    lu = spla.splu(S)
+    tf = time.perf_counter() - t
+    t = time.perf_counter()
+    x = lu.solve(b)
+    ts = time.perf_counter() - t
+    return {"value": round(tf + ts, 3), "unit": "s", "cores": 1, "kind": "stand-in: scipy SuperLU splu (no libumfpack in this pipeline)",
+            "sample": "%d^3 grid (n=%d): factor %.2f s, solve %.3f s, fill %d, max rel. error %.1e"
+                      % (ms, n, tf, ts, int(lu.L.nnz + lu.U.nnz), float(np.max(np.abs(x - xs) / np.abs(xs))))}
+
+
+def lu_c5(pkg, torch, m=100, cpu_sample=0):
     import numpy as np
     import scipy.sparse as sp
     U = pkg.umfpack
@@ -180,4 +204,6 @@ def lu_c5(pkg, torch, m=100):
     del fa, an
     gc.collect()
     pkg._ffi.release_cached_memory()
+    if cpu_sample:
+        out["cpu_baseline"] = _superlu_sample(pkg, cpu_sample)
     return out
