@@ -572,7 +572,7 @@ constexpr size_t kRngLdsBytes =
 
 template <bool NUMERIC>
 __global__ __launch_bounds__(kRngThreads) void spgemm_range_kernel(Csc A, Csc B, int64_t nrowsA, const int64_t *__restrict__ list,
-                                                           int nlist, int *__restrict__ counts,
+                                                           int nlist, const int64_t *__restrict__ nprod, int *__restrict__ counts,
                                                            const int64_t *__restrict__ Cp, int *__restrict__ Ci,
                                                            double *__restrict__ Cx, int64_t *__restrict__ fallback,
                                                            int *__restrict__ nfallback, unsigned *__restrict__ scratch_key,
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(kRngThreads) void spgemm_range_kernel(Csc A, Csc B,
   for (int li = blockIdx.x; li < nlist; li += gridDim.x) {
     const int64_t j = list[li];
     const int qs = B.p[j], nb = B.p[j + 1] - qs;
-    if (nb > kRngNb) {
+    if (nb > kRngNb || nprod[j] > (int64_t)kRngMaxProducts) {  // (the 64-bit count: the prefix sums below are 32-bit)
       if (tid == 0) fallback[atomicAdd(nfallback, 1)] = j;
       continue;
     }
@@ -1878,10 +1878,10 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     SPL_HIP(hipMemsetAsync(fallback_count.get(), 0, sizeof(int), s));
     if (numeric)
       hipLaunchKernelGGL(spgemm_range_kernel<true>, dim3(range_grid), dim3(kRngThreads), kRngLdsBytes, s, A, B, nrowsA, dense_list.get(),
-                         ndense, cnt, where, oi, ox, fallback_list.get(), fallback_count.get(), range_key.get(), range_val.get());
+                         ndense, nprod.get(), cnt, where, oi, ox, fallback_list.get(), fallback_count.get(), range_key.get(), range_val.get());
     else
       hipLaunchKernelGGL(spgemm_range_kernel<false>, dim3(range_grid), dim3(kRngThreads), kRngLdsBytes, s, A, B, nrowsA, dense_list.get(),
-                         ndense, cnt, where, oi, ox, fallback_list.get(), fallback_count.get(), range_key.get(), range_val.get());
+                         ndense, nprod.get(), cnt, where, oi, ox, fallback_list.get(), fallback_count.get(), range_key.get(), range_val.get());
     int nfb = 0;
     SPL_HIP(hipMemcpyAsync(&nfb, fallback_count.get(), sizeof(int), hipMemcpyDeviceToHost, s));
     SPL_HIP(hipStreamSynchronize(s));
