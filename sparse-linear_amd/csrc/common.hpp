@@ -220,7 +220,7 @@ struct Factors;
 size_t mf_device_bytes(const mf::Tree &T);
 mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, const int *d_Ai, const double *d_Ax,
                        const int *d_Rp, const int *d_Rj, const double *d_Rx, const int *d_perm, const int *d_inv,
-                       hipStream_t s);
+                       hipStream_t s, bool symmetric = false);
 int mf_singular(const mf::Factors *F);
 void mf_solve(const mf::Factors *F, int sys, double *d_c, int k, size_t stride, hipStream_t s);
 void mf_free(mf::Factors *F);

@@ -23,6 +23,12 @@ constexpr int NB = 64;   // panel width
 struct Band {
   double *AB;
   int n, kl, ku, ldab, doff;
+  // sym = 1 (multifrontal fronts of a matrix with A == A^T, round 3): LU without interchanges of a symmetric matrix
+  // is L D L^T, U = D L^T.  Then the pivot rows are not solved for but written as the scaled transposes of the pivot
+  // columns (trsm_tile), and the trailing update only computes the tiles on and below the diagonal (update_tile): half
+  // the flops of the update, which is 89 % of the factorisation at config C5.  Entries above the diagonal TILES of a
+  // trailing block are stale from then on; nothing reads them (extend_add_kernel mirrors the lower triangle).
+  int sym = 0;
   __device__ __forceinline__ bool in_band(int i, int j) const { return i - j <= kl && j - i <= ku; }
   __device__ __forceinline__ double &at(int i, int j) const {
     return AB[(size_t)(doff + i) + (size_t)j * (size_t)(ldab - 1)];
@@ -30,7 +36,7 @@ struct Band {
   __device__ __forceinline__ double get(int i, int j) const { return in_band(i, j) ? at(i, j) : 0.0; }
 };
 inline Band band_view(double *AB, int n, int kl, int ku, int ldab) { return Band{AB, n, kl, ku, ldab, ku}; }
-inline Band dense_view(double *F, int n, int ld) { return Band{F, n, n, n, ld + 1, 0}; }
+inline Band dense_view(double *F, int n, int ld, int sym = 0) { return Band{F, n, n, n, ld + 1, 0, sym}; }
 
 // ---- factorisation ----------------------------------------------------------------------------
 typedef double double4v __attribute__((ext_vector_type(4)));
@@ -217,6 +223,7 @@ __device__ __forceinline__ void trsm_tile(const Band &b, int j0, int jb, int nro
   const int tid = threadIdx.x;
   const int ntile_l = (nrows_below + 63) / 64;
   const bool is_l = tile < ntile_l;
+  if (b.sym && !is_l) return;  // the pivot rows come from the L tiles below (U12 = D L21^T)
   const int rend = j0 + jb + nrows_below, cend = j0 + jb + ncols_right;
   const int lo = tid % 64, hi = tid / 64;  // t = tid + 256 u  ->  t % 64 = lo, t / 64 = hi + 4 u
   int r0, c0;
@@ -263,7 +270,10 @@ __device__ __forceinline__ void trsm_tile(const Band &b, int j0, int jb, int nro
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = r0 + p.row(c), j = c0 + p.col(a, r);
-        if (i < rlim && j < clim && b.in_band(i, j)) b.at(i, j) = acc[a][c][r];
+        if (i < rlim && j < clim && b.in_band(i, j)) {
+          b.at(i, j) = acc[a][c][r];
+          if (b.sym) b.at(j, i) = b.at(j, j) * acc[a][c][r];  // U(j, i) = d_j L(i, j), d_j = U11(j, j) (diag_block_factor stored it)
+        }
       }
 }
 
@@ -302,6 +312,7 @@ __device__ __forceinline__ void update_tile(const Band &b, const Region &g, int 
                                             int *__restrict__ singular, double *__restrict__ next_invL,
                                             double *__restrict__ next_invU, double *dsm) {
   const int r0 = g.rb + tx * 64, c0 = g.cb + ty * 64;
+  if (b.sym && c0 > r0) return;  // symmetric fronts: only the tiles on and below the diagonal (rb == cb)
   if (r0 - (c0 + 63) > b.kl || c0 - (r0 + 63) > b.ku) return;  // tile entirely outside the band
   double(*Us)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);            // Us[k][c] = U(kb + k, c0 + c)
   double(*Ls)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + KS * LDP);  // Ls[k][r] = L(r0 + r, kb + k)

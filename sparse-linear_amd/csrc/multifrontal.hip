@@ -48,6 +48,7 @@ struct TreeView {  // raw pointers for kernels
   double *arena;      // factor panels (resident)
   const int64_t *cboff;  // >= 0: the Schur complement of this front was saved to `cut` (nb x nb, ld nb)
   double *cut;
+  int sym;  // 1: A == A^T, the fronts are factored as L D L^T (Band::sym)
   __device__ __forceinline__ double *front(int f) const { return region[depth[f] & 1] + foff[f]; }
 };
 
@@ -147,9 +148,14 @@ __global__ __launch_bounds__(256) void extend_add_kernel(const int *__restrict__
   for (int u = 0; u < 4; ++u) {
     const int cc = cc0 + u;
     if (cc >= nb) break;
+    if (t.sym && cc > r) break;  // symmetric fronts: the child's lower triangle only (what lies above its diagonal tiles is stale)
     const double v = saved >= 0 ? t.cut[saved + (int64_t)r + (int64_t)cc * nb]
                                 : t.front(c)[(int64_t)(npc + r) + (int64_t)(npc + cc) * t.ld[c]];
     dst[(int64_t)rel[cc] * ldp] += v;
+    // ... mirrored into the parent's upper triangle: its diagonal tiles are read whole.  (r, cc) and (cc, r) of
+    // different children never meet in one word at a time other than through += of distinct threads of ONE launch
+    // on distinct addresses: (rel[cc], rel[r]) is written by this thread only
+    if (t.sym && cc != r) t.front(p)[(int64_t)rel[cc] + (int64_t)rel[r] * ldp] += v;
   }
 }
 
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int np = t.np[f];
   if (np == 0) return;
   const int fs = np + t.nb[f];
-  const Band b{t.front(f), fs, fs, fs, t.ld[f] + 1, 0};
+  const Band b{t.front(f), fs, fs, fs, t.ld[f] + 1, 0, t.sym};
   front_factor_by_workgroup(b, np, invs + t.ioff[f], singular, dsm);
 }
 
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // K = 64 update whose tile (0,0) factors the next diagonal block on the way (the look-ahead).
 __device__ __forceinline__ Band mid_front(const TreeView &t, int f) {
   const int fs = t.np[f] + t.nb[f];
-  return Band{t.front(f), fs, fs, fs, t.ld[f] + 1, 0};
+  return Band{t.front(f), fs, fs, fs, t.ld[f] + 1, 0, t.sym};
 }
 __device__ __forceinline__ double *mid_slot(const TreeView &t, double *invs, int f, int j0) {
   return invs + t.ioff[f] + (int64_t)(j0 / NB) * (2 * NB * NB);
@@ -800,7 +806,7 @@ size_t mf_device_bytes(const mf::Tree &T) {  // resident part; the transient par
 // arrays, d_perm: new -> old, d_inv: old -> new
 mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, const int *d_Ai, const double *d_Ax,
                        const int *d_Rp, const int *d_Rj, const double *d_Rx, const int *d_perm, const int *d_inv,
-                       hipStream_t s) {
+                       hipStream_t s, bool symmetric) {
   const mf::Tree &T = *tree;
   const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // phase times on stderr (diagnostic)
   auto clock_now = [] { return std::chrono::steady_clock::now(); };
@@ -885,7 +891,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   F.view = TreeView{D.p0.get(),    D.np.get(),   D.nb.get(),   D.ld.get(),   D.parent.get(), D.front_of.get(),
                     D.bidx.get(),  D.rel.get(),  D.depth.get(), D.ldp.get(), D.ldu.get(),    D.bptr.get(),
                     F.d_foff.get(), D.ioff.get(), D.woff.get(), D.roff.get(), D.poff.get(),  D.uoff.get(),
-                    {region0.get(), region1.get()}, F.arena.get(), F.d_cboff.get(), cutbuf.get()};
+                    {region0.get(), region1.get()}, F.arena.get(), F.d_cboff.get(), cutbuf.get(), symmetric ? 1 : 0};
   F.level_lists.resize((size_t)nd);
   F.small_lists.resize((size_t)nd);
   F.small_counts.assign((size_t)nd, 0);
@@ -1147,7 +1153,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
       for (int i = b0; i < b1; ++i) {
         const int f = T.by_depth[(size_t)d][(size_t)i];
         if (T.np[(size_t)f] == 0 || T.fs(f) <= mid_limit) continue;
-        const Band b = dense_view(region_of(d) + plan.foff[(size_t)f], T.fs(f), T.ld[(size_t)f]);
+        const Band b = dense_view(region_of(d) + plan.foff[(size_t)f], T.fs(f), T.ld[(size_t)f], symmetric ? 1 : 0);
         const int lane = turn++ % kStreams;
         factor_loop(b, T.np[(size_t)f], F.invs.get() + T.ioff[(size_t)f], singular.get(), side[lane], side[kStreams + lane]);
       }

@@ -61,6 +61,7 @@ struct Numeric {
   int n = 0, kl = 0, ku = 0, ldab = 1;
   int singular = 0;
   int nopiv = 0;  // 1: blocked factorisation without interchanges
+  int mf_sym = 0;  // 1: the multifrontal factors held are those of a symmetric matrix (L D L^T: half the update flops)
   // set when a refactorisation failed after the previous factors were released: the object holds no
   // usable factors any more and every later solve returns an error instead of launching kernels
   std::atomic<int> broken{0};
@@ -525,6 +526,38 @@ void set_ordering(Numeric *N, const std::vector<int> &perm, const std::vector<in
   SPL_HIP(hipStreamSynchronize(s));
 }
 
+// A == A^T exactly?  The row-major images of A and of A^T (both with ascending columns inside a row) are then the same
+// arrays, bit for bit.
+__global__ __launch_bounds__(256) void same_csr_kernel(int64_t n, int64_t nnz, const int *__restrict__ p1, const int *__restrict__ p2,
+                                                       const int *__restrict__ i1, const int *__restrict__ i2,
+                                                       const double *__restrict__ x1, const double *__restrict__ x2,
+                                                       int *__restrict__ differ) {
+  bool bad = false;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz + n + 1; k += (int64_t)gridDim.x * blockDim.x) {
+    if (k < nnz) bad |= i1[k] != i2[k] || __double_as_longlong(x1[k]) != __double_as_longlong(x2[k]);
+    else bad |= p1[k - nnz] != p2[k - nnz];
+  }
+  if (bad) *differ = 1;
+}
+
+static bool matrix_is_symmetric(const Numeric *N, hipStream_t s) {
+  const char *e = getenv("SPL_LU_SYMMETRIC");
+  if (e && e[0] == '0') return false;
+  const Matrix *A = N->A, *At = N->At;
+  if (!A || !At || A->nnz != At->nnz || !A->rowptr.get() || !At->rowptr.get()) return false;
+  DBuf<int> differ(1);
+  SPL_HIP(hipMemsetAsync(differ.get(), 0, sizeof(int), s));
+  const int64_t total = A->nnz + (int64_t)N->n + 1;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(same_csr_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (int64_t)N->n, A->nnz, A->rowptr.get(),
+                     At->rowptr.get(), A->colidx.get(), At->colidx.get(), A->val.get(), At->val.get(), differ.get());
+  int h = 1;
+  SPL_HIP(hipMemcpyAsync(&h, differ.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+  SPL_HIP(hipStreamSynchronize(s));
+  return h == 0;
+}
+
 // multifrontal factors without interchanges on the nested-dissection tree (multifrontal.hip)
 void factor_multifrontal(Numeric *N, hipStream_t s) {
   N->AB.release();
@@ -534,8 +567,11 @@ void factor_multifrontal(Numeric *N, hipStream_t s) {
   if (mf_device_bytes(*N->tree) > free_b - free_b / 8) throw DeviceError{SPL_ERROR_out_of_memory};
   N->nopiv = 1;
   if (!N->A->rowptr.get()) throw DeviceError{SPL_ERROR_index_overflow};  // int32 row pointers at this seam
+  // a symmetric matrix (exactly: A == A^T) is factored as L D L^T on the same fronts: the trailing updates only
+  // compute the tiles on and below the diagonal (Band::sym, csrc/dense_lu_kernels.hpp); SPL_LU_SYMMETRIC=0: plain LU
+  N->mf_sym = matrix_is_symmetric(N, s) ? 1 : 0;
   N->mfact = mf_factor(N->tree, N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), N->A->rowptr.get(),
-                       N->A->colidx.get(), N->A->val.get(), N->perm.get(), N->inv.get(), s);
+                       N->A->colidx.get(), N->A->val.get(), N->perm.get(), N->inv.get(), s, N->mf_sym != 0);
   N->singular = mf_singular(N->mfact);
 }
 
@@ -608,6 +644,7 @@ bool factor_static_pivot(Numeric *N, const int *Ap, const int *Ai, const double 
     N->spA = B.release();
     N->spAt = Bt.release();
     N->nopiv = 1;
+    N->mf_sym = 0;  // B = Dr P A Dc is not symmetric
     N->mfact = mf_factor(N->tree, N->spAt->rowptr.get(), N->spAt->colidx.get(), N->spAt->val.get(), N->spA->rowptr.get(),
                          N->spA->colidx.get(), N->spA->val.get(), N->perm.get(), N->inv.get(), s);
     if (mf_singular(N->mfact)) {  // a zero pivot: these factors are useless; the band fallback rebuilds everything
@@ -1266,7 +1303,7 @@ int spl_umfpack_stats(void *NumericIn, double out[8]) {
   out[1] = (double)N->n;
   if (N->mfact) {
     out[4] = (double)mf_device_bytes(*N->tree);
-    out[5] = N->tree->flops;
+    out[5] = N->mf_sym ? 0.5 * N->tree->flops : N->tree->flops;  // L D L^T on the same fronts: about half the flops of LU
     out[6] = (double)N->tree->nfronts;
   } else {
     out[2] = (double)N->kl;

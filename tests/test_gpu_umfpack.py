@@ -601,3 +601,78 @@ def test_static_pivoting_complex_mesh(gpu, pkg):
         assert _backward_error(op, x, b) <= 1e-12
         xd = U.linearSolveManyDevice_(fact, mode, M, torch.from_numpy(b[None, :].copy()).cuda()).cpu().numpy()[0]
         assert _backward_error(op, xd, b) <= 1e-12
+
+
+# ---- symmetric matrices: L D L^T on the same fronts (csrc/dense_lu_kernels.hpp Band::sym)
+@pytest.mark.parametrize("limits", ["default", "small"])
+@pytest.mark.parametrize("kind,m", [("2d", 45), ("2d", 130), ("3d", 22), ("indef", 90)])
+def test_symmetric_matrix_is_factored_as_ldlt(gpu, pkg, O, kind, m, limits, monkeypatch):
+    """A == A^T exactly: the tree runs in its symmetric mode (U12 = D L21^T instead of a second triangular solve, the
+    trailing update only on and below the diagonal, extend-add mirrors the lower triangle) — half the flops in the
+    statistics, and the solutions of both systems those of the plain LU of the same fronts (SPL_LU_SYMMETRIC=0) to
+    1e-10.  "indef": a shifted Laplacian with eigenvalues of both signs (symmetric indefinite: D has both signs; the
+    speculation without interchanges is checked by its backward error as for any matrix).  "small": the size classes
+    lowered so that lockstep, multi-launch and many-workgroup code all run on these trees."""
+    import scipy.sparse as sp
+    if limits == "small":
+        monkeypatch.setenv("SPL_MF_SMALL", "64")
+        monkeypatch.setenv("SPL_MF_MIDMAX", "512")
+        monkeypatch.setenv("SPL_MF_BIGSOLVE", "64")
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    rng = np.random.default_rng(m)
+    if kind == "indef":
+        T = sp.diags([-np.ones(m - 1), 2.0 * np.ones(m), -np.ones(m - 1)], (-1, 0, 1))
+        W = sp.triu(sp.random(m * m, m * m, density=2.0 / (m * m), random_state=3, data_rvs=lambda k: rng.uniform(-0.3, 0.3, k)), 1)
+        S = sp.csc_matrix(sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m)) - 1.2345 * sp.identity(m * m) + W + W.T)
+        S.sort_indices()
+        n = m * m
+        A = pkg.Matrix(n, n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
+    else:
+        n, A = _grid_matrix(pkg, O, kind, m)
+        S = csc_tuple_to_scipy(mat_to_tuple(A))
+    U = pkg.umfpack
+    bs = [rng.uniform(0.5, 1.5, n) for _ in range(2)]
+    fs = U.factor(A, U.analyze(A))
+    monkeypatch.setenv("SPL_LU_SYMMETRIC", "0")
+    fl = U.factor(A, U.analyze(A))
+    monkeypatch.delenv("SPL_LU_SYMMETRIC")
+    assert fs.path == fl.path == (4 if kind == "indef" else 3)  # 4: not diagonally dominant, the factors are a speculation
+    assert fs.stats["flops"] == 0.5 * fl.stats["flops"] and fs.stats["fronts"] == fl.stats["fronts"]
+    for mode in (U.UmfpackNormal, U.UmfpackTrans):
+        xs = U.linearSolveMany_(fs, mode, A, bs)
+        xl = U.linearSolveMany_(fl, mode, A, bs)
+        for p, q, b in zip(xs, xl, bs):
+            assert O.count_not_close(p, q, 1e-10) == 0
+            assert _backward_error(S, p, b) <= 1e-13
+
+
+def test_almost_symmetric_matrix_takes_plain_lu(gpu, pkg, O, monkeypatch):
+    """one value off by one ulp, or one entry present on one side only: not symmetric, the plain LU runs (full flops)
+    and solves both systems"""
+    import scipy.sparse as sp
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    m = 40
+    n, A0 = _grid_matrix(pkg, O, "2d", m)
+    S0 = csc_tuple_to_scipy(mat_to_tuple(A0)).tocsc()
+    U = pkg.umfpack
+    full = None
+    for variant in ("sym", "ulp", "pattern"):
+        S = S0.copy()
+        if variant == "ulp":
+            k = S.indptr[7]  # entry (6, 7): off the diagonal
+            assert S.indices[k] == 6
+            S.data[k] = np.nextafter(S.data[k], 0.0)
+        elif variant == "pattern":
+            S = sp.csc_matrix(S + sp.csc_matrix(([0.125], ([3], [n - 5])), shape=(n, n)))
+        S.sort_indices()
+        A = pkg.Matrix(n, n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
+        f = U.factor(A, U.analyze(A))
+        assert f.path == 3
+        monkeypatch.setenv("SPL_LU_SYMMETRIC", "0")
+        full = U.factor(A, U.analyze(A)).stats["flops"]  # the same tree as plain LU
+        monkeypatch.delenv("SPL_LU_SYMMETRIC")
+        assert f.stats["flops"] == (0.5 * full if variant == "sym" else full)
+        xs = np.random.default_rng(5).uniform(0.5, 1.5, n)
+        for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, sp.csc_matrix(S.T))):
+            b = np.asarray(op @ xs).ravel()
+            assert _backward_error(op, U.linearSolve_(f, mode, A, b), b) <= 1e-13

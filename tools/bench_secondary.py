@@ -189,14 +189,27 @@ def lu_c5(pkg, torch, m=100, cpu_sample=0):
     st = fa.stats
     err = float(np.max(np.abs(x - xs) / np.abs(xs)))
     res = float(np.max(np.abs(S @ x - b)) / (np.max(np.abs(b)) + 6 * np.max(np.abs(x))))
+    # the same matrix factored again with the same analysis (what FEAST does per contour point): its panels and fronts
+    # come back from the library's pool — the steady state, free of what the driver does to freshly released memory
+    del fa
+    gc.collect()
+    t4 = time.perf_counter()
+    fa = U.factor(A, an)
+    torch.cuda.synchronize()
+    t5 = time.perf_counter()
+    steady = t5 - t4
+    total = (t1 - t0) + steady + (t3 - t2)
+    rate = st["flops"] / max(steady, 1e-9) * 1e-12
     out = {"workload": "sparse LU + triangular solves, 3-D 7-point Poisson %d^3: n=%d nnz=%d, umfpack_di_symbolic/numeric/solve"
                        % (m, n, int(rp[-1])),
-           "value": round(t3 - t0, 3), "unit": "s", "higher_is_better": False,
-           "analyze_s": round(t1 - t0, 3), "factor_s": round(t2 - t1, 3), "solve_s": round(t3 - t2, 3),
+           "value": round(total, 3), "unit": "s", "higher_is_better": False,
+           "value_is": "analyze + factor (steady state: second factorisation with the same analysis) + solve, as DESIGN.md's ladder",
+           "analyze_s": round(t1 - t0, 3), "factor_s": round(steady, 3), "first_factor_s": round(t2 - t1, 3), "solve_s": round(t3 - t2, 3),
            "factorisation": {"path": st["path"], "fronts": st["fronts"], "device_GB": round(st["device_bytes"] * 1e-9, 2),
-                             "flops": st["flops"], "TFLOP_per_s": round(st["flops"] / max(t2 - t1, 1e-9) * 1e-12, 2)},
-           "roofline": {"bound": "mfma", "achieved": round(st["flops"] / max(t2 - t1, 1e-9) * 1e-12, 2), "peak": 78.6,
-                        "unit": "TFLOP/s", "frac": round(st["flops"] / max(t2 - t1, 1e-9) * 1e-12 / 78.6, 4), "traffic": None,
+                             "flops": st["flops"], "TFLOP_per_s": round(rate, 2),
+                             "note": "flops executed: a symmetric matrix is factored as L D L^T on the same fronts (half the update flops of LU)"},
+           "roofline": {"bound": "mfma", "achieved": round(rate, 2), "peak": 78.6,
+                        "unit": "TFLOP/s", "frac": round(rate / 78.6, 4), "traffic": None,
                         "note": "whole numeric factorisation (all launches) against the fp64 matrix-core peak; "
                                 "back-to-back v_mfma_f64_16x16x4 issue at 47 TFLOP/s on this part (profiles/r01_dense_lu_rate_probe.txt)"},
            "parity": {"max_rel_err_vs_manufactured": err, "within_1e-10": bool(err < 1e-10), "scaled_residual": res},
