@@ -152,10 +152,11 @@ __global__ __launch_bounds__(256) void extend_add_kernel(const int *__restrict__
     const double v = saved >= 0 ? t.cut[saved + (int64_t)r + (int64_t)cc * nb]
                                 : t.front(c)[(int64_t)(npc + r) + (int64_t)(npc + cc) * t.ld[c]];
     dst[(int64_t)rel[cc] * ldp] += v;
-    // ... mirrored into the parent's upper triangle: its diagonal tiles are read whole.  (r, cc) and (cc, r) of
-    // different children never meet in one word at a time other than through += of distinct threads of ONE launch
-    // on distinct addresses: (rel[cc], rel[r]) is written by this thread only
-    if (t.sym && cc != r) t.front(p)[(int64_t)rel[cc] + (int64_t)rel[r] * ldp] += v;
+    // ... mirrored into the parent's upper triangle where the parent reads it: the 64 x 64 blocks on its diagonal
+    // (diagonal blocks are factored, and diagonal tiles of the trailing update computed, whole; every other tile above
+    // the diagonal is written by the triangular solves, U12 = D L21^T, before anything reads it).  rel is increasing,
+    // so (rel[cc], rel[r]) lies above the diagonal and is written by this thread only.
+    if (t.sym && cc != r && (rel[cc] >> 6) == (rel[r] >> 6)) t.front(p)[(int64_t)rel[cc] + (int64_t)rel[r] * ldp] += v;
   }
 }
 
