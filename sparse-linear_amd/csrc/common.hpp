@@ -183,8 +183,13 @@ void segmented_sort_pairs_u32(const int64_t *d_ptr64, int64_t nseg, unsigned *d_
 // the `zi` wrapper's note on a `di` Numeric object: which row pairs of the embedding it swapped
 void numeric_set_pair_swap(void *Numeric, std::vector<char> &&flags);
 const std::vector<char> *numeric_pair_swap(void *Numeric);  // nullptr: none
+// ... and, for a complex symmetric matrix, the unit-modulus diagonal D = diag(u_r) of the congruence D A D it embedded
+// symmetrically (umfpack_zi.hip): n pairs (re, im)
+void numeric_set_pair_unit(void *Numeric, std::vector<double> &&u);
+const std::vector<double> *numeric_pair_unit(void *Numeric);  // nullptr: none
 // symbolic analysis of the real embedding of a complex matrix, ordered on the complex pattern (umfpack.hip)
 int symbolic_of_embedding(int n, const int *Ap, const int *Ai, const int *Ep, const int *Ei, void **Symbolic);
+double symbolic_tree_flops(void *Symbolic);  // LU flops of the multifrontal tree of a `di` analysis; 0: band path
 int numeric_of_embedding(const int *Ep, const int *Ei, const double *Ex, void *Symbolic, void **Numeric);
 uint64_t pattern_hash(const int *Ai, int64_t nnz);
 void finalize_matrix(Matrix *m, hipStream_t s);

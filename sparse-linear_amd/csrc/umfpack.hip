@@ -82,6 +82,7 @@ struct Numeric {
   Matrix *At = nullptr;  // rows of A^T (residual b - A^T x)
   // set by the `zi` wrapper (umfpack_zi.hip): rows 2r, 2r+1 of the real embedding were swapped
   std::vector<char> pair_swap;
+  std::vector<double> pair_unit;  // zi wrapper, complex symmetric matrices: unit-modulus u_r (re, im) of the congruence D A D
   // Static pivoting (static_pivot.hpp): 0 not tried, 1 the factors held are those of B = Dr P A Dc on B's own
   // tree (still a checked speculation), 2 tried and given up.  spA / spAt: rows of B / of B^T on the device
   // (what mf_factor scatters); sp_idx / sp_scale: the permutations and scalings around a solve with B's factors,
@@ -854,6 +855,10 @@ int numeric_of_embedding(const int *Ep, const int *Ei, const double *Ex, void *S
 int symbolic_of_embedding(int n, const int *Ap, const int *Ai, const int *Ep, const int *Ei, void **SymbolicOut) {
   return symbolic_common(n, Ap, Ai, 2, Ep, Ei, SymbolicOut);
 }
+double symbolic_tree_flops(void *SymbolicIn) {
+  Symbolic *S = as_symbolic(SymbolicIn);
+  return S && S->tree ? S->tree->flops : 0.0;
+}
 }  // namespace spl
 
 extern "C" {
@@ -1273,6 +1278,13 @@ void numeric_set_pair_swap(void *NumericIn, std::vector<char> &&flags) {
 const std::vector<char> *numeric_pair_swap(void *NumericIn) {
   Numeric *N = as_numeric(NumericIn);
   return N && !N->pair_swap.empty() ? &N->pair_swap : nullptr;
+}
+void numeric_set_pair_unit(void *NumericIn, std::vector<double> &&u) {
+  if (Numeric *N = as_numeric(NumericIn)) N->pair_unit = std::move(u);
+}
+const std::vector<double> *numeric_pair_unit(void *NumericIn) {
+  Numeric *N = as_numeric(NumericIn);
+  return N && !N->pair_unit.empty() ? &N->pair_unit : nullptr;
 }
 }  // namespace spl
 

@@ -169,6 +169,115 @@ def test_zi_split_arrays_through_the_c_abi(gpu, pkg):
     L.umfpack_zi_free_symbolic(C.byref(sym))
 
 
+# ---- complex symmetric matrices: symmetric real embedding, L D L^T on the tree (csrc/umfpack_zi.hip, head) ----------
+def _bwd(S, x, b):
+    r = np.abs(S @ x - b)
+    den = abs(S) @ np.abs(x) + np.abs(b)
+    return float(np.max(r / np.where(den > 0, den, 1.0)))
+
+
+@pytest.mark.parametrize("dim,m", [(2, 60), (3, 16)])
+@pytest.mark.parametrize("z", [4.0 + 0.01j, 0.7 - 0.4j, -0.2 + 3.0j, 6.0 + 0.0j])
+def test_complex_symmetric_shift_is_factored_as_ldlt(gpu, pkg, dim, m, z, monkeypatch):
+    """FEAST's z B - A for real symmetric A, B (complex symmetric, not Hermitian): the zi wrapper embeds D A D
+    symmetrically (|u_r| = 1, real positive diagonal) and the tree runs its L D L^T mode — half the flops of the
+    general embedding (SPL_ZI_SYMMETRIC=0), the same solutions of A x = b and A^H y = c to 1e-10; packed, batched and
+    device right-hand sides.  z = 4 + 0.01i puts Re z on A's diagonal (the real pivot of the plain embedding is 0),
+    z = 6 is a real shift (every u_r is 1 or i)."""
+    import scipy.sparse as sp
+    import torch
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    rng = np.random.default_rng(m)
+    T = sp.diags([-np.ones(m - 1), 2.0 * np.ones(m), -np.ones(m - 1)], (-1, 0, 1))
+    I = sp.identity(m)
+    A = (sp.kron(I, T) + sp.kron(T, I)) if dim == 2 else (sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(T, I), I))
+    n = A.shape[0]
+    B = sp.diags(rng.uniform(0.8, 1.25, n))
+    S = sp.csc_matrix(z * B - A)
+    S.sort_indices()
+    M = pkg.Matrix(n, n, S.indptr, S.indices, S.data)
+    U = pkg.umfpack
+    monkeypatch.setenv("SPL_ZI_SYMMETRIC", "1")  # by itself the wrapper does this from 1e12 flops of the tree on
+    fs = U.factor(M, U.analyze(M))
+    monkeypatch.setenv("SPL_ZI_SYMMETRIC", "0")
+    fg = U.factor(M, U.analyze(M))
+    monkeypatch.delenv("SPL_ZI_SYMMETRIC")
+    fd = U.factor(M, U.analyze(M))
+    assert fd.stats["flops"] == fg.stats["flops"] < 1e12  # small trees keep the general embedding
+    assert fs.path in (3, 4) and fg.path in (3, 4)
+    assert fs.stats["flops"] == 0.5 * fg.stats["flops"] and fs.stats["fronts"] == fg.stats["fronts"]
+    xs = [rng.uniform(0.5, 1.5, n) + 1j * rng.uniform(-1, 1, n) for _ in range(3)]
+    for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, sp.csc_matrix(S.conj().T))):
+        bs = [np.asarray(op @ x).ravel() for x in xs]
+        one = U.linearSolve_(fs, mode, M, bs[0])
+        ref = U.linearSolve_(fg, mode, M, bs[0])
+        assert _bwd(op, one, bs[0]) <= 1e-13
+        assert np.max(np.abs(one - ref)) <= 1e-10 * np.max(np.abs(ref))
+        for got, b in zip(U.linearSolveMany_(fs, mode, M, bs), bs):
+            assert _bwd(op, got, b) <= 1e-13
+        Xd = U.linearSolveManyDevice_(fs, mode, M, torch.from_numpy(np.stack(bs)).cuda()).cpu().numpy()
+        for got, b in zip(Xd, bs):
+            assert _bwd(op, got, b) <= 1e-13
+
+
+def test_complex_symmetric_split_arrays_and_hermitian_stays_general(gpu, pkg, monkeypatch):
+    """the symmetric embedding through umfpack_zi_* with split real / imaginary arrays (Az, Xz, Bz non-NULL); and a
+    complex HERMITIAN matrix (A == A^H, not A^T) takes the general embedding (all the flops of its tree)"""
+    import ctypes as C
+    import scipy.sparse as sp
+    L = pkg._ffi.lib()
+    pkg.umfpack._declare()
+    rng = np.random.default_rng(9)
+    m = 30
+    T = sp.diags([-np.ones(m - 1), 2.0 * np.ones(m), -np.ones(m - 1)], (-1, 0, 1))
+    K = sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m))
+    n = m * m
+    W = sp.triu(sp.random(n, n, density=3.0 / n, random_state=2), 1) * (0.2 + 0.3j)
+    S = sp.csc_matrix((1.3 + 0.6j) * sp.identity(n) - K + W + W.T)  # complex symmetric
+    S.sort_indices()
+    assert abs(S - S.T).max() == 0 and abs(S - S.conj().T).max() > 0
+    ap, ai = S.indptr.astype(np.int32), S.indices.astype(np.int32)
+    ax, az = np.ascontiguousarray(S.data.real), np.ascontiguousarray(S.data.imag)
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    P = lambda a, t: a.ctypes.data_as(t)
+    sym, num = C.c_void_p(), C.c_void_p()
+    monkeypatch.setenv("SPL_ZI_SYMMETRIC", "1")
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    assert L.umfpack_zi_symbolic(n, n, P(ap, ip), P(ai, ip), P(ax, dp), P(az, dp), C.byref(sym), None, None) == 0
+    assert L.umfpack_zi_numeric(P(ap, ip), P(ai, ip), P(ax, dp), P(az, dp), sym, C.byref(num), None, None) == 0
+    for sys_, op in ((0, S), (1, sp.csc_matrix(S.conj().T))):
+        xs = rng.normal(size=n) + 1j * rng.normal(size=n)
+        b = np.asarray(op @ xs).ravel()
+        bx, bz = np.ascontiguousarray(b.real), np.ascontiguousarray(b.imag)
+        xx, xz = np.zeros(n), np.zeros(n)
+        assert L.umfpack_zi_solve(sys_, P(ap, ip), P(ai, ip), P(ax, dp), P(az, dp), P(xx, dp), P(xz, dp), P(bx, dp),
+                                  P(bz, dp), num, None, None) == 0
+        assert _bwd(op, xx + 1j * xz, b) <= 1e-13
+        k = 3
+        Xs = rng.normal(size=(k, n)) + 1j * rng.normal(size=(k, n))
+        Bm = np.stack([np.asarray(op @ Xs[c]).ravel() for c in range(k)])
+        bx, bz = np.ascontiguousarray(Bm.real), np.ascontiguousarray(Bm.imag)
+        xx, xz = np.zeros((k, n)), np.zeros((k, n))
+        assert L.spl_umfpack_zi_solve_many(sys_, P(ap, ip), P(ai, ip), P(ax, dp), P(az, dp), k, P(xx, dp), P(xz, dp),
+                                           P(bx, dp), P(bz, dp), num) == 0
+        for c in range(k):
+            assert _bwd(op, xx[c] + 1j * xz[c], Bm[c]) <= 1e-13
+    L.umfpack_zi_free_numeric(C.byref(num))
+    L.umfpack_zi_free_symbolic(C.byref(sym))
+    # Hermitian: general embedding
+    H = sp.csc_matrix(4.5 * sp.identity(n) - K + W + W.conj().T)
+    H.sort_indices()
+    M = pkg.Matrix(n, n, H.indptr, H.indices, H.data)
+    U = pkg.umfpack
+    fh = U.factor(M, U.analyze(M))
+    monkeypatch.setenv("SPL_ZI_SYMMETRIC", "0")
+    fg = U.factor(M, U.analyze(M))
+    assert fh.stats["flops"] == fg.stats["flops"]
+    xs = rng.normal(size=n) + 1j * rng.normal(size=n)
+    b = np.asarray(H @ xs).ravel()
+    assert _bwd(H, U.linearSolve_(fh, U.UmfpackNormal, M, b), b) <= 1e-13
+
+
 # ---- native Complex Double SpMV (csrc/spmv_z.hip) against the oracle's complex restatement of axpy_ -------------
 def _rand_complex(O, rng, nr, nc, k, ints=False):
     A = O.compress(nr, nc, rng.integers(0, nr, k), rng.integers(0, nc, k), rng.normal(size=k))
