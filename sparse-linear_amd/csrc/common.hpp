@@ -190,7 +190,8 @@ const std::vector<double> *numeric_pair_unit(void *Numeric);  // nullptr: none
 // symbolic analysis of the real embedding of a complex matrix, ordered on the complex pattern (umfpack.hip)
 int symbolic_of_embedding(int n, const int *Ap, const int *Ai, const int *Ep, const int *Ei, void **Symbolic);
 double symbolic_tree_flops(void *Symbolic);  // LU flops of the multifrontal tree of a `di` analysis; 0: band path
-int numeric_of_embedding(const int *Ep, const int *Ei, const double *Ex, void *Symbolic, void **Numeric);
+int numeric_of_embedding(const int *Ep, const int *Ei, const double *Ex, void *Symbolic, void **Numeric, int native = 0);
+bool symbolic_has_complex_tree(void *Symbolic);  // the analysis kept the tree of the complex pattern (native complex fronts possible)
 uint64_t pattern_hash(const int *Ai, int64_t nnz);
 void finalize_matrix(Matrix *m, hipStream_t s);
 int spmv_cus(const Matrix *m);  // CUs the persistent SpMV images are laid out for: the device's minus the reserved ones
@@ -222,10 +223,10 @@ namespace mf {
 struct Tree;
 struct Factors;
 }  // namespace mf
-size_t mf_device_bytes(const mf::Tree &T);
+size_t mf_device_bytes(const mf::Tree &T, int zm = 1);  // zm = 2: complex fronts (two planes)
 mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, const int *d_Ai, const double *d_Ax,
                        const int *d_Rp, const int *d_Rj, const double *d_Rx, const int *d_perm, const int *d_inv,
-                       hipStream_t s, bool symmetric = false);
+                       hipStream_t s, bool symmetric = false, bool zfront = false);
 int mf_singular(const mf::Factors *F);
 void mf_solve(const mf::Factors *F, int sys, double *d_c, int k, size_t stride, hipStream_t s);
 void mf_free(mf::Factors *F);

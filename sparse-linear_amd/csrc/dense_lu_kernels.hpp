@@ -29,6 +29,10 @@ struct Band {
   // the flops of the update, which is 89 % of the factorisation at config C5.  Entries above the diagonal TILES of a
   // trailing block are stale from then on; nothing reads them (extend_add_kernel mirrors the lower triangle).
   int sym = 0;
+  // zoff != 0: a COMPLEX dense front in two planes (round 3, native `zi` fronts): the real parts at AB, the imaginary
+  // parts zoff doubles further, same leading dimension.  The *_z device functions below read both; every index
+  // computation is the one of the real kernels.
+  size_t zoff = 0;
   __device__ __forceinline__ bool in_band(int i, int j) const { return i - j <= kl && j - i <= ku; }
   __device__ __forceinline__ double &at(int i, int j) const {
     return AB[(size_t)(doff + i) + (size_t)j * (size_t)(ldab - 1)];
@@ -36,7 +40,7 @@ struct Band {
   __device__ __forceinline__ double get(int i, int j) const { return in_band(i, j) ? at(i, j) : 0.0; }
 };
 inline Band band_view(double *AB, int n, int kl, int ku, int ldab) { return Band{AB, n, kl, ku, ldab, ku}; }
-inline Band dense_view(double *F, int n, int ld, int sym = 0) { return Band{F, n, n, n, ld + 1, 0, sym}; }
+inline Band dense_view(double *F, int n, int ld, int sym = 0, size_t zoff = 0) { return Band{F, n, n, n, ld + 1, 0, sym, zoff}; }
 
 // ---- factorisation ----------------------------------------------------------------------------
 typedef double double4v __attribute__((ext_vector_type(4)));
@@ -490,6 +494,493 @@ __device__ __forceinline__ void front_factor_by_workgroup(const Band &b, int npi
   }
 }
 
+
+// ---- complex fronts (two planes, Band::zoff): the same blocked algorithm in complex arithmetic ------------------
+// A complex product on the fp64 matrix cores is four real ones: (Lr Ur - Li Ui) + i (Lr Ui + Li Ur).  The tile
+// kernels below are the real ones with every operand staged twice (two planes) and four MFMAs where the real kernel
+// issues one; indices, tiles, look-ahead and the symmetric mode (U = D L^T, no conjugation: complex SYMMETRIC
+// matrices) are unchanged.  Inverse blocks: [inv(L11) re | im | inv(U11) re | im], NB x NB column-major each.
+constexpr int kInvBlockZ = 4 * NB * NB;
+constexpr size_t kDiagLdsZ = (size_t)(2 * NB * LDP + 4 * NB) * sizeof(double);  // D re, D im, multiplier columns
+constexpr size_t kTrsmLdsZ = (size_t)4 * 32 * LDP * sizeof(double);
+constexpr int KSZ = 16;  // K slice of the complex update (four LDS tiles per slice)
+constexpr size_t kUpdateLdsZ = (size_t)4 * KSZ * LDP * sizeof(double);
+
+__device__ __forceinline__ void crecip(double pr, double pi, double &qr, double &qi) {  // 1 / (pr + i pi), Smith
+  if (fabs(pr) >= fabs(pi)) {
+    const double r = pi / pr, d = pr + pi * r;
+    qr = 1.0 / d;
+    qi = -r / d;
+  } else {
+    const double r = pr / pi, d = pr * r + pi;
+    qr = r / d;
+    qi = -1.0 / d;
+  }
+}
+
+// diag_block_factor in complex arithmetic: same register layout (lane = row, wave w owns the columns c = w mod 4),
+// same pivot loop, two registers per entry
+__device__ __forceinline__ void diag_block_factor_z(const Band &b, int j0, int jb, double (*Dr)[LDP], double (*Di)[LDP],
+                                                    double (*lcr)[NB], double (*lci)[NB], int *__restrict__ singular,
+                                                    double *__restrict__ invL, double *__restrict__ invU) {
+  const int tid = threadIdx.x;
+  const int tr = tid & 63, tc = tid >> 6;
+  constexpr int NS = NB / 4;
+  {
+    double ar[NS], ai[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      ar[u] = Dr[tr][4 * u + tc];
+      ai[u] = Di[tr][4 * u + tc];
+    }
+#pragma unroll 1
+    for (int g = 0; g < NS; ++g) {
+#pragma unroll
+      for (int kw = 0; kw < 4; ++kw) {
+        const int k = 4 * g + kw;
+        if (tc == kw) {
+          const double pr = readlane_f64(ar[0], k), pi = readlane_f64(ai[0], k);
+          if (pr == 0.0 && pi == 0.0) {
+            if (tr == 0) atomicOr(singular, 1);
+          } else if (tr > k) {
+            double qr, qi;
+            crecip(pr, pi, qr, qi);
+            const double t = ar[0] * qr - ai[0] * qi;
+            ai[0] = ar[0] * qi + ai[0] * qr;
+            ar[0] = t;
+          }
+          lcr[k & 1][tr] = ar[0];
+          lci[k & 1][tr] = ai[0];
+        }
+        __syncthreads();
+        const double lr = tr > k ? lcr[k & 1][tr] : 0.0, li = tr > k ? lci[k & 1][tr] : 0.0;
+        if (tc > kw) {
+          const double ur = readlane_f64(ar[0], k), ui = readlane_f64(ai[0], k);
+          ar[0] -= lr * ur - li * ui;
+          ai[0] -= lr * ui + li * ur;
+        }
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          if (g + 4 * qd < NS) {
+#pragma unroll
+            for (int j = (qd == 0 ? 1 : 4 * qd); j < 4 * qd + 4; ++j) {
+              const double ur = readlane_f64(ar[j], k), ui = readlane_f64(ai[j], k);
+              ar[j] -= lr * ur - li * ui;
+              ai[j] -= lr * ui + li * ur;
+            }
+          }
+        }
+      }
+      Dr[tr][4 * g + tc] = ar[0];
+      Di[tr][4 * g + tc] = ai[0];
+#pragma unroll
+      for (int j = 0; j + 1 < NS; ++j) {
+        ar[j] = ar[j + 1];
+        ai[j] = ai[j + 1];
+      }
+      ar[NS - 1] = 0.0;
+      ai[NS - 1] = 0.0;
+    }
+  }
+  __syncthreads();
+  for (int c = tc; c < jb; c += 4)
+    if (tr < jb) {
+      double *dst = &b.at(j0 + tr, j0 + c);
+      dst[0] = Dr[tr][c];
+      dst[b.zoff] = Di[tr][c];
+    }
+  double *dinvr = &lcr[0][0], *dinvi = &lci[0][0];
+  if (tid < NB) {
+    const double dr = Dr[tid][tid], di = Di[tid][tid];
+    double qr = 0.0, qi = 0.0;
+    if (dr != 0.0 || di != 0.0) crecip(dr, di, qr, qi);
+    dinvr[tid] = qr;
+    dinvi[tid] = qi;
+  }
+  __syncthreads();
+  double xr[NS], xi[NS], yr[NS], yi[NS];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    xr[u] = yr[u] = (tr == 4 * u + tc) ? 1.0 : 0.0;
+    xi[u] = yi[u] = 0.0;
+  }
+#pragma unroll 1
+  for (int s = 0; s < NB; ++s) {
+    {
+      const int k = NB - 1 - s, ks = k >> 2;
+      const double dkr = dinvr[k], dki = dinvi[k];
+      const double ur = tr < k ? Dr[tr][k] : 0.0, ui = tr < k ? Di[tr][k] : 0.0;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        if (4 * qd + 3 >= ks) {
+#pragma unroll
+          for (int u = 4 * qd; u < 4 * qd + 4; ++u) {
+            const double rr = readlane_f64(xr[u], k), ri = readlane_f64(xi[u], k);
+            const double kr = rr * dkr - ri * dki, ki = rr * dki + ri * dkr;
+            xr[u] = (tr == k) ? kr : xr[u] - (ur * kr - ui * ki);
+            xi[u] = (tr == k) ? ki : xi[u] - (ur * ki + ui * kr);
+          }
+        }
+      }
+    }
+    {
+      const int k = s, ks = k >> 2;
+      const double lr = tr > k ? Dr[tr][k] : 0.0, li = tr > k ? Di[tr][k] : 0.0;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        if (4 * qd <= ks) {
+#pragma unroll
+          for (int u = 4 * qd; u < 4 * qd + 4; ++u) {
+            const double rr = readlane_f64(yr[u], k), ri = readlane_f64(yi[u], k);
+            yr[u] -= lr * rr - li * ri;
+            yi[u] -= lr * ri + li * rr;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const int c = 4 * u + tc;
+    invU[tr + c * NB] = xr[u];
+    invU[NB * NB + tr + c * NB] = xi[u];
+    invL[tr + c * NB] = yr[u];
+    invL[NB * NB + tr + c * NB] = yi[u];
+  }
+}
+
+// the diagonal block (identity-padded beyond jb) into the two LDS tiles
+__device__ __forceinline__ void load_diag_z(const Band &b, int j0, int jb, double (*Dr)[LDP], double (*Di)[LDP]) {
+  const int tr = threadIdx.x & 63, tc = threadIdx.x >> 6;
+  for (int c = tc; c < NB; c += 4) {
+    const bool in = tr < jb && c < jb;
+    const double *src = in ? &b.at(j0 + tr, j0 + c) : nullptr;
+    Dr[tr][c] = in ? src[0] : (tr == c ? 1.0 : 0.0);
+    Di[tr][c] = in ? src[b.zoff] : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void diag_lu_kernel_z(Band b, int j0, int jb, int *__restrict__ singular,
+                                                        double *__restrict__ invL, double *__restrict__ invU) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double(*Dr)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);
+  double(*Di)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + NB * LDP);
+  double(*lcr)[NB] = reinterpret_cast<double(*)[NB]>(dsm + 2 * NB * LDP);
+  double(*lci)[NB] = reinterpret_cast<double(*)[NB]>(dsm + 2 * NB * LDP + 2 * NB);
+  load_diag_z(b, j0, jb, Dr, Di);
+  __syncthreads();
+  diag_block_factor_z(b, j0, jb, Dr, Di, lcr, lci, singular, invL, invU);
+}
+
+// acc += C * R for complex tiles in planes (Cs: indexed by the output column, Rs: by the output row)
+template <int KD>
+__device__ __forceinline__ void mfma_tile_64_z(const double (*Cr)[LDP], const double (*Ci)[LDP], const double (*Rr)[LDP],
+                                               const double (*Ri)[LDP], const TilePos &p, double4v (&accr)[2][2],
+                                               double4v (&acci)[2][2]) {
+#pragma unroll 2
+  for (int k0 = 0; k0 < KD; k0 += 4) {
+    double afr[2], afi[2], bfr[2], bfi[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      afr[a] = Cr[k0 + p.lk][p.qc + a * 16 + p.li];
+      afi[a] = Ci[k0 + p.lk][p.qc + a * 16 + p.li];
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bfr[c] = Rr[k0 + p.lk][p.qr + c * 16 + p.li];
+      bfi[c] = Ri[k0 + p.lk][p.qr + c * 16 + p.li];
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        accr[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[a], bfr[c], accr[a][c], 0, 0, 0);
+        accr[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-afi[a], bfi[c], accr[a][c], 0, 0, 0);
+        acci[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[a], bfi[c], acci[a][c], 0, 0, 0);
+        acci[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(afi[a], bfr[c], acci[a][c], 0, 0, 0);
+      }
+  }
+}
+
+// panel solves of a complex dense front (trsm_tile): L21 tile <- A21 tile * inv(U11), U12 tile <- inv(L11) * A12 tile
+__device__ __forceinline__ void trsm_tile_z(const Band &b, int j0, int jb, int nrows_below, int ncols_right,
+                                            const double *__restrict__ invL, const double *__restrict__ invU, int tile,
+                                            double *dsm) {
+  constexpr int KH = 32;
+  double(*Csr)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);
+  double(*Csi)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + KH * LDP);
+  double(*Rsr)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + 2 * KH * LDP);
+  double(*Rsi)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + 3 * KH * LDP);
+  const int tid = threadIdx.x;
+  const int ntile_l = (nrows_below + 63) / 64;
+  const bool is_l = tile < ntile_l;
+  if (b.sym && !is_l) return;
+  const int rend = j0 + jb + nrows_below, cend = j0 + jb + ncols_right;
+  const int lo = tid % 64, hi = tid / 64;
+  const size_t z = b.zoff;
+  int r0, c0;
+  double rvr[16], rvi[16], cvr[16], cvi[16];
+  if (is_l) {
+    r0 = j0 + jb + tile * 64, c0 = j0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = hi + 4 * u;
+      const bool in = k < jb && r0 + lo < rend;
+      const double *src = &b.at(in ? r0 + lo : j0, in ? j0 + k : j0);
+      rvr[u] = in ? src[0] : 0.0;
+      rvi[u] = in ? src[z] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      cvr[u] = invU[tid + 256 * u];
+      cvi[u] = invU[NB * NB + tid + 256 * u];
+    }
+  } else {
+    r0 = j0, c0 = j0 + jb + (tile - ntile_l) * 64;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      rvr[u] = invL[tid + 256 * u];
+      rvi[u] = invL[NB * NB + tid + 256 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int c = hi + 4 * u;
+      const bool in = lo < jb && c0 + c < cend;
+      const double *src = &b.at(in ? j0 + lo : j0, in ? c0 + c : j0);
+      cvr[u] = in ? src[0] : 0.0;
+      cvi[u] = in ? src[z] : 0.0;
+    }
+  }
+  const TilePos p;
+  double4v accr[2][2], acci[2][2];
+  zero_acc(accr);
+  zero_acc(acci);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      Rsr[hi + 4 * u][lo] = rvr[8 * h + u];
+      Rsi[hi + 4 * u][lo] = rvi[8 * h + u];
+    }
+    if (lo / KH == h) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        Csr[lo - KH * h][hi + 4 * u] = cvr[u];
+        Csi[lo - KH * h][hi + 4 * u] = cvi[u];
+      }
+    }
+    __syncthreads();
+    mfma_tile_64_z<KH>(Csr, Csi, Rsr, Rsi, p, accr, acci);
+  }
+  const int rlim = is_l ? rend : j0 + jb, clim = is_l ? j0 + jb : cend;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = r0 + p.row(c), j = c0 + p.col(a, r);
+        if (i < rlim && j < clim) {
+          double *dst = &b.at(i, j);
+          dst[0] = accr[a][c][r];
+          dst[z] = acci[a][c][r];
+          if (b.sym) {  // U(j, i) = d_j L(i, j), d_j = U11(j, j); no conjugation: complex symmetric
+            const double *d = &b.at(j, j);
+            double *ut = &b.at(j, i);
+            ut[0] = d[0] * accr[a][c][r] - d[z] * acci[a][c][r];
+            ut[z] = d[0] * acci[a][c][r] + d[z] * accr[a][c][r];
+          }
+        }
+      }
+}
+
+__global__ __launch_bounds__(256) void trsm_gemm_kernel_z(Band b, int j0, int jb, int nrows_below, int ncols_right,
+                                                          const double *__restrict__ invL,
+                                                          const double *__restrict__ invU) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  trsm_tile_z(b, j0, jb, nrows_below, ncols_right, invL, invU, (int)blockIdx.x, dsm);
+}
+
+// trailing update of a complex dense front (update_tile): K slices of KSZ through four LDS tiles
+template <bool LOOKAHEAD>
+__device__ __forceinline__ void update_tile_z(const Band &b, const Region &g, int tx, int ty,
+                                              int *__restrict__ singular, double *__restrict__ next_invL,
+                                              double *__restrict__ next_invU, double *dsm) {
+  const int r0 = g.rb + tx * 64, c0 = g.cb + ty * 64;
+  if (b.sym && c0 > r0) return;
+  double(*Usr)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);
+  double(*Usi)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + KSZ * LDP);
+  double(*Lsr)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + 2 * KSZ * LDP);
+  double(*Lsi)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + 3 * KSZ * LDP);
+  const int tid = threadIdx.x;
+  const size_t z = b.zoff;
+  const bool interior = r0 + 64 <= g.re && c0 + 64 <= g.ce && g.klen % KSZ == 0;
+  const size_t cs = (size_t)(b.ldab - 1);
+  const TilePos p;
+  double coldr[2][2][4], coldi[2][2][4];
+  if (interior) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const double *src = &b.at(r0 + p.row(c), c0 + p.col(a, 0));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          coldr[a][c][r] = src[(size_t)(4 * r) * cs];
+          coldi[a][c][r] = src[(size_t)(4 * r) * cs + z];
+        }
+      }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = r0 + p.row(c), j = c0 + p.col(a, r);
+          const bool in = i < b.n && j < b.n;
+          const double *src = &b.at(in ? i : 0, in ? j : 0);
+          coldr[a][c][r] = in ? src[0] : 0.0;
+          coldi[a][c][r] = in ? src[z] : 0.0;
+        }
+  }
+  double4v accr[2][2], acci[2][2];
+  zero_acc(accr);
+  zero_acc(acci);
+  constexpr int PER = KSZ * 64 / 256;
+  double elr[PER], eli[PER], eur[PER], eui[PER];
+  const double *lsrc = interior ? &b.at(r0 + tid % 64, g.kb + tid / 64) : nullptr;
+  const double *usrc = interior ? &b.at(g.kb + tid % KSZ, c0 + tid / KSZ) : nullptr;
+  auto fetch = [&](int k0) {
+    if (interior) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const double *lp = lsrc + (size_t)(k0 + 4 * u) * cs;
+        const double *up = usrc + (size_t)k0 + (size_t)(256 / KSZ * u) * cs;
+        elr[u] = lp[0];
+        eli[u] = lp[z];
+        eur[u] = up[0];
+        eui[u] = up[z];
+      }
+      return;
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int t = tid + u * 256;
+      const int r = t % 64, k = t / 64;
+      const bool lin = k0 + k < g.klen && r0 + r < g.re;
+      const double *lp = &b.at(lin ? r0 + r : 0, lin ? g.kb + k0 + k : 0);
+      elr[u] = lin ? lp[0] : 0.0;
+      eli[u] = lin ? lp[z] : 0.0;
+      const int k2 = t % KSZ, c = t / KSZ;
+      const bool uin = k0 + k2 < g.klen && c0 + c < g.ce;
+      const double *up = &b.at(uin ? g.kb + k0 + k2 : 0, uin ? c0 + c : 0);
+      eur[u] = uin ? up[0] : 0.0;
+      eui[u] = uin ? up[z] : 0.0;
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < g.klen; k0 += KSZ) {
+    if (k0) __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int t = tid + u * 256;
+      Lsr[t / 64][t % 64] = elr[u];
+      Lsi[t / 64][t % 64] = eli[u];
+      Usr[t % KSZ][t / KSZ] = eur[u];
+      Usi[t % KSZ][t / KSZ] = eui[u];
+    }
+    __syncthreads();
+    if (k0 + KSZ < g.klen) fetch(k0 + KSZ);
+    mfma_tile_64_z<KSZ>(Usr, Usi, Lsr, Lsi, p, accr, acci);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = r0 + p.row(c), j = c0 + p.col(a, r);
+        coldr[a][c][r] -= accr[a][c][r];
+        coldi[a][c][r] -= acci[a][c][r];
+        if (interior || (i < g.re && j < g.ce)) {
+          double *dst = &b.at(i, j);
+          dst[0] = coldr[a][c][r];
+          dst[z] = coldi[a][c][r];
+        }
+      }
+  if (!LOOKAHEAD) return;
+  if (tx != 0 || ty != 0 || r0 >= g.npiv) return;
+  const int jbn = min(NB, g.npiv - r0);
+  __syncthreads();
+  double(*Dr)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);
+  double(*Di)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + NB * LDP);
+  double(*lcr)[NB] = reinterpret_cast<double(*)[NB]>(dsm + 2 * NB * LDP);
+  double(*lci)[NB] = reinterpret_cast<double(*)[NB]>(dsm + 2 * NB * LDP + 2 * NB);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tr = p.row(c), tcn = p.col(a, r);
+        const bool in = tr < jbn && tcn < jbn;
+        Dr[tr][tcn] = in ? coldr[a][c][r] : (tr == tcn ? 1.0 : 0.0);
+        Di[tr][tcn] = in ? coldi[a][c][r] : 0.0;
+      }
+  __syncthreads();
+  diag_block_factor_z(b, r0, jbn, Dr, Di, lcr, lci, singular, next_invL, next_invU);
+}
+
+__global__ __launch_bounds__(256) void gemm_update_kernel_z(Band b, Region g, int *__restrict__ singular,
+                                                            double *__restrict__ next_invL,
+                                                            double *__restrict__ next_invU) {
+  int tx = blockIdx.x, ty = blockIdx.y;
+  if (g.lshape) {
+    tx = (int)blockIdx.x < g.ntile_rows ? (int)blockIdx.x : 0;
+    ty = (int)blockIdx.x < g.ntile_rows ? 0 : (int)blockIdx.x - g.ntile_rows + 1;
+  }
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  update_tile_z<true>(b, g, tx, ty, singular, next_invL, next_invU, dsm);
+}
+
+__global__ __launch_bounds__(256) void gemm_update_bulk_kernel_z(Band b, Region g, int *__restrict__ singular) {
+  if (blockIdx.x == 0 && blockIdx.y == 0) return;
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  update_tile_z<false>(b, g, (int)blockIdx.x, (int)blockIdx.y, singular, nullptr, nullptr, dsm);
+}
+
+// the whole partial factorisation of one small complex front by one workgroup
+__device__ __forceinline__ void front_factor_by_workgroup_z(const Band &b, int npiv, double *invs,
+                                                            int *__restrict__ singular, double *dsm) {
+  double(*Dr)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);
+  double(*Di)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + NB * LDP);
+  double(*lcr)[NB] = reinterpret_cast<double(*)[NB]>(dsm + 2 * NB * LDP);
+  double(*lci)[NB] = reinterpret_cast<double(*)[NB]>(dsm + 2 * NB * LDP + 2 * NB);
+  const int n = b.n;
+  for (int j0 = 0; j0 < npiv; j0 += NB) {
+    const int jb = min(NB, npiv - j0);
+    double *invL = invs + (size_t)(j0 / NB) * kInvBlockZ, *invU = invL + 2 * NB * NB;
+    load_diag_z(b, j0, jb, Dr, Di);
+    __syncthreads();
+    diag_block_factor_z(b, j0, jb, Dr, Di, lcr, lci, singular, invL, invU);
+    __syncthreads();
+    const int rest = n - (j0 + jb);
+    if (rest <= 0) break;
+    const int ntile = (rest + 63) / 64;
+    for (int tile = 0; tile < 2 * ntile; ++tile) {
+      trsm_tile_z(b, j0, jb, rest, rest, invL, invU, tile, dsm);
+      __syncthreads();
+    }
+    Region g{j0 + jb, n, j0 + jb, n, j0, jb, 0, ntile, npiv};
+    for (int t = 0; t < ntile * ntile; ++t) {
+      update_tile_z<false>(b, g, t % ntile, t / ntile, singular, nullptr, nullptr, dsm);
+      __syncthreads();
+    }
+  }
+}
+
 // ---- blocked solves -----------------------------------------------------------------------------
 // The factorisation keeps inv(L11) and inv(U11) of every diagonal block, so a block of the
 // triangular solve is a 64 x 64 matrix-vector product instead of a 64-step substitution chain.
@@ -713,6 +1204,14 @@ inline void set_factor_attributes() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));  // uses less
   SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_update_bulk_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
+  SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_lu_kernel_z),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDiagLdsZ));
+  SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_gemm_kernel_z),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrsmLdsZ));
+  SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_update_kernel_z),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDiagLdsZ));
+  SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_update_bulk_kernel_z),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpdateLdsZ));
   attr_set = true;
 }
 
@@ -736,25 +1235,35 @@ struct LookaheadFork {
   }
 };
 
+template <bool Z = false>
 inline void factor_loop(const Band &b, int npiv, double *d_invs, int *d_singular, hipStream_t s,
                         hipStream_t helper = nullptr) {
   set_factor_attributes();
   LookaheadFork fork(helper);
   const int n = b.n, kl = b.kl, ku = b.ku;
-  const size_t gemm_lds = kTileBytes + 2 * NB * sizeof(double);
-  auto slot = [&](int j) { return d_invs + (size_t)(j / NB) * (2 * NB * NB); };
+  const size_t gemm_lds = Z ? kDiagLdsZ : kTileBytes + 2 * NB * sizeof(double);
+  constexpr size_t blk = Z ? (size_t)kInvBlockZ : (size_t)(2 * NB * NB), half = blk / 2;  // inv(L11) | inv(U11)
+  auto slot = [&](int j) { return d_invs + (size_t)(j / NB) * blk; };
   auto below_of = [&](int jend) { return std::max(0, std::min(n, jend + kl) - jend); };  // rows with in-band entries
   auto right_of = [&](int jend) { return std::max(0, std::min(n, jend + ku) - jend); };
   auto diag = [&](int j0, int jb) {
-    hipLaunchKernelGGL(diag_lu_kernel, dim3(1), dim3(256), kTileBytes + 2 * NB * sizeof(double), s, b, j0, jb,
-                       d_singular, slot(j0), slot(j0) + NB * NB);
+    if (Z)
+      hipLaunchKernelGGL(diag_lu_kernel_z, dim3(1), dim3(256), kDiagLdsZ, s, b, j0, jb, d_singular, slot(j0),
+                         slot(j0) + half);
+    else
+      hipLaunchKernelGGL(diag_lu_kernel, dim3(1), dim3(256), kTileBytes + 2 * NB * sizeof(double), s, b, j0, jb,
+                         d_singular, slot(j0), slot(j0) + half);
   };
   auto trsm = [&](int j0, int jb) {
     const int below = below_of(j0 + jb), right = right_of(j0 + jb);
     const int tiles = (below + 63) / 64 + (right + 63) / 64;
-    if (tiles > 0)
+    if (tiles <= 0) return;
+    if (Z)
+      hipLaunchKernelGGL(trsm_gemm_kernel_z, dim3((unsigned)tiles), dim3(256), kTrsmLdsZ, s, b, j0, jb, below, right,
+                         slot(j0), slot(j0) + half);
+    else
       hipLaunchKernelGGL(trsm_gemm_kernel, dim3((unsigned)tiles), dim3(256), kTrsmLds, s, b, j0, jb, below,
-                         right, slot(j0), slot(j0) + NB * NB);
+                         right, slot(j0), slot(j0) + half);
   };
   // trailing update of rows/cols from `origin` with the K range [kb, kb+klen); factors the diagonal
   // block at `origin` on the way (look-ahead) when it is a pivot block.  Returns whether it did.
@@ -769,17 +1278,29 @@ inline void factor_loop(const Band &b, int npiv, double *d_invs, int *d_singular
       // wavefronts per SIMD on this one; both start after the panel solves and meet again after
       SPL_HIP(hipEventRecord(fork.ready, s));
       SPL_HIP(hipStreamWaitEvent(fork.helper, fork.ready, 0));
-      hipLaunchKernelGGL(gemm_update_kernel, dim3(1, 1), dim3(256), gemm_lds, fork.helper, b, g, d_singular,
-                         slot(origin), slot(origin) + NB * NB);
-      SPL_HIP(hipEventRecord(fork.done, fork.helper));
-      hipLaunchKernelGGL(gemm_update_bulk_kernel, dim3((unsigned)ntr, (unsigned)ntc), dim3(256), gemm_lds, s, b, g,
-                         d_singular);
+      if (Z) {
+        hipLaunchKernelGGL(gemm_update_kernel_z, dim3(1, 1), dim3(256), gemm_lds, fork.helper, b, g, d_singular,
+                           slot(origin), slot(origin) + half);
+        SPL_HIP(hipEventRecord(fork.done, fork.helper));
+        hipLaunchKernelGGL(gemm_update_bulk_kernel_z, dim3((unsigned)ntr, (unsigned)ntc), dim3(256), kUpdateLdsZ, s, b,
+                           g, d_singular);
+      } else {
+        hipLaunchKernelGGL(gemm_update_kernel, dim3(1, 1), dim3(256), gemm_lds, fork.helper, b, g, d_singular,
+                           slot(origin), slot(origin) + half);
+        SPL_HIP(hipEventRecord(fork.done, fork.helper));
+        hipLaunchKernelGGL(gemm_update_bulk_kernel, dim3((unsigned)ntr, (unsigned)ntc), dim3(256), gemm_lds, s, b, g,
+                           d_singular);
+      }
       SPL_HIP(hipStreamWaitEvent(s, fork.done, 0));
       return origin < npiv;
     }
     const dim3 grid = lshape ? dim3((unsigned)(ntr + ntc - 1)) : dim3((unsigned)ntr, (unsigned)ntc);
-    hipLaunchKernelGGL(gemm_update_kernel, grid, dim3(256), gemm_lds, s, b, g, d_singular, slot(origin),
-                       slot(origin) + NB * NB);
+    if (Z)
+      hipLaunchKernelGGL(gemm_update_kernel_z, grid, dim3(256), gemm_lds, s, b, g, d_singular, slot(origin),
+                         slot(origin) + half);
+    else
+      hipLaunchKernelGGL(gemm_update_kernel, grid, dim3(256), gemm_lds, s, b, g, d_singular, slot(origin),
+                         slot(origin) + half);
     return origin < npiv;
   };
   bool diag_done = false;  // the previous update already factored this diagonal block

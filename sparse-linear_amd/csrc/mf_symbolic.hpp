@@ -509,7 +509,11 @@ struct Worker {
 // the real embedding of umfpack_zi.hip, mult = 2, unknowns interleaved — and the tree is the one of the expanded
 // (n mult) x (n mult) matrix: ordered on the small graph (a half of the vertices, a quarter of the edges), every
 // vertex then replaced by its mult unknowns, which stay together in their front.  `leaf` counts small vertices.
-inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, int mult = 1) {
+inline void expand_tree(Tree &T, int mult);
+inline void layout_tree(Tree &T);
+// unexpanded != nullptr (mult > 1): also receives the tree of the small graph itself, laid out for fronts of its own
+// n unknowns (native complex fronts, multifrontal.hip: one dissection serves both)
+inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, int mult = 1, Tree *unexpanded = nullptr) {
   T = Tree();
   T.n = n;
   const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // phase times on stderr (diagnostic)
@@ -630,6 +634,20 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
   }
   lap("boundaries");
   if (mult > 1) {
+    if (unexpanded) {
+      *unexpanded = T;
+      layout_tree(*unexpanded);
+    }
+    expand_tree(T, mult);
+    lap("expansion");
+  }
+  layout_tree(T);
+}
+
+// every vertex replaced by its mult unknowns, which stay together in their front
+inline void expand_tree(Tree &T, int mult) {
+  const int n = T.n, nf = T.nfronts;
+  {
     const size_t m = (size_t)mult;
     std::vector<int> perm((size_t)n * m), inv((size_t)n * m), front_of((size_t)n * m), bidx(T.bidx.size() * m);
     for (size_t k = 0; k < (size_t)n; ++k)
@@ -651,8 +669,14 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
     }
     for (int f = 0; f <= nf; ++f) T.bptr[(size_t)f] *= mult;
     T.n = n * mult;
-    lap("expansion");
   }
+}
+
+inline void layout_tree(Tree &T) {
+  const int nf = T.nfronts;
+  T.front_elems = T.panel_elems = T.inv_elems = T.work_elems = T.rel_elems = 0;
+  T.region_elems[0] = T.region_elems[1] = 0;
+  T.flops = 0.0;
   // storage layout and work estimate
   T.ld.assign((size_t)nf, 0);
   T.foff.assign((size_t)nf, 0);

@@ -49,7 +49,17 @@ struct TreeView {  // raw pointers for kernels
   const int64_t *cboff;  // >= 0: the Schur complement of this front was saved to `cut` (nb x nb, ld nb)
   double *cut;
   int sym;  // 1: A == A^T, the fronts are factored as L D L^T (Band::sym)
-  __device__ __forceinline__ double *front(int f) const { return region[depth[f] & 1] + foff[f]; }
+  // zm = 2: COMPLEX fronts (native `zi` factorisation, round 3).  Every array of doubles holds two planes per object —
+  // real parts, then imaginary parts — at twice the real offset: a front at region + 2 foff[f] with its planes
+  // fplane(f) apart, its P panel at arena + 2 poff[f] (planes ldp np apart), U at arena + 2 uoff[f] (ldu nb), a saved
+  // Schur complement at cut + 2 cboff[f] (nb nb), its inverse blocks at invs + 2 ioff[f] (kInvBlockZ per block).
+  // Indices, leading dimensions and the tree are those of a real matrix with the same pattern.  zm = 1: real.
+  int zm;
+  __device__ __forceinline__ double *front(int f) const { return region[depth[f] & 1] + (int64_t)zm * foff[f]; }
+  __device__ __forceinline__ int64_t fplane(int f) const {  // doubles of one plane of the whole front (make_plan)
+    const int64_t fs = np[f] + nb[f];
+    return ((int64_t)ld[f] * (fs > 1 ? fs : 1) + 15) / 16 * 16;
+  }
 };
 
 template <typename T>
@@ -78,6 +88,10 @@ __device__ __forceinline__ int item_of_tile(const int64_t *__restrict__ prefix, 
 // the CSR arrays (the columns right of it) — every entry lands in the front of its
 // earlier-eliminated index exactly once, and a level only reads the columns and rows of its own
 // pivots.  Flat grid: prefix = groups of 32 pivots before each front.
+// Z: the arrays are those of the real embedding E of a complex matrix (umfpack_zi.hip: interleaved unknowns, block
+// (r, j) = [[re, -im], [im, re]]) and perm / inv its expanded ordering; column 2j of E holds column j of the complex
+// matrix as (re, im) pairs, row 2j of E holds row j as (re, -im) pairs.
+template <bool Z>
 __global__ __launch_bounds__(256) void assemble_kernel(const int *__restrict__ list,
                                                        const int64_t *__restrict__ prefix, int count, TreeView t,
                                                        const int *__restrict__ perm, const int *__restrict__ inv,
@@ -89,9 +103,31 @@ __global__ __launch_bounds__(256) void assemble_kernel(const int *__restrict__ l
   const int f = list[fi];
   const int lp = (int)(flat - prefix[fi]) * 32 + (int)(threadIdx.x >> 3), part = threadIdx.x & 7;
   if (lp >= t.np[f]) return;
-  const int g = t.p0[f] + lp, j = perm[g];
+  const int g = t.p0[f] + lp;
   double *F = t.front(f);
   const int64_t ld = t.ld[f];
+  if (Z) {
+    const int j2 = perm[2 * g];  // = 2 j
+    const int64_t z = t.fplane(f);
+    for (int p = Ap[j2] + 2 * part; p < Ap[j2 + 1]; p += 16) {
+      const int gi = inv[Ai[p]] >> 1;
+      if (gi >= g) {
+        double *dst = F + (int64_t)local_pos(t, f, gi) + (int64_t)lp * ld;
+        dst[0] = Ax[p];
+        dst[z] = Ax[p + 1];
+      }
+    }
+    for (int p = Rp[j2] + 2 * part; p < Rp[j2 + 1]; p += 16) {
+      const int gk = inv[Rj[p]] >> 1;
+      if (gk > g) {
+        double *dst = F + (int64_t)lp + (int64_t)local_pos(t, f, gk) * ld;
+        dst[0] = Rx[p];
+        dst[z] = -Rx[p + 1];
+      }
+    }
+    return;
+  }
+  const int j = perm[g];
   for (int p = Ap[j] + part; p < Ap[j + 1]; p += 8) {
     const int gi = inv[Ai[p]];
     if (gi >= g) F[(int64_t)local_pos(t, f, gi) + (int64_t)lp * ld] = Ax[p];
@@ -127,6 +163,7 @@ constexpr int kTileCols = 16;  // a workgroup moves 64 rows x 16 columns: 4 colu
 // parent += Schur complement of the listed children.  Flat 1-D grid over the 64 x 16 tiles of all
 // children (prefix = tiles before each child): no workgroup is launched for nothing, whatever the
 // mix of sizes.  Lanes run down the rows: contiguous in the child, nearly so in the parent.
+template <bool Z>
 __global__ __launch_bounds__(256) void extend_add_kernel(const int *__restrict__ children,
                                                          const int64_t *__restrict__ prefix, int count,
                                                          TreeView t) {
@@ -149,9 +186,21 @@ __global__ __launch_bounds__(256) void extend_add_kernel(const int *__restrict__
     const int cc = cc0 + u;
     if (cc >= nb) break;
     if (t.sym && cc > r) break;  // symmetric fronts: the child's lower triangle only (what lies above its diagonal tiles is stale)
-    const double v = saved >= 0 ? t.cut[saved + (int64_t)r + (int64_t)cc * nb]
-                                : t.front(c)[(int64_t)(npc + r) + (int64_t)(npc + cc) * t.ld[c]];
+    const double *src = saved >= 0 ? t.cut + (Z ? 2 : 1) * saved + (int64_t)r + (int64_t)cc * nb
+                                   : t.front(c) + (int64_t)(npc + r) + (int64_t)(npc + cc) * t.ld[c];
+    const double v = src[0];
     dst[(int64_t)rel[cc] * ldp] += v;
+    if (Z) {
+      const int64_t zc = saved >= 0 ? (int64_t)nb * nb : t.fplane(c), zp = t.fplane(p);
+      const double vi = src[zc];
+      dst[(int64_t)rel[cc] * ldp + zp] += vi;
+      if (t.sym && cc != r && (rel[cc] >> 6) == (rel[r] >> 6)) {
+        double *m = t.front(p) + (int64_t)rel[cc] + (int64_t)rel[r] * ldp;
+        m[0] += v;
+        m[zp] += vi;
+      }
+      continue;
+    }
     // ... mirrored into the parent's upper triangle where the parent reads it: the 64 x 64 blocks on its diagonal
     // (diagonal blocks are factored, and diagonal tiles of the trailing update computed, whole; every other tile above
     // the diagonal is written by the triangular solves, U12 = D L21^T, before anything reads it).  rel is increasing,
@@ -161,16 +210,21 @@ __global__ __launch_bounds__(256) void extend_add_kernel(const int *__restrict__
 }
 
 // Schur complement of a finished front -> the cut buffer (its parent is assembled much later)
+template <bool Z>
 __global__ __launch_bounds__(256) void save_cb_kernel(int f, TreeView t) {
   const int np = t.np[f], nb = t.nb[f];
   const int ntr = (nb + 63) >> 6;
   const int r = (int)(blockIdx.x % ntr) * 64 + (threadIdx.x & 63), cc = (int)(blockIdx.x / ntr) * 4 + (threadIdx.x >> 6);
   if (r >= nb || cc >= nb) return;
-  t.cut[t.cboff[f] + (int64_t)r + (int64_t)cc * nb] = t.front(f)[(int64_t)(np + r) + (int64_t)(np + cc) * t.ld[f]];
+  const double *src = t.front(f) + (int64_t)(np + r) + (int64_t)(np + cc) * t.ld[f];
+  double *dst = t.cut + (Z ? 2 : 1) * t.cboff[f] + (int64_t)r + (int64_t)cc * nb;
+  dst[0] = src[0];
+  if (Z) dst[(int64_t)nb * nb] = src[t.fplane(f)];
 }
 
 // factor panels of the listed (finished) fronts -> arena, flat grid over the 64 x 16 tiles of the
 // panels: which = 0: P = columns [0, np) (fs rows); which = 1: U = rows [0, np) of the other columns
+template <bool Z>
 __global__ __launch_bounds__(256) void compact_kernel(const int *__restrict__ list,
                                                       const int64_t *__restrict__ prefix, int count, TreeView t,
                                                       int which) {
@@ -190,12 +244,17 @@ __global__ __launch_bounds__(256) void compact_kernel(const int *__restrict__ li
   for (int u = 0; u < 4; ++u) {
     const int j = j0 + u;
     if (j >= cols) break;
-    if (which == 0) t.arena[t.poff[f] + (int64_t)i + (int64_t)j * t.ldp[f]] = src[(int64_t)j * ld];
-    else t.arena[t.uoff[f] + (int64_t)i + (int64_t)j * t.ldu[f]] = src[(int64_t)(np + j) * ld];
+    constexpr int ZM = Z ? 2 : 1;
+    const double *from = which == 0 ? src + (int64_t)j * ld : src + (int64_t)(np + j) * ld;
+    double *to = which == 0 ? t.arena + ZM * t.poff[f] + (int64_t)i + (int64_t)j * t.ldp[f]
+                            : t.arena + ZM * t.uoff[f] + (int64_t)i + (int64_t)j * t.ldu[f];
+    to[0] = from[0];
+    if (Z) to[which == 0 ? (int64_t)t.ldp[f] * np : (int64_t)t.ldu[f] * nb] = from[t.fplane(f)];
   }
 }
 
 // small fronts of a tree level: one workgroup per front runs the whole partial factorisation
+template <bool Z>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void front_factor_kernel(const int *__restrict__ list, TreeView t,
                                                            double *__restrict__ invs, int *__restrict__ singular) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
@@ -203,9 +262,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int np = t.np[f];
   if (np == 0) return;
   const int fs = np + t.nb[f];
-  const Band b{t.front(f), fs, fs, fs, t.ld[f] + 1, 0, t.sym};
-  front_factor_by_workgroup(b, np, invs + t.ioff[f], singular, dsm);
+  if (Z) {
+    const Band b{t.front(f), fs, fs, fs, t.ld[f] + 1, 0, t.sym, (size_t)t.fplane(f)};
+    front_factor_by_workgroup_z(b, np, invs + 2 * t.ioff[f], singular, dsm);
+  } else {
+    const Band b{t.front(f), fs, fs, fs, t.ld[f] + 1, 0, t.sym};
+    front_factor_by_workgroup(b, np, invs + t.ioff[f], singular, dsm);
+  }
 }
+constexpr size_t kFrontLdsZ = kDiagLdsZ > kTrsmLdsZ ? kDiagLdsZ : kTrsmLdsZ;
 
 // Medium fronts of a tree level, all together, one block step at a time: a front of a few
 // thousand rows is a chain of launches that each fill a fraction of the chip, and a level holds tens
@@ -215,18 +280,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // K = 64 update whose tile (0,0) factors the next diagonal block on the way (the look-ahead).
 __device__ __forceinline__ Band mid_front(const TreeView &t, int f) {
   const int fs = t.np[f] + t.nb[f];
-  return Band{t.front(f), fs, fs, fs, t.ld[f] + 1, 0, t.sym};
+  return Band{t.front(f), fs, fs, fs, t.ld[f] + 1, 0, t.sym, t.zm == 2 ? (size_t)t.fplane(f) : 0};
 }
 __device__ __forceinline__ double *mid_slot(const TreeView &t, double *invs, int f, int j0) {
-  return invs + t.ioff[f] + (int64_t)(j0 / NB) * (2 * NB * NB);
+  return invs + (int64_t)t.zm * t.ioff[f] + (int64_t)(j0 / NB) * (t.zm == 2 ? kInvBlockZ : 2 * NB * NB);
 }
 
+template <bool Z>
 __global__ __launch_bounds__(256) void mid_diag_kernel(const int *__restrict__ list, TreeView t,
                                                        double *__restrict__ invs, int *__restrict__ singular) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   const int f = list[blockIdx.x];
   const Band b = mid_front(t, f);
   const int jb = min(NB, t.np[f]);
+  if (Z) {
+    double(*Dr)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);
+    double(*Di)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm + NB * LDP);
+    double(*lcr)[NB] = reinterpret_cast<double(*)[NB]>(dsm + 2 * NB * LDP);
+    double(*lci)[NB] = reinterpret_cast<double(*)[NB]>(dsm + 2 * NB * LDP + 2 * NB);
+    load_diag_z(b, 0, jb, Dr, Di);
+    __syncthreads();
+    double *slot = mid_slot(t, invs, f, 0);
+    diag_block_factor_z(b, 0, jb, Dr, Di, lcr, lci, singular, slot, slot + 2 * NB * NB);
+    return;
+  }
   double(*D)[LDP] = reinterpret_cast<double(*)[LDP]>(dsm);
   double(*lcol)[NB] = reinterpret_cast<double(*)[NB]>(dsm + NB * LDP);
   const int tr = threadIdx.x & 63, tc = threadIdx.x >> 6;
@@ -236,6 +313,7 @@ __global__ __launch_bounds__(256) void mid_diag_kernel(const int *__restrict__ l
   diag_block_factor(b, 0, jb, D, lcol, singular, slot, slot + NB * NB);
 }
 
+template <bool Z>
 __global__ __launch_bounds__(256) void mid_trsm_kernel(const int *__restrict__ list,
                                                        const int64_t *__restrict__ prefix, int count, int step,
                                                        TreeView t, double *__restrict__ invs) {
@@ -246,9 +324,11 @@ __global__ __launch_bounds__(256) void mid_trsm_kernel(const int *__restrict__ l
   const Band b = mid_front(t, f);
   const int j0 = step * NB, jb = min(NB, t.np[f] - j0), rest = b.n - (j0 + jb);
   const double *slot = mid_slot(t, invs, f, j0);
-  trsm_tile(b, j0, jb, rest, rest, slot, slot + NB * NB, (int)(flat - prefix[fi]), dsm);
+  if (Z) trsm_tile_z(b, j0, jb, rest, rest, slot, slot + 2 * NB * NB, (int)(flat - prefix[fi]), dsm);
+  else trsm_tile(b, j0, jb, rest, rest, slot, slot + NB * NB, (int)(flat - prefix[fi]), dsm);
 }
 
+template <bool Z>
 __global__ __launch_bounds__(256) void mid_update_kernel(const int *__restrict__ list,
                                                          const int64_t *__restrict__ prefix, int count, int step,
                                                          TreeView t, double *__restrict__ invs,
@@ -263,7 +343,8 @@ __global__ __launch_bounds__(256) void mid_update_kernel(const int *__restrict__
   const int tile = (int)(flat - prefix[fi]);
   const Region g{origin, b.n, origin, b.n, j0, jb, 0, ntile, np};
   double *next = mid_slot(t, invs, f, origin);  // only written when origin is a pivot block
-  update_tile<true>(b, g, tile % ntile, tile / ntile, singular, next, next + NB * NB, dsm);
+  if (Z) update_tile_z<true>(b, g, tile % ntile, tile / ntile, singular, next, next + 2 * NB * NB, dsm);
+  else update_tile<true>(b, g, tile % ntile, tile / ntile, singular, next, next + NB * NB, dsm);
 }
 
 constexpr int kSmallFront = 128;   // fronts up to this size are factored by one workgroup each
@@ -283,20 +364,43 @@ constexpr int kBigSolve = 256;       // fronts above this size are solved by man
 struct Panels {
   const double *P, *U;
   int np, nb, fs, ldp, ldu;
+  size_t pz, uz;  // complex fronts: the imaginary planes of P and U lie this many doubles further (0: real)
   // column j of F, rows from 0 (valid rows: fs for j < np, np otherwise)
   __device__ __forceinline__ const double *col(int j) const {
     return j < np ? P + (size_t)j * ldp : U + (size_t)(j - np) * ldu;
   }
   __device__ __forceinline__ int col_stride(int j) const { return j < np ? ldp : ldu; }
+  __device__ __forceinline__ size_t zcol(int j) const { return j < np ? pz : uz; }
 };
 
 __device__ __forceinline__ Panels panels_of(const TreeView &t, int f) {
-  return Panels{t.arena + t.poff[f], t.arena + t.uoff[f], t.np[f], t.nb[f], t.np[f] + t.nb[f], t.ldp[f], t.ldu[f]};
+  const int np = t.np[f], nb = t.nb[f];
+  if (t.zm == 2)
+    return Panels{t.arena + 2 * t.poff[f], t.arena + 2 * t.uoff[f], np, nb, np + nb, t.ldp[f], t.ldu[f],
+                  (size_t)t.ldp[f] * (size_t)np, (size_t)t.ldu[f] * (size_t)nb};
+  return Panels{t.arena + t.poff[f], t.arena + t.uoff[f], np, nb, np + nb, t.ldp[f], t.ldu[f], 0, 0};
+}
+
+// acc[:] += e * v[:] over NR columns; Z: the columns are (re, im) pairs of NR / 2 complex right-hand sides and
+// e = er + i ei
+template <int NR, bool Z>
+__device__ __forceinline__ void mac_row(double (&acc)[NR], double er, double ei, const double *v) {
+  if (!Z) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] += er * v[r];
+  } else {
+#pragma unroll
+    for (int q = 0; q < NR / 2; ++q) {
+      acc[2 * q] += er * v[2 * q] - ei * v[2 * q + 1];
+      acc[2 * q + 1] += er * v[2 * q + 1] + ei * v[2 * q];
+    }
+  }
 }
 
 // v = T w for the 64 x 64 inverse diagonal block (column-major), T = inv or inv^T, NR columns; the
 // first 256 threads of the workgroup, 4 per row
-template <bool TRANS, int NR>
+// (Z: the inverse in two planes NB * NB apart; TRANS is then the CONJUGATE transpose)
+template <bool TRANS, int NR, bool Z = false>
 __device__ __forceinline__ void apply_inverse_block(const double *__restrict__ inv, const double (*w)[NR],
                                                     double (*v)[NR]) {
   if (threadIdx.x >= 256) return;
@@ -307,9 +411,10 @@ __device__ __forceinline__ void apply_inverse_block(const double *__restrict__ i
 #pragma unroll 4
   for (int u = 0; u < NB / 4; ++u) {
     const int tt = q + 4 * u;
-    const double e = TRANS ? inv[tt + l * NB] : inv[l + tt * NB];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) acc[r] += e * w[tt][r];
+    const int at = TRANS ? tt + l * NB : l + tt * NB;
+    const double e = inv[at];
+    const double ei = Z ? (TRANS ? -inv[NB * NB + at] : inv[NB * NB + at]) : 0.0;
+    mac_row<NR, Z>(acc, e, ei, &w[tt][0]);
   }
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -323,13 +428,13 @@ __device__ __forceinline__ void apply_inverse_block(const double *__restrict__ i
 // a matrix entry is loaded once for all NR columns.  The jb columns c0 .. c0+jb-1 lie on one side of
 // np.  Untransposed the panels run down i (thread = row, 8 loads in flight); transposed they run
 // along tt (a wavefront per row, lanes along tt, butterfly sums).  W is fs x NR column-major.
-template <bool TRANS, int NR>
+template <bool TRANS, int NR, bool Z = false>
 __device__ __forceinline__ void couple_block(const Panels &fr, int ilo, int ihi, int c0, int jb,
                                              const double (*v)[NR], double *W) {
   const int fs = fr.fs;
   if (!TRANS) {
     const double *base = fr.col(c0);
-    const size_t cs = (size_t)fr.col_stride(c0);
+    const size_t cs = (size_t)fr.col_stride(c0), zp = fr.zcol(c0);
     for (int i = ilo + threadIdx.x; i < ihi; i += blockDim.x) {
       const double *row = base + i;
       double acc[NR];
@@ -337,45 +442,57 @@ __device__ __forceinline__ void couple_block(const Panels &fr, int ilo, int ihi,
       for (int r = 0; r < NR; ++r) acc[r] = 0.0;
       int tt = 0;
       for (; tt + 8 <= jb; tt += 8) {
-        double e[8];
+        double e[8], ei[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) e[u] = row[(size_t)(tt + u) * cs];
+        for (int u = 0; u < 8; ++u) {
+          e[u] = row[(size_t)(tt + u) * cs];
+          ei[u] = Z ? row[(size_t)(tt + u) * cs + zp] : 0.0;
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-          for (int r = 0; r < NR; ++r) acc[r] += e[u] * v[tt + u][r];
+        for (int u = 0; u < 8; ++u) mac_row<NR, Z>(acc, e[u], ei[u], &v[tt + u][0]);
       }
       for (; tt < jb; ++tt) {
         const double e = row[(size_t)tt * cs];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) acc[r] += e * v[tt][r];
+        const double ei = Z ? row[(size_t)tt * cs + zp] : 0.0;
+        mac_row<NR, Z>(acc, e, ei, &v[tt][0]);
       }
 #pragma unroll
       for (int r = 0; r < NR; ++r) W[(size_t)r * fs + i] -= acc[r];
     }
   } else {
-    // M(i, c0 + tt) = F(c0 + tt, i): rows c0 .. of column i of F, contiguous
+    // M(i, c0 + tt) = F(c0 + tt, i) (Z: its conjugate): rows c0 .. of column i of F, contiguous
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     constexpr int RW = NR == 1 ? 8 : 2;  // rows per wavefront and trip
     for (int i0 = ilo + wave * RW; i0 < ihi; i0 += nw * RW) {
-      double e[RW];
+      double e[RW], ei[RW];
 #pragma unroll
-      for (int u = 0; u < RW; ++u) e[u] = (i0 + u < ihi && lane < jb) ? fr.col(i0 + u)[c0 + lane] : 0.0;
+      for (int u = 0; u < RW; ++u) {
+        const bool in = i0 + u < ihi && lane < jb;
+        const double *src = in ? fr.col(i0 + u) + c0 + lane : nullptr;
+        e[u] = in ? src[0] : 0.0;
+        ei[u] = (Z && in) ? -src[fr.zcol(i0 + u)] : 0.0;
+      }
 #pragma unroll
-      for (int u = 0; u < RW; ++u)
+      for (int u = 0; u < RW; ++u) {
+        double part[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) part[r] = 0.0;
+        if (lane < jb) mac_row<NR, Z>(part, e[u], ei[u], &v[lane][0]);
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-          double sacc = lane < jb ? e[u] * v[lane][r] : 0.0;
+          double sacc = part[r];
 #pragma unroll
           for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
           if (lane == 0 && i0 + u < ihi) W[(size_t)r * fs + i0 + u] -= sacc;
         }
+      }
     }
   }
 }
 
 // W = [rhs at the pivots | 0]
-template <int NR>
+// (Z: column r of W is the real (r even) or imaginary part of the packed complex right-hand side r / 2)
+template <int NR, bool Z = false>
 __global__ __launch_bounds__(256) void solve_init_kernel(const int *__restrict__ list, TreeView t,
                                                          const double *__restrict__ c, size_t stride,
                                                          double *__restrict__ work) {
@@ -384,7 +501,8 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const int *__restrict__
   double *W = work + (size_t)t.woff[f] * NR;
   for (int o = threadIdx.x; o < fs * NR; o += blockDim.x) {
     const int i = o % fs, r = o / fs;
-    W[o] = i < np ? c[(size_t)r * stride + t.p0[f] + i] : 0.0;
+    if (Z) W[o] = i < np ? c[(size_t)(r >> 1) * stride + 2 * (size_t)(t.p0[f] + i) + (r & 1)] : 0.0;
+    else W[o] = i < np ? c[(size_t)r * stride + t.p0[f] + i] : 0.0;
   }
 }
 
@@ -406,7 +524,7 @@ __global__ __launch_bounds__(256) void solve_gather_kernel(const int *__restrict
 
 // forward elimination inside a front: y = M11^-1 W[0:np) block by block (stored inverses of the diagonal
 // blocks), every later entry of W loses its coupling with the block just solved
-template <bool TRANS, int NR>
+template <bool TRANS, int NR, bool Z = false>
 __global__ __launch_bounds__(kSolveThreads) void solve_forward_kernel(const int *__restrict__ list, TreeView t,
                                                                       const double *__restrict__ invs,
                                                                       double *__restrict__ work) {
@@ -423,21 +541,22 @@ __global__ __launch_bounds__(kSolveThreads) void solve_forward_kernel(const int 
     }
     __syncthreads();
     // forward: L (unit lower) or U^T -> inverse of L11, or of U11 transposed
-    const double *inv = invs + t.ioff[f] + (size_t)(j0 / NB) * (2 * NB * NB) + (TRANS ? NB * NB : 0);
-    apply_inverse_block<TRANS, NR>(inv, w, v);
+    constexpr size_t blk = Z ? (size_t)kInvBlockZ : (size_t)(2 * NB * NB);
+    const double *inv = invs + (Z ? 2 : 1) * t.ioff[f] + (size_t)(j0 / NB) * blk + (TRANS ? blk / 2 : 0);
+    apply_inverse_block<TRANS, NR, Z>(inv, w, v);
     __syncthreads();
     for (int o = threadIdx.x; o < jb * NR; o += blockDim.x) {
       const int l = o % jb, r = o / jb;
       W[(size_t)r * fs + j0 + l] = v[l][r];
     }
-    couple_block<TRANS, NR>(fr, j0 + jb, fs, j0, jb, v, W);
+    couple_block<TRANS, NR, Z>(fr, j0 + jb, fs, j0, jb, v, W);
     __syncthreads();
   }
 }
 
 // back substitution inside a front: x_piv = M11^-1 (y - M12 x_bnd), x_bnd read from the solution of
 // the ancestors; writes the pivots' part of the solution
-template <bool TRANS, int NR>
+template <bool TRANS, int NR, bool Z = false>
 __global__ __launch_bounds__(kSolveThreads) void solve_backward_kernel(const int *__restrict__ list, TreeView t,
                                                                        const double *__restrict__ invs,
                                                                        double *__restrict__ work,
@@ -452,10 +571,11 @@ __global__ __launch_bounds__(kSolveThreads) void solve_backward_kernel(const int
     const int kb = min(NB, nb - k0);
     for (int o = threadIdx.x; o < NB * NR; o += blockDim.x) {
       const int l = o % NB, r = o / NB;
-      v[l][r] = l < kb ? x[(size_t)r * stride + b[k0 + l]] : 0.0;
+      if (Z) v[l][r] = l < kb ? x[(size_t)(r >> 1) * stride + 2 * (size_t)b[k0 + l] + (r & 1)] : 0.0;
+      else v[l][r] = l < kb ? x[(size_t)r * stride + b[k0 + l]] : 0.0;
     }
     __syncthreads();
-    couple_block<TRANS, NR>(fr, 0, np, np + k0, kb, v, W);
+    couple_block<TRANS, NR, Z>(fr, 0, np, np + k0, kb, v, W);
     __syncthreads();
   }
   const int nblk = (np + NB - 1) / NB;
@@ -467,14 +587,16 @@ __global__ __launch_bounds__(kSolveThreads) void solve_backward_kernel(const int
     }
     __syncthreads();
     // backward: U or L^T -> inverse of U11, or of L11 transposed
-    const double *inv = invs + t.ioff[f] + (size_t)blk * (2 * NB * NB) + (TRANS ? 0 : NB * NB);
-    apply_inverse_block<TRANS, NR>(inv, w, v);
+    constexpr size_t ib = Z ? (size_t)kInvBlockZ : (size_t)(2 * NB * NB);
+    const double *inv = invs + (Z ? 2 : 1) * t.ioff[f] + (size_t)blk * ib + (TRANS ? 0 : ib / 2);
+    apply_inverse_block<TRANS, NR, Z>(inv, w, v);
     __syncthreads();
     for (int o = threadIdx.x; o < jb * NR; o += blockDim.x) {
       const int l = o % jb, r = o / jb;
-      x[(size_t)r * stride + p0 + j0 + l] = v[l][r];
+      if (Z) x[(size_t)(r >> 1) * stride + 2 * (size_t)(p0 + j0 + l) + (r & 1)] = v[l][r];
+      else x[(size_t)r * stride + p0 + j0 + l] = v[l][r];
     }
-    couple_block<TRANS, NR>(fr, 0, j0, j0, jb, v, W);
+    couple_block<TRANS, NR, Z>(fr, 0, j0, j0, jb, v, W);
     __syncthreads();
   }
 }
@@ -681,6 +803,7 @@ struct Factors {
   std::vector<std::vector<int64_t>> h_ctile[2], h_ptile, h_utile, h_atile;  // h_atile: groups of 32 pivots (assembly)
   std::vector<DBuf<int64_t>> ctile[2], ptile, utile, atile;
   int singular = 0;
+  int zm = 1;         // 2: complex fronts in two planes (TreeView::zm)
   int big_solve = 0;  // fronts above this size are solved by many workgroups (kBigSolve; SPL_MF_BIGSOLVE)
   // those fronts, per depth, and the flat grids of their lockstep solve kernels: segments of
   // count + 1 prefix sums (workgroups before each front), in this order: untransposed forward
@@ -798,16 +921,19 @@ Plan make_plan(const mf::Tree &T, int cut) {
 
 }  // namespace
 
-size_t mf_device_bytes(const mf::Tree &T) {  // resident part; the transient part is planned in mf_factor
-  return ((size_t)T.panel_elems + (size_t)T.inv_elems + 3 * (size_t)T.work_elems) * sizeof(double) +
+size_t mf_device_bytes(const mf::Tree &T, int zm) {  // resident part; the transient part is planned in mf_factor
+  return ((size_t)zm * ((size_t)T.panel_elems + (size_t)T.inv_elems) + 3 * (size_t)zm * (size_t)T.work_elems) * sizeof(double) +
          ((size_t)T.bidx.size() + (size_t)T.rel_elems + 14 * (size_t)T.nfronts + (size_t)T.n) * sizeof(int64_t);
 }
 
 // numeric factorisation of P A P^T; d_Ap/d_Ai/d_Ax: CSC arrays of A on the device, d_Rp/d_Rj/d_Rx: its CSR
 // arrays, d_perm: new -> old, d_inv: old -> new
-mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, const int *d_Ai, const double *d_Ax,
-                       const int *d_Rp, const int *d_Rj, const double *d_Rx, const int *d_perm, const int *d_inv,
-                       hipStream_t s, bool symmetric) {
+namespace {
+template <bool Z>
+mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, const int *d_Ai, const double *d_Ax,
+                         const int *d_Rp, const int *d_Rj, const double *d_Rx, const int *d_perm, const int *d_inv,
+                         hipStream_t s, bool symmetric) {
+  constexpr int ZM = Z ? 2 : 1;
   const mf::Tree &T = *tree;
   const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // phase times on stderr (diagnostic)
   auto clock_now = [] { return std::chrono::steady_clock::now(); };
@@ -822,24 +948,27 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   std::unique_ptr<mf::Factors> Fp(new mf::Factors());
   mf::Factors &F = *Fp;
   F.tree = tree;
+  F.zm = ZM;
   F.big_solve = getenv("SPL_MF_BIGSOLVE") ? std::max(64, atoi(getenv("SPL_MF_BIGSOLVE"))) : kBigSolve;
+  if (Z) F.big_solve = 0x7fffffff;  // complex fronts: every front is solved by one workgroup (no lockstep solve kernels yet)
   const int nd = T.maxdepth + 1, nf = T.nfronts;
   const int small_limit = getenv("SPL_MF_SMALL") ? std::max(64, atoi(getenv("SPL_MF_SMALL"))) : kSmallFront;  // tuning knob
   // ---- memory plan: the smallest cut depth whose transient part fits next to the resident part
   Plan plan;
   {
     const size_t free_b = device_free_bytes();
-    const double budget = (double)free_b - (double)free_b / 16 - (double)mf_device_bytes(T);
+    const double budget = (double)free_b - (double)free_b / 16 - (double)mf_device_bytes(T, ZM);
     const char *force = getenv("SPL_MF_CUT");  // tests: force a cut depth
     bool ok = false;
     for (int cut = force ? std::max(0, std::min(atoi(force), nd - 1)) : 0; cut < std::max(nd, 1) && cut <= 10; ++cut) {
       plan = make_plan(T, cut);
-      if ((double)plan.transient_elems() * sizeof(double) <= budget || force) { ok = true; break; }
+      if ((double)plan.transient_elems() * sizeof(double) * ZM <= budget || force) { ok = true; break; }
     }
     if (!ok) throw DeviceError{SPL_ERROR_out_of_memory};
     if (timing)
-      fprintf(stderr, "[mf_factor] panels %.1f GB, transient %.1f GB at cut depth %d (free %.1f GB)\n",
-              T.panel_elems * 8e-9, plan.transient_elems() * 8e-9, plan.cut, free_b * 1e-9);
+      fprintf(stderr, "[mf_factor] %spanels %.1f GB, transient %.1f GB at cut depth %d (free %.1f GB)\n",
+              Z ? "complex fronts: " : "", ZM * T.panel_elems * 8e-9, ZM * plan.transient_elems() * 8e-9, plan.cut,
+              free_b * 1e-9);
   }
   // the device copy of the tree and the relative indices: built once per tree and device, then shared
   {
@@ -871,7 +1000,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
       const TreeView v{N.p0.get(),   N.np.get(),   N.nb.get(),   N.ld.get(),   N.parent.get(), N.front_of.get(),
                        N.bidx.get(), N.rel.get(),  N.depth.get(), N.ldp.get(), N.ldu.get(),    N.bptr.get(),
                        nullptr,      N.ioff.get(), N.woff.get(), N.roff.get(), N.poff.get(),   N.uoff.get(),
-                       {nullptr, nullptr}, nullptr, nullptr, nullptr};
+                       {nullptr, nullptr}, nullptr, nullptr, nullptr, 0, 1};
       if (nf > 0) hipLaunchKernelGGL(rel_kernel, dim3((unsigned)nf), dim3(256), 0, s, nf, v, N.rel.get());
       SPL_HIP(hipStreamSynchronize(s));  // the host vectors of the tree may go away with it
       SPL_HIP(hipGetLastError());
@@ -884,15 +1013,15 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   upload_vec(F.d_foff, plan.foff, s);
   upload_vec(F.d_cboff, plan.cboff, s);
   lap("tree uploads (queued)");
-  F.arena.alloc((size_t)T.panel_elems);
-  F.invs.alloc((size_t)T.inv_elems);
-  DBuf<double> region0((size_t)plan.region_elems[0]), region1((size_t)plan.region_elems[1]),
-      cutbuf((size_t)plan.cut_elems);  // transient
+  F.arena.alloc((size_t)ZM * (size_t)T.panel_elems);
+  F.invs.alloc((size_t)ZM * (size_t)T.inv_elems);
+  DBuf<double> region0((size_t)ZM * (size_t)plan.region_elems[0]), region1((size_t)ZM * (size_t)plan.region_elems[1]),
+      cutbuf((size_t)ZM * (size_t)plan.cut_elems);  // transient
   lap("hipMalloc");
   F.view = TreeView{D.p0.get(),    D.np.get(),   D.nb.get(),   D.ld.get(),   D.parent.get(), D.front_of.get(),
                     D.bidx.get(),  D.rel.get(),  D.depth.get(), D.ldp.get(), D.ldu.get(),    D.bptr.get(),
                     F.d_foff.get(), D.ioff.get(), D.woff.get(), D.roff.get(), D.poff.get(),  D.uoff.get(),
-                    {region0.get(), region1.get()}, F.arena.get(), F.d_cboff.get(), cutbuf.get(), symmetric ? 1 : 0};
+                    {region0.get(), region1.get()}, F.arena.get(), F.d_cboff.get(), cutbuf.get(), symmetric ? 1 : 0, ZM};
   F.level_lists.resize((size_t)nd);
   F.small_lists.resize((size_t)nd);
   F.small_counts.assign((size_t)nd, 0);
@@ -1012,10 +1141,16 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   set_factor_attributes();
   static bool attr_set = false;
   if (!attr_set) {
-    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&front_factor_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
-    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mid_trsm_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&front_factor_kernel<Z>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(Z ? kFrontLdsZ : 2 * kTileBytes)));
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mid_trsm_kernel<Z>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(Z ? kTrsmLdsZ : 2 * kTileBytes)));
+    if (Z) {
+      SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mid_diag_kernel<Z>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDiagLdsZ));
+      SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mid_update_kernel<Z>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDiagLdsZ));
+    }
     attr_set = true;
   }
   F.make_streams();
@@ -1040,10 +1175,10 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
     const int64_t tp = F.h_ptile[(size_t)d][(size_t)b1] - F.h_ptile[(size_t)d][(size_t)b0];
     const int64_t tu = F.h_utile[(size_t)d][(size_t)b1] - F.h_utile[(size_t)d][(size_t)b0];
     if (tp > 0)
-      hipLaunchKernelGGL(compact_kernel, dim3((unsigned)tp), dim3(256), 0, s, F.level_lists[(size_t)d].get() + b0,
+      hipLaunchKernelGGL(compact_kernel<Z>, dim3((unsigned)tp), dim3(256), 0, s, F.level_lists[(size_t)d].get() + b0,
                          F.ptile[(size_t)d].get() + b0, b1 - b0, F.view, 0);
     if (tu > 0)
-      hipLaunchKernelGGL(compact_kernel, dim3((unsigned)tu), dim3(256), 0, s, F.level_lists[(size_t)d].get() + b0,
+      hipLaunchKernelGGL(compact_kernel<Z>, dim3((unsigned)tu), dim3(256), 0, s, F.level_lists[(size_t)d].get() + b0,
                          F.utile[(size_t)d].get() + b0, b1 - b0, F.view, 1);
   };
   // levels dbot .. dtop (bottom-up) of the fronts with ids lo..hi.  children_saved: the children of
@@ -1057,13 +1192,13 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
       int64_t extent = 0;
       for (int i = b0; i < b1; ++i) {
         const int f = T.by_depth[(size_t)d][(size_t)i];
-        extent = std::max(extent, plan.foff[(size_t)f] + (int64_t)T.ld[(size_t)f] * std::max(T.fs(f), 1));
+        extent = std::max(extent, plan.foff[(size_t)f] + ((int64_t)T.ld[(size_t)f] * std::max(T.fs(f), 1) + 15) / 16 * 16);
       }
-      SPL_HIP(hipMemsetAsync(region_of(d), 0, (size_t)extent * sizeof(double), s));
+      SPL_HIP(hipMemsetAsync(region_of(d), 0, (size_t)ZM * (size_t)extent * sizeof(double), s));
       {
         const int64_t groups = F.h_atile[(size_t)d][(size_t)b1] - F.h_atile[(size_t)d][(size_t)b0];
         if (groups > 0)
-          hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)groups), dim3(256), 0, s,
+          hipLaunchKernelGGL(assemble_kernel<Z>, dim3((unsigned)groups), dim3(256), 0, s,
                              F.level_lists[(size_t)d].get() + b0, F.atile[(size_t)d].get() + b0, b1 - b0, F.view, d_perm,
                              d_inv, d_Ap, d_Ai, d_Ax, d_Rp, d_Rj, d_Rx);
       }
@@ -1076,7 +1211,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
           if (c1 == c0) continue;
           const int64_t tc = F.h_ctile[sl][(size_t)d][(size_t)c1] - F.h_ctile[sl][(size_t)d][(size_t)c0];
           if (tc > 0)
-            hipLaunchKernelGGL(extend_add_kernel, dim3((unsigned)tc), dim3(256), 0, s,
+            hipLaunchKernelGGL(extend_add_kernel<Z>, dim3((unsigned)tc), dim3(256), 0, s,
                                F.child_lists[sl][(size_t)d].get() + c0, F.ctile[sl][(size_t)d].get() + c0, c1 - c0,
                                F.view);
         }
@@ -1095,7 +1230,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
       int s0, s1;
       range_of(F.h_small[(size_t)d], lo, hi, s0, s1);
       if (s1 > s0)
-        hipLaunchKernelGGL(front_factor_kernel, dim3((unsigned)(s1 - s0)), dim3(256), 2 * kTileBytes, s,
+        hipLaunchKernelGGL(front_factor_kernel<Z>, dim3((unsigned)(s1 - s0)), dim3(256), Z ? kFrontLdsZ : 2 * kTileBytes, s,
                            F.small_lists[(size_t)d].get() + s0, F.view, F.invs.get(), singular.get());
       // medium fronts: lockstep over block steps, one flat launch per phase and step
       {
@@ -1135,18 +1270,18 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
           const std::vector<int64_t> &hp = staged64.back();
           const int *dl = mid_lists.back().get();
           const int64_t *dp = mid_prefixes.back().get();
-          hipLaunchKernelGGL(mid_diag_kernel, dim3((unsigned)count), dim3(256), kTileBytes + 2 * NB * sizeof(double), s,
-                             dl, F.view, F.invs.get(), singular.get());
+          hipLaunchKernelGGL(mid_diag_kernel<Z>, dim3((unsigned)count), dim3(256),
+                             Z ? kDiagLdsZ : kTileBytes + 2 * NB * sizeof(double), s, dl, F.view, F.invs.get(), singular.get());
           for (int st = 0; st < steps; ++st) {
             const size_t base = ((size_t)st * 2) * (size_t)(count + 1);
             const int64_t nt = hp[base + (size_t)count], nu = hp[base + (size_t)(count + 1) + (size_t)count];
             if (nt > 0)
-              hipLaunchKernelGGL(mid_trsm_kernel, dim3((unsigned)nt), dim3(256), kTrsmLds, s, dl, dp + base, count,
-                                 st, F.view, F.invs.get());
+              hipLaunchKernelGGL(mid_trsm_kernel<Z>, dim3((unsigned)nt), dim3(256), Z ? kTrsmLdsZ : kTrsmLds, s, dl,
+                                 dp + base, count, st, F.view, F.invs.get());
             if (nu > 0)
-              hipLaunchKernelGGL(mid_update_kernel, dim3((unsigned)nu), dim3(256),
-                                 kTileBytes + 2 * NB * sizeof(double), s, dl, dp + base + (size_t)(count + 1), count, st,
-                                 F.view, F.invs.get(), singular.get());
+              hipLaunchKernelGGL(mid_update_kernel<Z>, dim3((unsigned)nu), dim3(256),
+                                 Z ? kDiagLdsZ : kTileBytes + 2 * NB * sizeof(double), s, dl,
+                                 dp + base + (size_t)(count + 1), count, st, F.view, F.invs.get(), singular.get());
           }
         }
       }
@@ -1154,9 +1289,12 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
       for (int i = b0; i < b1; ++i) {
         const int f = T.by_depth[(size_t)d][(size_t)i];
         if (T.np[(size_t)f] == 0 || T.fs(f) <= mid_limit) continue;
-        const Band b = dense_view(region_of(d) + plan.foff[(size_t)f], T.fs(f), T.ld[(size_t)f], symmetric ? 1 : 0);
+        const size_t plane = Z ? (size_t)(((int64_t)T.ld[(size_t)f] * std::max(T.fs(f), 1) + 15) / 16 * 16) : 0;
+        const Band b = dense_view(region_of(d) + (size_t)ZM * (size_t)plan.foff[(size_t)f], T.fs(f), T.ld[(size_t)f],
+                                  symmetric ? 1 : 0, plane);
         const int lane = turn++ % kStreams;
-        factor_loop(b, T.np[(size_t)f], F.invs.get() + T.ioff[(size_t)f], singular.get(), side[lane], side[kStreams + lane]);
+        factor_loop<Z>(b, T.np[(size_t)f], F.invs.get() + (size_t)ZM * (size_t)T.ioff[(size_t)f], singular.get(), side[lane],
+                       side[kStreams + lane]);
       }
       if (turn > 0)
         for (int i = 0; i < kStreams && i < turn; ++i) SPL_HIP(hipStreamSynchronize(side[i]));
@@ -1178,7 +1316,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
       compact_fronts(plan.cut, r, r);
       const int nb = T.nb[(size_t)r];
       const int64_t ntile = (int64_t)((nb + 63) / 64) * ((nb + 3) / 4);
-      if (ntile > 0) hipLaunchKernelGGL(save_cb_kernel, dim3((unsigned)ntile), dim3(256), 0, s, r, F.view);
+      if (ntile > 0) hipLaunchKernelGGL(save_cb_kernel<Z>, dim3((unsigned)ntile), dim3(256), 0, s, r, F.view);
       SPL_HIP(hipStreamSynchronize(s));
     }
     process(0, nf - 1, 0, plan.cut - 1, true);  // the top of the tree
@@ -1192,6 +1330,16 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
   F.view.region[0] = F.view.region[1] = nullptr;  // the transient buffers are released here
   F.view.cut = nullptr;
   return Fp.release();
+}
+}  // namespace
+
+// zfront: the arrays are those of the real embedding of a complex matrix and `tree` is the tree of the COMPLEX pattern
+// (half the unknowns): fronts, panels and inverses are complex, in two planes (TreeView::zm)
+mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, const int *d_Ai, const double *d_Ax,
+                       const int *d_Rp, const int *d_Rj, const double *d_Rx, const int *d_perm, const int *d_inv,
+                       hipStream_t s, bool symmetric, bool zfront) {
+  return zfront ? mf_factor_t<true>(tree, d_Ap, d_Ai, d_Ax, d_Rp, d_Rj, d_Rx, d_perm, d_inv, s, symmetric)
+                : mf_factor_t<false>(tree, d_Ap, d_Ai, d_Ax, d_Rp, d_Rj, d_Rx, d_perm, d_inv, s, symmetric);
 }
 
 // NR columns (c + r * stride) through the tree: up with L (or U^T), down with U (or L^T).  Per level:
@@ -1213,7 +1361,7 @@ static void launch_big_super(const mf::Factors &F, const mf::Factors::BigLevel &
                        B.prefix(kind, step), B.count, step, F.view, F.invs.get(), work, zbuf, B.row_blocks);
 }
 
-template <bool TRANS, int NR>
+template <bool TRANS, int NR, bool Z = false>
 static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride, double *work, double *zbuf,
                                   hipStream_t s) {
   const mf::Tree &T = *F.tree;
@@ -1235,19 +1383,19 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
   t_last = std::chrono::steady_clock::now();
   for (int d = nd - 1; d >= 0; --d) {
     const unsigned nf = (unsigned)T.by_depth[(size_t)d].size();
-    hipLaunchKernelGGL(solve_init_kernel<NR>, dim3(nf), dim3(256), 0, s, F.level_lists[(size_t)d].get(), F.view, c,
-                       stride, work);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_init_kernel<NR, Z>), dim3(nf), dim3(256), 0, s, F.level_lists[(size_t)d].get(),
+                       F.view, c, stride, work);
     if (d + 1 < nd)
       for (int sl = 0; sl < 2; ++sl)
         if (F.child_counts[sl][(size_t)d] > 0)
           hipLaunchKernelGGL(solve_gather_kernel<NR>, dim3((unsigned)F.child_counts[sl][(size_t)d]), dim3(256), 0, s,
                              F.child_lists[sl][(size_t)d].get(), F.view, work);
     if (F.solve_counts[(size_t)d] > 0)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_forward_kernel<TRANS, NR>), dim3((unsigned)F.solve_counts[(size_t)d]),
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_forward_kernel<TRANS, NR, Z>), dim3((unsigned)F.solve_counts[(size_t)d]),
                          dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work);
     lap("up small  ", d);
     const mf::Factors::BigLevel &B = F.big[(size_t)d];
-    if (B.count > 0) {
+    if (!Z && B.count > 0) {
       // untransposed: the boundary rows get their updates inside the pass over the pivot columns;
       // transposed: U11^T on the pivots, then the boundary with U12^T
       for (int k = 0; k < B.steps; ++k) launch_big_super<FWD, NR>(F, B, TRANS ? 1 : 0, k, work, zbuf, s);
@@ -1259,12 +1407,12 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
   }
   for (int d = 0; d < nd; ++d) {
     if (F.solve_counts[(size_t)d] > 0)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_backward_kernel<TRANS, NR>), dim3((unsigned)F.solve_counts[(size_t)d]),
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_backward_kernel<TRANS, NR, Z>), dim3((unsigned)F.solve_counts[(size_t)d]),
                          dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work, c,
                          stride);
     lap("down small", d);
     const mf::Factors::BigLevel &B = F.big[(size_t)d];
-    if (B.count > 0) {
+    if (!Z && B.count > 0) {
       if (B.total(4) > 0) {
         hipLaunchKernelGGL(big_gather_x_kernel<NR>, dim3(B.total(4)), dim3(256), 0, s, B.list.get(), B.prefix(4),
                            B.count, F.view, c, stride, work, zbuf);
@@ -1286,6 +1434,25 @@ void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride,
   const mf::Factors &F = *Fp;
   const mf::Tree &T = *F.tree;
   if (T.n == 0 || k == 0) return;
+  if (F.zm == 2) {
+    // complex fronts: the k columns are packed complex vectors of T.n entries (stride doubles apart); a complex
+    // right-hand side is two real columns of the work matrices: one at a time, or four together
+    constexpr int kGroupZ = 4;
+    const int nrz = k == 1 ? 2 : 2 * kGroupZ;
+    DBuf<double> wz((size_t)T.work_elems * nrz);
+    if (k == 1) {
+      if (sys == 0) solve_columns_on_tree<false, 2, true>(F, d_c, stride, wz.get(), nullptr, s);
+      else solve_columns_on_tree<true, 2, true>(F, d_c, stride, wz.get(), nullptr, s);
+    } else {
+      for (int c0 = 0; c0 < k; c0 += kGroupZ) {  // (k is a multiple of kSolveGroup = 8 here: zero-padded by the caller)
+        double *c = d_c + (size_t)c0 * stride;
+        if (sys == 0) solve_columns_on_tree<false, 2 * kGroupZ, true>(F, c, stride, wz.get(), nullptr, s);
+        else solve_columns_on_tree<true, 2 * kGroupZ, true>(F, c, stride, wz.get(), nullptr, s);
+      }
+    }
+    SPL_HIP(hipStreamSynchronize(s));
+    return;
+  }
   const int nr = k == 1 ? 1 : kSolveGroup;
   DBuf<double> both((size_t)T.work_elems * nr * 2);  // work and z matrices of all fronts, one allocation
   struct Span {

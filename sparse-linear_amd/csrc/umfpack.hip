@@ -53,6 +53,9 @@ struct Symbolic {
   uint64_t ai_hash = 0;   // ... together with a hash of the row indices
   // nested-dissection tree of the multifrontal path, present when that path is the cheaper one
   std::shared_ptr<const mf::Tree> tree;
+  // embeddings of complex matrices (umfpack_zi.hip): the tree of the COMPLEX pattern itself, from the same dissection
+  // (tree is its expansion): what the native complex fronts are built on
+  std::shared_ptr<const mf::Tree> ztree;
 };
 
 struct Numeric {
@@ -62,6 +65,13 @@ struct Numeric {
   int singular = 0;
   int nopiv = 0;  // 1: blocked factorisation without interchanges
   int mf_sym = 0;  // 1: the multifrontal factors held are those of a symmetric matrix (L D L^T: half the update flops)
+  // Native complex fronts (round 3).  This object holds the real embedding E of a complex matrix (umfpack_zi.hip) for
+  // residuals, refinement and every fallback; with zfront = 1 the multifrontal factors are those of the COMPLEX matrix
+  // on the tree of its own pattern (ztree: half the unknowns, complex fronts in two planes, multifrontal.hip) — a
+  // solve with them is a solve with E (packed complex vectors ARE the real vectors of the embedding), at half the
+  // flops and bytes.  zsym: the complex matrix is symmetric (A == A^T): L D L^T.
+  std::shared_ptr<const mf::Tree> ztree;
+  int zfront = 0, zsym = 0;
   // set when a refactorisation failed after the previous factors were released: the object holds no
   // usable factors any more and every later solve returns an error instead of launching kernels
   std::atomic<int> broken{0};
@@ -101,6 +111,7 @@ struct Numeric {
 };
 
 thread_local bool t_pattern_vouched = false;  // set around umfpack_di_numeric by spl::numeric_of_embedding
+thread_local int t_native_complex = 0;  // ... 1: the embedding is plain (no swapped pairs): native complex fronts may serve it; 2: and A == A^T
 
 // 64-bit hash of the row indices: the second half of the pattern check in numeric (the pointers are
 // compared exactly; a pattern with the same column counts but other rows would be scattered with a
@@ -559,20 +570,36 @@ static bool matrix_is_symmetric(const Numeric *N, hipStream_t s) {
   return h == 0;
 }
 
+// resident bytes of the tree factors held (or about to be built)
+static size_t tree_factor_bytes(const Numeric *N) {
+  if (N->zfront && N->ztree) return mf_device_bytes(*N->ztree, 2);
+  return N->tree ? mf_device_bytes(*N->tree, 1) : 0;
+}
+
 // multifrontal factors without interchanges on the nested-dissection tree (multifrontal.hip)
 void factor_multifrontal(Numeric *N, hipStream_t s) {
   N->AB.release();
   N->blkinv.release();
   if (N->mfact) { mf_free(N->mfact); N->mfact = nullptr; }
   const size_t free_b = device_free_bytes();
-  if (mf_device_bytes(*N->tree) > free_b - free_b / 8) throw DeviceError{SPL_ERROR_out_of_memory};
+  N->zfront = N->ztree ? 1 : 0;
+  if (tree_factor_bytes(N) > free_b - free_b / 8) throw DeviceError{SPL_ERROR_out_of_memory};
   N->nopiv = 1;
   if (!N->A->rowptr.get()) throw DeviceError{SPL_ERROR_index_overflow};  // int32 row pointers at this seam
+  if (N->zfront) {
+    // the embedding of a complex matrix: complex fronts on the tree of the complex pattern, assembled from E's own
+    // arrays (column 2j / row 2j of E hold column / row j of the complex matrix); perm / inv are the expanded ordering
+    N->mf_sym = N->zsym;
+    N->mfact = mf_factor(N->ztree, N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), N->A->rowptr.get(),
+                         N->A->colidx.get(), N->A->val.get(), N->perm.get(), N->inv.get(), s, N->mf_sym != 0, true);
+    N->singular = mf_singular(N->mfact);
+    return;
+  }
   // a symmetric matrix (exactly: A == A^T) is factored as L D L^T on the same fronts: the trailing updates only
   // compute the tiles on and below the diagonal (Band::sym, csrc/dense_lu_kernels.hpp); SPL_LU_SYMMETRIC=0: plain LU
   N->mf_sym = matrix_is_symmetric(N, s) ? 1 : 0;
   N->mfact = mf_factor(N->tree, N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), N->A->rowptr.get(),
-                       N->A->colidx.get(), N->A->val.get(), N->perm.get(), N->inv.get(), s, N->mf_sym != 0);
+                       N->A->colidx.get(), N->A->val.get(), N->perm.get(), N->inv.get(), s, N->mf_sym != 0, false);
   N->singular = mf_singular(N->mfact);
 }
 
@@ -602,9 +629,9 @@ bool factor_static_pivot(Numeric *N, const int *Ap, const int *Ai, const double 
   if (timing) fprintf(stderr, "[static pivot] B and its tree (%d fronts, %.3g flops) at %.1f ms\n", tree->nfronts, tree->flops, since());
   {
     size_t held = (N->AB.n + N->blkinv.n) * sizeof(double);
-    if (N->mfact && N->tree) held += mf_device_bytes(*N->tree);
+    if (N->mfact) held += tree_factor_bytes(N);
     const size_t avail = device_free_bytes() + held;
-    if (mf_device_bytes(*tree) + (size_t)Bp[(size_t)n] * 24 > avail - avail / 8) return false;
+    if (mf_device_bytes(*tree, 1) + (size_t)Bp[(size_t)n] * 24 > avail - avail / 8) return false;
   }
   void *hBt = nullptr, *hB = nullptr;
   if (spl_matrix_create_csr(n, n, 0, n, Bp.data(), Bi.data(), Bx.data(), &hBt) != SPL_OK) return false;
@@ -632,6 +659,8 @@ bool factor_static_pivot(Numeric *N, const int *Ap, const int *Ai, const double 
     N->blkinv.release();
     if (N->mfact) { mf_free(N->mfact); N->mfact = nullptr; }
     N->tree = tree;
+    N->ztree.reset();  // B = Dr P E Dc is not the embedding of a complex matrix: real fronts from here on
+    N->zfront = 0;
     set_ordering(N, tree->perm, tree->inv, s);
     for (int a = 0; a < 4; ++a) {
       N->sp_idx[a].alloc((size_t)n);
@@ -647,7 +676,7 @@ bool factor_static_pivot(Numeric *N, const int *Ap, const int *Ai, const double 
     N->nopiv = 1;
     N->mf_sym = 0;  // B = Dr P A Dc is not symmetric
     N->mfact = mf_factor(N->tree, N->spAt->rowptr.get(), N->spAt->colidx.get(), N->spAt->val.get(), N->spA->rowptr.get(),
-                         N->spA->colidx.get(), N->spA->val.get(), N->perm.get(), N->inv.get(), s);
+                         N->spA->colidx.get(), N->spA->val.get(), N->perm.get(), N->inv.get(), s, false, false);
     if (mf_singular(N->mfact)) {  // a zero pivot: these factors are useless; the band fallback rebuilds everything
       N->sp_stage = 2;
       return false;
@@ -674,7 +703,7 @@ void factor_band(Numeric *N, bool nopiv, hipStream_t s) {
   const size_t band_elems = (size_t)ldab_new * (size_t)n;
   {
     size_t held = (N->AB.n + N->blkinv.n) * sizeof(double);
-    if (N->mfact && N->tree) held += mf_device_bytes(*N->tree);
+    if (N->mfact) held += tree_factor_bytes(N);
     const size_t avail = device_free_bytes() + held;
     if (band_elems * sizeof(double) > avail - avail / 8) throw DeviceError{SPL_ERROR_out_of_memory};  // too wide
   }
@@ -682,6 +711,8 @@ void factor_band(Numeric *N, bool nopiv, hipStream_t s) {
     if (N->mfact || N->tree) {  // leaving the multifrontal path: the band paths use the RCM ordering
       if (N->mfact) { mf_free(N->mfact); N->mfact = nullptr; }
       N->tree.reset();
+      N->ztree.reset();
+      N->zfront = 0;
       set_ordering(N, N->band_perm, N->band_inv, s);
     }
     if (N->sp_stage == 1) N->sp_stage = 2;  // the factors of B are gone: solves use the plain gathers again
@@ -758,10 +789,11 @@ static int symbolic_common(int n, const int *Ap, const int *Ai, int mult, const 
     const char *method = getenv("SPL_LU_METHOD");
     const bool force_mf = method && method[0] == 'm', force_band = method && method[0] == 'b';
     std::future<std::shared_ptr<mf::Tree>> tree_job;
+    std::shared_ptr<mf::Tree> small_tree = mult > 1 ? std::make_shared<mf::Tree>() : nullptr;  // of the complex pattern
     if (!force_band && (force_mf || S->n >= 1024))
-      tree_job = std::async(std::launch::async, [n, Ap, Ai, mult] {
+      tree_job = std::async(std::launch::async, [n, Ap, Ai, mult, small_tree] {
         std::shared_ptr<mf::Tree> T = std::make_shared<mf::Tree>();
-        mf::build_tree(n, Ap, Ai, 256 / mult, *T, mult);
+        mf::build_tree(n, Ap, Ai, 256 / mult, *T, mult, small_tree.get());
         return T;
       });
     const bool timing = getenv("SPL_MF_TIMING") != nullptr;
@@ -811,7 +843,10 @@ static int symbolic_common(int n, const int *Ap, const int *Ai, int mult, const 
       // small fronts).  The break-even is near n = 2 000 on 2-D and 3-D meshes alike.
       const double t_band = 1.4e-6 * S->n + band_flops / 3e13;
       const double t_tree = 2.5e-3 + T->flops / 2e13;
-      if (force_mf || t_tree < t_band) S->tree = T;
+      if (force_mf || t_tree < t_band) {
+        S->tree = T;
+        if (small_tree && small_tree->nfronts > 0) S->ztree = small_tree;
+      }
     }
     *SymbolicOut = S.release();
     return UMFPACK_OK;
@@ -842,12 +877,19 @@ namespace spl {
 uint64_t pattern_hash(const int *Ai, int64_t nnz) { return hash_indices(Ai, nnz); }
 
 // numeric factorisation of an embedding whose pattern the caller has already checked against its own record
-int numeric_of_embedding(const int *Ep, const int *Ei, const double *Ex, void *Symbolic, void **Numeric) {
+// native: 0 the embedding has swapped pairs or scaled blocks (real fronts only); 1 it is the plain embedding of a complex
+// matrix (native complex fronts may serve it); 2 and that matrix is symmetric
+int numeric_of_embedding(const int *Ep, const int *Ei, const double *Ex, void *Symbolic, void **Numeric, int native) {
   struct Vouch {
-    Vouch() { t_pattern_vouched = true; }
-    ~Vouch() { t_pattern_vouched = false; }
-  } vouch;
+    explicit Vouch(int native) { t_pattern_vouched = true; t_native_complex = native; }
+    ~Vouch() { t_pattern_vouched = false; t_native_complex = 0; }
+  } vouch(native);
   return umfpack_di_numeric(Ep, Ei, Ex, Symbolic, Numeric, nullptr, nullptr);
+}
+bool symbolic_has_complex_tree(void *SymbolicIn) {
+  Symbolic *S = as_symbolic(SymbolicIn);
+  const char *zn = getenv("SPL_ZI_NATIVE");
+  return S && S->tree && S->ztree && !(zn && zn[0] == '0');
 }
 
 // analysis of the real embedding of an n x n complex matrix from the complex pattern itself (umfpack_zi.hip);
@@ -917,6 +959,13 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
     N->band_perm = S->perm;
     N->band_inv = S->inv;
     N->tree = S->tree;
+    {
+      const char *zn = getenv("SPL_ZI_NATIVE");  // 0: the real fronts of the embedding also for complex matrices
+      if (t_native_complex && S->tree && S->ztree && !(zn && zn[0] == '0')) {
+        N->ztree = S->ztree;
+        N->zsym = t_native_complex == 2 ? 1 : 0;
+      }
+    }
     set_ordering(N, N->tree ? N->tree->perm : N->band_perm, N->tree ? N->tree->inv : N->band_inv, s);
     // device copies of A for the residuals of the refinement: rows of A (transposed on the
     // device) and rows of A^T (the CSC arrays as they are)
@@ -1313,8 +1362,13 @@ int spl_umfpack_stats(void *NumericIn, double out[8]) {
   for (int i = 0; i < 8; ++i) out[i] = 0.0;
   out[0] = (double)spl_umfpack_path(NumericIn);
   out[1] = (double)N->n;
-  if (N->mfact) {
-    out[4] = (double)mf_device_bytes(*N->tree);
+  if (N->mfact && N->zfront && N->ztree) {
+    out[4] = (double)mf_device_bytes(*N->ztree, 2);
+    out[5] = 4.0 * (N->mf_sym ? 0.5 * N->ztree->flops : N->ztree->flops);  // a complex multiply-add is four real ones
+    out[6] = (double)N->ztree->nfronts;
+    out[7] = 1.0;  // native complex fronts
+  } else if (N->mfact) {
+    out[4] = (double)mf_device_bytes(*N->tree, 1);
     out[5] = N->mf_sym ? 0.5 * N->tree->flops : N->tree->flops;  // L D L^T on the same fronts: about half the flops of LU
     out[6] = (double)N->tree->nfronts;
   } else {

@@ -272,9 +272,15 @@ int umfpack_zi_numeric(const int Ap[], const int Ai[], const double Ax[], const 
     // L D L^T (head of this file) where the tree has work to halve: below ~1e12 flops (2-D meshes of 10^6 unknowns, 3-D ones below ~50^3) the
     // factorisation is launch-bound and the symmetry check on the host costs more than the flops saved.
     // SPL_ZI_SYMMETRIC=0: the general embedding for every matrix; =1: the symmetric one whenever A == A^T
+    // Native complex fronts (csrc/multifrontal.hip, TreeView::zm) take the PLAIN embedding — no swapped pairs, no
+    // congruence: a complex pivot is as good as its modulus — whenever the analysis chose the tree; a complex symmetric
+    // matrix is then factored as L D L^T in complex arithmetic.  The embeddings below serve the band path, and
+    // SPL_ZI_NATIVE=0.
+    const bool native = spl::symbolic_has_complex_tree(S->di);
     const char *zs = getenv("SPL_ZI_SYMMETRIC");
-    const bool wanted = zs ? zs[0] != '0' : spl::symbolic_tree_flops(S->di) >= 1e12;
-    const bool symmetric = wanted && n > 1 && complex_symmetric(n, Ap, Ai, Ax, Az);
+    const bool wanted = native || (zs ? zs[0] != '0' : spl::symbolic_tree_flops(S->di) >= 1e12);
+    const bool is_sym = wanted && n > 1 && complex_symmetric(n, Ap, Ai, Ax, Az);
+    const bool symmetric = is_sym && !native;
     std::vector<char> swap;
     std::vector<double> unit;
     bool any = false;
@@ -302,7 +308,7 @@ int umfpack_zi_numeric(const int Ap[], const int Ai[], const double Ax[], const 
         unit[(size_t)2 * j] = ur;
         unit[(size_t)2 * j + 1] = ui;
       }
-    } else {
+    } else if (!native) {
       swap.assign((size_t)n, 0);
       for (int j = 0; j < n; ++j)
         for (int p = Ap[j]; p < Ap[j + 1]; ++p)
@@ -315,10 +321,13 @@ int umfpack_zi_numeric(const int Ap[], const int Ai[], const double Ax[], const 
     if (!embed(n, Ap, Ai, Ax, Az, true, E, any ? swap.data() : nullptr, symmetric ? unit.data() : nullptr))
       return UMFPACK_ERROR_out_of_memory;
     if (timing)
-      fprintf(stderr, "[zi numeric] %s embedding built on the host %8.2f ms\n", symmetric ? "symmetric" : "general",
+      fprintf(stderr, "[zi numeric] %s embedding built on the host %8.2f ms\n",
+              native ? (is_sym ? "plain (native complex fronts, symmetric)" : "plain (native complex fronts)")
+                     : symmetric ? "symmetric" : "general",
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     (void)Control; (void)Info;
-    const int st = spl::numeric_of_embedding(E.p.data(), E.i.data(), E.x.data(), S->di, Numeric);
+    const int st = spl::numeric_of_embedding(E.p.data(), E.i.data(), E.x.data(), S->di, Numeric,
+                                             native ? (is_sym ? 2 : 1) : 0);
     if (st >= 0 && any) spl::numeric_set_pair_swap(*Numeric, std::move(swap));
     if (st >= 0 && symmetric) spl::numeric_set_pair_unit(*Numeric, std::move(unit));
     return st;

@@ -117,7 +117,7 @@ class Factors(_Handle):
         buf = (C.c_double * 8)()
         if _declare().spl_umfpack_stats(self.value, buf) != 0:
             raise UmfpackError("spl_umfpack_stats: invalid Numeric object")
-        keys = ("path", "n", "kl", "ku", "device_bytes", "flops", "fronts")
+        keys = ("path", "n", "kl", "ku", "device_bytes", "flops", "fronts", "complex_fronts")
         return dict(zip(keys, [float(v) if k in ("device_bytes", "flops") else int(v) for k, v in zip(keys, buf)]))
 
 

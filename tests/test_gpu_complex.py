@@ -176,16 +176,22 @@ def _bwd(S, x, b):
     return float(np.max(r / np.where(den > 0, den, 1.0)))
 
 
+@pytest.mark.parametrize("limits", ["default", "small"])
 @pytest.mark.parametrize("dim,m", [(2, 60), (3, 16)])
 @pytest.mark.parametrize("z", [4.0 + 0.01j, 0.7 - 0.4j, -0.2 + 3.0j, 6.0 + 0.0j])
-def test_complex_symmetric_shift_is_factored_as_ldlt(gpu, pkg, dim, m, z, monkeypatch):
-    """FEAST's z B - A for real symmetric A, B (complex symmetric, not Hermitian): the zi wrapper embeds D A D
-    symmetrically (|u_r| = 1, real positive diagonal) and the tree runs its L D L^T mode — half the flops of the
-    general embedding (SPL_ZI_SYMMETRIC=0), the same solutions of A x = b and A^H y = c to 1e-10; packed, batched and
-    device right-hand sides.  z = 4 + 0.01i puts Re z on A's diagonal (the real pivot of the plain embedding is 0),
-    z = 6 is a real shift (every u_r is 1 or i)."""
+def test_complex_symmetric_shift_native_and_embedded(gpu, pkg, dim, m, z, limits, monkeypatch):
+    """FEAST's z B - A for real symmetric A, B (complex symmetric, not Hermitian), three ways: (1) native complex fronts
+    in their L D L^T mode (the default once the tree is chosen: a quarter of the flops of (3)), (2) SPL_ZI_NATIVE=0,
+    SPL_ZI_SYMMETRIC=1: the symmetric real embedding of D A D (|u_r| = 1, real positive diagonal) on real fronts in
+    L D L^T mode (half), (3) the general real embedding.  The same solutions of A x = b and A^H y = c to 1e-10, backward
+    errors at rounding level; packed, batched and device right-hand sides.  z = 4 + 0.01i puts Re z on A's diagonal (the
+    real pivot of the plain embedding is 0), z = 6 is a real shift.  "small": size classes lowered so that the
+    one-workgroup, lockstep and multi-launch kernels all run."""
     import scipy.sparse as sp
     import torch
+    if limits == "small":
+        monkeypatch.setenv("SPL_MF_SMALL", "64")
+        monkeypatch.setenv("SPL_MF_MIDMAX", "256")
     monkeypatch.setenv("SPL_LU_METHOD", "mf")
     rng = np.random.default_rng(m)
     T = sp.diags([-np.ones(m - 1), 2.0 * np.ones(m), -np.ones(m - 1)], (-1, 0, 1))
@@ -197,32 +203,87 @@ def test_complex_symmetric_shift_is_factored_as_ldlt(gpu, pkg, dim, m, z, monkey
     S.sort_indices()
     M = pkg.Matrix(n, n, S.indptr, S.indices, S.data)
     U = pkg.umfpack
+    fn = U.factor(M, U.analyze(M))
+    monkeypatch.setenv("SPL_ZI_NATIVE", "0")
     monkeypatch.setenv("SPL_ZI_SYMMETRIC", "1")  # by itself the wrapper does this from 1e12 flops of the tree on
     fs = U.factor(M, U.analyze(M))
     monkeypatch.setenv("SPL_ZI_SYMMETRIC", "0")
     fg = U.factor(M, U.analyze(M))
     monkeypatch.delenv("SPL_ZI_SYMMETRIC")
     fd = U.factor(M, U.analyze(M))
+    monkeypatch.delenv("SPL_ZI_NATIVE")
     assert fd.stats["flops"] == fg.stats["flops"] < 1e12  # small trees keep the general embedding
-    assert fs.path in (3, 4) and fg.path in (3, 4)
-    assert fs.stats["flops"] == 0.5 * fg.stats["flops"] and fs.stats["fronts"] == fg.stats["fronts"]
-    xs = [rng.uniform(0.5, 1.5, n) + 1j * rng.uniform(-1, 1, n) for _ in range(3)]
+    assert fn.path in (3, 4) and fs.path in (3, 4) and fg.path in (3, 4)
+    sn, ss, sg = fn.stats, fs.stats, fg.stats
+    assert (sn["complex_fronts"], ss["complex_fronts"], sg["complex_fronts"]) == (1, 0, 0)
+    assert ss["flops"] == 0.5 * sg["flops"] and ss["fronts"] == sg["fronts"] == sn["fronts"]
+    assert abs(sn["flops"] - 0.25 * sg["flops"]) <= 1e-9 * sg["flops"] and sn["device_bytes"] < sg["device_bytes"]
+    xs = [rng.uniform(0.5, 1.5, n) + 1j * rng.uniform(-1, 1, n) for _ in range(5)]
     for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, sp.csc_matrix(S.conj().T))):
         bs = [np.asarray(op @ x).ravel() for x in xs]
-        one = U.linearSolve_(fs, mode, M, bs[0])
         ref = U.linearSolve_(fg, mode, M, bs[0])
+        for f in (fn, fs):
+            one = U.linearSolve_(f, mode, M, bs[0])
+            assert _bwd(op, one, bs[0]) <= 1e-13
+            assert np.max(np.abs(one - ref)) <= 1e-10 * np.max(np.abs(ref))
+            for got, b in zip(U.linearSolveMany_(f, mode, M, bs), bs):
+                assert _bwd(op, got, b) <= 1e-13
+            Xd = U.linearSolveManyDevice_(f, mode, M, torch.from_numpy(np.stack(bs)).cuda()).cpu().numpy()
+            for got, b in zip(Xd, bs):
+                assert _bwd(op, got, b) <= 1e-13
+    assert fn.stats["complex_fronts"] == 1  # no fallback happened on the way
+
+
+@pytest.mark.parametrize("limits", ["default", "small"])
+@pytest.mark.parametrize("kind", ["dominant", "general", "hermitian"])
+def test_native_complex_fronts_unsymmetric(gpu, pkg, kind, limits, monkeypatch):
+    """complex matrices without symmetry on a mesh pattern through the native complex fronts (plain complex LU on the
+    tree): a column-dominant one (path 3), one with a weak diagonal (a speculation, path 4 — or whatever the fallbacks
+    end on: the answer is what is checked) and a Hermitian one; both systems, one and several right-hand sides, against
+    the real fronts of the embedding (SPL_ZI_NATIVE=0)"""
+    import scipy.sparse as sp
+    if limits == "small":
+        monkeypatch.setenv("SPL_MF_SMALL", "64")
+        monkeypatch.setenv("SPL_MF_MIDMAX", "256")
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    rng = np.random.default_rng(17)
+    m = 48
+    T = sp.diags([np.ones(m - 1), np.ones(m), np.ones(m - 1)], (-1, 0, 1))
+    P = sp.csc_matrix(sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m)), dtype=np.complex128)
+    n = m * m
+    P.data = rng.uniform(-1, 1, P.nnz) + 1j * rng.uniform(-1, 1, P.nnz)
+    if kind == "hermitian":
+        P = sp.csc_matrix(sp.triu(P, 1) + sp.triu(P, 1).conj().T + sp.diags(rng.uniform(6.0, 7.0, n)))
+    else:
+        w = np.asarray(abs(P).sum(axis=0)).ravel()
+        ph = np.exp(1j * rng.uniform(0, 2 * np.pi, n))
+        # dominance is decided on the real embedding: |Re a_jj| against the 1-norms of the other entries
+        P.setdiag(2.0 * w + 0j if kind == "dominant" else 0.6 * w * ph)
+    S = sp.csc_matrix(P)
+    S.sort_indices()
+    M = pkg.Matrix(n, n, S.indptr, S.indices, S.data)
+    U = pkg.umfpack
+    fn = U.factor(M, U.analyze(M))
+    assert fn.stats["complex_fronts"] == 1 and fn.path in {"dominant": (3,), "general": (4,), "hermitian": (3, 4)}[kind]
+    monkeypatch.setenv("SPL_ZI_NATIVE", "0")
+    fe = U.factor(M, U.analyze(M))
+    monkeypatch.delenv("SPL_ZI_NATIVE")
+    assert fe.stats["complex_fronts"] == 0 and abs(fn.stats["flops"] - 0.5 * fe.stats["flops"]) <= 1e-9 * fe.stats["flops"]
+    xs = [rng.normal(size=n) + 1j * rng.normal(size=n) for _ in range(9)]
+    for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, sp.csc_matrix(S.conj().T))):
+        bs = [np.asarray(op @ x).ravel() for x in xs]
+        one, ref = U.linearSolve_(fn, mode, M, bs[0]), U.linearSolve_(fe, mode, M, bs[0])
         assert _bwd(op, one, bs[0]) <= 1e-13
-        assert np.max(np.abs(one - ref)) <= 1e-10 * np.max(np.abs(ref))
-        for got, b in zip(U.linearSolveMany_(fs, mode, M, bs), bs):
-            assert _bwd(op, got, b) <= 1e-13
-        Xd = U.linearSolveManyDevice_(fs, mode, M, torch.from_numpy(np.stack(bs)).cuda()).cpu().numpy()
-        for got, b in zip(Xd, bs):
+        assert np.max(np.abs(one - ref)) <= 1e-9 * np.max(np.abs(ref))
+        for got, b in zip(U.linearSolveMany_(fn, mode, M, bs), bs):
             assert _bwd(op, got, b) <= 1e-13
 
 
-def test_complex_symmetric_split_arrays_and_hermitian_stays_general(gpu, pkg, monkeypatch):
-    """the symmetric embedding through umfpack_zi_* with split real / imaginary arrays (Az, Xz, Bz non-NULL); and a
-    complex HERMITIAN matrix (A == A^H, not A^T) takes the general embedding (all the flops of its tree)"""
+@pytest.mark.parametrize("native", ["0", "1"])
+def test_complex_symmetric_split_arrays_and_hermitian_stays_general(gpu, pkg, native, monkeypatch):
+    """a complex symmetric matrix through umfpack_zi_* with split real / imaginary arrays (Az, Xz, Bz non-NULL), on the
+    symmetric embedding (native = 0) and on native complex fronts; and a complex HERMITIAN matrix (A == A^H, not A^T)
+    is factored as plain LU either way (all the flops of its tree)"""
     import ctypes as C
     import scipy.sparse as sp
     L = pkg._ffi.lib()
@@ -242,6 +303,7 @@ def test_complex_symmetric_split_arrays_and_hermitian_stays_general(gpu, pkg, mo
     P = lambda a, t: a.ctypes.data_as(t)
     sym, num = C.c_void_p(), C.c_void_p()
     monkeypatch.setenv("SPL_ZI_SYMMETRIC", "1")
+    monkeypatch.setenv("SPL_ZI_NATIVE", native)
     monkeypatch.setenv("SPL_LU_METHOD", "mf")
     assert L.umfpack_zi_symbolic(n, n, P(ap, ip), P(ai, ip), P(ax, dp), P(az, dp), C.byref(sym), None, None) == 0
     assert L.umfpack_zi_numeric(P(ap, ip), P(ai, ip), P(ax, dp), P(az, dp), sym, C.byref(num), None, None) == 0
@@ -272,7 +334,7 @@ def test_complex_symmetric_split_arrays_and_hermitian_stays_general(gpu, pkg, mo
     fh = U.factor(M, U.analyze(M))
     monkeypatch.setenv("SPL_ZI_SYMMETRIC", "0")
     fg = U.factor(M, U.analyze(M))
-    assert fh.stats["flops"] == fg.stats["flops"]
+    assert fh.stats["flops"] == fg.stats["flops"] and fh.stats["complex_fronts"] == int(native)
     xs = rng.normal(size=n) + 1j * rng.normal(size=n)
     b = np.asarray(H @ xs).ravel()
     assert _bwd(H, U.linearSolve_(fh, U.UmfpackNormal, M, b), b) <= 1e-13
