@@ -1001,7 +1001,23 @@ constexpr int SW = 16;
 // lane = row, wave q takes t = q mod SW, partial sums meet in LDS.  Transposed (MODE 2/3) it runs
 // along t: lanes along t, wave q takes rows l = q mod SW, butterfly reduction.  A band entry is
 // loaded once for all NR right-hand sides.  Ends with the result visible to the whole workgroup.
-template <int MODE, int NR>
+// acc[:] += e * v[:] over NR columns; Z: the columns are (re, im) pairs of NR / 2 complex right-hand sides, e = er + i ei
+template <int NR, bool Z>
+__device__ __forceinline__ void mac_cols(double (&acc)[NR], double er, double ei, const double *v) {
+  if (!Z) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] += er * v[r];
+  } else {
+#pragma unroll
+    for (int q = 0; q < NR / 2; ++q) {
+      acc[2 * q] += er * v[2 * q] - ei * v[2 * q + 1];
+      acc[2 * q + 1] += er * v[2 * q + 1] + ei * v[2 * q];
+    }
+  }
+}
+
+// (Z: a complex dense matrix in two planes, Band::zoff; the transposed modes are then CONJUGATE transposes)
+template <int MODE, int NR, bool Z = false>
 __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, const double (*vv)[NR],
                                        double (*res)[NR], double (*part)[64][NR]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1013,18 +1029,19 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
     if (i >= 0 && i < b.n) {
       int t = wave;
       for (; t + 7 * SW < nc; t += 8 * SW) {  // 8 independent loads in flight per lane
-        double e[8];
+        double e[8], ei[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) e[u] = b.get(i, cb + t + SW * u);
+        for (int u = 0; u < 8; ++u) {
+          e[u] = b.get(i, cb + t + SW * u);
+          ei[u] = Z ? (&b.at(i, cb + t + SW * u))[b.zoff] : 0.0;
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-          for (int r = 0; r < NR; ++r) acc[r] += e[u] * vv[t + SW * u][r];
+        for (int u = 0; u < 8; ++u) mac_cols<NR, Z>(acc, e[u], ei[u], &vv[t + SW * u][0]);
       }
       for (; t < nc; t += SW) {
         const double e = b.get(i, cb + t);
-#pragma unroll
-        for (int r = 0; r < NR; ++r) acc[r] += e * vv[t][r];
+        const double ei = Z ? (&b.at(i, cb + t))[b.zoff] : 0.0;
+        mac_cols<NR, Z>(acc, e, ei, &vv[t][0]);
       }
     }
 #pragma unroll
@@ -1046,14 +1063,16 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
     for (int q = 0; q < RPW; ++q)
 #pragma unroll
       for (int r = 0; r < NR; ++r) acc[q][r] = 0.0;
-    double e[SB][RPW];
+    double e[SB][RPW], ei[SB][RPW];
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
       const int t = lane + 64 * u;
 #pragma unroll
       for (int q = 0; q < RPW; ++q) {
         const int i = rb + wave + SW * q;
-        e[u][q] = (t < nc && i >= 0 && i < b.n) ? b.get(cb + t, i) : 0.0;
+        const bool in = t < nc && i >= 0 && i < b.n;
+        e[u][q] = in ? b.get(cb + t, i) : 0.0;
+        ei[u][q] = (Z && in) ? -(&b.at(cb + t, i))[b.zoff] : 0.0;
       }
     }
 #pragma unroll
@@ -1061,11 +1080,7 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
       const int t = lane + 64 * u;
       if (t < nc) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          const double x = vv[t][r];
-#pragma unroll
-          for (int q = 0; q < RPW; ++q) acc[q][r] += e[u][q] * x;
-        }
+        for (int q = 0; q < RPW; ++q) mac_cols<NR, Z>(acc[q], e[u][q], ei[u][q], &vv[t][0]);
       }
     }
 #pragma unroll
@@ -1083,7 +1098,7 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
 
 // res[l][r] = sum_t T(l, t) * w[t][r] with T = inv(L11), inv(U11), inv(U11)^T, inv(L11)^T (MODE 0..3);
 // inv is column-major NB x NB.
-template <int MODE, int NR>
+template <int MODE, int NR, bool Z = false>
 __device__ __forceinline__ void gemv_inv(const double *__restrict__ inv, const double (*w)[NR], double (*res)[NR],
                                          double (*part)[64][NR]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1095,8 +1110,8 @@ __device__ __forceinline__ void gemv_inv(const double *__restrict__ inv, const d
     for (int u = 0; u < NB / SW; ++u) {
       const int t = wave + SW * u;
       const double e = inv[lane + t * NB];
-#pragma unroll
-      for (int r = 0; r < NR; ++r) acc[r] += e * w[t][r];
+      const double ei = Z ? inv[NB * NB + lane + t * NB] : 0.0;
+      mac_cols<NR, Z>(acc, e, ei, &w[t][0]);
     }
 #pragma unroll
     for (int r = 0; r < NR; ++r) part[wave][lane][r] = acc[r];
@@ -1110,10 +1125,15 @@ __device__ __forceinline__ void gemv_inv(const double *__restrict__ inv, const d
     }
   } else {
     for (int l = wave; l < 64; l += SW) {
-      const double e = inv[lane + l * NB];  // T(l, t) = inv(t, l)
+      const double e = inv[lane + l * NB];  // T(l, t) = inv(t, l) (Z: conjugated)
+      const double ei = Z ? -inv[NB * NB + lane + l * NB] : 0.0;
+      double prod[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) prod[r] = 0.0;
+      mac_cols<NR, Z>(prod, e, ei, &w[lane][0]);
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        double sacc = e * w[lane][r];
+        double sacc = prod[r];
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
         if (lane == 0) res[l][r] = sacc;
@@ -1127,7 +1147,7 @@ __device__ __forceinline__ void gemv_inv(const double *__restrict__ inv, const d
 // `tile`: which rows outside the super block this workgroup updates: `tiles` consecutive blocks of 64
 // rows starting at block tile * tiles (workgroup 0 also writes `out`).  Every workgroup redoes the
 // in-super-block solve first, so large systems take several blocks per workgroup.
-template <int MODE, int NR>
+template <int MODE, int NR, bool Z = false>
 __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__restrict__ invs, int j0, int jbs,
                                                  double *in, double *__restrict__ out, size_t stride, int tile,
                                                  double *dsm, int tiles = 1) {
@@ -1146,14 +1166,15 @@ __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__
     // couplings with the sub-blocks of this super block that are already solved
     const int cb = fwd ? j0 : js + jb;
     const int nc = fwd ? js - j0 : j0 + jbs - (js + jb);
-    gemv64<MODE, NR>(b, js, cb, nc, v + (cb - j0), res, part);
+    gemv64<MODE, NR, Z>(b, js, cb, nc, v + (cb - j0), res, part);
     for (int o = tid; o < NB * NR; o += SW * 64) {
       const int l = o % NB, r = o / NB;
       w[l][r] = l < jb ? in[(size_t)r * stride + js + l] - res[l][r] : 0.0;
     }
     __syncthreads();
-    const double *inv = invs + (size_t)(js / NB) * (2 * NB * NB) + ((MODE == 1 || MODE == 2) ? NB * NB : 0);
-    gemv_inv<MODE, NR>(inv, w, res, part);
+    constexpr size_t blk = Z ? (size_t)kInvBlockZ : (size_t)(2 * NB * NB);
+    const double *inv = invs + (size_t)(js / NB) * blk + ((MODE == 1 || MODE == 2) ? blk / 2 : 0);
+    gemv_inv<MODE, NR, Z>(inv, w, res, part);
     for (int o = tid; o < NB * NR; o += SW * 64) {
       const int l = o % NB, r = o / NB;
       if (l < jb) v[js - j0 + l][r] = res[l][r];
@@ -1170,7 +1191,7 @@ __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__
     const int blk = tile * tiles + q;
     const int rb = fwd ? j0 + jbs + blk * 64 : j0 - (blk + 1) * 64;
     if (fwd ? rb >= b.n : rb + 64 <= 0) break;  // workgroup-uniform
-    gemv64<MODE, NR>(b, rb, j0, jbs, v, res, part);
+    gemv64<MODE, NR, Z>(b, rb, j0, jbs, v, res, part);
     for (int o = tid; o < 64 * NR; o += SW * 64) {
       const int l = o % 64, r = o / 64;
       const int i = rb + l;

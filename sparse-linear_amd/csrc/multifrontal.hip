@@ -381,22 +381,6 @@ __device__ __forceinline__ Panels panels_of(const TreeView &t, int f) {
   return Panels{t.arena + t.poff[f], t.arena + t.uoff[f], np, nb, np + nb, t.ldp[f], t.ldu[f], 0, 0};
 }
 
-// acc[:] += e * v[:] over NR columns; Z: the columns are (re, im) pairs of NR / 2 complex right-hand sides and
-// e = er + i ei
-template <int NR, bool Z>
-__device__ __forceinline__ void mac_row(double (&acc)[NR], double er, double ei, const double *v) {
-  if (!Z) {
-#pragma unroll
-    for (int r = 0; r < NR; ++r) acc[r] += er * v[r];
-  } else {
-#pragma unroll
-    for (int q = 0; q < NR / 2; ++q) {
-      acc[2 * q] += er * v[2 * q] - ei * v[2 * q + 1];
-      acc[2 * q + 1] += er * v[2 * q + 1] + ei * v[2 * q];
-    }
-  }
-}
-
 // v = T w for the 64 x 64 inverse diagonal block (column-major), T = inv or inv^T, NR columns; the
 // first 256 threads of the workgroup, 4 per row
 // (Z: the inverse in two planes NB * NB apart; TRANS is then the CONJUGATE transpose)
@@ -414,7 +398,7 @@ __device__ __forceinline__ void apply_inverse_block(const double *__restrict__ i
     const int at = TRANS ? tt + l * NB : l + tt * NB;
     const double e = inv[at];
     const double ei = Z ? (TRANS ? -inv[NB * NB + at] : inv[NB * NB + at]) : 0.0;
-    mac_row<NR, Z>(acc, e, ei, &w[tt][0]);
+    mac_cols<NR, Z>(acc, e, ei, &w[tt][0]);
   }
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -449,12 +433,12 @@ __device__ __forceinline__ void couple_block(const Panels &fr, int ilo, int ihi,
           ei[u] = Z ? row[(size_t)(tt + u) * cs + zp] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) mac_row<NR, Z>(acc, e[u], ei[u], &v[tt + u][0]);
+        for (int u = 0; u < 8; ++u) mac_cols<NR, Z>(acc, e[u], ei[u], &v[tt + u][0]);
       }
       for (; tt < jb; ++tt) {
         const double e = row[(size_t)tt * cs];
         const double ei = Z ? row[(size_t)tt * cs + zp] : 0.0;
-        mac_row<NR, Z>(acc, e, ei, &v[tt][0]);
+        mac_cols<NR, Z>(acc, e, ei, &v[tt][0]);
       }
 #pragma unroll
       for (int r = 0; r < NR; ++r) W[(size_t)r * fs + i] -= acc[r];
@@ -477,7 +461,7 @@ __device__ __forceinline__ void couple_block(const Panels &fr, int ilo, int ihi,
         double part[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) part[r] = 0.0;
-        if (lane < jb) mac_row<NR, Z>(part, e[u], ei[u], &v[lane][0]);
+        if (lane < jb) mac_cols<NR, Z>(part, e[u], ei[u], &v[lane][0]);
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           double sacc = part[r];
@@ -609,6 +593,7 @@ struct BigFront {
   int f, np, nb, fs, ldp, ldu, blk;  // blk: index of this workgroup inside its front
   const double *P, *U;
   double *W, *Z;
+  size_t pz, uz;  // complex fronts: offsets of the imaginary planes of P and U (0: real)
 };
 template <int NR>
 __device__ __forceinline__ BigFront big_front(const int *__restrict__ list, const int64_t *__restrict__ prefix,
@@ -624,8 +609,10 @@ __device__ __forceinline__ BigFront big_front(const int *__restrict__ list, cons
   b.ldp = t.ldp[f];
   b.ldu = t.ldu[f];
   b.blk = (int)(flat - prefix[fi]);
-  b.P = t.arena + t.poff[f];
-  b.U = t.arena + t.uoff[f];
+  b.P = t.arena + (int64_t)t.zm * t.poff[f];
+  b.U = t.arena + (int64_t)t.zm * t.uoff[f];
+  b.pz = t.zm == 2 ? (size_t)b.ldp * (size_t)b.np : 0;
+  b.uz = t.zm == 2 ? (size_t)b.ldu * (size_t)b.nb : 0;
   b.W = work + (size_t)t.woff[f] * NR;
   b.Z = zbuf + (size_t)t.woff[f] * NR;
   return b;
@@ -633,7 +620,7 @@ __device__ __forceinline__ BigFront big_front(const int *__restrict__ list, cons
 
 // one super-block step (256 pivots) of the triangular pass MODE through the pivot columns of every
 // listed front that has a step `step`: forward passes take W -> Z, backward passes Z -> W
-template <int MODE, int NR>
+template <int MODE, int NR, bool Z = false>
 __global__ __launch_bounds__(SW * 64) void big_super_kernel(const int *__restrict__ list,
                                                             const int64_t *__restrict__ prefix, int count, int step,
                                                             TreeView t, const double *__restrict__ invs,
@@ -645,13 +632,13 @@ __global__ __launch_bounds__(SW * 64) void big_super_kernel(const int *__restric
   const int j0 = (fwd ? step : nsup - 1 - step) * span, jbs = min(span, b.np - j0);
   // untransposed forward: the boundary rows of the front get their updates inside the pass
   const int n = MODE == 0 ? b.fs : b.np;
-  const Band band{const_cast<double *>(b.P), n, n, n, b.ldp + 1, 0};
-  solve_super_tile<MODE, NR>(band, invs + t.ioff[b.f], j0, jbs, fwd ? b.W : b.Z, fwd ? b.Z : b.W, (size_t)b.fs,
-                             b.blk, dsm, row_blocks);
+  const Band band{const_cast<double *>(b.P), n, n, n, b.ldp + 1, 0, 0, b.pz};
+  solve_super_tile<MODE, NR, Z>(band, invs + (Z ? 2 : 1) * t.ioff[b.f], j0, jbs, fwd ? b.W : b.Z, fwd ? b.Z : b.W,
+                                (size_t)b.fs, b.blk, dsm, row_blocks);
 }
 
 // boundary part of the solution into the front's work matrix: W[r * fs + np + k] = x[r * stride + bidx[k]]
-template <int NR>
+template <int NR, bool Z = false>
 __global__ __launch_bounds__(256) void big_gather_x_kernel(const int *__restrict__ list,
                                                            const int64_t *__restrict__ prefix, int count, TreeView t,
                                                            const double *__restrict__ x, size_t stride, double *work,
@@ -661,12 +648,13 @@ __global__ __launch_bounds__(256) void big_gather_x_kernel(const int *__restrict
   if (k >= b.nb) return;
   const int g = t.bidx[t.bptr[b.f] + k];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) b.W[(size_t)r * b.fs + b.np + k] = x[(size_t)r * stride + g];
+  for (int r = 0; r < NR; ++r)
+    b.W[(size_t)r * b.fs + b.np + k] = Z ? x[(size_t)(r >> 1) * stride + 2 * (size_t)g + (r & 1)] : x[(size_t)r * stride + g];
 }
 
 // Z[i][:] -= sum_k M(i, np + k) W[np + k][:], i < np: 64 rows per workgroup.  Untransposed
 // M(i, np + k) = U(i, k); transposed = F(np + k, i) in P.
-template <bool TRANS, int NR>
+template <bool TRANS, int NR, bool Z = false>
 __global__ __launch_bounds__(256) void big_gemv_kernel(const int *__restrict__ list,
                                                        const int64_t *__restrict__ prefix, int count, TreeView t,
                                                        double *work, double *zbuf) {
@@ -686,18 +674,27 @@ __global__ __launch_bounds__(256) void big_gemv_kernel(const int *__restrict__ l
       const double *row = U + (size_t)i;
       int k = wave;
       for (; k + 28 < nb; k += 32) {
-        double e[8];
+        double e[8], ei[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) e[u] = row[(size_t)(k + 4 * u) * ldu];
+        for (int u = 0; u < 8; ++u) {
+          e[u] = row[(size_t)(k + 4 * u) * ldu];
+          ei[u] = Z ? row[(size_t)(k + 4 * u) * ldu + b.uz] : 0.0;
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 8; ++u) {
+          double xv[NR];
 #pragma unroll
-          for (int r = 0; r < NR; ++r) acc[r] += e[u] * xb[(size_t)r * fs + k + 4 * u];
+          for (int r = 0; r < NR; ++r) xv[r] = xb[(size_t)r * fs + k + 4 * u];
+          mac_cols<NR, Z>(acc, e[u], ei[u], xv);
+        }
       }
       for (; k < nb; k += 4) {
         const double e = row[(size_t)k * ldu];
+        const double ei = Z ? row[(size_t)k * ldu + b.uz] : 0.0;
+        double xv[NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) acc[r] += e * xb[(size_t)r * fs + k];
+        for (int r = 0; r < NR; ++r) xv[r] = xb[(size_t)r * fs + k];
+        mac_cols<NR, Z>(acc, e, ei, xv);
       }
     }
 #pragma unroll
@@ -716,16 +713,19 @@ __global__ __launch_bounds__(256) void big_gemv_kernel(const int *__restrict__ l
 #pragma unroll
         for (int r = 0; r < NR; ++r) acc[u][r] = 0.0;
       for (int k = lane; k < nb; k += 64) {
-        double e[RW];
+        double e[RW], ei[RW];
 #pragma unroll
-        for (int u = 0; u < RW; ++u)
-          e[u] = i0 + rr + u < np ? P[(size_t)(np + k) + (size_t)(i0 + rr + u) * ldp] : 0.0;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          const double xk = xb[(size_t)r * fs + k];
-#pragma unroll
-          for (int u = 0; u < RW; ++u) acc[u][r] += e[u] * xk;
+        for (int u = 0; u < RW; ++u) {
+          const bool in = i0 + rr + u < np;
+          const double *src = P + (size_t)(np + k) + (size_t)(in ? i0 + rr + u : 0) * ldp;
+          e[u] = in ? src[0] : 0.0;
+          ei[u] = (Z && in) ? -src[b.pz] : 0.0;  // conjugate transpose
         }
+        double xv[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) xv[r] = xb[(size_t)r * fs + k];
+#pragma unroll
+        for (int u = 0; u < RW; ++u) mac_cols<NR, Z>(acc[u], e[u], ei[u], xv);
       }
 #pragma unroll
       for (int u = 0; u < RW; ++u)
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void big_gemv_kernel(const int *__restrict__ l
 
 // transposed forward elimination, boundary part: W[np + k][:] -= sum_t U(t, k) Z[t][:]  (U^T y); one
 // wavefront per boundary index, lanes along t
-template <int NR>
+template <int NR, bool Z = false>
 __global__ __launch_bounds__(256) void big_boundary_t_kernel(const int *__restrict__ list,
                                                              const int64_t *__restrict__ prefix, int count,
                                                              TreeView t, double *work, double *zbuf) {
@@ -755,8 +755,11 @@ __global__ __launch_bounds__(256) void big_boundary_t_kernel(const int *__restri
   for (int r = 0; r < NR; ++r) acc[r] = 0.0;
   for (int tt = lane; tt < b.np; tt += 64) {
     const double e = col[tt];
+    const double ei = Z ? -col[tt + b.uz] : 0.0;  // conjugate transpose
+    double zv[NR];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) acc[r] += e * b.Z[(size_t)r * b.fs + tt];
+    for (int r = 0; r < NR; ++r) zv[r] = b.Z[(size_t)r * b.fs + tt];
+    mac_cols<NR, Z>(acc, e, ei, zv);
   }
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(256) void big_boundary_t_kernel(const int *__restri
 }
 
 // the pivots' part of the solution of every listed front: x[p0 + i] = W[i]
-template <int NR>
+template <int NR, bool Z = false>
 __global__ __launch_bounds__(256) void big_scatter_x_kernel(const int *__restrict__ list,
                                                             const int64_t *__restrict__ prefix, int count,
                                                             TreeView t, double *work, double *zbuf,
@@ -777,7 +780,10 @@ __global__ __launch_bounds__(256) void big_scatter_x_kernel(const int *__restric
   if (i >= b.np) return;
   const int p0 = t.p0[b.f];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) x[(size_t)r * stride + p0 + i] = b.W[(size_t)r * b.fs + i];
+  for (int r = 0; r < NR; ++r) {
+    if (Z) x[(size_t)(r >> 1) * stride + 2 * (size_t)(p0 + i) + (r & 1)] = b.W[(size_t)r * b.fs + i];
+    else x[(size_t)r * stride + p0 + i] = b.W[(size_t)r * b.fs + i];
+  }
 }
 
 }  // namespace
@@ -950,7 +956,6 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
   F.tree = tree;
   F.zm = ZM;
   F.big_solve = getenv("SPL_MF_BIGSOLVE") ? std::max(64, atoi(getenv("SPL_MF_BIGSOLVE"))) : kBigSolve;
-  if (Z) F.big_solve = 0x7fffffff;  // complex fronts: every front is solved by one workgroup (no lockstep solve kernels yet)
   const int nd = T.maxdepth + 1, nf = T.nfronts;
   const int small_limit = getenv("SPL_MF_SMALL") ? std::max(64, atoi(getenv("SPL_MF_SMALL"))) : kSmallFront;  // tuning knob
   // ---- memory plan: the smallest cut depth whose transient part fits next to the resident part
@@ -1345,19 +1350,19 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
 // NR columns (c + r * stride) through the tree: up with L (or U^T), down with U (or L^T).  Per level:
 // the fronts of up to big_solve rows by one workgroup each, the larger ones in lockstep — one flat
 // launch per super-block step over all of them (Factors::BigLevel).
-template <int MODE, int NR>
+template <int MODE, int NR, bool Z = false>
 static void launch_big_super(const mf::Factors &F, const mf::Factors::BigLevel &B, int kind, int step, double *work,
                              double *zbuf, hipStream_t s) {
   constexpr size_t lds = (size_t)((SB + 2) * NB + SW * 64) * NR * sizeof(double);
   static bool attr_set = false;  // one flag per instantiation
   if (!attr_set) {
-    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&big_super_kernel<MODE, NR>),
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&big_super_kernel<MODE, NR, Z>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   const unsigned groups = B.total(kind, step);
   if (groups > 0)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(big_super_kernel<MODE, NR>), dim3(groups), dim3(SW * 64), lds, s, B.list.get(),
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(big_super_kernel<MODE, NR, Z>), dim3(groups), dim3(SW * 64), lds, s, B.list.get(),
                        B.prefix(kind, step), B.count, step, F.view, F.invs.get(), work, zbuf, B.row_blocks);
 }
 
@@ -1395,13 +1400,13 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
                          dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work);
     lap("up small  ", d);
     const mf::Factors::BigLevel &B = F.big[(size_t)d];
-    if (!Z && B.count > 0) {
+    if (B.count > 0) {
       // untransposed: the boundary rows get their updates inside the pass over the pivot columns;
       // transposed: U11^T on the pivots, then the boundary with U12^T
-      for (int k = 0; k < B.steps; ++k) launch_big_super<FWD, NR>(F, B, TRANS ? 1 : 0, k, work, zbuf, s);
+      for (int k = 0; k < B.steps; ++k) launch_big_super<FWD, NR, Z>(F, B, TRANS ? 1 : 0, k, work, zbuf, s);
       if (TRANS && B.total(3) > 0)
-        hipLaunchKernelGGL(big_boundary_t_kernel<NR>, dim3(B.total(3)), dim3(256), 0, s, B.list.get(), B.prefix(3),
-                           B.count, F.view, work, zbuf);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_boundary_t_kernel<NR, Z>), dim3(B.total(3)), dim3(256), 0, s, B.list.get(),
+                           B.prefix(3), B.count, F.view, work, zbuf);
     }
     lap("up large  ", d);
   }
@@ -1412,17 +1417,17 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
                          stride);
     lap("down small", d);
     const mf::Factors::BigLevel &B = F.big[(size_t)d];
-    if (!Z && B.count > 0) {
+    if (B.count > 0) {
       if (B.total(4) > 0) {
-        hipLaunchKernelGGL(big_gather_x_kernel<NR>, dim3(B.total(4)), dim3(256), 0, s, B.list.get(), B.prefix(4),
-                           B.count, F.view, c, stride, work, zbuf);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_kernel<TRANS, NR>), dim3(B.total(5)), dim3(256), 0, s,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gather_x_kernel<NR, Z>), dim3(B.total(4)), dim3(256), 0, s, B.list.get(),
+                           B.prefix(4), B.count, F.view, c, stride, work, zbuf);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_kernel<TRANS, NR, Z>), dim3(B.total(5)), dim3(256), 0, s,
                            B.list.get(), B.prefix(5), B.count, F.view, work, zbuf);
       }
       // the pivot block alone; columns of Z / W are fs apart
-      for (int k = 0; k < B.steps; ++k) launch_big_super<BWD, NR>(F, B, 2, k, work, zbuf, s);
-      hipLaunchKernelGGL(big_scatter_x_kernel<NR>, dim3(B.total(6)), dim3(256), 0, s, B.list.get(), B.prefix(6),
-                         B.count, F.view, work, zbuf, c, stride);
+      for (int k = 0; k < B.steps; ++k) launch_big_super<BWD, NR, Z>(F, B, 2, k, work, zbuf, s);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(big_scatter_x_kernel<NR, Z>), dim3(B.total(6)), dim3(256), 0, s, B.list.get(),
+                         B.prefix(6), B.count, F.view, work, zbuf, c, stride);
     }
     lap("down large", d);
   }
@@ -1439,15 +1444,16 @@ void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride,
     // right-hand side is two real columns of the work matrices: one at a time, or four together
     constexpr int kGroupZ = 4;
     const int nrz = k == 1 ? 2 : 2 * kGroupZ;
-    DBuf<double> wz((size_t)T.work_elems * nrz);
+    DBuf<double> wz((size_t)T.work_elems * nrz * 2);  // work and z matrices
+    double *wk = wz.get(), *zb = wz.get() + (size_t)T.work_elems * nrz;
     if (k == 1) {
-      if (sys == 0) solve_columns_on_tree<false, 2, true>(F, d_c, stride, wz.get(), nullptr, s);
-      else solve_columns_on_tree<true, 2, true>(F, d_c, stride, wz.get(), nullptr, s);
+      if (sys == 0) solve_columns_on_tree<false, 2, true>(F, d_c, stride, wk, zb, s);
+      else solve_columns_on_tree<true, 2, true>(F, d_c, stride, wk, zb, s);
     } else {
       for (int c0 = 0; c0 < k; c0 += kGroupZ) {  // (k is a multiple of kSolveGroup = 8 here: zero-padded by the caller)
         double *c = d_c + (size_t)c0 * stride;
-        if (sys == 0) solve_columns_on_tree<false, 2 * kGroupZ, true>(F, c, stride, wz.get(), nullptr, s);
-        else solve_columns_on_tree<true, 2 * kGroupZ, true>(F, c, stride, wz.get(), nullptr, s);
+        if (sys == 0) solve_columns_on_tree<false, 2 * kGroupZ, true>(F, c, stride, wk, zb, s);
+        else solve_columns_on_tree<true, 2 * kGroupZ, true>(F, c, stride, wk, zb, s);
       }
     }
     SPL_HIP(hipStreamSynchronize(s));

@@ -186,12 +186,13 @@ def test_complex_symmetric_shift_native_and_embedded(gpu, pkg, dim, m, z, limits
     L D L^T mode (half), (3) the general real embedding.  The same solutions of A x = b and A^H y = c to 1e-10, backward
     errors at rounding level; packed, batched and device right-hand sides.  z = 4 + 0.01i puts Re z on A's diagonal (the
     real pivot of the plain embedding is 0), z = 6 is a real shift.  "small": size classes lowered so that the
-    one-workgroup, lockstep and multi-launch kernels all run."""
+    one-workgroup, lockstep and multi-launch kernels of the factorisation and the many-workgroup solves all run."""
     import scipy.sparse as sp
     import torch
     if limits == "small":
         monkeypatch.setenv("SPL_MF_SMALL", "64")
         monkeypatch.setenv("SPL_MF_MIDMAX", "256")
+        monkeypatch.setenv("SPL_MF_BIGSOLVE", "64")
     monkeypatch.setenv("SPL_LU_METHOD", "mf")
     rng = np.random.default_rng(m)
     T = sp.diags([-np.ones(m - 1), 2.0 * np.ones(m), -np.ones(m - 1)], (-1, 0, 1))
@@ -245,6 +246,7 @@ def test_native_complex_fronts_unsymmetric(gpu, pkg, kind, limits, monkeypatch):
     if limits == "small":
         monkeypatch.setenv("SPL_MF_SMALL", "64")
         monkeypatch.setenv("SPL_MF_MIDMAX", "256")
+        monkeypatch.setenv("SPL_MF_BIGSOLVE", "64")
     monkeypatch.setenv("SPL_LU_METHOD", "mf")
     rng = np.random.default_rng(17)
     m = 48

@@ -1,11 +1,20 @@
 #!/bin/bash
-# complex symmetric z I - A (FEAST contour point): symmetric embedding (L D L^T) against the general embedding
-for sym in 1 0; do
-  echo "SPL_ZI_SYMMETRIC=$sym"
-  SPL_ZI_SYMMETRIC=$sym timeout -k 10 400 python tools/bench_solve.py --grid 60,100 --cpu-max 0 --shift "3.0+0.5j" 2>&1 | grep "^{" | python -c "
+# complex symmetric z I - A (FEAST contour point) through umfpack_zi_*: native complex fronts (L D L^T), the symmetric
+# real embedding of D A D (SPL_ZI_NATIVE=0 SPL_ZI_SYMMETRIC=1) and the general real embedding (=0 / =0)
+run() {  # label, env..., then bench_solve args after --
+  label=$1; shift
+  envs=()
+  while [ "$1" != "--" ]; do envs+=("$1"); shift; done
+  shift
+  echo "== $label"
+  env "${envs[@]}" timeout -k 10 400 python tools/bench_solve.py --cpu-max 0 "$@" 2>&1 | grep "^{" | python -c "
 import sys, json
 for l in sys.stdin:
-    d = json.loads(l); print(d['m'], d['gpu'], d['max_rel_err_vs_manufactured'], d['transposed_max_rel_err'], d['factorisation']['path'], d['factorisation']['flops'], d['factorisation']['device_GB'])"
-done
-SPL_ZI_SYMMETRIC=1 timeout -k 10 200 python tools/bench_solve.py --dim 2 --grid 1000 --cpu-max 0 --shift "0.001+0.0005j" 2>&1 | grep "^{" | cut -c1-600
-SPL_ZI_SYMMETRIC=0 timeout -k 10 200 python tools/bench_solve.py --dim 2 --grid 1000 --cpu-max 0 --shift "0.001+0.0005j" 2>&1 | grep "^{" | cut -c1-600
+    d = json.loads(l); print(d['m'], d['gpu'], 'err %.1e %.1e' % (d['max_rel_err_vs_manufactured'], d['transposed_max_rel_err']), 'path', d['factorisation']['path'], 'flops %.3g' % d['factorisation']['flops'], 'GB', d['factorisation']['device_GB'])"
+}
+G3=${1:-60,100}
+run "native complex fronts, 3-D" SPL_ZI_NATIVE=1 -- --grid $G3 --shift "3.0+0.5j"
+run "symmetric embedding, 3-D" SPL_ZI_NATIVE=0 SPL_ZI_SYMMETRIC=1 -- --grid $G3 --shift "3.0+0.5j"
+run "general embedding, 3-D" SPL_ZI_NATIVE=0 SPL_ZI_SYMMETRIC=0 -- --grid $G3 --shift "3.0+0.5j"
+run "native complex fronts, 2-D 1000^2" SPL_ZI_NATIVE=1 -- --dim 2 --grid 1000 --shift "0.001+0.0005j"
+run "general embedding, 2-D 1000^2" SPL_ZI_NATIVE=0 SPL_ZI_SYMMETRIC=0 -- --dim 2 --grid 1000 --shift "0.001+0.0005j"
