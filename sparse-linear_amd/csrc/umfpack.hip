@@ -886,12 +886,18 @@ int numeric_of_embedding(const int *Ep, const int *Ei, const double *Ex, void *S
   } vouch(native);
   return umfpack_di_numeric(Ep, Ei, Ex, Symbolic, Numeric, nullptr, nullptr);
 }
+// Native complex fronts serve this analysis?  They need the tree (of the complex pattern), and pay where the tree has
+// flops to halve: below ~1e12 flops of the embedding's tree (2-D meshes up to 10^6 unknowns) a factorisation is
+// launch-bound either way and a batch of right-hand sides takes twice the passes over the tree (four complex columns
+// per pass against eight real ones).  SPL_ZI_NATIVE=1 / 0: always / never.
 bool symbolic_has_complex_tree(void *SymbolicIn) {
   Symbolic *S = as_symbolic(SymbolicIn);
+  if (!S || !S->tree || !S->ztree) return false;
   const char *zn = getenv("SPL_ZI_NATIVE");
-  return S && S->tree && S->ztree && !(zn && zn[0] == '0');
+  if (zn && zn[0] == '0') return false;
+  if (zn && zn[0] == '1') return true;
+  return S->tree->flops >= 1e12;
 }
-
 // analysis of the real embedding of an n x n complex matrix from the complex pattern itself (umfpack_zi.hip);
 // (Ep, Ei): the pattern of the embedding, 2n x 2n, interleaved unknowns
 int symbolic_of_embedding(int n, const int *Ap, const int *Ai, const int *Ep, const int *Ei, void **SymbolicOut) {

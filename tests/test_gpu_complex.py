@@ -204,16 +204,17 @@ def test_complex_symmetric_shift_native_and_embedded(gpu, pkg, dim, m, z, limits
     S.sort_indices()
     M = pkg.Matrix(n, n, S.indptr, S.indices, S.data)
     U = pkg.umfpack
+    monkeypatch.setenv("SPL_ZI_NATIVE", "1")  # by itself the wrapper goes native from 1e12 flops of the embedding's tree on
     fn = U.factor(M, U.analyze(M))
     monkeypatch.setenv("SPL_ZI_NATIVE", "0")
-    monkeypatch.setenv("SPL_ZI_SYMMETRIC", "1")  # by itself the wrapper does this from 1e12 flops of the tree on
+    monkeypatch.setenv("SPL_ZI_SYMMETRIC", "1")
     fs = U.factor(M, U.analyze(M))
     monkeypatch.setenv("SPL_ZI_SYMMETRIC", "0")
     fg = U.factor(M, U.analyze(M))
     monkeypatch.delenv("SPL_ZI_SYMMETRIC")
-    fd = U.factor(M, U.analyze(M))
     monkeypatch.delenv("SPL_ZI_NATIVE")
-    assert fd.stats["flops"] == fg.stats["flops"] < 1e12  # small trees keep the general embedding
+    fd = U.factor(M, U.analyze(M))
+    assert fd.stats["flops"] == fg.stats["flops"] < 1e12 and fd.stats["complex_fronts"] == 0  # small trees: general embedding
     assert fn.path in (3, 4) and fs.path in (3, 4) and fg.path in (3, 4)
     sn, ss, sg = fn.stats, fs.stats, fg.stats
     assert (sn["complex_fronts"], ss["complex_fronts"], sg["complex_fronts"]) == (1, 0, 0)
@@ -265,11 +266,11 @@ def test_native_complex_fronts_unsymmetric(gpu, pkg, kind, limits, monkeypatch):
     S.sort_indices()
     M = pkg.Matrix(n, n, S.indptr, S.indices, S.data)
     U = pkg.umfpack
+    monkeypatch.setenv("SPL_ZI_NATIVE", "1")
     fn = U.factor(M, U.analyze(M))
     assert fn.stats["complex_fronts"] == 1 and fn.path in {"dominant": (3,), "general": (4,), "hermitian": (3, 4)}[kind]
     monkeypatch.setenv("SPL_ZI_NATIVE", "0")
     fe = U.factor(M, U.analyze(M))
-    monkeypatch.delenv("SPL_ZI_NATIVE")
     assert fe.stats["complex_fronts"] == 0 and abs(fn.stats["flops"] - 0.5 * fe.stats["flops"]) <= 1e-9 * fe.stats["flops"]
     xs = [rng.normal(size=n) + 1j * rng.normal(size=n) for _ in range(9)]
     for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, sp.csc_matrix(S.conj().T))):

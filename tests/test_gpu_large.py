@@ -268,3 +268,34 @@ def test_c5_poisson3d_200_lu_full_size(gpu, pkg, O):
     import gc
     gc.collect()
     pkg._ffi.release_cached_memory()
+
+
+def test_zi_native_complex_fronts_by_default_3d(gpu, pkg):
+    """a FEAST contour point z I - A on the 3-D 7-point Laplacian at 56^3 (175 616 complex unknowns; the tree of the
+    embedding has > 1e12 flops): umfpack_zi_numeric takes the native complex fronts by itself, in their L D L^T mode
+    (A == A^T); A x = b and A^H y = c to a backward error at rounding level, one and several right-hand sides"""
+    import scipy.sparse as sp
+    m = 56
+    T = sp.diags([-np.ones(m - 1), 2.0 * np.ones(m), -np.ones(m - 1)], (-1, 0, 1))
+    I = sp.identity(m)
+    K = sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(T, I), I)
+    n = m ** 3
+    S = sp.csc_matrix((3.0 + 0.5j) * sp.identity(n) - K)
+    S.sort_indices()
+    M = pkg.Matrix(n, n, S.indptr, S.indices, S.data)
+    U = pkg.umfpack
+    f = U.factor(M, U.analyze(M))
+    st = f.stats
+    assert st["complex_fronts"] == 1 and st["path"] in (3, 4) and st["n"] == 2 * n
+    rng = np.random.default_rng(3)
+    xs = [rng.normal(size=n) + 1j * rng.normal(size=n) for _ in range(3)]
+
+    def bwd(op, x, b):
+        return float(np.max(np.abs(op @ x - b) / (abs(op) @ np.abs(x) + np.abs(b))))
+
+    for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, sp.csc_matrix(S.conj().T))):
+        bs = [np.asarray(op @ x).ravel() for x in xs]
+        assert bwd(op, U.linearSolve_(f, mode, M, bs[0]), bs[0]) <= 1e-13
+        for got, b in zip(U.linearSolveMany_(f, mode, M, bs), bs):
+            assert bwd(op, got, b) <= 1e-13
+    assert f.stats["complex_fronts"] == 1
