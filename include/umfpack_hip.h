@@ -42,10 +42,14 @@
  * band does not fit the HBM — a large mesh — solve returns UMFPACK_ERROR_out_of_memory and the
  * object keeps its previous factors).  SPL_LU_STATIC_PIVOT=0 skips the first stage.  SPL_LU_METHOD=band|mf forces the ordering.  Square matrices only (the reference's linearSolve_
  * assumes square, Umfpack.hs:93).
- * The complex (`zi`) entry points (Internal.hs:69-115) are served through the real 2n x 2n
- * embedding with interleaved unknowns (csrc/umfpack_zi.hip): packed complex arrays (imaginary
+ * The complex (`zi`) entry points (Internal.hs:69-115): a Numeric object holds the real 2n x 2n
+ * embedding with interleaved unknowns (csrc/umfpack_zi.hip) — packed complex arrays (imaginary
  * pointer NULL, the only form the reference uses, Internal.hs:124-132) ARE the real arrays of the
- * embedded system; sys = 1 is the conjugate transpose, as in UMFPACK.
+ * embedded system; sys = 1 is the conjugate transpose, as in UMFPACK — for residuals, refinement
+ * and every fallback above.  The factors themselves are NATIVE COMPLEX fronts (two planes per
+ * front, complex arithmetic on the fp64 matrix cores, L D L^T when A == A^T; csrc/multifrontal.hip,
+ * round 3) whenever the analysis chose the multifrontal tree and that tree has work to halve
+ * (1e12 flops; SPL_ZI_NATIVE=1|0 forces); the band path and small trees factor the embedding.
  */
 #ifndef UMFPACK_HIP_H
 #define UMFPACK_HIP_H
@@ -133,7 +137,8 @@ int spl_umfpack_path(void *Numeric);
  * nullPtr).  out[0] path as above, out[1] n, out[2] kl and out[3] ku of the reordered matrix
  * (band paths), out[4] bytes of device memory the factors occupy, out[5] flops of the numeric
  * factorisation (band: 2 n kl ku; multifrontal: summed over the fronts), out[6] number of fronts
- * (0 on the band paths), out[7] 0.  Returns 0, or -1 if the object is invalid. */
+ * (0 on the band paths), out[7] 1 when the fronts are native complex ones (`zi` objects; out[5]
+ * then counts 4 real flops per complex multiply-add pair), else 0.  Returns 0, or -1 if the object is invalid. */
 int spl_umfpack_stats(void *Numeric, double out[8]);
 
 #ifdef __cplusplus
