@@ -37,9 +37,11 @@ def handle_to_csc_tuple(H):
     return (nr, nc, cp, rows[order], v[order])
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 1), (37, 129, 400), (5000, 4000, 90_000), (300, 128 * 7, 30_000),
-                                   (200_000, 150_000, 3_000_000)])
-@pytest.mark.parametrize("tiled", ["1", "0"])
+_LIN_SHAPES = [(1, 1, 1), (37, 129, 400), (5000, 4000, 90_000), (300, 128 * 7, 30_000)]
+
+
+# every shape through both kernel sets; the large case once, through the tiled kernels
+@pytest.mark.parametrize("shape,tiled", [(sh, t) for t in ("1", "0") for sh in _LIN_SHAPES] + [((200_000, 150_000, 3_000_000), "1")])
 def test_lin_on_handles_matches_oracle_bitwise(gpu, pkg, O, monkeypatch, shape, tiled):
     monkeypatch.setenv("SPL_LIN_TILED", tiled)
     nr, nc, k = shape
@@ -48,8 +50,6 @@ def test_lin_on_handles_matches_oracle_bitwise(gpu, pkg, O, monkeypatch, shape, 
     HA = pkg.DeviceMatrix.from_csc(tuple_to_mat(pkg, A))
     HB = pkg.DeviceMatrix.from_csc(tuple_to_mat(pkg, B))
     big = nr >= 100_000
-    if big and tiled == "0":
-        pytest.skip("the large case once, through the tiled kernel")
     for al, be in (((-1.0, 2.5),) if big else ((1.0, 1.0), (-1.0, 2.5), (0.0, 1.0))):
         HC = HA.lin(al, HB, be)
         Co = O.lin(al, A, be, B)
