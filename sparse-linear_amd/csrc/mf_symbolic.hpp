@@ -67,6 +67,10 @@ struct Tree {
   int64_t panel_elems = 0, inv_elems = 0, work_elems = 0, rel_elems = 0;
   double flops = 0.0;
   std::vector<std::vector<int>> by_depth;  // fronts of each tree level
+  // levels of the level structure the root region was cut with (0: the graph is disconnected).  A breadth-first
+  // search has at most diameter + 1 levels and every ordering has bandwidth >= (n - 1) / diameter: a lower bound of
+  // what a band factorisation of this pattern costs, without computing a band ordering (umfpack.hip)
+  int root_levels = 0;
   int fs(int f) const { return np[(size_t)f] + nb[(size_t)f]; }
   // What a numeric factorisation derives from the tree alone — its arrays on the device, the positions of every
   // boundary index inside the parent's front — is built by the first factorisation and kept here for the later
@@ -83,13 +87,49 @@ struct Tree {
     ldp = o.ldp; ldu = o.ldu; ioff = o.ioff; woff = o.woff; roff = o.roff; level_elems = o.level_elems;
     region_elems[0] = o.region_elems[0]; region_elems[1] = o.region_elems[1];
     front_elems = o.front_elems; panel_elems = o.panel_elems; inv_elems = o.inv_elems; work_elems = o.work_elems;
-    rel_elems = o.rel_elems; flops = o.flops; by_depth = o.by_depth;
+    rel_elems = o.rel_elems; flops = o.flops; by_depth = o.by_depth; root_levels = o.root_levels;
     device_cache.reset();
     return *this;
   }
 };
 
 namespace detail {
+
+// every off-diagonal entry (i, j) has its partner (j, i)?  Rows ascending inside a column (else: false at worst).
+inline bool structurally_symmetric(int n, const int *Ap, const int *Ai) {
+  std::atomic<bool> ok{true};
+  auto check = [&](int j0, int j1) {
+    for (int j = j0; j < j1; ++j) {
+      if (!ok.load(std::memory_order_relaxed)) return;
+      for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
+        const int r = Ai[p];
+        if (r == j) continue;
+        if (r < 0 || r >= n) { ok.store(false, std::memory_order_relaxed); return; }
+        const int *first = Ai + Ap[r], *last = Ai + Ap[r + 1];
+        const int *it = std::lower_bound(first, last, j);
+        if (it == last || *it != j) { ok.store(false, std::memory_order_relaxed); return; }
+      }
+    }
+  };
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt ? (nt > 8 ? 8 : nt) : 1;
+  if (Ap[n] < 200000 || nt < 2) {
+    check(0, n);
+  } else {
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; ++t) {
+      const int j0 = (int)((int64_t)n * t / nt), j1 = (int)((int64_t)n * (t + 1) / nt);
+      try {
+        pool.emplace_back(check, j0, j1);
+      } catch (...) {
+        check(j0, j1);
+      }
+    }
+    check(0, (int)((int64_t)n / nt));
+    for (std::thread &th : pool) th.join();
+  }
+  return ok.load();
+}
 
 struct Node {
   int left = -1, right = -1;  // indices in the same vector (post-order: children before the parent)
@@ -114,6 +154,7 @@ struct Shared {
   int max_team = 1;
   int team_region = kTeamRegion, team_frontier = kTeamFrontier;  // SPL_ND_TEAM_REGION / _FRONTIER (experiments)
   bool timing = false;
+  int root_levels = 0;  // levels of the root region's final level structure (written by the depth-0 call only)
   std::atomic<int> stamp{0};
   Shared(int n_, const std::vector<int64_t> &xa, const std::vector<int> &ad, int leaf_)
       : n(n_), xadj(xa), adj(ad), leaf(leaf_), verts((size_t)n_), mark((size_t)n_, 0), level((size_t)n_, 0) {
@@ -442,6 +483,7 @@ struct Worker {
       return join(lo, lo + na, hi, Node(), depth);
     }
     const int nlev = (int)level_ptr.size() - 1;
+    if (depth == 0) S.root_levels = nlev;
     if (nlev < 3) {
       // No interior level: every vertex is within one step of both ends.  A small region, or a
       // genuinely dense one, becomes a leaf.  A large one held together by a few hubs (a dense row
@@ -513,7 +555,9 @@ inline void expand_tree(Tree &T, int mult);
 inline void layout_tree(Tree &T);
 // unexpanded != nullptr (mult > 1): also receives the tree of the small graph itself, laid out for fronts of its own
 // n unknowns (native complex fronts, multifrontal.hip: one dissection serves both)
-inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, int mult = 1, Tree *unexpanded = nullptr) {
+// pattern_symmetric: 1 / 0 if the caller has already run detail::structurally_symmetric, -1: not known
+inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, int mult = 1, Tree *unexpanded = nullptr,
+                       int pattern_symmetric_hint = -1) {
   T = Tree();
   T.n = n;
   const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // phase times on stderr (diagnostic)
@@ -524,17 +568,34 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
     fprintf(stderr, "[build_tree] %-24s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
     t_last = now;
   };
-  // adjacency of A + A^T without the diagonal (duplicates are harmless for BFS and are removed from
-  // the boundary lists by sort + unique)
+  // adjacency of A + A^T without the diagonal.  A structurally symmetric pattern (meshes, FEAST's z B - A; rows
+  // ascending inside a column, as the entry points validate) IS its own adjacency: the column lists minus the diagonal,
+  // half the edges the general construction below would make the traversals scan (there every entry contributes to
+  // both of its ends, so a symmetric pair appears twice: harmless for BFS, removed from the boundary lists by sort +
+  // unique, but twice the edge work).
+  const bool pattern_symmetric = pattern_symmetric_hint >= 0 ? pattern_symmetric_hint != 0 : detail::structurally_symmetric(n, Ap, Ai);
   std::vector<int64_t> xadj((size_t)n + 1, 0);
-  for (int j = 0; j < n; ++j)
-    for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
-      const int i = Ai[p];
-      if (i != j) { ++xadj[(size_t)i + 1]; ++xadj[(size_t)j + 1]; }
+  std::vector<int> adj;
+  if (pattern_symmetric) {
+    for (int j = 0; j < n; ++j) {
+      int64_t len = 0;
+      for (int p = Ap[j]; p < Ap[j + 1]; ++p) len += Ai[p] != j;
+      xadj[(size_t)j + 1] = xadj[(size_t)j] + len;
     }
-  for (int i = 0; i < n; ++i) xadj[(size_t)i + 1] += xadj[(size_t)i];
-  std::vector<int> adj((size_t)xadj[(size_t)n]);
-  {
+    adj.resize((size_t)xadj[(size_t)n]);
+    for (int j = 0; j < n; ++j) {
+      int64_t q = xadj[(size_t)j];
+      for (int p = Ap[j]; p < Ap[j + 1]; ++p)
+        if (Ai[p] != j) adj[(size_t)q++] = Ai[p];
+    }
+  } else {
+    for (int j = 0; j < n; ++j)
+      for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
+        const int i = Ai[p];
+        if (i != j) { ++xadj[(size_t)i + 1]; ++xadj[(size_t)j + 1]; }
+      }
+    for (int i = 0; i < n; ++i) xadj[(size_t)i + 1] += xadj[(size_t)i];
+    adj.resize((size_t)xadj[(size_t)n]);
     std::vector<int64_t> cur(xadj.begin(), xadj.end() - 1);
     for (int j = 0; j < n; ++j)
       for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
@@ -542,12 +603,13 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
         if (i != j) { adj[(size_t)cur[(size_t)i]++] = j; adj[(size_t)cur[(size_t)j]++] = i; }
       }
   }
-  lap("adjacency of A + A^T");
+  lap(pattern_symmetric ? "adjacency (symmetric pattern)" : "adjacency of A + A^T");
   detail::Shared shared(n, xadj, adj, leaf);
   std::vector<detail::Node> nodes;
   if (n > 0) {
     detail::Worker w(shared);
     nodes = w.dissect(0, n, 0);
+    T.root_levels = shared.root_levels;
   }
   lap("dissection");
   // the node vector is a post-order: children before their parent

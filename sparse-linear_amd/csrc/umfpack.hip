@@ -56,6 +56,7 @@ struct Symbolic {
   // embeddings of complex matrices (umfpack_zi.hip): the tree of the COMPLEX pattern itself, from the same dissection
   // (tree is its expansion): what the native complex fronts are built on
   std::shared_ptr<const mf::Tree> ztree;
+  bool have_band = false;  // perm / inv / kl / ku are set (large matrices whose tree wins by a lower bound skip them)
 };
 
 struct Numeric {
@@ -694,8 +695,38 @@ bool factor_static_pivot(Numeric *N, const int *Ap, const int *Ai, const double 
 // (re)build the band factors of P A P^T from the device copy of A^T's rows (= the CSC arrays);
 // nopiv selects the blocked no-interchange factorisation (band_nopiv.hip) or LAPACK-style
 // partial pivoting.  Throws DeviceError; sets N->singular.
+// The reverse Cuthill-McKee ordering of an object whose analysis skipped it (symbolic_common: the tree won by a lower
+// bound), from the pattern the object holds: the rows of A^T are the columns of A.
+static void ensure_band_ordering(Numeric *N, hipStream_t s) {
+  const int n = N->n;
+  if ((int)N->band_perm.size() == n || n == 0) return;
+  if (!N->At || !N->At->rowptr.get()) throw DeviceError{SPL_ERROR_index_overflow};
+  const size_t nnz = (size_t)N->At->nnz;
+  std::vector<int> p((size_t)n + 1), i(nnz);
+  SPL_HIP(hipMemcpyAsync(p.data(), N->At->rowptr.get(), ((size_t)n + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+  SPL_HIP(hipMemcpyAsync(i.data(), N->At->colidx.get(), nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+  SPL_HIP(hipStreamSynchronize(s));
+  std::vector<int> perm, inv((size_t)n, 0);
+  rcm_order(n, p.data(), i.data(), perm);
+  for (int k = 0; k < n; ++k) inv[(size_t)perm[(size_t)k]] = k;
+  int kl = 0, ku = 0;
+  for (int j = 0; j < n; ++j) {
+    const int nj = inv[(size_t)j];
+    for (int q = p[(size_t)j]; q < p[(size_t)j + 1]; ++q) {
+      const int ni = inv[(size_t)i[(size_t)q]];
+      kl = std::max(kl, ni - nj);
+      ku = std::max(ku, nj - ni);
+    }
+  }
+  N->band_perm.swap(perm);
+  N->band_inv.swap(inv);
+  N->kl = kl;
+  N->ku = ku;
+}
+
 void factor_band(Numeric *N, bool nopiv, hipStream_t s) {
   const int n = N->n;
+  ensure_band_ordering(N, s);
   // Will the band fit?  Decided BEFORE anything of the current factors is released: a band that does not
   // fit (a large 3-D matrix whose speculation failed) must leave the object as it was — its speculative
   // factors still answer solves, which then report the error again instead of reading freed memory.
@@ -790,16 +821,19 @@ static int symbolic_common(int n, const int *Ap, const int *Ai, int mult, const 
     const bool force_mf = method && method[0] == 'm', force_band = method && method[0] == 'b';
     std::future<std::shared_ptr<mf::Tree>> tree_job;
     std::shared_ptr<mf::Tree> small_tree = mult > 1 ? std::make_shared<mf::Tree>() : nullptr;  // of the complex pattern
-    if (!force_band && (force_mf || S->n >= 1024))
-      tree_job = std::async(std::launch::async, [n, Ap, Ai, mult, small_tree] {
+    const bool want_tree = !force_band && (force_mf || S->n >= 1024);
+    const int pattern_symmetric = want_tree ? (mf::detail::structurally_symmetric(n, Ap, Ai) ? 1 : 0) : -1;
+    if (want_tree)
+      tree_job = std::async(std::launch::async, [n, Ap, Ai, mult, small_tree, pattern_symmetric] {
         std::shared_ptr<mf::Tree> T = std::make_shared<mf::Tree>();
-        mf::build_tree(n, Ap, Ai, 256 / mult, *T, mult, small_tree.get());
+        mf::build_tree(n, Ap, Ai, 256 / mult, *T, mult, small_tree.get(), pattern_symmetric);
         return T;
       });
     const bool timing = getenv("SPL_MF_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-    try {
+    // the band ordering (reverse Cuthill-McKee) and its bandwidths
+    auto band_ordering = [&] {
       std::vector<int> perm, inv((size_t)n, 0);
       rcm_order(n, Ap, Ai, perm);
       if (timing) fprintf(stderr, "[symbolic] RCM done at %.1f ms\n", since());
@@ -827,23 +861,47 @@ static int symbolic_common(int n, const int *Ap, const int *Ai, int mult, const 
         S->kl = mult * kl + (mult - 1);
         S->ku = mult * ku + (mult - 1);
       }
+      S->have_band = true;
+    };
+    // Measured model of the two factorisations (MI355X, tools/bench_band_vs_tree.py): the band
+    // is a chain of n / 64 block steps of a few launches each, about 1.4 us per column however
+    // narrow it is, plus its flops at the rate of its large windows; the tree costs a few
+    // launches per level (about 2.5 ms for a whole tree) plus its flops at a lower rate (many
+    // small fronts).  The break-even is near n = 2 000 on 2-D and 3-D meshes alike.
+    auto band_seconds = [&](double kl, double ku) { return 1.4e-6 * S->n + 2.0 * S->n * kl * ku / 3e13; };
+    // Large matrices (round 3): the dissection first, with every core (the band ordering used to run beside it and
+    // took a thread and its share of the memory system: 1.5 s at config C5, behind which a shorter dissection would
+    // only have waited).  The level structure the root region was cut with bounds the band from below — a breadth-
+    // first search has at most diameter + 1 levels, and no ordering has a bandwidth below (n - 1) / diameter — so
+    // where even that band loses to the tree, the band ordering is not computed at all; a fallback that needs it
+    // later (factor_band) computes it then, from the pattern the Numeric object holds.
+    // (structurally symmetric patterns only: there kl = ku >= that bandwidth; an unsymmetric pattern may have one narrow
+    // side, and keeps the two orderings side by side)
+    const bool tree_first = tree_job.valid() && S->n >= 100000 && pattern_symmetric == 1 && !getenv("SPL_LU_ALWAYS_RCM");
+    try {
+      if (!tree_first) band_ordering();
     } catch (...) {
       if (tree_job.valid()) tree_job.wait();  // Ap / Ai are borrowed: nobody may outlive this call
       throw;
     }
     if (tree_job.valid()) {
-      if (timing) fprintf(stderr, "[symbolic] bandwidths done at %.1f ms\n", since());
+      if (timing && !tree_first) fprintf(stderr, "[symbolic] bandwidths done at %.1f ms\n", since());
       std::shared_ptr<mf::Tree> T = tree_job.get();
       if (timing) fprintf(stderr, "[symbolic] nested dissection tree ready at %.1f ms\n", since());
-      const double band_flops = 2.0 * S->n * (double)S->kl * (double)S->ku;
-      // Measured model of the two factorisations (MI355X, tools/bench_band_vs_tree.py): the band
-      // is a chain of n / 64 block steps of a few launches each, about 1.4 us per column however
-      // narrow it is, plus its flops at the rate of its large windows; the tree costs a few
-      // launches per level (about 2.5 ms for a whole tree) plus its flops at a lower rate (many
-      // small fronts).  The break-even is near n = 2 000 on 2-D and 3-D meshes alike.
-      const double t_band = 1.4e-6 * S->n + band_flops / 3e13;
       const double t_tree = 2.5e-3 + T->flops / 2e13;
-      if (force_mf || t_tree < t_band) {
+      bool take_tree = force_mf;
+      if (tree_first && !take_tree) {
+        const mf::Tree &Ts = small_tree && small_tree->nfronts > 0 ? *small_tree : *T;  // the graph that was dissected
+        const double bw = Ts.root_levels >= 2 ? std::ceil((double)(n - 1) / (double)(Ts.root_levels - 1)) : 0.0;
+        const double kmin = mult * bw;  // both half-bandwidths of a structurally symmetric reordering of A + A^T's pattern
+        if (kmin > 0 && t_tree < band_seconds(kmin, kmin)) take_tree = true;
+        if (timing) fprintf(stderr, "[symbolic] %d levels: band >= %.0f wide, %.3g s at least; tree %.3g s\n", Ts.root_levels, kmin, band_seconds(kmin, kmin), t_tree);
+      }
+      if (!take_tree) {
+        if (!S->have_band) band_ordering();
+        take_tree = t_tree < band_seconds((double)S->kl, (double)S->ku);
+      }
+      if (take_tree) {
         S->tree = T;
         if (small_tree && small_tree->nfronts > 0) S->ztree = small_tree;
       }
@@ -962,7 +1020,7 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
     N->ipiv.alloc((size_t)n);
     N->perm.alloc((size_t)n);
     N->inv.alloc((size_t)n);
-    N->band_perm = S->perm;
+    N->band_perm = S->perm;  // (empty when the analysis skipped the band ordering: ensure_band_ordering)
     N->band_inv = S->inv;
     N->tree = S->tree;
     {

@@ -676,3 +676,25 @@ def test_almost_symmetric_matrix_takes_plain_lu(gpu, pkg, O, monkeypatch):
         for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, sp.csc_matrix(S.T))):
             b = np.asarray(op @ xs).ravel()
             assert _backward_error(op, U.linearSolve_(f, mode, A, b), b) <= 1e-13
+
+
+def test_band_ordering_is_computed_on_demand(gpu, pkg, O, monkeypatch):
+    """from 1e5 unknowns on, a structurally symmetric pattern whose tree wins against the best band its level structure
+    allows is analysed without a band ordering (csrc/umfpack.hip, symbolic_common); a factorisation that needs the
+    band after all — here forced: partial pivoting — computes reverse Cuthill-McKee then, from the pattern the object
+    holds.  2-D Poisson 320^2 = 102 400 unknowns."""
+    m = 320
+    n, A = _grid_matrix(pkg, O, "2d", m)
+    U = pkg.umfpack
+    an = U.analyze(A)
+    f = U.factor(A, an)
+    assert f.path == 3 and f.stats["kl"] == 0
+    monkeypatch.setenv("SPL_LU_FORCE_PIVOT", "1")
+    fb = U.factor(A, an)  # the same analysis object
+    st = fb.stats
+    assert st["path"] == 0 and 0 < st["kl"] == st["ku"] <= m
+    xs = np.random.default_rng(2).uniform(0.5, 1.5, n)
+    S = csc_tuple_to_scipy(mat_to_tuple(A))
+    b = np.asarray(S @ xs).ravel()
+    for fac in (f, fb):
+        assert _backward_error(S, U.linearSolve_(fac, U.UmfpackNormal, A, b), b) <= 1e-13
