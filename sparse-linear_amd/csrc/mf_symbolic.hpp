@@ -93,6 +93,16 @@ struct Tree {
   }
 };
 
+// Optional accelerator for the level structures of large regions (csrc/nd_levels.hip builds them on the GPU; this
+// header stays free of HIP).  levels(): the pseudo-peripheral level structure of the region region[0 .. size) — a
+// traversal from region[0], then, if that reached everything, another from the far end — as `queue` (the vertices
+// grouped by level, in a deterministic order inside a level) and `level_ptr`; returns the number of vertices reached
+// (< size: the region is disconnected and the outputs are not meaningful).  Thread-safe.
+struct LevelService {
+  virtual ~LevelService() {}
+  virtual int levels(const int *region, int size, std::vector<int> &queue, std::vector<int64_t> &level_ptr) = 0;
+};
+
 namespace detail {
 
 // every off-diagonal entry (i, j) has its partner (j, i)?  Rows ascending inside a column (else: false at worst).
@@ -154,6 +164,10 @@ struct Shared {
   int max_team = 1;
   int team_region = kTeamRegion, team_frontier = kTeamFrontier;  // SPL_ND_TEAM_REGION / _FRONTIER (experiments)
   bool timing = false;
+  LevelService *service = nullptr;  // level structures of regions of service_min vertices and more (nullptr: none)
+  // The device serves one region at a time (siblings wait for each other) while the host dissects the regions of a
+  // depth side by side: the GPU pays where regions are few and large — the top of the tree, the serial part.
+  int service_min = 1000000;        // SPL_ND_GPU_MIN (0: never)
   int root_levels = 0;  // levels of the root region's final level structure (written by the depth-0 call only)
   std::atomic<int> stamp{0};
   Shared(int n_, const std::vector<int64_t> &xa, const std::vector<int> &ad, int leaf_)
@@ -165,6 +179,7 @@ struct Shared {
     if (const char *e = getenv("SPL_ND_TEAM")) max_team = std::max(1, std::min(atoi(e), 64));
     if (const char *e = getenv("SPL_ND_TEAM_REGION")) team_region = std::max(1024, atoi(e));
     if (const char *e = getenv("SPL_ND_TEAM_FRONTIER")) team_frontier = std::max(64, atoi(e));
+    if (const char *e = getenv("SPL_ND_GPU_MIN")) service_min = atoi(e);
     if (n >= team_region && max_team > 1) claim.assign((size_t)n, 0);
   }
 };
@@ -432,8 +447,26 @@ struct Worker {
     region_stamp = ++S.stamp;
     for (int i = lo; i < hi; ++i) S.mark[(size_t)S.verts[(size_t)i]] = region_stamp;
     lap("region stamp");
-    int reached;
-    if (hint >= 0 && size <= kHintBelow && S.mark[(size_t)hint] == region_stamp) {
+    int reached = -1;
+    bool from_service = false;
+    if (S.service && S.service_min > 0 && size >= S.service_min) {
+      try {
+        reached = S.service->levels(S.verts.data() + lo, size, queue, level_ptr);
+      } catch (...) {  // no memory on the device, or any other failure there: the host code below takes the region
+        reached = -1;
+      }
+      from_service = reached == size;
+      if (from_service) {
+        lap("level structure (GPU)");
+        // the separator is thinned below by looking at the marks and levels of its neighbours: give the level after
+        // the cut what a host traversal would have left there (the cut level is chosen further down, so this is
+        // done for the candidates' successors lazily: see `touches`)
+        bfs_stamp = ++S.stamp;
+      }
+    }
+    if (from_service) {
+      // nothing else to do here
+    } else if (hint >= 0 && size <= kHintBelow && S.mark[(size_t)hint] == region_stamp) {
       reached = bfs(hint, region_stamp);
     } else {
       reached = traverse(S.verts[(size_t)lo], region_stamp, size);
@@ -519,6 +552,11 @@ struct Worker {
       if (best >= 0) break;
     }
     const int t = best;
+    if (from_service)  // the host's marks and levels of level t + 1, as a host traversal would have left them
+      for (int64_t q = level_ptr[(size_t)t + 1]; q < level_ptr[(size_t)t + 2]; ++q) {
+        S.mark[(size_t)queue[(size_t)q]] = bfs_stamp;
+        S.level[(size_t)queue[(size_t)q]] = t + 1;
+      }
     // queue = [levels < t | level t | levels > t]; thin the separator: a vertex of level t without a
     // neighbour in level t+1 can join the first side
     std::vector<int> side1(queue.begin(), queue.begin() + level_ptr[(size_t)t]);
@@ -556,8 +594,10 @@ inline void layout_tree(Tree &T);
 // unexpanded != nullptr (mult > 1): also receives the tree of the small graph itself, laid out for fronts of its own
 // n unknowns (native complex fronts, multifrontal.hip: one dissection serves both)
 // pattern_symmetric: 1 / 0 if the caller has already run detail::structurally_symmetric, -1: not known
+// make_service: called with the adjacency (n, xadj, adj) once it is built; may return nullptr
+using ServiceFactory = std::unique_ptr<LevelService> (*)(int, const int64_t *, const int *);
 inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, int mult = 1, Tree *unexpanded = nullptr,
-                       int pattern_symmetric_hint = -1) {
+                       int pattern_symmetric_hint = -1, ServiceFactory make_service = nullptr) {
   T = Tree();
   T.n = n;
   const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // phase times on stderr (diagnostic)
@@ -605,6 +645,12 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
   }
   lap(pattern_symmetric ? "adjacency (symmetric pattern)" : "adjacency of A + A^T");
   detail::Shared shared(n, xadj, adj, leaf);
+  std::unique_ptr<LevelService> service;
+  if (make_service && shared.service_min > 0 && n >= shared.service_min) {
+    service = make_service(n, xadj.data(), adj.data());
+    shared.service = service.get();
+    lap(service ? "graph to the GPU" : "no GPU level service");
+  }
   std::vector<detail::Node> nodes;
   if (n > 0) {
     detail::Worker w(shared);

@@ -826,7 +826,7 @@ static int symbolic_common(int n, const int *Ap, const int *Ai, int mult, const 
     if (want_tree)
       tree_job = std::async(std::launch::async, [n, Ap, Ai, mult, small_tree, pattern_symmetric] {
         std::shared_ptr<mf::Tree> T = std::make_shared<mf::Tree>();
-        mf::build_tree(n, Ap, Ai, 256 / mult, *T, mult, small_tree.get(), pattern_symmetric);
+        mf::build_tree(n, Ap, Ai, 256 / mult, *T, mult, small_tree.get(), pattern_symmetric, &make_gpu_level_service);
         return T;
       });
     const bool timing = getenv("SPL_MF_TIMING") != nullptr;
