@@ -720,16 +720,19 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
     const int nthreads = (int)std::min<unsigned>(hw ? hw : 1, 32);
     for (int d = T.maxdepth; d >= 0; --d) {
       const std::vector<int> &L = T.by_depth[(size_t)d];
-      if (nthreads <= 1 || L.size() < 64) {
+      if (nthreads <= 1 || L.size() < 2) {
         for (int f : L) boundary_of(f);
         continue;
       }
+      // (the few fronts of the top levels are the largest: one each per thread; lower down in chunks)
+      const size_t chunk = L.size() < 64 ? 1 : 16;
+      const int team = (int)std::min<size_t>((size_t)nthreads, (L.size() + chunk - 1) / chunk);
       std::atomic<size_t> next_item{0};
       std::vector<std::thread> pool;
-      for (int w = 0; w < nthreads; ++w)
+      for (int w = 0; w < team; ++w)
         pool.emplace_back([&] {
-          for (size_t i = next_item.fetch_add(16); i < L.size(); i = next_item.fetch_add(16))
-            for (size_t k = i; k < std::min(i + 16, L.size()); ++k) boundary_of(L[k]);
+          for (size_t i = next_item.fetch_add(chunk); i < L.size(); i = next_item.fetch_add(chunk))
+            for (size_t k = i; k < std::min(i + chunk, L.size()); ++k) boundary_of(L[k]);
         });
       for (std::thread &th : pool) th.join();
     }

@@ -811,7 +811,6 @@ static int symbolic_common(int n, const int *Ap, const int *Ai, int mult, const 
     S->n = n * mult;
     S->nnz = Ep[S->n];
     S->Ap.assign(Ep, Ep + S->n + 1);
-    S->ai_hash = hash_indices(Ei, S->nnz);
     // The two orderings are independent host work: for anything that is not tiny the nested
     // dissection runs on its own thread(s) while this one does the band ordering.
     // Multifrontal or band?  The band factorisation costs about 2 n kl ku flops and n (kl+ku+1)
@@ -832,6 +831,12 @@ static int symbolic_common(int n, const int *Ap, const int *Ai, int mult, const 
     const bool timing = getenv("SPL_MF_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    try {
+      S->ai_hash = hash_indices(Ei, S->nnz);  // (beside the dissection)
+    } catch (...) {
+      if (tree_job.valid()) tree_job.wait();
+      throw;
+    }
     // the band ordering (reverse Cuthill-McKee) and its bandwidths
     auto band_ordering = [&] {
       std::vector<int> perm, inv((size_t)n, 0);
