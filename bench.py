@@ -61,8 +61,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--no-secondary", action="store_true", help="skip the banded / C4 / C5 block after the timed region")
-    ap.add_argument("--secondary", default="banded,c5:200,c4,c5:100",
-                    help="which secondary configurations to run, in this order (comma separated: banded, c4, c5:<m>); the 200^3 "
+    ap.add_argument("--secondary", default="banded,c5:200,c4,c5:100,zi:100",
+                    help="which secondary configurations to run, in this order (comma separated: banded, c4, c5:<m>, zi:<m>); the 200^3 "
                          "factorisation comes early: it asks the driver for 255 GB, and memory other configurations have just "
                          "released is still being wiped in the background (DESIGN.md, Device memory)")
     args = ap.parse_args()
@@ -455,6 +455,8 @@ def main():
                 elif item == "c4" or item.startswith("c4:"):  # c4:<scale> (tests): a smaller R-MAT matrix, same code
                     scale = int(item[3:]) if item.startswith("c4:") else 20
                     secondary["c4_spgemm_rmat%d" % scale] = sec.spgemm_c4(pkg, torch, scale=scale, cpu_rows=min(2048, 1 << scale))
+                elif item.startswith("zi:"):  # row f3: complex LU on native complex fronts
+                    secondary["f3_zi_lu_shifted_poisson3d_%s" % item[3:]] = sec.lu_zi(pkg, torch, int(item[3:]))
                 elif item.startswith("c5:"):
                     m = int(item[3:])
                     torch.cuda.empty_cache()

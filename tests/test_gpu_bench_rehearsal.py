@@ -135,14 +135,15 @@ def test_secondary_block_rides_on_the_headline_line(gpu):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "400000", "--steps", "3", "--warmup", "1",
-           "--cpu-reps", "1", "--secondary", "banded,c5:16,c4:12"]
+           "--cpu-reps", "1", "--secondary", "banded,c5:16,c4:12,zi:14"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["metric"] == "fp64 CSR SpMV effective GB/s" and out["n_gpus"] == 1 and out["parity"]["not_close_1e-10"] == 0
     assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["kind"] == "port"
     sec = out["secondary"]
-    assert set(sec) == {"c2_banded_spmv", "c5_lu_poisson3d_16", "c4_spgemm_rmat12"}
+    assert set(sec) == {"c2_banded_spmv", "c5_lu_poisson3d_16", "c4_spgemm_rmat12", "f3_zi_lu_shifted_poisson3d_14"}
+    assert sec["f3_zi_lu_shifted_poisson3d_14"]["parity"]["within_1e-10"] and sec["f3_zi_lu_shifted_poisson3d_14"]["unit"] == "s"
     assert sec["c2_banded_spmv"]["parity"]["bit_identical"] and sec["c2_banded_spmv"]["roofline"]["bound"] == "hbm"
     assert sec["c5_lu_poisson3d_16"]["parity"]["within_1e-10"] and sec["c5_lu_poisson3d_16"]["unit"] == "s"
     assert sec["c4_spgemm_rmat12"]["parity"]["structure_and_values_bit_identical"]
