@@ -948,7 +948,7 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
     if (!timing) return;
     (void)hipDeviceSynchronize();
     const auto now = clock_now();
-    fprintf(stderr, "[mf_factor] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_start).count());
+    fprintf(stderr, "[mf_factor] %-52s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_start).count());
     t_start = now;
   };
   std::unique_ptr<mf::Factors> Fp(new mf::Factors());
@@ -1305,9 +1305,15 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
         for (int i = 0; i < kStreams && i < turn; ++i) SPL_HIP(hipStreamSynchronize(side[i]));
       if (timing) {
         int big = 0;
-        for (int i = b0; i < b1; ++i) big = std::max(big, T.fs(T.by_depth[(size_t)d][(size_t)i]));
-        char what[64];
-        snprintf(what, sizeof what, "level %d: %d fronts, max %d", d, b1 - b0, big);
+        double fl = 0.0;
+        for (int i = b0; i < b1; ++i) {
+          const int f = T.by_depth[(size_t)d][(size_t)i];
+          big = std::max(big, T.fs(f));
+          const double p = T.np[(size_t)f], q = T.nb[(size_t)f];
+          fl += 2.0 / 3.0 * p * p * p + 2.0 * p * p * q + 2.0 * p * q * q;
+        }
+        char what[96];
+        snprintf(what, sizeof what, "level %d: %d fronts, max %d, %.3g LU flops", d, b1 - b0, big, fl * ZM * ZM);
         lap(what);
       }
     }
