@@ -137,8 +137,10 @@ int spl_umfpack_path(void *Numeric);
  * nullPtr).  out[0] path as above, out[1] n, out[2] kl and out[3] ku of the reordered matrix
  * (band paths), out[4] bytes of device memory the factors occupy, out[5] flops of the numeric
  * factorisation (band: 2 n kl ku; multifrontal: summed over the fronts), out[6] number of fronts
- * (0 on the band paths), out[7] 1 when the fronts are native complex ones (`zi` objects; out[5]
- * then counts 4 real flops per complex multiply-add pair), else 0.  Returns 0, or -1 if the object is invalid. */
+ * (0 on the band paths), out[7] flags: bit 0 the fronts are native complex ones (`zi` objects; out[5]
+ * then counts 4 real flops per complex multiply-add pair), bit 1 threshold pivoting inside the diagonal
+ * blocks of the fronts was on (matrices that are not diagonally dominant).  Returns 0, or -1 if the object
+ * is invalid. */
 int spl_umfpack_stats(void *Numeric, double out[8]);
 
 #ifdef __cplusplus

@@ -229,7 +229,9 @@ std::unique_ptr<mf::LevelService> make_gpu_level_service(int n, const int64_t *x
 size_t mf_device_bytes(const mf::Tree &T, int zm = 1);  // zm = 2: complex fronts (two planes)
 mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, const int *d_Ai, const double *d_Ax,
                        const int *d_Rp, const int *d_Rj, const double *d_Rx, const int *d_perm, const int *d_inv,
-                       hipStream_t s, bool symmetric = false, bool zfront = false);
+                       hipStream_t s, bool symmetric = false, bool zfront = false, bool pivot = false,
+                       const double *d_rscale = nullptr);  // pivot: threshold pivoting inside the diagonal blocks, on
+                                                           // candidates scaled by d_rscale (new ordering of `tree`)
 int mf_singular(const mf::Factors *F);
 void mf_solve(const mf::Factors *F, int sys, double *d_c, int k, size_t stride, hipStream_t s);
 void mf_free(mf::Factors *F);

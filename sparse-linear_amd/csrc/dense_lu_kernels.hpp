@@ -33,6 +33,16 @@ struct Band {
   // parts zoff doubles further, same leading dimension.  The *_z device functions below read both; every index
   // computation is the one of the real kernels.
   size_t zoff = 0;
+  // piv = 1 (multifrontal fronts of a matrix that is not diagonally dominant, round 3): threshold partial pivoting
+  // INSIDE every 64 x 64 diagonal block — the rows of a pivot block are fully summed, so any of them may serve as the
+  // pivot of a column of the block.  The interchange stays local: P_b A_bb = L_bb U_bb, and P_b is folded into the
+  // stored inverse (inv(L11) P_b), through which the panel solves and the triangular solves see the block; nothing
+  // outside diag_block_factor knows.  A pivot is taken out of its natural turn only when it is below 0.1 of the largest
+  // candidate (UMFPACK's default threshold), so well-behaved blocks give the factors they gave without it.
+  int piv = 0;
+  // ... candidates are compared AFTER scaling by rscale[row of the view] when given (1 / sum of the absolute values of
+  // that row of the matrix: UMFPACK's default row scaling) — magnitudes of rows with different scales say nothing
+  const double *rscale = nullptr;
   __device__ __forceinline__ bool in_band(int i, int j) const { return i - j <= kl && j - i <= ku; }
   __device__ __forceinline__ double &at(int i, int j) const {
     return AB[(size_t)(doff + i) + (size_t)j * (size_t)(ldab - 1)];
@@ -40,7 +50,9 @@ struct Band {
   __device__ __forceinline__ double get(int i, int j) const { return in_band(i, j) ? at(i, j) : 0.0; }
 };
 inline Band band_view(double *AB, int n, int kl, int ku, int ldab) { return Band{AB, n, kl, ku, ldab, ku}; }
-inline Band dense_view(double *F, int n, int ld, int sym = 0, size_t zoff = 0) { return Band{F, n, n, n, ld + 1, 0, sym, zoff}; }
+inline Band dense_view(double *F, int n, int ld, int sym = 0, size_t zoff = 0, int piv = 0, const double *rscale = nullptr) {
+  return Band{F, n, n, n, ld + 1, 0, sym, zoff, piv, rscale};
+}
 
 // ---- factorisation ----------------------------------------------------------------------------
 typedef double double4v __attribute__((ext_vector_type(4)));
@@ -65,15 +77,23 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // The two inverses are built the same way (right-looking substitution on an identity), U^-1 with
 // k descending and L^-1 with k ascending in the same loop.
 // Results: LU'd block to band storage and tile D, inverses (NB x NB column-major) to invL / invU.
-__device__ __forceinline__ void diag_block_factor(const Band &b, int j0, int jb, double (*D)[LDP],
-                                                  double (*lcol)[NB], int *__restrict__ singular,
-                                                  double *__restrict__ invL, double *__restrict__ invU) {
+constexpr double kPivotThreshold = 0.1;
+
+template <bool PIV>
+__device__ __forceinline__ void diag_block_factor_t(const Band &b, int j0, int jb, double (*D)[LDP],
+                                                    double (*lcol)[NB], int *__restrict__ singular,
+                                                    double *__restrict__ invL, double *__restrict__ invU) {
   const int tid = threadIdx.x;
   const int tr = tid & 63, tc = tid >> 6;
   constexpr int NS = NB / 4;  // register slots per thread
   double a[NS];
 #pragma unroll
   for (int u = 0; u < NS; ++u) a[u] = D[tr][4 * u + tc];
+  // PIV: implicit row interchanges.  `done`: this row has been a pivot; `mypos`: in which step.  The pivot row of step
+  // k travels to the other wavefronts through the padding word of row k of tile D.
+  bool done = false;
+  int mypos = tr;
+  const double rs = (PIV && b.rscale && tr < jb) ? b.rscale[j0 + tr] : 1.0;
   // The pivot loops stay rolled (straight-line code of this size would run at instruction-fetch
   // speed).  Register slots must be indexed statically, so the slots are shifted down by one
   // after every group of 4 pivots: in group g slot j holds column 4 (g + j) + wave, the pivot
@@ -84,22 +104,46 @@ __device__ __forceinline__ void diag_block_factor(const Band &b, int j0, int jb,
     for (int kw = 0; kw < 4; ++kw) {
       const int k = 4 * g + kw;
       if (tc == kw) {
-        const double piv = readlane_f64(a[0], k);
+        int prow = k;
+        if (PIV) {
+          // largest candidate among the rows that have not been pivots yet (ties: the smallest row), and the row whose
+          // natural turn it is: row k, or the first unused one if row k went earlier
+          double best = done ? -1.0 : fabs(a[0]) * rs;
+          int brow = tr;
+#pragma unroll
+          for (int off = 32; off >= 1; off >>= 1) {
+            const double ob = __shfl_xor(best, off, 64);
+            const int orow = __shfl_xor(brow, off, 64);
+            if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
+          }
+          const unsigned long long unused = __ballot(!done);
+          const int nat = ((unused >> k) & 1ull) ? k : (int)__ffsll((long long)unused) - 1;
+          const double anat = fabs(readlane_f64(a[0], nat)) * readlane_f64(rs, nat);
+          prow = (anat >= kPivotThreshold * best) ? nat : brow;
+          prow = __builtin_amdgcn_readfirstlane(prow);
+        }
+        const double piv = readlane_f64(a[0], prow);
         if (piv == 0.0) {
           if (tr == 0) atomicOr(singular, 1);
-        } else if (tr > k) {
+        } else if (PIV ? (!done && tr != prow) : (tr > k)) {
           a[0] = a[0] / piv;
         }
         lcol[k & 1][tr] = a[0];
+        if (PIV && tr == 0) reinterpret_cast<int &>(D[k][NB]) = prow;
       }
       __syncthreads();
-      const double l = tr > k ? lcol[k & 1][tr] : 0.0;
-      if (tc > kw) a[0] -= l * readlane_f64(a[0], k);
+      int prow = k;
+      if (PIV) {
+        prow = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int &>(D[k][NB]));
+        if (tr == prow) { done = true; mypos = k; }
+      }
+      const double l = (PIV ? !done : (tr > k)) ? lcol[k & 1][tr] : 0.0;
+      if (tc > kw) a[0] -= l * readlane_f64(a[0], prow);
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         if (g + 4 * qd < NS) {  // some slot of this quarter still holds a live column
 #pragma unroll
-          for (int j = (qd == 0 ? 1 : 4 * qd); j < 4 * qd + 4; ++j) a[j] -= l * readlane_f64(a[j], k);
+          for (int j = (qd == 0 ? 1 : 4 * qd); j < 4 * qd + 4; ++j) a[j] -= l * readlane_f64(a[j], prow);
         }
       }
     }
@@ -109,6 +153,16 @@ __device__ __forceinline__ void diag_block_factor(const Band &b, int j0, int jb,
     a[NS - 1] = 0.0;
   }
   __syncthreads();
+  if (PIV) {
+    // rows into pivot order: D'[step in which the row was the pivot] = D[row]; the padding words keep the pivot rows
+    double v[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) v[u] = D[tr][4 * u + tc];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NS; ++u) D[mypos][4 * u + tc] = v[u];
+    __syncthreads();
+  }
   for (int c = tc; c < jb; c += 4)
     if (tr < jb && b.in_band(j0 + tr, j0 + c)) b.at(j0 + tr, j0 + c) = D[tr][c];
   // reciprocals of the pivots, once
@@ -154,8 +208,16 @@ __device__ __forceinline__ void diag_block_factor(const Band &b, int j0, int jb,
   for (int u = 0; u < NS; ++u) {
     const int c = 4 * u + tc;
     invU[tr + c * NB] = x[u];
-    invL[tr + c * NB] = y[u];
+    // PIV: inv(L11) P_b — column c of inv(L11) multiplies the row that was the pivot of step c
+    invL[tr + (PIV ? reinterpret_cast<const int &>(D[c][NB]) : c) * NB] = y[u];
   }
+}
+
+__device__ __forceinline__ void diag_block_factor(const Band &b, int j0, int jb, double (*D)[LDP],
+                                                  double (*lcol)[NB], int *__restrict__ singular,
+                                                  double *__restrict__ invL, double *__restrict__ invU) {
+  if (b.piv) diag_block_factor_t<true>(b, j0, jb, D, lcol, singular, invL, invU);
+  else diag_block_factor_t<false>(b, j0, jb, D, lcol, singular, invL, invU);
 }
 
 __global__ __launch_bounds__(256) void diag_lu_kernel(Band b, int j0, int jb, int *__restrict__ singular,
@@ -520,12 +582,16 @@ __device__ __forceinline__ void crecip(double pr, double pi, double &qr, double 
 
 // diag_block_factor in complex arithmetic: same register layout (lane = row, wave w owns the columns c = w mod 4),
 // same pivot loop, two registers per entry
-__device__ __forceinline__ void diag_block_factor_z(const Band &b, int j0, int jb, double (*Dr)[LDP], double (*Di)[LDP],
-                                                    double (*lcr)[NB], double (*lci)[NB], int *__restrict__ singular,
-                                                    double *__restrict__ invL, double *__restrict__ invU) {
+template <bool PIV>
+__device__ __forceinline__ void diag_block_factor_zt(const Band &b, int j0, int jb, double (*Dr)[LDP], double (*Di)[LDP],
+                                                     double (*lcr)[NB], double (*lci)[NB], int *__restrict__ singular,
+                                                     double *__restrict__ invL, double *__restrict__ invU) {
   const int tid = threadIdx.x;
   const int tr = tid & 63, tc = tid >> 6;
   constexpr int NS = NB / 4;
+  bool done = false;  // PIV: implicit row interchanges, as in diag_block_factor_t (moduli instead of absolute values)
+  int mypos = tr;
+  const double rs = (PIV && b.rscale && tr < jb) ? b.rscale[j0 + tr] : 1.0;
   {
     double ar[NS], ai[NS];
 #pragma unroll
@@ -539,10 +605,26 @@ __device__ __forceinline__ void diag_block_factor_z(const Band &b, int j0, int j
       for (int kw = 0; kw < 4; ++kw) {
         const int k = 4 * g + kw;
         if (tc == kw) {
-          const double pr = readlane_f64(ar[0], k), pi = readlane_f64(ai[0], k);
+          int prow = k;
+          if (PIV) {
+            double best = done ? -1.0 : (ar[0] * ar[0] + ai[0] * ai[0]) * rs * rs;
+            int brow = tr;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+              const double ob = __shfl_xor(best, off, 64);
+              const int orow = __shfl_xor(brow, off, 64);
+              if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
+            }
+            const unsigned long long unused = __ballot(!done);
+            const int nat = ((unused >> k) & 1ull) ? k : (int)__ffsll((long long)unused) - 1;
+            const double nr = readlane_f64(ar[0], nat), ni = readlane_f64(ai[0], nat), ns = readlane_f64(rs, nat);
+            prow = ((nr * nr + ni * ni) * ns * ns >= kPivotThreshold * kPivotThreshold * best) ? nat : brow;
+            prow = __builtin_amdgcn_readfirstlane(prow);
+          }
+          const double pr = readlane_f64(ar[0], prow), pi = readlane_f64(ai[0], prow);
           if (pr == 0.0 && pi == 0.0) {
             if (tr == 0) atomicOr(singular, 1);
-          } else if (tr > k) {
+          } else if (PIV ? (!done && tr != prow) : (tr > k)) {
             double qr, qi;
             crecip(pr, pi, qr, qi);
             const double t = ar[0] * qr - ai[0] * qi;
@@ -551,11 +633,18 @@ __device__ __forceinline__ void diag_block_factor_z(const Band &b, int j0, int j
           }
           lcr[k & 1][tr] = ar[0];
           lci[k & 1][tr] = ai[0];
+          if (PIV && tr == 0) reinterpret_cast<int &>(Dr[k][NB]) = prow;
         }
         __syncthreads();
-        const double lr = tr > k ? lcr[k & 1][tr] : 0.0, li = tr > k ? lci[k & 1][tr] : 0.0;
+        int prow = k;
+        if (PIV) {
+          prow = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int &>(Dr[k][NB]));
+          if (tr == prow) { done = true; mypos = k; }
+        }
+        const bool below = PIV ? !done : (tr > k);
+        const double lr = below ? lcr[k & 1][tr] : 0.0, li = below ? lci[k & 1][tr] : 0.0;
         if (tc > kw) {
-          const double ur = readlane_f64(ar[0], k), ui = readlane_f64(ai[0], k);
+          const double ur = readlane_f64(ar[0], prow), ui = readlane_f64(ai[0], prow);
           ar[0] -= lr * ur - li * ui;
           ai[0] -= lr * ui + li * ur;
         }
@@ -564,7 +653,7 @@ __device__ __forceinline__ void diag_block_factor_z(const Band &b, int j0, int j
           if (g + 4 * qd < NS) {
 #pragma unroll
             for (int j = (qd == 0 ? 1 : 4 * qd); j < 4 * qd + 4; ++j) {
-              const double ur = readlane_f64(ar[j], k), ui = readlane_f64(ai[j], k);
+              const double ur = readlane_f64(ar[j], prow), ui = readlane_f64(ai[j], prow);
               ar[j] -= lr * ur - li * ui;
               ai[j] -= lr * ui + li * ur;
             }
@@ -583,6 +672,21 @@ __device__ __forceinline__ void diag_block_factor_z(const Band &b, int j0, int j
     }
   }
   __syncthreads();
+  if (PIV) {  // rows into pivot order
+    double vr[NS], vi[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      vr[u] = Dr[tr][4 * u + tc];
+      vi[u] = Di[tr][4 * u + tc];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      Dr[mypos][4 * u + tc] = vr[u];
+      Di[mypos][4 * u + tc] = vi[u];
+    }
+    __syncthreads();
+  }
   for (int c = tc; c < jb; c += 4)
     if (tr < jb) {
       double *dst = &b.at(j0 + tr, j0 + c);
@@ -644,9 +748,17 @@ __device__ __forceinline__ void diag_block_factor_z(const Band &b, int j0, int j
     const int c = 4 * u + tc;
     invU[tr + c * NB] = xr[u];
     invU[NB * NB + tr + c * NB] = xi[u];
-    invL[tr + c * NB] = yr[u];
-    invL[NB * NB + tr + c * NB] = yi[u];
+    const int cl = PIV ? reinterpret_cast<const int &>(Dr[c][NB]) : c;  // inv(L11) P_b
+    invL[tr + cl * NB] = yr[u];
+    invL[NB * NB + tr + cl * NB] = yi[u];
   }
+}
+
+__device__ __forceinline__ void diag_block_factor_z(const Band &b, int j0, int jb, double (*Dr)[LDP], double (*Di)[LDP],
+                                                    double (*lcr)[NB], double (*lci)[NB], int *__restrict__ singular,
+                                                    double *__restrict__ invL, double *__restrict__ invU) {
+  if (b.piv) diag_block_factor_zt<true>(b, j0, jb, Dr, Di, lcr, lci, singular, invL, invU);
+  else diag_block_factor_zt<false>(b, j0, jb, Dr, Di, lcr, lci, singular, invL, invU);
 }
 
 // the diagonal block (identity-padded beyond jb) into the two LDS tiles

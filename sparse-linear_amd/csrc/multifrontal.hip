@@ -55,6 +55,8 @@ struct TreeView {  // raw pointers for kernels
   // Schur complement at cut + 2 cboff[f] (nb nb), its inverse blocks at invs + 2 ioff[f] (kInvBlockZ per block).
   // Indices, leading dimensions and the tree are those of a real matrix with the same pattern.  zm = 1: real.
   int zm;
+  int piv;  // 1: threshold pivoting inside the diagonal blocks (Band::piv)
+  const double *rscale;  // ... with these row scales (per unknown of the tree, new ordering; nullptr: none)
   __device__ __forceinline__ double *front(int f) const { return region[depth[f] & 1] + (int64_t)zm * foff[f]; }
   __device__ __forceinline__ int64_t fplane(int f) const {  // doubles of one plane of the whole front (make_plan)
     const int64_t fs = np[f] + nb[f];
@@ -263,10 +265,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (np == 0) return;
   const int fs = np + t.nb[f];
   if (Z) {
-    const Band b{t.front(f), fs, fs, fs, t.ld[f] + 1, 0, t.sym, (size_t)t.fplane(f)};
+    const Band b{t.front(f), fs, fs, fs, t.ld[f] + 1, 0, t.sym, (size_t)t.fplane(f), t.piv, t.rscale ? t.rscale + t.p0[f] : nullptr};
     front_factor_by_workgroup_z(b, np, invs + 2 * t.ioff[f], singular, dsm);
   } else {
-    const Band b{t.front(f), fs, fs, fs, t.ld[f] + 1, 0, t.sym};
+    const Band b{t.front(f), fs, fs, fs, t.ld[f] + 1, 0, t.sym, 0, t.piv, t.rscale ? t.rscale + t.p0[f] : nullptr};
     front_factor_by_workgroup(b, np, invs + t.ioff[f], singular, dsm);
   }
 }
@@ -280,7 +282,8 @@ constexpr size_t kFrontLdsZ = kDiagLdsZ > kTrsmLdsZ ? kDiagLdsZ : kTrsmLdsZ;
 // K = 64 update whose tile (0,0) factors the next diagonal block on the way (the look-ahead).
 __device__ __forceinline__ Band mid_front(const TreeView &t, int f) {
   const int fs = t.np[f] + t.nb[f];
-  return Band{t.front(f), fs, fs, fs, t.ld[f] + 1, 0, t.sym, t.zm == 2 ? (size_t)t.fplane(f) : 0};
+  return Band{t.front(f), fs, fs, fs, t.ld[f] + 1, 0, t.sym, t.zm == 2 ? (size_t)t.fplane(f) : 0, t.piv,
+              t.rscale ? t.rscale + t.p0[f] : nullptr};
 }
 __device__ __forceinline__ double *mid_slot(const TreeView &t, double *invs, int f, int j0) {
   return invs + (int64_t)t.zm * t.ioff[f] + (int64_t)(j0 / NB) * (t.zm == 2 ? kInvBlockZ : 2 * NB * NB);
@@ -938,8 +941,9 @@ namespace {
 template <bool Z>
 mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, const int *d_Ai, const double *d_Ax,
                          const int *d_Rp, const int *d_Rj, const double *d_Rx, const int *d_perm, const int *d_inv,
-                         hipStream_t s, bool symmetric) {
+                         hipStream_t s, bool symmetric, bool pivot, const double *d_rscale) {
   constexpr int ZM = Z ? 2 : 1;
+  if (symmetric) pivot = false;  // L D L^T needs symmetric interchanges
   const mf::Tree &T = *tree;
   const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // phase times on stderr (diagnostic)
   auto clock_now = [] { return std::chrono::steady_clock::now(); };
@@ -1005,7 +1009,7 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
       const TreeView v{N.p0.get(),   N.np.get(),   N.nb.get(),   N.ld.get(),   N.parent.get(), N.front_of.get(),
                        N.bidx.get(), N.rel.get(),  N.depth.get(), N.ldp.get(), N.ldu.get(),    N.bptr.get(),
                        nullptr,      N.ioff.get(), N.woff.get(), N.roff.get(), N.poff.get(),   N.uoff.get(),
-                       {nullptr, nullptr}, nullptr, nullptr, nullptr, 0, 1};
+                       {nullptr, nullptr}, nullptr, nullptr, nullptr, 0, 1, 0, nullptr};
       if (nf > 0) hipLaunchKernelGGL(rel_kernel, dim3((unsigned)nf), dim3(256), 0, s, nf, v, N.rel.get());
       SPL_HIP(hipStreamSynchronize(s));  // the host vectors of the tree may go away with it
       SPL_HIP(hipGetLastError());
@@ -1026,7 +1030,8 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
   F.view = TreeView{D.p0.get(),    D.np.get(),   D.nb.get(),   D.ld.get(),   D.parent.get(), D.front_of.get(),
                     D.bidx.get(),  D.rel.get(),  D.depth.get(), D.ldp.get(), D.ldu.get(),    D.bptr.get(),
                     F.d_foff.get(), D.ioff.get(), D.woff.get(), D.roff.get(), D.poff.get(),  D.uoff.get(),
-                    {region0.get(), region1.get()}, F.arena.get(), F.d_cboff.get(), cutbuf.get(), symmetric ? 1 : 0, ZM};
+                    {region0.get(), region1.get()}, F.arena.get(), F.d_cboff.get(), cutbuf.get(), symmetric ? 1 : 0, ZM,
+                    pivot ? 1 : 0, pivot ? d_rscale : nullptr};
   F.level_lists.resize((size_t)nd);
   F.small_lists.resize((size_t)nd);
   F.small_counts.assign((size_t)nd, 0);
@@ -1296,7 +1301,8 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
         if (T.np[(size_t)f] == 0 || T.fs(f) <= mid_limit) continue;
         const size_t plane = Z ? (size_t)(((int64_t)T.ld[(size_t)f] * std::max(T.fs(f), 1) + 15) / 16 * 16) : 0;
         const Band b = dense_view(region_of(d) + (size_t)ZM * (size_t)plan.foff[(size_t)f], T.fs(f), T.ld[(size_t)f],
-                                  symmetric ? 1 : 0, plane);
+                                  symmetric ? 1 : 0, plane, pivot ? 1 : 0,
+                                  pivot && d_rscale ? d_rscale + T.p0[(size_t)f] : nullptr);
         const int lane = turn++ % kStreams;
         factor_loop<Z>(b, T.np[(size_t)f], F.invs.get() + (size_t)ZM * (size_t)T.ioff[(size_t)f], singular.get(), side[lane],
                        side[kStreams + lane]);
@@ -1348,9 +1354,9 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
 // (half the unknowns): fronts, panels and inverses are complex, in two planes (TreeView::zm)
 mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, const int *d_Ai, const double *d_Ax,
                        const int *d_Rp, const int *d_Rj, const double *d_Rx, const int *d_perm, const int *d_inv,
-                       hipStream_t s, bool symmetric, bool zfront) {
-  return zfront ? mf_factor_t<true>(tree, d_Ap, d_Ai, d_Ax, d_Rp, d_Rj, d_Rx, d_perm, d_inv, s, symmetric)
-                : mf_factor_t<false>(tree, d_Ap, d_Ai, d_Ax, d_Rp, d_Rj, d_Rx, d_perm, d_inv, s, symmetric);
+                       hipStream_t s, bool symmetric, bool zfront, bool pivot, const double *d_rscale) {
+  return zfront ? mf_factor_t<true>(tree, d_Ap, d_Ai, d_Ax, d_Rp, d_Rj, d_Rx, d_perm, d_inv, s, symmetric, pivot, d_rscale)
+                : mf_factor_t<false>(tree, d_Ap, d_Ai, d_Ax, d_Rp, d_Rj, d_Rx, d_perm, d_inv, s, symmetric, pivot, d_rscale);
 }
 
 // NR columns (c + r * stride) through the tree: up with L (or U^T), down with U (or L^T).  Per level:

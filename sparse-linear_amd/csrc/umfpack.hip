@@ -73,6 +73,13 @@ struct Numeric {
   // flops and bytes.  zsym: the complex matrix is symmetric (A == A^T): L D L^T.
   std::shared_ptr<const mf::Tree> ztree;
   int zfront = 0, zsym = 0;
+  // Threshold pivoting inside the diagonal blocks of the fronts (Band::piv): on for every matrix that is not
+  // diagonally dominant by columns — its factors without interchanges are a speculation, and the rows of a pivot block
+  // are free to change places.  A symmetric matrix is first tried as L D L^T (no interchanges: half the flops); if the
+  // check of a solve rejects those factors, the same tree is factored once more as LU with block pivoting
+  // (block_pivot_retry) before static pivoting takes over.  SPL_LU_BLOCK_PIVOT=0: never.
+  int dominant = 0, mf_piv = 0, block_pivot_retry = 0;
+  DBuf<double> rscale;  // row scales of the block pivoting (new ordering of the tree in use)
   // set when a refactorisation failed after the previous factors were released: the object holds no
   // usable factors any more and every later solve returns an error instead of launching kernels
   std::atomic<int> broken{0};
@@ -571,6 +578,19 @@ static bool matrix_is_symmetric(const Numeric *N, hipStream_t s) {
   return h == 0;
 }
 
+// rs[g] = 1 / sum_j |A(perm[step g], j)| (1 if the row is empty): the row scales of the block pivoting, in the new
+// ordering; step = 2 for the native complex tree on an embedding (row 2g of E stands for complex row g)
+__global__ __launch_bounds__(256) void row_scale_kernel(int64_t m, int step, const int *__restrict__ perm,
+                                                        const int64_t *__restrict__ rowptr, const double *__restrict__ val,
+                                                        double *__restrict__ rs) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= m) return;
+  const int i = perm[step * g] ;
+  double sum = 0.0;
+  for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p) sum += fabs(val[p]);
+  rs[g] = sum > 0.0 && sum < 1e300 ? 1.0 / sum : 1.0;
+}
+
 // resident bytes of the tree factors held (or about to be built)
 static size_t tree_factor_bytes(const Numeric *N) {
   if (N->zfront && N->ztree) return mf_device_bytes(*N->ztree, 2);
@@ -587,20 +607,34 @@ void factor_multifrontal(Numeric *N, hipStream_t s) {
   if (tree_factor_bytes(N) > free_b - free_b / 8) throw DeviceError{SPL_ERROR_out_of_memory};
   N->nopiv = 1;
   if (!N->A->rowptr.get()) throw DeviceError{SPL_ERROR_index_overflow};  // int32 row pointers at this seam
+  const char *bp = getenv("SPL_LU_BLOCK_PIVOT");
+  const bool pivot = !N->dominant && !(bp && bp[0] == '0');
+  if (pivot && N->A->rowptr64.get()) {
+    const int step = N->zfront ? 2 : 1;
+    const int64_t m = (int64_t)N->n / step;
+    if ((int64_t)N->rscale.n != m) N->rscale.alloc((size_t)m);
+    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, m, step, N->perm.get(),
+                       N->A->rowptr64.get(), N->A->val.get(), N->rscale.get());
+  }
+  const double *rscale = pivot && N->rscale.get() && N->A->rowptr64.get() ? N->rscale.get() : nullptr;
   if (N->zfront) {
     // the embedding of a complex matrix: complex fronts on the tree of the complex pattern, assembled from E's own
     // arrays (column 2j / row 2j of E hold column / row j of the complex matrix); perm / inv are the expanded ordering
-    N->mf_sym = N->zsym;
+    N->mf_sym = N->zsym && !N->block_pivot_retry;
+    N->mf_piv = pivot && !N->mf_sym;
     N->mfact = mf_factor(N->ztree, N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), N->A->rowptr.get(),
-                         N->A->colidx.get(), N->A->val.get(), N->perm.get(), N->inv.get(), s, N->mf_sym != 0, true);
+                         N->A->colidx.get(), N->A->val.get(), N->perm.get(), N->inv.get(), s, N->mf_sym != 0, true,
+                         N->mf_piv != 0, rscale);
     N->singular = mf_singular(N->mfact);
     return;
   }
   // a symmetric matrix (exactly: A == A^T) is factored as L D L^T on the same fronts: the trailing updates only
   // compute the tiles on and below the diagonal (Band::sym, csrc/dense_lu_kernels.hpp); SPL_LU_SYMMETRIC=0: plain LU
-  N->mf_sym = matrix_is_symmetric(N, s) ? 1 : 0;
+  N->mf_sym = !N->block_pivot_retry && matrix_is_symmetric(N, s) ? 1 : 0;
+  N->mf_piv = pivot && !N->mf_sym;
   N->mfact = mf_factor(N->tree, N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), N->A->rowptr.get(),
-                       N->A->colidx.get(), N->A->val.get(), N->perm.get(), N->inv.get(), s, N->mf_sym != 0, false);
+                       N->A->colidx.get(), N->A->val.get(), N->perm.get(), N->inv.get(), s, N->mf_sym != 0, false,
+                       N->mf_piv != 0, rscale);
   N->singular = mf_singular(N->mfact);
 }
 
@@ -1056,6 +1090,7 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
     bool dominant = false;
     if (!force_pivot)
       dominant = band_is_column_dominant(n, N->At->rowptr.get(), N->At->colidx.get(), N->At->val.get(), s);
+    N->dominant = dominant ? 1 : 0;
     if (!force_pivot && (dominant || !no_speculation)) {
       bool fits = true;
       try {
@@ -1298,6 +1333,21 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B,
       if (turn.owns_lock() && N->speculative && !(worst <= 1e-13)) {
         // first the static-pivoting stage (stays on the tree, still checked by this very loop), then, if that
         // fails too, the band factorisation with partial pivoting
+        // a symmetric matrix whose L D L^T speculation failed: the same tree once more as LU with threshold pivoting
+        // inside the diagonal blocks (no host work), then the static-pivoting stage
+        if (N->mfact && N->mf_sym && !N->mf_piv && !N->block_pivot_retry && N->sp_stage == 0 && N->tree) {
+          const char *bp = getenv("SPL_LU_BLOCK_PIVOT");
+          if (!(bp && bp[0] == '0')) {
+            N->block_pivot_retry = 1;
+            try {
+              factor_multifrontal(N, s);
+            } catch (const DeviceError &) {
+              N->broken = 1;
+              throw;
+            }
+            if (!N->singular) goto again;
+          }
+        }
         if (factor_static_pivot_of_copy(N, s)) goto again;
         if (N->sp_stage == 1 && !polished) {
           // the factors held ARE those of static pivoting and refinement has stalled: a Krylov polish preconditioned
@@ -1435,8 +1485,9 @@ int spl_umfpack_stats(void *NumericIn, double out[8]) {
     out[4] = (double)mf_device_bytes(*N->ztree, 2);
     out[5] = 4.0 * (N->mf_sym ? 0.5 * N->ztree->flops : N->ztree->flops);  // a complex multiply-add is four real ones
     out[6] = (double)N->ztree->nfronts;
-    out[7] = 1.0;  // native complex fronts
+    out[7] = 1.0 + (N->mf_piv ? 2.0 : 0.0);  // bit 0: native complex fronts; bit 1: threshold pivoting inside the diagonal blocks
   } else if (N->mfact) {
+    out[7] = N->mf_piv ? 2.0 : 0.0;
     out[4] = (double)mf_device_bytes(*N->tree, 1);
     out[5] = N->mf_sym ? 0.5 * N->tree->flops : N->tree->flops;  // L D L^T on the same fronts: about half the flops of LU
     out[6] = (double)N->tree->nfronts;

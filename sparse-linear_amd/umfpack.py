@@ -117,8 +117,12 @@ class Factors(_Handle):
         buf = (C.c_double * 8)()
         if _declare().spl_umfpack_stats(self.value, buf) != 0:
             raise UmfpackError("spl_umfpack_stats: invalid Numeric object")
-        keys = ("path", "n", "kl", "ku", "device_bytes", "flops", "fronts", "complex_fronts")
-        return dict(zip(keys, [float(v) if k in ("device_bytes", "flops") else int(v) for k, v in zip(keys, buf)]))
+        keys = ("path", "n", "kl", "ku", "device_bytes", "flops", "fronts", "flags")
+        st = dict(zip(keys, [float(v) if k in ("device_bytes", "flops") else int(v) for k, v in zip(keys, buf)]))
+        flags = st.pop("flags")
+        st["complex_fronts"] = flags & 1          # native complex fronts (zi objects)
+        st["block_pivoting"] = (flags >> 1) & 1   # threshold pivoting inside the diagonal blocks of the fronts
+        return st
 
 
 def analyze(mat):

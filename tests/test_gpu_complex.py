@@ -505,3 +505,34 @@ def test_native_complex_edge_shapes(gpu, pkg, O):
     assert (C0.nrows, C0.ncols, C0.pointers.tolist()) == (3, 0, [0])
     y = pkg.mulV(E, np.ones(4, dtype=np.complex128))
     assert y.shape == (3,) and not np.any(y)
+
+
+def test_native_complex_fronts_block_pivoting(gpu, pkg, monkeypatch):
+    """threshold pivoting inside the diagonal blocks on native complex fronts: 2 x 2 blocks [[1e-14, 3i], [3, 1e-14 i]]
+    with weak complex coupling (no usable diagonal: without interchanges the factors are useless) — the speculation
+    holds with block pivoting, both systems"""
+    import scipy.sparse as sp
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    monkeypatch.setenv("SPL_ZI_NATIVE", "1")
+    rng = np.random.default_rng(12)
+    m = 40
+    n = m * m
+    lo = np.zeros(n - 1, dtype=np.complex128)
+    up = np.zeros(n - 1, dtype=np.complex128)
+    lo[0::2] = 3.0
+    up[0::2] = 3.0j
+    d = np.where(np.arange(n) % 2 == 0, 1e-14, 1e-14j)
+    far = rng.uniform(-0.1, 0.1, n - m) + 1j * rng.uniform(-0.1, 0.1, n - m)
+    B = sp.diags([lo, d, up, far], (-1, 0, 1, m), format="csc")
+    B.sort_indices()
+    M = pkg.Matrix(n, n, B.indptr, B.indices, B.data)
+    U = pkg.umfpack
+    f = U.factor(M, U.analyze(M))
+    st = f.stats
+    assert st["complex_fronts"] == 1 and st["block_pivoting"] == 1 and st["path"] == 4
+    xs = rng.normal(size=n) + 1j * rng.normal(size=n)
+    for mode, op in ((U.UmfpackNormal, B), (U.UmfpackTrans, sp.csc_matrix(B.conj().T))):
+        b = np.asarray(op @ xs).ravel()
+        x = U.linearSolve_(f, mode, M, b)
+        assert _bwd(op, x, b) <= 1e-13
+    assert f.stats["complex_fronts"] == 1 and f.path == 4  # no fallback was needed

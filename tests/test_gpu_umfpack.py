@@ -319,8 +319,18 @@ def test_multifrontal_unsymmetric_values_and_fallback(gpu, pkg, O, monkeypatch):
     B = sp.diags([off, np.full(n, 1e-14), off, rng.uniform(-0.1, 0.1, n - m)], (-1, 0, 1, m), format="csc")
     B.sort_indices()
     M = pkg.Matrix(n, n, B.indptr, B.indices, B.data)
+    # round 3: threshold pivoting inside the diagonal blocks of the fronts takes the 3s by itself — the speculation holds
     fact = U.factor(M, U.analyze(M))
-    assert fact.path == 4
+    assert fact.path == 4 and fact.stats["block_pivoting"] == 1
+    for mode, op in ((U.UmfpackNormal, B), (U.UmfpackTrans, B.T.tocsc())):
+        x = U.linearSolve_(fact, mode, M, op @ xs)
+        assert fact.path == 4 and np.max(np.abs(x - xs)) / np.max(np.abs(xs)) < 1e-10
+    many = U.linearSolveMany_(fact, U.UmfpackNormal, M, [B @ xs, 2.0 * (B @ xs)])
+    assert np.max(np.abs(many[1] - 2.0 * xs)) / np.max(np.abs(xs)) < 1e-10
+    # without it (SPL_LU_BLOCK_PIVOT=0), the stages of round 2:
+    monkeypatch.setenv("SPL_LU_BLOCK_PIVOT", "0")
+    fact = U.factor(M, U.analyze(M))
+    assert fact.path == 4 and fact.stats["block_pivoting"] == 0
     x = U.linearSolve_(fact, U.UmfpackNormal, M, B @ xs)
     assert fact.path == 5  # static pivoting: the transversal takes the 3s, the factors stay on the tree
     assert np.max(np.abs(x - xs)) / np.max(np.abs(xs)) < 1e-10
@@ -746,3 +756,54 @@ def test_level_structures_on_the_gpu(gpu, pkg, O, kind, monkeypatch):
     assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
     assert all(np.array_equal(p, q) for p, q in zip(results[0][2], results[1][2]))
     assert results[0][0] <= 1.25 * host.stats["flops"]
+
+
+# ---- threshold pivoting inside the diagonal blocks of the fronts (csrc/dense_lu_kernels.hpp, Band::piv) ------------
+def test_block_pivoting_symmetric_retry_and_row_scales(gpu, pkg, monkeypatch):
+    """(1) a SYMMETRIC matrix of 2 x 2 blocks [[1e-14, 3], [3, 1e-14]] with weak coupling: its L D L^T speculation (no
+    interchanges) is rejected by the first solve, the same tree is factored again as LU with block pivoting (all the
+    flops of the tree, block_pivoting = 1) and holds — no static pivoting, no host matching.  (2) an unsymmetric mesh
+    matrix whose rows and columns are scaled by 10^U(-6, 6): candidates are compared after UMFPACK's row scaling, the
+    speculation holds at once; both systems to a backward error at rounding level."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    U = pkg.umfpack
+    rng = np.random.default_rng(77)
+    m = 48
+    n = m * m
+    off = np.zeros(n - 1)
+    off[0::2] = 3.0
+    far = rng.uniform(-0.1, 0.1, n - m)
+    B = sp.diags([far, off, np.full(n, 1e-14), off, far], (-m, -1, 0, 1, m), format="csc")
+    B.sort_indices()
+    assert abs(B - B.T).max() == 0
+    M = pkg.Matrix(n, n, B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data)
+    fact = U.factor(M, U.analyze(M))
+    full = None
+    st = fact.stats
+    assert st["path"] == 4 and st["block_pivoting"] == 0  # symmetric: L D L^T first
+    half = st["flops"]
+    xs = rng.uniform(0.5, 1.5, n)
+    for mode, op in ((U.UmfpackNormal, B), (U.UmfpackTrans, B.T.tocsc())):
+        b = np.asarray(op @ xs).ravel()
+        x = U.linearSolve_(fact, mode, M, b)
+        assert _backward_error(op, x, b) <= 1e-13
+    st = fact.stats
+    assert st["path"] == 4 and st["block_pivoting"] == 1 and st["flops"] == 2.0 * half
+    # (2)
+    T = sp.diags([np.ones(20), np.ones(21), np.ones(20)], (-1, 0, 1))
+    I = sp.identity(21)
+    P = (sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(T, I), I)).tocoo()
+    n2 = 21 ** 3
+    v = rng.uniform(-1.0, 1.0, P.nnz)
+    dr, dc = 10.0 ** rng.uniform(-6, 6, n2), 10.0 ** rng.uniform(-6, 6, n2)
+    S = sp.csc_matrix((v * dr[P.row] * dc[P.col], (P.row, P.col)), shape=(n2, n2))
+    S.sort_indices()
+    M2 = pkg.Matrix(n2, n2, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
+    f2 = U.factor(M2, U.analyze(M2))
+    assert f2.stats["block_pivoting"] == 1
+    x2 = rng.uniform(0.5, 1.5, n2)
+    for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, sp.csc_matrix(S.T))):
+        b = np.asarray(op @ x2).ravel()
+        assert _backward_error(op, U.linearSolve_(f2, mode, M2, b), b) <= 1e-13
+    assert f2.path in (4, 5)
