@@ -27,8 +27,10 @@
  * permuted matrix WITHOUT row interchanges, blocked on the fp64 matrix cores — in band storage,
  * or multifrontal on the tree (dense frontal matrices, Schur complements passed to the parent) —
  * when the matrix is diagonally dominant by columns (provably safe) and, as a speculation, for
- * every other matrix too; LAPACK-style band LU with partial pivoting otherwise (a zero pivot,
- * SPL_LU_FORCE_PIVOT=1, or a failed speculation).  solve (GPU): blocked substitution through the
+ * every other matrix too — on the tree then with threshold partial pivoting (0.1, after UMFPACK's row scaling)
+ * among the fully summed rows of every 64 x 64 pivot block, the interchange folded into the block's stored
+ * inverse (round 3; a symmetric matrix is tried as L D L^T first); LAPACK-style band LU with partial pivoting
+ * otherwise (a zero pivot, SPL_LU_FORCE_PIVOT=1, or a failed speculation).  solve (GPU): blocked substitution through the
  * band or up and down the tree, and SpMV-based iterative refinement with UMFPACK's stopping rules.
  * A speculation is checked by every solve: unless the refined solution is backward stable to
  * rounding level (componentwise backward error <= 1e-13), the object is refactored and the system
