@@ -1,5 +1,11 @@
 // umfpack_zi.hip — the complex (`zi`) half of the UMFPACK link-time ABI
-// (suitesparse/src/Numeric/LinearAlgebra/Umfpack/Internal.hs:69-135), first version.
+// (suitesparse/src/Numeric/LinearAlgebra/Umfpack/Internal.hs:69-135).
+//
+// Round 3: where the analysis chooses the multifrontal tree (and the tree has work to halve), the factors are NATIVE
+// COMPLEX fronts on the tree of the complex pattern (csrc/multifrontal.hip, TreeView::zm; csrc/dense_lu_kernels.hpp,
+// the *_z functions).  The object still holds the real embedding described below — packed complex vectors are its
+// real vectors, so the complex factors solve it — for residuals, refinement and every fallback; the band path and
+// small trees factor it as before.
 //
 // A complex n x n system  (R + iI)(x + iy) = b + ic  is solved as the real 2n x 2n system with
 // interleaved unknowns (x0, y0, x1, y1, ...):  block (i,j) of the embedding E is [[R, -I], [I, R]].
@@ -7,8 +13,7 @@
 // Internal.hs:124-132) are then exactly the real vectors of the embedded system, and E^T is the
 // embedding of A^H, so sys = 1 (UMFPACK_At, the conjugate transpose) maps to the real transposed
 // solve.  Symbolic / Numeric handles are the `di` handles of E; all arithmetic runs in the same
-// GPU kernels as the real path (band LU, banded solves, SpMV-based refinement).  A native
-// complex band kernel (half the index traffic) is the follow-up; values differ from a complex-
+// GPU kernels as the real path (band LU, banded solves, SpMV-based refinement); values differ from a complex-
 // arithmetic LU only in rounding, and `ident <\> v == v` (suitesparse/tests/test-umfpack.hs:16-19,
 // on Vector (Complex Double)) holds exactly.
 //
