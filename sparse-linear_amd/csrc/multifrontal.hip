@@ -449,7 +449,7 @@ __device__ __forceinline__ void couple_block(const Panels &fr, int ilo, int ihi,
   } else {
     // M(i, c0 + tt) = F(c0 + tt, i) (Z: its conjugate): rows c0 .. of column i of F, contiguous
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    constexpr int RW = NR == 1 ? 8 : 2;  // rows per wavefront and trip
+    constexpr int RW = NR <= 2 ? 8 : 2;  // rows per wavefront and trip (one real or one complex right-hand side: more loads in flight)
     for (int i0 = ilo + wave * RW; i0 < ihi; i0 += nw * RW) {
       double e[RW], ei[RW];
 #pragma unroll
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) void big_gemv_kernel(const int *__restrict__ l
       for (int r = 0; r < NR; ++r)
         z[(size_t)r * fs + i] -= (part[0][lane][r] + part[1][lane][r]) + (part[2][lane][r] + part[3][lane][r]);
   } else {
-    constexpr int RW = NR == 1 ? 16 : 2;  // rows of the chunk per wavefront and trip (= loads in flight)
+    constexpr int RW = NR <= 2 ? 16 : 2;  // rows of the chunk per wavefront and trip (= loads in flight)
     for (int rr = wave * RW; rr < 64; rr += 4 * RW) {
       double acc[RW][NR];
 #pragma unroll
