@@ -171,13 +171,24 @@ struct GpuLevels : mf::LevelService {
       sl.keys = reinterpret_cast<unsigned long long *>(take(N * 8));
       sl.keys_alt = reinterpret_cast<unsigned long long *>(take(N * 8));
       sl.sort_temp = take(sort_temp_bytes ? sort_temp_bytes : 1);
-      SPL_HIP(hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking));
+      if (hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking) != hipSuccess) {
+        sl.s = nullptr;
+        for (Slot &made : slots)
+          if (made.s) (void)hipStreamDestroy(made.s);
+        throw DeviceError{SPL_ERROR_internal};
+      }
     }
-    hipStream_t s = slots[0].s;
-    SPL_HIP(hipMemcpyAsync(xadj, h_xadj, (N + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    if (nnz) SPL_HIP(hipMemcpyAsync(adj, h_adj, nnz * sizeof(int), hipMemcpyHostToDevice, s));
-    SPL_HIP(hipMemsetAsync(mark, 0, N * sizeof(int), s));
-    SPL_HIP(hipStreamSynchronize(s));
+    try {
+      hipStream_t s = slots[0].s;
+      SPL_HIP(hipMemcpyAsync(xadj, h_xadj, (N + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+      if (nnz) SPL_HIP(hipMemcpyAsync(adj, h_adj, nnz * sizeof(int), hipMemcpyHostToDevice, s));
+      SPL_HIP(hipMemsetAsync(mark, 0, N * sizeof(int), s));
+      SPL_HIP(hipStreamSynchronize(s));
+    } catch (...) {  // (the destructor does not run for an object whose constructor throws)
+      for (Slot &sl : slots)
+        if (sl.s) (void)hipStreamDestroy(sl.s);
+      throw;
+    }
   }
 
   Slot &acquire() {
