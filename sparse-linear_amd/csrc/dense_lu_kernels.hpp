@@ -1107,11 +1107,15 @@ constexpr int SB = 4;
 // Workgroups of SW = 16 wavefronts: these kernels are chains of short latency-bound phases, and the
 // wider workgroup shortens every phase (more loads in flight per row).
 constexpr int SW = 16;
+// ... 8 where 16 right-hand-side columns travel together (the complex fronts' groups of eight): the partial sums of the
+// wavefronts, SW x 64 x NR doubles of LDS, would not fit beside the rest otherwise
+template <int NR>
+constexpr int solve_waves() { return NR >= 16 ? 8 : SW; }
 
 // res[l][r] = sum_{t < nc} M(rb + l, cb + t) * vv[t][r], l < 64, r < NR right-hand sides; M =
 // matrix of the triangular system.  Untransposed (MODE 0/1) band storage runs down the rows:
-// lane = row, wave q takes t = q mod SW, partial sums meet in LDS.  Transposed (MODE 2/3) it runs
-// along t: lanes along t, wave q takes rows l = q mod SW, butterfly reduction.  A band entry is
+// lane = row, wave q takes t = q mod SWV, partial sums meet in LDS.  Transposed (MODE 2/3) it runs
+// along t: lanes along t, wave q takes rows l = q mod SWV, butterfly reduction.  A band entry is
 // loaded once for all NR right-hand sides.  Ends with the result visible to the whole workgroup.
 // acc[:] += e * v[:] over NR columns; Z: the columns are (re, im) pairs of NR / 2 complex right-hand sides, e = er + i ei
 template <int NR, bool Z>
@@ -1132,6 +1136,7 @@ __device__ __forceinline__ void mac_cols(double (&acc)[NR], double er, double ei
 template <int MODE, int NR, bool Z = false>
 __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, const double (*vv)[NR],
                                        double (*res)[NR], double (*part)[64][NR]) {
+  constexpr int SWV = solve_waves<NR>();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (MODE <= 1) {
     const int i = rb + lane;
@@ -1140,17 +1145,17 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
     for (int r = 0; r < NR; ++r) acc[r] = 0.0;
     if (i >= 0 && i < b.n) {
       int t = wave;
-      for (; t + 7 * SW < nc; t += 8 * SW) {  // 8 independent loads in flight per lane
+      for (; t + 7 * SWV < nc; t += 8 * SWV) {  // 8 independent loads in flight per lane
         double e[8], ei[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          e[u] = b.get(i, cb + t + SW * u);
-          ei[u] = Z ? (&b.at(i, cb + t + SW * u))[b.zoff] : 0.0;
+          e[u] = b.get(i, cb + t + SWV * u);
+          ei[u] = Z ? (&b.at(i, cb + t + SWV * u))[b.zoff] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) mac_cols<NR, Z>(acc, e[u], ei[u], &vv[t + SW * u][0]);
+        for (int u = 0; u < 8; ++u) mac_cols<NR, Z>(acc, e[u], ei[u], &vv[t + SWV * u][0]);
       }
-      for (; t < nc; t += SW) {
+      for (; t < nc; t += SWV) {
         const double e = b.get(i, cb + t);
         const double ei = Z ? (&b.at(i, cb + t))[b.zoff] : 0.0;
         mac_cols<NR, Z>(acc, e, ei, &vv[t][0]);
@@ -1159,17 +1164,17 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
 #pragma unroll
     for (int r = 0; r < NR; ++r) part[wave][lane][r] = acc[r];
     __syncthreads();
-    for (int o = threadIdx.x; o < 64 * NR; o += SW * 64) {
+    for (int o = threadIdx.x; o < 64 * NR; o += SWV * 64) {
       const int l = o / NR, r = o % NR;
       double tot = 0.0;
 #pragma unroll
-      for (int q = 0; q < SW; ++q) tot += part[q][l][r];
+      for (int q = 0; q < SWV; ++q) tot += part[q][l][r];
       res[l][r] = tot;
     }
   } else {
     // nc <= SB * NB = 256: at most 4 strips of 64 columns; the 4 rows of this wave and the strips
     // are unrolled so that all 16 loads of a lane are in flight together
-    constexpr int RPW = 64 / SW;
+    constexpr int RPW = 64 / SWV;
     double acc[RPW][NR];
 #pragma unroll
     for (int q = 0; q < RPW; ++q)
@@ -1181,7 +1186,7 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
       const int t = lane + 64 * u;
 #pragma unroll
       for (int q = 0; q < RPW; ++q) {
-        const int i = rb + wave + SW * q;
+        const int i = rb + wave + SWV * q;
         const bool in = t < nc && i >= 0 && i < b.n;
         e[u][q] = in ? b.get(cb + t, i) : 0.0;
         ei[u][q] = (Z && in) ? -(&b.at(cb + t, i))[b.zoff] : 0.0;
@@ -1202,7 +1207,7 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
         double sacc = acc[q][r];
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
-        if (lane == 0) res[wave + SW * q][r] = sacc;
+        if (lane == 0) res[wave + SWV * q][r] = sacc;
       }
   }
   __syncthreads();
@@ -1213,14 +1218,15 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
 template <int MODE, int NR, bool Z = false>
 __device__ __forceinline__ void gemv_inv(const double *__restrict__ inv, const double (*w)[NR], double (*res)[NR],
                                          double (*part)[64][NR]) {
+  constexpr int SWV = solve_waves<NR>();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (MODE <= 1) {
     double acc[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = 0.0;
 #pragma unroll
-    for (int u = 0; u < NB / SW; ++u) {
-      const int t = wave + SW * u;
+    for (int u = 0; u < NB / SWV; ++u) {
+      const int t = wave + SWV * u;
       const double e = inv[lane + t * NB];
       const double ei = Z ? inv[NB * NB + lane + t * NB] : 0.0;
       mac_cols<NR, Z>(acc, e, ei, &w[t][0]);
@@ -1228,15 +1234,15 @@ __device__ __forceinline__ void gemv_inv(const double *__restrict__ inv, const d
 #pragma unroll
     for (int r = 0; r < NR; ++r) part[wave][lane][r] = acc[r];
     __syncthreads();
-    for (int o = threadIdx.x; o < 64 * NR; o += SW * 64) {
+    for (int o = threadIdx.x; o < 64 * NR; o += SWV * 64) {
       const int l = o / NR, r = o % NR;
       double tot = 0.0;
 #pragma unroll
-      for (int q = 0; q < SW; ++q) tot += part[q][l][r];
+      for (int q = 0; q < SWV; ++q) tot += part[q][l][r];
       res[l][r] = tot;
     }
   } else {
-    for (int l = wave; l < 64; l += SW) {
+    for (int l = wave; l < 64; l += SWV) {
       const double e = inv[lane + l * NB];  // T(l, t) = inv(t, l) (Z: conjugated)
       const double ei = Z ? -inv[NB * NB + lane + l * NB] : 0.0;
       double prod[NR];
@@ -1263,14 +1269,15 @@ template <int MODE, int NR, bool Z = false>
 __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__restrict__ invs, int j0, int jbs,
                                                  double *in, double *__restrict__ out, size_t stride, int tile,
                                                  double *dsm, int tiles = 1) {
+  constexpr int SWV = solve_waves<NR>();
   double(*v)[NR] = reinterpret_cast<double(*)[NR]>(dsm);                          // [SB * NB]
   double(*w)[NR] = reinterpret_cast<double(*)[NR]>(dsm + SB * NB * NR);           // [NB]
   double(*res)[NR] = reinterpret_cast<double(*)[NR]>(dsm + (SB + 1) * NB * NR);   // [NB]
-  double(*part)[64][NR] = reinterpret_cast<double(*)[64][NR]>(dsm + (SB + 2) * NB * NR);  // [SW]
+  double(*part)[64][NR] = reinterpret_cast<double(*)[64][NR]>(dsm + (SB + 2) * NB * NR);  // [SWV]
   constexpr bool fwd = (MODE == 0 || MODE == 2);
   const int tid = threadIdx.x;
   const int nsub = (jbs + NB - 1) / NB;
-  for (int t = tid; t < SB * NB * NR; t += SW * 64) (&v[0][0])[t] = 0.0;
+  for (int t = tid; t < SB * NB * NR; t += SWV * 64) (&v[0][0])[t] = 0.0;
   __syncthreads();
   for (int k = 0; k < nsub; ++k) {
     const int sblk = fwd ? k : nsub - 1 - k;
@@ -1279,7 +1286,7 @@ __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__
     const int cb = fwd ? j0 : js + jb;
     const int nc = fwd ? js - j0 : j0 + jbs - (js + jb);
     gemv64<MODE, NR, Z>(b, js, cb, nc, v + (cb - j0), res, part);
-    for (int o = tid; o < NB * NR; o += SW * 64) {
+    for (int o = tid; o < NB * NR; o += SWV * 64) {
       const int l = o % NB, r = o / NB;
       w[l][r] = l < jb ? in[(size_t)r * stride + js + l] - res[l][r] : 0.0;
     }
@@ -1287,14 +1294,14 @@ __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__
     constexpr size_t blk = Z ? (size_t)kInvBlockZ : (size_t)(2 * NB * NB);
     const double *inv = invs + (size_t)(js / NB) * blk + ((MODE == 1 || MODE == 2) ? blk / 2 : 0);
     gemv_inv<MODE, NR, Z>(inv, w, res, part);
-    for (int o = tid; o < NB * NR; o += SW * 64) {
+    for (int o = tid; o < NB * NR; o += SWV * 64) {
       const int l = o % NB, r = o / NB;
       if (l < jb) v[js - j0 + l][r] = res[l][r];
     }
     __syncthreads();
   }
   if (tile == 0)
-    for (int o = tid; o < jbs * NR; o += SW * 64) {
+    for (int o = tid; o < jbs * NR; o += SWV * 64) {
       const int t = o % jbs, r = o / jbs;
       out[(size_t)r * stride + j0 + t] = v[t][r];
     }
@@ -1304,7 +1311,7 @@ __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__
     const int rb = fwd ? j0 + jbs + blk * 64 : j0 - (blk + 1) * 64;
     if (fwd ? rb >= b.n : rb + 64 <= 0) break;  // workgroup-uniform
     gemv64<MODE, NR, Z>(b, rb, j0, jbs, v, res, part);
-    for (int o = tid; o < 64 * NR; o += SW * 64) {
+    for (int o = tid; o < 64 * NR; o += SWV * 64) {
       const int l = o % 64, r = o / 64;
       const int i = rb + l;
       const bool ok = fwd ? (i < b.n) : (i >= 0);
@@ -1315,7 +1322,7 @@ __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__
 }
 
 template <int MODE, int NR>
-__global__ __launch_bounds__(SW * 64) void solve_super_kernel(Band b, const double *__restrict__ invs, int j0,
+__global__ __launch_bounds__(solve_waves<NR>() * 64) void solve_super_kernel(Band b, const double *__restrict__ invs, int j0,
                                                               int jbs, double *in, double *__restrict__ out,
                                                               size_t stride) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
@@ -1464,7 +1471,7 @@ template <int MODE, int NR>
 inline void solve_pass(const Band &b, const double *d_invs, int bw, double *in, double *out, size_t stride,
                        hipStream_t s, int npiv = -1) {
   constexpr bool fwd = (MODE == 0 || MODE == 2);
-  constexpr size_t lds = (size_t)((SB + 2) * NB + SW * 64) * NR * sizeof(double);
+  constexpr size_t lds = (size_t)((SB + 2) * NB + solve_waves<NR>() * 64) * NR * sizeof(double);
   static bool attr_set = false;  // one flag per instantiation
   if (!attr_set) {
     SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_super_kernel<MODE, NR>),
@@ -1477,7 +1484,7 @@ inline void solve_pass(const Band &b, const double *d_invs, int bw, double *in, 
     const int j0 = (fwd ? k : nsup - 1 - k) * step, jbs = std::min(step, npiv - j0);
     const int rows = fwd ? std::max(0, std::min(n, j0 + jbs + bw) - (j0 + jbs)) : std::min(j0, bw);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_super_kernel<MODE, NR>), dim3((unsigned)std::max(1, (rows + 63) / 64)),
-                       dim3(SW * 64), lds, s, b, d_invs, j0, jbs, in, out, stride);
+                       dim3(solve_waves<NR>() * 64), lds, s, b, d_invs, j0, jbs, in, out, stride);
   }
 }
 

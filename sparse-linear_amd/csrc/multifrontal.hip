@@ -503,7 +503,8 @@ __global__ __launch_bounds__(256) void solve_gather_kernel(const int *__restrict
   const int *rel = t.rel + t.roff[c];
   const double *Wc = work + (size_t)t.woff[c] * NR;
   double *Wp = work + (size_t)t.woff[p] * NR;
-  for (int o = threadIdx.x; o < nbc * NR; o += blockDim.x) {
+  // (gridDim.y workgroups share a child: the children of the top levels have boundaries of thousands of indices)
+  for (int o = blockIdx.y * blockDim.x + threadIdx.x; o < nbc * NR; o += gridDim.y * blockDim.x) {
     const int k = o % nbc, r = o / nbc;
     Wp[(size_t)r * fsp + rel[k]] += Wc[(size_t)r * fsc + npc + k];
   }
@@ -624,7 +625,7 @@ __device__ __forceinline__ BigFront big_front(const int *__restrict__ list, cons
 // one super-block step (256 pivots) of the triangular pass MODE through the pivot columns of every
 // listed front that has a step `step`: forward passes take W -> Z, backward passes Z -> W
 template <int MODE, int NR, bool Z = false>
-__global__ __launch_bounds__(SW * 64) void big_super_kernel(const int *__restrict__ list,
+__global__ __launch_bounds__(solve_waves<NR>() * 64) void big_super_kernel(const int *__restrict__ list,
                                                             const int64_t *__restrict__ prefix, int count, int step,
                                                             TreeView t, const double *__restrict__ invs,
                                                             double *work, double *zbuf, int row_blocks) {
@@ -657,16 +658,23 @@ __global__ __launch_bounds__(256) void big_gather_x_kernel(const int *__restrict
 
 // Z[i][:] -= sum_k M(i, np + k) W[np + k][:], i < np: 64 rows per workgroup.  Untransposed
 // M(i, np + k) = U(i, k); transposed = F(np + k, i) in P.
+// gemv_waves wavefronts per workgroup split the boundary columns: a level has few large fronts and a front np / 64
+// workgroups, so the kernel lives on loads in flight per workgroup, not on workgroups (round 3: 4 -> 16 wavefronts)
+template <int NR>
+constexpr int gemv_waves() { return NR >= 16 ? 8 : 16; }  // (the partial sums: GW x 64 x NR doubles of static LDS)
 template <bool TRANS, int NR, bool Z = false>
-__global__ __launch_bounds__(256) void big_gemv_kernel(const int *__restrict__ list,
-                                                       const int64_t *__restrict__ prefix, int count, TreeView t,
-                                                       double *work, double *zbuf) {
-  __shared__ double part[4][64][NR];
+__global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_kernel(const int *__restrict__ list,
+                                                                         const int64_t *__restrict__ prefix, int count,
+                                                                         TreeView t, double *work, double *zbuf) {
+  constexpr int GW = gemv_waves<NR>();
+  __shared__ double part[GW][64][NR];
   const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
   const double *P = b.P, *U = b.U, *xb = b.W + b.np;
   double *z = b.Z;
   const int np = b.np, nb = b.nb, fs = b.fs, ldp = b.ldp, ldu = b.ldu;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (wave index as a scalar: the loop counters below are then wavefront-uniform for the compiler too, and the entries of
+  // x they index — the same for all 64 rows — come through the scalar cache instead of as 64-lane vector loads)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int i0 = b.blk * 64;
   if (!TRANS) {
     const int i = i0 + lane;
@@ -676,22 +684,22 @@ __global__ __launch_bounds__(256) void big_gemv_kernel(const int *__restrict__ l
     if (i < np) {
       const double *row = U + (size_t)i;
       int k = wave;
-      for (; k + 28 < nb; k += 32) {
+      for (; k + 7 * GW < nb; k += 8 * GW) {
         double e[8], ei[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          e[u] = row[(size_t)(k + 4 * u) * ldu];
-          ei[u] = Z ? row[(size_t)(k + 4 * u) * ldu + b.uz] : 0.0;
+          e[u] = row[(size_t)(k + GW * u) * ldu];
+          ei[u] = Z ? row[(size_t)(k + GW * u) * ldu + b.uz] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           double xv[NR];
 #pragma unroll
-          for (int r = 0; r < NR; ++r) xv[r] = xb[(size_t)r * fs + k + 4 * u];
+          for (int r = 0; r < NR; ++r) xv[r] = xb[(size_t)r * fs + k + GW * u];
           mac_cols<NR, Z>(acc, e[u], ei[u], xv);
         }
       }
-      for (; k < nb; k += 4) {
+      for (; k < nb; k += GW) {
         const double e = row[(size_t)k * ldu];
         const double ei = Z ? row[(size_t)k * ldu + b.uz] : 0.0;
         double xv[NR];
@@ -705,11 +713,15 @@ __global__ __launch_bounds__(256) void big_gemv_kernel(const int *__restrict__ l
     __syncthreads();
     if (wave == 0 && i < np)
 #pragma unroll
-      for (int r = 0; r < NR; ++r)
-        z[(size_t)r * fs + i] -= (part[0][lane][r] + part[1][lane][r]) + (part[2][lane][r] + part[3][lane][r]);
+      for (int r = 0; r < NR; ++r) {
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < GW; ++q) sum += part[q][lane][r];
+        z[(size_t)r * fs + i] -= sum;
+      }
   } else {
     constexpr int RW = NR <= 2 ? 16 : 2;  // rows of the chunk per wavefront and trip (= loads in flight)
-    for (int rr = wave * RW; rr < 64; rr += 4 * RW) {
+    for (int rr = wave * RW; rr < 64; rr += GW * RW) {
       double acc[RW][NR];
 #pragma unroll
       for (int u = 0; u < RW; ++u)
@@ -806,6 +818,7 @@ struct Factors {
   std::vector<int> solve_counts;
   std::vector<DBuf<int>> child_lists[2];             // children (by slot) of the fronts of each depth
   std::vector<int> child_counts[2];
+  std::vector<int> child_maxnb[2];                   // ... and the largest boundary among them
   std::vector<std::vector<int>> h_small, h_child[2];  // host copies (ascending ids) of small_lists / child_lists
   // tiles (64 x 16) before each item of child_lists (Schur complements) and of level_lists (P and
   // U panels): the flat grids of extend-add and compaction
@@ -1042,6 +1055,7 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
   for (int sl = 0; sl < 2; ++sl) {
     F.child_lists[sl].resize((size_t)nd);
     F.child_counts[sl].assign((size_t)nd, 0);
+    F.child_maxnb[sl].assign((size_t)nd, 0);
     F.h_child[sl].assign((size_t)nd, std::vector<int>());
   }
   std::vector<std::vector<int>> staged;  // host copies must outlive the asynchronous uploads
@@ -1106,6 +1120,7 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
       for (int c : T.by_depth[(size_t)d + 1]) F.h_child[T.slot[(size_t)c]][(size_t)d].push_back(c);
       for (int sl = 0; sl < 2; ++sl) {
         F.child_counts[sl][(size_t)d] = (int)F.h_child[sl][(size_t)d].size();
+        for (int c : F.h_child[sl][(size_t)d]) F.child_maxnb[sl][(size_t)d] = std::max(F.child_maxnb[sl][(size_t)d], T.nb[(size_t)c]);
         upload_vec(F.child_lists[sl][(size_t)d], F.h_child[sl][(size_t)d], s);
       }
     }
@@ -1365,7 +1380,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
 template <int MODE, int NR, bool Z = false>
 static void launch_big_super(const mf::Factors &F, const mf::Factors::BigLevel &B, int kind, int step, double *work,
                              double *zbuf, hipStream_t s) {
-  constexpr size_t lds = (size_t)((SB + 2) * NB + SW * 64) * NR * sizeof(double);
+  constexpr size_t lds = (size_t)((SB + 2) * NB + solve_waves<NR>() * 64) * NR * sizeof(double);
   static bool attr_set = false;  // one flag per instantiation
   if (!attr_set) {
     SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&big_super_kernel<MODE, NR, Z>),
@@ -1374,7 +1389,7 @@ static void launch_big_super(const mf::Factors &F, const mf::Factors::BigLevel &
   }
   const unsigned groups = B.total(kind, step);
   if (groups > 0)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(big_super_kernel<MODE, NR, Z>), dim3(groups), dim3(SW * 64), lds, s, B.list.get(),
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(big_super_kernel<MODE, NR, Z>), dim3(groups), dim3(solve_waves<NR>() * 64), lds, s, B.list.get(),
                        B.prefix(kind, step), B.count, step, F.view, F.invs.get(), work, zbuf, B.row_blocks);
 }
 
@@ -1404,9 +1419,12 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
                        F.view, c, stride, work);
     if (d + 1 < nd)
       for (int sl = 0; sl < 2; ++sl)
-        if (F.child_counts[sl][(size_t)d] > 0)
-          hipLaunchKernelGGL(solve_gather_kernel<NR>, dim3((unsigned)F.child_counts[sl][(size_t)d]), dim3(256), 0, s,
+        if (F.child_counts[sl][(size_t)d] > 0) {
+          const int64_t most = (int64_t)F.child_maxnb[sl][(size_t)d] * NR;  // entries of the largest child
+          const unsigned share = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (most + 2047) / 2048));
+          hipLaunchKernelGGL(solve_gather_kernel<NR>, dim3((unsigned)F.child_counts[sl][(size_t)d], share), dim3(256), 0, s,
                              F.child_lists[sl][(size_t)d].get(), F.view, work);
+        }
     if (F.solve_counts[(size_t)d] > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_forward_kernel<TRANS, NR, Z>), dim3((unsigned)F.solve_counts[(size_t)d]),
                          dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work);
@@ -1433,7 +1451,7 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
       if (B.total(4) > 0) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gather_x_kernel<NR, Z>), dim3(B.total(4)), dim3(256), 0, s, B.list.get(),
                            B.prefix(4), B.count, F.view, c, stride, work, zbuf);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_kernel<TRANS, NR, Z>), dim3(B.total(5)), dim3(256), 0, s,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_kernel<TRANS, NR, Z>), dim3(B.total(5)), dim3(gemv_waves<NR>() * 64), 0, s,
                            B.list.get(), B.prefix(5), B.count, F.view, work, zbuf);
       }
       // the pivot block alone; columns of Z / W are fs apart
@@ -1454,7 +1472,7 @@ void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride,
   if (F.zm == 2) {
     // complex fronts: the k columns are packed complex vectors of T.n entries (stride doubles apart); a complex
     // right-hand side is two real columns of the work matrices: one at a time, or four together
-    constexpr int kGroupZ = 4;
+    constexpr int kGroupZ = 8;  // = kSolveGroup columns of the caller, each a packed complex vector: 16 real columns
     const int nrz = k == 1 ? 2 : 2 * kGroupZ;
     DBuf<double> wz((size_t)T.work_elems * nrz * 2);  // work and z matrices
     double *wk = wz.get(), *zb = wz.get() + (size_t)T.work_elems * nrz;

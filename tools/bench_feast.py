@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--m0", type=int, default=24)
     ap.add_argument("--lo", type=float, default=0.02)
     ap.add_argument("--hi", type=float, default=0.035)
+    ap.add_argument("--dim", type=int, default=2, choices=[2, 3], help="2: m^2 grid (5-point), 3: m^3 grid (7-point)")
     args = ap.parse_args()
     import numpy as np
     import scipy.sparse as sp
@@ -27,14 +28,21 @@ def main():
     pkg = load_package()
     torch.cuda.set_device(0)
     m = args.grid
-    n = m * m
+    n = m ** args.dim
     T = sp.diags([-np.ones(m - 1), 2 * np.ones(m), -np.ones(m - 1)], (-1, 0, 1))
-    S = (sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m))).tocsc()
+    I = sp.identity(m)
+    if args.dim == 2:
+        S = (sp.kron(I, T) + sp.kron(T, I)).tocsc()
+    else:
+        S = (sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(T, I), I)).tocsc()
     S.sort_indices()
     A = pkg.Matrix(n, n, S.indptr, S.indices, S.data.astype(np.complex128))
     k = np.arange(1, m + 1)
     ev1 = 2.0 - 2.0 * np.cos(k * np.pi / (m + 1))
-    exact = np.sort((ev1[:, None] + ev1[None, :]).ravel())
+    if args.dim == 2:
+        exact = np.sort((ev1[:, None] + ev1[None, :]).ravel())
+    else:
+        exact = np.sort((ev1[:, None, None] + ev1[None, :, None] + ev1[None, None, :]).ravel())
     inside = exact[(exact > args.lo) & (exact < args.hi)]
     t = time.perf_counter()
     lam, X = pkg.feast.eigSH(args.m0, (args.lo, args.hi), A)
@@ -43,7 +51,7 @@ def main():
     lam = np.sort(np.asarray(lam))
     ok = len(lam) == len(inside)
     err = float(np.max(np.abs(lam - inside) / inside)) if ok and len(lam) else None
-    print(json.dumps({"matrix": "2-D Laplacian %d^2" % m, "n": n, "window": [args.lo, args.hi], "m0": args.m0,
+    print(json.dumps({"matrix": "%d-D Laplacian %d^%d" % (args.dim, m, args.dim), "n": n, "window": [args.lo, args.hi], "m0": args.m0,
                       "eigenvalues_exact_in_window": len(inside), "found": len(lam), "max_rel_error": err,
                       "seconds": round(dt, 3),
                       "stage_seconds": {k: round(v, 3) for k, v in pkg.feast.geigSH_.last_clock.items()}}), flush=True)
