@@ -720,7 +720,7 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_kernel(const i
         z[(size_t)r * fs + i] -= sum;
       }
   } else {
-    constexpr int RW = NR <= 2 ? 16 : 2;  // rows of the chunk per wavefront and trip (= loads in flight)
+    constexpr int RW = NR <= 2 ? 4 : 2;  // rows of the chunk per wavefront and trip (GW wavefronts share its 64 rows)
     for (int rr = wave * RW; rr < 64; rr += GW * RW) {
       double acc[RW][NR];
 #pragma unroll
