@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <memory>
 #include <new>
 #include <vector>
@@ -66,6 +67,22 @@ struct DBuf {
 };
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Kernel attributes (hipFuncSetAttribute: dynamic LDS above 64 KB) are per DEVICE: a `static bool` would leave the second
+// GPU of a process without them.  One bit per device in a mask per call site; true for the first caller on the current
+// device.  (Two threads racing on the first use both set the attributes: the loser of fetch_or still proceeds only
+// after its own check below, and setting them twice is harmless.)
+inline bool first_use_on_this_device(std::atomic<uint64_t> &mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return true;
+  const uint64_t bit = 1ull << (dev & 63);
+  return (mask.load(std::memory_order_acquire) & bit) == 0;
+}
+inline void mark_used_on_this_device(std::atomic<uint64_t> &mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
+}
 
 // sets the device for the current thread and restores the previous one on exit
 struct DeviceGuard {

@@ -1334,8 +1334,8 @@ __global__ __launch_bounds__(solve_waves<NR>() * 64) void solve_super_kernel(Ban
 inline size_t inverse_block_elems(int npiv) { return (size_t)((npiv + NB - 1) / NB) * (2 * NB * NB); }
 
 inline void set_factor_attributes() {
-  static bool attr_set = false;
-  if (attr_set) return;
+  static std::atomic<uint64_t> attr_set{0};  // one bit per device
+  if (!first_use_on_this_device(attr_set)) return;
   SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_lu_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileBytes)));
   SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&trsm_gemm_kernel),
@@ -1352,7 +1352,7 @@ inline void set_factor_attributes() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDiagLdsZ));
   SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_update_bulk_kernel_z),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kUpdateLdsZ));
-  attr_set = true;
+  mark_used_on_this_device(attr_set);
 }
 
 // Right-looking blocked LU without interchanges of the first npiv columns/rows of the view b
@@ -1472,11 +1472,11 @@ inline void solve_pass(const Band &b, const double *d_invs, int bw, double *in, 
                        hipStream_t s, int npiv = -1) {
   constexpr bool fwd = (MODE == 0 || MODE == 2);
   constexpr size_t lds = (size_t)((SB + 2) * NB + solve_waves<NR>() * 64) * NR * sizeof(double);
-  static bool attr_set = false;  // one flag per instantiation
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};  // one mask per instantiation, one bit per device
+  if (first_use_on_this_device(attr_set)) {
     SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_super_kernel<MODE, NR>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    mark_used_on_this_device(attr_set);
   }
   if (npiv < 0) npiv = b.n;
   const int n = b.n, step = SB * NB, nsup = (npiv + step - 1) / step;

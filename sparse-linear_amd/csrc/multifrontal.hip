@@ -1164,8 +1164,8 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
   DBuf<int> singular(1);
   SPL_HIP(hipMemsetAsync(singular.get(), 0, sizeof(int), s));
   set_factor_attributes();
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};  // one bit per device
+  if (first_use_on_this_device(attr_set)) {
     SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&front_factor_kernel<Z>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(Z ? kFrontLdsZ : 2 * kTileBytes)));
     SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mid_trsm_kernel<Z>),
@@ -1176,7 +1176,7 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
       SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mid_update_kernel<Z>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDiagLdsZ));
     }
-    attr_set = true;
+    mark_used_on_this_device(attr_set);
   }
   F.make_streams();
   hipStream_t *side = F.side;
@@ -1381,11 +1381,11 @@ template <int MODE, int NR, bool Z = false>
 static void launch_big_super(const mf::Factors &F, const mf::Factors::BigLevel &B, int kind, int step, double *work,
                              double *zbuf, hipStream_t s) {
   constexpr size_t lds = (size_t)((SB + 2) * NB + solve_waves<NR>() * 64) * NR * sizeof(double);
-  static bool attr_set = false;  // one flag per instantiation
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};  // one mask per instantiation, one bit per device
+  if (first_use_on_this_device(attr_set)) {
     SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&big_super_kernel<MODE, NR, Z>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    mark_used_on_this_device(attr_set);
   }
   const unsigned groups = B.total(kind, step);
   if (groups > 0)

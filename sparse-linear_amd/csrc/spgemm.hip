@@ -1814,15 +1814,15 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   const bool key32_s = allow32 && nrowsA <= (1LL << (31 - ilog2_ceil(kSmallProducts)));
   const bool key32_m = allow32 && nrowsA <= (1LL << (31 - ilog2_ceil(kMediumProducts)));
   const bool key32_x = allow32 && nrowsA <= (1LL << (31 - ilog2_ceil(kLargeProducts)));
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};  // one bit per device
+  if (first_use_on_this_device(attr_set)) {
     SPL_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void *>(&spgemm_block_kernel<kLargeProducts, kLargeB, true, false>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LXn::total));
     SPL_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void *>(&spgemm_block_kernel<kLargeProducts, kLargeB, true, true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LXn32::total));
-    attr_set = true;
+    mark_used_on_this_device(attr_set);
   }
   // Heavy columns (bin L): the row-range kernel takes those it can keep in LDS (spgemm_range_kernel), the others —
   // appended to a second list — go to the dense accumulators, whose pool is only allocated when that list is not empty.
