@@ -536,3 +536,43 @@ def test_native_complex_fronts_block_pivoting(gpu, pkg, monkeypatch):
         x = U.linearSolve_(f, mode, M, b)
         assert _bwd(op, x, b) <= 1e-13
     assert f.stats["complex_fronts"] == 1 and f.path == 4  # no fallback was needed
+
+
+def test_native_complex_fronts_fall_back_to_static_pivoting(gpu, pkg, monkeypatch):
+    """a complex mesh matrix with random values and a useless diagonal on native complex fronts: whatever the stages do
+    — block pivoting holds, or static pivoting refactors the EMBEDDING on real fronts (the complex tree is given up:
+    complex_fronts drops to 0 with path 5) — both systems come back backward stable; packed and device right-hand sides"""
+    import scipy.sparse as sp
+    import torch
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    monkeypatch.setenv("SPL_ZI_NATIVE", "1")
+    rng = np.random.default_rng(31)
+    m = 44
+    T = sp.diags([np.ones(m - 1), np.ones(m), np.ones(m - 1)], (-1, 0, 1))
+    S = sp.csc_matrix(sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m)), dtype=np.complex128)
+    S.data = rng.uniform(-1, 1, S.nnz) + 1j * rng.uniform(-1, 1, S.nnz)
+    S.setdiag(1e-12 * (rng.uniform(0.5, 1.0, S.shape[0]) + 0j))
+    S = sp.csc_matrix(S)
+    S.sort_indices()
+    n = S.shape[0]
+    M = pkg.Matrix(n, n, S.indptr, S.indices, S.data)
+    U = pkg.umfpack
+    for pivot in ("1", "0"):
+        monkeypatch.setenv("SPL_LU_BLOCK_PIVOT", pivot)
+        fact = U.factor(M, U.analyze(M))
+        st = fact.stats
+        # (a zero pivot on the way — block pivoting out of candidates inside a pivot block, or total cancellation behind
+        # the 1e-12 pivots of the natural order — sends numeric to static pivoting at once; else the speculation stands
+        # until a solve checks it)
+        assert (st["path"], st["complex_fronts"]) in ((4, 1), (5, 0)), st
+        xs = rng.uniform(0.5, 1.5, n) + 1j * rng.uniform(-1, 1, n)
+        for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, sp.csc_matrix(S.conj().T))):
+            b = np.asarray(op @ xs).ravel()
+            x = U.linearSolve_(fact, mode, M, b)
+            assert _bwd(op, x, b) <= 1e-12
+            xd = U.linearSolveManyDevice_(fact, mode, M, torch.from_numpy(b[None, :].copy()).cuda()).cpu().numpy()[0]
+            assert _bwd(op, xd, b) <= 1e-12
+        st = fact.stats
+        assert (st["path"], st["complex_fronts"]) in ((4, 1), (5, 0), (0, 0)), st
+        if pivot == "0":
+            assert st["path"] in (5, 0)  # no interchanges at all on a diagonal of 1e-12: the speculation cannot hold
