@@ -34,6 +34,10 @@ constexpr int kBlock = 64;  // pivot block of the dense kernels (NB of band_nopi
 // regions up to this size start their level structure from the end vertex their parent hands down
 // (one BFS instead of two); larger regions, whose separators carry the flops, search properly
 constexpr int kHintBelow = 40000;
+// ... and regions of any size whose PARENT's level structure was that of a planar-like graph: levels^2 >= vertices / 2
+// (a 2-D mesh of s x s vertices has 1.5 s .. 2 s levels; a 3-D one of s^3 has 3 s, which passes only below 18^3).
+// There the end the parent hands down is as good a root as the search would find, and the traversals — thousands of
+// narrow levels: sequential on the host, a launch each on the device — are the whole cost of the analysis.
 // Level structures of regions of kTeamRegion vertices and more are built by a team of threads
 // (team_bfs): these traversals are the serial part of the dissection — the top regions, one after
 // the other down the tree.  A region's team is its share of the threads (the regions of a depth run
@@ -98,9 +102,10 @@ struct Tree {
 // traversal from region[0], then, if that reached everything, another from the far end — as `queue` (the vertices
 // grouped by level, in a deterministic order inside a level) and `level_ptr`; returns the number of vertices reached
 // (< size: the region is disconnected and the outputs are not meaningful).  Thread-safe.
+// root >= 0: ONE traversal, from that vertex (a hint from the parent region).
 struct LevelService {
   virtual ~LevelService() {}
-  virtual int levels(const int *region, int size, std::vector<int> &queue, std::vector<int64_t> &level_ptr) = 0;
+  virtual int levels(const int *region, int size, std::vector<int> &queue, std::vector<int64_t> &level_ptr, int root = -1) = 0;
 };
 
 namespace detail {
@@ -396,19 +401,20 @@ struct Worker {
 
   // subtrees of the two vertex ranges, then `top` as their parent; large ranges get their own thread
   // hint_l / hint_r: an extreme vertex of each side to start its level structure from (-1: none)
-  std::vector<Node> join(int lo, int mid, int hi, Node &&top, int depth, int hint_l = -1, int hint_r = -1) {
+  std::vector<Node> join(int lo, int mid, int hi, Node &&top, int depth, int hint_l = -1, int hint_r = -1,
+                         bool thin = false) {
     std::vector<Node> left, right;
     const bool fork = depth < 8 && mid - lo >= 20000 && hi - mid >= 20000;
     if (fork) {
-      std::future<std::vector<Node>> other = std::async(std::launch::async, [this, lo, mid, depth, hint_l] {
+      std::future<std::vector<Node>> other = std::async(std::launch::async, [this, lo, mid, depth, hint_l, thin] {
         Worker w(S);
-        return w.dissect(lo, mid, depth + 1, hint_l);
+        return w.dissect(lo, mid, depth + 1, hint_l, thin);
       });
-      right = dissect(mid, hi, depth + 1, hint_r);
+      right = dissect(mid, hi, depth + 1, hint_r, thin);
       left = other.get();
     } else {
-      if (mid > lo) left = dissect(lo, mid, depth + 1, hint_l);
-      if (hi > mid) right = dissect(mid, hi, depth + 1, hint_r);
+      if (mid > lo) left = dissect(lo, mid, depth + 1, hint_l, thin);
+      if (hi > mid) right = dissect(mid, hi, depth + 1, hint_r, thin);
     }
     std::vector<Node> out;
     out.reserve(left.size() + right.size() + 1);
@@ -433,7 +439,7 @@ struct Worker {
 
   // hint: a vertex of the region known to lie at one of its ends (the root or the deepest vertex of
   // the parent's level structure): one BFS from it replaces the two of the pseudo-peripheral search
-  std::vector<Node> dissect(int lo, int hi, int depth, int hint = -1) {
+  std::vector<Node> dissect(int lo, int hi, int depth, int hint = -1, bool thin_parent = false) {
     const int size = hi - lo;
     if (size <= S.leaf) return make_leaf(lo, hi);
     auto t_last = std::chrono::steady_clock::now();
@@ -449,9 +455,10 @@ struct Worker {
     lap("region stamp");
     int reached = -1;
     bool from_service = false;
+    const bool use_hint = hint >= 0 && (size <= kHintBelow || thin_parent) && S.mark[(size_t)hint] == region_stamp;
     if (S.service && S.service_min > 0 && size >= S.service_min) {
       try {
-        reached = S.service->levels(S.verts.data() + lo, size, queue, level_ptr);
+        reached = S.service->levels(S.verts.data() + lo, size, queue, level_ptr, use_hint ? hint : -1);
       } catch (...) {  // no memory on the device, or any other failure there: the host code below takes the region
         reached = -1;
       }
@@ -466,8 +473,8 @@ struct Worker {
     }
     if (from_service) {
       // nothing else to do here
-    } else if (hint >= 0 && size <= kHintBelow && S.mark[(size_t)hint] == region_stamp) {
-      reached = bfs(hint, region_stamp);
+    } else if (use_hint) {
+      reached = traverse(hint, region_stamp, size);
     } else {
       reached = traverse(S.verts[(size_t)lo], region_stamp, size);
       lap("first level structure");
@@ -578,7 +585,8 @@ struct Worker {
     const int end1 = queue.front(), end2 = queue.back();  // the two ends of this level structure
     std::vector<int>().swap(side1);
     std::vector<int>().swap(side2);
-    return join(lo, lo + n1, lo + n1 + n2, std::move(top), depth, end1, end2);
+    const bool thin = (int64_t)nlev * nlev * 2 >= (int64_t)size;
+    return join(lo, lo + n1, lo + n1 + n2, std::move(top), depth, end1, end2, thin);
   }
 };
 

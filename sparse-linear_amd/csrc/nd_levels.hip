@@ -238,7 +238,8 @@ struct GpuLevels : mf::LevelService {
     }
   }
 
-  int levels(const int *region, int size, std::vector<int> &out_queue, std::vector<int64_t> &out_level_ptr) override {
+  int levels(const int *region, int size, std::vector<int> &out_queue, std::vector<int64_t> &out_level_ptr,
+             int root) override {
     DeviceGuard g(device);
     Slot &sl = acquire();
     struct Release {
@@ -264,10 +265,10 @@ struct GpuLevels : mf::LevelService {
     hipLaunchKernelGGL(nd_stamp_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, s, sl.verts, size,
                        mark, region_stamp);
     lap(0);
-    int nlev = traverse(sl, region[0], region_stamp, first);
+    int nlev = traverse(sl, root >= 0 ? root : region[0], region_stamp, first);
     int reached = h_levptr[(size_t)nlev];
     lap(1);
-    if (reached == size) {
+    if (reached == size && root < 0) {
       // once more from the far end: the smallest vertex id of the last level (a choice that does not depend on the
       // order the atomics produced)
       const int lb = h_levptr[(size_t)nlev - 1], le = h_levptr[(size_t)nlev];
