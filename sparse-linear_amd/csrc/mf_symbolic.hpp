@@ -625,17 +625,38 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
   std::vector<int64_t> xadj((size_t)n + 1, 0);
   std::vector<int> adj;
   if (pattern_symmetric) {
-    for (int j = 0; j < n; ++j) {
-      int64_t len = 0;
-      for (int p = Ap[j]; p < Ap[j + 1]; ++p) len += Ai[p] != j;
-      xadj[(size_t)j + 1] = xadj[(size_t)j] + len;
-    }
+    // column ranges on threads: lengths, one sequential prefix sum, then the lists
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = (Ap[n] < 2000000 || nt < 2) ? 1 : (nt > 8 ? 8 : nt);
+    auto on_ranges = [&](auto body) {
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nt; ++t) {
+        const int j0 = (int)((int64_t)n * t / nt), j1 = (int)((int64_t)n * (t + 1) / nt);
+        try {
+          pool.emplace_back(body, j0, j1);
+        } catch (...) {
+          body(j0, j1);
+        }
+      }
+      body(0, (int)((int64_t)n / nt));
+      for (std::thread &th : pool) th.join();
+    };
+    on_ranges([&](int j0, int j1) {
+      for (int j = j0; j < j1; ++j) {
+        int64_t len = 0;
+        for (int p = Ap[j]; p < Ap[j + 1]; ++p) len += Ai[p] != j;
+        xadj[(size_t)j + 1] = len;
+      }
+    });
+    for (int j = 0; j < n; ++j) xadj[(size_t)j + 1] += xadj[(size_t)j];
     adj.resize((size_t)xadj[(size_t)n]);
-    for (int j = 0; j < n; ++j) {
-      int64_t q = xadj[(size_t)j];
-      for (int p = Ap[j]; p < Ap[j + 1]; ++p)
-        if (Ai[p] != j) adj[(size_t)q++] = Ai[p];
-    }
+    on_ranges([&](int j0, int j1) {
+      for (int j = j0; j < j1; ++j) {
+        int64_t q = xadj[(size_t)j];
+        for (int p = Ap[j]; p < Ap[j + 1]; ++p)
+          if (Ai[p] != j) adj[(size_t)q++] = Ai[p];
+      }
+    });
   } else {
     for (int j = 0; j < n; ++j)
       for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
