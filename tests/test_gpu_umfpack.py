@@ -807,3 +807,62 @@ def test_block_pivoting_symmetric_retry_and_row_scales(gpu, pkg, monkeypatch):
         b = np.asarray(op @ x2).ravel()
         assert _backward_error(op, U.linearSolve_(f2, mode, M2, b), b) <= 1e-13
     assert f2.path in (4, 5)
+
+
+def test_umfpack_entry_points_from_several_threads(gpu, pkg, O, monkeypatch):
+    """`safe` foreign calls may arrive concurrently from several OS threads (only FEAST serialises,
+    Feast.hs:134): analyze / factor / solve of different matrices — a symmetric mesh (L D L^T), an unsymmetric one that
+    is not dominant (block pivoting), a complex shift on native complex fronts, the GPU level service — from four
+    threads at once, three rounds each, give what the same calls give one after the other"""
+    import threading
+    import scipy.sparse as sp
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    monkeypatch.setenv("SPL_ZI_NATIVE", "1")
+    monkeypatch.setenv("SPL_ND_GPU_MIN", "3000")
+    U = pkg.umfpack
+    rng = np.random.default_rng(99)
+    cases = []
+    n1, A1 = _grid_matrix(pkg, O, "2d", 70)
+    cases.append((A1, csc_tuple_to_scipy(mat_to_tuple(A1)), rng.uniform(0.5, 1.5, n1)))
+    n2, A2 = _grid_matrix(pkg, O, "3d", 18)
+    cases.append((A2, csc_tuple_to_scipy(mat_to_tuple(A2)), rng.uniform(0.5, 1.5, n2)))
+    m = 50
+    T = sp.diags([np.ones(m - 1), np.ones(m), np.ones(m - 1)], (-1, 0, 1))
+    P = sp.csc_matrix(sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m)))
+    P.data = rng.uniform(-1.0, 1.0, P.nnz)
+    P.setdiag(rng.uniform(2.0, 3.0, m * m))  # not dominant (column sums up to 4), fine with block pivoting
+    P = sp.csc_matrix(P)
+    P.sort_indices()
+    cases.append((pkg.Matrix(m * m, m * m, P.indptr.astype(np.int32), P.indices.astype(np.int32), P.data), P,
+                  rng.uniform(0.5, 1.5, m * m)))
+    K = csc_tuple_to_scipy(mat_to_tuple(A1))
+    Z = sp.csc_matrix((2.5 + 0.7j) * sp.identity(n1) - K)
+    Z.sort_indices()
+    cases.append((pkg.Matrix(n1, n1, Z.indptr, Z.indices, Z.data), Z, rng.uniform(0.5, 1.5, n1) + 1j * rng.uniform(0.5, 1.5, n1)))
+
+    def run(case):
+        A, S, xs = case
+        b = np.asarray(S @ xs).ravel()
+        f = U.factor(A, U.analyze(A))
+        x = U.linearSolve_(f, U.UmfpackNormal, A, b)
+        return x, _backward_error(S, x, b)
+
+    serial = [run(c) for c in cases]
+    assert all(be <= 1e-13 for _, be in serial)
+    results, errors = {}, []
+
+    def work(t):
+        try:
+            for it in range(3):
+                results[(t, it)] = run(cases[t])
+        except Exception as e:  # pragma: no cover
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for (t, it), (x, be) in results.items():
+        assert be <= 1e-13 and np.array_equal(x, serial[t][0]), (t, it, be)
