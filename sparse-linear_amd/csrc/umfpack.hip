@@ -1297,11 +1297,43 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B,
       const int max_steps = N->speculative ? 10 : 2;
       const double stall = 0.5;
       for (int it = 0; it < max_steps && nactive > 0; ++it) {
-        factor_solve(N, sys, dr.get(), dd.get(), dwork.get(), k, stride, s);
         SPL_HIP(hipMemcpyAsync(dxn.get(), dx.get(), used * sizeof(double), hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(add_kernel, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, s, used, dxn.get(),
-                           dd.get());
+        if (nactive == k) {
+          factor_solve(N, sys, dr.get(), dd.get(), dwork.get(), k, stride, s);
+          hipLaunchKernelGGL(add_kernel, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, s, used, dxn.get(),
+                             dd.get());
+        } else {
+          // Only the columns still being refined go through the factors, side by side: a walk over the tree (or the
+          // band) costs the same for a group of kSolveGroup columns whatever they hold, and the columns of a batch
+          // rarely all need the second step (drn is free until the backward error below).
+          int ka = 0;
+          for (int c = 0; c < k; ++c)
+            if (active[(size_t)c])
+              SPL_HIP(hipMemcpyAsync(drn.get() + (size_t)ka++ * stride, dr.get() + (size_t)c * stride,
+                                     stride * sizeof(double), hipMemcpyDeviceToDevice, s));
+          const int ka_alloc = ka == 1 ? 1 : (ka + kSolveGroup - 1) / kSolveGroup * kSolveGroup;
+          if (ka_alloc > ka) {
+            SPL_HIP(hipMemsetAsync(drn.get() + (size_t)ka * stride, 0, (size_t)(ka_alloc - ka) * stride * sizeof(double), s));
+            SPL_HIP(hipMemsetAsync(dwork.get() + (size_t)ka * stride, 0, (size_t)(ka_alloc - ka) * stride * sizeof(double), s));
+          }
+          factor_solve(N, sys, drn.get(), dd.get(), dwork.get(), ka, stride, s);
+          ka = 0;
+          for (int c = 0; c < k; ++c)
+            if (active[(size_t)c])
+              hipLaunchKernelGGL(add_kernel, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, s, stride,
+                                 dxn.get() + (size_t)c * stride, dd.get() + (size_t)ka++ * stride);
+        }
         backward_error(dxn.get(), drn.get(), on);
+        if (timing) {
+          double lo = 1e300, hi = 0.0, lo2 = 1e300, hi2 = 0.0;
+          for (int c = 0; c < k; ++c)
+            if (active[(size_t)c]) {
+              lo = std::min(lo, omega[(size_t)c]), hi = std::max(hi, omega[(size_t)c]);
+              lo2 = std::min(lo2, on[(size_t)c]), hi2 = std::max(hi2, on[(size_t)c]);
+            }
+          fprintf(stderr, "[solve] columns refined in this step: %d of %d, backward errors %.2e .. %.2e -> %.2e .. %.2e\n",
+                  nactive, k, lo, hi, lo2, hi2);
+        }
         lap("refinement step");
         for (int c = 0; c < k; ++c) {
           if (!active[(size_t)c]) continue;

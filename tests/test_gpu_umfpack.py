@@ -243,6 +243,37 @@ def test_batched_linear_solve_matches_one_at_a_time(gpu, pkg, O, k, force_pivot,
         assert O.count_not_close(x, U.linearSolve_(fact, U.UmfpackNormal, A, b), 1e-12) == 0
 
 
+@pytest.mark.parametrize("method", ["band", "mf"])
+@pytest.mark.parametrize("k,zero_cols", [(11, (0, 3, 4, 9)), (16, (1,)), (9, (0, 1, 2, 3, 4, 5, 6, 8)), (3, (2,))])
+def test_refinement_takes_only_unfinished_columns_through_the_factors(gpu, pkg, O, method, k, zero_cols, monkeypatch):
+    """a batch in which some columns are done after the first solve (zero right-hand sides: backward error 0) while the
+    others take refinement steps: those still refining are gathered side by side for the step (one, a part of a group of
+    eight, more than a group) and must come out exactly as when each is solved alone; the finished ones stay untouched"""
+    import scipy.sparse as sp
+    monkeypatch.setenv("SPL_LU_METHOD", method)
+    m = 40
+    n = m * m
+    rp, ci, v = O.gen_poisson2d_csr(m)
+    v = v.copy()
+    v[ci == np.repeat(np.arange(n), np.diff(rp))] -= 1.37  # indefinite shift: the first solve is not at rounding level
+    A = pkg.Matrix(n, n, rp, ci, v)
+    S = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    rng = np.random.default_rng(100 * k + len(zero_cols))
+    bs = [np.zeros(n) if c in zero_cols else rng.normal(size=n) * 10.0 ** rng.integers(-3, 4) for c in range(k)]
+    U = pkg.umfpack
+    fact = U.factor(A, U.analyze(A))
+    for mode in (U.UmfpackNormal, U.UmfpackTrans):
+        many = U.linearSolveMany_(fact, mode, A, bs)
+        for c, (b, x) in enumerate(zip(bs, many)):
+            if c in zero_cols:
+                assert not np.any(x)
+                continue
+            one = U.linearSolve_(fact, mode, A, b)
+            assert O.count_not_close(x, one, 1e-12) == 0
+            op = S if mode == U.UmfpackNormal else S.T
+            assert np.max(np.abs(op @ x - b)) / (np.max(np.abs(b)) + 6 * np.max(np.abs(x))) < 1e-13
+
+
 # ---- multifrontal path (SPL_LU_METHOD=mf forces it on small matrices; large meshes take it by themselves)
 def _grid_matrix(pkg, O, kind, m):
     if kind == "2d":
