@@ -1118,16 +1118,35 @@ constexpr int solve_waves() { return NR >= 16 ? 8 : SW; }
 // along t: lanes along t, wave q takes rows l = q mod SWV, butterfly reduction.  A band entry is
 // loaded once for all NR right-hand sides.  Ends with the result visible to the whole workgroup.
 // acc[:] += e * v[:] over NR columns; Z: the columns are (re, im) pairs of NR / 2 complex right-hand sides, e = er + i ei
-template <int NR, bool Z>
+template <int NR, bool Z, bool FUSED = true>
 __device__ __forceinline__ void mac_cols(double (&acc)[NR], double er, double ei, const double *v) {
-  if (!Z) {
+  // FUSED: fused multiply-adds, spelled out — the library is built with -ffp-contract=off (the SpMV keeps the
+  // reference's two roundings), and the solves with many columns are bound by the issue of these instructions where v
+  // comes from LDS: half as many this way (the step of a large front with 16 columns: 83 -> 59 us).  Not FUSED: the
+  // plain expressions, for big_gemv_kernel, whose v arrive through the scalar cache — there the compiler's schedule of
+  // the fused form waits for the scalar loads almost twice as often (measured: 192 -> 334 us per launch).
+  if (!FUSED) {
+    if (!Z) {
 #pragma unroll
-    for (int r = 0; r < NR; ++r) acc[r] += er * v[r];
+      for (int r = 0; r < NR; ++r) acc[r] += er * v[r];
+    } else {
+#pragma unroll
+      for (int q = 0; q < NR / 2; ++q) {
+        acc[2 * q] += er * v[2 * q] - ei * v[2 * q + 1];
+        acc[2 * q + 1] += er * v[2 * q + 1] + ei * v[2 * q];
+      }
+    }
+  } else if (!Z) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = __builtin_fma(er, v[r], acc[r]);
   } else {
+    // (the two terms of an accumulator NR instructions apart: back to back the second waits for the first)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = __builtin_fma(er, v[r], acc[r]);
 #pragma unroll
     for (int q = 0; q < NR / 2; ++q) {
-      acc[2 * q] += er * v[2 * q] - ei * v[2 * q + 1];
-      acc[2 * q + 1] += er * v[2 * q + 1] + ei * v[2 * q];
+      acc[2 * q] = __builtin_fma(-ei, v[2 * q + 1], acc[2 * q]);
+      acc[2 * q + 1] = __builtin_fma(ei, v[2 * q], acc[2 * q + 1]);
     }
   }
 }
@@ -1135,7 +1154,7 @@ __device__ __forceinline__ void mac_cols(double (&acc)[NR], double er, double ei
 // (Z: a complex dense matrix in two planes, Band::zoff; the transposed modes are then CONJUGATE transposes)
 template <int MODE, int NR, bool Z = false>
 __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, const double (*vv)[NR],
-                                       double (*res)[NR], double (*part)[64][NR]) {
+                                       double (*res)[NR], double *part) {
   constexpr int SWV = solve_waves<NR>();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (MODE <= 1) {
@@ -1162,13 +1181,13 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
       }
     }
 #pragma unroll
-    for (int r = 0; r < NR; ++r) part[wave][lane][r] = acc[r];
+    for (int r = 0; r < NR; ++r) part[(wave * NR + r) * 64 + lane] = acc[r];  // (lanes side by side: no bank conflicts)
     __syncthreads();
     for (int o = threadIdx.x; o < 64 * NR; o += SWV * 64) {
-      const int l = o / NR, r = o % NR;
+      const int r = o / 64, l = o % 64;
       double tot = 0.0;
 #pragma unroll
-      for (int q = 0; q < SWV; ++q) tot += part[q][l][r];
+      for (int q = 0; q < SWV; ++q) tot += part[(q * NR + r) * 64 + l];
       res[l][r] = tot;
     }
   } else {
@@ -1213,50 +1232,159 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
   __syncthreads();
 }
 
-// res[l][r] = sum_t T(l, t) * w[t][r] with T = inv(L11), inv(U11), inv(U11)^T, inv(L11)^T (MODE 0..3);
-// inv is column-major NB x NB.
-template <int MODE, int NR, bool Z = false>
-__device__ __forceinline__ void gemv_inv(const double *__restrict__ inv, const double (*w)[NR], double (*res)[NR],
-                                         double (*part)[64][NR]) {
-  constexpr int SWV = solve_waves<NR>();
+// ---- the solve inside a super block -----------------------------------------------------------------------------------
+// A super block is SB sub-blocks of 64 unknowns; sub-block k needs (1) its couplings with the k sub-blocks solved
+// before it, (2) the stored inverse of its diagonal block, (3) its right-hand side.  Round 3 took two of the three
+// dependent rounds of global loads per sub-block out of the chain of barriers: the right-hand side of the whole super
+// block is read once, into v, before the first sub-block (a sub-block replaces its 64 entries of v by the solution), and
+// the entries of the inverse a thread multiplies with are fetched into registers one sub-block AHEAD (ie / iei), so they
+// travel while the previous sub-block goes through its barriers.  The couplings are loaded where they are used, eight
+// (or two strips) in flight per thread: a sub-block ahead they would take up to 3 x 64 / wavefronts (complex: twice
+// that) more registers per thread, which the kernels with 16 columns do not have (the compiler spills them: measured,
+// 83 -> 148 us per step).  Partial sums of the wavefronts meet in LDS as part[wave][r][lane] (lanes side by side: no
+// bank conflicts), and the reductions write w / v directly.
+// Untransposed (MODE 0/1): lane = row, the wavefronts split the columns.  Transposed (MODE 2/3): lanes along the
+// columns, the wavefronts split the rows, butterfly reduction.
+template <int MODE, int NR, bool Z>
+__device__ __forceinline__ void inverse_load(const double *__restrict__ inv, double *ie, double *iei) {
+  constexpr int SWV = solve_waves<NR>(), NE = NB / SWV;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {  // MODE <= 1: T(lane, t), t = wave + SWV u;  transposed: T(l, lane) = inv(lane, l), l likewise
+    const int idx = lane + (wave + SWV * u) * NB;
+    ie[u] = inv[idx];
+    if (Z) iei[u] = MODE <= 1 ? inv[NB * NB + idx] : -inv[NB * NB + idx];
+  }
+}
+
+// w[l][:] = raw[l][:] - sum_{t < nc} M(rb + l, cb + t) vv[t][:], l < jb (0 beyond)
+template <int MODE, int NR, bool Z>
+__device__ __forceinline__ void coupling_apply(const Band &b, int rb, int cb, int nc, const double (*vv)[NR],
+                                               const double (*raw)[NR], int jb, double (*w)[NR], double *part) {
+  constexpr int SWV = solve_waves<NR>(), NE = NB / SWV;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (nc <= 0) {  // (uniform) the first sub-block of a pass
+    for (int o = threadIdx.x; o < NB * NR; o += SWV * 64) {
+      const int l = o / NR, r = o % NR;
+      w[l][r] = l < jb ? raw[l][r] : 0.0;
+    }
+  } else if (MODE <= 1) {
+    const int i = rb + lane;
+    double acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = 0.0;
+    if (i >= 0 && i < b.n) {
+      int t = wave;
+      for (; t + 7 * SWV < nc; t += 8 * SWV) {  // 8 independent loads in flight per lane
+        double e[8], ei[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          e[u] = b.get(i, cb + t + SWV * u);
+          ei[u] = Z ? (&b.at(i, cb + t + SWV * u))[b.zoff] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mac_cols<NR, Z>(acc, e[u], ei[u], &vv[t + SWV * u][0]);
+      }
+      for (; t < nc; t += SWV) {
+        const double e = b.get(i, cb + t);
+        const double ei = Z ? (&b.at(i, cb + t))[b.zoff] : 0.0;
+        mac_cols<NR, Z>(acc, e, ei, &vv[t][0]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) part[(wave * NR + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 64 * NR; o += SWV * 64) {
+      const int r = o / 64, l = o % 64;
+      double tot = 0.0;
+#pragma unroll
+      for (int q = 0; q < SWV; ++q) tot += part[(q * NR + r) * 64 + l];
+      w[l][r] = l < jb ? raw[l][r] - tot : 0.0;
+    }
+  } else {
+    // nc <= (SB - 1) * 64: at most 3 strips of 64 columns, two of them in flight together
+    double acc[NE][NR];
+#pragma unroll
+    for (int q = 0; q < NE; ++q)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[q][r] = 0.0;
+    for (int u0 = 0; u0 * 64 < nc; u0 += 2) {
+      double e[2][NE], ei[2][NE];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = lane + 64 * (u0 + u);
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+          const int i = rb + wave + SWV * q;
+          const bool in = t < nc && i >= 0 && i < b.n;
+          e[u][q] = in ? b.get(cb + t, i) : 0.0;
+          ei[u][q] = (Z && in) ? -(&b.at(cb + t, i))[b.zoff] : 0.0;  // conjugate transpose
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = lane + 64 * (u0 + u);
+        if (t < nc) {
+#pragma unroll
+          for (int q = 0; q < NE; ++q) mac_cols<NR, Z>(acc[q], e[u][q], ei[u][q], &vv[t][0]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int l = wave + SWV * q;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        double sacc = acc[q][r];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
+        if (lane == 0) w[l][r] = l < jb ? raw[l][r] - sacc : 0.0;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// dst[l][:] = sum_t T(l, t) w[t][:], l < jb, with T = inv(L11), inv(U11), inv(U11)^T, inv(L11)^T (MODE 0..3) in ie / iei
+template <int MODE, int NR, bool Z, class Prefetch>
+__device__ __forceinline__ void inverse_apply(const double *ie, const double *iei, const double (*w)[NR], int jb,
+                                              double (*dst)[NR], double *part, Prefetch prefetch) {
+  constexpr int SWV = solve_waves<NR>(), NE = NB / SWV;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (MODE <= 1) {
     double acc[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = 0.0;
 #pragma unroll
-    for (int u = 0; u < NB / SWV; ++u) {
-      const int t = wave + SWV * u;
-      const double e = inv[lane + t * NB];
-      const double ei = Z ? inv[NB * NB + lane + t * NB] : 0.0;
-      mac_cols<NR, Z>(acc, e, ei, &w[t][0]);
-    }
+    for (int u = 0; u < NE; ++u) mac_cols<NR, Z>(acc, ie[u], Z ? iei[u] : 0.0, &w[wave + SWV * u][0]);
+    prefetch();
 #pragma unroll
-    for (int r = 0; r < NR; ++r) part[wave][lane][r] = acc[r];
+    for (int r = 0; r < NR; ++r) part[(wave * NR + r) * 64 + lane] = acc[r];
     __syncthreads();
     for (int o = threadIdx.x; o < 64 * NR; o += SWV * 64) {
-      const int l = o / NR, r = o % NR;
+      const int r = o / 64, l = o % 64;
       double tot = 0.0;
 #pragma unroll
-      for (int q = 0; q < SWV; ++q) tot += part[q][l][r];
-      res[l][r] = tot;
+      for (int q = 0; q < SWV; ++q) tot += part[(q * NR + r) * 64 + l];
+      if (l < jb) dst[l][r] = tot;
     }
   } else {
-    for (int l = wave; l < 64; l += SWV) {
-      const double e = inv[lane + l * NB];  // T(l, t) = inv(t, l) (Z: conjugated)
-      const double ei = Z ? -inv[NB * NB + lane + l * NB] : 0.0;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int l = wave + SWV * u;
       double prod[NR];
 #pragma unroll
       for (int r = 0; r < NR; ++r) prod[r] = 0.0;
-      mac_cols<NR, Z>(prod, e, ei, &w[lane][0]);
+      mac_cols<NR, Z>(prod, ie[u], Z ? iei[u] : 0.0, &w[lane][0]);
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         double sacc = prod[r];
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
-        if (lane == 0) res[l][r] = sacc;
+        if (lane == 0 && l < jb) dst[l][r] = sacc;
       }
     }
+    prefetch();
   }
   __syncthreads();
 }
@@ -1269,36 +1397,39 @@ template <int MODE, int NR, bool Z = false>
 __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__restrict__ invs, int j0, int jbs,
                                                  double *in, double *__restrict__ out, size_t stride, int tile,
                                                  double *dsm, int tiles = 1) {
-  constexpr int SWV = solve_waves<NR>();
+  constexpr int SWV = solve_waves<NR>(), NE = NB / SWV;
   double(*v)[NR] = reinterpret_cast<double(*)[NR]>(dsm);                          // [SB * NB]
   double(*w)[NR] = reinterpret_cast<double(*)[NR]>(dsm + SB * NB * NR);           // [NB]
   double(*res)[NR] = reinterpret_cast<double(*)[NR]>(dsm + (SB + 1) * NB * NR);   // [NB]
-  double(*part)[64][NR] = reinterpret_cast<double(*)[64][NR]>(dsm + (SB + 2) * NB * NR);  // [SWV]
+  double *part = dsm + (SB + 2) * NB * NR;                                        // [SWV][NR][64]
   constexpr bool fwd = (MODE == 0 || MODE == 2);
   const int tid = threadIdx.x;
   const int nsub = (jbs + NB - 1) / NB;
-  for (int t = tid; t < SB * NB * NR; t += SWV * 64) (&v[0][0])[t] = 0.0;
-  __syncthreads();
-  for (int k = 0; k < nsub; ++k) {
-    const int sblk = fwd ? k : nsub - 1 - k;
-    const int js = j0 + sblk * NB, jb = min(NB, j0 + jbs - js);
-    // couplings with the sub-blocks of this super block that are already solved
-    const int cb = fwd ? j0 : js + jb;
-    const int nc = fwd ? js - j0 : j0 + jbs - (js + jb);
-    gemv64<MODE, NR, Z>(b, js, cb, nc, v + (cb - j0), res, part);
-    for (int o = tid; o < NB * NR; o += SWV * 64) {
-      const int l = o % NB, r = o / NB;
-      w[l][r] = l < jb ? in[(size_t)r * stride + js + l] - res[l][r] : 0.0;
-    }
-    __syncthreads();
+  {
+    double ie[NE], iei[NE];
     constexpr size_t blk = Z ? (size_t)kInvBlockZ : (size_t)(2 * NB * NB);
-    const double *inv = invs + (size_t)(js / NB) * blk + ((MODE == 1 || MODE == 2) ? blk / 2 : 0);
-    gemv_inv<MODE, NR, Z>(inv, w, res, part);
-    for (int o = tid; o < NB * NR; o += SWV * 64) {
-      const int l = o % NB, r = o / NB;
-      if (l < jb) v[js - j0 + l][r] = res[l][r];
+    constexpr size_t half = (MODE == 1 || MODE == 2) ? blk / 2 : 0;
+    inverse_load<MODE, NR, Z>(invs + (size_t)(j0 / NB + (fwd ? 0 : nsub - 1)) * blk + half, ie, iei);
+    // v starts as the right-hand side of the super block; every sub-block replaces its 64 entries by the solution
+    for (int o = tid; o < SB * NB * NR; o += SWV * 64) {
+      const int t = o % (SB * NB), r = o / (SB * NB);
+      v[t][r] = t < jbs ? in[(size_t)r * stride + j0 + t] : 0.0;
     }
     __syncthreads();
+    for (int k = 0; k < nsub; ++k) {
+      const int sblk = fwd ? k : nsub - 1 - k;
+      const int js = j0 + sblk * NB, jb = min(NB, j0 + jbs - js);
+      // couplings with the sub-blocks of this super block that are already solved
+      const int cb = fwd ? j0 : js + jb;
+      const int nc = fwd ? js - j0 : j0 + jbs - (js + jb);
+      coupling_apply<MODE, NR, Z>(b, js, cb, nc, v + (cb - j0), v + (js - j0), jb, w, part);
+      // (the last sub-block fetches its own inverse again: a branch here would make the compiler sink the multiplications
+      // of inverse_apply below it, with every operand they read from LDS kept in registers meanwhile)
+      const int next = k + 1 < nsub ? (fwd ? sblk + 1 : sblk - 1) : sblk;
+      inverse_apply<MODE, NR, Z>(ie, iei, w, jb, v + (js - j0), part, [&]() {
+        inverse_load<MODE, NR, Z>(invs + (size_t)(j0 / NB + next) * blk + half, ie, iei);
+      });
+    }
   }
   if (tile == 0)
     for (int o = tid; o < jbs * NR; o += SWV * 64) {

@@ -696,7 +696,7 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_kernel(const i
           double xv[NR];
 #pragma unroll
           for (int r = 0; r < NR; ++r) xv[r] = xb[(size_t)r * fs + k + GW * u];
-          mac_cols<NR, Z>(acc, e[u], ei[u], xv);
+          mac_cols<NR, Z, false>(acc, e[u], ei[u], xv);
         }
       }
       for (; k < nb; k += GW) {
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_kernel(const i
         double xv[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) xv[r] = xb[(size_t)r * fs + k];
-        mac_cols<NR, Z>(acc, e, ei, xv);
+        mac_cols<NR, Z, false>(acc, e, ei, xv);
       }
     }
 #pragma unroll
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_kernel(const i
 #pragma unroll
         for (int r = 0; r < NR; ++r) xv[r] = xb[(size_t)r * fs + k];
 #pragma unroll
-        for (int u = 0; u < RW; ++u) mac_cols<NR, Z>(acc[u], e[u], ei[u], xv);
+        for (int u = 0; u < RW; ++u) mac_cols<NR, Z, false>(acc[u], e[u], ei[u], xv);
       }
 #pragma unroll
       for (int u = 0; u < RW; ++u)
