@@ -594,7 +594,7 @@ __global__ __launch_bounds__(kSolveThreads) void solve_backward_kernel(const int
 // (prefix = workgroups before each front, computed on the host when the factors are built): one
 // launch per step and level however many fronts the level holds.
 struct BigFront {
-  int f, np, nb, fs, ldp, ldu, blk;  // blk: index of this workgroup inside its front
+  int f, np, nb, fs, ldp, ldu, blk, item;  // blk: index of this workgroup inside its front; item: of the front in the list
   const double *P, *U;
   double *W, *Z;
   size_t pz, uz;  // complex fronts: offsets of the imaginary planes of P and U (0: real)
@@ -607,6 +607,7 @@ __device__ __forceinline__ BigFront big_front(const int *__restrict__ list, cons
   const int f = list[fi];
   BigFront b;
   b.f = f;
+  b.item = fi;
   b.np = t.np[f];
   b.nb = t.nb[f];
   b.fs = b.np + b.nb;
@@ -684,15 +685,18 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_kernel(const i
     if (i < np) {
       const double *row = U + (size_t)i;
       int k = wave;
-      for (; k + 7 * GW < nb; k += 8 * GW) {
-        double e[8], ei[8];
+      // UF entries in flight per lane: a level has few large fronts, so the kernel is bound by the bytes a workgroup
+      // keeps in flight (8 wavefronts with 16 columns have the registers for twice as many)
+      constexpr int UF = NR >= 16 ? 16 : 8;
+      for (; k + (UF - 1) * GW < nb; k += UF * GW) {
+        double e[UF], ei[UF];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UF; ++u) {
           e[u] = row[(size_t)(k + GW * u) * ldu];
           ei[u] = Z ? row[(size_t)(k + GW * u) * ldu + b.uz] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UF; ++u) {
           double xv[NR];
 #pragma unroll
           for (int r = 0; r < NR; ++r) xv[r] = xb[(size_t)r * fs + k + GW * u];
@@ -751,6 +755,93 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_kernel(const i
           if (lane == 0 && i0 + rr + u < np) z[(size_t)r * fs + i0 + rr + u] -= acc[u][r];
         }
     }
+  }
+}
+
+// The untransposed product again, spread over more workgroups (round 3).  A level of the upper tree has few large
+// fronts and a front np / 64 blocks of rows: with one workgroup per block the kernel above keeps 40 - 150 CUs busy, each
+// with 64 x nb x NR multiply-adds — for 16 columns that is the issue rate of ONE CU's vector pipes per block (195 us
+// per launch at 80^3, 1 TB/s).  Here a workgroup takes 64 rows x kGemvChunk boundary columns; the entries of x it needs
+// go through LDS once (k-major, so a multiply-add reads its NR values as broadcast 16-byte words and the fused form of
+// mac_cols pays).  Fronts with one chunk subtract their sums from Z directly; the chunks of larger ones write partial
+// sums to scratch ([chunk][r][i] behind the front's offset) and big_gemv_reduce_kernel subtracts them in chunk order:
+// the result does not depend on the schedule.
+constexpr int kGemvChunk = 512;
+template <int NR, bool Z = false>
+__global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(const int *__restrict__ list,
+                                                                               const int64_t *__restrict__ prefix, int count,
+                                                                               TreeView t, double *work, double *zbuf,
+                                                                               const int64_t *__restrict__ pofs,
+                                                                               double *__restrict__ scratch) {
+  constexpr int GW = gemv_waves<NR>();
+  extern __shared__ __attribute__((aligned(16))) double gsm[];
+  double(*xs)[NR] = reinterpret_cast<double(*)[NR]>(gsm);  // [kGemvChunk]
+  double *part = gsm + (size_t)kGemvChunk * NR;              // [GW][NR][64]
+  const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
+  const int np = b.np, nb = b.nb, fs = b.fs, ldu = b.ldu;
+  const int nch = (nb + kGemvChunk - 1) / kGemvChunk;
+  const int rb = b.blk / nch, ch = b.blk - rb * nch;
+  const int i0 = rb * 64, k0 = ch * kGemvChunk, kn = min(kGemvChunk, nb - k0);
+  const double *xb = b.W + b.np + k0;
+  for (int o = threadIdx.x; o < kn * NR; o += GW * 64) {
+    const int kk = o % kn, r = o / kn;
+    xs[kk][r] = xb[(size_t)r * fs + kk];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = i0 + lane;
+  double acc[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) acc[r] = 0.0;
+  if (i < np) {
+    const double *row = b.U + (size_t)i + (size_t)k0 * ldu;
+    int k = wave;
+    for (; k + 7 * GW < kn; k += 8 * GW) {
+      double e[8], ei[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        e[u] = row[(size_t)(k + GW * u) * ldu];
+        ei[u] = Z ? row[(size_t)(k + GW * u) * ldu + b.uz] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) mac_cols<NR, Z>(acc, e[u], ei[u], &xs[k + GW * u][0]);
+    }
+    for (; k < kn; k += GW) {
+      const double e = row[(size_t)k * ldu];
+      const double ei = Z ? row[(size_t)k * ldu + b.uz] : 0.0;
+      mac_cols<NR, Z>(acc, e, ei, &xs[k][0]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) part[(wave * NR + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  double *out = nch > 1 ? scratch + (size_t)pofs[b.item] * NR + (size_t)ch * NR * np : nullptr;
+  for (int o = threadIdx.x; o < 64 * NR; o += GW * 64) {
+    const int r = o / 64, l = o % 64;
+    if (i0 + l >= np) continue;
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < GW; ++q) tot += part[(q * NR + r) * 64 + l];
+    if (out) out[(size_t)r * np + i0 + l] = tot;
+    else b.Z[(size_t)r * fs + i0 + l] -= tot;
+  }
+}
+
+template <int NR>
+__global__ __launch_bounds__(256) void big_gemv_reduce_kernel(const int *__restrict__ list, const int64_t *__restrict__ prefix,
+                                                              int count, TreeView t, double *work, double *zbuf,
+                                                              const int64_t *__restrict__ pofs,
+                                                              const double *__restrict__ scratch) {
+  const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
+  const int i = b.blk * 256 + (int)threadIdx.x;
+  if (i >= b.np) return;
+  const int nch = (b.nb + kGemvChunk - 1) / kGemvChunk;
+  const double *in = scratch + (size_t)pofs[b.item] * NR;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    double tot = 0.0;
+    for (int c = 0; c < nch; ++c) tot += in[((size_t)c * NR + r) * b.np + i];
+    b.Z[(size_t)r * b.fs + i] -= tot;
   }
 }
 
@@ -827,6 +918,7 @@ struct Factors {
   int singular = 0;
   int zm = 1;         // 2: complex fronts in two planes (TreeView::zm)
   int big_solve = 0;  // fronts above this size are solved by many workgroups (kBigSolve; SPL_MF_BIGSOLVE)
+  int64_t gemv_scratch = 0;  // doubles per right-hand-side column the chunked boundary product of a level needs at most
   // those fronts, per depth, and the flat grids of their lockstep solve kernels: segments of
   // count + 1 prefix sums (workgroups before each front), in this order: untransposed forward
   // steps [0, steps), transposed forward steps, backward steps, then the boundary kernel of the
@@ -837,7 +929,9 @@ struct Factors {
     DBuf<int> list;
     std::vector<int64_t> h;
     DBuf<int64_t> d;
-    size_t seg(int kind, int k = 0) const {  // kind 0 fwd, 1 fwd^T, 2 bwd, 3 boundary^T, 4 gather, 5 gemv, 6 scatter
+    // kind 0 fwd, 1 fwd^T, 2 bwd, 3 boundary^T, 4 gather, 5 gemv (transposed), 6 scatter, 7 gemv in chunks, 8 its
+    // reduction, 9 offsets of the fronts in its scratch (doubles per column)
+    size_t seg(int kind, int k = 0) const {
       const size_t which = kind < 3 ? (size_t)kind * (size_t)steps + (size_t)k : (size_t)3 * steps + (size_t)(kind - 3);
       return which * (size_t)(count + 1);
     }
@@ -1087,7 +1181,7 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
         for (int f : large) first_step += (T.fs(f) + 63) / 64;
         B.row_blocks = first_step >= 4096 ? kSolveRowBlocks : 1;
         const int rbk = B.row_blocks;
-        B.h.assign((size_t)(3 * B.steps + 4) * (size_t)(B.count + 1), 0);
+        B.h.assign((size_t)(3 * B.steps + 7) * (size_t)(B.count + 1), 0);
         auto fill = [&](int kind, int k, auto groups_of) {
           int64_t *pre = B.h.data() + B.seg(kind, k);
           for (int i = 0; i < B.count; ++i) pre[i + 1] = pre[i] + groups_of(large[(size_t)i]);
@@ -1111,6 +1205,11 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
         fill(4, 0, [&](int f) -> int64_t { return (T.nb[(size_t)f] + 255) / 256; });
         fill(5, 0, [&](int f) -> int64_t { return T.nb[(size_t)f] > 0 ? (T.np[(size_t)f] + 63) / 64 : 0; });
         fill(6, 0, [&](int f) -> int64_t { return (T.np[(size_t)f] + 255) / 256; });
+        auto chunks = [&](int f) -> int64_t { return (T.nb[(size_t)f] + kGemvChunk - 1) / kGemvChunk; };
+        fill(7, 0, [&](int f) -> int64_t { return (int64_t)((T.np[(size_t)f] + 63) / 64) * chunks(f); });
+        fill(8, 0, [&](int f) -> int64_t { return chunks(f) > 1 ? (T.np[(size_t)f] + 255) / 256 : 0; });
+        fill(9, 0, [&](int f) -> int64_t { return chunks(f) > 1 ? chunks(f) * T.np[(size_t)f] : 0; });
+        F.gemv_scratch = std::max(F.gemv_scratch, B.h[B.seg(9) + (size_t)B.count]);
         staged.push_back(std::move(large));
         upload_vec(B.list, staged.back(), s);
         upload_vec(B.d, B.h, s);
@@ -1395,7 +1494,7 @@ static void launch_big_super(const mf::Factors &F, const mf::Factors::BigLevel &
 
 template <bool TRANS, int NR, bool Z = false>
 static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride, double *work, double *zbuf,
-                                  hipStream_t s) {
+                                  double *gscr, hipStream_t s) {
   const mf::Tree &T = *F.tree;
   const int nd = T.maxdepth + 1;
   double *invs = F.invs.get();
@@ -1451,8 +1550,23 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
       if (B.total(4) > 0) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gather_x_kernel<NR, Z>), dim3(B.total(4)), dim3(256), 0, s, B.list.get(),
                            B.prefix(4), B.count, F.view, c, stride, work, zbuf);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_kernel<TRANS, NR, Z>), dim3(B.total(5)), dim3(gemv_waves<NR>() * 64), 0, s,
-                           B.list.get(), B.prefix(5), B.count, F.view, work, zbuf);
+        if (TRANS) {
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_kernel<TRANS, NR, Z>), dim3(B.total(5)), dim3(gemv_waves<NR>() * 64), 0, s,
+                             B.list.get(), B.prefix(5), B.count, F.view, work, zbuf);
+        } else {
+          constexpr size_t lds = (size_t)(kGemvChunk + gemv_waves<NR>() * 64) * NR * sizeof(double);
+          static std::atomic<uint64_t> attr_set{0};  // one mask per instantiation, one bit per device
+          if (first_use_on_this_device(attr_set)) {
+            SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&big_gemv_chunk_kernel<NR, Z>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            mark_used_on_this_device(attr_set);
+          }
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_chunk_kernel<NR, Z>), dim3(B.total(7)), dim3(gemv_waves<NR>() * 64), lds, s,
+                             B.list.get(), B.prefix(7), B.count, F.view, work, zbuf, B.prefix(9), gscr);
+          if (B.total(8) > 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_reduce_kernel<NR>), dim3(B.total(8)), dim3(256), 0, s, B.list.get(),
+                               B.prefix(8), B.count, F.view, work, zbuf, B.prefix(9), gscr);
+        }
       }
       // the pivot block alone; columns of Z / W are fs apart
       for (int k = 0; k < B.steps; ++k) launch_big_super<BWD, NR, Z>(F, B, 2, k, work, zbuf, s);
@@ -1474,35 +1588,35 @@ void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride,
     // right-hand side is two real columns of the work matrices: one at a time, or four together
     constexpr int kGroupZ = 8;  // = kSolveGroup columns of the caller, each a packed complex vector: 16 real columns
     const int nrz = k == 1 ? 2 : 2 * kGroupZ;
-    DBuf<double> wz((size_t)T.work_elems * nrz * 2);  // work and z matrices
-    double *wk = wz.get(), *zb = wz.get() + (size_t)T.work_elems * nrz;
+    DBuf<double> wz(((size_t)T.work_elems * 2 + (size_t)F.gemv_scratch) * nrz);  // work and z matrices, scratch of the boundary products
+    double *wk = wz.get(), *zb = wz.get() + (size_t)T.work_elems * nrz, *gs = zb + (size_t)T.work_elems * nrz;
     if (k == 1) {
-      if (sys == 0) solve_columns_on_tree<false, 2, true>(F, d_c, stride, wk, zb, s);
-      else solve_columns_on_tree<true, 2, true>(F, d_c, stride, wk, zb, s);
+      if (sys == 0) solve_columns_on_tree<false, 2, true>(F, d_c, stride, wk, zb, gs, s);
+      else solve_columns_on_tree<true, 2, true>(F, d_c, stride, wk, zb, gs, s);
     } else {
       for (int c0 = 0; c0 < k; c0 += kGroupZ) {  // (k is a multiple of kSolveGroup = 8 here: zero-padded by the caller)
         double *c = d_c + (size_t)c0 * stride;
-        if (sys == 0) solve_columns_on_tree<false, 2 * kGroupZ, true>(F, c, stride, wk, zb, s);
-        else solve_columns_on_tree<true, 2 * kGroupZ, true>(F, c, stride, wk, zb, s);
+        if (sys == 0) solve_columns_on_tree<false, 2 * kGroupZ, true>(F, c, stride, wk, zb, gs, s);
+        else solve_columns_on_tree<true, 2 * kGroupZ, true>(F, c, stride, wk, zb, gs, s);
       }
     }
     SPL_HIP(hipStreamSynchronize(s));
     return;
   }
   const int nr = k == 1 ? 1 : kSolveGroup;
-  DBuf<double> both((size_t)T.work_elems * nr * 2);  // work and z matrices of all fronts, one allocation
+  DBuf<double> both(((size_t)T.work_elems * 2 + (size_t)F.gemv_scratch) * nr);  // work and z matrices of all fronts, scratch: one allocation
   struct Span {
     double *p;
     double *get() const { return p; }
-  } work{both.get()}, zbuf{both.get() + (size_t)T.work_elems * nr};
+  } work{both.get()}, zbuf{both.get() + (size_t)T.work_elems * nr}, gscr{both.get() + (size_t)T.work_elems * nr * 2};
   if (k == 1) {
-    if (sys == 0) solve_columns_on_tree<false, 1>(F, d_c, stride, work.get(), zbuf.get(), s);
-    else solve_columns_on_tree<true, 1>(F, d_c, stride, work.get(), zbuf.get(), s);
+    if (sys == 0) solve_columns_on_tree<false, 1>(F, d_c, stride, work.get(), zbuf.get(), gscr.get(), s);
+    else solve_columns_on_tree<true, 1>(F, d_c, stride, work.get(), zbuf.get(), gscr.get(), s);
   } else {
     for (int c0 = 0; c0 < k; c0 += kSolveGroup) {
       double *c = d_c + (size_t)c0 * stride;
-      if (sys == 0) solve_columns_on_tree<false, kSolveGroup>(F, c, stride, work.get(), zbuf.get(), s);
-      else solve_columns_on_tree<true, kSolveGroup>(F, c, stride, work.get(), zbuf.get(), s);
+      if (sys == 0) solve_columns_on_tree<false, kSolveGroup>(F, c, stride, work.get(), zbuf.get(), gscr.get(), s);
+      else solve_columns_on_tree<true, kSolveGroup>(F, c, stride, work.get(), zbuf.get(), gscr.get(), s);
     }
   }
   SPL_HIP(hipStreamSynchronize(s));  // the work matrices are freed on return
