@@ -357,7 +357,9 @@ constexpr int kStreams = 8;        // larger fronts of a level are spread over t
 // ---- solves ---------------------------------------------------------------------------------------
 // NR right-hand sides travel through the tree together: every front has a work matrix W (fs x NR,
 // column-major), column r of the right-hand sides / solution is c + r * stride.
-constexpr int kSolveThreads = 1024;  // one workgroup per front, 16 wavefronts for the coupling loops
+constexpr int kSolveThreads = 1024;  // one workgroup per front, 16 wavefronts for the coupling loops ...
+template <int NR>
+constexpr int solve_threads() { return NR >= 16 ? 512 : kSolveThreads; }  // ... 8 with 16 columns (256 registers per thread)
 constexpr int kSolveRowBlocks = 4;   // blocks of 64 rows per workgroup in the lockstep solve steps
 constexpr int kBigSolve = 256;       // fronts above this size are solved by many workgroups, in lockstep
 
@@ -420,31 +422,45 @@ __device__ __forceinline__ void couple_block(const Panels &fr, int ilo, int ihi,
                                              const double (*v)[NR], double *W) {
   const int fs = fr.fs;
   if (!TRANS) {
+    // A wavefront takes 16 rows, its four quarters a quarter of the columns each (tt = g, g + 4, ...): a front of this
+    // class has at most 256 rows, so with a thread per row three quarters of the workgroup idled while every row walked
+    // its 64 columns eight loads at a time (round 3: two rounds of loads instead of eight, and all 16 wavefronts
+    // multiply; the quarters meet by two shuffles per column of W)
     const double *base = fr.col(c0);
     const size_t cs = (size_t)fr.col_stride(c0), zp = fr.zcol(c0);
-    for (int i = ilo + threadIdx.x; i < ihi; i += blockDim.x) {
-      const double *row = base + i;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int g = lane >> 4, rl = lane & 15;
+    const int nu = (jb - g + 3) / 4;  // columns of this quarter
+    for (int ib = ilo + wave * 16; ib < ihi; ib += nw * 16) {
+      const int i = ib + rl;
       double acc[NR];
 #pragma unroll
       for (int r = 0; r < NR; ++r) acc[r] = 0.0;
-      int tt = 0;
-      for (; tt + 8 <= jb; tt += 8) {
-        double e[8], ei[8];
+      if (i < ihi) {
+        const double *row = base + i + (size_t)g * cs;
+        int u = 0;
+        for (; u + 8 <= nu; u += 8) {
+          double e[8], ei[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          e[u] = row[(size_t)(tt + u) * cs];
-          ei[u] = Z ? row[(size_t)(tt + u) * cs + zp] : 0.0;
+          for (int q = 0; q < 8; ++q) {
+            e[q] = row[(size_t)(4 * (u + q)) * cs];
+            ei[q] = Z ? row[(size_t)(4 * (u + q)) * cs + zp] : 0.0;
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) mac_cols<NR, Z>(acc, e[q], ei[q], &v[g + 4 * (u + q)][0]);
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) mac_cols<NR, Z>(acc, e[u], ei[u], &v[tt + u][0]);
-      }
-      for (; tt < jb; ++tt) {
-        const double e = row[(size_t)tt * cs];
-        const double ei = Z ? row[(size_t)tt * cs + zp] : 0.0;
-        mac_cols<NR, Z>(acc, e, ei, &v[tt][0]);
+        for (; u < nu; ++u) {
+          const double e = row[(size_t)(4 * u) * cs];
+          const double ei = Z ? row[(size_t)(4 * u) * cs + zp] : 0.0;
+          mac_cols<NR, Z>(acc, e, ei, &v[g + 4 * u][0]);
+        }
       }
 #pragma unroll
-      for (int r = 0; r < NR; ++r) W[(size_t)r * fs + i] -= acc[r];
+      for (int r = 0; r < NR; ++r) {
+        acc[r] += __shfl_xor(acc[r], 16, 64);
+        acc[r] += __shfl_xor(acc[r], 32, 64);
+        if (g == 0 && i < ihi) W[(size_t)r * fs + i] -= acc[r];
+      }
     }
   } else {
     // M(i, c0 + tt) = F(c0 + tt, i) (Z: its conjugate): rows c0 .. of column i of F, contiguous
@@ -513,7 +529,7 @@ __global__ __launch_bounds__(256) void solve_gather_kernel(const int *__restrict
 // forward elimination inside a front: y = M11^-1 W[0:np) block by block (stored inverses of the diagonal
 // blocks), every later entry of W loses its coupling with the block just solved
 template <bool TRANS, int NR, bool Z = false>
-__global__ __launch_bounds__(kSolveThreads) void solve_forward_kernel(const int *__restrict__ list, TreeView t,
+__global__ __launch_bounds__(solve_threads<NR>()) void solve_forward_kernel(const int *__restrict__ list, TreeView t,
                                                                       const double *__restrict__ invs,
                                                                       double *__restrict__ work) {
   __shared__ double w[NB][NR], v[NB][NR];
@@ -545,7 +561,7 @@ __global__ __launch_bounds__(kSolveThreads) void solve_forward_kernel(const int 
 // back substitution inside a front: x_piv = M11^-1 (y - M12 x_bnd), x_bnd read from the solution of
 // the ancestors; writes the pivots' part of the solution
 template <bool TRANS, int NR, bool Z = false>
-__global__ __launch_bounds__(kSolveThreads) void solve_backward_kernel(const int *__restrict__ list, TreeView t,
+__global__ __launch_bounds__(solve_threads<NR>()) void solve_backward_kernel(const int *__restrict__ list, TreeView t,
                                                                        const double *__restrict__ invs,
                                                                        double *__restrict__ work,
                                                                        double *__restrict__ x, size_t stride) {
@@ -1526,7 +1542,7 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
         }
     if (F.solve_counts[(size_t)d] > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_forward_kernel<TRANS, NR, Z>), dim3((unsigned)F.solve_counts[(size_t)d]),
-                         dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work);
+                         dim3(solve_threads<NR>()), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work);
     lap("up small  ", d);
     const mf::Factors::BigLevel &B = F.big[(size_t)d];
     if (B.count > 0) {
@@ -1542,7 +1558,7 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
   for (int d = 0; d < nd; ++d) {
     if (F.solve_counts[(size_t)d] > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_backward_kernel<TRANS, NR, Z>), dim3((unsigned)F.solve_counts[(size_t)d]),
-                         dim3(kSolveThreads), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work, c,
+                         dim3(solve_threads<NR>()), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work, c,
                          stride);
     lap("down small", d);
     const mf::Factors::BigLevel &B = F.big[(size_t)d];
