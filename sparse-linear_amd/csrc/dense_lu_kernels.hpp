@@ -1345,6 +1345,114 @@ __device__ __forceinline__ void coupling_apply(const Band &b, int rb, int cb, in
   __syncthreads();
 }
 
+// The couplings a sub-block ahead as well, where the registers allow (couplings_ahead): K strips of 64 columns, NE
+// entries per strip and thread, loaded without a branch (an entry outside the system or the band is read from the first
+// word of the array and replaced by zero: a branch per entry makes the compiler wait for every load where it is issued,
+// and a branch around the loads makes it sink the multiplications of the step below them).
+template <int NR, bool Z>
+constexpr bool couplings_ahead() { return NR <= 2; }
+
+template <int MODE, int NR, bool Z, int K>
+__device__ __forceinline__ void coupling_load(const Band &b, int rb, int cb, int nc, double *ce, double *cei) {
+  constexpr int SWV = solve_waves<NR>(), NE = NB / SWV;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (MODE <= 1) {
+    const int i = rb + lane;
+    const bool row = i >= 0 && i < b.n;
+#pragma unroll
+    for (int j = 0; j < K * NE; ++j) {
+      const int t = wave + SWV * j;
+      const bool in = row && t < nc && b.in_band(i, cb + t);
+      const double *p = in ? &b.at(i, cb + t) : b.AB;
+      const double re = *p;
+      ce[j] = in ? re : 0.0;
+      if (Z) {
+        const double im = p[b.zoff];
+        cei[j] = in ? im : 0.0;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      const int t = lane + 64 * u;
+#pragma unroll
+      for (int q = 0; q < NE; ++q) {
+        const int i = rb + wave + SWV * q;
+        const bool in = t < nc && i >= 0 && i < b.n && b.in_band(cb + t, i);
+        const double *p = in ? &b.at(cb + t, i) : b.AB;
+        const double re = *p;
+        ce[u * NE + q] = in ? re : 0.0;
+        if (Z) {
+          const double im = p[b.zoff];
+          cei[u * NE + q] = in ? -im : 0.0;  // conjugate transpose
+        }
+      }
+    }
+  }
+}
+
+// coupling_apply with the entries in registers; `prefetch` runs between this thread's multiplications and the barrier
+template <int MODE, int NR, bool Z, int K, class Prefetch>
+__device__ __forceinline__ void coupling_apply_regs(const double *ce, const double *cei, int nc, const double (*vv)[NR],
+                                                    const double (*raw)[NR], int jb, double (*w)[NR], double *part,
+                                                    Prefetch prefetch) {
+  constexpr int SWV = solve_waves<NR>(), NE = NB / SWV;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (K == 0) {
+    prefetch();
+    for (int o = threadIdx.x; o < NB * NR; o += SWV * 64) {
+      const int l = o / NR, r = o % NR;
+      w[l][r] = l < jb ? raw[l][r] : 0.0;
+    }
+  } else if (MODE <= 1) {
+    double acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = 0.0;
+#pragma unroll
+    for (int j = 0; j < K * NE; ++j) {
+      const int t = min(wave + SWV * j, SB * NB - 1);  // (entries beyond nc are zero; v there is finite)
+      mac_cols<NR, Z>(acc, ce[j], Z ? cei[j] : 0.0, &vv[t][0]);
+    }
+    prefetch();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) part[(wave * NR + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 64 * NR; o += SWV * 64) {
+      const int r = o / 64, l = o % 64;
+      double tot = 0.0;
+#pragma unroll
+      for (int q = 0; q < SWV; ++q) tot += part[(q * NR + r) * 64 + l];
+      w[l][r] = l < jb ? raw[l][r] - tot : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      double acc[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[r] = 0.0;
+#pragma unroll
+      for (int u = 0; u < K; ++u) mac_cols<NR, Z>(acc, ce[u * NE + q], Z ? cei[u * NE + q] : 0.0, &vv[lane + 64 * u][0]);
+      const int l = wave + SWV * q;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        double sacc = acc[r];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
+        if (lane == 0) w[l][r] = l < jb ? raw[l][r] - sacc : 0.0;
+      }
+    }
+    prefetch();
+  }
+  __syncthreads();
+}
+
+// sub-block K of the super block [j0, j0 + jbs) and, recursively, the ones after it (K is a compile-time constant so that
+// the prefetched entries stay in registers)
+template <int MODE, int NR, bool Z, int K>
+__device__ __forceinline__ void super_sub_block(const Band &b, const double *__restrict__ invs, int j0, int jbs, int nsub,
+                                                double (*v)[NR], double (*w)[NR], double *part, double *ce, double *cei,
+                                                double *ie, double *iei);
+
 // dst[l][:] = sum_t T(l, t) w[t][:], l < jb, with T = inv(L11), inv(U11), inv(U11)^T, inv(L11)^T (MODE 0..3) in ie / iei
 template <int MODE, int NR, bool Z, class Prefetch>
 __device__ __forceinline__ void inverse_apply(const double *ie, const double *iei, const double (*w)[NR], int jb,
@@ -1389,6 +1497,35 @@ __device__ __forceinline__ void inverse_apply(const double *ie, const double *ie
   __syncthreads();
 }
 
+template <int MODE, int NR, bool Z, int K>
+__device__ __forceinline__ void super_sub_block(const Band &b, const double *__restrict__ invs, int j0, int jbs, int nsub,
+                                                double (*v)[NR], double (*w)[NR], double *part, double *ce, double *cei,
+                                                double *ie, double *iei) {
+  if (K >= nsub) return;  // (uniform over the workgroup)
+  constexpr bool fwd = (MODE == 0 || MODE == 2);
+  constexpr size_t blk = Z ? (size_t)kInvBlockZ : (size_t)(2 * NB * NB);
+  constexpr size_t half = (MODE == 1 || MODE == 2) ? blk / 2 : 0;
+  const int sblk = fwd ? K : nsub - 1 - K;
+  const int js = j0 + sblk * NB, jb = min(NB, j0 + jbs - js);
+  const int cb = fwd ? j0 : js + jb;
+  const int nc = fwd ? js - j0 : j0 + jbs - (js + jb);
+  // the next sub-block's place, for the loads issued on its behalf (none left: this one's again, all entries masked)
+  const bool more = K + 1 < nsub;
+  const int sblk2 = more ? (fwd ? sblk + 1 : sblk - 1) : sblk;
+  const int js2 = j0 + sblk2 * NB, jb2 = min(NB, j0 + jbs - js2);
+  const int cb2 = fwd ? j0 : js2 + jb2;
+  const int nc2 = more ? (fwd ? js2 - j0 : j0 + jbs - (js2 + jb2)) : 0;
+  // (min: vv + 64 u stays inside v whatever nc is)
+  coupling_apply_regs<MODE, NR, Z, K>(ce, cei, nc, v + (cb - j0 <= (SB - K) * NB ? cb - j0 : 0), v + (js - j0), jb, w, part, [&]() {
+    coupling_load<MODE, NR, Z, (K + 1 < SB ? K + 1 : 0)>(b, js2, cb2, nc2, ce, cei);
+  });
+  inverse_apply<MODE, NR, Z>(ie, iei, w, jb, v + (js - j0), part, [&]() {
+    inverse_load<MODE, NR, Z>(invs + (size_t)(j0 / NB + sblk2) * blk + half, ie, iei);
+  });
+  if constexpr (K + 1 < SB)
+    super_sub_block<MODE, NR, Z, K + 1>(b, invs, j0, jbs, nsub, v, w, part, ce, cei, ie, iei);
+}
+
 // NR right-hand sides at once: column r of in/out starts at r * stride
 // `tile`: which rows outside the super block this workgroup updates: `tiles` consecutive blocks of 64
 // rows starting at block tile * tiles (workgroup 0 also writes `out`).  Every workgroup redoes the
@@ -1416,6 +1553,10 @@ __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__
       v[t][r] = t < jbs ? in[(size_t)r * stride + j0 + t] : 0.0;
     }
     __syncthreads();
+    if (couplings_ahead<NR, Z>()) {
+      double ce[(SB - 1) * NE], cei[(SB - 1) * NE];
+      super_sub_block<MODE, NR, Z, 0>(b, invs, j0, jbs, nsub, v, w, part, ce, cei, ie, iei);
+    } else
     for (int k = 0; k < nsub; ++k) {
       const int sblk = fwd ? k : nsub - 1 - k;
       const int js = j0 + sblk * NB, jb = min(NB, j0 + jbs - js);
