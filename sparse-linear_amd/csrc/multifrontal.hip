@@ -493,16 +493,17 @@ __device__ __forceinline__ void couple_block(const Panels &fr, int ilo, int ihi,
   }
 }
 
-// W = [rhs at the pivots | 0]
+// W = [rhs at the pivots | 0] of front blockIdx.x: all fronts in one launch before the walk (every front has its own W;
+// round 3: a launch per level cost 27 x 36 us per walk at 80^3 — each level waited for its largest front), gridDim.y
+// workgroups per front
 // (Z: column r of W is the real (r even) or imaginary part of the packed complex right-hand side r / 2)
 template <int NR, bool Z = false>
-__global__ __launch_bounds__(256) void solve_init_kernel(const int *__restrict__ list, TreeView t,
-                                                         const double *__restrict__ c, size_t stride,
+__global__ __launch_bounds__(256) void solve_init_kernel(TreeView t, const double *__restrict__ c, size_t stride,
                                                          double *__restrict__ work) {
-  const int f = list[blockIdx.x];
+  const int f = blockIdx.x;
   const int np = t.np[f], fs = np + t.nb[f];
   double *W = work + (size_t)t.woff[f] * NR;
-  for (int o = threadIdx.x; o < fs * NR; o += blockDim.x) {
+  for (int o = blockIdx.y * blockDim.x + threadIdx.x; o < fs * NR; o += gridDim.y * blockDim.x) {
     const int i = o % fs, r = o / fs;
     if (Z) W[o] = i < np ? c[(size_t)(r >> 1) * stride + 2 * (size_t)(t.p0[f] + i) + (r & 1)] : 0.0;
     else W[o] = i < np ? c[(size_t)r * stride + t.p0[f] + i] : 0.0;
@@ -853,12 +854,14 @@ __global__ __launch_bounds__(256) void big_gemv_reduce_kernel(const int *__restr
   if (i >= b.np) return;
   const int nch = (b.nb + kGemvChunk - 1) / kGemvChunk;
   const double *in = scratch + (size_t)pofs[b.item] * NR;
+  double tot[NR];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    double tot = 0.0;
-    for (int c = 0; c < nch; ++c) tot += in[((size_t)c * NR + r) * b.np + i];
-    b.Z[(size_t)r * b.fs + i] -= tot;
-  }
+  for (int r = 0; r < NR; ++r) tot[r] = 0.0;
+  for (int c = 0; c < nch; ++c)  // (NR loads in flight per thread; chunk order: the sums do not depend on the schedule)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) tot[r] += in[((size_t)c * NR + r) * b.np + i];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) b.Z[(size_t)r * b.fs + i] -= tot[r];
 }
 
 // transposed forward elimination, boundary part: W[np + k][:] -= sum_t U(t, k) Z[t][:]  (U^T y); one
@@ -1528,10 +1531,9 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
   };
   if (timing) (void)hipStreamSynchronize(s);
   t_last = std::chrono::steady_clock::now();
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_init_kernel<NR, Z>), dim3((unsigned)T.nfronts, 8), dim3(256), 0, s, F.view, c, stride,
+                     work);
   for (int d = nd - 1; d >= 0; --d) {
-    const unsigned nf = (unsigned)T.by_depth[(size_t)d].size();
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_init_kernel<NR, Z>), dim3(nf), dim3(256), 0, s, F.level_lists[(size_t)d].get(),
-                       F.view, c, stride, work);
     if (d + 1 < nd)
       for (int sl = 0; sl < 2; ++sl)
         if (F.child_counts[sl][(size_t)d] > 0) {
