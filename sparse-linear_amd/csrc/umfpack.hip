@@ -336,11 +336,16 @@ __global__ __launch_bounds__(1024) void band_lu_fused_kernel(int n, int kl, int 
 }
 
 // column blockIdx.y: out[k] = in[perm[k]]
+// conj (vectors of interleaved (re, im) pairs): 1 = the entries with an odd SOURCE index change sign, 2 = those with an
+// odd destination index — the complex conjugate of the vector in its original ordering, on the way in or out
 __global__ void gather_perm_kernel(int n, const int *__restrict__ perm, const double *__restrict__ in,
-                                   double *__restrict__ out, size_t stride) {
+                                   double *__restrict__ out, size_t stride, int conj) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t col = (size_t)blockIdx.y * stride;
-  if (k < n) out[col + k] = in[col + perm[k]];
+  if (k >= n) return;
+  const int src = perm[k];
+  const double v = in[col + src];
+  out[col + k] = ((conj == 1 && (src & 1)) || (conj == 2 && (k & 1))) ? -v : v;
 }
 
 // column blockIdx.y: out[k] = scale[k] * in[idx[k]]
@@ -538,9 +543,14 @@ void factor_solve(const Numeric *N, int sys, const double *d_b, double *d_x, dou
     return;
   }
   // B = P A P^T  =>  A x = b  <=>  B (P x) = P b ; (P v)[k] = v[perm[k]]
-  hipLaunchKernelGGL(gather_perm_kernel, g, dim3(256), 0, s, n, N->perm.get(), d_b, d_work, stride);
-  band_solve(N, sys, d_work, k, stride, s);
-  hipLaunchKernelGGL(gather_perm_kernel, g, dim3(256), 0, s, n, N->inv.get(), d_work, d_x, stride);  // x[i] = z[inv[i]]
+  // Factors of a SYMMETRIC matrix (L D L^T on the tree): the transposed system is the same system, so it takes the
+  // untransposed kernels (the faster ones: their panels run down the contiguous direction).  On native complex fronts
+  // sys = At asks for the CONJUGATE transpose: A^H = conj(A) for A == A^T, and conj(A) x = b <=> A conj(x) = conj(b).
+  const bool same = sys != UMFPACK_A && N->mfact && N->mf_sym && !N->mf_piv;
+  const bool conj = same && N->zfront;
+  hipLaunchKernelGGL(gather_perm_kernel, g, dim3(256), 0, s, n, N->perm.get(), d_b, d_work, stride, conj ? 1 : 0);
+  band_solve(N, same ? UMFPACK_A : sys, d_work, k, stride, s);
+  hipLaunchKernelGGL(gather_perm_kernel, g, dim3(256), 0, s, n, N->inv.get(), d_work, d_x, stride, conj ? 2 : 0);  // x[i] = z[inv[i]]
 }
 
 // install an ordering (new -> old, old -> new) on the device
