@@ -1112,6 +1112,40 @@ constexpr int SW = 16;
 template <int NR>
 constexpr int solve_waves() { return NR >= 16 ? 8 : SW; }
 
+// Sums over the 64 lanes of N values per lane (N a power of two) by recursive halving: at every step a lane keeps one
+// half of its values and sends the other to its partner, so N values cost about N shuffles — a butterfly per value costs
+// 6 N (round 3: the transposed solves with 16 columns spent most of their instructions there).  Afterwards lane L holds
+// in val[0 .. N / 64) the sums of indices L * N / 64 + k (N >= 64), or in val[0] the sum of index L / (64 / N) (N < 64:
+// the 64 / N lanes of a group all hold it).
+template <int C, int M, int N>
+__device__ __forceinline__ void wave_reduce_step(double (&val)[N], int lane) {
+  if constexpr (M >= 1) {
+    if constexpr (C > 1) {
+      constexpr int half = C / 2;
+      const bool up = (lane & M) != 0;
+#pragma unroll
+      for (int j = 0; j < half; ++j) {
+        const double keep = up ? val[j + half] : val[j];
+        const double send = up ? val[j] : val[j + half];
+        val[j] = keep + __shfl_xor(send, M, 64);
+      }
+      wave_reduce_step<half, M / 2, N>(val, lane);
+    } else {
+      val[0] += __shfl_xor(val[0], M, 64);
+      wave_reduce_step<1, M / 2, N>(val, lane);
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ void wave_reduce_scatter(double (&val)[N]) {
+  wave_reduce_step<N, 32, N>(val, (int)(threadIdx.x & 63));
+}
+// the index of val[k] after wave_reduce_scatter<N>, and whether this lane is the one that should store it
+template <int N>
+__device__ __forceinline__ int wave_reduce_index(int lane, int k) { return N >= 64 ? lane * (N / 64) + k : lane / (64 / (N < 64 ? N : 64)); }
+template <int N>
+__device__ __forceinline__ bool wave_reduce_owner(int lane) { return N >= 64 ? true : lane % (64 / (N < 64 ? N : 64)) == 0; }
+
 // res[l][r] = sum_{t < nc} M(rb + l, cb + t) * vv[t][r], l < 64, r < NR right-hand sides; M =
 // matrix of the triangular system.  Untransposed (MODE 0/1) band storage runs down the rows:
 // lane = row, wave q takes t = q mod SWV, partial sums meet in LDS.  Transposed (MODE 2/3) it runs
@@ -1191,43 +1225,45 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
       res[l][r] = tot;
     }
   } else {
-    // nc <= SB * NB = 256: at most 4 strips of 64 columns; the 4 rows of this wave and the strips
-    // are unrolled so that all 16 loads of a lane are in flight together
+    // nc <= SB * NB = 256: at most 4 strips of 64 columns.  A wavefront has 64 / SWV rows; RG of them at a time, all
+    // strips unrolled so that the 4 RG loads of a lane are in flight together (16 columns: two rows at a time — eight
+    // rows of accumulators are 256 registers, and the compiler spilled 600 - 800 bytes per lane: 450 us per step)
     constexpr int RPW = 64 / SWV;
-    double acc[RPW][NR];
+    constexpr int RG = NR >= 16 ? 2 : RPW;
+#pragma unroll 1
+    for (int q0 = 0; q0 < RPW; q0 += RG) {
+      double acc[RG * NR];
 #pragma unroll
-    for (int q = 0; q < RPW; ++q)
+      for (int o = 0; o < RG * NR; ++o) acc[o] = 0.0;
+      double e[SB][RG], ei[SB][RG];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) acc[q][r] = 0.0;
-    double e[SB][RPW], ei[SB][RPW];
+      for (int u = 0; u < SB; ++u) {
+        const int t = lane + 64 * u;
 #pragma unroll
-    for (int u = 0; u < SB; ++u) {
-      const int t = lane + 64 * u;
+        for (int q = 0; q < RG; ++q) {
+          const int i = rb + wave + SWV * (q0 + q);
+          const bool in = t < nc && i >= 0 && i < b.n;
+          e[u][q] = in ? b.get(cb + t, i) : 0.0;
+          ei[u][q] = (Z && in) ? -(&b.at(cb + t, i))[b.zoff] : 0.0;
+        }
+      }
 #pragma unroll
-      for (int q = 0; q < RPW; ++q) {
-        const int i = rb + wave + SWV * q;
-        const bool in = t < nc && i >= 0 && i < b.n;
-        e[u][q] = in ? b.get(cb + t, i) : 0.0;
-        ei[u][q] = (Z && in) ? -(&b.at(cb + t, i))[b.zoff] : 0.0;
+      for (int u = 0; u < SB; ++u) {
+        const int t = lane + 64 * u;
+        if (t < nc) {
+#pragma unroll
+          for (int q = 0; q < RG; ++q) mac_cols<NR, Z>(*reinterpret_cast<double(*)[NR]>(&acc[q * NR]), e[u][q], ei[u][q], &vv[t][0]);
+        }
+      }
+      wave_reduce_scatter<RG * NR>(acc);
+      if (wave_reduce_owner<RG * NR>(lane)) {
+#pragma unroll
+        for (int k = 0; k < (RG * NR >= 64 ? RG * NR / 64 : 1); ++k) {
+          const int idx = wave_reduce_index<RG * NR>(lane, k);
+          res[wave + SWV * (q0 + idx / NR)][idx % NR] = acc[k];
+        }
       }
     }
-#pragma unroll
-    for (int u = 0; u < SB; ++u) {
-      const int t = lane + 64 * u;
-      if (t < nc) {
-#pragma unroll
-        for (int q = 0; q < RPW; ++q) mac_cols<NR, Z>(acc[q], e[u][q], ei[u][q], &vv[t][0]);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < RPW; ++q)
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        double sacc = acc[q][r];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
-        if (lane == 0) res[wave + SWV * q][r] = sacc;
-      }
   }
   __syncthreads();
 }
@@ -1302,43 +1338,41 @@ __device__ __forceinline__ void coupling_apply(const Band &b, int rb, int cb, in
       w[l][r] = l < jb ? raw[l][r] - tot : 0.0;
     }
   } else {
-    // nc <= (SB - 1) * 64: at most 3 strips of 64 columns, two of them in flight together
-    double acc[NE][NR];
+    // nc <= (SB - 1) * 64: at most 3 strips of 64 columns, all in flight together, RG rows of the wavefront at a time
+    constexpr int RG = NR >= 16 ? 2 : NE;
+#pragma unroll 1
+    for (int q0 = 0; q0 < NE; q0 += RG) {
+      double acc[RG * NR];
 #pragma unroll
-    for (int q = 0; q < NE; ++q)
+      for (int o = 0; o < RG * NR; ++o) acc[o] = 0.0;
+      double e[SB - 1][RG], ei[SB - 1][RG];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) acc[q][r] = 0.0;
-    for (int u0 = 0; u0 * 64 < nc; u0 += 2) {
-      double e[2][NE], ei[2][NE];
+      for (int u = 0; u < SB - 1; ++u) {
+        const int t = lane + 64 * u;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int t = lane + 64 * (u0 + u);
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-          const int i = rb + wave + SWV * q;
+        for (int q = 0; q < RG; ++q) {
+          const int i = rb + wave + SWV * (q0 + q);
           const bool in = t < nc && i >= 0 && i < b.n;
           e[u][q] = in ? b.get(cb + t, i) : 0.0;
           ei[u][q] = (Z && in) ? -(&b.at(cb + t, i))[b.zoff] : 0.0;  // conjugate transpose
         }
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int t = lane + 64 * (u0 + u);
+      for (int u = 0; u < SB - 1; ++u) {
+        const int t = lane + 64 * u;
         if (t < nc) {
 #pragma unroll
-          for (int q = 0; q < NE; ++q) mac_cols<NR, Z>(acc[q], e[u][q], ei[u][q], &vv[t][0]);
+          for (int q = 0; q < RG; ++q) mac_cols<NR, Z>(*reinterpret_cast<double(*)[NR]>(&acc[q * NR]), e[u][q], ei[u][q], &vv[t][0]);
         }
       }
-    }
+      wave_reduce_scatter<RG * NR>(acc);
+      if (wave_reduce_owner<RG * NR>(lane)) {
 #pragma unroll
-    for (int q = 0; q < NE; ++q) {
-      const int l = wave + SWV * q;
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        double sacc = acc[q][r];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
-        if (lane == 0) w[l][r] = l < jb ? raw[l][r] - sacc : 0.0;
+        for (int k = 0; k < (RG * NR >= 64 ? RG * NR / 64 : 1); ++k) {
+          const int idx = wave_reduce_index<RG * NR>(lane, k);
+          const int l = wave + SWV * (q0 + idx / NR), r = idx % NR;
+          w[l][r] = l < jb ? raw[l][r] - acc[k] : 0.0;
+        }
       }
     }
   }
@@ -1477,19 +1511,23 @@ __device__ __forceinline__ void inverse_apply(const double *ie, const double *ie
       if (l < jb) dst[l][r] = tot;
     }
   } else {
+    constexpr int RG = NR >= 16 ? 2 : NE;  // rows of this wavefront whose products are summed together
 #pragma unroll
-    for (int u = 0; u < NE; ++u) {
-      const int l = wave + SWV * u;
-      double prod[NR];
+    for (int u0 = 0; u0 < NE; u0 += RG) {
+      double prod[RG * NR];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) prod[r] = 0.0;
-      mac_cols<NR, Z>(prod, ie[u], Z ? iei[u] : 0.0, &w[lane][0]);
+      for (int o = 0; o < RG * NR; ++o) prod[o] = 0.0;
 #pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        double sacc = prod[r];
+      for (int q = 0; q < RG; ++q)
+        mac_cols<NR, Z>(*reinterpret_cast<double(*)[NR]>(&prod[q * NR]), ie[u0 + q], Z ? iei[u0 + q] : 0.0, &w[lane][0]);
+      wave_reduce_scatter<RG * NR>(prod);
+      if (wave_reduce_owner<RG * NR>(lane)) {
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
-        if (lane == 0 && l < jb) dst[l][r] = sacc;
+        for (int k = 0; k < (RG * NR >= 64 ? RG * NR / 64 : 1); ++k) {
+          const int idx = wave_reduce_index<RG * NR>(lane, k);
+          const int l = wave + SWV * (u0 + idx / NR);
+          if (l < jb) dst[l][idx % NR] = prod[k];
+        }
       }
     }
     prefetch();

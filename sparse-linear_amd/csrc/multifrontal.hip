@@ -475,19 +475,17 @@ __device__ __forceinline__ void couple_block(const Panels &fr, int ilo, int ihi,
         e[u] = in ? src[0] : 0.0;
         ei[u] = (Z && in) ? -src[fr.zcol(i0 + u)] : 0.0;
       }
+      double part[RW * NR];
 #pragma unroll
-      for (int u = 0; u < RW; ++u) {
-        double part[NR];
+      for (int o = 0; o < RW * NR; ++o) part[o] = 0.0;
+      if (lane < jb) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) part[r] = 0.0;
-        if (lane < jb) mac_cols<NR, Z>(part, e[u], ei[u], &v[lane][0]);
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          double sacc = part[r];
-#pragma unroll
-          for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
-          if (lane == 0 && i0 + u < ihi) W[(size_t)r * fs + i0 + u] -= sacc;
-        }
+        for (int u = 0; u < RW; ++u) mac_cols<NR, Z>(*reinterpret_cast<double(*)[NR]>(&part[u * NR]), e[u], ei[u], &v[lane][0]);
+      }
+      wave_reduce_scatter<RW * NR>(part);  // (recursive halving: about one shuffle per sum instead of six)
+      if (wave_reduce_owner<RW * NR>(lane)) {
+        const int idx = wave_reduce_index<RW * NR>(lane, 0), u = idx / NR, r = idx % NR;  // (RW * NR <= 64)
+        if (i0 + u < ihi) W[(size_t)r * fs + i0 + u] -= part[0];
       }
     }
   }
@@ -763,14 +761,12 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_kernel(const i
 #pragma unroll
         for (int u = 0; u < RW; ++u) mac_cols<NR, Z, false>(acc[u], e[u], ei[u], xv);
       }
-#pragma unroll
-      for (int u = 0; u < RW; ++u)
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-#pragma unroll
-          for (int m = 32; m >= 1; m >>= 1) acc[u][r] += __shfl_xor(acc[u][r], m, 64);
-          if (lane == 0 && i0 + rr + u < np) z[(size_t)r * fs + i0 + rr + u] -= acc[u][r];
-        }
+      double(&flat)[RW * NR] = *reinterpret_cast<double(*)[RW * NR]>(&acc[0][0]);
+      wave_reduce_scatter<RW * NR>(flat);
+      if (wave_reduce_owner<RW * NR>(lane)) {
+        const int idx = wave_reduce_index<RW * NR>(lane, 0), u = idx / NR, r = idx % NR;  // (RW * NR <= 64)
+        if (i0 + rr + u < np) z[(size_t)r * fs + i0 + rr + u] -= flat[0];
+      }
     }
   }
 }
@@ -886,12 +882,8 @@ __global__ __launch_bounds__(256) void big_boundary_t_kernel(const int *__restri
     for (int r = 0; r < NR; ++r) zv[r] = b.Z[(size_t)r * b.fs + tt];
     mac_cols<NR, Z>(acc, e, ei, zv);
   }
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) acc[r] += __shfl_xor(acc[r], m, 64);
-    if (lane == 0) b.W[(size_t)r * b.fs + b.np + k] -= acc[r];
-  }
+  wave_reduce_scatter<NR>(acc);
+  if (wave_reduce_owner<NR>(lane)) b.W[(size_t)wave_reduce_index<NR>(lane, 0) * b.fs + b.np + k] -= acc[0];
 }
 
 // the pivots' part of the solution of every listed front: x[p0 + i] = W[i]

@@ -4,8 +4,8 @@ cd /tmp && export TMPDIR=/tmp
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out/zsolve_prof
 rm -rf "$out"; mkdir -p "$out"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python3 "$repo/tools/profile_zi_solve.py" "${1:-80}" "${2:-16}" "${3:-3}" > "$out.log" 2>&1
-grep "batched solve" "$out.log" | cut -c1-90
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python3 "$repo/tools/profile_zi_solve.py" "${1:-80}" "${2:-16}" "${3:-3}" ${4:-} > "$out.log" 2>&1
+grep "batched" "$out.log" | cut -c1-90
 python3 - "$out" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_stats.csv")[0]
