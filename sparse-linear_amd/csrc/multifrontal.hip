@@ -672,113 +672,20 @@ __global__ __launch_bounds__(256) void big_gather_x_kernel(const int *__restrict
     b.W[(size_t)r * b.fs + b.np + k] = Z ? x[(size_t)(r >> 1) * stride + 2 * (size_t)g + (r & 1)] : x[(size_t)r * stride + g];
 }
 
-// Z[i][:] -= sum_k M(i, np + k) W[np + k][:], i < np: 64 rows per workgroup.  Untransposed
-// M(i, np + k) = U(i, k); transposed = F(np + k, i) in P.
-// gemv_waves wavefronts per workgroup split the boundary columns: a level has few large fronts and a front np / 64
-// workgroups, so the kernel lives on loads in flight per workgroup, not on workgroups (round 3: 4 -> 16 wavefronts)
+// Z[i][:] -= sum_k M(i, np + k) W[np + k][:], i < np: the boundary's part in the back substitution of a large front.
+// Untransposed M(i, np + k) = U(i, k); transposed = F(np + k, i) in P (Z: its conjugate).
+// A level of the upper tree has few large fronts and a front np / 64 blocks of rows: with one workgroup per block (the
+// kernel of rounds 1 - 2) 40 - 150 CUs were busy, each with 64 x nb x NR multiply-adds — for 16 columns that is the
+// issue rate of ONE CU's vector pipes per block (195 us per launch at 80^3, 1 TB/s).  Here a workgroup takes 64 rows x
+// kGemvChunk boundary columns (round 3); the entries of x it needs go through LDS once.  Fronts with one chunk subtract
+// their sums from Z directly; the chunks of larger ones write partial sums to scratch ([chunk][r][i] behind the front's
+// offset) and big_gemv_reduce_kernel subtracts them in chunk order: the result does not depend on the schedule.
+// Untransposed: lane = row, gemv_waves wavefronts split the chunk's columns, x k-major in LDS (a multiply-add reads its
+// NR values as broadcast 16-byte words, so the fused form of mac_cols pays), partial sums meet in LDS.
+// Transposed: lanes along the chunk's columns (contiguous in P), the wavefronts split the rows, x r-major in LDS (lanes
+// read side by side), lane sums by recursive halving.
 template <int NR>
-constexpr int gemv_waves() { return NR >= 16 ? 8 : 16; }  // (the partial sums: GW x 64 x NR doubles of static LDS)
-template <bool TRANS, int NR, bool Z = false>
-__global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_kernel(const int *__restrict__ list,
-                                                                         const int64_t *__restrict__ prefix, int count,
-                                                                         TreeView t, double *work, double *zbuf) {
-  constexpr int GW = gemv_waves<NR>();
-  __shared__ double part[GW][64][NR];
-  const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
-  const double *P = b.P, *U = b.U, *xb = b.W + b.np;
-  double *z = b.Z;
-  const int np = b.np, nb = b.nb, fs = b.fs, ldp = b.ldp, ldu = b.ldu;
-  // (wave index as a scalar: the loop counters below are then wavefront-uniform for the compiler too, and the entries of
-  // x they index — the same for all 64 rows — come through the scalar cache instead of as 64-lane vector loads)
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int i0 = b.blk * 64;
-  if (!TRANS) {
-    const int i = i0 + lane;
-    double acc[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) acc[r] = 0.0;
-    if (i < np) {
-      const double *row = U + (size_t)i;
-      int k = wave;
-      // UF entries in flight per lane: a level has few large fronts, so the kernel is bound by the bytes a workgroup
-      // keeps in flight (8 wavefronts with 16 columns have the registers for twice as many)
-      constexpr int UF = NR >= 16 ? 16 : 8;
-      for (; k + (UF - 1) * GW < nb; k += UF * GW) {
-        double e[UF], ei[UF];
-#pragma unroll
-        for (int u = 0; u < UF; ++u) {
-          e[u] = row[(size_t)(k + GW * u) * ldu];
-          ei[u] = Z ? row[(size_t)(k + GW * u) * ldu + b.uz] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < UF; ++u) {
-          double xv[NR];
-#pragma unroll
-          for (int r = 0; r < NR; ++r) xv[r] = xb[(size_t)r * fs + k + GW * u];
-          mac_cols<NR, Z, false>(acc, e[u], ei[u], xv);
-        }
-      }
-      for (; k < nb; k += GW) {
-        const double e = row[(size_t)k * ldu];
-        const double ei = Z ? row[(size_t)k * ldu + b.uz] : 0.0;
-        double xv[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) xv[r] = xb[(size_t)r * fs + k];
-        mac_cols<NR, Z, false>(acc, e, ei, xv);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < NR; ++r) part[wave][lane][r] = acc[r];
-    __syncthreads();
-    if (wave == 0 && i < np)
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        double sum = 0.0;
-#pragma unroll
-        for (int q = 0; q < GW; ++q) sum += part[q][lane][r];
-        z[(size_t)r * fs + i] -= sum;
-      }
-  } else {
-    constexpr int RW = NR <= 2 ? 4 : 2;  // rows of the chunk per wavefront and trip (GW wavefronts share its 64 rows)
-    for (int rr = wave * RW; rr < 64; rr += GW * RW) {
-      double acc[RW][NR];
-#pragma unroll
-      for (int u = 0; u < RW; ++u)
-#pragma unroll
-        for (int r = 0; r < NR; ++r) acc[u][r] = 0.0;
-      for (int k = lane; k < nb; k += 64) {
-        double e[RW], ei[RW];
-#pragma unroll
-        for (int u = 0; u < RW; ++u) {
-          const bool in = i0 + rr + u < np;
-          const double *src = P + (size_t)(np + k) + (size_t)(in ? i0 + rr + u : 0) * ldp;
-          e[u] = in ? src[0] : 0.0;
-          ei[u] = (Z && in) ? -src[b.pz] : 0.0;  // conjugate transpose
-        }
-        double xv[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) xv[r] = xb[(size_t)r * fs + k];
-#pragma unroll
-        for (int u = 0; u < RW; ++u) mac_cols<NR, Z, false>(acc[u], e[u], ei[u], xv);
-      }
-      double(&flat)[RW * NR] = *reinterpret_cast<double(*)[RW * NR]>(&acc[0][0]);
-      wave_reduce_scatter<RW * NR>(flat);
-      if (wave_reduce_owner<RW * NR>(lane)) {
-        const int idx = wave_reduce_index<RW * NR>(lane, 0), u = idx / NR, r = idx % NR;  // (RW * NR <= 64)
-        if (i0 + rr + u < np) z[(size_t)r * fs + i0 + rr + u] -= flat[0];
-      }
-    }
-  }
-}
-
-// The untransposed product again, spread over more workgroups (round 3).  A level of the upper tree has few large
-// fronts and a front np / 64 blocks of rows: with one workgroup per block the kernel above keeps 40 - 150 CUs busy, each
-// with 64 x nb x NR multiply-adds — for 16 columns that is the issue rate of ONE CU's vector pipes per block (195 us
-// per launch at 80^3, 1 TB/s).  Here a workgroup takes 64 rows x kGemvChunk boundary columns; the entries of x it needs
-// go through LDS once (k-major, so a multiply-add reads its NR values as broadcast 16-byte words and the fused form of
-// mac_cols pays).  Fronts with one chunk subtract their sums from Z directly; the chunks of larger ones write partial
-// sums to scratch ([chunk][r][i] behind the front's offset) and big_gemv_reduce_kernel subtracts them in chunk order:
-// the result does not depend on the schedule.
+constexpr int gemv_waves() { return NR >= 16 ? 8 : 16; }  // (the partial sums: GW x 64 x NR doubles of LDS)
 constexpr int kGemvChunk = 512;
 template <int NR, bool Z = false>
 __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(const int *__restrict__ list,
@@ -837,6 +744,65 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(c
     for (int q = 0; q < GW; ++q) tot += part[(q * NR + r) * 64 + l];
     if (out) out[(size_t)r * np + i0 + l] = tot;
     else b.Z[(size_t)r * fs + i0 + l] -= tot;
+  }
+}
+
+template <int NR, bool Z = false>
+__global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_t_kernel(const int *__restrict__ list,
+                                                                                 const int64_t *__restrict__ prefix, int count,
+                                                                                 TreeView t, double *work, double *zbuf,
+                                                                                 const int64_t *__restrict__ pofs,
+                                                                                 double *__restrict__ scratch) {
+  constexpr int GW = gemv_waves<NR>();
+  extern __shared__ __attribute__((aligned(16))) double gsm[];
+  double(*xs)[kGemvChunk] = reinterpret_cast<double(*)[kGemvChunk]>(gsm);  // [NR]
+  const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
+  const int np = b.np, nb = b.nb, fs = b.fs, ldp = b.ldp;
+  const int nch = (nb + kGemvChunk - 1) / kGemvChunk;
+  const int rb = b.blk / nch, ch = b.blk - rb * nch;
+  const int i0 = rb * 64, k0 = ch * kGemvChunk, kn = min(kGemvChunk, nb - k0);
+  const double *xb = b.W + b.np + k0;
+  for (int o = threadIdx.x; o < kGemvChunk * NR; o += GW * 64) {
+    const int kk = o % kGemvChunk, r = o / kGemvChunk;
+    xs[r][kk] = kk < kn ? xb[(size_t)r * fs + kk] : 0.0;  // (zeros past the chunk's end: the loads below are clamped, not masked)
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double *out = nch > 1 ? scratch + (size_t)pofs[b.item] * NR + (size_t)ch * NR * np : nullptr;
+  const double *P = b.P + (size_t)(np + k0);
+  constexpr int RW = NR <= 2 ? 4 : 2;  // rows per wavefront and trip
+  for (int rr = wave * RW; rr < 64; rr += GW * RW) {
+    double acc[RW * NR];
+#pragma unroll
+    for (int o = 0; o < RW * NR; ++o) acc[o] = 0.0;
+    const double *col[RW];
+#pragma unroll
+    for (int u = 0; u < RW; ++u) col[u] = P + (size_t)min(i0 + rr + u, np - 1) * ldp;  // (rows past np: read again, not stored)
+#pragma unroll 4
+    for (int kk = lane; kk < kGemvChunk; kk += 64) {
+      if (kk - lane >= kn) break;  // (uniform)
+      const int kc = min(kk, kn - 1);
+      double e[RW], ei[RW];
+#pragma unroll
+      for (int u = 0; u < RW; ++u) {
+        e[u] = col[u][kc];
+        ei[u] = Z ? -col[u][kc + b.pz] : 0.0;  // conjugate transpose
+      }
+      double xv[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) xv[r] = xs[r][kk];
+#pragma unroll
+      for (int u = 0; u < RW; ++u) mac_cols<NR, Z>(*reinterpret_cast<double(*)[NR]>(&acc[u * NR]), e[u], ei[u], xv);
+    }
+    wave_reduce_scatter<RW * NR>(acc);
+    if (wave_reduce_owner<RW * NR>(lane)) {
+      const int idx = wave_reduce_index<RW * NR>(lane, 0), u = idx / NR, r = idx % NR;  // (RW * NR <= 64)
+      const int i = i0 + rr + u;
+      if (i < np) {
+        if (out) out[(size_t)r * np + i] = acc[0];
+        else b.Z[(size_t)r * fs + i] -= acc[0];
+      }
+    }
   }
 }
 
@@ -1560,19 +1526,25 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
       if (B.total(4) > 0) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gather_x_kernel<NR, Z>), dim3(B.total(4)), dim3(256), 0, s, B.list.get(),
                            B.prefix(4), B.count, F.view, c, stride, work, zbuf);
-        if (TRANS) {
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_kernel<TRANS, NR, Z>), dim3(B.total(5)), dim3(gemv_waves<NR>() * 64), 0, s,
-                             B.list.get(), B.prefix(5), B.count, F.view, work, zbuf);
-        } else {
-          constexpr size_t lds = (size_t)(kGemvChunk + gemv_waves<NR>() * 64) * NR * sizeof(double);
+        {
+          constexpr size_t lds = TRANS ? (size_t)kGemvChunk * NR * sizeof(double)
+                                       : (size_t)(kGemvChunk + gemv_waves<NR>() * 64) * NR * sizeof(double);
           static std::atomic<uint64_t> attr_set{0};  // one mask per instantiation, one bit per device
           if (first_use_on_this_device(attr_set)) {
-            SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&big_gemv_chunk_kernel<NR, Z>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (TRANS)
+              SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&big_gemv_chunk_t_kernel<NR, Z>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            else
+              SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&big_gemv_chunk_kernel<NR, Z>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             mark_used_on_this_device(attr_set);
           }
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_chunk_kernel<NR, Z>), dim3(B.total(7)), dim3(gemv_waves<NR>() * 64), lds, s,
-                             B.list.get(), B.prefix(7), B.count, F.view, work, zbuf, B.prefix(9), gscr);
+          if (TRANS)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_chunk_t_kernel<NR, Z>), dim3(B.total(7)), dim3(gemv_waves<NR>() * 64), lds,
+                               s, B.list.get(), B.prefix(7), B.count, F.view, work, zbuf, B.prefix(9), gscr);
+          else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_chunk_kernel<NR, Z>), dim3(B.total(7)), dim3(gemv_waves<NR>() * 64), lds, s,
+                               B.list.get(), B.prefix(7), B.count, F.view, work, zbuf, B.prefix(9), gscr);
           if (B.total(8) > 0)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_reduce_kernel<NR>), dim3(B.total(8)), dim3(256), 0, s, B.list.get(),
                                B.prefix(8), B.count, F.view, work, zbuf, B.prefix(9), gscr);
