@@ -1281,13 +1281,23 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
 // bank conflicts), and the reductions write w / v directly.
 // Untransposed (MODE 0/1): lane = row, the wavefronts split the columns.  Transposed (MODE 2/3): lanes along the
 // columns, the wavefronts split the rows, butterfly reduction.
+// Transposed systems inside a super block with 8 or 16 columns: the rows on the lanes as in the untransposed ones (the
+// matrix entries then come by strided loads — the few blocks of a super block sit in the L2 —, but the sums need no
+// shuffles: with the lanes along the columns the in-super-block solve of 16 complex columns spent ~100 us, three times
+// the untransposed one, mostly in lane reductions).  One or two columns keep the lanes along the columns.
+template <int NR>
+constexpr bool rows_on_lanes() { return NR >= 8; }
+
 template <int MODE, int NR, bool Z>
 __device__ __forceinline__ void inverse_load(const double *__restrict__ inv, double *ie, double *iei) {
   constexpr int SWV = solve_waves<NR>(), NE = NB / SWV;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int u = 0; u < NE; ++u) {  // MODE <= 1: T(lane, t), t = wave + SWV u;  transposed: T(l, lane) = inv(lane, l), l likewise
-    const int idx = lane + (wave + SWV * u) * NB;
+  for (int u = 0; u < NE; ++u) {
+    // MODE <= 1: T(lane, t), t = wave + SWV u;  transposed: T(l, lane) = inv(lane, l), l likewise — or, with the rows on
+    // the lanes there too (rows_on_lanes), T(lane, t) = inv(t, lane): strided loads of a block that sits in the L2
+    const int t = wave + SWV * u;
+    const int idx = (MODE >= 2 && rows_on_lanes<NR>()) ? t + lane * NB : lane + t * NB;
     ie[u] = inv[idx];
     if (Z) iei[u] = MODE <= 1 ? inv[NB * NB + idx] : -inv[NB * NB + idx];
   }
@@ -1304,7 +1314,8 @@ __device__ __forceinline__ void coupling_apply(const Band &b, int rb, int cb, in
       const int l = o / NR, r = o % NR;
       w[l][r] = l < jb ? raw[l][r] : 0.0;
     }
-  } else if (MODE <= 1) {
+  } else if (MODE <= 1 || rows_on_lanes<NR>()) {
+    constexpr bool TR = MODE >= 2;  // M(i, c) = conj(F(c, i))
     const int i = rb + lane;
     double acc[NR];
 #pragma unroll
@@ -1315,15 +1326,17 @@ __device__ __forceinline__ void coupling_apply(const Band &b, int rb, int cb, in
         double e[8], ei[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          e[u] = b.get(i, cb + t + SWV * u);
-          ei[u] = Z ? (&b.at(i, cb + t + SWV * u))[b.zoff] : 0.0;
+          const int c = cb + t + SWV * u;
+          e[u] = TR ? b.get(c, i) : b.get(i, c);
+          ei[u] = Z ? (TR ? -(&b.at(c, i))[b.zoff] : (&b.at(i, c))[b.zoff]) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) mac_cols<NR, Z>(acc, e[u], ei[u], &vv[t + SWV * u][0]);
       }
       for (; t < nc; t += SWV) {
-        const double e = b.get(i, cb + t);
-        const double ei = Z ? (&b.at(i, cb + t))[b.zoff] : 0.0;
+        const int c = cb + t;
+        const double e = TR ? b.get(c, i) : b.get(i, c);
+        const double ei = Z ? (TR ? -(&b.at(c, i))[b.zoff] : (&b.at(i, c))[b.zoff]) : 0.0;
         mac_cols<NR, Z>(acc, e, ei, &vv[t][0]);
       }
     }
@@ -1493,7 +1506,7 @@ __device__ __forceinline__ void inverse_apply(const double *ie, const double *ie
                                               double (*dst)[NR], double *part, Prefetch prefetch) {
   constexpr int SWV = solve_waves<NR>(), NE = NB / SWV;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (MODE <= 1) {
+  if (MODE <= 1 || rows_on_lanes<NR>()) {
     double acc[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = 0.0;

@@ -269,7 +269,9 @@ def test_refinement_takes_only_unfinished_columns_through_the_factors(gpu, pkg, 
                 assert not np.any(x)
                 continue
             one = U.linearSolve_(fact, mode, A, b)
-            assert O.count_not_close(x, one, 1e-12) == 0
+            # (an indefinite matrix, and kernels for 8 columns that add in another order than those for one: agreement
+            # to the conditioning, backward errors at rounding level for both)
+            assert O.count_not_close(x, one, 1e-9) == 0
             op = S if mode == U.UmfpackNormal else S.T
             assert np.max(np.abs(op @ x - b)) / (np.max(np.abs(b)) + 6 * np.max(np.abs(x))) < 1e-13
 
