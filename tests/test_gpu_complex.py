@@ -282,6 +282,45 @@ def test_native_complex_fronts_unsymmetric(gpu, pkg, kind, limits, monkeypatch):
             assert _bwd(op, got, b) <= 1e-13
 
 
+@pytest.mark.parametrize("complex_values", [False, True])
+def test_batched_solves_with_boundary_products_in_several_chunks(gpu, pkg, complex_values, monkeypatch):
+    """a 3-D mesh large enough that fronts below the root have boundaries of more than 512 indices: the boundary product
+    of the back substitution then runs in several chunks per block of rows, partial sums through scratch and the
+    reduction kernel (multifrontal.hip: big_gemv_chunk_kernel, big_gemv_chunk_t_kernel, big_gemv_reduce_kernel); 9
+    right-hand sides (a full group of eight and a group of one), both systems, unsymmetric values so that the transposed
+    kernels run; real fronts and native complex fronts"""
+    import scipy.sparse as sp
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    monkeypatch.setenv("SPL_ZI_NATIVE", "1")
+    rng = np.random.default_rng(23)
+    m = 34
+    n = m ** 3
+    T = sp.diags([-np.ones(m - 1), 2.0 * np.ones(m), -np.ones(m - 1)], (-1, 0, 1))
+    I = sp.identity(m)
+    K = sp.csc_matrix(sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(T, I), I))
+    K.sort_indices()
+    vals = K.data * rng.uniform(0.8, 1.2, K.nnz)  # same pattern, no symmetry, rows stay dominant enough
+    if complex_values:
+        vals = vals * np.exp(0.3j * rng.uniform(-1, 1, K.nnz))
+    S = sp.csc_matrix((vals, K.indices, K.indptr), shape=(n, n)) + 0.5 * sp.identity(n)
+    S = sp.csc_matrix(S)
+    S.sort_indices()
+    M = pkg.Matrix(n, n, S.indptr, S.indices, S.data)
+    U = pkg.umfpack
+    f = U.factor(M, U.analyze(M))
+    st = f.stats
+    assert st["path"] in (3, 4) and st["fronts"] > 100 and st["complex_fronts"] == (1 if complex_values else 0)
+    xs = [rng.normal(size=n) + (1j * rng.normal(size=n) if complex_values else 0.0) for _ in range(9)]
+    for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, sp.csc_matrix(S.conj().T))):
+        bs = [np.asarray(op @ x).ravel() for x in xs]
+        got = U.linearSolveMany_(f, mode, M, bs)
+        for x, g, b in zip(xs, got, bs):
+            assert _bwd(op, g, b) <= 1e-13
+            assert np.max(np.abs(g - x)) <= 1e-9 * np.max(np.abs(x))
+        one = U.linearSolve_(f, mode, M, bs[3])
+        assert np.max(np.abs(one - got[3])) <= 1e-10 * np.max(np.abs(one))
+
+
 @pytest.mark.parametrize("native", ["0", "1"])
 def test_complex_symmetric_split_arrays_and_hermitian_stays_general(gpu, pkg, native, monkeypatch):
     """a complex symmetric matrix through umfpack_zi_* with split real / imaginary arrays (Az, Xz, Bz non-NULL), on the
