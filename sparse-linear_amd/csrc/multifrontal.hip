@@ -696,7 +696,7 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(c
   constexpr int GW = gemv_waves<NR>();
   extern __shared__ __attribute__((aligned(16))) double gsm[];
   double(*xs)[NR] = reinterpret_cast<double(*)[NR]>(gsm);  // [kGemvChunk]
-  double *part = gsm + (size_t)kGemvChunk * NR;              // [GW][NR][64]
+  double *part = gsm;  // [GW][NR][64], in the place of xs once every wavefront is done with it (two workgroups per CU)
   const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
   const int np = b.np, nb = b.nb, fs = b.fs, ldu = b.ldu;
   const int nch = (nb + kGemvChunk - 1) / kGemvChunk;
@@ -732,6 +732,7 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(c
       mac_cols<NR, Z>(acc, e, ei, &xs[k][0]);
     }
   }
+  __syncthreads();
 #pragma unroll
   for (int r = 0; r < NR; ++r) part[(wave * NR + r) * 64 + lane] = acc[r];
   __syncthreads();
@@ -1527,8 +1528,7 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
         hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gather_x_kernel<NR, Z>), dim3(B.total(4)), dim3(256), 0, s, B.list.get(),
                            B.prefix(4), B.count, F.view, c, stride, work, zbuf);
         {
-          constexpr size_t lds = TRANS ? (size_t)kGemvChunk * NR * sizeof(double)
-                                       : (size_t)(kGemvChunk + gemv_waves<NR>() * 64) * NR * sizeof(double);
+          constexpr size_t lds = (size_t)(TRANS ? kGemvChunk : std::max(kGemvChunk, gemv_waves<NR>() * 64)) * NR * sizeof(double);
           static std::atomic<uint64_t> attr_set{0};  // one mask per instantiation, one bit per device
           if (first_use_on_this_device(attr_set)) {
             if (TRANS)
