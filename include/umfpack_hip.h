@@ -117,7 +117,11 @@ int spl_umfpack_zi_solve_many(int sys, const int Ap[], const int Ai[], const dou
 /* The same with the right-hand sides and the solutions in DEVICE memory (n x nrhs doubles, column-major;
  * complex ones packed (re, im) pairs: 2 n x nrhs doubles), for callers that keep a whole subspace in HBM
  * between the solves, the SpMVs and the dense products of an iteration (the FEAST-style loop,
- * Feast.hs:197-233).  The call returns when the solutions are written.  Ap/Ai/Ax stay HOST arrays — the
+ * Feast.hs:197-233).  The call returns when the solutions are written.  Streams: numeric and solve entry points
+ * work on the calling thread's default stream (hipStreamPerThread) — ordered with the legacy default stream, where a
+ * caller's own kernels usually produce d_B, exactly as the legacy stream itself is; a caller that fills d_B on a
+ * non-blocking stream of its own synchronises that stream first.  Calls from different host threads (the contour
+ * points of a FEAST iteration) overlap on the device.  Ap/Ai/Ax stay HOST arrays — the
  * arguments umfpack_*_solve ignores on the way to the factors are what a failed speculation is refactored
  * from — and may be NULL, which rules that refactoring out (the band fallback remains). */
 int spl_umfpack_di_solve_many_dev(int sys, const int Ap[], const int Ai[], const double Ax[], int nrhs, double *d_X,

@@ -26,6 +26,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "dense_lu_kernels.hpp"
@@ -917,19 +918,20 @@ struct Factors {
     const int64_t *prefix(int kind, int k = 0) const { return d.get() + seg(kind, k); }
   };
   std::vector<BigLevel> big;
-  // independent large fronts of a level run on these (factorisation and solves): one set per
-  // device for the whole process, created on first use and never destroyed (objects come and go by
-  // the thousand in a contour integration; work of different objects on the same stream is merely
-  // ordered)
+  // independent large fronts of a level run on these (factorisation): one set per device and host
+  // thread, created on first use and never destroyed (objects come and go by the thousand in a
+  // contour integration; work of different objects on the same stream is merely ordered)
   hipStream_t *side = nullptr;
   int nside = 0;
   void make_streams() {
+    // (round 3: one set per device AND host thread — factorisations issued by different threads, the contour points of
+    // a FEAST iteration, then overlap on the device instead of queueing behind each other on shared streams)
     static std::mutex mu;
-    static std::map<int, std::unique_ptr<hipStream_t[]>> sets;
+    static std::map<std::pair<int, std::thread::id>, std::unique_ptr<hipStream_t[]>> sets;
     int device = 0;
     SPL_HIP(hipGetDevice(&device));
     std::lock_guard<std::mutex> lk(mu);
-    std::unique_ptr<hipStream_t[]> &set = sets[device];
+    std::unique_ptr<hipStream_t[]> &set = sets[std::make_pair(device, std::this_thread::get_id())];
     if (!set) {
       // kStreams for the fronts, kStreams beside them for the look-ahead tiles of their large windows
       std::unique_ptr<hipStream_t[]> fresh(new hipStream_t[2 * kStreams]);

@@ -1045,7 +1045,10 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
     }
     N = new Numeric();
     SPL_HIP(hipGetDevice(&N->device));
-    hipStream_t s = nullptr;
+    // the calling thread's default stream: ordered after and before work on the legacy default stream (the caller's
+    // torch kernels, this library's other entry points) like the legacy stream itself, but factorisations and solves
+    // issued by different host threads — the contour points of a FEAST iteration — overlap on the device
+    hipStream_t s = hipStreamPerThread;
     const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // phase times on stderr (diagnostic)
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -1248,7 +1251,10 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B,
   if (N->broken) return UMFPACK_ERROR_invalid_Numeric_object;  // a failed refactorisation left no factors
   try {
     DeviceGuard g(N->device);
-    hipStream_t s = nullptr;
+    // the calling thread's default stream: ordered after and before work on the legacy default stream (the caller's
+    // torch kernels, this library's other entry points) like the legacy stream itself, but factorisations and solves
+    // issued by different host threads — the contour points of a FEAST iteration — overlap on the device
+    hipStream_t s = hipStreamPerThread;
     if (n == 0 || k == 0) return N->singular ? UMFPACK_WARNING_singular_matrix : UMFPACK_OK;
     const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // phase times on stderr (diagnostic)
     auto t_last = std::chrono::steady_clock::now();

@@ -57,6 +57,24 @@ def _apply(mat, V):
     return out
 
 
+_pool = None
+_tls = __import__("threading").local()
+
+
+def _contour_pool():
+    """worker threads for the contour points of an iteration (SPL_FEAST_THREADS, default 2; 1 = in the calling
+    thread): created once — the library keeps a set of streams per host thread that ever factored"""
+    global _pool
+    import os
+    k = int(os.environ.get("SPL_FEAST_THREADS", "2"))
+    if k <= 1:
+        return None
+    if _pool is None or _pool._max_workers != k:
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(max_workers=k, thread_name_prefix="feast-contour")
+    return _pool
+
+
 def geigSH_(params, m0, interval, matA, matB=None, guess=None):
     """(eigenvalues, eigenvectors, residuals) of A x = lambda B x inside (emin, emax); A (and B)
     Hermitian.  m0 = subspace size, must be >= the number of eigenvalues in the interval.
@@ -119,37 +137,65 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
     tol = 10.0 ** (-params.feastTolerance)
     lam, X, res = np.zeros(0), np.zeros((n, 0), dtype=complex), np.zeros(0)
     last_trace = None
-    clock = {"values": 0.0, "factor": 0.0, "solve": 0.0, "spmv": 0.0, "dense": 0.0}
+    clock = {"values": 0.0, "factor": 0.0, "solve": 0.0, "contour": 0.0, "spmv": 0.0, "dense": 0.0}
 
     def tick(key, t0):
         torch.cuda.synchronize(dev)
         clock[key] += time.perf_counter() - t0
         return time.perf_counter()
 
+    pool = _contour_pool()
     for it in range(20):
         t0 = time.perf_counter()
         BY = _apply(opB, Y)                                                    # ijob 40
         rhs = BY if BY.dtype == torch.complex128 else BY.to(torch.complex128)
         t0 = tick("spmv", t0)
-        Q = torch.zeros((m0, n), dtype=sub_t, device=dev)
-        for th in thetas:
+        def contour_point(th):
+            # One contour point: the factorisation of ze*B - A and the solves with it.  Runs on a worker thread: the
+            # points of an iteration are independent, and one mid-sized factorisation is a chain of short launches
+            # that leaves most of the device idle — the library's LU entry points work on the calling thread's own
+            # streams, so two points in flight overlap (80^3: 1.4x the factorisations, 1.85x the solves per second).
+            torch.cuda.set_device(dev)
+            if pool is not None:
+                # torch's own work of this point (allocations, the weighted sums) on a stream of this thread: on the
+                # legacy default stream every such operation is a barrier for the LU streams of ALL threads.  The
+                # library's calls return when their results are complete, and this function ends with a synchronise.
+                if not hasattr(_tls, "stream"):
+                    _tls.stream = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(_tls.stream):
+                    return contour_point_on_this_stream(th)
+            return contour_point_on_this_stream(th)
+
+        def contour_point_on_this_stream(th):
+            t = time.perf_counter()
             ze = c + r * np.exp(1j * th)
             w = complex(r * np.exp(1j * th) / ne)
             mat = type(shifted)(n, n, shifted.pointers, shifted.indices, ze * b_u - a_u)   # ijob 10: ze*B - A
-            t0 = tick("values", t0)
+            t1 = time.perf_counter()
             fact = U.factor(mat, analysis)                                     #          numeric LU, same analysis
-            t0 = tick("factor", t0)
+            t2 = time.perf_counter()
             # ijob 11 (Feast.hs:197-201 solves one subspace column at a time): all m0 vectors in one pass
             # through the factors
             qs = U.linearSolveManyDevice_(fact, U.UmfpackNormal, mat, rhs)
             if real_problem:
-                Q += 2.0 * (qs * w).real
+                part = 2.0 * (qs * w).real
             else:
                 qh = U.linearSolveManyDevice_(fact, U.UmfpackTrans, mat, rhs)  # ijob 21: the mirrored point
-                Q += qs * w + qh * w.conjugate()
+                part = qs * w + qh * w.conjugate()
                 del qh
             del fact, qs
-            t0 = tick("solve", t0)
+            torch.cuda.synchronize(dev)
+            return part, (t1 - t, t2 - t1, time.perf_counter() - t2)
+
+        parts = [contour_point(th) for th in thetas] if pool is None else list(pool.map(contour_point, thetas))
+        Q = torch.zeros((m0, n), dtype=sub_t, device=dev)
+        for part, (tv, tf, ts) in parts:   # summed in contour order whatever the threads did: same bits every run
+            Q += part
+            clock["values"] += tv          # (thread seconds: with several points in flight they add up to more than
+            clock["factor"] += tf          # the wall time of the stage, which is "contour")
+            clock["solve"] += ts
+        del parts
+        t0 = tick("contour", t0)
         # Rayleigh-Ritz on the filtered subspace (dense, m0 x m0)
         AQ = _apply(opA, Q)                                                    # ijob 30
         BQ = _apply(opB, Q)                                                    # ijob 40
