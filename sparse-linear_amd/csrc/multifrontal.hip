@@ -360,7 +360,7 @@ constexpr int kStreams = 8;        // larger fronts of a level are spread over t
 // column-major), column r of the right-hand sides / solution is c + r * stride.
 constexpr int kSolveThreads = 1024;  // one workgroup per front, 16 wavefronts for the coupling loops ...
 template <int NR>
-constexpr int solve_threads() { return NR >= 16 ? 512 : kSolveThreads; }  // ... 8 with 16 columns (256 registers per thread)
+constexpr int solve_threads() { return (NR >= 16 || NR <= 2) ? 512 : kSolveThreads; }  // ... 8 with 16 columns (256 registers per thread) and with one or two (levels of thousands of small fronts: four workgroups per CU instead of two)
 constexpr int kSolveRowBlocks = 4;   // blocks of 64 rows per workgroup in the lockstep solve steps
 constexpr int kBigSolve = 256;       // fronts above this size are solved by many workgroups, in lockstep
 
