@@ -29,6 +29,7 @@ namespace {
 
 constexpr int kBfsThreads = 256;
 constexpr int kBfsBlocks = 128;
+constexpr int kBfsShare = 4;  // lanes per frontier vertex
 constexpr int kBatch = 64;  // levels enqueued between two looks at the level pointers
 
 __global__ __launch_bounds__(256) void nd_stamp_kernel(const int *__restrict__ verts, int size, int *__restrict__ mark,
@@ -57,21 +58,25 @@ __global__ __launch_bounds__(kBfsThreads) void nd_level_kernel(const int64_t *__
                                                                unsigned *__restrict__ blocks_done) {
   const int beg = levptr[l], end = levptr[l + 1];
   const int lane = threadIdx.x & 63;
-  // whole wavefronts stay in the loop together (the slot reservation below is a wavefront operation)
-  for (int base = beg + (int)(blockIdx.x * kBfsThreads) + (int)(threadIdx.x & ~63); base < end;
-       base += (int)(gridDim.x * kBfsThreads)) {
-    const int i = base + lane;
+  // kBfsShare lanes share a vertex and take every kBfsShare-th neighbour: a level is a chain of dependent round trips
+  // (neighbour, its mark, the claim, the append) per neighbour a lane walks, and the levels of a mesh are short — a
+  // 2-D mesh of 2e6 vertices has 2 800 of at most 2 000 vertices (round 3: 4 lanes per vertex, 10.5 -> 7 us per level).
+  // Whole wavefronts stay in the loop together (the slot reservation below is a wavefront operation)
+  constexpr int per_wave = 64 / kBfsShare;
+  for (int base = beg + (int)(blockIdx.x * (kBfsThreads / kBfsShare)) + (int)(threadIdx.x >> 6) * per_wave; base < end;
+       base += (int)(gridDim.x * (kBfsThreads / kBfsShare))) {
+    const int i = base + lane / kBfsShare;
     int64_t p = 0, pe = 0;
     if (i < end) {
       const int v = queue[i];
-      p = xadj[v];
+      p = xadj[v] + lane % kBfsShare;
       pe = xadj[v + 1];
     }
     while (__any(p < pe)) {
       int u = -1;
       if (p < pe) {
         const int cand = adj[p];
-        ++p;
+        p += kBfsShare;
         if (mark[cand] == accept && atomicCAS(&mark[cand], accept, stamp) == accept) u = cand;
       }
       const unsigned long long won = __ballot(u >= 0);
