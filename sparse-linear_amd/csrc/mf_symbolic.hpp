@@ -173,6 +173,10 @@ struct Shared {
   // The device serves one region at a time (siblings wait for each other) while the host dissects the regions of a
   // depth side by side: the GPU pays where regions are few and large — the top of the tree, the serial part.
   int service_min = 1000000;        // SPL_ND_GPU_MIN (0: never)
+  // ... 150 000 below a parent whose level structure is not planar-like (3-D meshes: a few hundred wide levels per
+  // region — 100^3 analysis 0.133 -> 0.111 s, 160^3 0.485 -> 0.434 s; the thousands of narrow levels of a 2-D mesh
+  // cost the device more than the host's threads below 10^6 vertices: 3000^2 0.65 -> 0.91 s with this limit for all)
+  int service_min_bulky = 150000;
   int root_levels = 0;  // levels of the root region's final level structure (written by the depth-0 call only)
   std::atomic<int> stamp{0};
   Shared(int n_, const std::vector<int64_t> &xa, const std::vector<int> &ad, int leaf_)
@@ -184,7 +188,7 @@ struct Shared {
     if (const char *e = getenv("SPL_ND_TEAM")) max_team = std::max(1, std::min(atoi(e), 64));
     if (const char *e = getenv("SPL_ND_TEAM_REGION")) team_region = std::max(1024, atoi(e));
     if (const char *e = getenv("SPL_ND_TEAM_FRONTIER")) team_frontier = std::max(64, atoi(e));
-    if (const char *e = getenv("SPL_ND_GPU_MIN")) service_min = atoi(e);
+    if (const char *e = getenv("SPL_ND_GPU_MIN")) service_min = service_min_bulky = atoi(e);
     if (n >= team_region && max_team > 1) claim.assign((size_t)n, 0);
   }
 };
@@ -456,7 +460,7 @@ struct Worker {
     int reached = -1;
     bool from_service = false;
     const bool use_hint = hint >= 0 && (size <= kHintBelow || thin_parent) && S.mark[(size_t)hint] == region_stamp;
-    if (S.service && S.service_min > 0 && size >= S.service_min) {
+    if (S.service && S.service_min > 0 && size >= (thin_parent || depth == 0 ? S.service_min : S.service_min_bulky)) {
       try {
         reached = S.service->levels(S.verts.data() + lo, size, queue, level_ptr, use_hint ? hint : -1);
       } catch (...) {  // no memory on the device, or any other failure there: the host code below takes the region
