@@ -145,6 +145,7 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
         return time.perf_counter()
 
     pool = _contour_pool()
+    held = [0.0]  # device bytes of the largest factorisation seen (one list cell: written from the worker threads)
     for it in range(20):
         t0 = time.perf_counter()
         BY = _apply(opB, Y)                                                    # ijob 40
@@ -173,6 +174,7 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
             mat = type(shifted)(n, n, shifted.pointers, shifted.indices, ze * b_u - a_u)   # ijob 10: ze*B - A
             t1 = time.perf_counter()
             fact = U.factor(mat, analysis)                                     #          numeric LU, same analysis
+            held[0] = max(held[0], float(fact.stats["device_bytes"]))
             t2 = time.perf_counter()
             # ijob 11 (Feast.hs:197-201 solves one subspace column at a time): all m0 vectors in one pass
             # through the factors
@@ -187,7 +189,16 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
             torch.cuda.synchronize(dev)
             return part, (t1 - t, t2 - t1, time.perf_counter() - t2)
 
-        parts = [contour_point(th) for th in thetas] if pool is None else list(pool.map(contour_point, thetas))
+        if pool is not None and held[0] == 0.0:
+            # the first point of the run alone: what a factorisation holds decides whether two fit side by side (panels
+            # + transient fronts + the work of the solves: taken as twice the resident bytes, against 80 % of the device)
+            first = contour_point_on_this_stream(thetas[0])
+            if 2 * 2.0 * held[0] > 0.8 * torch.cuda.get_device_properties(dev).total_memory:
+                pool = None
+            rest = [contour_point(th) for th in thetas[1:]] if pool is None else list(pool.map(contour_point, thetas[1:]))
+            parts = [first] + rest
+        else:
+            parts = [contour_point(th) for th in thetas] if pool is None else list(pool.map(contour_point, thetas))
         Q = torch.zeros((m0, n), dtype=sub_t, device=dev)
         for part, (tv, tf, ts) in parts:   # summed in contour order whatever the threads did: same bits every run
             Q += part
