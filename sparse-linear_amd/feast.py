@@ -186,7 +186,8 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
                 part = qs * w + qh * w.conjugate()
                 del qh
             del fact, qs
-            torch.cuda.synchronize(dev)
+            # (this thread's torch stream only: a device-wide synchronise would wait for the other points in flight)
+            torch.cuda.current_stream(dev).synchronize()
             return part, (t1 - t, t2 - t1, time.perf_counter() - t2)
 
         if pool is not None and held[0] == 0.0:
