@@ -1185,13 +1185,19 @@ __device__ __forceinline__ void mac_cols(double (&acc)[NR], double er, double ei
   }
 }
 
+// the tile updates of the transposed modes with the rows on the lanes too, where the lane sums cost the most (16
+// columns: a step of the transposed pass 81 -> 74 us; strided loads, each line shared by the eight wavefronts)
+template <int NR>
+constexpr bool tile_rows_on_lanes() { return NR >= 16; }
+
 // (Z: a complex dense matrix in two planes, Band::zoff; the transposed modes are then CONJUGATE transposes)
 template <int MODE, int NR, bool Z = false>
 __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, const double (*vv)[NR],
                                        double (*res)[NR], double *part) {
   constexpr int SWV = solve_waves<NR>();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (MODE <= 1) {
+  if (MODE <= 1 || tile_rows_on_lanes<NR>()) {
+    constexpr bool TR = MODE >= 2;  // M(i, c) = conj(F(c, i))
     const int i = rb + lane;
     double acc[NR];
 #pragma unroll
@@ -1202,15 +1208,17 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
         double e[8], ei[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          e[u] = b.get(i, cb + t + SWV * u);
-          ei[u] = Z ? (&b.at(i, cb + t + SWV * u))[b.zoff] : 0.0;
+          const int c = cb + t + SWV * u;
+          e[u] = TR ? b.get(c, i) : b.get(i, c);
+          ei[u] = Z ? (TR ? -(&b.at(c, i))[b.zoff] : (&b.at(i, c))[b.zoff]) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) mac_cols<NR, Z>(acc, e[u], ei[u], &vv[t + SWV * u][0]);
       }
       for (; t < nc; t += SWV) {
-        const double e = b.get(i, cb + t);
-        const double ei = Z ? (&b.at(i, cb + t))[b.zoff] : 0.0;
+        const int c = cb + t;
+        const double e = TR ? b.get(c, i) : b.get(i, c);
+        const double ei = Z ? (TR ? -(&b.at(c, i))[b.zoff] : (&b.at(i, c))[b.zoff]) : 0.0;
         mac_cols<NR, Z>(acc, e, ei, &vv[t][0]);
       }
     }
