@@ -463,6 +463,45 @@ __device__ __forceinline__ void couple_block(const Panels &fr, int ilo, int ihi,
         if (g == 0 && i < ihi) W[(size_t)r * fs + i] -= acc[r];
       }
     }
+  } else if (NR >= 8) {
+    // M(i, c0 + tt) = F(c0 + tt, i) (Z: its conjugate), with the rows i on the lanes as above: a lane walks rows
+    // c0 + g, c0 + g + 4, ... of ITS column of F (the four quarters of a row read neighbouring doubles; a line is used
+    // up over four trips), and the sums need two shuffles per column of W instead of a reduction over the 64 lanes
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int g = lane >> 4, rl = lane & 15;
+    const int nu = (jb - g + 3) / 4;
+    for (int ib = ilo + wave * 16; ib < ihi; ib += nw * 16) {
+      const int i = ib + rl;
+      double acc[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[r] = 0.0;
+      if (i < ihi) {
+        const double *colp = fr.col(i) + c0 + g;
+        const size_t zp = fr.zcol(i);
+        int u = 0;
+        for (; u + 8 <= nu; u += 8) {
+          double e[8], ei[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            e[q] = colp[4 * (u + q)];
+            ei[q] = Z ? -colp[4 * (u + q) + zp] : 0.0;
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) mac_cols<NR, Z>(acc, e[q], ei[q], &v[g + 4 * (u + q)][0]);
+        }
+        for (; u < nu; ++u) {
+          const double e = colp[4 * u];
+          const double ei = Z ? -colp[4 * u + zp] : 0.0;
+          mac_cols<NR, Z>(acc, e, ei, &v[g + 4 * u][0]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        acc[r] += __shfl_xor(acc[r], 16, 64);
+        acc[r] += __shfl_xor(acc[r], 32, 64);
+        if (g == 0 && i < ihi) W[(size_t)r * fs + i] -= acc[r];
+      }
+    }
   } else {
     // M(i, c0 + tt) = F(c0 + tt, i) (Z: its conjugate): rows c0 .. of column i of F, contiguous
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
