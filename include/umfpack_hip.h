@@ -149,6 +149,16 @@ int spl_umfpack_path(void *Numeric);
  * is invalid. */
 int spl_umfpack_stats(void *Numeric, double out[8]);
 
+/* the most recent solve call that finished on a Numeric object, and the size of a walk over its factors (the
+ * measurement of the triangular solves: SURVEY.md 8d "SpTRSV").  UMFPACK reports the first four through
+ * Info[UMFPACK_IR_TAKEN], [UMFPACK_IR_ATTEMPTED], [UMFPACK_OMEGA1] (umfpack_di_solve here fills them too when Info is
+ * not NULL; the reference passes nullPtr, Umfpack.hs:99).  out[0] walks over the factors (forward + backward
+ * substitution: the first solve plus one per refinement step attempted), out[1] refinement steps kept, out[2]
+ * attempted, out[3] largest componentwise backward error max_i |r_i| / (|A||x| + |b|)_i among the delivered columns,
+ * out[4] bytes ONE walk reads: 8 per stored entry of L and U (dense panels, no index arrays) + 16 n for the vectors.
+ * Returns 0, or -1 if the object is invalid. */
+int spl_umfpack_solve_report(void *Numeric, double out[8]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1525,8 +1525,21 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
     (void)hipStreamSynchronize(s);
     const auto now = std::chrono::steady_clock::now();
     const double ms = std::chrono::duration<double, std::milli>(now - t_last).count();
-    fprintf(stderr, "[mf_solve] %s level %2d: %4d large of %6zu fronts %8.2f ms\n", dir, d, F.big[(size_t)d].count,
-            T.by_depth[(size_t)d].size(), ms);
+    // bytes of factor panels this phase reads: forward L11 / 2 + L21 (transposed: U11 / 2, U12 in the boundary kernel),
+    // backward U11 / 2 + U12 — half the pivot block and one coupling panel either way
+    const bool large = dir[0] == 'u' ? dir[3] == 'l' : dir[5] == 'l';
+    double bytes = 0.0;
+    int maxnp = 0;
+    for (int f : T.by_depth[(size_t)d]) {
+      const bool is_big = T.fs(f) > F.big_solve && T.np[(size_t)f] > 0;
+      if (is_big != large) continue;
+      const double np = T.np[(size_t)f], nb = T.fs(f) - T.np[(size_t)f];
+      bytes += (np * np * 0.5 + np * nb) * 8.0 * F.zm;
+      maxnp = std::max(maxnp, T.np[(size_t)f]);
+    }
+    fprintf(stderr, "[mf_solve] %s level %2d: %4d large of %6zu fronts %8.2f ms  %8.1f MB %6.2f TB/s  steps %d max np %d\n", dir, d,
+            F.big[(size_t)d].count, T.by_depth[(size_t)d].size(), ms, bytes * 1e-6, ms > 0 ? bytes / ms * 1e-9 : 0.0,
+            large ? F.big[(size_t)d].steps : 0, maxnp);
     t_last = now;
   };
   if (timing) (void)hipStreamSynchronize(s);

@@ -106,6 +106,11 @@ struct Numeric {
   // (what mf_factor scatters); sp_idx / sp_scale: the permutations and scalings around a solve with B's factors,
   // composed with B's nested-dissection ordering — [0] before, [1] after A x = b; [2] before, [3] after A^T x = b.
   int sp_stage = 0;
+  // the most recent solve call that finished on this object (spl_umfpack_solve_report; UMFPACK reports the like in
+  // Info[UMFPACK_IR_TAKEN .. UMFPACK_OMEGA1]): walks over the factors (first solve + refinement steps, whatever path),
+  // refinement steps kept / attempted, largest componentwise backward error among the delivered columns
+  std::atomic<int> last_walks{0}, last_ir_taken{0}, last_ir_attempted{0};
+  std::atomic<double> last_omega{0.0};
   Matrix *spA = nullptr, *spAt = nullptr;
   DBuf<int> sp_idx[4];
   DBuf<double> sp_scale[4];
@@ -467,19 +472,97 @@ __global__ void residual_kernel(int n, const double *__restrict__ b, const doubl
   }
 }
 
+// The same two quantities in ONE pass over the rows of op, with the residual accumulated in twice the working
+// precision (round 4): every product a_ik x_k is taken with its rounding error (fma), every addition with its own
+// (Knuth's two-sum), the errors summed beside the main sum, and the eight partial sums of a row meet the same way.
+// r_i is then the correctly rounded residual up to one rounding of the final sum, not the 1 .. (row length) roundings of
+// a plain b - A x.  Why it matters: the componentwise backward error of a refined solution sits at eps / 2 or below,
+// while a plainly evaluated residual carries about a row length of roundings of its own — the measured omega then
+// stalls at 1.2 .. 1.3 eps (3-D Poisson, 8e6 unknowns: 2.76e-16 after the first refinement step), UMFPACK's test
+// omega < eps never fires, and a second refinement step — a whole walk over the factors, 65 ms of 230 at C5 — is spent
+// to find out that it changes nothing.  UMFPACK's rules are unchanged; what they look at is more accurate.
+// (SPL_LU_RESIDUAL=plain: the three-kernel form above.)
+__device__ __forceinline__ void two_sum(double a, double b, double &s, double &e) {
+  s = a + b;
+  const double bb = s - a;
+  e = (a - (s - bb)) + (b - bb);
+}
+__global__ __launch_bounds__(256) void residual_dd_kernel(int n, const int64_t *__restrict__ rowptr,
+                                                          const int *__restrict__ colidx, const double *__restrict__ val,
+                                                          const double *__restrict__ x, const double *__restrict__ b,
+                                                          double *__restrict__ r, double *__restrict__ omega, size_t stride) {
+  const int i = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 3), part = threadIdx.x & 7;
+  const size_t col = (size_t)blockIdx.y * stride;
+  double hi = 0.0, lo = 0.0, ab = 0.0;
+  if (i < n) {
+    if (part == 0) hi = b[col + i];
+    for (int64_t p = rowptr[i] + part; p < rowptr[i + 1]; p += 8) {
+      const double a = val[p], xv = x[col + colidx[p]];
+      const double ph = a * xv, pl = __builtin_fma(a, xv, -ph);
+      double sm, e;
+      two_sum(hi, -ph, sm, e);
+      hi = sm;
+      lo += e - pl;
+      ab += fabs(a) * fabs(xv);
+    }
+  }
+#pragma unroll
+  for (int d = 1; d < 8; d <<= 1) {
+    const double oh = __shfl_xor(hi, d, 64), ol = __shfl_xor(lo, d, 64);
+    double sm, e;
+    two_sum(hi, oh, sm, e);
+    hi = sm;
+    lo += ol + e;
+    ab += __shfl_xor(ab, d, 64);
+  }
+  double a = 0.0;
+  if (i < n && part == 0) {
+    const double v = hi + lo;
+    r[col + i] = v;
+    const double den = ab + fabs(b[col + i]);
+    a = fabs(v);
+    if (a > 0.0) a = den > 0.0 ? a / den : 1e300 * 1e300;
+    if (!(a == a)) a = 1e300 * 1e300;  // NaN counts as +inf
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) a = fmax(a, __shfl_xor(a, d, 64));
+  if ((threadIdx.x & 63) == 0 && a > 0.0) {
+    unsigned long long *slot = reinterpret_cast<unsigned long long *>(omega + blockIdx.y);
+    const unsigned long long mine = (unsigned long long)__double_as_longlong(a);
+    if (mine > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, mine);
+  }
+}
+
 __global__ void add_kernel(size_t n, double *__restrict__ x, const double *__restrict__ d) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] += d[i];
 }
 
-// vector helpers of the FGMRES polish (gmres_polish): out += <a, b>;  y = alpha * x + beta * y
-__global__ __launch_bounds__(256) void dot_kernel(size_t n, const double *__restrict__ a, const double *__restrict__ b,
-                                                  double *__restrict__ out) {
+// vector helpers of the FGMRES polish (gmres_polish): <a, b> in two stages — every workgroup writes the sum of its
+// share to part[blockIdx.x] (fixed strides, fixed tree), one workgroup adds the parts in index order: the same bits on
+// every run (an atomic sum made polished solutions differ from run to run: ADVICE r3);  y = alpha * x + beta * y
+__global__ __launch_bounds__(256) void dot_part_kernel(size_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                                       double *__restrict__ part) {
+  __shared__ double red[4];
   double acc = 0.0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += a[i] * b[i];
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
-  if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(out, acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void dot_final_kernel(int nparts, const double *__restrict__ part, double *__restrict__ out) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int sft = 128; sft > 0; sft >>= 1) {
+    if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
 }
 __global__ __launch_bounds__(256) void axpby_kernel(size_t n, double alpha, const double *__restrict__ x, double beta,
                                                     double *__restrict__ y) {
@@ -1180,12 +1263,12 @@ static bool factor_static_pivot_of_copy(Numeric *N, hipStream_t s) {
 static void gmres_polish(Numeric *N, int sys, const Matrix *op, const double *b, double *x, double *work, int m,
                          hipStream_t s) {
   const size_t n = (size_t)N->n;
-  DBuf<double> V((size_t)(m + 1) * n), Z((size_t)m * n), w(n), dsc(1);
   const unsigned gv = (unsigned)((n + 255) / 256), gd = gv < 1024 ? gv : 1024;
+  DBuf<double> V((size_t)(m + 1) * n), Z((size_t)m * n), w(n), dsc(1 + (size_t)gd);
   auto dot = [&](const double *a, const double *c) {
     double h = 0.0;
-    SPL_HIP(hipMemsetAsync(dsc.get(), 0, sizeof(double), s));
-    hipLaunchKernelGGL(dot_kernel, dim3(gd), dim3(256), 0, s, n, a, c, dsc.get());
+    hipLaunchKernelGGL(dot_part_kernel, dim3(gd), dim3(256), 0, s, n, a, c, dsc.get() + 1);
+    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, s, (int)gd, dsc.get() + 1, dsc.get());
     SPL_HIP(hipMemcpyAsync(&h, dsc.get(), sizeof(double), hipMemcpyDeviceToHost, s));
     SPL_HIP(hipStreamSynchronize(s));
     return h;
@@ -1246,7 +1329,7 @@ static void gmres_polish(Numeric *N, int sys, const Matrix *op, const double *b,
 
 // device_io: X and B are device pointers (spl_umfpack_*_solve_many_dev), else host
 static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B, const int *Ap, const int *Ai,
-                         const double *Ax, bool device_io = false) {
+                         const double *Ax, bool device_io = false, double *Info = nullptr) {
   const int n = N->n;
   if (N->broken) return UMFPACK_ERROR_invalid_Numeric_object;  // a failed refactorisation left no factors
   try {
@@ -1287,13 +1370,26 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B,
     if (N->speculative) turn.lock();
     std::vector<double> omega((size_t)k, 0.0), on((size_t)k, 0.0);
     bool polished = false;
+    int walks = 0, ir_taken = 0, ir_attempted = 0;
+    double delivered = 0.0;
     lap("buffers, upload of b");
   again:
     factor_solve(N, sys, db.get(), dx.get(), dwork.get(), k, stride, s);
+    ++walks;
     lap("solve with the factors");
     if (!N->singular) {
       const Matrix *op = sys == UMFPACK_A ? N->A : N->At;
+      const char *rs = getenv("SPL_LU_RESIDUAL");
+      const bool plain_residual = op->vw != 1 || (rs && rs[0] == 'p');
       auto backward_error = [&](const double *x, double *r, std::vector<double> &out) {
+        if (!plain_residual) {
+          SPL_HIP(hipMemsetAsync(domega.get(), 0, (size_t)k * sizeof(double), s));
+          hipLaunchKernelGGL(residual_dd_kernel, dim3((unsigned)(((size_t)n * 8 + 255) / 256), (unsigned)k), dim3(256), 0, s,
+                             n, op->rowptr64.get(), op->colidx.get(), op->val.get(), x, db.get(), r, domega.get(), stride);
+          SPL_HIP(hipMemcpyAsync(out.data(), domega.get(), (size_t)k * sizeof(double), hipMemcpyDeviceToHost, s));
+          SPL_HIP(hipStreamSynchronize(s));
+          return;
+        }
         for (int c = 0; c < k; ++c) {
           int st = launch_spmv(op, x + (size_t)c * stride, dax.get() + (size_t)c * stride, 0, s);
           if (st != SPL_OK) throw DeviceError{st};
@@ -1319,6 +1415,8 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B,
       const double stall = 0.5;
       for (int it = 0; it < max_steps && nactive > 0; ++it) {
         SPL_HIP(hipMemcpyAsync(dxn.get(), dx.get(), used * sizeof(double), hipMemcpyDeviceToDevice, s));
+        ++walks;
+        ++ir_attempted;
         if (nactive == k) {
           factor_solve(N, sys, dr.get(), dd.get(), dwork.get(), k, stride, s);
           hipLaunchKernelGGL(add_kernel, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, s, used, dxn.get(),
@@ -1356,6 +1454,9 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B,
                   nactive, k, lo, hi, lo2, hi2);
         }
         lap("refinement step");
+        bool kept = false;
+        for (int c = 0; c < k; ++c) kept |= active[(size_t)c] && on[(size_t)c] <= omega[(size_t)c];
+        ir_taken += kept ? 1 : 0;
         for (int c = 0; c < k; ++c) {
           if (!active[(size_t)c]) continue;
           const double o_new = on[(size_t)c], o_old = omega[(size_t)c];
@@ -1386,6 +1487,7 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B,
       // refined solution is backward stable to rounding level, as pivoted factors would make it
       double worst = 0.0;
       for (int c = 0; c < k; ++c) worst = (omega[(size_t)c] <= worst) ? worst : omega[(size_t)c];  // NaN -> worst
+      delivered = worst;
       if (turn.owns_lock() && N->speculative && !(worst <= 1e-13)) {
         // first the static-pivoting stage (stays on the tree, still checked by this very loop), then, if that
         // fails too, the band factorisation with partial pivoting
@@ -1414,15 +1516,21 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B,
             for (int c = 0; c < k; ++c)
               if (!(omega[(size_t)c] <= 1e-13))
                 for (int cycle = 0; cycle < 3; ++cycle) {
-                  gmres_polish(N, sys, op, db.get() + (size_t)c * stride, dx.get() + (size_t)c * stride, dwork.get(), 20, s);
+                  // the polish writes the column in place: keep the iterate it started from, and put it back when the
+                  // cycle made the backward error worse — omega[c] is then the error of what is delivered
+                  const size_t off = (size_t)c * stride;
+                  SPL_HIP(hipMemcpyAsync(dxn.get() + off, dx.get() + off, stride * sizeof(double), hipMemcpyDeviceToDevice, s));
+                  gmres_polish(N, sys, op, db.get() + off, dx.get() + off, dwork.get(), 20, s);
                   backward_error(dx.get(), dr.get(), on);
                   const bool better = on[(size_t)c] < 0.5 * omega[(size_t)c];
                   if (on[(size_t)c] <= omega[(size_t)c]) omega[(size_t)c] = on[(size_t)c];
+                  else SPL_HIP(hipMemcpyAsync(dx.get() + off, dxn.get() + off, stride * sizeof(double), hipMemcpyDeviceToDevice, s));
                   if (timing) fprintf(stderr, "[solve] FGMRES cycle %d, column %d: backward error %.2e\n", cycle, c, on[(size_t)c]);
                   if (omega[(size_t)c] <= 1e-13 || !better) break;
                 }
             worst = 0.0;
             for (int c = 0; c < k; ++c) worst = (omega[(size_t)c] <= worst) ? worst : omega[(size_t)c];
+            delivered = worst;
             lap("FGMRES polish");
             if (worst <= 1e-13) goto deliver;
           }
@@ -1449,6 +1557,17 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B,
     SPL_HIP(hipStreamSynchronize(s));
     SPL_HIP(hipGetLastError());
     lap("download of x");
+    N->last_walks = walks;
+    N->last_ir_taken = ir_taken;
+    N->last_ir_attempted = ir_attempted;
+    N->last_omega = delivered;
+    if (Info) {  // what umfpack_*_solve reports there (umfpack.h: UMFPACK_IR_TAKEN 80, _IR_ATTEMPTED 81, _OMEGA1 82, _OMEGA2 83)
+      Info[0] = N->singular ? UMFPACK_WARNING_singular_matrix : UMFPACK_OK;
+      Info[80] = ir_taken;
+      Info[81] = ir_attempted;
+      Info[82] = delivered;  // one quantity here: max_i |r_i| / (|A||x| + |b|)_i over all rows (omega2's rows do not occur:
+      Info[83] = 0.0;        // the denominator of a row with entries never vanishes unless its whole numerator does)
+    }
     return N->singular ? UMFPACK_WARNING_singular_matrix : UMFPACK_OK;
   } catch (const DeviceError &e) {
     return e.status == SPL_ERROR_out_of_memory ? UMFPACK_ERROR_out_of_memory : UMFPACK_ERROR_internal_error;
@@ -1461,13 +1580,13 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B,
 
 int umfpack_di_solve(int sys, const int Ap[], const int Ai[], const double Ax[], double X[],
                      const double B[], void *NumericIn, const double Control[], double Info[]) {
-  (void)Control; (void)Info;
+  (void)Control;
   Numeric *N = as_numeric(NumericIn);
   if (!N) return UMFPACK_ERROR_invalid_Numeric_object;
   if (!X || !B) return UMFPACK_ERROR_argument_missing;
   if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;  // UMFPACK needs A for refinement
   if (sys != UMFPACK_A && sys != UMFPACK_At) return UMFPACK_ERROR_invalid_system;
-  return solve_columns(N, sys, 1, X, B, Ap, Ai, Ax);
+  return solve_columns(N, sys, 1, X, B, Ap, Ai, Ax, false, Info);
 }
 
 // batched linearSolve: nrhs right-hand sides in one call (see umfpack_hip.h)
@@ -1553,6 +1672,33 @@ int spl_umfpack_stats(void *NumericIn, double out[8]) {
     out[4] = (double)(N->AB.n + N->blkinv.n) * sizeof(double);
     out[5] = 2.0 * (double)N->n * (double)N->kl * (double)N->ku;
   }
+  return 0;
+}
+
+// the most recent solve on this object and the bytes a walk over its factors reads (see umfpack_hip.h)
+int spl_umfpack_solve_report(void *NumericIn, double out[8]) {
+  Numeric *N = as_numeric(NumericIn);
+  if (!N || !out) return -1;
+  for (int i = 0; i < 8; ++i) out[i] = 0.0;
+  out[0] = (double)N->last_walks.load();
+  out[1] = (double)N->last_ir_taken.load();
+  out[2] = (double)N->last_ir_attempted.load();
+  out[3] = N->last_omega.load();
+  // factor entries a walk touches, each once: the tree's panels — np^2 + 2 np nb per front (L11 and U11 share the
+  // pivot block, L21, U12; complex fronts: two planes) —, or the band; 8 bytes each, no index arrays (dense panels);
+  // plus the right-hand side in and the solution out
+  double entries = 0.0;
+  const mf::Tree *T = N->mfact ? ((N->zfront && N->ztree) ? N->ztree.get() : N->tree.get()) : nullptr;
+  if (T) {
+    for (int f = 0; f < T->nfronts; ++f) {
+      const double np = T->np[(size_t)f], nb = T->nb[(size_t)f];
+      entries += np * np + 2.0 * np * nb;
+    }
+    if (N->zfront && N->ztree) entries *= 2.0;
+  } else {
+    entries = (double)N->n * ((double)N->kl + (double)N->ku + 1.0);
+  }
+  out[4] = 8.0 * entries + 16.0 * (double)N->n;
   return 0;
 }
 

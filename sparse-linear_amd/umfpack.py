@@ -64,6 +64,8 @@ def _declare():
     L.spl_umfpack_path.argtypes = [vp]
     L.spl_umfpack_stats.restype = C.c_int
     L.spl_umfpack_stats.argtypes = [vp, C.POINTER(C.c_double)]
+    L.spl_umfpack_solve_report.restype = C.c_int
+    L.spl_umfpack_solve_report.argtypes = [vp, C.POINTER(C.c_double)]
     L._umf_declared = True
     return L
 
@@ -123,6 +125,16 @@ class Factors(_Handle):
         st["complex_fronts"] = flags & 1          # native complex fronts (zi objects)
         st["block_pivoting"] = (flags >> 1) & 1   # threshold pivoting inside the diagonal blocks of the fronts
         return st
+
+    @property
+    def solve_report(self):
+        """the most recent solve on these factors and the bytes one walk over them reads (spl_umfpack_solve_report,
+        include/umfpack_hip.h): what UMFPACK returns in Info[UMFPACK_IR_TAKEN / _IR_ATTEMPTED / _OMEGA1]"""
+        buf = (C.c_double * 8)()
+        if _declare().spl_umfpack_solve_report(self.value, buf) != 0:
+            raise UmfpackError("spl_umfpack_solve_report: invalid Numeric object")
+        return {"walks": int(buf[0]), "ir_taken": int(buf[1]), "ir_attempted": int(buf[2]),
+                "backward_error": float(buf[3]), "walk_bytes": float(buf[4])}
 
 
 def analyze(mat):

@@ -582,11 +582,22 @@ def test_stalled_static_pivoting_is_polished_by_fgmres(gpu, pkg, monkeypatch):
     xs = rng.uniform(0.5, 1.5, n)
     b = np.asarray(S @ xs).ravel()
     fact = U.factor(M, U.analyze(M))
+    # (round 4: residuals accumulated in twice the working precision — refinement with them no longer stalls on this
+    # matrix; the plainly evaluated residual, SPL_LU_RESIDUAL=plain, reproduces the stall the polish was written for)
+    x = U.linearSolve_(fact, U.UmfpackNormal, M, b)
+    assert fact.path == 5 and _backward_error(S, x, b) <= 1e-13
+    assert fact.solve_report["backward_error"] <= 1e-13
+    monkeypatch.setenv("SPL_LU_RESIDUAL", "plain")
     x = U.linearSolve_(fact, U.UmfpackNormal, M, b)
     assert fact.path == 5 and _backward_error(S, x, b) <= 1e-13
     monkeypatch.setenv("SPL_LU_GMRES", "0")
     x0 = U.linearSolve_(fact, U.UmfpackNormal, M, b)
     assert 1e-13 < _backward_error(S, x0, b) <= 1e-9
+    # what the object reports is the error of what it delivered, measured its own way
+    assert 0.1 * _backward_error(S, x0, b) <= fact.solve_report["backward_error"] <= 10.0 * _backward_error(S, x0, b)
+    monkeypatch.delenv("SPL_LU_RESIDUAL")
+    x1 = U.linearSolve_(fact, U.UmfpackNormal, M, b)
+    assert _backward_error(S, x1, b) <= 1e-9
 
 
 def test_solve_many_device_pointers_match_host(gpu, pkg, O):
