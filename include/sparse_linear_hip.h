@@ -68,6 +68,12 @@ void spl_free(void *p);
  * fails; this gives them back now (e.g. before another library needs the memory) and returns the
  * number of bytes released.  SPL_CACHE_DEVICE_MEMORY=0 in the environment: never keep any. */
 unsigned long long spl_release_cached_memory(void);
+/* Seconds this process has spent inside hipMalloc on behalf of the library so far (requests the kept blocks could
+ * not serve).  A request that reaches into memory the driver is still wiping — released by this or an earlier
+ * process a few seconds before — waits there, and nothing the process has queued on the device runs meanwhile
+ * (tools/probe/malloc_overlap_probe.hip): the difference around a call tells how much of it was that wait
+ * (benchmarks: the first factorisation of a large matrix against the steady state). */
+double spl_device_alloc_seconds(void);
 
 /* ---- one-shot operations on borrowed host CSC 5-tuples ---------------------- */
 

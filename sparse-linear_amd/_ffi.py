@@ -81,6 +81,8 @@ def _declare(L):
     L.spl_device_count.argtypes = []
     L.spl_release_cached_memory.restype = C.c_ulonglong
     L.spl_release_cached_memory.argtypes = []
+    L.spl_device_alloc_seconds.restype = C.c_double
+    L.spl_device_alloc_seconds.argtypes = []
     L.spl_free.restype = None
     L.spl_free.argtypes = [C.c_void_p]
     sigs = {
@@ -160,6 +162,11 @@ def check(where, status):
 
 def device_count():
     return int(lib().spl_device_count())
+
+
+def device_alloc_seconds():
+    """seconds this process has spent inside hipMalloc for the library so far (spl_device_alloc_seconds)"""
+    return float(lib().spl_device_alloc_seconds())
 
 
 def release_cached_memory():

@@ -200,6 +200,8 @@ void spl_free(void *p) { free(p); }
 
 unsigned long long spl_release_cached_memory(void) { return (unsigned long long)device_release_cached(); }
 
+double spl_device_alloc_seconds(void) { return device_alloc_seconds(); }
+
 int spl_matrix_create(int nrows, int ncols, const int *Ap, const int *Ai, const double *Ax, void **H) {
   return spl_matrix_create_rowblock(nrows, ncols, Ap, Ai, Ax, 0, 1, H);
 }

@@ -37,6 +37,7 @@ void *device_alloc(size_t bytes);
 void device_free(void *p) noexcept;
 size_t device_free_bytes();      // free memory as the driver reports it + what the pool would give back
 size_t device_release_cached();  // returns the bytes given back to the driver
+double device_alloc_seconds();  // seconds spent inside hipMalloc so far (pool misses)
 
 // RAII device buffer, movable
 template <typename T>

@@ -12,6 +12,8 @@
 // Blocks between kSmallMin and kCacheMin are kept as well, up to kSmallKeptMax bytes in total: a hipFree
 // synchronises the device and costs 0.1-0.2 ms, and an operation like the ordered SpGEMM allocates and releases some
 // twenty work arrays of 1-500 MB per call — 3 ms of a 19 ms product on config C4 before this tier existed.
+#include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -53,6 +55,17 @@ struct Pool {
   }
 };
 
+// seconds this process has spent inside hipMalloc on behalf of device_alloc (spl_device_alloc_seconds): a request that
+// reaches into memory the driver is still wiping waits there, and nothing the process has queued runs meanwhile
+// (tools/probe/malloc_overlap_probe.hip) — the one part of a first factorisation that the steady state does not have
+std::atomic<long long> g_alloc_ns{0};
+hipError_t timed_malloc(void **p, size_t bytes) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const hipError_t e = hipMalloc(p, bytes);
+  g_alloc_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  return e;
+}
+
 Pool &pool() {
   static Pool *p = new Pool();  // never destroyed: DBufs of static lifetime may outlive any order
   return *p;
@@ -64,12 +77,12 @@ void *device_alloc(size_t bytes) {
   Pool &P = pool();
   void *p = nullptr;
   if (bytes < kSmallMin || !P.enabled) {
-    hipError_t e = hipMalloc(&p, bytes);
+    hipError_t e = timed_malloc(&p, bytes);
     if (e == hipErrorOutOfMemory && P.kept_bytes) {
       (void)hipGetLastError();
       std::lock_guard<std::mutex> lk(P.mu);
       P.release_kept(-1);
-      e = hipMalloc(&p, bytes);
+      e = timed_malloc(&p, bytes);
     }
     SPL_HIP(e);
     return p;
@@ -87,11 +100,11 @@ void *device_alloc(size_t bytes) {
     P.kept.erase(it);
     return p;
   }
-  hipError_t e = hipMalloc(&p, bytes);
+  hipError_t e = timed_malloc(&p, bytes);
   if (e == hipErrorOutOfMemory && P.kept_bytes) {
     (void)hipGetLastError();
     P.release_kept(-1);
-    e = hipMalloc(&p, bytes);
+    e = timed_malloc(&p, bytes);
   }
   SPL_HIP(e);
   P.live[p] = Pool::Block{bytes, device};
@@ -139,6 +152,8 @@ size_t device_free_bytes() {
     if (kv.second.second == device) free_b += kv.first;
   return free_b;
 }
+
+double device_alloc_seconds() { return (double)g_alloc_ns.load() * 1e-9; }
 
 size_t device_release_cached() {
   Pool &P = pool();

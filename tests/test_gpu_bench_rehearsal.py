@@ -129,23 +129,35 @@ def test_four_ranks_all_schedules(gpu):
 
 
 def test_secondary_block_rides_on_the_headline_line(gpu):
-    """the banded / C4 / C5 block bench.py appends at N = 1 (tools/bench_secondary.py), on small instances of the same
-    code: every entry carries value, unit, roofline and parity; the headline fields are untouched"""
+    """the C5 / banded / C4 / SpMV block bench.py appends at N = 1 (tools/bench_secondary.py, one child process per
+    item), on small instances of the same code: every entry carries value, unit, roofline and parity — the LU entries
+    the roofline of their triangular solves too —, an item that fails costs only itself, the headline fields are untouched"""
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "400000", "--steps", "3", "--warmup", "1",
-           "--cpu-reps", "1", "--secondary", "banded,c5:16,c4:12,zi:14"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+           "--cpu-reps", "1", "--secondary", "c5:16:cpu8,banded,no-such-item,c4:12,zi:14,spmv:poisson3d:16,spmv:rmat:12"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["metric"] == "fp64 CSR SpMV effective GB/s" and out["n_gpus"] == 1 and out["parity"]["not_close_1e-10"] == 0
     assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["kind"] == "port"
     sec = out["secondary"]
-    assert set(sec) == {"c2_banded_spmv", "c5_lu_poisson3d_16", "c4_spgemm_rmat12", "f3_zi_lu_shifted_poisson3d_14"}
+    assert set(sec) == {"c2_banded_spmv", "c5_lu_poisson3d_16", "c4_spgemm_rmat12", "f3_zi_lu_shifted_poisson3d_14",
+                        "spmv_poisson3d_16", "spmv_rmat_12", "no-such-item"}
+    assert "error" in sec["no-such-item"]
     assert sec["f3_zi_lu_shifted_poisson3d_14"]["parity"]["within_1e-10"] and sec["f3_zi_lu_shifted_poisson3d_14"]["unit"] == "s"
     assert sec["c2_banded_spmv"]["parity"]["bit_identical"] and sec["c2_banded_spmv"]["roofline"]["bound"] == "hbm"
-    assert sec["c5_lu_poisson3d_16"]["parity"]["within_1e-10"] and sec["c5_lu_poisson3d_16"]["unit"] == "s"
+    lu = sec["c5_lu_poisson3d_16"]
+    assert lu["parity"]["within_1e-10"] and lu["unit"] == "s" and lu["parity"]["second_solve_bit_identical"]
+    assert lu["value"] >= lu["analyze_s"] + lu["first_factor_s"]  # the one-shot figure: analysis + FIRST factorisation + first solve
+    sr = lu["solve_roofline"]
+    assert sr["bound"] == "hbm" and sr["walks"] >= 1 and sr["bytes_per_walk"] > 16 * 4096 and 0 < sr["frac"] < 1
+    assert sr["walks"] == 1 + sr["refinement_steps"] and sr["backward_error"] < 2.3e-16
+    assert lu["cpu_baseline"]["same_workload"] is False
+    assert sec["f3_zi_lu_shifted_poisson3d_14"]["solve_roofline"]["walks"] >= 1
+    for k in ("spmv_poisson3d_16", "spmv_rmat_12"):
+        assert sec[k]["parity"]["bit_identical"] and sec[k]["roofline"]["bound"] == "hbm" and sec[k]["unit"] == "GB/s"
     assert sec["c4_spgemm_rmat12"]["parity"]["structure_and_values_bit_identical"]
     assert sec["c4_spgemm_rmat12"]["cpu_baseline"]["kind"] == "port" and sec["c4_spgemm_rmat12"]["unit"] == "Gproducts/s"
 

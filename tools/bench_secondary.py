@@ -10,6 +10,14 @@ timed region (N = 1 only) so that the driver's one bench line carries every conf
                    umfpack_di_* ABI, TFLOP/s of the factorisation, error against the manufactured solution,
                    scaled residual
 
+  spmv_other(...)  the SpMV kernel on the matrices of the other configurations — C5's 3-D Poisson matrix (200^3) and
+                   C4's R-MAT matrix (BASELINE.md §3 lists their bytes) — with roofline and the whole y against the oracle
+  lu_zi(...)       row f3: the complex entry points on a FEAST contour point
+
+bench.py runs every item in a child process of its own (`python tools/bench_secondary.py --item c5:200 ...`, one JSON
+line on stdout): a fault, an out-of-memory kill or a hang in one of them costs that item, never the headline line
+(ADVICE r3), and a factorisation measured there IS the one-shot case — a fresh process, nothing in the library's pool.
+
 The oracle appears only in the parity / cpu_baseline legs, never in a timed call."""
 import gc
 import hashlib
@@ -188,7 +196,13 @@ def lu_zi(pkg, torch, m=100):
     x = U.linearSolve_(fa, U.UmfpackNormal, A, b)
     torch.cuda.synchronize()
     t3 = time.perf_counter()
+    t = time.perf_counter()
+    U.linearSolve_(fa, U.UmfpackNormal, A, b)  # the same call again: the solve in its steady state
+    torch.cuda.synchronize()
+    solve2 = time.perf_counter() - t
+    rep = fa.solve_report
     bh = np.asarray(S.conj().T @ xs).ravel()
+    t3b = time.perf_counter()
     xh = U.linearSolve_(fa, U.UmfpackTrans, A, bh)
     t4 = time.perf_counter()
     st = fa.stats
@@ -203,16 +217,18 @@ def lu_zi(pkg, torch, m=100):
     rate = st["flops"] / max(steady, 1e-9) * 1e-12
     out = {"workload": "complex sparse LU + solves (umfpack_zi_symbolic/numeric/solve), z I - A on the 3-D 7-point Laplacian %d^3, "
                        "z = 3 + 0.5i: n=%d complex unknowns, nnz=%d" % (m, n, int(S.nnz)),
-           "value": round((t1 - t0) + steady + (t3 - t2), 3), "unit": "s", "higher_is_better": False,
-           "value_is": "analyze + factor (steady state) + solve of A x = b",
+           "value": round(t3 - t0, 3), "unit": "s", "higher_is_better": False,
+           "value_is": "one shot in a fresh process: analyze + FIRST factorisation + first solve of A x = b",
+           "steady_state_s": round((t1 - t0) + steady + solve2, 3),
            "analyze_s": round(t1 - t0, 3), "factor_s": round(steady, 3), "first_factor_s": round(t2 - t1, 3),
-           "solve_s": round(t3 - t2, 3), "solve_conjugate_transposed_s": round(t4 - t3, 3),
+           "first_solve_s": round(t3 - t2, 3), "solve_s": round(solve2, 3), "solve_conjugate_transposed_s": round(t4 - t3b, 3),
            "factorisation": {"path": st["path"], "native_complex_fronts": bool(st["complex_fronts"]), "fronts": st["fronts"],
                              "device_GB": round(st["device_bytes"] * 1e-9, 2), "flops": st["flops"],
                              "TFLOP_per_s": round(rate, 2)},
            "roofline": {"bound": "mfma", "achieved": round(rate, 2), "peak": 78.6, "unit": "TFLOP/s",
                         "frac": round(rate / 78.6, 4), "traffic": None,
                         "note": "real flops executed (4 per complex multiply-add pair; L D L^T) over the whole numeric factorisation"},
+           "solve_roofline": _solve_roofline(rep, solve2, "second linearSolve_ call (steady state), complex panels in two planes"),
            "parity": {"max_rel_err_vs_manufactured": err, "conjugate_transposed_max_rel_err": errh,
                       "within_1e-10": bool(err < 1e-10 and errh < 1e-10)},
            "cpu_baseline": None}
@@ -222,10 +238,25 @@ def lu_zi(pkg, torch, m=100):
     return out
 
 
+def _solve_roofline(rep, seconds, what):
+    """HBM roofline of the triangular solves of one `linearSolve_` call: every walk over the factors (forward and
+    backward substitution: the first solve and one per refinement step) reads each stored entry of L and U once —
+    8 bytes, dense panels without index arrays — plus the vectors (SURVEY.md §8d "SpTRSV"); the residuals between the
+    walks (an SpMV each) are in the time and not in the bytes."""
+    B = rep["walks"] * rep["walk_bytes"]
+    gbps = B / max(seconds, 1e-12) / 1e9
+    return {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+            "traffic": None, "walks": rep["walks"], "bytes_per_walk": rep["walk_bytes"], "refinement_steps": rep["ir_attempted"],
+            "backward_error": rep["backward_error"], "of": what,
+            "note": "bytes = walks x (8 per stored factor entry + 16 n); time = the whole solve call (upload of b, walks, "
+                    "residuals in twice the working precision, download of x)"}
+
+
 def lu_c5(pkg, torch, m=100, cpu_sample=0):
     import numpy as np
     import scipy.sparse as sp
     U = pkg.umfpack
+    ffi = pkg._ffi
     n = m ** 3
     H = pkg.DeviceMatrix.synthetic("poisson3d", m)
     rp, ci, v = H.export_csr()  # symmetric: CSR arrays == CSC arrays
@@ -234,53 +265,177 @@ def lu_c5(pkg, torch, m=100, cpu_sample=0):
     S = sp.csc_matrix((v, ci, rp), shape=(n, n))
     xs = np.random.default_rng(0xBEEF).uniform(0.5, 1.5, n)  # manufactured solution
     b = S @ xs
-    # start from an idle device, as a fresh process would: what earlier configurations left in the library's pool goes
-    # back to the driver, and the driver's background wipe of released memory (~40 GB/s; a hipMalloc that lands on
-    # memory still being wiped waits for it: DESIGN.md "Device memory") is over before the clock starts
-    released = pkg._ffi.release_cached_memory()
-    torch.cuda.empty_cache()
-    idle_wait = 0.5 + released / 10e9 if m >= 150 else 0.0
-    time.sleep(idle_wait)
+    # The one-shot case, `linearSolve` (Umfpack.hs:38-46): this process has factored nothing yet and the library's pool
+    # is empty.  What the device's memory looks like is not in our hands: a hipMalloc that reaches into memory an
+    # earlier process released seconds ago waits for the driver's wipe (hipmalloc_s below says how long).
+    a0 = ffi.device_alloc_seconds()
     t0 = time.perf_counter()
     an = U.analyze(A)
     t1 = time.perf_counter()
+    a1 = ffi.device_alloc_seconds()
     fa = U.factor(A, an)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
+    a2 = ffi.device_alloc_seconds()
     x = U.linearSolve_(fa, U.UmfpackNormal, A, b)
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     st = fa.stats
+    rep1 = fa.solve_report
     err = float(np.max(np.abs(x - xs) / np.abs(xs)))
     res = float(np.max(np.abs(S @ x - b)) / (np.max(np.abs(b)) + 6 * np.max(np.abs(x))))
+    # steady state of the solve: the same call again (kernels loaded, work vectors from the pool)
+    t = time.perf_counter()
+    x2 = U.linearSolve_(fa, U.UmfpackNormal, A, b)
+    torch.cuda.synchronize()
+    solve2 = time.perf_counter() - t
+    rep = fa.solve_report
+    same = bool(np.array_equal(x, x2))
     # the same matrix factored again with the same analysis (what FEAST does per contour point): its panels and fronts
-    # come back from the library's pool — the steady state, free of what the driver does to freshly released memory
+    # come back from the library's pool — the steady state
     del fa
     gc.collect()
     t4 = time.perf_counter()
     fa = U.factor(A, an)
     torch.cuda.synchronize()
-    t5 = time.perf_counter()
-    steady = t5 - t4
-    total = (t1 - t0) + steady + (t3 - t2)
+    steady = time.perf_counter() - t4
+    one_shot = t3 - t0
+    total = (t1 - t0) + steady + solve2
     rate = st["flops"] / max(steady, 1e-9) * 1e-12
     out = {"workload": "sparse LU + triangular solves, 3-D 7-point Poisson %d^3: n=%d nnz=%d, umfpack_di_symbolic/numeric/solve"
                        % (m, n, int(rp[-1])),
-           "value": round(total, 3), "unit": "s", "higher_is_better": False,
-           "value_is": "analyze + factor (steady state: second factorisation with the same analysis) + solve, as DESIGN.md's ladder",
-           "analyze_s": round(t1 - t0, 3), "factor_s": round(steady, 3), "first_factor_s": round(t2 - t1, 3), "solve_s": round(t3 - t2, 3),
+           "value": round(one_shot, 3), "unit": "s", "higher_is_better": False,
+           "value_is": "one shot in a fresh process: analyze + FIRST factorisation + first solve (what `linearSolve`, Umfpack.hs:38-46, pays)",
+           "steady_state_s": round(total, 3),
+           "steady_state_is": "analyze + second factorisation with the same analysis (panels from the pool) + second solve",
+           "analyze_s": round(t1 - t0, 3), "first_factor_s": round(t2 - t1, 3), "factor_s": round(steady, 3),
+           "first_factor_hipmalloc_s": round(a2 - a1, 3), "analyze_hipmalloc_s": round(a1 - a0, 3),
+           "first_solve_s": round(t3 - t2, 3), "solve_s": round(solve2, 3),
            "factorisation": {"path": st["path"], "fronts": st["fronts"], "device_GB": round(st["device_bytes"] * 1e-9, 2),
                              "flops": st["flops"], "TFLOP_per_s": round(rate, 2),
                              "note": "flops executed: a symmetric matrix is factored as L D L^T on the same fronts (half the update flops of LU)"},
            "roofline": {"bound": "mfma", "achieved": round(rate, 2), "peak": 78.6,
                         "unit": "TFLOP/s", "frac": round(rate / 78.6, 4), "traffic": None,
-                        "note": "whole numeric factorisation (all launches) against the fp64 matrix-core peak; "
+                        "note": "whole numeric factorisation in its steady state (all launches) against the fp64 matrix-core peak; "
                                 "back-to-back v_mfma_f64_16x16x4 issue at 47 TFLOP/s on this part (profiles/r01_dense_lu_rate_probe.txt)"},
-           "parity": {"max_rel_err_vs_manufactured": err, "within_1e-10": bool(err < 1e-10), "scaled_residual": res},
-           "idle_wait_before_s": round(idle_wait, 2), "cpu_baseline": None}
+           "solve_roofline": _solve_roofline(rep, solve2, "second linearSolve_ call (steady state)"),
+           "parity": {"max_rel_err_vs_manufactured": err, "within_1e-10": bool(err < 1e-10), "scaled_residual": res,
+                      "componentwise_backward_error": rep1["backward_error"], "second_solve_bit_identical": same},
+           "cpu_baseline": None}
     del fa, an
     gc.collect()
-    pkg._ffi.release_cached_memory()
+    ffi.release_cached_memory()
     if cpu_sample:
         out["cpu_baseline"] = _superlu_sample(pkg, cpu_sample)
+        out["cpu_baseline"]["same_workload"] = False
+        out["cpu_baseline"]["note"] = ("a DIFFERENT size (%d^3): SuperLU's fill makes the full grid take minutes to hours on one core; "
+                                       "there is no same-size CPU figure (profiles/r04_superlu_64.json: 64^3)" % cpu_sample)
     return out
+
+
+def spmv_other(pkg, torch, which, steps=20):
+    """the SpMV kernel on C5's matrix (`poisson3d:<m>`) or C4's (`rmat:<scale>`): y = A x, device-resident, reference
+    order; HIP events around `steps` launches; the whole y against the oracle's CSR loop on the exported arrays"""
+    import numpy as np
+    from oracle import oracle as O
+    ffi = pkg._ffi
+    s = torch.cuda.current_stream()
+    kind, arg = which.split(":")
+    if kind == "poisson3d":
+        m = int(arg)
+        H = pkg.DeviceMatrix.synthetic("poisson3d", m)
+        name = "3-D 7-point Poisson %d^3 (config C5's matrix)" % m
+    else:
+        H = pkg.DeviceMatrix.rmat(int(arg), 32, (0.25, 0.25, 0.25))
+        name = "R-MAT scale %s, edge factor 32, Erdos-Renyi quadrants (config C4's matrix)" % arg
+    H.optimize()
+    inf = H.info()
+    n, nnz = inf["nrows_local"], inf["nnz"]
+    x = torch.empty(n, dtype=torch.float64, device="cuda")
+    ffi.check("vec", ffi.lib().spl_vector_synthetic_dev(0xBEEF, 0, n, x.data_ptr(), s.cuda_stream))
+    y = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        H.spmv_dev(x.data_ptr(), y.data_ptr(), stream=s.cuda_stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(s)
+    for _ in range(steps):
+        H.spmv_dev(x.data_ptr(), y.data_ptr(), stream=s.cuda_stream)
+    e1.record(s)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    B = 12 * nnz + 4 * (n + 1) + 8 * n + 8 * n
+    kcode = H.spmv_kernel()
+    kernel = {8: "spmv_blocked_lockstep", 15: "spmv_sell", 16: "spmv_panel"}.get(kcode, "spmv_stream")
+    rp, ci, v = H.export_csr()
+    yo = np.zeros(n)
+    t = time.perf_counter()
+    O.csr_gaxpy32(rp.astype(np.int32), ci, v, x.cpu().numpy(), yo)
+    t_cpu = time.perf_counter() - t
+    out = {"workload": "SpMV y = A x fp64, int32 indices: %s, n=%d nnz=%d" % (name, n, nnz),
+           "value": round(B / ms / 1e6, 1), "unit": "GB/s", "ms_per_step": round(ms, 4), "steps": steps, "sum_order": "reference",
+           "roofline": {"bound": "hbm", "achieved": round(B / ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(B / ms / 1e6 / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": kernel,
+                        "kernel_ms": round(ms, 4), "bytes_per_launch": B},
+           "parity": {"rows_checked": int(n), "bit_identical": bool(np.array_equal(y.cpu().numpy(), yo)),
+                      "how": "whole y against the oracle's CSR loop (reference order) on the exported arrays"},
+           "cpu_baseline": {"value": round(B / t_cpu / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+                            "sample": "the same matrix, one serial CSR pass of the oracle, %.3f s" % t_cpu}}
+    H.free()
+    del x, y
+    return out
+
+
+def run_item(item, n=10_000_000, draws=20, steps=20):
+    """one secondary configuration by name -> (key, result)"""
+    import torch
+    import sys
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    torch.cuda.set_device(0)
+    if item == "banded":
+        return "c2_banded_spmv", banded_c2(pkg, torch, n=n, draws=draws, steps=steps)
+    if item == "c4" or item.startswith("c4:"):  # c4:<scale> (tests): a smaller R-MAT matrix, same code
+        scale = int(item[3:]) if item.startswith("c4:") else 20
+        return "c4_spgemm_rmat%d" % scale, spgemm_c4(pkg, torch, scale=scale, cpu_rows=min(2048, 1 << scale))
+    if item.startswith("zi:"):  # row f3: complex LU on native complex fronts
+        return "f3_zi_lu_shifted_poisson3d_%s" % item[3:], lu_zi(pkg, torch, int(item[3:]))
+    if item.startswith("spmv:"):  # spmv:poisson3d:<m> | spmv:rmat:<scale>
+        which = item[5:]
+        return "spmv_%s" % which.replace(":", "_"), spmv_other(pkg, torch, which, steps=steps)
+    if item.startswith("c5:"):  # c5:<m>[:cpu<ms>]
+        parts = item.split(":")
+        m = int(parts[1])
+        cpu = int(parts[2][3:]) if len(parts) > 2 and parts[2].startswith("cpu") else 0
+        key = "c5_lu_poisson3d_%d" % m
+        free, _tot = torch.cuda.mem_get_info()
+        need = 262e9 * (m / 200.0) ** 4  # panels + transient fronts grow like m^4
+        if free < need:
+            return key, {"skipped": "needs %.0f GB of free HBM, %.0f GB are free" % (need / 1e9, free / 1e9)}
+        return key, lu_c5(pkg, torch, m, cpu_sample=cpu)
+    raise ValueError("unknown secondary configuration %r" % item)
+
+
+def main():
+    import argparse
+    import sys
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--item", required=True)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--draws", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20)
+    args = ap.parse_args()
+    t = time.perf_counter()
+    try:
+        key, res = run_item(args.item, args.n, args.draws, args.steps)
+    except Exception as e:  # reported, not raised: the parent merges whatever it gets
+        key, res = args.item, {"error": "%s: %s" % (type(e).__name__, e)}
+    if isinstance(res, dict):
+        res["wall_s"] = round(time.perf_counter() - t, 2)
+    sys.stdout.write("\n" + json.dumps({"key": key, "result": res}) + "\n")
+    sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""First against second factorisation of the same matrix in a fresh process (phase times, SPL_MF_TIMING=1):
+where a one-shot `linearSolve` pays more than the steady state.  usage: first_factor_probe.py [m]"""
+import gc, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from __graft_entry__ import load_package
+pkg = load_package()
+torch.cuda.set_device(0)
+U = pkg.umfpack
+m = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+if len(sys.argv) > 2:  # warm-up on a small grid first: code objects loaded, streams made
+    H = pkg.DeviceMatrix.synthetic("poisson3d", 16)
+    rp, ci, v = H.export_csr(); H.free()
+    W = pkg.Matrix(4096, 4096, rp, ci, v)
+    U.linearSolve_(U.factor(W, U.analyze(W)), U.UmfpackNormal, W, np.ones(4096))
+H = pkg.DeviceMatrix.synthetic("poisson3d", m)
+rp, ci, v = H.export_csr(); H.free()
+n = m ** 3
+A = pkg.Matrix(n, n, rp, ci, v)
+if os.environ.get("FFP_QUIET") != "1":
+    os.environ["SPL_MF_TIMING"] = "1"
+t0 = time.perf_counter(); an = U.analyze(A); t1 = time.perf_counter()
+print("== analyze %.3f s" % (t1 - t0), file=sys.stderr, flush=True)
+for rep in range(3):
+    t = time.perf_counter(); fa = U.factor(A, an); torch.cuda.synchronize(); dt = time.perf_counter() - t
+    print("== factor #%d %.3f s" % (rep, dt), file=sys.stderr, flush=True)
+    del fa; gc.collect()
