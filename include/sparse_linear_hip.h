@@ -284,6 +284,9 @@ int spl_matrix_set_reserved_cus(void *H, int reserved);
  * `milliseconds` (at most 2000) on `stream` — a stand-in for a collective's channel kernels when measuring what
  * reserved CUs are worth on one GPU (tools/bench_reserved_cus.py). */
 int spl_debug_occupy(int blocks, int threads, double milliseconds, double *d_buf, size_t count, void *stream);
+/* diagnostics / tests: the library's own radix sort (csrc/radix_sort.hip; the nested dissection orders its level
+ * structures with it) on d_keys[0 .. n) in device memory, in place, ascending by the low nbits bits of the keys */
+int spl_debug_sort_u64(unsigned long long *d_keys, long long n, int nbits, void *stream);
 /* build the column-sorted panel image with an explicit shape (tuning / ablation): panels of
  * rows_per_panel rows (<= 20479: one workgroup's LDS), index blocks of 2^cols_log2 columns
  * (<= 17); 0,0 = choose.  form: 0 default; 1 / 2 = one 64-entry chunk per load instruction with 1 / 2

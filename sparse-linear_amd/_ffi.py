@@ -126,6 +126,7 @@ def _declare(L):
         "spl_matrix_set_spmv_order": [C.c_void_p, i],
         "spl_matrix_set_reserved_cus": [C.c_void_p, i],
         "spl_debug_occupy": [i, i, C.c_double, C.c_void_p, C.c_size_t, C.c_void_p],
+        "spl_debug_sort_u64": [C.c_void_p, C.c_longlong, i, C.c_void_p],
         "spl_matrix_spmv_kernel": [C.c_void_p],
         "spl_vector_synthetic_dev": [u64, i64, i64, C.c_void_p, C.c_void_p],
         "spl_peer_exchange_create": [i, i, i, i64, c_i64_p, C.c_char_p, c_void_pp],

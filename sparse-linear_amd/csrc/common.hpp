@@ -173,6 +173,10 @@ inline Matrix *as_matrix(void *h) {
 // exclusive prefix sum of n counts; out has n+1 entries (out[n] = total).
 void exclusive_scan_i32_to_i64(const int *d_in, int64_t *d_out, int64_t n, hipStream_t s);
 void exclusive_scan_i64(const int64_t *d_in, int64_t *d_out, int64_t n, hipStream_t s);
+// radix_sort.hip: LSD radix sort of 64-bit keys by their bits [0, nbits); returns the buffer holding the result
+size_t radix_sort_u64_temp_bytes(int64_t n);
+unsigned long long *radix_sort_u64(unsigned long long *keys, unsigned long long *alt, int64_t n, int nbits, void *temp,
+                                   hipStream_t s);
 void narrow_i64_to_i32(const int64_t *d_in, int *d_out, int64_t n, hipStream_t s);
 void widen_i32_to_i64(const int *d_in, int64_t *d_out, int64_t n, hipStream_t s);
 

@@ -10,12 +10,10 @@
 // algorithm expects; the last workgroup of a launch records where the next level ends.  The number of levels is not
 // known in advance: the host enqueues the launches in batches and looks at the level pointers after each batch (a
 // launch on an empty frontier does nothing).  The order INSIDE a level depends on the atomics; it is made
-// deterministic afterwards by a radix sort of (level, vertex) keys — the tree must not depend on scheduling.
+// deterministic afterwards by a radix sort of (level, vertex) keys (radix_sort.hip) — the tree must not depend on scheduling.
 // What comes back: the queue (vertices by level, ascending ids inside a level) and the level pointers; the marks of
 // this file are its own (the host's are not touched), so a region the GPU finds disconnected is simply traversed
 // again by the host code.
-#include <hipcub/hipcub.hpp>
-
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -99,9 +97,11 @@ __global__ __launch_bounds__(kBfsThreads) void nd_level_kernel(const int64_t *__
   }
 }
 
-// key of queue position i: (level << 32) | vertex
+// key of queue position i: (level << vbits) | vertex, vbits = the bits a vertex id takes (the sort's passes are per 8
+// bits of key: 23 + 10 bits at config C5, five passes where (level << 32) | vertex would take six)
 __global__ __launch_bounds__(256) void nd_keys_kernel(const int *__restrict__ queue, const int *__restrict__ levptr,
-                                                      int nlev, int reached, unsigned long long *__restrict__ keys) {
+                                                      int nlev, int reached, int vbits,
+                                                      unsigned long long *__restrict__ keys) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= reached) return;
   int lo = 0, hi = nlev - 1;  // level of position i: levptr[lev] <= i < levptr[lev + 1]
@@ -109,13 +109,13 @@ __global__ __launch_bounds__(256) void nd_keys_kernel(const int *__restrict__ qu
     const int mid = (lo + hi + 1) >> 1;
     if (levptr[mid] <= i) lo = mid; else hi = mid - 1;
   }
-  keys[i] = ((unsigned long long)(unsigned)lo << 32) | (unsigned)queue[i];
+  keys[i] = ((unsigned long long)(unsigned)lo << vbits) | (unsigned)queue[i];
 }
 
-__global__ __launch_bounds__(256) void nd_unkey_kernel(const unsigned long long *__restrict__ keys, int reached,
+__global__ __launch_bounds__(256) void nd_unkey_kernel(const unsigned long long *__restrict__ keys, int reached, int vbits,
                                                        int *__restrict__ queue) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < reached) queue[i] = (int)(unsigned)(keys[i] & 0xffffffffull);
+  if (i < reached) queue[i] = (int)(unsigned)(keys[i] & ((1ull << vbits) - 1ull));
 }
 
 // Buffers of one traversal in flight.  The regions of a depth are dissected side by side by host threads; each call
@@ -155,10 +155,7 @@ struct GpuLevels : mf::LevelService {
   GpuLevels(int n_, const int64_t *h_xadj, const int *h_adj) : n(n_) {
     SPL_HIP(hipGetDevice(&device));
     const size_t nnz = (size_t)h_xadj[n], N = (size_t)n;
-    size_t bytes = 0;
-    SPL_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, n,
-                                              0, 64, (hipStream_t) nullptr));
-    sort_temp_bytes = bytes;
+    sort_temp_bytes = radix_sort_u64_temp_bytes(n);
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t per_slot = up(N * 4) * 2 + up((N + kBatch + 4) * 4) + up(16) + up(N * 8) * 2 + up(sort_temp_bytes ? sort_temp_bytes : 1);
     const size_t total = up((N + 1) * 8) + up((nnz ? nnz : 1) * 4) + up(N * 4) + kSlots * per_slot;
@@ -290,14 +287,13 @@ struct GpuLevels : mf::LevelService {
     // deterministic order inside the levels
     SPL_HIP(hipMemcpyAsync(sl.levptr, h_levptr.data(), ((size_t)nlev + 1) * sizeof(int), hipMemcpyHostToDevice, s));
     const unsigned gb = (unsigned)((reached + 255) / 256);
-    hipLaunchKernelGGL(nd_keys_kernel, dim3(gb), dim3(256), 0, s, sl.queue, sl.levptr, nlev, reached,
-                       sl.keys);
-    int level_bits = 1;
+    int level_bits = 1, vbits = 1;
     while ((1ll << level_bits) < nlev) ++level_bits;
-    size_t bytes = sort_temp_bytes;
-    SPL_HIP(hipcub::DeviceRadixSort::SortKeys(sl.sort_temp, bytes, sl.keys, sl.keys_alt, reached, 0,
-                                              32 + level_bits, s));
-    hipLaunchKernelGGL(nd_unkey_kernel, dim3(gb), dim3(256), 0, s, sl.keys_alt, reached, sl.queue);
+    while ((1ll << vbits) < n) ++vbits;
+    hipLaunchKernelGGL(nd_keys_kernel, dim3(gb), dim3(256), 0, s, sl.queue, sl.levptr, nlev, reached, vbits,
+                       sl.keys);
+    const unsigned long long *sorted = radix_sort_u64(sl.keys, sl.keys_alt, reached, vbits + level_bits, sl.sort_temp, s);
+    hipLaunchKernelGGL(nd_unkey_kernel, dim3(gb), dim3(256), 0, s, sorted, reached, vbits, sl.queue);
     lap(3);
     out_queue.resize((size_t)reached);
     SPL_HIP(hipMemcpyAsync(out_queue.data(), sl.queue, (size_t)reached * sizeof(int), hipMemcpyDeviceToHost, s));

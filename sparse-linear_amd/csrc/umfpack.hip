@@ -954,8 +954,17 @@ static int symbolic_common(int n, const int *Ap, const int *Ai, int mult, const 
     std::shared_ptr<mf::Tree> small_tree = mult > 1 ? std::make_shared<mf::Tree>() : nullptr;  // of the complex pattern
     const bool want_tree = !force_band && (force_mf || S->n >= 1024);
     const int pattern_symmetric = want_tree ? (mf::detail::structurally_symmetric(n, Ap, Ai) ? 1 : 0) : -1;
+    // HIP's current device belongs to the THREAD and is 0 in a new one: the job takes the caller's along, so that the
+    // level service (nd_levels.hip: a slab of 1 GiB and more, every traversal kernel) lands on the device the caller
+    // selected — with one rank per GPU every rank's analysis would pile onto device 0 otherwise
+    int caller_device = -1;
+    if (hipGetDevice(&caller_device) != hipSuccess) {
+      caller_device = -1;
+      (void)hipGetLastError();
+    }
     if (want_tree)
-      tree_job = std::async(std::launch::async, [n, Ap, Ai, mult, small_tree, pattern_symmetric] {
+      tree_job = std::async(std::launch::async, [n, Ap, Ai, mult, small_tree, pattern_symmetric, caller_device] {
+        if (caller_device >= 0 && hipSetDevice(caller_device) != hipSuccess) (void)hipGetLastError();
         std::shared_ptr<mf::Tree> T = std::make_shared<mf::Tree>();
         mf::build_tree(n, Ap, Ai, 256 / mult, *T, mult, small_tree.get(), pattern_symmetric, &make_gpu_level_service);
         return T;
@@ -1029,7 +1038,10 @@ static int symbolic_common(int n, const int *Ap, const int *Ai, int mult, const 
       bool take_tree = force_mf;
       if (tree_first && !take_tree) {
         const mf::Tree &Ts = small_tree && small_tree->nfronts > 0 ? *small_tree : *T;  // the graph that was dissected
-        const double bw = Ts.root_levels >= 2 ? std::ceil((double)(n - 1) / (double)(Ts.root_levels - 1)) : 0.0;
+        // A lower bound on the bandwidth of ANY symmetric reordering: with bandwidth w a path of length d reaches at most
+        // 1 + d w vertices, so w >= (n - 1) / diameter; the root's level structure has eccentricity root_levels - 1 and
+        // diameter <= 2 eccentricity (dividing by the eccentricity itself is up to twice too large)
+        const double bw = Ts.root_levels >= 2 ? std::ceil((double)(n - 1) / (2.0 * (double)(Ts.root_levels - 1))) : 0.0;
         const double kmin = mult * bw;  // both half-bandwidths of a structurally symmetric reordering of A + A^T's pattern
         if (kmin > 0 && t_tree < band_seconds(kmin, kmin)) take_tree = true;
         if (timing) fprintf(stderr, "[symbolic] %d levels: band >= %.0f wide, %.3g s at least; tree %.3g s\n", Ts.root_levels, kmin, band_seconds(kmin, kmin), t_tree);

@@ -58,6 +58,7 @@ def _apply(mat, V):
 
 
 _pool = None
+_pool_workers = 0
 _tls = __import__("threading").local()
 
 
@@ -69,9 +70,11 @@ def _contour_pool():
     k = int(os.environ.get("SPL_FEAST_THREADS", "2"))
     if k <= 1:
         return None
-    if _pool is None or _pool._max_workers != k:
+    global _pool_workers
+    if _pool is None or _pool_workers != k:
         from concurrent.futures import ThreadPoolExecutor
         _pool = ThreadPoolExecutor(max_workers=k, thread_name_prefix="feast-contour")
+        _pool_workers = k
     return _pool
 
 
@@ -161,9 +164,16 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
                 # torch's own work of this point (allocations, the weighted sums) on a stream of this thread: on the
                 # legacy default stream every such operation is a barrier for the LU streams of ALL threads.  The
                 # library's calls return when their results are complete, and this function ends with a synchronise.
-                if not hasattr(_tls, "stream"):
-                    _tls.stream = torch.cuda.Stream(device=dev)
-                with torch.cuda.stream(_tls.stream):
+                # (one stream per worker thread AND device: a stream belongs to the device it was made on, and entering it
+                # makes that device current — a later call on another device must not inherit it)
+                streams = getattr(_tls, "streams", None)
+                if streams is None:
+                    streams = _tls.streams = {}
+                key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+                if key not in streams:
+                    streams[key] = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(streams[key]):
+                    torch.cuda.set_device(dev)
                     return contour_point_on_this_stream(th)
             return contour_point_on_this_stream(th)
 

@@ -62,6 +62,19 @@ def test_product_never_imports_oracle():
                 assert "libsparse_oracle" not in text, f
 
 
+def test_product_is_written_from_scratch_no_vendor_primitives():
+    """north_star: from scratch, not a vendor library wrapped — no sparse / BLAS / solver / primitive library of the
+    platform is included or linked by the product (a library radix sort had crept into the LU analysis)"""
+    import re
+    pkg_dir = os.path.join(ROOT, "sparse-linear_amd")
+    banned = re.compile(r"hipcub|rocprim|rocsparse|hipsparse|rocblas|hipblas|rocsolver|hipsolver|rocthrust|thrust/", re.I)
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".hip", ".hpp", ".h", ".cpp", ".py")) or f == "Makefile":
+                for no, line in enumerate(open(os.path.join(dirpath, f)), 1):
+                    assert not banned.search(line), "%s:%d: %s" % (f, no, line.strip())
+
+
 def test_marshalling_refuses_arrays_shorter_than_the_pointers_say():
     """the 5-tuple of withConstMatrix carries no lengths (Foreign.hs:24-41): the Python mirror checks them before the
     C side would read pointers[ncols] indices and values out of shorter arrays (no GPU needed: the check is host side)"""

@@ -133,3 +133,24 @@ def test_compress_dev_bounds_rows_before_columns(gpu, pkg):
     with pytest.raises(Exception) as e:
         pkg.DeviceMatrix.compress_dev(3, 3, 3, r.data_ptr(), c.data_ptr(), v.data_ptr())
     assert "bounds" in str(e.value).lower() or "-" in str(e.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nbits", [(0, 33), (1, 33), (63, 7), (64, 8), (4096, 16), (4097, 33), (70001, 9), (1 << 20, 33),
+                                     (3_000_001, 41), (1 << 20, 64)])
+def test_radix_sort_u64_matches_numpy(gpu, pkg, n, nbits):
+    """csrc/radix_sort.hip (the hand-written sort behind the nested dissection's level structures: no vendor primitive
+    in the product): keys with random low `nbits` bits and one common pattern above them come back ascending"""
+    import torch
+    rng = np.random.default_rng(n + nbits)
+    lo = rng.integers(0, 1 << min(nbits, 62), n, dtype=np.uint64) if nbits < 64 else rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)
+    hi = np.uint64(0) if nbits >= 62 else np.uint64(0x2A) << np.uint64(nbits)
+    keys = (lo | hi).astype(np.uint64)
+    if n > 10:  # duplicates and an already sorted stretch
+        keys[: n // 8] = keys[n // 8: 2 * (n // 8)]
+        keys[-(n // 4):] = np.sort(keys[-(n // 4):])
+    d = torch.from_numpy(keys.view(np.int64).copy()).cuda() if n else torch.empty(0, dtype=torch.int64, device="cuda")
+    st = pkg._ffi.lib().spl_debug_sort_u64(d.data_ptr() if n else None, n, nbits, None)
+    assert st == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy().view(np.uint64), np.sort(keys))

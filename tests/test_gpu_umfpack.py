@@ -754,6 +754,32 @@ def test_band_ordering_is_computed_on_demand(gpu, pkg, O, monkeypatch):
         assert _backward_error(S, U.linearSolve_(fac, U.UmfpackNormal, A, b), b) <= 1e-13
 
 
+def test_analysis_thread_uses_the_callers_device(gpu, pkg, O, monkeypatch):
+    """the nested dissection runs on a thread of its own, and HIP's current device is per thread (0 in a new
+    one) — the level service must follow the device the CALLER selected.  Needs two devices: with device 1 current, the
+    slab of the service (at least 1 GiB, kept by the library's pool afterwards) must not appear on device 0."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices")
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    monkeypatch.setenv("SPL_ND_GPU_MIN", "2000")
+    n, A = _grid_matrix(pkg, O, "3d", 36)
+    U = pkg.umfpack
+    pkg._ffi.release_cached_memory()
+    prev = torch.cuda.current_device()
+    try:
+        torch.cuda.set_device(1)
+        free0 = torch.cuda.mem_get_info(0)[0]
+        free1 = torch.cuda.mem_get_info(1)[0]
+        an = U.analyze(A)
+        assert free0 - torch.cuda.mem_get_info(0)[0] < (1 << 29), "the analysis allocated on device 0"
+        assert free1 - torch.cuda.mem_get_info(1)[0] >= (1 << 30), "the level service's slab is not on the caller's device"
+        del an
+    finally:
+        torch.cuda.set_device(prev)
+        pkg._ffi.release_cached_memory()
+
+
 @pytest.mark.parametrize("kind", ["3d", "2d", "two_components", "unsymmetric_pattern"])
 def test_level_structures_on_the_gpu(gpu, pkg, O, kind, monkeypatch):
     """the nested dissection's level structures of large regions built on the device (csrc/nd_levels.hip; by default
