@@ -82,6 +82,10 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd).returncode)
 
+    # dmabuf IPC is the only kind this platform's host driver supports: without it hipIpcGetMemHandle fails ("invalid
+    # argument") — for RCCL's own buffers as for the one-sided exchange of csrc/peer.hip.  The pool's boxes export it
+    # already; a box that does not gets it here, before anything initialises HIP (a value that is set is left alone).
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -262,6 +266,10 @@ def main():
                     h.free()
         handles = winner_handles
         del y_plain
+        if rank == 0:  # on stderr, so that a run that fails later can still be diagnosed from its tail
+            sys.stderr.write("exchange of y, ms per step before the timed region: %s -> %s (%s)\n"
+                             % (", ".join("%s %.4f" % kv for kv in tuning.items()), best_key, exchange))
+            sys.stderr.flush()
     y_pieces = op.y_local if isinstance(op.y_local, list) else [op.y_local]
 
     def spmv():  # the kernel(s) of one step alone
@@ -302,6 +310,7 @@ def main():
     # behind (its flag is sticky).  Such a run is not a result: every rank goes back to the plain step — the whole
     # row block, one RCCL all-gather — and the region is timed again.
     exchange_failed = 0.0
+    fell_back = False
     if N > 1:
         exchange_failed = agree(1.0 if (hasattr(op, "failed") and op.failed()) else 0.0, dist.ReduceOp.MAX)
         if exchange_failed:
@@ -317,6 +326,7 @@ def main():
             op = dist_mod.RowBlockSpMV(n, dist_mod.equal_row_bounds(n, N), rank, N, kernels[0], "cuda")
             y_pieces = [op.y_local]
             exchange = "one RCCL all-gather of y after the kernel (fallback: the one-sided exchange timed out)"
+            fell_back = True
             nnz_local = H0.info()["nnz"]
             B_local = spmv_bytes(nnz_local, r1 - r0, n)
             info = H0.info()
@@ -397,6 +407,8 @@ def main():
     out["y_sum"], out["y_norm2"] = float(yh.sum()), float(np.sqrt((yh * yh).sum()))  # equal to ~1e-15 under either order
     if tuning:
         out["config"]["exchange_ms_per_step_by_chunks"] = tuning  # measured before the timed region
+    if fell_back:
+        out["config"]["exchange_fallback"] = "the one-sided exchange gave up during the timed region; the region was timed again over RCCL"
     if len(handles) > 1:
         roofline["launches_per_step"] = len(handles)
 

@@ -27,6 +27,8 @@
 // be reading buffer (k - 1) % 2.
 #include "common.hpp"
 
+#include <algorithm>
+#include <cstring>
 #include <vector>
 
 namespace spl {
@@ -49,6 +51,10 @@ struct PeerExchange {
   unsigned step = 0;
   bool connected = false;
   bool flags_fine = false, data_fine = false;
+  // tests only (SPL_PEER_TEST_FAIL_AT_STEP=k[:rank]): the wait of step k gives up at once, as if a peer had not
+  // delivered within its bound — the caller's failure path (bench.py: fall back to RCCL, time the region again) can
+  // then be exercised without a broken link
+  unsigned fail_at_step = 0;
 };
 
 // fine-grained device memory whose IPC handle can be taken, or nullptr
@@ -67,8 +73,9 @@ inline PeerExchange *as_px(void *p) {
 
 // one thread: wait until the flag of every piece not owned by `self` shows at least `step`; bounded (about 2 s)
 __global__ void peer_wait_kernel(const unsigned *__restrict__ flags, int npieces, int world, int self, unsigned step,
-                                 unsigned *__restrict__ error) {
+                                 unsigned *__restrict__ error, int give_up) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (give_up) { *error = 1; return; }  // (tests: PeerExchange::fail_at_step)
   const unsigned long long t0 = wall_clock64();
   for (int q = 0; q < npieces; ++q) {
     if (q % world == self) continue;
@@ -104,6 +111,10 @@ int spl_peer_exchange_create(int rank, int world, int chunks, int64_t n, const i
     px->chunks = chunks;
     px->n = n;
     px->bounds.assign(bounds, bounds + (size_t)chunks * world + 1);
+    if (const char *tf = getenv("SPL_PEER_TEST_FAIL_AT_STEP")) {
+      const char *colon = strchr(tf, ':');
+      if (!colon || atoi(colon + 1) == rank) px->fail_at_step = (unsigned)std::max(0, atoi(tf));
+    }
     const size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(double);
     const char *fd = getenv("SPL_PEER_FINEGRAINED_DATA");
     const bool want_fine_data = fd && fd[0] == '1';
@@ -222,7 +233,7 @@ int spl_peer_exchange_finish(void *X, void *stream, double **y_full) {
     const unsigned step = ++px->step;
     if (px->world > 1)
       hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, px->flags, px->chunks * px->world, px->world, px->rank,
-                         step, px->error);
+                         step, px->error, px->fail_at_step != 0 && step == px->fail_at_step ? 1 : 0);
     *y_full = px->buf[step & 1u];
     SPL_HIP(hipGetLastError());
     return SPL_OK;

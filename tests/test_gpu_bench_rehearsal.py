@@ -22,8 +22,9 @@ def _free_port():
     return p
 
 
-def _run(nproc, extra, chunks=None, exchange=None, plain=False):
+def _run(nproc, extra, chunks=None, exchange=None, plain=False, env_extra=None, want_stderr=False):
     env = dict(os.environ, SPL_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(env_extra or {})
     if chunks is not None:
         env["SPL_BENCH_CHUNKS"] = str(chunks)
     if exchange is not None:
@@ -43,6 +44,8 @@ def _run(nproc, extra, chunks=None, exchange=None, plain=False):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout  # exactly one JSON line, from rank 0
+    if want_stderr:
+        return json.loads(lines[0]), r.stderr
     return json.loads(lines[0])
 
 
@@ -160,6 +163,31 @@ def test_secondary_block_rides_on_the_headline_line(gpu):
         assert sec[k]["parity"]["bit_identical"] and sec[k]["roofline"]["bound"] == "hbm" and sec[k]["unit"] == "GB/s"
     assert sec["c4_spgemm_rmat12"]["parity"]["structure_and_values_bit_identical"]
     assert sec["c4_spgemm_rmat12"]["cpu_baseline"]["kind"] == "port" and sec["c4_spgemm_rmat12"]["unit"] == "Gproducts/s"
+
+
+@pytest.mark.parametrize("nproc,chunks", [(2, 1), (3, 2)])
+def test_one_sided_exchange_that_gives_up_in_the_timed_region_falls_back_to_the_collective(gpu, nproc, chunks):
+    """the fallback of bench.py after a one-sided exchange that timed out DURING the timed region had never
+    run.  SPL_PEER_TEST_FAIL_AT_STEP makes the wait kernel of csrc/peer.hip give up at a chosen step (here: inside the
+    timed steps, after the 14 steps the start-up tournament spends on the candidate and the warm-up step): every rank
+    must agree on the failure, release the exchange (IPC mappings, copy streams, the pieces' matrices), rebuild the
+    plain row-block step, time the region again and deliver the y of a single rank — exit status 0, and the line says
+    what happened.  Twice in a row from this process: nothing is left behind that the second run would trip over."""
+    args = ["--rows", "480000"]
+    one = _run(1, args)
+    for attempt in range(2):
+        out, err = _run(nproc, args, chunks=chunks, exchange="peer", env_extra={"SPL_PEER_TEST_FAIL_AT_STEP": "16"},
+                        want_stderr=True)
+        assert out["n_gpus"] == nproc and out["y_sha1"] == one["y_sha1"]
+        assert "fallback" in out["config"]["workload"] and "exchange_fallback" in out["config"]
+        assert "invalid" not in out
+        assert "falling back to the RCCL all-gather" in err and "exchange of y, ms per step before the timed region" in err
+    # only ONE rank's wait gives up (a single late link): the others must follow it into the fallback all the same
+    out = _run(nproc, args, chunks=chunks, exchange="peer", env_extra={"SPL_PEER_TEST_FAIL_AT_STEP": "17:%d" % (nproc - 1)})
+    assert out["y_sha1"] == one["y_sha1"] and "exchange_fallback" in out["config"]
+    # the switch off: the forced one-sided exchange is what the line reports, no fallback
+    out = _run(nproc, args, chunks=chunks, exchange="peer")
+    assert out["y_sha1"] == one["y_sha1"] and "exchange_fallback" not in out["config"] and "one-sided" in out["config"]["workload"]
 
 
 def test_three_ranks_all_schedules(gpu):
