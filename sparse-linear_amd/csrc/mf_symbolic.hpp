@@ -405,20 +405,21 @@ struct Worker {
 
   // subtrees of the two vertex ranges, then `top` as their parent; large ranges get their own thread
   // hint_l / hint_r: an extreme vertex of each side to start its level structure from (-1: none)
+  // peels: consecutive cuts above these ranges that left more than nine tenths of their region on one side
   std::vector<Node> join(int lo, int mid, int hi, Node &&top, int depth, int hint_l = -1, int hint_r = -1,
-                         bool thin = false) {
+                         bool thin = false, int peels = 0) {
     std::vector<Node> left, right;
     const bool fork = depth < 8 && mid - lo >= 20000 && hi - mid >= 20000;
     if (fork) {
-      std::future<std::vector<Node>> other = std::async(std::launch::async, [this, lo, mid, depth, hint_l, thin] {
+      std::future<std::vector<Node>> other = std::async(std::launch::async, [this, lo, mid, depth, hint_l, thin, peels] {
         Worker w(S);
-        return w.dissect(lo, mid, depth + 1, hint_l, thin);
+        return w.dissect(lo, mid, depth + 1, hint_l, thin, peels);
       });
-      right = dissect(mid, hi, depth + 1, hint_r, thin);
+      right = dissect(mid, hi, depth + 1, hint_r, thin, peels);
       left = other.get();
     } else {
-      if (mid > lo) left = dissect(lo, mid, depth + 1, hint_l, thin);
-      if (hi > mid) right = dissect(mid, hi, depth + 1, hint_r, thin);
+      if (mid > lo) left = dissect(lo, mid, depth + 1, hint_l, thin, peels);
+      if (hi > mid) right = dissect(mid, hi, depth + 1, hint_r, thin, peels);
     }
     std::vector<Node> out;
     out.reserve(left.size() + right.size() + 1);
@@ -443,9 +444,18 @@ struct Worker {
 
   // hint: a vertex of the region known to lie at one of its ends (the root or the deepest vertex of
   // the parent's level structure): one BFS from it replaces the two of the pseudo-peripheral search
-  std::vector<Node> dissect(int lo, int hi, int depth, int hint = -1, bool thin_parent = false) {
+  // A graph without separators — the pattern of A + A^T of a mesh matrix whose rows arrive in random order is an
+  // expander: half a dozen levels, the smallest interior one next to the root — would be peeled ten vertices at a time,
+  // every peel a traversal of the whole region (round 3: 18 s of analysis at 4e5 unknowns, tools/fuzz_lu_scale.py family
+  // perm2d, for a tree nobody can factor).  After kMaxPeels such cuts in a row the region is left as it is: a leaf
+  // whose front cannot fit, so the numeric phase goes straight to static pivoting, whose transversal gives the
+  // matrix its mesh pattern back (umfpack.hip).  Hubs taken out one at a time (arrow matrices) get a longer rope.
+  static constexpr int kMaxPeels = 6, kMaxHubPeels = 64;
+  std::vector<Node> dissect(int lo, int hi, int depth, int hint = -1, bool thin_parent = false, int peels = 0) {
     const int size = hi - lo;
     if (size <= S.leaf) return make_leaf(lo, hi);
+    if (peels >= kMaxPeels && peels < 1000 && size > 16 * S.leaf) return make_leaf(lo, hi);
+    if (peels >= 1000 + kMaxHubPeels && size > 16 * S.leaf) return make_leaf(lo, hi);
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {  // SPL_MF_TIMING: the phases of the top regions
       if (!S.timing || depth > 2) return;
@@ -548,7 +558,8 @@ struct Worker {
       Node top;
       top.piv.push_back(S.verts[(size_t)hub]);
       std::swap(S.verts[(size_t)hub], S.verts[(size_t)hi - 1]);
-      return join(lo, hi - 1, hi - 1, std::move(top), depth);
+      // (hub peels count from 1000 on: a separate, longer budget)
+      return join(lo, hi - 1, hi - 1, std::move(top), depth, -1, -1, false, peels >= 1000 ? peels + 1 : 1001);
     }
     // smallest level among the balanced ones; the balance requirement is relaxed until one exists
     int best = -1;
@@ -590,7 +601,8 @@ struct Worker {
     std::vector<int>().swap(side1);
     std::vector<int>().swap(side2);
     const bool thin = (int64_t)nlev * nlev * 2 >= (int64_t)size;
-    return join(lo, lo + n1, lo + n1 + n2, std::move(top), depth, end1, end2, thin);
+    const bool peel = (double)std::max(n1, n2) > 0.9 * (double)size;
+    return join(lo, lo + n1, lo + n1 + n2, std::move(top), depth, end1, end2, thin, peel ? (peels >= 1000 ? 1 : peels + 1) : 0);
   }
 };
 

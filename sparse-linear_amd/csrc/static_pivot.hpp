@@ -24,6 +24,11 @@
 #pragma once
 
 #include <stdint.h>
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <limits>
@@ -112,78 +117,264 @@ inline bool max_product_transversal(int n, const int *Ap, const int *Ai, const d
       }
     }
   }
-  // shortest augmenting paths for the rest
-  std::vector<double> d((size_t)n, inf);
-  std::vector<int> pred((size_t)n, -1);     // column from which row i was reached
-  std::vector<char> done((size_t)n, 0);
-  std::vector<int> touched, settled;
-  typedef std::pair<double, int> Item;
-  std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
-  // Time budget: the searches are sequential host work (about 45 rows settled per unknown on a 3-D mesh with a
-  // useless diagonal: 3 s at 2e5 unknowns, 34 s at 1e6 on one core).  A matrix that needs more than
-  // `max_seconds` is left to the caller's next fallback rather than holding a solve call for many minutes.
+  // Shortest augmenting paths for the rest: one Dijkstra search on reduced costs per unmatched column, SEVERAL AT A
+  // TIME (round 4).  A search only reads the duals and the matching of the rows it reaches, and what it would do
+  // to them — dual updates on the rows it settled, the augmentation along its path — stays inside that set.  So the
+  // next `batch` unmatched columns are searched side by side by a team of threads against the state as it is, each with
+  // distances, predecessors and a heap of its own; then the results are applied one after the other in column order,
+  // and a result is applied only if no row it reached has been changed by a result applied before it in this round
+  // (it is then exactly what a search started now would find); the others stay unmatched and are searched again.
+  // Searches are local — a few hundred rows of 10^5 .. 10^6 while many columns are unmatched — so most results stand;
+  // towards the end they grow and collide, and the batch shrinks with the share that stood.  What is applied, and in
+  // which order, depends on the results only, never on which thread produced them or when: the matching and the
+  // scalings are the same for every team size (tests/test_static_pivot.py), and still a minimum-cost perfect matching
+  // with its dual variables — a sequence of shortest augmenting paths, in another order of the columns.
+  // Per row the shared state is one 16-byte record (dual, match) and a thread's own another (distance, predecessor,
+  // settled): a search is a chain of cache misses, one per array it touches per row (round 3 had five arrays); the
+  // heap is a 4-ary array heap with lazy deletion, emptied by forgetting its length.
+  struct Shared {
+    double u;
+    int col, dirty;  // dirty: the round in which a result last changed this row
+  };
+  struct Own {
+    double d;
+    int pred, done;
+  };
+  struct Item {
+    double d;
+    int i;
+  };
+  struct Heap {
+    std::vector<Item> a;
+    void clear() { a.clear(); }
+    bool empty() const { return a.empty(); }
+    void push(double dd, int i) {
+      size_t k = a.size();
+      a.push_back(Item{dd, i});
+      while (k > 0) {
+        const size_t par = (k - 1) >> 2;
+        if (a[par].d <= dd) break;
+        a[k] = a[par];
+        k = par;
+      }
+      a[k] = Item{dd, i};
+    }
+    Item pop() {
+      const Item top = a[0];
+      const Item last = a.back();
+      a.pop_back();
+      const size_t sz = a.size();
+      if (sz > 0) {
+        size_t k = 0;
+        for (;;) {
+          const size_t c0 = 4 * k + 1;
+          if (c0 >= sz) break;
+          size_t best = c0;
+          const size_t ce = c0 + 4 < sz ? c0 + 4 : sz;
+          for (size_t q = c0 + 1; q < ce; ++q)
+            if (a[q].d < a[best].d) best = q;
+          if (a[best].d >= last.d) break;
+          a[k] = a[best];
+          k = best;
+        }
+        a[k] = last;
+      }
+      return top;
+    }
+  };
+  struct Result {
+    int j0 = -1, end_row = -1;
+    double L = 0.0;
+    std::vector<int> touched;                      // every row the search reached
+    std::vector<std::pair<int, double>> settled;   // (row, distance)
+    std::vector<int> path;                         // rows of the augmenting path, end row first
+    std::vector<int> path_col;                     // path_col[k]: the column path[k] will be matched to
+    int64_t work = 0;
+  };
+  struct Scratch {
+    std::vector<Own> own;
+    Heap heap;
+  };
+  std::vector<Shared> R((size_t)n);
+  for (int i = 0; i < n; ++i) R[(size_t)i] = Shared{u[(size_t)i], T.col_of_row[(size_t)i], -1};
+  std::vector<int> pending;
+  for (int j = 0; j < n; ++j)
+    if (T.row_of_col[(size_t)j] < 0) pending.push_back(j);
+  // The order of the columns is free.  Ascending, neighbours in the numbering — neighbours in a mesh — would be searched
+  // in the same round and collide; a fixed pseudo-random order (the same for every run and team) spreads a round over
+  // the whole matrix.
+  {
+    uint64_t state = 0x9E3779B97F4A7C15ull;
+    for (size_t k = pending.size(); k > 1; --k) {
+      state = state * 6364136223846793005ull + 1442695040888963407ull;
+      std::swap(pending[k - 1], pending[(size_t)((state >> 33) % k)]);
+    }
+  }
+  auto search = [&](int j0, Scratch &S, Result &out) {
+    out.j0 = j0;
+    out.end_row = -1;
+    out.touched.clear();
+    out.settled.clear();
+    out.path.clear();
+    out.path_col.clear();
+    out.work = 0;
+    S.heap.clear();
+    Own *own = S.own.data();
+    int j = j0;
+    double lowest = 0.0;     // distance at which column j was reached
+    double best_free = inf;  // shortest distance to a free row seen so far: nothing longer can be the answer
+    for (;;) {
+      const double base = lowest - v[(size_t)j];
+      for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
+        const int i = Ai[p];
+        Own &o = own[i];
+        if (o.done) continue;
+        const Shared &r = R[(size_t)i];
+        const double dn = base + (c[(size_t)p] - r.u);  // (an infinite cost stays infinite: never below best_free)
+        if (!(dn < best_free)) continue;
+        if (r.col < 0) best_free = dn;
+        if (dn < o.d) {
+          if (o.d == inf) out.touched.push_back(i);
+          o.d = dn;
+          o.pred = j;
+          S.heap.push(dn, i);
+        }
+      }
+      int i = -1;
+      while (!S.heap.empty()) {
+        const Item it = S.heap.pop();
+        const Own &o = own[it.i];
+        if (!o.done && it.d <= o.d) { i = it.i; break; }
+      }
+      if (i < 0) break;  // no augmenting path
+      Own &o = own[i];
+      o.done = 1;
+      out.settled.emplace_back(i, o.d);
+      ++out.work;
+      lowest = o.d;
+      if (R[(size_t)i].col < 0) { out.end_row = i; break; }
+      j = R[(size_t)i].col;
+    }
+    if (out.end_row >= 0) {
+      out.L = own[out.end_row].d;
+      for (int i = out.end_row;;) {
+        const int jc = own[i].pred;
+        out.path.push_back(i);
+        out.path_col.push_back(jc);
+        if (jc == j0) break;
+        i = T.row_of_col[(size_t)jc];
+      }
+    }
+    for (int i : out.touched) own[i] = Own{inf, -1, 0};
+  };
+  // the team: SPL_SP_THREADS, by default the hardware's threads up to 16 (a one-GPU share of a host); small problems
+  // are not worth threads
+  int team = 1;
+  {
+    const char *e = getenv("SPL_SP_THREADS");
+    const unsigned hw = std::thread::hardware_concurrency();
+    team = e ? atoi(e) : (int)std::min<unsigned>(hw ? hw : 1u, 16u);
+    if (team < 1) team = 1;
+    if (!e && pending.size() < 2000) team = 1;
+  }
+  constexpr int kMaxBatch = 64, kMinBatch = 1;
+  std::vector<Scratch> scratch((size_t)team);
+  for (Scratch &S : scratch) S.own.assign((size_t)n, Own{inf, -1, 0});
+  std::vector<Result> results((size_t)kMaxBatch);
+  // round state shared with the helpers (spinning on atomics: a round lasts microseconds to milliseconds)
+  std::atomic<int> round_id{0}, next_item{0}, done_items{0}, stop{0};
+  int batch_n = 0;          // written before round_id is advanced (release), read after (acquire)
+  const int *batch_cols = nullptr;
+  auto work_on_round = [&](Scratch &S) {
+    for (;;) {
+      const int k = next_item.fetch_add(1, std::memory_order_relaxed);
+      if (k >= batch_n) break;
+      search(batch_cols[k], S, results[(size_t)k]);
+      done_items.fetch_add(1, std::memory_order_release);
+    }
+  };
+  std::vector<std::thread> helpers;
+  for (int t = 1; t < team; ++t) {
+    try {
+      helpers.emplace_back([&, t] {
+        int seen = 0;
+        for (;;) {
+          int now;
+          int spins = 0;
+          while ((now = round_id.load(std::memory_order_acquire)) == seen) {
+            if (stop.load(std::memory_order_acquire)) return;
+            if (++spins > 2000) { std::this_thread::yield(); spins = 0; }
+          }
+          seen = now;
+          work_on_round(scratch[(size_t)t]);
+        }
+      });
+    } catch (...) {
+      break;  // fewer helpers than asked for: the rounds do not depend on their number
+    }
+  }
+  struct StopHelpers {
+    std::atomic<int> &stop;
+    std::vector<std::thread> &helpers;
+    ~StopHelpers() {
+      stop.store(1, std::memory_order_release);
+      for (std::thread &th : helpers) th.join();
+    }
+  } stop_helpers{stop, helpers};
+  // Time budget: a matrix that needs more than `max_seconds` is left to the caller's next fallback rather than
+  // holding a solve call for many minutes.
   const auto t_start = std::chrono::steady_clock::now();
   int64_t work = 0, next_check = 1 << 20;
-  for (int j0 = 0; j0 < n; ++j0) {
-    if (T.row_of_col[(size_t)j0] >= 0) continue;
+  int batch = kMaxBatch, round = 0;
+  size_t head = 0;  // pending[head ..) are the unmatched columns
+  std::vector<int> retry;
+  while (head < pending.size()) {
     if (work > next_check) {
       next_check = work + (1 << 20);
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > max_seconds) return false;
     }
-    touched.clear();
-    settled.clear();
-    while (!heap.empty()) heap.pop();
-    int j = j0, end_row = -1;
-    double lowest = 0.0;  // distance at which column j was reached
-    double best_free = inf;  // shortest distance to a free row seen so far: nothing longer can be the answer
-    for (;;) {
-      for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
-        const int i = Ai[p];
-        if (done[(size_t)i] || c[(size_t)p] == inf) continue;
-        const double dn = lowest + (c[(size_t)p] - u[(size_t)i] - v[(size_t)j]);
-        if (dn >= best_free) continue;
-        if (T.col_of_row[(size_t)i] < 0) best_free = dn;
-        if (dn < d[(size_t)i]) {
-          if (d[(size_t)i] == inf) touched.push_back(i);
-          d[(size_t)i] = dn;
-          pred[(size_t)i] = j;
-          heap.push(Item(dn, i));
-        }
+    ++round;
+    batch_n = (int)std::min<size_t>((size_t)batch, pending.size() - head);
+    batch_cols = pending.data() + head;
+    next_item.store(0, std::memory_order_relaxed);
+    done_items.store(0, std::memory_order_relaxed);
+    round_id.store(round, std::memory_order_release);
+    work_on_round(scratch[0]);
+    while (done_items.load(std::memory_order_acquire) < batch_n) {
+    }
+    // apply the results in column order
+    retry.clear();
+    int stood = 0;
+    for (int k = 0; k < batch_n; ++k) {
+      Result &res = results[(size_t)k];
+      work += res.work;
+      if (res.end_row < 0) return false;  // no augmenting path: structurally singular (no applied result can create one)
+      bool clean = true;
+      for (int i : res.touched)
+        if (R[(size_t)i].dirty == round) { clean = false; break; }
+      if (!clean) { retry.push_back(res.j0); continue; }
+      ++stood;
+      const double L = res.L;
+      // dual update: settled rows u_i += d_i - L; their matched columns (and j0) v_j += L - (distance of j)
+      for (const std::pair<int, double> &sd : res.settled) {
+        Shared &r = R[(size_t)sd.first];
+        if (r.col >= 0) v[(size_t)r.col] += L - sd.second;
+        r.u += sd.second - L;
+        r.dirty = round;
       }
-      int i = -1;
-      while (!heap.empty()) {
-        const Item it = heap.top();
-        heap.pop();
-        if (!done[(size_t)it.second] && it.first <= d[(size_t)it.second]) { i = it.second; break; }
+      v[(size_t)res.j0] += L;
+      for (size_t q = 0; q < res.path.size(); ++q) {
+        T.row_of_col[(size_t)res.path_col[q]] = res.path[q];
+        R[(size_t)res.path[q]].col = res.path_col[q];
       }
-      if (i < 0) break;  // no augmenting path: structurally singular
-      done[(size_t)i] = 1;
-      settled.push_back(i);
-      ++work;
-      lowest = d[(size_t)i];
-      if (T.col_of_row[(size_t)i] < 0) { end_row = i; break; }
-      j = T.col_of_row[(size_t)i];
     }
-    if (end_row < 0) return false;
-    const double L = d[(size_t)end_row];
-    // dual update: settled rows u_i += d_i - L; their matched columns (and j0) v_j += L - (distance of j)
-    for (int i : settled) {
-      const int jm = T.col_of_row[(size_t)i];
-      if (jm >= 0) v[(size_t)jm] += L - d[(size_t)i];
-      u[(size_t)i] += d[(size_t)i] - L;
-    }
-    v[(size_t)j0] += L;
-    // augment along the predecessor columns
-    for (int i = end_row;;) {
-      const int jc = pred[(size_t)i];
-      const int prev = T.row_of_col[(size_t)jc];
-      T.row_of_col[(size_t)jc] = i;
-      T.col_of_row[(size_t)i] = jc;
-      if (jc == j0) break;
-      i = prev;
-    }
-    for (int i : touched) { d[(size_t)i] = inf; pred[(size_t)i] = -1; done[(size_t)i] = 0; }
+    // the columns that have to be searched again go back to the front of the queue, in order
+    head += (size_t)batch_n - retry.size();
+    std::copy(retry.begin(), retry.end(), pending.begin() + (int64_t)head);
+    batch = std::max(kMinBatch, std::min(kMaxBatch, 2 * stood));
   }
+  for (int i = 0; i < n; ++i) { u[(size_t)i] = R[(size_t)i].u; T.col_of_row[(size_t)i] = R[(size_t)i].col; }
+  if (getenv("SPL_SP_VERBOSE")) fprintf(stderr, "[transversal] %d threads, %d rounds, %lld rows settled\n", team, round, (long long)work);
   T.dr.resize((size_t)n);
   T.dc.resize((size_t)n);
   for (int i = 0; i < n; ++i) T.dr[(size_t)i] = std::exp(u[(size_t)i]);

@@ -16,17 +16,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def checker(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("sp") / "sp_check")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "sparse-linear_amd", "csrc"),
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "sparse-linear_amd", "csrc"),
                     os.path.join(ROOT, "tests", "native", "sp_check.cpp"), "-o", exe], check=True)
     return exe
 
 
-def run(checker, S):
+def run(checker, S, threads=None):
     S = sp.csc_matrix(S)
     S.sort_indices()
     text = "%d %d\n%s\n%s\n%s\n" % (S.shape[0], S.nnz, " ".join(map(str, S.indptr)), " ".join(map(str, S.indices)),
                                   " ".join(repr(float(v)) for v in S.data))
-    r = subprocess.run([checker], input=text, capture_output=True, text=True, timeout=300)
+    env = dict(os.environ)
+    if threads is not None:
+        env["SPL_SP_THREADS"] = str(threads)
+    r = subprocess.run([checker], input=text, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     out = {}
     for line in r.stdout.splitlines():
@@ -83,6 +86,24 @@ def test_mesh_pattern_and_two_by_two_blocks(checker):
     check(S, out)
     rows = np.array(out["rows"].split(), dtype=int)
     assert np.array_equal(rows, np.arange(n) ^ 1)
+
+
+def test_searches_side_by_side_give_the_same_optimal_matching(checker):
+    """round 4: the shortest-augmenting-path searches of a batch of unmatched columns run on a team of threads against
+    the same state, and their results are applied in column order when nothing they read has changed.  What is applied
+    depends on the results only: the matching and the scalings are the same, digit for digit, for every team size —
+    and optimal (scipy's matching).  A 2-D mesh with a useless diagonal leaves a sixth of the columns to the searches."""
+    rng = np.random.default_rng(11)
+    m = 110
+    T = sp.diags([np.ones(m - 1), np.ones(m), np.ones(m - 1)], (-1, 0, 1))
+    S = (sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m))).tocsc()
+    S.data = rng.uniform(-1.0, 1.0, S.nnz)
+    S.setdiag(1e-12)
+    S, one = run(checker, S, threads=1)
+    check(S, one)
+    for team in (2, 5):
+        _, out = run(checker, S, threads=team)
+        assert out == one
 
 
 def test_structurally_singular_is_refused(checker):
