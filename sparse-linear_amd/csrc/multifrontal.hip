@@ -684,14 +684,15 @@ template <int MODE, int NR, bool Z = false>
 __global__ __launch_bounds__(solve_waves<NR>() * 64) void big_super_kernel(const int *__restrict__ list,
                                                             const int64_t *__restrict__ prefix, int count, int step,
                                                             TreeView t, const double *__restrict__ invs,
-                                                            double *work, double *zbuf, int row_blocks) {
+                                                            double *work, double *zbuf, int row_blocks, int pivots_only) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   constexpr bool fwd = (MODE == 0 || MODE == 2);
   const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
   const int span = SB * NB, nsup = (b.np + span - 1) / span;
   const int j0 = (fwd ? step : nsup - 1 - step) * span, jbs = min(span, b.np - j0);
-  // untransposed forward: the boundary rows of the front get their updates inside the pass
-  const int n = MODE == 0 ? b.fs : b.np;
+  // untransposed forward: the boundary rows of the front get their updates inside the pass (rounds 1 - 3), or —
+  // pivots_only, round 4 — from big_gemv_chunk_kernel<.., FWD> once the pivots are solved (see there)
+  const int n = (MODE == 0 && !pivots_only) ? b.fs : b.np;
   const Band band{const_cast<double *>(b.P), n, n, n, b.ldp + 1, 0, 0, b.pz};
   solve_super_tile<MODE, NR, Z>(band, invs + (Z ? 2 : 1) * t.ioff[b.f], j0, jbs, fwd ? b.W : b.Z, fwd ? b.Z : b.W,
                                 (size_t)b.fs, b.blk, dsm, row_blocks);
@@ -727,7 +728,14 @@ __global__ __launch_bounds__(256) void big_gather_x_kernel(const int *__restrict
 template <int NR>
 constexpr int gemv_waves() { return NR >= 16 ? 8 : 16; }  // (the partial sums: GW x 64 x NR doubles of LDS)
 constexpr int kGemvChunk = 512;
-template <int NR, bool Z = false>
+// FWD (round 4): the same product for the FORWARD pass of the untransposed systems, the boundary rows' share of it:
+// W[np + i][:] -= sum_t L21(i, t) Z[t][:], i < nb, with L21 = rows np .. fs of the pivot columns (in P) and Z the solved
+// pivots.  Rounds 1 - 3 did this inside the super-block steps (a step updated ALL rows below it): every workgroup of a
+// step first redoes the in-super-block solve — a chain of barriers without a byte of HBM traffic — and only then
+// streams its rows, so the part of the forward pass that carries the bytes ran at 2.1 - 2.2 TB/s on the top levels of
+// config C5 where the backward pass, whose boundary product always was a kernel of its own, reaches 3.2 - 3.9.  Now the
+// steps stay inside the pivot block and the nb x np panel below it is streamed once, by this kernel, with every CU on it.
+template <int NR, bool Z = false, bool FWD = false>
 __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(const int *__restrict__ list,
                                                                                const int64_t *__restrict__ prefix, int count,
                                                                                TreeView t, double *work, double *zbuf,
@@ -738,11 +746,13 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(c
   double(*xs)[NR] = reinterpret_cast<double(*)[NR]>(gsm);  // [kGemvChunk]
   double *part = gsm;  // [GW][NR][64], in the place of xs once every wavefront is done with it (two workgroups per CU)
   const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
-  const int np = b.np, nb = b.nb, fs = b.fs, ldu = b.ldu;
+  // the product is (np x nb) from U, or — FWD — (nb x np) from the rows of P below the pivot block: `np` / `nb` below
+  // are the rows / columns of the product
+  const int np = FWD ? b.nb : b.np, nb = FWD ? b.np : b.nb, fs = b.fs, ldu = FWD ? b.ldp : b.ldu;
   const int nch = (nb + kGemvChunk - 1) / kGemvChunk;
   const int rb = b.blk / nch, ch = b.blk - rb * nch;
   const int i0 = rb * 64, k0 = ch * kGemvChunk, kn = min(kGemvChunk, nb - k0);
-  const double *xb = b.W + b.np + k0;
+  const double *xb = FWD ? b.Z + k0 : b.W + b.np + k0;
   for (int o = threadIdx.x; o < kn * NR; o += GW * 64) {
     const int kk = o % kn, r = o / kn;
     xs[kk][r] = xb[(size_t)r * fs + kk];
@@ -754,21 +764,22 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(c
 #pragma unroll
   for (int r = 0; r < NR; ++r) acc[r] = 0.0;
   if (i < np) {
-    const double *row = b.U + (size_t)i + (size_t)k0 * ldu;
+    const double *row = (FWD ? b.P + (size_t)b.np : b.U) + (size_t)i + (size_t)k0 * ldu;
+    const size_t zo = FWD ? b.pz : b.uz;
     int k = wave;
     for (; k + 7 * GW < kn; k += 8 * GW) {
       double e[8], ei[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         e[u] = row[(size_t)(k + GW * u) * ldu];
-        ei[u] = Z ? row[(size_t)(k + GW * u) * ldu + b.uz] : 0.0;
+        ei[u] = Z ? row[(size_t)(k + GW * u) * ldu + zo] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) mac_cols<NR, Z>(acc, e[u], ei[u], &xs[k + GW * u][0]);
     }
     for (; k < kn; k += GW) {
       const double e = row[(size_t)k * ldu];
-      const double ei = Z ? row[(size_t)k * ldu + b.uz] : 0.0;
+      const double ei = Z ? row[(size_t)k * ldu + zo] : 0.0;
       mac_cols<NR, Z>(acc, e, ei, &xs[k][0]);
     }
   }
@@ -784,6 +795,7 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(c
 #pragma unroll
     for (int q = 0; q < GW; ++q) tot += part[(q * NR + r) * 64 + l];
     if (out) out[(size_t)r * np + i0 + l] = tot;
+    else if (FWD) b.W[(size_t)r * fs + b.np + i0 + l] -= tot;
     else b.Z[(size_t)r * fs + i0 + l] -= tot;
   }
 }
@@ -847,24 +859,26 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_t_kernel
   }
 }
 
-template <int NR>
+template <int NR, bool FWD = false>
 __global__ __launch_bounds__(256) void big_gemv_reduce_kernel(const int *__restrict__ list, const int64_t *__restrict__ prefix,
                                                               int count, TreeView t, double *work, double *zbuf,
                                                               const int64_t *__restrict__ pofs,
                                                               const double *__restrict__ scratch) {
   const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
+  const int rows = FWD ? b.nb : b.np, cols = FWD ? b.np : b.nb;
   const int i = b.blk * 256 + (int)threadIdx.x;
-  if (i >= b.np) return;
-  const int nch = (b.nb + kGemvChunk - 1) / kGemvChunk;
+  if (i >= rows) return;
+  const int nch = (cols + kGemvChunk - 1) / kGemvChunk;
   const double *in = scratch + (size_t)pofs[b.item] * NR;
   double tot[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) tot[r] = 0.0;
   for (int c = 0; c < nch; ++c)  // (NR loads in flight per thread; chunk order: the sums do not depend on the schedule)
 #pragma unroll
-    for (int r = 0; r < NR; ++r) tot[r] += in[((size_t)c * NR + r) * b.np + i];
+    for (int r = 0; r < NR; ++r) tot[r] += in[((size_t)c * NR + r) * rows + i];
+  double *dst = FWD ? b.W + b.np : b.Z;
 #pragma unroll
-  for (int r = 0; r < NR; ++r) b.Z[(size_t)r * b.fs + i] -= tot[r];
+  for (int r = 0; r < NR; ++r) dst[(size_t)r * b.fs + i] -= tot[r];
 }
 
 // transposed forward elimination, boundary part: W[np + k][:] -= sum_t U(t, k) Z[t][:]  (U^T y); one
@@ -948,7 +962,8 @@ struct Factors {
     std::vector<int64_t> h;
     DBuf<int64_t> d;
     // kind 0 fwd, 1 fwd^T, 2 bwd, 3 boundary^T, 4 gather, 5 gemv (transposed), 6 scatter, 7 gemv in chunks, 8 its
-    // reduction, 9 offsets of the fronts in its scratch (doubles per column)
+    // reduction, 9 offsets of the fronts in its scratch (doubles per column); 10, 11, 12: the same three for the
+    // forward boundary product (nb rows x np columns)
     size_t seg(int kind, int k = 0) const {
       const size_t which = kind < 3 ? (size_t)kind * (size_t)steps + (size_t)k : (size_t)3 * steps + (size_t)(kind - 3);
       return which * (size_t)(count + 1);
@@ -1200,7 +1215,7 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
         for (int f : large) first_step += (T.fs(f) + 63) / 64;
         B.row_blocks = first_step >= 4096 ? kSolveRowBlocks : 1;
         const int rbk = B.row_blocks;
-        B.h.assign((size_t)(3 * B.steps + 7) * (size_t)(B.count + 1), 0);
+        B.h.assign((size_t)(3 * B.steps + 10) * (size_t)(B.count + 1), 0);
         auto fill = [&](int kind, int k, auto groups_of) {
           int64_t *pre = B.h.data() + B.seg(kind, k);
           for (int i = 0; i < B.count; ++i) pre[i + 1] = pre[i] + groups_of(large[(size_t)i]);
@@ -1229,6 +1244,11 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
         fill(8, 0, [&](int f) -> int64_t { return chunks(f) > 1 ? (T.np[(size_t)f] + 255) / 256 : 0; });
         fill(9, 0, [&](int f) -> int64_t { return chunks(f) > 1 ? chunks(f) * T.np[(size_t)f] : 0; });
         F.gemv_scratch = std::max(F.gemv_scratch, B.h[B.seg(9) + (size_t)B.count]);
+        auto fchunks = [&](int f) -> int64_t { return (T.np[(size_t)f] + kGemvChunk - 1) / kGemvChunk; };
+        fill(10, 0, [&](int f) -> int64_t { return (int64_t)((T.nb[(size_t)f] + 63) / 64) * fchunks(f); });
+        fill(11, 0, [&](int f) -> int64_t { return fchunks(f) > 1 ? (T.nb[(size_t)f] + 255) / 256 : 0; });
+        fill(12, 0, [&](int f) -> int64_t { return fchunks(f) > 1 ? fchunks(f) * T.nb[(size_t)f] : 0; });
+        F.gemv_scratch = std::max(F.gemv_scratch, B.h[B.seg(12) + (size_t)B.count]);
         staged.push_back(std::move(large));
         upload_vec(B.list, staged.back(), s);
         upload_vec(B.d, B.h, s);
@@ -1497,7 +1517,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
 // launch per super-block step over all of them (Factors::BigLevel).
 template <int MODE, int NR, bool Z = false>
 static void launch_big_super(const mf::Factors &F, const mf::Factors::BigLevel &B, int kind, int step, double *work,
-                             double *zbuf, hipStream_t s) {
+                             double *zbuf, hipStream_t s, int pivots_only = 0) {
   constexpr size_t lds = (size_t)((SB + 2) * NB + solve_waves<NR>() * 64) * NR * sizeof(double);
   static std::atomic<uint64_t> attr_set{0};  // one mask per instantiation, one bit per device
   if (first_use_on_this_device(attr_set)) {
@@ -1508,7 +1528,7 @@ static void launch_big_super(const mf::Factors &F, const mf::Factors::BigLevel &
   const unsigned groups = B.total(kind, step);
   if (groups > 0)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(big_super_kernel<MODE, NR, Z>), dim3(groups), dim3(solve_waves<NR>() * 64), lds, s, B.list.get(),
-                       B.prefix(kind, step), B.count, step, F.view, F.invs.get(), work, zbuf, B.row_blocks);
+                       B.prefix(kind, step), B.count, step, F.view, F.invs.get(), work, zbuf, B.row_blocks, pivots_only);
 }
 
 template <bool TRANS, int NR, bool Z = false>
@@ -1563,7 +1583,25 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
     if (B.count > 0) {
       // untransposed: the boundary rows get their updates inside the pass over the pivot columns;
       // transposed: U11^T on the pivots, then the boundary with U12^T
-      for (int k = 0; k < B.steps; ++k) launch_big_super<FWD, NR, Z>(F, B, TRANS ? 1 : 0, k, work, zbuf, s);
+      // (split: SPL_MF_SPLIT_FWD=0 restores the steps over all fs rows of rounds 1 - 3, for ablation)
+      const char *sf = getenv("SPL_MF_SPLIT_FWD");
+      const bool split = !(sf && sf[0] == '0');
+      const bool pivots_only = !TRANS && split;
+      for (int k = 0; k < B.steps; ++k) launch_big_super<FWD, NR, Z>(F, B, (TRANS || pivots_only) ? 1 : 0, k, work, zbuf, s, pivots_only ? 1 : 0);
+      if (pivots_only && B.total(10) > 0) {
+        constexpr size_t lds = (size_t)std::max(kGemvChunk, gemv_waves<NR>() * 64) * NR * sizeof(double);
+        static std::atomic<uint64_t> attr_set{0};  // one mask per instantiation, one bit per device
+        if (first_use_on_this_device(attr_set)) {
+          SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&big_gemv_chunk_kernel<NR, Z, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          mark_used_on_this_device(attr_set);
+        }
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_chunk_kernel<NR, Z, true>), dim3(B.total(10)), dim3(gemv_waves<NR>() * 64), lds, s,
+                           B.list.get(), B.prefix(10), B.count, F.view, work, zbuf, B.prefix(12), gscr);
+        if (B.total(11) > 0)
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_reduce_kernel<NR, true>), dim3(B.total(11)), dim3(256), 0, s, B.list.get(),
+                             B.prefix(11), B.count, F.view, work, zbuf, B.prefix(12), gscr);
+      }
       if (TRANS && B.total(3) > 0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(big_boundary_t_kernel<NR, Z>), dim3(B.total(3)), dim3(256), 0, s, B.list.get(),
                            B.prefix(3), B.count, F.view, work, zbuf);

@@ -267,13 +267,15 @@ inline bool max_product_transversal(int n, const int *Ap, const int *Ai, const d
     }
     for (int i : out.touched) own[i] = Own{inf, -1, 0};
   };
-  // the team: SPL_SP_THREADS, by default the hardware's threads up to 16 (a one-GPU share of a host); small problems
-  // are not worth threads
+  // the team: SPL_SP_THREADS, by default the hardware's threads up to 8 (measured on the GPU box's host, 1e6-unknown
+  // 3-D mesh with a useless diagonal: 27.6 s with one thread, 19.7 with four or eight, 22.3 with sixteen — the last
+  // hundreds of columns search most of the matrix each and collide, so the end is sequential whatever the team);
+  // small problems are not worth threads
   int team = 1;
   {
     const char *e = getenv("SPL_SP_THREADS");
     const unsigned hw = std::thread::hardware_concurrency();
-    team = e ? atoi(e) : (int)std::min<unsigned>(hw ? hw : 1u, 16u);
+    team = e ? atoi(e) : (int)std::min<unsigned>(hw ? hw : 1u, 8u);
     if (team < 1) team = 1;
     if (!e && pending.size() < 2000) team = 1;
   }

@@ -182,6 +182,9 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
             ze = c + r * np.exp(1j * th)
             w = complex(r * np.exp(1j * th) / ne)
             mat = type(shifted)(n, n, shifted.pointers, shifted.indices, ze * b_u - a_u)   # ijob 10: ze*B - A
+            kept = getattr(shifted, "_narrowed", None)  # the same pattern arrays: their int32 copies serve every point
+            if kept is not None and kept[0] is mat.pointers and kept[1] is mat.indices:
+                mat._narrowed = kept
             t1 = time.perf_counter()
             fact = U.factor(mat, analysis)                                     #          numeric LU, same analysis
             held[0] = max(held[0], float(fact.stats["device_bytes"]))

@@ -42,7 +42,7 @@ def _oops(fn, msg):
 class Matrix(object):
     """Matrix in compressed sparse column (CSC) format (Sparse.hs:67-76)."""
 
-    __slots__ = ("ncols", "nrows", "pointers", "indices", "values", "_handle", "__weakref__")
+    __slots__ = ("ncols", "nrows", "pointers", "indices", "values", "_handle", "_narrowed", "__weakref__")
 
     def __init__(self, ncols, nrows, pointers, indices, values):
         self.ncols = int(ncols)
@@ -110,7 +110,19 @@ class Matrix(object):
         if nz < 0 or nz > len(self.indices) or nz > len(self.values):
             _oops("withConstMatrix", "last pointer %d, but %d indices and %d values" % (nz, len(self.indices), len(self.values)))
         vals = self.values.view(F64) if self.is_complex else self.values
-        return (self.nrows, self.ncols, as_i32(self.pointers), as_i32(self.indices), as_f64(vals))
+        # The reference narrows its 64-bit Int arrays on EVERY call (Foreign.hs:39-41: 2.4 GB of conversion per FFI call at
+        # config C2).  A Matrix is a value — the fields of the Haskell record cannot change — so the
+        # mirror narrows once and keeps the int32 copies while `pointers` and `indices` are the objects they were
+        # (round 4: at config C5 the copy was 30 ms of every 170 ms `linearSolve_`).  Arrays changed IN PLACE after a
+        # call are not noticed: build a new Matrix instead, as the reference's combinators do.
+        kept = getattr(self, "_narrowed", None)
+        if kept is None or kept[0] is not self.pointers or kept[1] is not self.indices:
+            kept = (self.pointers, self.indices, as_i32(self.pointers), as_i32(self.indices))
+            try:
+                self._narrowed = kept
+            except AttributeError:  # (a subclass with __slots__)
+                pass
+        return (self.nrows, self.ncols, kept[2], kept[3], as_f64(vals))
 
     def _parts(self):
         """real and imaginary parts as two real matrices with the same pattern"""

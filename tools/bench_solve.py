@@ -69,6 +69,10 @@ def main():
                        "total_s": round(t3 - t0, 3)},
                "max_rel_err_vs_manufactured": err, "scaled_residual": res, "within_1e-10": bool(err < 1e-10)}
         st = fa.stats
+        rep = fa.solve_report
+        out["solve"] = {"walks": rep["walks"], "refinement_steps": rep["ir_attempted"], "backward_error": rep["backward_error"],
+                        "GB_per_walk": round(rep["walk_bytes"] * 1e-9, 3),
+                        "TB_per_s": round(rep["walks"] * rep["walk_bytes"] / max(t3 - t2, 1e-9) * 1e-12, 3)}
         out["factorisation"] = {"path": st["path"], "kl": st["kl"], "ku": st["ku"], "fronts": st["fronts"],
                                 "device_GB": round(st["device_bytes"] * 1e-9, 2), "flops": st["flops"],
                                 "TFLOP_per_s": round(st["flops"] / max(t2 - t1, 1e-9) * 1e-12, 2)}
