@@ -1585,6 +1585,47 @@ __device__ __forceinline__ void super_sub_block(const Band &b, const double *__r
     super_sub_block<MODE, NR, Z, K + 1>(b, invs, j0, jbs, nsub, v, w, part, ce, cei, ie, iei);
 }
 
+// The solve INSIDE the super block [j0, j0 + jbs): v holds its right-hand side on entry (rows beyond jbs zero) and its
+// solution on return; w, part: scratch.  All threads of the workgroup; ends with a barrier.
+// ie / iei: the entries of the FIRST sub-block's inverse this thread multiplies with, requested by the caller before it
+// loads v (first_inverse_load), so that they travel meanwhile.
+template <int MODE, int NR, bool Z = false>
+__device__ __forceinline__ void first_inverse_load(const double *__restrict__ invs, int j0, int jbs, double *ie, double *iei) {
+  constexpr bool fwd = (MODE == 0 || MODE == 2);
+  const int nsub = (jbs + NB - 1) / NB;
+  constexpr size_t blk = Z ? (size_t)kInvBlockZ : (size_t)(2 * NB * NB);
+  constexpr size_t half = (MODE == 1 || MODE == 2) ? blk / 2 : 0;
+  inverse_load<MODE, NR, Z>(invs + (size_t)(j0 / NB + (fwd ? 0 : nsub - 1)) * blk + half, ie, iei);
+}
+template <int MODE, int NR, bool Z = false>
+__device__ __forceinline__ void solve_super_block_in_lds(const Band &b, const double *__restrict__ invs, int j0, int jbs,
+                                                         double (*v)[NR], double (*w)[NR], double *part, double *ie,
+                                                         double *iei) {
+  constexpr bool fwd = (MODE == 0 || MODE == 2);
+  constexpr int NE = NB / solve_waves<NR>();
+  const int nsub = (jbs + NB - 1) / NB;
+  constexpr size_t blk = Z ? (size_t)kInvBlockZ : (size_t)(2 * NB * NB);
+  constexpr size_t half = (MODE == 1 || MODE == 2) ? blk / 2 : 0;
+  if (couplings_ahead<NR, Z>()) {
+    double ce[(SB - 1) * NE], cei[(SB - 1) * NE];
+    super_sub_block<MODE, NR, Z, 0>(b, invs, j0, jbs, nsub, v, w, part, ce, cei, ie, iei);
+  } else
+  for (int k = 0; k < nsub; ++k) {
+    const int sblk = fwd ? k : nsub - 1 - k;
+    const int js = j0 + sblk * NB, jb = min(NB, j0 + jbs - js);
+    // couplings with the sub-blocks of this super block that are already solved
+    const int cb = fwd ? j0 : js + jb;
+    const int nc = fwd ? js - j0 : j0 + jbs - (js + jb);
+    coupling_apply<MODE, NR, Z>(b, js, cb, nc, v + (cb - j0), v + (js - j0), jb, w, part);
+    // (the last sub-block fetches its own inverse again: a branch here would make the compiler sink the multiplications
+    // of inverse_apply below it, with every operand they read from LDS kept in registers meanwhile)
+    const int next = k + 1 < nsub ? (fwd ? sblk + 1 : sblk - 1) : sblk;
+    inverse_apply<MODE, NR, Z>(ie, iei, w, jb, v + (js - j0), part, [&]() {
+      inverse_load<MODE, NR, Z>(invs + (size_t)(j0 / NB + next) * blk + half, ie, iei);
+    });
+  }
+}
+
 // NR right-hand sides at once: column r of in/out starts at r * stride
 // `tile`: which rows outside the super block this workgroup updates: `tiles` consecutive blocks of 64
 // rows starting at block tile * tiles (workgroup 0 also writes `out`).  Every workgroup redoes the
@@ -1593,44 +1634,22 @@ template <int MODE, int NR, bool Z = false>
 __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__restrict__ invs, int j0, int jbs,
                                                  double *in, double *__restrict__ out, size_t stride, int tile,
                                                  double *dsm, int tiles = 1) {
-  constexpr int SWV = solve_waves<NR>(), NE = NB / SWV;
+  constexpr int SWV = solve_waves<NR>();
   double(*v)[NR] = reinterpret_cast<double(*)[NR]>(dsm);                          // [SB * NB]
   double(*w)[NR] = reinterpret_cast<double(*)[NR]>(dsm + SB * NB * NR);           // [NB]
   double(*res)[NR] = reinterpret_cast<double(*)[NR]>(dsm + (SB + 1) * NB * NR);   // [NB]
   double *part = dsm + (SB + 2) * NB * NR;                                        // [SWV][NR][64]
   constexpr bool fwd = (MODE == 0 || MODE == 2);
   const int tid = threadIdx.x;
-  const int nsub = (jbs + NB - 1) / NB;
-  {
-    double ie[NE], iei[NE];
-    constexpr size_t blk = Z ? (size_t)kInvBlockZ : (size_t)(2 * NB * NB);
-    constexpr size_t half = (MODE == 1 || MODE == 2) ? blk / 2 : 0;
-    inverse_load<MODE, NR, Z>(invs + (size_t)(j0 / NB + (fwd ? 0 : nsub - 1)) * blk + half, ie, iei);
-    // v starts as the right-hand side of the super block; every sub-block replaces its 64 entries by the solution
-    for (int o = tid; o < SB * NB * NR; o += SWV * 64) {
-      const int t = o % (SB * NB), r = o / (SB * NB);
-      v[t][r] = t < jbs ? in[(size_t)r * stride + j0 + t] : 0.0;
-    }
-    __syncthreads();
-    if (couplings_ahead<NR, Z>()) {
-      double ce[(SB - 1) * NE], cei[(SB - 1) * NE];
-      super_sub_block<MODE, NR, Z, 0>(b, invs, j0, jbs, nsub, v, w, part, ce, cei, ie, iei);
-    } else
-    for (int k = 0; k < nsub; ++k) {
-      const int sblk = fwd ? k : nsub - 1 - k;
-      const int js = j0 + sblk * NB, jb = min(NB, j0 + jbs - js);
-      // couplings with the sub-blocks of this super block that are already solved
-      const int cb = fwd ? j0 : js + jb;
-      const int nc = fwd ? js - j0 : j0 + jbs - (js + jb);
-      coupling_apply<MODE, NR, Z>(b, js, cb, nc, v + (cb - j0), v + (js - j0), jb, w, part);
-      // (the last sub-block fetches its own inverse again: a branch here would make the compiler sink the multiplications
-      // of inverse_apply below it, with every operand they read from LDS kept in registers meanwhile)
-      const int next = k + 1 < nsub ? (fwd ? sblk + 1 : sblk - 1) : sblk;
-      inverse_apply<MODE, NR, Z>(ie, iei, w, jb, v + (js - j0), part, [&]() {
-        inverse_load<MODE, NR, Z>(invs + (size_t)(j0 / NB + next) * blk + half, ie, iei);
-      });
-    }
+  double ie[NB / SWV], iei[NB / SWV];
+  first_inverse_load<MODE, NR, Z>(invs, j0, jbs, ie, iei);
+  // v starts as the right-hand side of the super block; every sub-block replaces its 64 entries by the solution
+  for (int o = tid; o < SB * NB * NR; o += SWV * 64) {
+    const int t = o % (SB * NB), r = o / (SB * NB);
+    v[t][r] = t < jbs ? in[(size_t)r * stride + j0 + t] : 0.0;
   }
+  __syncthreads();
+  solve_super_block_in_lds<MODE, NR, Z>(b, invs, j0, jbs, v, w, part, ie, iei);
   if (tile == 0)
     for (int o = tid; o < jbs * NR; o += SWV * 64) {
       const int t = o % jbs, r = o / jbs;
@@ -1649,6 +1668,81 @@ __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__
       if (ok) in[(size_t)r * stride + i] -= res[l][r];
     }
     __syncthreads();  // res and part are reused by the next block
+  }
+}
+
+// The same steps as a software pipeline over launches (round 4).  Step k of a pass needs its super block's rows final,
+// and in the plain form that means every row update of step k - 1: a launch per step, each the whole chain "solve 256
+// unknowns in four dependent sub-blocks, THEN stream the rows" — 26 us per step at config C5 for 6.5 us worth of bytes.
+// Here launch k carries two kinds of workgroups that depend on EARLIER launches only:
+//   lead  (<= SB per system)   solve super block k from  in + carry  (carry: see below), write it to `out`, and
+//                              compute the update of the NEXT super block's rows only, as plain stores into `carry`;
+//   bulk  (the rest)           the row updates of step k - 1 beyond that next super block, with the solved super block
+//                              k - 1 read from `out` (no redone solve): read-modify-write of `in`.
+// Rows of super block m thus receive  carry[m]  from the lead of launch m - 1 (one writer, no read-modify-write) and
+// their `in` updates from the bulk groups of launches <= m - 1 (steps <= m - 2): no two launches — and no two groups of
+// one launch — touch the same words, every sum keeps its order, and the latency chain of a step (the lead) runs beside
+// the bytes of the step before (the bulk) instead of in front of its own.  A pass takes steps + 1 launches.
+//   role 0: lead, `tile` = which 64-row block of the next super block (0 also writes `out`); first: no carry yet
+//   role 1: bulk of the step whose super block is [j0, j0 + jbs): blocks SB + tile * tiles ... of the rows beyond
+template <int MODE, int NR, bool Z = false>
+__device__ __forceinline__ void solve_super_pipelined(const Band &b, const double *__restrict__ invs, int j0, int jbs,
+                                                      double *in, double *out, double *carry, size_t stride, int role,
+                                                      int tile, bool first, double *dsm, int tiles) {
+  constexpr int SWV = solve_waves<NR>();
+  double(*v)[NR] = reinterpret_cast<double(*)[NR]>(dsm);                          // [SB * NB]
+  double(*w)[NR] = reinterpret_cast<double(*)[NR]>(dsm + SB * NB * NR);           // [NB]
+  double(*res)[NR] = reinterpret_cast<double(*)[NR]>(dsm + (SB + 1) * NB * NR);   // [NB]
+  double *part = dsm + (SB + 2) * NB * NR;                                        // [SWV][NR][64]
+  constexpr bool fwd = (MODE == 0 || MODE == 2);
+  const int tid = threadIdx.x;
+  if (role == 0) {
+    double ie[NB / SWV], iei[NB / SWV];
+    first_inverse_load<MODE, NR, Z>(invs, j0, jbs, ie, iei);
+    for (int o = tid; o < SB * NB * NR; o += SWV * 64) {
+      const int t = o % (SB * NB), r = o / (SB * NB);
+      double x = 0.0;
+      if (t < jbs) {
+        x = in[(size_t)r * stride + j0 + t];
+        if (!first) x += carry[(size_t)r * stride + j0 + t];
+      }
+      v[t][r] = x;
+    }
+    __syncthreads();
+    solve_super_block_in_lds<MODE, NR, Z>(b, invs, j0, jbs, v, w, part, ie, iei);
+    if (tile == 0)
+      for (int o = tid; o < jbs * NR; o += SWV * 64) {
+        const int t = o % jbs, r = o / jbs;
+        out[(size_t)r * stride + j0 + t] = v[t][r];
+      }
+    const int rb = fwd ? j0 + jbs + tile * 64 : j0 - (tile + 1) * 64;
+    if (fwd ? rb >= b.n : rb + 64 <= 0) return;  // workgroup-uniform: no such rows (the last super block)
+    gemv64<MODE, NR, Z>(b, rb, j0, jbs, v, res, part);
+    for (int o = tid; o < 64 * NR; o += SWV * 64) {
+      const int l = o % 64, r = o / 64;
+      const int i = rb + l;
+      const bool ok = fwd ? (i < b.n) : (i >= 0);
+      if (ok) carry[(size_t)r * stride + i] = -res[l][r];
+    }
+  } else {
+    for (int o = tid; o < SB * NB * NR; o += SWV * 64) {
+      const int t = o % (SB * NB), r = o / (SB * NB);
+      v[t][r] = t < jbs ? out[(size_t)r * stride + j0 + t] : 0.0;
+    }
+    __syncthreads();
+    for (int q = 0; q < tiles; ++q) {
+      const int blk = SB + tile * tiles + q;
+      const int rb = fwd ? j0 + jbs + blk * 64 : j0 - (blk + 1) * 64;
+      if (fwd ? rb >= b.n : rb + 64 <= 0) break;  // workgroup-uniform
+      gemv64<MODE, NR, Z>(b, rb, j0, jbs, v, res, part);
+      for (int o = tid; o < 64 * NR; o += SWV * 64) {
+        const int l = o % 64, r = o / 64;
+        const int i = rb + l;
+        const bool ok = fwd ? (i < b.n) : (i >= 0);
+        if (ok) in[(size_t)r * stride + i] -= res[l][r];
+      }
+      __syncthreads();  // res and part are reused by the next block
+    }
   }
 }
 

@@ -698,6 +698,36 @@ __global__ __launch_bounds__(solve_waves<NR>() * 64) void big_super_kernel(const
                                 (size_t)b.fs, b.blk, dsm, row_blocks);
 }
 
+// The same pass as a software pipeline over launches (solve_super_pipelined, dense_lu_kernels.hpp): launch k carries,
+// for every listed front, the lead groups of its step k (solve super block k, hand the next super block its update
+// through `cbuf`) and the bulk groups of its step k - 1 (all other row updates, with the solved super block read back).
+// Pivot block only (n = np): the boundary rows have their own streaming product.  prefix: groups before each front in
+// THIS launch (lead groups first).
+template <int MODE, int NR, bool Z = false>
+__global__ __launch_bounds__(solve_waves<NR>() * 64) void big_super_pipe_kernel(const int *__restrict__ list,
+                                                            const int64_t *__restrict__ prefix, int count, int launch,
+                                                            TreeView t, const double *__restrict__ invs,
+                                                            double *work, double *zbuf, double *cbuf, int row_blocks) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  constexpr bool fwd = (MODE == 0 || MODE == 2);
+  const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
+  constexpr int span = SB * NB;
+  const int n = b.np, nsup = (n + span - 1) / span;
+  int nlead = 0;
+  if (launch < nsup) {
+    const int j0 = (fwd ? launch : nsup - 1 - launch) * span, jbs = min(span, n - j0);
+    const int beyond = fwd ? n - (j0 + jbs) : j0;
+    nlead = max(1, min(SB, (beyond + 63) / 64));
+  }
+  const int role = b.blk < nlead ? 0 : 1;
+  const int step = role == 0 ? launch : launch - 1;  // (a bulk group exists only where step launch - 1 does: host prefix)
+  const int j0 = (fwd ? step : nsup - 1 - step) * span, jbs = min(span, n - j0);
+  const Band band{const_cast<double *>(b.P), n, n, n, b.ldp + 1, 0, 0, b.pz};
+  double *carry = cbuf + (size_t)t.woff[b.f] * NR;
+  solve_super_pipelined<MODE, NR, Z>(band, invs + (Z ? 2 : 1) * t.ioff[b.f], j0, jbs, fwd ? b.W : b.Z, fwd ? b.Z : b.W, carry,
+                                     (size_t)b.fs, role, role == 0 ? b.blk : b.blk - nlead, step == 0, dsm, row_blocks);
+}
+
 // boundary part of the solution into the front's work matrix: W[r * fs + np + k] = x[r * stride + bidx[k]]
 template <int NR, bool Z = false>
 __global__ __launch_bounds__(256) void big_gather_x_kernel(const int *__restrict__ list,
@@ -964,8 +994,12 @@ struct Factors {
     // kind 0 fwd, 1 fwd^T, 2 bwd, 3 boundary^T, 4 gather, 5 gemv (transposed), 6 scatter, 7 gemv in chunks, 8 its
     // reduction, 9 offsets of the fronts in its scratch (doubles per column); 10, 11, 12: the same three for the
     // forward boundary product (nb rows x np columns)
+    // 13, 14: the pipelined passes over the pivot block (forward, backward): launches [0, steps]
     size_t seg(int kind, int k = 0) const {
-      const size_t which = kind < 3 ? (size_t)kind * (size_t)steps + (size_t)k : (size_t)3 * steps + (size_t)(kind - 3);
+      size_t which;
+      if (kind < 3) which = (size_t)kind * (size_t)steps + (size_t)k;
+      else if (kind < 13) which = (size_t)3 * steps + (size_t)(kind - 3);
+      else which = (size_t)3 * steps + 10 + (size_t)(kind - 13) * (size_t)(steps + 1) + (size_t)k;
       return which * (size_t)(count + 1);
     }
     unsigned total(int kind, int k = 0) const { return (unsigned)h[seg(kind, k) + (size_t)count]; }
@@ -1215,7 +1249,7 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
         for (int f : large) first_step += (T.fs(f) + 63) / 64;
         B.row_blocks = first_step >= 4096 ? kSolveRowBlocks : 1;
         const int rbk = B.row_blocks;
-        B.h.assign((size_t)(3 * B.steps + 10) * (size_t)(B.count + 1), 0);
+        B.h.assign((size_t)(3 * B.steps + 10 + 2 * (B.steps + 1)) * (size_t)(B.count + 1), 0);
         auto fill = [&](int kind, int k, auto groups_of) {
           int64_t *pre = B.h.data() + B.seg(kind, k);
           for (int i = 0; i < B.count; ++i) pre[i + 1] = pre[i] + groups_of(large[(size_t)i]);
@@ -1234,6 +1268,24 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
             if (k >= nsup) return 0;
             return std::max(1, (((nsup - 1 - k) * span + 63) / 64 + rbk - 1) / rbk);
           });
+        }
+        for (int k = 0; k <= B.steps; ++k) {  // the pipelined passes: lead groups of step k + bulk groups of step k - 1
+          auto groups = [&](int f, bool forward) -> int64_t {
+            const int np = T.np[(size_t)f], nsup = (np + span - 1) / span;
+            auto beyond = [&](int st) {  // rows of the pivot block still to be updated by step st
+              const int j0 = (forward ? st : nsup - 1 - st) * span, jbs = std::min(span, np - j0);
+              return forward ? np - (j0 + jbs) : j0;
+            };
+            int64_t g = 0;
+            if (k < nsup) g += std::max(1, std::min(SB, (beyond(k) + 63) / 64));
+            if (k >= 1 && k - 1 < nsup) {
+              const int rest = beyond(k - 1) - span;
+              if (rest > 0) g += ((rest + 63) / 64 + rbk - 1) / rbk;
+            }
+            return g;
+          };
+          fill(13, k, [&](int f) { return groups(f, true); });
+          fill(14, k, [&](int f) { return groups(f, false); });
         }
         fill(3, 0, [&](int f) -> int64_t { return (T.nb[(size_t)f] + 3) / 4; });
         fill(4, 0, [&](int f) -> int64_t { return (T.nb[(size_t)f] + 255) / 256; });
@@ -1531,9 +1583,27 @@ static void launch_big_super(const mf::Factors &F, const mf::Factors::BigLevel &
                        B.prefix(kind, step), B.count, step, F.view, F.invs.get(), work, zbuf, B.row_blocks, pivots_only);
 }
 
+template <int MODE, int NR, bool Z = false>
+static void launch_big_pipe(const mf::Factors &F, const mf::Factors::BigLevel &B, int kind, double *work, double *zbuf,
+                            double *cbuf, hipStream_t s) {
+  constexpr size_t lds = (size_t)((SB + 2) * NB + solve_waves<NR>() * 64) * NR * sizeof(double);
+  static std::atomic<uint64_t> attr_set{0};  // one mask per instantiation, one bit per device
+  if (first_use_on_this_device(attr_set)) {
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&big_super_pipe_kernel<MODE, NR, Z>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    mark_used_on_this_device(attr_set);
+  }
+  for (int k = 0; k <= B.steps; ++k) {
+    const unsigned groups = B.total(kind, k);
+    if (groups > 0)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(big_super_pipe_kernel<MODE, NR, Z>), dim3(groups), dim3(solve_waves<NR>() * 64), lds, s,
+                         B.list.get(), B.prefix(kind, k), B.count, k, F.view, F.invs.get(), work, zbuf, cbuf, B.row_blocks);
+  }
+}
+
 template <bool TRANS, int NR, bool Z = false>
 static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride, double *work, double *zbuf,
-                                  double *gscr, hipStream_t s) {
+                                  double *gscr, double *cbuf, hipStream_t s) {
   const mf::Tree &T = *F.tree;
   const int nd = T.maxdepth + 1;
   double *invs = F.invs.get();
@@ -1587,6 +1657,11 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
       const char *sf = getenv("SPL_MF_SPLIT_FWD");
       const bool split = !(sf && sf[0] == '0');
       const bool pivots_only = !TRANS && split;
+      // (pipe: SPL_MF_PIPE=0 restores one launch per step with the whole chain in it, for ablation)
+      const char *pe = getenv("SPL_MF_PIPE");
+      const bool pipe = !(pe && pe[0] == '0') && (TRANS || pivots_only);
+      if (pipe) launch_big_pipe<FWD, NR, Z>(F, B, 13, work, zbuf, cbuf, s);
+      else
       for (int k = 0; k < B.steps; ++k) launch_big_super<FWD, NR, Z>(F, B, (TRANS || pivots_only) ? 1 : 0, k, work, zbuf, s, pivots_only ? 1 : 0);
       if (pivots_only && B.total(10) > 0) {
         constexpr size_t lds = (size_t)std::max(kGemvChunk, gemv_waves<NR>() * 64) * NR * sizeof(double);
@@ -1643,7 +1718,12 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
         }
       }
       // the pivot block alone; columns of Z / W are fs apart
-      for (int k = 0; k < B.steps; ++k) launch_big_super<BWD, NR, Z>(F, B, 2, k, work, zbuf, s);
+      {
+        const char *pe = getenv("SPL_MF_PIPE");
+        if (!(pe && pe[0] == '0')) launch_big_pipe<BWD, NR, Z>(F, B, 14, work, zbuf, cbuf, s);
+        else
+        for (int k = 0; k < B.steps; ++k) launch_big_super<BWD, NR, Z>(F, B, 2, k, work, zbuf, s);
+      }
       hipLaunchKernelGGL(HIP_KERNEL_NAME(big_scatter_x_kernel<NR, Z>), dim3(B.total(6)), dim3(256), 0, s, B.list.get(),
                          B.prefix(6), B.count, F.view, work, zbuf, c, stride);
     }
@@ -1662,35 +1742,37 @@ void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride,
     // right-hand side is two real columns of the work matrices: one at a time, or four together
     constexpr int kGroupZ = 8;  // = kSolveGroup columns of the caller, each a packed complex vector: 16 real columns
     const int nrz = k == 1 ? 2 : 2 * kGroupZ;
-    DBuf<double> wz(((size_t)T.work_elems * 2 + (size_t)F.gemv_scratch) * nrz);  // work and z matrices, scratch of the boundary products
+    DBuf<double> wz(((size_t)T.work_elems * 3 + (size_t)F.gemv_scratch) * nrz);  // work, z and carry matrices, scratch of the boundary products
     double *wk = wz.get(), *zb = wz.get() + (size_t)T.work_elems * nrz, *gs = zb + (size_t)T.work_elems * nrz;
+    double *cb = gs + (size_t)F.gemv_scratch * nrz;
     if (k == 1) {
-      if (sys == 0) solve_columns_on_tree<false, 2, true>(F, d_c, stride, wk, zb, gs, s);
-      else solve_columns_on_tree<true, 2, true>(F, d_c, stride, wk, zb, gs, s);
+      if (sys == 0) solve_columns_on_tree<false, 2, true>(F, d_c, stride, wk, zb, gs, cb, s);
+      else solve_columns_on_tree<true, 2, true>(F, d_c, stride, wk, zb, gs, cb, s);
     } else {
       for (int c0 = 0; c0 < k; c0 += kGroupZ) {  // (k is a multiple of kSolveGroup = 8 here: zero-padded by the caller)
         double *c = d_c + (size_t)c0 * stride;
-        if (sys == 0) solve_columns_on_tree<false, 2 * kGroupZ, true>(F, c, stride, wk, zb, gs, s);
-        else solve_columns_on_tree<true, 2 * kGroupZ, true>(F, c, stride, wk, zb, gs, s);
+        if (sys == 0) solve_columns_on_tree<false, 2 * kGroupZ, true>(F, c, stride, wk, zb, gs, cb, s);
+        else solve_columns_on_tree<true, 2 * kGroupZ, true>(F, c, stride, wk, zb, gs, cb, s);
       }
     }
     SPL_HIP(hipStreamSynchronize(s));
     return;
   }
   const int nr = k == 1 ? 1 : kSolveGroup;
-  DBuf<double> both(((size_t)T.work_elems * 2 + (size_t)F.gemv_scratch) * nr);  // work and z matrices of all fronts, scratch: one allocation
+  DBuf<double> both(((size_t)T.work_elems * 3 + (size_t)F.gemv_scratch) * nr);  // work, z and carry matrices of all fronts, scratch: one allocation
   struct Span {
     double *p;
     double *get() const { return p; }
-  } work{both.get()}, zbuf{both.get() + (size_t)T.work_elems * nr}, gscr{both.get() + (size_t)T.work_elems * nr * 2};
+  } work{both.get()}, zbuf{both.get() + (size_t)T.work_elems * nr}, gscr{both.get() + (size_t)T.work_elems * nr * 2},
+      cbuf{both.get() + ((size_t)T.work_elems * 2 + (size_t)F.gemv_scratch) * nr};
   if (k == 1) {
-    if (sys == 0) solve_columns_on_tree<false, 1>(F, d_c, stride, work.get(), zbuf.get(), gscr.get(), s);
-    else solve_columns_on_tree<true, 1>(F, d_c, stride, work.get(), zbuf.get(), gscr.get(), s);
+    if (sys == 0) solve_columns_on_tree<false, 1>(F, d_c, stride, work.get(), zbuf.get(), gscr.get(), cbuf.get(), s);
+    else solve_columns_on_tree<true, 1>(F, d_c, stride, work.get(), zbuf.get(), gscr.get(), cbuf.get(), s);
   } else {
     for (int c0 = 0; c0 < k; c0 += kSolveGroup) {
       double *c = d_c + (size_t)c0 * stride;
-      if (sys == 0) solve_columns_on_tree<false, kSolveGroup>(F, c, stride, work.get(), zbuf.get(), gscr.get(), s);
-      else solve_columns_on_tree<true, kSolveGroup>(F, c, stride, work.get(), zbuf.get(), gscr.get(), s);
+      if (sys == 0) solve_columns_on_tree<false, kSolveGroup>(F, c, stride, work.get(), zbuf.get(), gscr.get(), cbuf.get(), s);
+      else solve_columns_on_tree<true, kSolveGroup>(F, c, stride, work.get(), zbuf.get(), gscr.get(), cbuf.get(), s);
     }
   }
   SPL_HIP(hipStreamSynchronize(s));  // the work matrices are freed on return
