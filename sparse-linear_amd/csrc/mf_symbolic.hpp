@@ -844,9 +844,13 @@ inline void layout_tree(Tree &T) {
   T.woff.assign((size_t)nf, 0);
   T.roff.assign((size_t)nf, 0);
   T.level_elems.assign((size_t)T.maxdepth + 1, 0);
-  auto pad_ld = [](int64_t v) {  // off the multiples of 32 doubles (column stride not a power of two)
-    v = std::max<int64_t>(v, 1);
-    return v % 32 == 0 ? v + 2 : v;
+  // Leading dimensions are odd multiples of 16 doubles: a column then starts on a 128-byte line, so the 64 rows a
+  // wavefront takes of it are four whole lines (round 4: with ld = fs a 512-byte segment straddled five — the PMC pass
+  // of the solve kernels read 1.19x the panels' bytes, tools/pmc_solve.sh), and the column stride is no multiple of 256
+  // bytes (the accesses along a row of the transposed kernels spread over the channels).
+  auto pad_ld = [](int64_t v) {
+    v = (std::max<int64_t>(v, 1) + 15) / 16 * 16;
+    return v % 32 == 0 ? v + 16 : v;
   };
   for (int f = 0; f < nf; ++f) {
     const int64_t fs = T.fs(f), p = T.np[(size_t)f], q = T.nb[(size_t)f];

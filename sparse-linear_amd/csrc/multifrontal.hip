@@ -781,7 +781,10 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(c
   const int np = FWD ? b.nb : b.np, nb = FWD ? b.np : b.nb, fs = b.fs, ldu = FWD ? b.ldp : b.ldu;
   const int nch = (nb + kGemvChunk - 1) / kGemvChunk;
   const int rb = b.blk / nch, ch = b.blk - rb * nch;
-  const int i0 = rb * 64, k0 = ch * kGemvChunk, kn = min(kGemvChunk, nb - k0);
+  // FWD: the rows start np rows down the pivot columns; the blocks of 64 are laid from the line boundary at or above
+  // that row (`skew` rows of the first block belong to the pivot block and are masked), so every block is whole lines
+  const int skew = FWD ? (b.np & 15) : 0;
+  const int i0 = rb * 64 - skew, k0 = ch * kGemvChunk, kn = min(kGemvChunk, nb - k0);
   const double *xb = FWD ? b.Z + k0 : b.W + b.np + k0;
   for (int o = threadIdx.x; o < kn * NR; o += GW * 64) {
     const int kk = o % kn, r = o / kn;
@@ -793,8 +796,8 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(c
   double acc[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) acc[r] = 0.0;
-  if (i < np) {
-    const double *row = (FWD ? b.P + (size_t)b.np : b.U) + (size_t)i + (size_t)k0 * ldu;
+  if (i >= 0 && i < np) {
+    const double *row = (FWD ? b.P + (size_t)b.np : b.U) + (ptrdiff_t)i + (size_t)k0 * ldu;
     const size_t zo = FWD ? b.pz : b.uz;
     int k = wave;
     for (; k + 7 * GW < kn; k += 8 * GW) {
@@ -820,7 +823,7 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(c
   double *out = nch > 1 ? scratch + (size_t)pofs[b.item] * NR + (size_t)ch * NR * np : nullptr;
   for (int o = threadIdx.x; o < 64 * NR; o += GW * 64) {
     const int r = o / 64, l = o % 64;
-    if (i0 + l >= np) continue;
+    if (i0 + l < 0 || i0 + l >= np) continue;
     double tot = 0.0;
 #pragma unroll
     for (int q = 0; q < GW; ++q) tot += part[(q * NR + r) * 64 + l];
@@ -1297,7 +1300,7 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
         fill(9, 0, [&](int f) -> int64_t { return chunks(f) > 1 ? chunks(f) * T.np[(size_t)f] : 0; });
         F.gemv_scratch = std::max(F.gemv_scratch, B.h[B.seg(9) + (size_t)B.count]);
         auto fchunks = [&](int f) -> int64_t { return (T.np[(size_t)f] + kGemvChunk - 1) / kGemvChunk; };
-        fill(10, 0, [&](int f) -> int64_t { return (int64_t)((T.nb[(size_t)f] + 63) / 64) * fchunks(f); });
+        fill(10, 0, [&](int f) -> int64_t { return (int64_t)((T.nb[(size_t)f] + (T.np[(size_t)f] & 15) + 63) / 64) * fchunks(f); });
         fill(11, 0, [&](int f) -> int64_t { return fchunks(f) > 1 ? (T.nb[(size_t)f] + 255) / 256 : 0; });
         fill(12, 0, [&](int f) -> int64_t { return fchunks(f) > 1 ? fchunks(f) * T.nb[(size_t)f] : 0; });
         F.gemv_scratch = std::max(F.gemv_scratch, B.h[B.seg(12) + (size_t)B.count]);
@@ -1659,7 +1662,9 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
       const bool pivots_only = !TRANS && split;
       // (pipe: SPL_MF_PIPE=0 restores one launch per step with the whole chain in it, for ablation)
       const char *pe = getenv("SPL_MF_PIPE");
-      const bool pipe = !(pe && pe[0] == '0') && (TRANS || pivots_only);
+      // (one or two columns only: with 8 or 16 the in-super-block solve is instruction-bound, and the bulk groups'
+      // reload of the solved super block costs more than the overlap gains: FEAST 80^3 solve stage 2.95 -> 3.05 s)
+      const bool pipe = !(pe && pe[0] == '0') && (TRANS || pivots_only) && NR <= 2;
       if (pipe) launch_big_pipe<FWD, NR, Z>(F, B, 13, work, zbuf, cbuf, s);
       else
       for (int k = 0; k < B.steps; ++k) launch_big_super<FWD, NR, Z>(F, B, (TRANS || pivots_only) ? 1 : 0, k, work, zbuf, s, pivots_only ? 1 : 0);
@@ -1720,7 +1725,7 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
       // the pivot block alone; columns of Z / W are fs apart
       {
         const char *pe = getenv("SPL_MF_PIPE");
-        if (!(pe && pe[0] == '0')) launch_big_pipe<BWD, NR, Z>(F, B, 14, work, zbuf, cbuf, s);
+        if (!(pe && pe[0] == '0') && NR <= 2) launch_big_pipe<BWD, NR, Z>(F, B, 14, work, zbuf, cbuf, s);
         else
         for (int k = 0; k < B.steps; ++k) launch_big_super<BWD, NR, Z>(F, B, 2, k, work, zbuf, s);
       }
