@@ -20,7 +20,7 @@
  * idempotent and may run on any thread; status: 0 OK, 1 singular-matrix warning, < 0 error;
  * only sys = 0 (A x = b) and sys = 1 (A^T x = b; UMFPACK_At) are ever passed (Umfpack.hs:95-97).
  *
- * Algorithm (as of round 3).  symbolic (host): a reverse-Cuthill-McKee band ordering and, from 1024
+ * Algorithm (HISTORY.md §4.5 for how it got there).  symbolic (host): a reverse-Cuthill-McKee band ordering and, from 1024
  * unknowns on, a nested-dissection ordering with its frontal tree; the one a measured time model
  * predicts to factor faster is kept (the tree from about 2000 unknowns on, narrow bands included:
  * the band factorisation is a chain of n / 64 block steps however narrow the band).  numeric (GPU): LU of the
