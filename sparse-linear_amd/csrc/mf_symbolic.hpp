@@ -746,41 +746,87 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
       const detail::Node &nd = nodes[(size_t)f];
       const int last = T.p0[(size_t)f] + T.np[(size_t)f];
       std::vector<int> &b = bnd[(size_t)f];
+      // the pivots' own later neighbours: few, sorted here; the children's lists arrive sorted and are merged in
+      std::vector<int> own;
       for (int g = T.p0[(size_t)f]; g < last; ++g) {
         const int v = T.perm[(size_t)g];
         for (int64_t p = xadj[(size_t)v]; p < xadj[(size_t)v + 1]; ++p) {
           const int h = T.inv[(size_t)adj[(size_t)p]];
-          if (h >= last) b.push_back(h);
+          if (h >= last) own.push_back(h);
         }
       }
-      for (int c : {nd.left, nd.right}) {
-        if (c < 0) continue;
-        for (int h : bnd[(size_t)c])
-          if (h >= last) b.push_back(h);
+      std::sort(own.begin(), own.end());
+      own.erase(std::unique(own.begin(), own.end()), own.end());
+      const std::vector<int> none;
+      const std::vector<int> &l = nd.left >= 0 ? bnd[(size_t)nd.left] : none, &r = nd.right >= 0 ? bnd[(size_t)nd.right] : none;
+      // three-way merge without duplicates of what lies beyond this front's pivots
+      size_t a = std::lower_bound(l.begin(), l.end(), last) - l.begin(), c = std::lower_bound(r.begin(), r.end(), last) - r.begin(), o = 0;
+      b.reserve(own.size() + (l.size() - a) + (r.size() - c));
+      const int kEnd = 0x7fffffff;
+      for (;;) {
+        const int x = a < l.size() ? l[a] : kEnd, y = c < r.size() ? r[c] : kEnd, z = o < own.size() ? own[o] : kEnd;
+        const int m = std::min(x, std::min(y, z));
+        if (m == kEnd) break;
+        b.push_back(m);
+        if (x == m) ++a;
+        if (y == m) ++c;
+        if (z == m) ++o;
       }
-      std::sort(b.begin(), b.end());
-      b.erase(std::unique(b.begin(), b.end()), b.end());
     };
+    // One team of threads for all levels (round 4: a pool spawned and joined per level cost more than the work of most
+    // of the 26 levels of a 10^6-unknown mesh): the main thread publishes a level, everyone takes chunks of its fronts,
+    // the level ends when all have reported; levels with little work stay with the main thread.
     const unsigned hw = std::thread::hardware_concurrency();
-    const int nthreads = (int)std::min<unsigned>(hw ? hw : 1, 32);
+    const int nthreads = (int)std::min<unsigned>(hw ? hw : 1, 16);
+    std::atomic<int> generation{0}, reported{0}, stop{0};
+    std::atomic<size_t> next_item{0};
+    const std::vector<int> *cur = nullptr;
+    size_t chunk = 1;
+    auto take_chunks = [&] {
+      const std::vector<int> &L = *cur;
+      for (size_t i = next_item.fetch_add(chunk); i < L.size(); i = next_item.fetch_add(chunk))
+        for (size_t k = i; k < std::min(i + chunk, L.size()); ++k) boundary_of(L[k]);
+    };
+    std::vector<std::thread> team;
+    if (nthreads > 1 && nf >= 512)
+      for (int w = 1; w < nthreads; ++w) {
+        try {
+          team.emplace_back([&] {
+            int seen = 0;
+            for (;;) {
+              int now, spins = 0;
+              while ((now = generation.load(std::memory_order_acquire)) == seen) {
+                if (stop.load(std::memory_order_acquire)) return;
+                if (++spins > 200) { std::this_thread::yield(); spins = 0; }
+              }
+              seen = now;
+              take_chunks();
+              reported.fetch_add(1, std::memory_order_release);
+            }
+          });
+        } catch (...) {
+          break;
+        }
+      }
     for (int d = T.maxdepth; d >= 0; --d) {
       const std::vector<int> &L = T.by_depth[(size_t)d];
-      if (nthreads <= 1 || L.size() < 2) {
+      int64_t pivots = 0;
+      for (int f : L) pivots += T.np[(size_t)f];
+      if (team.empty() || L.size() < 2 || (L.size() < 8 && pivots < 4096)) {
         for (int f : L) boundary_of(f);
         continue;
       }
       // (the few fronts of the top levels are the largest: one each per thread; lower down in chunks)
-      const size_t chunk = L.size() < 64 ? 1 : 16;
-      const int team = (int)std::min<size_t>((size_t)nthreads, (L.size() + chunk - 1) / chunk);
-      std::atomic<size_t> next_item{0};
-      std::vector<std::thread> pool;
-      for (int w = 0; w < team; ++w)
-        pool.emplace_back([&] {
-          for (size_t i = next_item.fetch_add(chunk); i < L.size(); i = next_item.fetch_add(chunk))
-            for (size_t k = i; k < std::min(i + chunk, L.size()); ++k) boundary_of(L[k]);
-        });
-      for (std::thread &th : pool) th.join();
+      cur = &L;
+      chunk = L.size() < 64 ? 1 : 16;
+      next_item.store(0, std::memory_order_relaxed);
+      reported.store(0, std::memory_order_relaxed);
+      generation.fetch_add(1, std::memory_order_release);
+      take_chunks();
+      while (reported.load(std::memory_order_acquire) < (int)team.size()) std::this_thread::yield();
     }
+    stop.store(1, std::memory_order_release);
+    for (std::thread &th : team) th.join();
     for (int f = 0; f < nf; ++f) {
       T.nb[(size_t)f] = (int)bnd[(size_t)f].size();
       T.bptr[(size_t)f + 1] = T.bptr[(size_t)f] + (int64_t)bnd[(size_t)f].size();

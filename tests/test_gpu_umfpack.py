@@ -287,6 +287,49 @@ def _grid_matrix(pkg, O, kind, m):
     return n, pkg.Matrix(n, n, rp, ci, v)
 
 
+@pytest.mark.parametrize("unsym", [False, True])
+def test_pipelined_steps_and_split_boundary_product_give_the_same_solution(gpu, pkg, O, unsym, monkeypatch):
+    """round 4, csrc/multifrontal.hip: (1) the super-block steps of the large fronts as a software pipeline over launches
+    (lead groups of step k beside the bulk row updates of step k - 1, the next super block's update handed over in a
+    carry array) subtract the same numbers in the same order as one launch per step: the solutions are the same bits
+    (SPL_MF_PIPE=0); (2) the boundary rows' share of the forward pass as a streaming product of its own sums the same
+    products in another association than the steps over all rows did (SPL_MF_SPLIT_FWD=0): the same solution to
+    rounding level.  A 3-D mesh whose top fronts take several super-block steps, symmetric (L D L^T) and unsymmetric
+    (both systems: the transposed kernels too); the solve report says two walks each."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("SPL_MF_BIGSOLVE", "64")  # many-workgroup solves from 64 rows on: more fronts, more steps
+    m = 30
+    n, A = _grid_matrix(pkg, O, "3d", m)
+    rng = np.random.default_rng(3)
+    if unsym:
+        S0 = csc_tuple_to_scipy(mat_to_tuple(A)).tocoo()
+        v = S0.data * rng.uniform(0.8, 1.2, S0.nnz)
+        v[S0.row == S0.col] = 7.0  # dominant: no interchanges, plain LU on the tree
+        S1 = sp.csc_matrix((v, (S0.row, S0.col)), shape=S0.shape)
+        S1.sort_indices()
+        A = pkg.Matrix(n, n, S1.indptr.astype(np.int32), S1.indices.astype(np.int32), S1.data)
+    S = csc_tuple_to_scipy(mat_to_tuple(A))
+    U = pkg.umfpack
+    xs = rng.uniform(0.5, 1.5, n)
+    fact = U.factor(A, U.analyze(A))
+    assert fact.path in (3, 4)
+    for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, sp.csc_matrix(S.T))):
+        b = np.asarray(op @ xs).ravel()
+        x = U.linearSolve_(fact, mode, A, b)
+        rep = fact.solve_report
+        assert rep["walks"] == 1 + rep["ir_attempted"] <= 3 and rep["backward_error"] < 2.3e-16
+        assert rep["walk_bytes"] > 16 * n
+        monkeypatch.setenv("SPL_MF_PIPE", "0")
+        x_plain = U.linearSolve_(fact, mode, A, b)
+        monkeypatch.setenv("SPL_MF_SPLIT_FWD", "0")
+        x_old = U.linearSolve_(fact, mode, A, b)
+        monkeypatch.delenv("SPL_MF_PIPE")
+        monkeypatch.delenv("SPL_MF_SPLIT_FWD")
+        assert np.array_equal(x, x_plain)
+        assert np.max(np.abs(x - x_old) / np.abs(x_old)) < 1e-13
+        assert np.max(np.abs(x - xs) / xs) < 1e-12
+
+
 @pytest.mark.parametrize("limits", ["default", "small"])
 @pytest.mark.parametrize("kind,m", [("2d", 7), ("2d", 45), ("2d", 130), ("3d", 9), ("3d", 22)])
 def test_multifrontal_matches_band_and_oracle(gpu, pkg, O, kind, m, limits, monkeypatch):
