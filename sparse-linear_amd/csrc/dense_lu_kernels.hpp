@@ -213,11 +213,214 @@ __device__ __forceinline__ void diag_block_factor_t(const Band &b, int j0, int j
   }
 }
 
+// The same without interchanges, BLOCKED by 16 (round 4).  The form above pays about 1 000 cycles per pivot — a
+// division, an LDS round trip and a workgroup barrier, because column k belongs to wavefront k mod 4, then 16 dependent
+// v_readlane + multiply-add pairs — and as many per step of the two inverses: 27 + 27 us per 64 x 64 block
+// (tools/probe/diag_bench.hip), on the chain of every block step of a front (a 100^3 factorisation spends 63 of its
+// 168 ms in 837 such steps, GPU busy but at a concurrency of 1.3: tools/trace_gaps.py).  Here:
+//   LU      four panels of 16 columns.  One wavefront factors a panel in registers (lane = row, 16 columns, the
+//           multiplier stays in its lane, the pivot row comes by v_readlane: no barrier inside a panel); a second one
+//           solves the 16 pivot rows of the remaining columns (lane = column, the 120 multipliers as broadcast LDS
+//           reads); the trailing 16 x 16 blocks are updated on the matrix cores (v_mfma_f64_16x16x4: lane l supplies
+//           A[l % 16][k0 + l / 16] and B[k0 + l / 16][l % 16], holds C[l / 16 + 4 r][l % 16]).  Three barriers a panel.
+//   inverses  by the block recurrence of a triangular inverse, in place in the tile: the four diagonal 16 x 16 blocks
+//           of both factors by substitution inside a wavefront (lanes 0 - 15 rows of L_ww, 16 - 31 rows of U_ww with
+//           their columns mirrored, so that both halves walk the same registers), then block column by block column —
+//           L from the right, U from the left, one pair per stage — X_ij = -(sum_k X_ik T_k + M_ii T_i) with
+//           T_k = L_kj M_jj: sixteen 16 x 16 x 16 products per factor on the matrix cores.  An MFMA result is laid out
+//           exactly as the B operand of the next product wants it, so the T_k never leave the registers.
+// Sums are associated differently from the form above (the matrix cores accumulate four products at a time, fused):
+// factors and inverses agree with it to rounding level, not bit for bit.
+__device__ __forceinline__ double4v mfma16(double a, double b, double4v acc) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+}
+// acc += Ablk * T, Ablk = the 16 x 16 block of tile D at (r0, c0) — masked: 0 full block, 1 unit lower triangle (ones on
+// the diagonal, zeros above), 2 upper triangle with its diagonal — and T a 16 x 16 block in MFMA result layout
+__device__ __forceinline__ double4v block_times(const double (*D)[LDP], int r0, int c0, int mask, double4v T, double4v acc) {
+  const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = 4 * r + kq;
+    double a = D[r0 + i][c0 + k];
+    if (mask == 1) a = i > k ? a : (i == k ? 1.0 : 0.0);
+    if (mask == 2) a = i <= k ? a : 0.0;
+    acc = mfma16(a, T[r], acc);
+  }
+  return acc;
+}
+// the 16 x 16 block of tile D at (r0, c0) as an MFMA B operand / result layout: element r = blk[lane / 16 + 4 r][lane % 16]
+__device__ __forceinline__ double4v block_as_b(const double (*D)[LDP], int r0, int c0, int mask) {
+  const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
+  double4v T;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = 4 * r + kq;
+    double v = D[r0 + k][c0 + j];
+    if (mask == 1) v = k > j ? v : (k == j ? 1.0 : 0.0);
+    if (mask == 2) v = k <= j ? v : 0.0;
+    T[r] = v;
+  }
+  return T;
+}
+
+__device__ __forceinline__ void diag_block_factor_blocked(const Band &b, int j0, int jb, double (*D)[LDP],
+                                                          int *__restrict__ singular, double *__restrict__ invL,
+                                                          double *__restrict__ invU) {
+  constexpr int PB = 16, NP = NB / PB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- LU, panel by panel
+#pragma unroll 1
+  for (int p = 0; p < NP; ++p) {
+    const int c0 = p * PB;
+    if (wave == 0) {
+      double a[PB];
+#pragma unroll
+      for (int c = 0; c < PB; ++c) a[c] = D[lane][c0 + c];
+#pragma unroll
+      for (int kk = 0; kk < PB; ++kk) {
+        const int k = c0 + kk;
+        const double piv = readlane_f64(a[kk], k);
+        if (piv == 0.0) {
+          if (lane == 0) atomicOr(singular, 1);
+        } else if (lane > k) {
+          a[kk] = a[kk] / piv;
+        }
+        const double l = lane > k ? a[kk] : 0.0;
+#pragma unroll
+        for (int c = kk + 1; c < PB; ++c) a[c] = __builtin_fma(-l, readlane_f64(a[c], k), a[c]);  // (fused: this chain is the step's latency)
+      }
+#pragma unroll
+      for (int c = 0; c < PB; ++c) D[lane][c0 + c] = a[c];
+    }
+    __syncthreads();
+    if (p + 1 == NP) break;
+    if (wave == 1) {  // the pivot rows of the columns to the right: U12 = inv(L_pp) A12, lane = column
+      const int col = c0 + PB + lane;
+      if (col < NB) {
+        double u[PB];
+#pragma unroll
+        for (int r = 0; r < PB; ++r) u[r] = D[c0 + r][col];
+#pragma unroll
+        for (int k = 0; k + 1 < PB; ++k)
+#pragma unroll
+          for (int r = k + 1; r < PB; ++r) u[r] = __builtin_fma(-D[c0 + r][c0 + k], u[k], u[r]);
+#pragma unroll
+        for (int r = 1; r < PB; ++r) D[c0 + r][col] = u[r];
+      }
+    }
+    __syncthreads();
+    const int nbk = NP - 1 - p;  // trailing blocks per side
+    for (int t = wave; t < nbk * nbk; t += 4) {
+      const int r0 = (p + 1 + t / nbk) * PB, q0 = (p + 1 + t % nbk) * PB;
+      double4v acc = {0.0, 0.0, 0.0, 0.0};
+      acc = block_times(D, r0, c0, 0, block_as_b(D, c0, q0, 0), acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) D[r0 + (lane >> 4) + 4 * r][q0 + (lane & 15)] -= acc[r];
+    }
+    __syncthreads();
+  }
+  // the factors to band storage
+  for (int c = wave; c < jb; c += 4)
+    if (lane < jb && b.in_band(j0 + lane, j0 + c)) b.at(j0 + lane, j0 + c) = D[lane][c];
+  __syncthreads();  // (the inverses overwrite the tile)
+  // ---- inverses, in place.  Diagonal blocks: wavefront w takes block w of both factors
+  {
+    const int d0 = wave * PB, half = lane >> 4, r = lane & 15;  // half 0: a row of L_ww, 1: of U_ww (2, 3: idle)
+    // z[c]: L rows hold column c of the inverse, U rows column 15 - c (both halves then need columns 0 .. s at step s)
+    double z[PB], co[PB];  // co[s]: this row's coefficient at step s: L(r, s), or U(r, 15 - s)
+#pragma unroll
+    for (int c = 0; c < PB; ++c) {
+      z[c] = ((half == 0 ? c : PB - 1 - c) == r) ? 1.0 : 0.0;
+      co[c] = half < 2 ? D[d0 + r][d0 + (half == 0 ? c : PB - 1 - c)] : 0.0;
+    }
+    double dinv = 1.0;  // 1 / U(r, r) in the U rows
+    if (half == 1) {
+      const double d = D[d0 + r][d0 + r];
+      dinv = d != 0.0 ? 1.0 / d : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < PB; ++s) {
+      // L: row s of inv(L_ww) is final (unit diagonal); rows below lose L(r, s) x it.  U: row k = 15 - s is final after
+      // scaling by 1 / U(k, k); rows above lose U(r, k) x it.
+      const double dk = readlane_f64(dinv, 16 + PB - 1 - s);
+      const bool below = half == 0 && r > s, above = half == 1 && r < PB - 1 - s, isk = half == 1 && r == PB - 1 - s;
+      const double cf = (below || above) ? co[s] : 0.0;
+#pragma unroll
+      for (int c = 0; c <= s; ++c) {
+        const double vl = readlane_f64(z[c], s), vu = readlane_f64(z[c], 16 + PB - 1 - s) * dk;
+        const double v = half == 0 ? vl : vu;
+        z[c] = isk ? vu : __builtin_fma(-cf, v, z[c]);
+      }
+    }
+    if (half == 0) {
+#pragma unroll
+      for (int c = 0; c < PB; ++c)
+        if (c < r) D[d0 + r][d0 + c] = z[c];
+    } else if (half == 1) {
+#pragma unroll
+      for (int c = 0; c < PB; ++c)
+        if (PB - 1 - c >= r) D[d0 + r][d0 + PB - 1 - c] = z[c];
+    }
+  }
+  __syncthreads();
+  // off-diagonal blocks: stage st pairs block column jl = 2 - st of inv(L) (rows below it) with ju = 1 + st of inv(U)
+#pragma unroll 1
+  for (int st = 0; st < NP - 1; ++st) {
+    const int jl = NP - 2 - st, ju = 1 + st, nout = st + 1;  // nout outputs per factor
+    // outputs 0 .. nout-1: L blocks (i = jl + 1 + t, jl); nout .. 2 nout - 1: U blocks (i = t', ju), t' = 0 .. ju - 1;
+    // a wavefront takes outputs wave and wave + 4 (at most six per stage)
+    auto output = [&](int t, int &i, int &j) -> double4v {
+      const bool isL = t < nout;
+      j = isL ? jl : ju;
+      i = isL ? jl + 1 + t : t - nout;
+      const double4v Mjj = block_as_b(D, j * PB, j * PB, isL ? 1 : 2);
+      double4v acc = {0.0, 0.0, 0.0, 0.0};
+      if (isL) {
+        // X_ij = -( sum_{k = j+1}^{i-1} X_ik T_k + M_ii T_i ),  T_k = L_kj M_jj
+        for (int k = j + 1; k <= i; ++k) {
+          double4v T = {0.0, 0.0, 0.0, 0.0};
+          T = block_times(D, k * PB, j * PB, 0, Mjj, T);
+          acc = block_times(D, i * PB, k * PB, k == i ? 1 : 0, T, acc);
+        }
+      } else {
+        // X_ij = -( M_ii T_i + sum_{k = i+1}^{j-1} X_ik T_k ),  T_k = U_kj M_jj
+        for (int k = i; k < j; ++k) {
+          double4v T = {0.0, 0.0, 0.0, 0.0};
+          T = block_times(D, k * PB, j * PB, 0, Mjj, T);
+          acc = block_times(D, i * PB, k * PB, k == i ? 2 : 0, T, acc);
+        }
+      }
+      return acc;
+    };
+    const bool has0 = wave < 2 * nout, has1 = wave + 4 < 2 * nout;
+    double4v X0 = {0.0, 0.0, 0.0, 0.0}, X1 = {0.0, 0.0, 0.0, 0.0};
+    int i0 = 0, q0 = 0, i1 = 0, q1 = 0;
+    if (has0) X0 = output(wave, i0, q0);
+    if (has1) X1 = output(wave + 4, i1, q1);
+    __syncthreads();  // every T of this stage has been formed from the original blocks of these two block columns
+    if (has0)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) D[i0 * PB + (lane >> 4) + 4 * r][q0 * PB + (lane & 15)] = -X0[r];
+    if (has1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) D[i1 * PB + (lane >> 4) + 4 * r][q1 * PB + (lane & 15)] = -X1[r];
+    __syncthreads();
+  }
+  for (int c = wave; c < NB; c += 4) {
+    const double v = D[lane][c];
+    invL[lane + c * NB] = lane > c ? v : (lane == c ? 1.0 : 0.0);
+    invU[lane + c * NB] = lane <= c ? v : 0.0;
+  }
+}
+
+// Band::piv: 0 no interchanges (the blocked form), 1 threshold pivoting inside the block, 2 no interchanges in the
+// unblocked form of rounds 1 - 3 (ablation: SPL_LU_DIAG=plain)
 __device__ __forceinline__ void diag_block_factor(const Band &b, int j0, int jb, double (*D)[LDP],
                                                   double (*lcol)[NB], int *__restrict__ singular,
                                                   double *__restrict__ invL, double *__restrict__ invU) {
-  if (b.piv) diag_block_factor_t<true>(b, j0, jb, D, lcol, singular, invL, invU);
-  else diag_block_factor_t<false>(b, j0, jb, D, lcol, singular, invL, invU);
+  if (b.piv == 1) diag_block_factor_t<true>(b, j0, jb, D, lcol, singular, invL, invU);
+  else if (b.piv == 2) diag_block_factor_t<false>(b, j0, jb, D, lcol, singular, invL, invU);
+  else diag_block_factor_blocked(b, j0, jb, D, singular, invL, invU);
 }
 
 __global__ __launch_bounds__(256) void diag_lu_kernel(Band b, int j0, int jb, int *__restrict__ singular,
@@ -754,11 +957,220 @@ __device__ __forceinline__ void diag_block_factor_zt(const Band &b, int j0, int 
   }
 }
 
+// diag_block_factor_blocked in complex arithmetic (two tiles, two registers per entry, four real matrix-core products
+// per complex block product): the same panels, stages and barriers
+struct C4 {
+  double4v r, i;
+};
+__device__ __forceinline__ C4 c4_zero() { return C4{{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; }
+// acc += Ablk * T (complex), Ablk = the 16 x 16 block at (r0, c0) of the tiles, masked as in block_times
+__device__ __forceinline__ C4 block_times_z(const double (*Dr)[LDP], const double (*Di)[LDP], int r0, int c0, int mask, C4 T, C4 acc) {
+  const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = 4 * r + kq;
+    double ar = Dr[r0 + i][c0 + k], ai = Di[r0 + i][c0 + k];
+    if (mask == 1) { ar = i > k ? ar : (i == k ? 1.0 : 0.0); ai = i > k ? ai : 0.0; }
+    if (mask == 2) { ar = i <= k ? ar : 0.0; ai = i <= k ? ai : 0.0; }
+    acc.r = mfma16(ar, T.r[r], acc.r);
+    acc.r = mfma16(-ai, T.i[r], acc.r);
+    acc.i = mfma16(ar, T.i[r], acc.i);
+    acc.i = mfma16(ai, T.r[r], acc.i);
+  }
+  return acc;
+}
+__device__ __forceinline__ C4 block_as_b_z(const double (*Dr)[LDP], const double (*Di)[LDP], int r0, int c0, int mask) {
+  const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
+  C4 T;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = 4 * r + kq;
+    double vr = Dr[r0 + k][c0 + j], vi = Di[r0 + k][c0 + j];
+    if (mask == 1) { vr = k > j ? vr : (k == j ? 1.0 : 0.0); vi = k > j ? vi : 0.0; }
+    if (mask == 2) { vr = k <= j ? vr : 0.0; vi = k <= j ? vi : 0.0; }
+    T.r[r] = vr;
+    T.i[r] = vi;
+  }
+  return T;
+}
+
+__device__ __forceinline__ void diag_block_factor_blocked_z(const Band &b, int j0, int jb, double (*Dr)[LDP], double (*Di)[LDP],
+                                                            int *__restrict__ singular, double *__restrict__ invL,
+                                                            double *__restrict__ invU) {
+  constexpr int PB = 16, NP = NB / PB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll 1
+  for (int p = 0; p < NP; ++p) {
+    const int c0 = p * PB;
+    if (wave == 0) {
+      double ar[PB], ai[PB];
+#pragma unroll
+      for (int c = 0; c < PB; ++c) { ar[c] = Dr[lane][c0 + c]; ai[c] = Di[lane][c0 + c]; }
+#pragma unroll
+      for (int kk = 0; kk < PB; ++kk) {
+        const int k = c0 + kk;
+        const double pr = readlane_f64(ar[kk], k), pi = readlane_f64(ai[kk], k);
+        if (pr == 0.0 && pi == 0.0) {
+          if (lane == 0) atomicOr(singular, 1);
+        } else if (lane > k) {
+          double qr, qi;
+          crecip(pr, pi, qr, qi);
+          const double tr_ = ar[kk] * qr - ai[kk] * qi, ti_ = ar[kk] * qi + ai[kk] * qr;
+          ar[kk] = tr_;
+          ai[kk] = ti_;
+        }
+        const double lr = lane > k ? ar[kk] : 0.0, li = lane > k ? ai[kk] : 0.0;
+#pragma unroll
+        for (int c = kk + 1; c < PB; ++c) {
+          const double ur = readlane_f64(ar[c], k), ui = readlane_f64(ai[c], k);
+          ar[c] -= lr * ur - li * ui;
+          ai[c] -= lr * ui + li * ur;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < PB; ++c) { Dr[lane][c0 + c] = ar[c]; Di[lane][c0 + c] = ai[c]; }
+    }
+    __syncthreads();
+    if (p + 1 == NP) break;
+    if (wave == 1) {
+      const int col = c0 + PB + lane;
+      if (col < NB) {
+        double ur[PB], ui[PB];
+#pragma unroll
+        for (int r = 0; r < PB; ++r) { ur[r] = Dr[c0 + r][col]; ui[r] = Di[c0 + r][col]; }
+#pragma unroll
+        for (int k = 0; k + 1 < PB; ++k)
+#pragma unroll
+          for (int r = k + 1; r < PB; ++r) {
+            const double lr = Dr[c0 + r][c0 + k], li = Di[c0 + r][c0 + k];
+            ur[r] -= lr * ur[k] - li * ui[k];
+            ui[r] -= lr * ui[k] + li * ur[k];
+          }
+#pragma unroll
+        for (int r = 1; r < PB; ++r) { Dr[c0 + r][col] = ur[r]; Di[c0 + r][col] = ui[r]; }
+      }
+    }
+    __syncthreads();
+    const int nbk = NP - 1 - p;
+    for (int t = wave; t < nbk * nbk; t += 4) {
+      const int r0 = (p + 1 + t / nbk) * PB, q0 = (p + 1 + t % nbk) * PB;
+      const C4 acc = block_times_z(Dr, Di, r0, c0, 0, block_as_b_z(Dr, Di, c0, q0, 0), c4_zero());
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Dr[r0 + (lane >> 4) + 4 * r][q0 + (lane & 15)] -= acc.r[r];
+        Di[r0 + (lane >> 4) + 4 * r][q0 + (lane & 15)] -= acc.i[r];
+      }
+    }
+    __syncthreads();
+  }
+  for (int c = wave; c < jb; c += 4)
+    if (lane < jb && b.in_band(j0 + lane, j0 + c)) {
+      double *dst = &b.at(j0 + lane, j0 + c);
+      dst[0] = Dr[lane][c];
+      dst[b.zoff] = Di[lane][c];
+    }
+  __syncthreads();
+  {
+    const int d0 = wave * PB, half = lane >> 4, r = lane & 15;
+    double zr[PB], zi[PB], cr[PB], ci[PB];
+#pragma unroll
+    for (int c = 0; c < PB; ++c) {
+      const int col = half == 0 ? c : PB - 1 - c;
+      zr[c] = (col == r) ? 1.0 : 0.0;
+      zi[c] = 0.0;
+      cr[c] = half < 2 ? Dr[d0 + r][d0 + col] : 0.0;
+      ci[c] = half < 2 ? Di[d0 + r][d0 + col] : 0.0;
+    }
+    double qr = 1.0, qi = 0.0;  // 1 / U(r, r) in the U rows
+    if (half == 1) {
+      const double dr = Dr[d0 + r][d0 + r], di = Di[d0 + r][d0 + r];
+      if (dr != 0.0 || di != 0.0) crecip(dr, di, qr, qi);
+      else qr = qi = 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < PB; ++s) {
+      const int ulane = 16 + PB - 1 - s;
+      const double dkr = readlane_f64(qr, ulane), dki = readlane_f64(qi, ulane);
+      const bool below = half == 0 && r > s, above = half == 1 && r < PB - 1 - s, isk = half == 1 && r == PB - 1 - s;
+      const double fr = (below || above) ? cr[s] : 0.0, fi = (below || above) ? ci[s] : 0.0;
+#pragma unroll
+      for (int c = 0; c <= s; ++c) {
+        const double lr = readlane_f64(zr[c], s), li = readlane_f64(zi[c], s);
+        const double wr = readlane_f64(zr[c], ulane), wi = readlane_f64(zi[c], ulane);
+        const double ur = wr * dkr - wi * dki, ui = wr * dki + wi * dkr;
+        const double vr = half == 0 ? lr : ur, vi = half == 0 ? li : ui;
+        zr[c] = isk ? ur : zr[c] - (fr * vr - fi * vi);
+        zi[c] = isk ? ui : zi[c] - (fr * vi + fi * vr);
+      }
+    }
+    if (half == 0) {
+#pragma unroll
+      for (int c = 0; c < PB; ++c)
+        if (c < r) { Dr[d0 + r][d0 + c] = zr[c]; Di[d0 + r][d0 + c] = zi[c]; }
+    } else if (half == 1) {
+#pragma unroll
+      for (int c = 0; c < PB; ++c)
+        if (PB - 1 - c >= r) { Dr[d0 + r][d0 + PB - 1 - c] = zr[c]; Di[d0 + r][d0 + PB - 1 - c] = zi[c]; }
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int st = 0; st < NP - 1; ++st) {
+    const int jl = NP - 2 - st, ju = 1 + st, nout = st + 1;
+    auto output = [&](int t, int &i, int &j) -> C4 {
+      const bool isL = t < nout;
+      j = isL ? jl : ju;
+      i = isL ? jl + 1 + t : t - nout;
+      const C4 Mjj = block_as_b_z(Dr, Di, j * PB, j * PB, isL ? 1 : 2);
+      C4 acc = c4_zero();
+      if (isL) {
+        for (int k = j + 1; k <= i; ++k) {
+          const C4 T = block_times_z(Dr, Di, k * PB, j * PB, 0, Mjj, c4_zero());
+          acc = block_times_z(Dr, Di, i * PB, k * PB, k == i ? 1 : 0, T, acc);
+        }
+      } else {
+        for (int k = i; k < j; ++k) {
+          const C4 T = block_times_z(Dr, Di, k * PB, j * PB, 0, Mjj, c4_zero());
+          acc = block_times_z(Dr, Di, i * PB, k * PB, k == i ? 2 : 0, T, acc);
+        }
+      }
+      return acc;
+    };
+    const bool has0 = wave < 2 * nout, has1 = wave + 4 < 2 * nout;
+    C4 X0 = c4_zero(), X1 = c4_zero();
+    int i0 = 0, q0 = 0, i1 = 0, q1 = 0;
+    if (has0) X0 = output(wave, i0, q0);
+    if (has1) X1 = output(wave + 4, i1, q1);
+    __syncthreads();
+    if (has0)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Dr[i0 * PB + (lane >> 4) + 4 * r][q0 * PB + (lane & 15)] = -X0.r[r];
+        Di[i0 * PB + (lane >> 4) + 4 * r][q0 * PB + (lane & 15)] = -X0.i[r];
+      }
+    if (has1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Dr[i1 * PB + (lane >> 4) + 4 * r][q1 * PB + (lane & 15)] = -X1.r[r];
+        Di[i1 * PB + (lane >> 4) + 4 * r][q1 * PB + (lane & 15)] = -X1.i[r];
+      }
+    __syncthreads();
+  }
+  for (int c = wave; c < NB; c += 4) {
+    const double vr = Dr[lane][c], vi = Di[lane][c];
+    invL[lane + c * NB] = lane > c ? vr : (lane == c ? 1.0 : 0.0);
+    invL[NB * NB + lane + c * NB] = lane > c ? vi : 0.0;
+    invU[lane + c * NB] = lane <= c ? vr : 0.0;
+    invU[NB * NB + lane + c * NB] = lane <= c ? vi : 0.0;
+  }
+}
+
 __device__ __forceinline__ void diag_block_factor_z(const Band &b, int j0, int jb, double (*Dr)[LDP], double (*Di)[LDP],
                                                     double (*lcr)[NB], double (*lci)[NB], int *__restrict__ singular,
                                                     double *__restrict__ invL, double *__restrict__ invU) {
-  if (b.piv) diag_block_factor_zt<true>(b, j0, jb, Dr, Di, lcr, lci, singular, invL, invU);
-  else diag_block_factor_zt<false>(b, j0, jb, Dr, Di, lcr, lci, singular, invL, invU);
+  if (b.piv == 1) diag_block_factor_zt<true>(b, j0, jb, Dr, Di, lcr, lci, singular, invL, invU);
+  else if (b.piv == 2) diag_block_factor_zt<false>(b, j0, jb, Dr, Di, lcr, lci, singular, invL, invU);
+  else diag_block_factor_blocked_z(b, j0, jb, Dr, Di, singular, invL, invU);
 }
 
 // the diagonal block (identity-padded beyond jb) into the two LDS tiles
