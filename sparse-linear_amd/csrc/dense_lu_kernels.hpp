@@ -283,11 +283,16 @@ __device__ __forceinline__ void diag_block_factor_blocked(const Band &b, int j0,
         if (piv == 0.0) {
           if (lane == 0) atomicOr(singular, 1);
         } else if (lane > k) {
-          a[kk] = a[kk] / piv;
+          // multiplier = a / pivot as a times a refined reciprocal (v_rcp_f64 + two Newton steps: the full division
+          // sequence is a dependent chain of its own on the path of every pivot)
+          double rp = __builtin_amdgcn_rcp(piv);
+          rp = __builtin_fma(rp, __builtin_fma(-piv, rp, 1.0), rp);
+          rp = __builtin_fma(rp, __builtin_fma(-piv, rp, 1.0), rp);
+          a[kk] = a[kk] * rp;
         }
         const double l = lane > k ? a[kk] : 0.0;
 #pragma unroll
-        for (int c = kk + 1; c < PB; ++c) a[c] = __builtin_fma(-l, readlane_f64(a[c], k), a[c]);  // (fused: this chain is the step's latency)
+        for (int c = kk + 1; c < PB; ++c) a[c] = __builtin_fma(-l, readlane_f64(a[c], k), a[c]);  // (ds_bpermute instead of v_readlane: slower, 34 -> 37 us)
       }
 #pragma unroll
       for (int c = 0; c < PB; ++c) D[lane][c0 + c] = a[c];
