@@ -901,6 +901,7 @@ int spl_matrix_optimize(void *H) {
     int st = guarded([&]() -> int { DeviceGuard g(m->device); measure_locality(m, nullptr); return SPL_OK; });
     if (st != SPL_OK) return st;
   }
+  if (panels_beat_stream(m)) return spl_matrix_build_panel(H, 0, 0, 0, 0);
   choose_blocking(m, &R, &w, &waves);
   if (R == 0) {
     // no blocking needed.  Regular rows with column locality (banded, stencil): the sliced-ELL

@@ -316,5 +316,6 @@ void choose_panels(const Matrix *m, int *rows_per_panel, int *w);
 void choose_panels(const Matrix *m, int *rows_per_panel, int *w, int *nslices);
 int spmv_kernel_in_use(const Matrix *m);
 bool panels_pay(const Matrix *m);
+bool panels_beat_stream(const Matrix *m);  // order-free mode: the panel image instead of the CSR-stream kernel
 
 }  // namespace spl

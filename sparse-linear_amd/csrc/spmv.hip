@@ -389,6 +389,17 @@ void choose_panels(const Matrix *m, int *rows_per_panel, int *w) { choose_panels
 // The panel image beats the column-blocked one when a 128-byte line of x meets enough entries of a
 // panel for lanes to share requests: entries per line = 16 * nnz/nrows * P / ncols.
 // (measured on C2, P = 19 532: 0.63 per line, 0.99 ms vs 1.19 ms; tools/bench_spmv_variants.py)
+// Order-free sums and rows that share no x lines: the column-sorted panels beat the CSR-stream kernel from the smallest
+// sizes measured on (x = 1 MB: 2.0 vs 1.7 TB/s; 8 MB: 3.0 vs 1.2; 32 MB: 3.2 vs 0.77 — round 3 left everything below
+// 32 MiB of x to the stream kernel: the R-MAT matrix of config C4, x = 8 MB, ran at 1.17 TB/s instead of 3.4)
+bool panels_beat_stream(const Matrix *m) {
+  if (!m->order_free || m->nrows_local < 1 || m->ncols < 1) return false;
+  if (m->ncols * 8 < (1LL << 20)) return false;        // tiny: one launch of anything
+  if (m->new_line_fraction < 0.5) return false;        // rows reuse their neighbours' lines: sliced ELL
+  if (m->nnz < 4 * m->nrows_local) return false;       // too sparse for the panels' chunks
+  return panels_pay(m);
+}
+
 bool panels_pay(const Matrix *m) {
   int P = 0, w = 0, ns = 1;
   choose_panels(m, &P, &w, &ns);
@@ -406,7 +417,11 @@ void choose_blocking(const Matrix *m, int *rows_per_panel, int *w, int *waves) {
   *w = 0;
   *waves = 16;
   const int64_t x_bytes = m->ncols * 8;
-  if (x_bytes <= (32LL << 20)) return;       // x fits the aggregate L2: gathers already hit
+  // (round 4: the limit was 32 MiB, "x fits the aggregate L2" — but a CU gathers through the 4 MiB L2 of its OWN XCD.
+  // Measured on random n x n, 20 draws per row, reference order (tools/probe/panel_threshold_sweep.py): x = 16 MB
+  // stream 0.62 ms, blocked 0.52; 32 MB 1.41 vs 0.53; 8 MB 0.23 vs 0.53 — the blocked image has a floor of ~0.5 ms of
+  // phases, so it pays from about 12 MiB of x on.)
+  if (x_bytes <= (12LL << 20)) return;
   if (m->new_line_fraction < 0.5) return;    // rows reuse their neighbours' lines (banded, stencil)
   if (m->nnz < 4 * m->nrows_local) return;   // too sparse for 64-entry chunks per segment
   const int cus = spmv_cus(m);

@@ -166,3 +166,35 @@ def test_panel_column_slices_exact_on_integers(gpu, pkg, O, monkeypatch):
     xh = rng.integers(-5, 6, n).astype(float)
     y = _run(torch, H, torch.from_numpy(xh).cuda())
     assert np.array_equal(y, O.mulV(A, xh))
+
+
+@pytest.mark.parametrize("n", [150_000, 1 << 19, 2_300_000])
+def test_optimize_picks_the_image_the_sweep_measured_faster(gpu, pkg, O, n):
+    """round 4 (tools/probe/panel_threshold_sweep.py): a CU gathers x through the 4 MiB L2 of its own XCD, not through
+    "the aggregate L2" — with order-free sums the column-sorted panels beat the CSR-stream kernel from 1 MB of x on
+    (round 3 left everything below 32 MiB to the stream kernel: config C4's R-MAT matrix ran at 1.2 instead of 3.4
+    TB/s), and the reference-order blocked image pays from about 12 MiB on.  Whatever is picked: the reference order
+    bit for bit, the free order to 1e-10."""
+    torch = gpu
+    H = pkg.DeviceMatrix.synthetic("random", n, 20)
+    rp, ci, v = H.export_csr()
+    xh = O.gen_vector(n)
+    x = torch.from_numpy(xh).cuda()
+    yo = np.zeros(n)
+    O.csr_gaxpy32(rp.astype(np.int32), ci, v, xh, yo)
+    H.optimize()  # reference order
+    assert H.spmv_kernel() == (8 if n * 8 > (12 << 20) else 0)
+    assert np.array_equal(_run(torch, H, x), yo)
+    H.free()
+    H = pkg.DeviceMatrix.synthetic("random", n, 20)
+    H.set_spmv_order(H.ORDER_FREE)
+    H.optimize()
+    assert H.spmv_kernel() == 16
+    assert O.count_not_close(_run(torch, H, x), yo, 1e-10) == 0
+    H.free()
+    # rows that share x lines keep the sliced ELL image in either order
+    B = pkg.DeviceMatrix.synthetic("banded", max(n, 400_000), 20)
+    B.set_spmv_order(B.ORDER_FREE)
+    B.optimize()
+    assert B.spmv_kernel() == 15
+    B.free()

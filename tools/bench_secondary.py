@@ -334,56 +334,71 @@ def lu_c5(pkg, torch, m=100, cpu_sample=0):
 
 
 def spmv_other(pkg, torch, which, steps=20):
-    """the SpMV kernel on C5's matrix (`poisson3d:<m>`) or C4's (`rmat:<scale>`): y = A x, device-resident, reference
-    order; HIP events around `steps` launches; the whole y against the oracle's CSR loop on the exported arrays"""
+    """the SpMV kernel on C5's matrix (`poisson3d:<m>`) or C4's (`rmat:<scale>`): y = A x, device-resident; HIP events
+    around `steps` launches; the whole y against the oracle's CSR loop on the exported arrays.  Both sum orders: the
+    reference's (bit-identical) and, as for the headline, the order-free one (1e-10 contract: column-sorted panels where
+    rows share no x lines); `value` is the better of the two, each is reported."""
     import numpy as np
     from oracle import oracle as O
     ffi = pkg._ffi
     s = torch.cuda.current_stream()
     kind, arg = which.split(":")
-    if kind == "poisson3d":
-        m = int(arg)
-        H = pkg.DeviceMatrix.synthetic("poisson3d", m)
-        name = "3-D 7-point Poisson %d^3 (config C5's matrix)" % m
-    else:
-        H = pkg.DeviceMatrix.rmat(int(arg), 32, (0.25, 0.25, 0.25))
-        name = "R-MAT scale %s, edge factor 32, Erdos-Renyi quadrants (config C4's matrix)" % arg
-    H.optimize()
-    inf = H.info()
-    n, nnz = inf["nrows_local"], inf["nnz"]
-    x = torch.empty(n, dtype=torch.float64, device="cuda")
-    ffi.check("vec", ffi.lib().spl_vector_synthetic_dev(0xBEEF, 0, n, x.data_ptr(), s.cuda_stream))
-    y = torch.zeros(n, dtype=torch.float64, device="cuda")
-    for _ in range(3):
-        H.spmv_dev(x.data_ptr(), y.data_ptr(), stream=s.cuda_stream)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record(s)
-    for _ in range(steps):
-        H.spmv_dev(x.data_ptr(), y.data_ptr(), stream=s.cuda_stream)
-    e1.record(s)
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / steps
-    B = 12 * nnz + 4 * (n + 1) + 8 * n + 8 * n
-    kcode = H.spmv_kernel()
-    kernel = {8: "spmv_blocked_lockstep", 15: "spmv_sell", 16: "spmv_panel"}.get(kcode, "spmv_stream")
-    rp, ci, v = H.export_csr()
-    yo = np.zeros(n)
-    t = time.perf_counter()
-    O.csr_gaxpy32(rp.astype(np.int32), ci, v, x.cpu().numpy(), yo)
-    t_cpu = time.perf_counter() - t
-    out = {"workload": "SpMV y = A x fp64, int32 indices: %s, n=%d nnz=%d" % (name, n, nnz),
-           "value": round(B / ms / 1e6, 1), "unit": "GB/s", "ms_per_step": round(ms, 4), "steps": steps, "sum_order": "reference",
-           "roofline": {"bound": "hbm", "achieved": round(B / ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(B / ms / 1e6 / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": kernel,
-                        "kernel_ms": round(ms, 4), "bytes_per_launch": B},
-           "parity": {"rows_checked": int(n), "bit_identical": bool(np.array_equal(y.cpu().numpy(), yo)),
-                      "how": "whole y against the oracle's CSR loop (reference order) on the exported arrays"},
-           "cpu_baseline": {"value": round(B / t_cpu / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
-                            "sample": "the same matrix, one serial CSR pass of the oracle, %.3f s" % t_cpu}}
-    H.free()
-    del x, y
-    return out
+
+    def make():
+        if kind == "poisson3d":
+            return pkg.DeviceMatrix.synthetic("poisson3d", int(arg)), "3-D 7-point Poisson %s^3 (config C5's matrix)" % arg
+        return (pkg.DeviceMatrix.rmat(int(arg), 32, (0.25, 0.25, 0.25)),
+                "R-MAT scale %s, edge factor 32, Erdos-Renyi quadrants (config C4's matrix)" % arg)
+
+    runs, yo, t_cpu, name, n, nnz, B = {}, None, 0.0, "", 0, 0, 0
+    for order in ("reference", "free"):
+        H, name = make()
+        if order == "free":
+            H.set_spmv_order(H.ORDER_FREE)
+        H.optimize()
+        inf = H.info()
+        n, nnz = inf["nrows_local"], inf["nnz"]
+        x = torch.empty(n, dtype=torch.float64, device="cuda")
+        ffi.check("vec", ffi.lib().spl_vector_synthetic_dev(0xBEEF, 0, n, x.data_ptr(), s.cuda_stream))
+        y = torch.zeros(n, dtype=torch.float64, device="cuda")
+        for _ in range(3):
+            H.spmv_dev(x.data_ptr(), y.data_ptr(), stream=s.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(s)
+        for _ in range(steps):
+            H.spmv_dev(x.data_ptr(), y.data_ptr(), stream=s.cuda_stream)
+        e1.record(s)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        B = 12 * nnz + 4 * (n + 1) + 8 * n + 8 * n
+        kcode = H.spmv_kernel()
+        kernel = {8: "spmv_blocked_lockstep", 15: "spmv_sell", 16: "spmv_panel"}.get(kcode, "spmv_stream")
+        if yo is None:
+            rp, ci, v = H.export_csr()
+            yo = np.zeros(n)
+            t = time.perf_counter()
+            O.csr_gaxpy32(rp.astype(np.int32), ci, v, x.cpu().numpy(), yo)
+            t_cpu = time.perf_counter() - t
+        yg = y.cpu().numpy()
+        runs[order] = {"ms_per_step": round(ms, 4), "GB_per_s": round(B / ms / 1e6, 1), "frac": round(B / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                       "kernel": kernel, "bit_identical": bool(np.array_equal(yg, yo)),
+                       "not_close_1e-10": int(O.count_not_close(yg, yo, 1e-10))}
+        H.free()
+        del x, y
+    best = min(runs, key=lambda k: runs[k]["ms_per_step"])
+    r = runs[best]
+    return {"workload": "SpMV y = A x fp64, int32 indices: %s, n=%d nnz=%d" % (name, n, nnz),
+            "value": r["GB_per_s"], "unit": "GB/s", "ms_per_step": r["ms_per_step"], "steps": steps, "sum_order": best,
+            "roofline": {"bound": "hbm", "achieved": r["GB_per_s"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": r["frac"],
+                         "traffic": None, "kernel": r["kernel"], "kernel_ms": r["ms_per_step"], "bytes_per_launch": B},
+            "by_sum_order": runs,
+            "parity": {"rows_checked": int(n), "bit_identical": runs["reference"]["bit_identical"],
+                       "order_free_not_close_1e-10": runs["free"]["not_close_1e-10"],
+                       "how": "whole y against the oracle's CSR loop (reference order) on the exported arrays: the reference-order "
+                              "kernel bit for bit, the order-free one to 1e-10 relative"},
+            "cpu_baseline": {"value": round(B / t_cpu / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+                             "sample": "the same matrix, one serial CSR pass of the oracle, %.3f s" % t_cpu}}
 
 
 def run_item(item, n=10_000_000, draws=20, steps=20):
