@@ -49,7 +49,17 @@ struct Band {
   }
   __device__ __forceinline__ double get(int i, int j) const { return in_band(i, j) ? at(i, j) : 0.0; }
 };
-inline Band band_view(double *AB, int n, int kl, int ku, int ldab) { return Band{AB, n, kl, ku, ldab, ku}; }
+// Band::piv of a factorisation WITHOUT interchanges: 0 (diagonal blocks by panels of 16 on the matrix cores, round 4), or 2
+// with SPL_LU_DIAG=plain in the environment (the unblocked form of rounds 1 - 3: ablation)
+inline int diag_form_without_interchanges() {
+  const char *e = getenv("SPL_LU_DIAG");
+  return (e && e[0] == 'p') ? 2 : 0;
+}
+inline Band band_view(double *AB, int n, int kl, int ku, int ldab) {
+  Band b{AB, n, kl, ku, ldab, ku};
+  b.piv = diag_form_without_interchanges();
+  return b;
+}
 inline Band dense_view(double *F, int n, int ld, int sym = 0, size_t zoff = 0, int piv = 0, const double *rscale = nullptr) {
   return Band{F, n, n, n, ld + 1, 0, sym, zoff, piv, rscale};
 }

@@ -1209,7 +1209,7 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
                     D.bidx.get(),  D.rel.get(),  D.depth.get(), D.ldp.get(), D.ldu.get(),    D.bptr.get(),
                     F.d_foff.get(), D.ioff.get(), D.woff.get(), D.roff.get(), D.poff.get(),  D.uoff.get(),
                     {region0.get(), region1.get()}, F.arena.get(), F.d_cboff.get(), cutbuf.get(), symmetric ? 1 : 0, ZM,
-                    pivot ? 1 : 0, pivot ? d_rscale : nullptr};
+                    pivot ? 1 : diag_form_without_interchanges(), pivot ? d_rscale : nullptr};
   F.level_lists.resize((size_t)nd);
   F.small_lists.resize((size_t)nd);
   F.small_counts.assign((size_t)nd, 0);
@@ -1509,7 +1509,7 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
         if (T.np[(size_t)f] == 0 || T.fs(f) <= mid_limit) continue;
         const size_t plane = Z ? (size_t)(((int64_t)T.ld[(size_t)f] * std::max(T.fs(f), 1) + 15) / 16 * 16) : 0;
         const Band b = dense_view(region_of(d) + (size_t)ZM * (size_t)plan.foff[(size_t)f], T.fs(f), T.ld[(size_t)f],
-                                  symmetric ? 1 : 0, plane, pivot ? 1 : 0,
+                                  symmetric ? 1 : 0, plane, pivot ? 1 : diag_form_without_interchanges(),
                                   pivot && d_rscale ? d_rscale + T.p0[(size_t)f] : nullptr);
         const int lane = turn++ % kStreams;
         factor_loop<Z>(b, T.np[(size_t)f], F.invs.get() + (size_t)ZM * (size_t)T.ioff[(size_t)f], singular.get(), side[lane],

@@ -287,6 +287,31 @@ def _grid_matrix(pkg, O, kind, m):
     return n, pkg.Matrix(n, n, rp, ci, v)
 
 
+@pytest.mark.parametrize("kind,m", [("3d", 20), ("2d", 90)])
+def test_blocked_diagonal_blocks_agree_with_the_unblocked_form(gpu, pkg, O, kind, m, monkeypatch):
+    """round 4: the 64 x 64 diagonal blocks of the fronts (and of the band) are factored by panels of 16 and inverted by
+    the block recurrence on the matrix cores; SPL_LU_DIAG=plain keeps the unblocked form of rounds 1 - 3.  Different
+    associations of the same sums: the solutions agree to rounding level, each with a backward error below eps."""
+    n, A = _grid_matrix(pkg, O, kind, m)
+    S = csc_tuple_to_scipy(mat_to_tuple(A))
+    U = pkg.umfpack
+    xs = np.random.default_rng(m).uniform(0.5, 1.5, n)
+    b = np.asarray(S @ xs).ravel()
+    sols = {}
+    for method in ("mf", "band"):
+        monkeypatch.setenv("SPL_LU_METHOD", method)
+        for form in ("blocked", "plain"):
+            if form == "plain":
+                monkeypatch.setenv("SPL_LU_DIAG", "plain")
+            else:
+                monkeypatch.delenv("SPL_LU_DIAG", raising=False)
+            fact = U.factor(A, U.analyze(A))
+            sols[method, form] = U.linearSolve_(fact, U.UmfpackNormal, A, b)
+            assert fact.solve_report["backward_error"] < 2.3e-16
+        assert np.max(np.abs(sols[method, "blocked"] - sols[method, "plain"]) / np.abs(sols[method, "plain"])) < 1e-12
+    assert np.max(np.abs(sols["mf", "blocked"] - xs) / xs) < 1e-11
+
+
 @pytest.mark.parametrize("unsym", [False, True])
 def test_pipelined_steps_and_split_boundary_product_give_the_same_solution(gpu, pkg, O, unsym, monkeypatch):
     """round 4, csrc/multifrontal.hip: (1) the super-block steps of the large fronts as a software pipeline over launches
