@@ -286,21 +286,24 @@ __device__ __forceinline__ void diag_block_factor_blocked(const Band &b, int j0,
       double a[PB];
 #pragma unroll
       for (int c = 0; c < PB; ++c) a[c] = D[lane][c0 + c];
+      bool zero_pivot = false;
 #pragma unroll
       for (int kk = 0; kk < PB; ++kk) {
+        // straight-line code: with a branch on the (uniform) zero test the compiler copies the sixteen registers of the
+        // row around every pivot; a zero pivot divides by one instead (exact) and is reported after the panel
         const int k = c0 + kk;
         const double piv = readlane_f64(a[kk], k);
-        if (piv == 0.0) {
-          if (lane == 0) atomicOr(singular, 1);
-        } else if (lane > k) {
-          // (a true division: a refined reciprocal — v_rcp_f64 + two Newton steps — saves 0.7 of 34 us and costs half an
-          // ulp per multiplier, which a static-pivoting case at the edge of what refinement recovers did not forgive)
-          a[kk] = a[kk] / piv;
-        }
-        const double l = lane > k ? a[kk] : 0.0;
+        const bool zero = piv == 0.0;
+        zero_pivot |= zero;
+        // (a true division: a refined reciprocal — v_rcp_f64 + two Newton steps — saves 0.7 of 34 us and costs half an
+        // ulp per multiplier, which a static-pivoting case at the edge of what refinement recovers did not forgive)
+        const double q = a[kk] / (zero ? 1.0 : piv);
+        const double l = lane > k ? q : 0.0;
+        a[kk] = lane > k ? q : a[kk];
 #pragma unroll
         for (int c = kk + 1; c < PB; ++c) a[c] = __builtin_fma(-l, readlane_f64(a[c], k), a[c]);  // (ds_bpermute instead of v_readlane: slower, 34 -> 37 us)
       }
+      if (zero_pivot && lane == 0) atomicOr(singular, 1);
 #pragma unroll
       for (int c = 0; c < PB; ++c) D[lane][c0 + c] = a[c];
     }
@@ -795,6 +798,15 @@ __device__ __forceinline__ void crecip(double pr, double pi, double &qr, double 
   }
 }
 
+// the same values without a branch (both quotients are formed and one is selected)
+__device__ __forceinline__ void crecip_straight(double pr, double pi, double &qr, double &qi) {
+  const bool wide = fabs(pr) >= fabs(pi);
+  const double num = wide ? pi : pr, den = wide ? pr : pi;
+  const double r = num / den, d = den + num * r, u = 1.0 / d, v = r / d;
+  qr = wide ? u : v;
+  qi = wide ? -v : -u;
+}
+
 // diag_block_factor in complex arithmetic: same register layout (lane = row, wave w owns the columns c = w mod 4),
 // same pivot loop, two registers per entry
 template <bool PIV>
@@ -1018,19 +1030,20 @@ __device__ __forceinline__ void diag_block_factor_blocked_z(const Band &b, int j
       double ar[PB], ai[PB];
 #pragma unroll
       for (int c = 0; c < PB; ++c) { ar[c] = Dr[lane][c0 + c]; ai[c] = Di[lane][c0 + c]; }
+      bool zero_pivot = false;
 #pragma unroll
       for (int kk = 0; kk < PB; ++kk) {
         const int k = c0 + kk;
+        // straight-line code, as in the real form: a zero pivot is reported after the panel and leaves its column as it is
         const double pr = readlane_f64(ar[kk], k), pi = readlane_f64(ai[kk], k);
-        if (pr == 0.0 && pi == 0.0) {
-          if (lane == 0) atomicOr(singular, 1);
-        } else if (lane > k) {
-          double qr, qi;
-          crecip(pr, pi, qr, qi);
-          const double tr_ = ar[kk] * qr - ai[kk] * qi, ti_ = ar[kk] * qi + ai[kk] * qr;
-          ar[kk] = tr_;
-          ai[kk] = ti_;
-        }
+        const bool zero = pr == 0.0 && pi == 0.0;
+        zero_pivot |= zero;
+        double qr, qi;
+        crecip_straight(zero ? 1.0 : pr, pi, qr, qi);
+        const bool below = lane > k && !zero;
+        const double tr_ = ar[kk] * qr - ai[kk] * qi, ti_ = ar[kk] * qi + ai[kk] * qr;
+        ar[kk] = below ? tr_ : ar[kk];
+        ai[kk] = below ? ti_ : ai[kk];
         const double lr = lane > k ? ar[kk] : 0.0, li = lane > k ? ai[kk] : 0.0;
 #pragma unroll
         for (int c = kk + 1; c < PB; ++c) {
@@ -1039,6 +1052,7 @@ __device__ __forceinline__ void diag_block_factor_blocked_z(const Band &b, int j
           ai[c] -= lr * ui + li * ur;
         }
       }
+      if (zero_pivot && lane == 0) atomicOr(singular, 1);
 #pragma unroll
       for (int c = 0; c < PB; ++c) { Dr[lane][c0 + c] = ar[c]; Di[lane][c0 + c] = ai[c]; }
     }

@@ -1024,9 +1024,10 @@ struct Factors {
     std::lock_guard<std::mutex> lk(mu);
     std::unique_ptr<hipStream_t[]> &set = sets[std::make_pair(device, std::this_thread::get_id())];
     if (!set) {
-      // kStreams for the fronts, kStreams beside them for the look-ahead tiles of their large windows
-      std::unique_ptr<hipStream_t[]> fresh(new hipStream_t[2 * kStreams]);
-      for (int i = 0; i < 2 * kStreams; ++i) SPL_HIP(hipStreamCreateWithFlags(&fresh[i], hipStreamNonBlocking));
+      // kStreams for the fronts, kStreams beside them for the look-ahead tiles of their large windows, one for the
+      // assembly work that runs beside the factorisation of a level (mf_factor_t)
+      std::unique_ptr<hipStream_t[]> fresh(new hipStream_t[2 * kStreams + 1]);
+      for (int i = 0; i < 2 * kStreams + 1; ++i) SPL_HIP(hipStreamCreateWithFlags(&fresh[i], hipStreamNonBlocking));
       set = std::move(fresh);
     }
     side = set.get();
@@ -1386,40 +1387,65 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
     begin = (int)(std::lower_bound(L.begin(), L.end(), lo) - L.begin());
     end = (int)(std::upper_bound(L.begin(), L.end(), hi) - L.begin());
   };
-  auto compact_fronts = [&](int d, int lo, int hi) {  // factor panels of the fronts lo..hi of level d -> arena
+  auto compact_fronts = [&](int d, int lo, int hi, hipStream_t q) {  // factor panels of the fronts lo..hi of level d -> arena
     int b0, b1;
     range_of(T.by_depth[(size_t)d], lo, hi, b0, b1);
     if (b1 == b0) return;
     const int64_t tp = F.h_ptile[(size_t)d][(size_t)b1] - F.h_ptile[(size_t)d][(size_t)b0];
     const int64_t tu = F.h_utile[(size_t)d][(size_t)b1] - F.h_utile[(size_t)d][(size_t)b0];
     if (tp > 0)
-      hipLaunchKernelGGL(compact_kernel<Z>, dim3((unsigned)tp), dim3(256), 0, s, F.level_lists[(size_t)d].get() + b0,
+      hipLaunchKernelGGL(compact_kernel<Z>, dim3((unsigned)tp), dim3(256), 0, q, F.level_lists[(size_t)d].get() + b0,
                          F.ptile[(size_t)d].get() + b0, b1 - b0, F.view, 0);
     if (tu > 0)
-      hipLaunchKernelGGL(compact_kernel<Z>, dim3((unsigned)tu), dim3(256), 0, s, F.level_lists[(size_t)d].get() + b0,
+      hipLaunchKernelGGL(compact_kernel<Z>, dim3((unsigned)tu), dim3(256), 0, q, F.level_lists[(size_t)d].get() + b0,
                          F.utile[(size_t)d].get() + b0, b1 - b0, F.view, 1);
+  };
+  // Assembly beside the factorisation (round 4): the fronts of a level live in the region the level two below it
+  // used, which is free as soon as the level between them has taken its children's Schur complements.  So while
+  // level d is factored, stream `aux` moves the panels of level d + 1 to the arena, then zeroes that region and
+  // scatters the entries of A of level d - 1 into it: of the three parts of an assembly only the extend-add stays on
+  // the chain of the levels (at 100^3: 12 of 27 ms).  SPL_MF_OVERLAP=0: everything on the main stream, as before.
+  const bool overlap = !(getenv("SPL_MF_OVERLAP") && atoi(getenv("SPL_MF_OVERLAP")) == 0);
+  hipStream_t aux = side[2 * kStreams];
+  struct Events {
+    hipEvent_t taken = nullptr, prepared = nullptr;  // extend-add of a level queued; region of the next level ready
+    ~Events() {
+      if (taken) (void)hipEventDestroy(taken);
+      if (prepared) (void)hipEventDestroy(prepared);
+    }
+  } ev;
+  SPL_HIP(hipEventCreateWithFlags(&ev.taken, hipEventDisableTiming));
+  SPL_HIP(hipEventCreateWithFlags(&ev.prepared, hipEventDisableTiming));
+  // the fronts lo..hi of level d start from zero in their region and receive their entries of A
+  auto prepare_level = [&](int d, int lo, int hi, hipStream_t q) -> int64_t {
+    int b0, b1;
+    range_of(T.by_depth[(size_t)d], lo, hi, b0, b1);
+    if (b1 == b0) return 0;
+    int64_t extent = 0;
+    for (int i = b0; i < b1; ++i) {
+      const int f = T.by_depth[(size_t)d][(size_t)i];
+      extent = std::max(extent, plan.foff[(size_t)f] + ((int64_t)T.ld[(size_t)f] * std::max(T.fs(f), 1) + 15) / 16 * 16);
+    }
+    SPL_HIP(hipMemsetAsync(region_of(d), 0, (size_t)ZM * (size_t)extent * sizeof(double), q));
+    const int64_t groups = F.h_atile[(size_t)d][(size_t)b1] - F.h_atile[(size_t)d][(size_t)b0];
+    if (groups > 0)
+      hipLaunchKernelGGL(assemble_kernel<Z>, dim3((unsigned)groups), dim3(256), 0, q, F.level_lists[(size_t)d].get() + b0,
+                         F.atile[(size_t)d].get() + b0, b1 - b0, F.view, d_perm, d_inv, d_Ap, d_Ai, d_Ax, d_Rp, d_Rj, d_Rx);
+    return extent;
   };
   // levels dbot .. dtop (bottom-up) of the fronts with ids lo..hi.  children_saved: the children of
   // level plan.cut - 1 are subtree roots, already compacted, their Schur complements in the cut buffer
   auto process = [&](int lo, int hi, int dtop, int dbot, bool children_saved) {
+    int prepared_level = -1;  // the level whose region stream `aux` has been told to prepare
+    int64_t prepared_extent = 0;
     for (int d = dbot; d >= dtop; --d) {
       int b0, b1;
       range_of(T.by_depth[(size_t)d], lo, hi, b0, b1);
       if (b1 == b0) continue;
       // this level's fronts start from zero in their region, receive their entries of A ...
-      int64_t extent = 0;
-      for (int i = b0; i < b1; ++i) {
-        const int f = T.by_depth[(size_t)d][(size_t)i];
-        extent = std::max(extent, plan.foff[(size_t)f] + ((int64_t)T.ld[(size_t)f] * std::max(T.fs(f), 1) + 15) / 16 * 16);
-      }
-      SPL_HIP(hipMemsetAsync(region_of(d), 0, (size_t)ZM * (size_t)extent * sizeof(double), s));
-      {
-        const int64_t groups = F.h_atile[(size_t)d][(size_t)b1] - F.h_atile[(size_t)d][(size_t)b0];
-        if (groups > 0)
-          hipLaunchKernelGGL(assemble_kernel<Z>, dim3((unsigned)groups), dim3(256), 0, s,
-                             F.level_lists[(size_t)d].get() + b0, F.atile[(size_t)d].get() + b0, b1 - b0, F.view, d_perm,
-                             d_inv, d_Ap, d_Ai, d_Ax, d_Rp, d_Rj, d_Rx);
-      }
+      int64_t extent = prepared_extent;
+      if (prepared_level == d) SPL_HIP(hipStreamWaitEvent(s, ev.prepared, 0));
+      else extent = prepare_level(d, lo, hi, s);
       // ... and the Schur complements of the children, one child slot after the other (two children
       // of a parent may touch the same entry: a fixed order keeps the sums reproducible)
       if (d + 1 < nd) {
@@ -1435,14 +1461,36 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
         }
         // the children are done with: keep their panels, their region is free again (subtree
         // roots were compacted when their subtree finished)
-        if (!(children_saved && d + 1 == plan.cut)) compact_fronts(d + 1, lo, hi);
+        if (overlap) {
+          SPL_HIP(hipEventRecord(ev.taken, s));  // (everything level d + 1 queued on s lies before it as well)
+          SPL_HIP(hipStreamWaitEvent(aux, ev.taken, 0));
+        }
+        if (!(children_saved && d + 1 == plan.cut)) compact_fronts(d + 1, lo, hi, overlap ? aux : s);
+      }
+      if (overlap && d + 1 < nd && d - 1 >= dtop) {
+        prepared_extent = prepare_level(d - 1, lo, hi, aux);
+        SPL_HIP(hipEventRecord(ev.prepared, aux));
+        prepared_level = d - 1;
       }
       // small fronts: one launch, one workgroup each; large fronts: the multi-launch blocked
       // factorisation, independent fronts spread over side streams
       SPL_HIP(hipStreamSynchronize(s));
       if (timing) {
-        char what[64];
-        snprintf(what, sizeof what, "level %d: assembly", d);
+        double ea = 0.0, cp = 0.0;  // entries the extend-add moves, entries of the children's panels
+        if (d + 1 < nd)
+          for (int sl = 0; sl < 2; ++sl) {
+            int c0, c1;
+            range_of(F.h_child[sl][(size_t)d], lo, hi, c0, c1);
+            for (int i = c0; i < c1; ++i) {
+              const int c = F.h_child[sl][(size_t)d][(size_t)i];
+              const double q = T.nb[(size_t)c], pp = T.np[(size_t)c];
+              ea += symmetric ? q * (q + 1) / 2 : q * q;
+              cp += pp * (pp + 2 * q);
+            }
+          }
+        char what[96];
+        snprintf(what, sizeof what, "level %d: assembly (zero %.0f, extend-add %.0f, panels %.0f MB)", d, ZM * extent * 8e-6,
+                 ZM * ea * 24e-6, ZM * cp * 16e-6);
         lap(what);
       }
       int s0, s1;
@@ -1531,21 +1579,22 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
         lap(what);
       }
     }
+    if (overlap) SPL_HIP(hipStreamSynchronize(aux));  // the panels of the last level but one are in the arena
   };
   if (plan.cut == 0) {
     process(0, nf - 1, 0, nd - 1, false);
-    compact_fronts(0, 0, nf - 1);
+    compact_fronts(0, 0, nf - 1, s);
   } else {
     for (int r : plan.roots) {  // one subtree after the other; its root's Schur complement is saved
       process(plan.first[(size_t)r], r, plan.cut, nd - 1, false);
-      compact_fronts(plan.cut, r, r);
+      compact_fronts(plan.cut, r, r, s);
       const int nb = T.nb[(size_t)r];
       const int64_t ntile = (int64_t)((nb + 63) / 64) * ((nb + 3) / 4);
       if (ntile > 0) hipLaunchKernelGGL(save_cb_kernel<Z>, dim3((unsigned)ntile), dim3(256), 0, s, r, F.view);
       SPL_HIP(hipStreamSynchronize(s));
     }
     process(0, nf - 1, 0, plan.cut - 1, true);  // the top of the tree
-    compact_fronts(0, 0, nf - 1);
+    compact_fronts(0, 0, nf - 1, s);
   }
   SPL_HIP(hipStreamSynchronize(s));
   lap("levels");

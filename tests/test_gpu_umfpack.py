@@ -355,6 +355,32 @@ def test_pipelined_steps_and_split_boundary_product_give_the_same_solution(gpu, 
         assert np.max(np.abs(x - xs) / xs) < 1e-12
 
 
+@pytest.mark.parametrize("cut", [None, "2"])
+@pytest.mark.parametrize("kind,m", [("3d", 26), ("2d", 150)])
+def test_assembly_beside_the_factorisation_gives_the_same_factors(gpu, pkg, O, kind, m, cut, monkeypatch):
+    """round 4, csrc/multifrontal.hip: while a level is factored a second stream moves the panels of the level below to
+    the arena, zeroes the freed region and scatters the entries of A of the level above into it; only the extend-add
+    stays between the levels.  The same kernels on the same data in another interleaving: the solution has the same bits
+    as with everything on one stream (SPL_MF_OVERLAP=0), also when the tree is cut into subtrees (SPL_MF_CUT), with the
+    size limits lowered so that a small tree runs every class of front."""
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    monkeypatch.setenv("SPL_MF_SMALL", "64")
+    monkeypatch.setenv("SPL_MF_MIDMAX", "512")
+    if cut:
+        monkeypatch.setenv("SPL_MF_CUT", cut)
+    n, A = _grid_matrix(pkg, O, kind, m)
+    S = csc_tuple_to_scipy(mat_to_tuple(A))
+    U = pkg.umfpack
+    xs = np.random.default_rng(m).uniform(0.5, 1.5, n)
+    b = np.asarray(S @ xs).ravel()
+    an = U.analyze(A)
+    x = [U.linearSolve_(U.factor(A, an), U.UmfpackNormal, A, b) for _ in range(2)]
+    monkeypatch.setenv("SPL_MF_OVERLAP", "0")
+    x_one_stream = U.linearSolve_(U.factor(A, an), U.UmfpackNormal, A, b)
+    assert np.array_equal(x[0], x_one_stream) and np.array_equal(x[1], x_one_stream)
+    assert np.max(np.abs(x[0] - xs) / xs) < 1e-11
+
+
 @pytest.mark.parametrize("limits", ["default", "small"])
 @pytest.mark.parametrize("kind,m", [("2d", 7), ("2d", 45), ("2d", 130), ("3d", 9), ("3d", 22)])
 def test_multifrontal_matches_band_and_oracle(gpu, pkg, O, kind, m, limits, monkeypatch):
