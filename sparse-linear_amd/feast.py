@@ -12,6 +12,7 @@ The contour quadrature and the Rayleigh-Ritz step (FEAST's published algorithm, 
 restated here in numpy on small dense matrices; every sparse operation goes through the C ABI.
 Interface: `eigSH m0 (emin, emax) A`, `geigSH m0 (emin, emax) A B` (Feast.hs:53-72).
 """
+import os
 import threading
 
 import numpy as np
@@ -70,7 +71,6 @@ def _contour_pool():
     side is capped by what a factorisation holds, see geigSH_ —; 1 = in the calling thread): created once — the library
     keeps a set of streams per host thread that ever factored"""
     global _pool
-    import os
     k = int(os.environ.get("SPL_FEAST_THREADS", "4"))
     if k <= 1:
         return None
@@ -154,12 +154,21 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
     pool = _contour_pool()
     held = [0.0]  # device bytes of the largest factorisation seen (one list cell: written from the worker threads)
     gate = [None]  # how many contour points may be in flight (set after the first one has shown what it holds)
+    # The contour points do not move between iterations, so neither do the factors of ze*B - A.  The reference keeps one
+    # factorisation at a time (Feast.hs:214-218: `put (Just (mat, fact))`, a refactorisation per point and iteration —
+    # what a CPU's memory allows); 288 GB of HBM hold all eight of a mid-sized problem (80^3: 8 x 10 GB), so the
+    # factors of a point stay resident for the later iterations as long as room remains for the work in flight
+    # (libfeast's fpm(10) "store factorisations").  Same factors, same bits.  SPL_FEAST_KEEP_FACTORS=0: the reference's way.
+    keep_factors = os.environ.get("SPL_FEAST_KEEP_FACTORS", "1") != "0"
+    kept = {}          # contour point -> (mat, fact)
+    kept_lock = threading.Lock()
+    counts = {"factorisations": 0, "factors_reused": 0}
     for it in range(20):
         t0 = time.perf_counter()
         BY = _apply(opB, Y)                                                    # ijob 40
         rhs = BY if BY.dtype == torch.complex128 else BY.to(torch.complex128)
         t0 = tick("spmv", t0)
-        def contour_point(th):
+        def contour_point(i):
             # One contour point: the factorisation of ze*B - A and the solves with it.  Runs on a worker thread: the
             # points of an iteration are independent, and one mid-sized factorisation is a chain of short launches
             # that leaves most of the device idle — the library's LU entry points work on the calling thread's own
@@ -167,10 +176,10 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
             torch.cuda.set_device(dev)
             if pool is not None and gate[0] is not None:
                 with gate[0]:
-                    return contour_point_in_flight(th)
-            return contour_point_in_flight(th)
+                    return contour_point_in_flight(i)
+            return contour_point_in_flight(i)
 
-        def contour_point_in_flight(th):
+        def contour_point_in_flight(i):
             if pool is not None:
                 # torch's own work of this point (allocations, the weighted sums) on a stream of this thread: on the
                 # legacy default stream every such operation is a barrier for the LU streams of ALL threads.  The
@@ -185,21 +194,39 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
                     streams[key] = torch.cuda.Stream(device=dev)
                 with torch.cuda.stream(streams[key]):
                     torch.cuda.set_device(dev)
-                    return contour_point_on_this_stream(th)
-            return contour_point_on_this_stream(th)
+                    return contour_point_on_this_stream(i)
+            return contour_point_on_this_stream(i)
 
-        def contour_point_on_this_stream(th):
+        def contour_point_on_this_stream(i):
             t = time.perf_counter()
+            th = thetas[i]
             ze = c + r * np.exp(1j * th)
             w = complex(r * np.exp(1j * th) / ne)
-            mat = type(shifted)(n, n, shifted.pointers, shifted.indices, ze * b_u - a_u)   # ijob 10: ze*B - A
-            kept = getattr(shifted, "_narrowed", None)  # the same pattern arrays: their int32 copies serve every point
-            if kept is not None and kept[0] is mat.pointers and kept[1] is mat.indices:
-                mat._narrowed = kept
-            t1 = time.perf_counter()
-            fact = U.factor(mat, analysis)                                     #          numeric LU, same analysis
-            held[0] = max(held[0], float(fact.stats["device_bytes"]))
-            t2 = time.perf_counter()
+            with kept_lock:
+                resident = kept.get(i)
+            if resident is not None:
+                mat, fact = resident
+                t1 = t2 = time.perf_counter()
+                with kept_lock:
+                    counts["factors_reused"] += 1
+            else:
+                mat = type(shifted)(n, n, shifted.pointers, shifted.indices, ze * b_u - a_u)   # ijob 10: ze*B - A
+                narrowed = getattr(shifted, "_narrowed", None)  # the same pattern arrays: their int32 copies serve every point
+                if narrowed is not None and narrowed[0] is mat.pointers and narrowed[1] is mat.indices:
+                    mat._narrowed = narrowed
+                t1 = time.perf_counter()
+                fact = U.factor(mat, analysis)                                 #          numeric LU, same analysis
+                held[0] = max(held[0], float(fact.stats["device_bytes"]))
+                t2 = time.perf_counter()
+                with kept_lock:
+                    counts["factorisations"] += 1
+                    if keep_factors:
+                        # room for the points in flight (panels + transient fronts + the work of their solves: taken
+                        # as twice the resident bytes each) must remain after this one stays
+                        free_bytes, _ = torch.cuda.mem_get_info(dev)
+                        in_flight = _pool_workers if pool is not None else 1
+                        if free_bytes >= 2.0 * held[0] * (in_flight + 1):
+                            kept[i] = (mat, fact)
             # ijob 11 (Feast.hs:197-201 solves one subspace column at a time): all m0 vectors in one pass
             # through the factors
             qs = U.linearSolveManyDevice_(fact, U.UmfpackNormal, mat, rhs)
@@ -209,7 +236,7 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
                 qh = U.linearSolveManyDevice_(fact, U.UmfpackTrans, mat, rhs)  # ijob 21: the mirrored point
                 part = qs * w + qh * w.conjugate()
                 del qh
-            del fact, qs
+            del fact, qs, resident
             # (this thread's torch stream only: a device-wide synchronise would wait for the other points in flight)
             torch.cuda.current_stream(dev).synchronize()
             return part, (t1 - t, t2 - t1, time.perf_counter() - t2)
@@ -217,16 +244,16 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
         if pool is not None and held[0] == 0.0:
             # the first point of the run alone: what a factorisation holds decides how many fit side by side (panels +
             # transient fronts + the work of the solves: taken as twice the resident bytes, against 80 % of the device)
-            first = contour_point_on_this_stream(thetas[0])
+            first = contour_point_on_this_stream(0)
             fit = int(0.8 * torch.cuda.get_device_properties(dev).total_memory // max(2.0 * held[0], 1.0))
             if fit < 2:
                 pool = None
             else:
                 gate[0] = threading.BoundedSemaphore(min(fit, _pool_workers))
-            rest = [contour_point(th) for th in thetas[1:]] if pool is None else list(pool.map(contour_point, thetas[1:]))
+            rest = [contour_point(i) for i in range(1, nh)] if pool is None else list(pool.map(contour_point, range(1, nh)))
             parts = [first] + rest
         else:
-            parts = [contour_point(th) for th in thetas] if pool is None else list(pool.map(contour_point, thetas))
+            parts = [contour_point(i) for i in range(nh)] if pool is None else list(pool.map(contour_point, range(nh)))
         Q = torch.zeros((m0, n), dtype=sub_t, device=dev)
         for part, (tv, tf, ts) in parts:   # summed in contour order whatever the threads did: same bits every run
             Q += part
@@ -277,7 +304,8 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
     X = Xs[sel].cpu().numpy().T.astype(np.complex128) if len(lam) else np.zeros((n, 0), dtype=complex)
     if params.feastDebug:
         print("feast seconds: " + ", ".join("%s %.3f" % kv for kv in sorted(clock.items())))
-    geigSH_.last_clock = dict(clock, iterations=it + 1)
+    kept.clear()
+    geigSH_.last_clock = dict(clock, iterations=it + 1, **counts)
     return lam, X, res
 
 

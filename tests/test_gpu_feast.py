@@ -85,3 +85,34 @@ def test_feast_real_and_complex_paths_agree(gpu, pkg):
     guess = rng.normal(size=(n, 8)) + 1j * rng.normal(size=(n, 8))
     lam_c, _, _ = pkg.feast.geigSH_(pkg.feast.defaultFeastParams, 8, (lo, hi), A, guess=guess)
     assert close_enough(np.sort(lam_r), exact[5:9], 1e-9) and close_enough(np.sort(lam_c), exact[5:9], 1e-9)
+
+
+@pytest.mark.parametrize("threads", ["1", "3"])
+def test_feast_resident_factors_give_the_same_bits_as_refactoring(gpu, pkg, threads, monkeypatch):
+    """round 4: the factors of ze*B - A of every contour point stay in HBM for the later iterations (the points do not
+    move); the reference refactors each point in each iteration (Feast.hs:214-218), which SPL_FEAST_KEEP_FACTORS=0
+    still does.  The same factors either way: eigenvalues and vectors agree bit for bit, with the contour points
+    on worker threads or not, and the later iterations factor nothing."""
+    monkeypatch.setenv("SPL_FEAST_THREADS", threads)
+    m = 12
+    H = pkg.DeviceMatrix.synthetic("poisson3d", m)
+    rp, ci, v = H.export_csr()
+    H.free()
+    n = m ** 3
+    A = pkg.Matrix(n, n, rp, ci, v)  # symmetric: its CSR arrays are its CSC arrays
+    ref = np.linalg.eigvalsh(pkg.pack(A))
+    uniq = np.unique(np.round(ref, 9))  # (a cube: the eigenvalues come in groups of 1, 3, 3, 3, 1, 6 ...)
+    lo, hi = 0.5 * (uniq[0] + uniq[1]), 0.5 * (uniq[2] + uniq[3])
+    inside = ref[(ref > lo) & (ref < hi)]
+    assert len(inside) == 6
+    params = pkg.feast.FeastParams(feastContourPoints=4)
+    lam1, X1 = pkg.feast.eigSHParams(params, 12, (lo, hi), A)
+    c1 = dict(pkg.feast.geigSH_.last_clock)
+    monkeypatch.setenv("SPL_FEAST_KEEP_FACTORS", "0")
+    lam0, X0 = pkg.feast.eigSHParams(params, 12, (lo, hi), A)
+    c0 = dict(pkg.feast.geigSH_.last_clock)
+    assert close_enough(np.sort(lam1), inside, 1e-9)
+    assert np.array_equal(lam1, lam0) and np.array_equal(X1, X0)
+    assert c1["iterations"] == c0["iterations"] >= 2
+    assert c0["factorisations"] == 4 * c0["iterations"] and c0["factors_reused"] == 0
+    assert c1["factorisations"] == 4 and c1["factors_reused"] == 4 * (c1["iterations"] - 1)
