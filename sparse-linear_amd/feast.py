@@ -163,6 +163,7 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
     kept = {}          # contour point -> (mat, fact)
     kept_lock = threading.Lock()
     counts = {"factorisations": 0, "factors_reused": 0}
+    alloc_s0 = _ffi.device_alloc_seconds()
     for it in range(20):
         t0 = time.perf_counter()
         BY = _apply(opB, Y)                                                    # ijob 40
@@ -305,7 +306,9 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
     if params.feastDebug:
         print("feast seconds: " + ", ".join("%s %.3f" % kv for kv in sorted(clock.items())))
     kept.clear()
-    geigSH_.last_clock = dict(clock, iterations=it + 1, **counts)
+    # (hipmalloc: seconds inside the driver's allocator — fresh memory another process released a moment ago is wiped
+    # first, and the kernels of every thread stand still meanwhile: DESIGN.md 5.5)
+    geigSH_.last_clock = dict(clock, iterations=it + 1, hipmalloc=_ffi.device_alloc_seconds() - alloc_s0, **counts)
     return lam, X, res
 
 
