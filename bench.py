@@ -61,9 +61,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--no-secondary", action="store_true", help="skip the banded / C4 / C5 block after the timed region")
-    ap.add_argument("--secondary", default="c5:200:cpu32,banded,spmv:poisson3d:200,spmv:rmat:20,c4,c5:100,zi:100",
+    ap.add_argument("--secondary", default="c5:200:cpu32,banded,spmv:poisson3d:200,spmv:rmat:20,c4,c5:100,zi:100,feast:80",
                     help="which secondary configurations to run, in this order, each in a child process of its own (comma "
-                         "separated: banded, c4[:<scale>], c5:<m>[:cpu<ms>], zi:<m>, spmv:poisson3d:<m>, spmv:rmat:<scale>); the "
+                         "separated: banded, c4[:<scale>], c5:<m>[:cpu<ms>], zi:<m>, feast:<m>, spmv:poisson3d:<m>, spmv:rmat:<scale>); the "
                          "200^3 factorisation comes first: it asks the driver for 255 GB, and memory other configurations have "
                          "just released is still being wiped in the background (DESIGN.md, Device memory)")
     args = ap.parse_args()

@@ -139,7 +139,7 @@ def test_secondary_block_rides_on_the_headline_line(gpu):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "400000", "--steps", "3", "--warmup", "1",
-           "--cpu-reps", "1", "--secondary", "c5:16:cpu8,banded,no-such-item,c4:12,zi:14,spmv:poisson3d:16,spmv:rmat:12"]
+           "--cpu-reps", "1", "--secondary", "c5:16:cpu8,banded,no-such-item,c4:12,zi:14,spmv:poisson3d:16,spmv:rmat:12,feast:10"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
@@ -147,7 +147,7 @@ def test_secondary_block_rides_on_the_headline_line(gpu):
     assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["kind"] == "port"
     sec = out["secondary"]
     assert set(sec) == {"c2_banded_spmv", "c5_lu_poisson3d_16", "c4_spgemm_rmat12", "f3_zi_lu_shifted_poisson3d_14",
-                        "spmv_poisson3d_16", "spmv_rmat_12", "no-such-item"}
+                        "spmv_poisson3d_16", "spmv_rmat_12", "no-such-item", "f4_feast_laplacian3d_10"}
     assert "error" in sec["no-such-item"]
     assert sec["f3_zi_lu_shifted_poisson3d_14"]["parity"]["within_1e-10"] and sec["f3_zi_lu_shifted_poisson3d_14"]["unit"] == "s"
     assert sec["c2_banded_spmv"]["parity"]["bit_identical"] and sec["c2_banded_spmv"]["roofline"]["bound"] == "hbm"
@@ -163,6 +163,9 @@ def test_secondary_block_rides_on_the_headline_line(gpu):
         assert sec[k]["parity"]["bit_identical"] and sec[k]["roofline"]["bound"] == "hbm" and sec[k]["unit"] == "GB/s"
     assert sec["c4_spgemm_rmat12"]["parity"]["structure_and_values_bit_identical"]
     assert sec["c4_spgemm_rmat12"]["cpu_baseline"]["kind"] == "port" and sec["c4_spgemm_rmat12"]["unit"] == "Gproducts/s"
+    fe = sec["f4_feast_laplacian3d_10"]
+    assert fe["within_1e-10"] and fe["found"] == fe["eigenvalues_exact_in_window"] > 0 and fe["unit"] == "s"
+    assert fe["stage_seconds"]["factorisations"] == 8 and fe["stage_seconds"]["iterations"] >= 1
 
 
 @pytest.mark.parametrize("nproc,chunks", [(2, 1), (3, 2)])

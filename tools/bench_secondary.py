@@ -401,6 +401,40 @@ def spmv_other(pkg, torch, which, steps=20):
                              "sample": "the same matrix, one serial CSR pass of the oracle, %.3f s" % t_cpu}}
 
 
+def feast_3d(pkg, torch, m=80, m0=16):
+    """row f4: the FEAST-style driver (sparse-linear_amd/feast.py, the reference's Feast.hs) on the 7-point Laplacian of an
+    m^3 grid — eight complex factorisations with ONE analysis, batched solves of m0 columns per contour point and
+    iteration, SpMVs, the m0 x m0 Rayleigh-Ritz problem — for a window of the spectrum whose eigenvalues are known in
+    closed form (sums of three 1-D eigenvalues 2 - 2 cos(k pi / (m + 1)))."""
+    import numpy as np
+    H = pkg.DeviceMatrix.synthetic("poisson3d", m)
+    rp, ci, v = H.export_csr()
+    H.free()
+    n = m ** 3
+    A = pkg.Matrix(n, n, rp, ci, v)  # symmetric: its CSR arrays are its CSC arrays
+    ev1 = 2.0 - 2.0 * np.cos(np.arange(1, m + 1) * np.pi / (m + 1))
+    exact = np.sort((ev1[:, None, None] + ev1[None, :, None] + ev1[None, None, :]).ravel())
+    # the window of profiles/r0*_feast_laplacian3d.json at m = 80 (10 eigenvalues), scaled like the spectrum's lower end
+    lo, hi = 0.003 * (81.0 / (m + 1)) ** 2, 0.0175 * (81.0 / (m + 1)) ** 2
+    inside = exact[(exact > lo) & (exact < hi)]
+    t = time.perf_counter()
+    lam, _X = pkg.feast.eigSH(m0, (lo, hi), A)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    lam = np.sort(np.asarray(lam))
+    ok = len(lam) == len(inside)
+    stages = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in pkg.feast.geigSH_.last_clock.items()}
+    return {"metric": "FEAST-style eigensolve seconds (3-D Laplacian %d^3, m0 = %d, 8 contour points)" % (m, m0),
+            "value": round(dt, 3), "unit": "s", "higher_is_better": False, "n": n,
+            "eigenvalues_exact_in_window": int(len(inside)), "found": int(len(lam)),
+            "max_rel_error": float(np.max(np.abs(lam - inside) / inside)) if ok and len(lam) else None,
+            "within_1e-10": bool(ok and len(lam) and np.max(np.abs(lam - inside) / inside) < 1e-10),
+            "stage_seconds": stages,
+            "note": "stage_seconds are thread seconds (contour points on SPL_FEAST_THREADS host threads), 'contour' the wall "
+                    "time of that stage; the factors of the contour points stay resident across the iterations "
+                    "(factors_reused), the reference refactors each time (Feast.hs:214-218)"}
+
+
 def run_item(item, n=10_000_000, draws=20, steps=20):
     """one secondary configuration by name -> (key, result)"""
     import torch
@@ -414,6 +448,8 @@ def run_item(item, n=10_000_000, draws=20, steps=20):
     if item == "c4" or item.startswith("c4:"):  # c4:<scale> (tests): a smaller R-MAT matrix, same code
         scale = int(item[3:]) if item.startswith("c4:") else 20
         return "c4_spgemm_rmat%d" % scale, spgemm_c4(pkg, torch, scale=scale, cpu_rows=min(2048, 1 << scale))
+    if item.startswith("feast:"):  # row f4: the FEAST-style driver
+        return "f4_feast_laplacian3d_%s" % item[6:], feast_3d(pkg, torch, int(item[6:]))
     if item.startswith("zi:"):  # row f3: complex LU on native complex fronts
         return "f3_zi_lu_shifted_poisson3d_%s" % item[3:], lu_zi(pkg, torch, int(item[3:]))
     if item.startswith("spmv:"):  # spmv:poisson3d:<m> | spmv:rmat:<scale>
