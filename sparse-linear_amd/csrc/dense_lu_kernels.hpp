@@ -583,6 +583,7 @@ __global__ __launch_bounds__(256) void trsm_gemm_kernel(Band b, int j0, int jb, 
 // off the critical path.
 constexpr int KS = 32;
 constexpr int kSplitTiles = 64;  // windows of at least this many tiles a side split off the look-ahead tile (factor_loop)
+constexpr int kAheadTiles = 80;  // ... and beyond this many tiles a side past the next pair, the pair's chain runs beside the bulk pass
 struct Region {
   int rb, re, cb, ce, kb, klen, lshape, ntile_rows;
   int npiv;  // pivots of the (partial) factorisation: the look-ahead only factors blocks below it
@@ -737,7 +738,7 @@ __global__ __launch_bounds__(256) void gemm_update_kernel(Band b, Region g, int 
 // main stream and tile (0,0) with its look-ahead as a one-workgroup launch of gemm_update_kernel on a
 // helper stream beside it (factor_loop).
 __global__ __launch_bounds__(256) void gemm_update_bulk_kernel(Band b, Region g, int *__restrict__ singular) {
-  if (blockIdx.x == 0 && blockIdx.y == 0) return;
+  if (g.lshape == 0 && blockIdx.x == 0 && blockIdx.y == 0) return;  // (lshape 2: the whole window, no tile is somebody else's)
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   update_tile<false>(b, g, (int)blockIdx.x, (int)blockIdx.y, singular, nullptr, nullptr, dsm);
 }
@@ -1496,7 +1497,7 @@ __global__ __launch_bounds__(256) void gemm_update_kernel_z(Band b, Region g, in
 }
 
 __global__ __launch_bounds__(256) void gemm_update_bulk_kernel_z(Band b, Region g, int *__restrict__ singular) {
-  if (blockIdx.x == 0 && blockIdx.y == 0) return;
+  if (g.lshape == 0 && blockIdx.x == 0 && blockIdx.y == 0) return;
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   update_tile_z<false>(b, g, (int)blockIdx.x, (int)blockIdx.y, singular, nullptr, nullptr, dsm);
 }
@@ -2306,6 +2307,27 @@ inline void factor_loop(const Band &b, int npiv, double *d_invs, int *d_singular
                          slot(origin) + half);
     return origin < npiv;
   };
+  // Look-ahead over pairs (round 4, dense views with a helper stream): the rest of the window used to be updated on s
+  // (one workgroup with the next diagonal block on the helper), and the next pair's panel solves waited behind it:
+  // 104 us of chain + the bulk pass per 128 pivots.  The next pair (c, d) only needs ITS two block columns and rows.
+  // So after the solves of pair (a, b): on s an L-shaped pass brings block column / row c up to date (K = a, b) and
+  // factors its diagonal block; the helper stream updates everything beyond d (K = a, b, the whole window at three
+  // wavefronts per SIMD); block column / row d gets a, b together with c in the L-shaped pass of the next pair
+  // (K = a, b, c: one contiguous range).  The chain of pair (c, d) then runs beside the bulk pass of pair (a, b); an
+  // L-shaped pass waits for the bulk pass before it (they write the same entries), bulk passes follow each other on
+  // the helper.  Only where the bulk pass outweighs the extra L-shaped pass: windows of kAheadTiles tiles a side.
+  const bool dense = kl >= n - 1 && ku >= n - 1;
+  // SPL_LU_LOOKAHEAD: 0 = off, k > 0 = from k tiles a side (tests: small fronts through this code); read at every call
+  const char *ahead_env = getenv("SPL_LU_LOOKAHEAD");
+  const bool ahead_off = ahead_env && atoi(ahead_env) == 0;
+  const int ahead_tiles = ahead_env && atoi(ahead_env) > 0 ? atoi(ahead_env) : kAheadTiles;
+  bool bulk_in_flight = false;  // a bulk pass on the helper that s has not waited for yet
+  int owed_kb = -1;             // block column / row j0 + NB still lacks the panels from here on (-1: nothing owed)
+  auto join_bulk = [&] {
+    if (!bulk_in_flight) return;
+    SPL_HIP(hipStreamWaitEvent(s, fork.done, 0));
+    bulk_in_flight = false;
+  };
   bool diag_done = false;  // the previous update already factored this diagonal block
   int j0 = 0;
   while (j0 < npiv) {
@@ -2315,16 +2337,40 @@ inline void factor_loop(const Band &b, int npiv, double *d_invs, int *d_singular
     if (j0 + 2 * NB <= npiv && kl >= NB && ku >= NB) {
       // pair of block steps: the first one only updates the panels of the second (L-shape), then
       // both update the rest of the window in one pass with K = 2 NB
-      const int j1 = j0 + NB;
-      if (!update(j1, j0, NB, j0 + NB, true)) diag(j1, NB);
+      const int j1 = j0 + NB, j2 = j1 + NB;
+      const int kb1 = owed_kb >= 0 ? owed_kb : j0;
+      owed_kb = -1;
+      if (!update(j1, kb1, j1 - kb1, j0 + NB, true)) diag(j1, NB);
       trsm(j1, NB);
-      diag_done = update(j1 + NB, j0, 2 * NB, j1 + NB, false);
+      const int beyond = n - (j2 + 2 * NB);  // side of the window beyond the next pair
+      if (dense && fork.helper && !ahead_off && j2 + 2 * NB <= npiv && beyond >= ahead_tiles * 64) {
+        SPL_HIP(hipEventRecord(fork.ready, s));  // the panels of a, b
+        join_bulk();                             // (the pass before wrote what the L-shaped pass adds to)
+        diag_done = update(j2, j0, 2 * NB, j2, true);
+        SPL_HIP(hipStreamWaitEvent(fork.helper, fork.ready, 0));
+        const int origin = j2 + 2 * NB, nt = (n - origin + 63) / 64;
+        Region g{origin, n, origin, n, j0, 2 * NB, 2, nt, npiv};
+        if (Z)
+          hipLaunchKernelGGL(gemm_update_bulk_kernel_z, dim3((unsigned)nt, (unsigned)nt), dim3(256), kUpdateLdsZ, fork.helper,
+                             b, g, d_singular);
+        else
+          hipLaunchKernelGGL(gemm_update_bulk_kernel, dim3((unsigned)nt, (unsigned)nt), dim3(256), gemm_lds, fork.helper, b, g,
+                             d_singular);
+        SPL_HIP(hipEventRecord(fork.done, fork.helper));
+        bulk_in_flight = true;
+        owed_kb = j0;
+      } else {
+        join_bulk();
+        diag_done = update(j2, j0, 2 * NB, j2, false);
+      }
       j0 += 2 * NB;
     } else {
+      join_bulk();
       diag_done = update(j0 + jb, j0, jb, j0 + jb, false);
       j0 += jb;
     }
   }
+  join_bulk();
 }
 
 // one triangular pass over the first npiv unknowns of the view (npiv = b.n: the whole system); in a

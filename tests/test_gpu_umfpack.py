@@ -355,6 +355,45 @@ def test_pipelined_steps_and_split_boundary_product_give_the_same_solution(gpu, 
         assert np.max(np.abs(x - xs) / xs) < 1e-12
 
 
+@pytest.mark.parametrize("unsym", [False, True])
+def test_pair_chain_beside_the_bulk_pass_gives_the_same_solution(gpu, pkg, O, unsym, monkeypatch):
+    """round 4, factor_loop (csrc/dense_lu_kernels.hpp): in large fronts the panel solves of the next pair of block steps
+    run beside the bulk pass of the pair before (an L-shaped pass brings the next block column / row up to date, the
+    second one receives three panels at once in the following pair).  SPL_LU_LOOKAHEAD=1 sends every front of at least
+    five blocks through that code (the product starts at 80 tiles beyond the next pair), =0 switches it off: the same
+    products in other groupings of K — solutions agree to rounding level, backward errors below eps; symmetric
+    (L D L^T) and unsymmetric fronts, both systems."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    monkeypatch.setenv("SPL_MF_MIDMAX", "256")  # fronts above 256 rows take the per-front pipeline
+    m = 34
+    n, A = _grid_matrix(pkg, O, "3d", m)
+    rng = np.random.default_rng(5)
+    if unsym:
+        S0 = csc_tuple_to_scipy(mat_to_tuple(A)).tocoo()
+        v = S0.data * rng.uniform(0.8, 1.2, S0.nnz)
+        v[S0.row == S0.col] = 7.0
+        S1 = sp.csc_matrix((v, (S0.row, S0.col)), shape=S0.shape)
+        S1.sort_indices()
+        A = pkg.Matrix(n, n, S1.indptr.astype(np.int32), S1.indices.astype(np.int32), S1.data)
+    S = csc_tuple_to_scipy(mat_to_tuple(A))
+    U = pkg.umfpack
+    xs = rng.uniform(0.5, 1.5, n)
+    an = U.analyze(A)
+    sols = {}
+    for ahead in ("1", "0"):
+        monkeypatch.setenv("SPL_LU_LOOKAHEAD", ahead)
+        fact = U.factor(A, an)
+        assert fact.path in (3, 4)
+        for mode, op in ((U.UmfpackNormal, S), (U.UmfpackTrans, sp.csc_matrix(S.T))):
+            b = np.asarray(op @ xs).ravel()
+            sols[ahead, mode] = U.linearSolve_(fact, mode, A, b)
+            assert fact.solve_report["backward_error"] < 2.3e-16
+    for mode in (U.UmfpackNormal, U.UmfpackTrans):
+        assert np.max(np.abs(sols["1", mode] - sols["0", mode]) / np.abs(sols["0", mode])) < 1e-12
+        assert np.max(np.abs(sols["1", mode] - xs) / xs) < 1e-11
+
+
 @pytest.mark.parametrize("cut", [None, "2"])
 @pytest.mark.parametrize("kind,m", [("3d", 26), ("2d", 150)])
 def test_assembly_beside_the_factorisation_gives_the_same_factors(gpu, pkg, O, kind, m, cut, monkeypatch):
