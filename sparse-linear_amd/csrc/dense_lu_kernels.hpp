@@ -622,8 +622,12 @@ __device__ __forceinline__ void update_tile(const Band &b, const Region &g, int 
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const double *src = &b.at(r0 + p.row(c), c0 + p.col(a, 0));
+        // (the window is read once and written once per pass: streaming hints keep it from pushing the panel tiles,
+        // which every tile of a row / column of the window reads again, out of the L2 — the bulk passes of a 100^3
+        // factorisation read 183 -> 157 GB, 137 -> 134.5 ms.  An XCD-aware tile order cut the panel re-reads by another
+        // 75 % and was SLOWER, 139 ms: the pass is not bound by HBM traffic — profiles/r04_concurrency_experiments.txt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cold[a][c][r] = src[(size_t)(4 * r) * cs];  // col(a, r) = col(a, 0) + 4 r
+        for (int r = 0; r < 4; ++r) cold[a][c][r] = __builtin_nontemporal_load(&src[(size_t)(4 * r) * cs]);  // col(a, r) = col(a, 0) + 4 r
       }
   } else {
 #pragma unroll
@@ -686,7 +690,8 @@ __device__ __forceinline__ void update_tile(const Band &b, const Region &g, int 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           cold[a][c][r] -= acc[a][c][r];
-          dst[(size_t)(4 * r) * cs] = cold[a][c][r];
+          if (LOOKAHEAD) dst[(size_t)(4 * r) * cs] = cold[a][c][r];  // (the next panel solves read these strips at once)
+          else __builtin_nontemporal_store(cold[a][c][r], &dst[(size_t)(4 * r) * cs]);
         }
       }
   } else {
