@@ -48,6 +48,8 @@ struct Band {
     return AB[(size_t)(doff + i) + (size_t)j * (size_t)(ldab - 1)];
   }
   __device__ __forceinline__ double get(int i, int j) const { return in_band(i, j) ? at(i, j) : 0.0; }
+  // the same with a streaming hint: factor panels in a triangular solve are read once per walk
+  __device__ __forceinline__ double get_nt(int i, int j) const { return in_band(i, j) ? __builtin_nontemporal_load(&at(i, j)) : 0.0; }
 };
 // Band::piv of a factorisation WITHOUT interchanges: 0 (diagonal blocks by panels of 16 on the matrix cores, round 4), or 2
 // with SPL_LU_DIAG=plain in the environment (the unblocked form of rounds 1 - 3: ablation)
@@ -1653,16 +1655,16 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int c = cb + t + SWV * u;
-          e[u] = TR ? b.get(c, i) : b.get(i, c);
-          ei[u] = Z ? (TR ? -(&b.at(c, i))[b.zoff] : (&b.at(i, c))[b.zoff]) : 0.0;
+          e[u] = TR ? b.get_nt(c, i) : b.get_nt(i, c);
+          ei[u] = Z ? (TR ? -__builtin_nontemporal_load(&b.at(c, i) + b.zoff) : __builtin_nontemporal_load(&b.at(i, c) + b.zoff)) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) mac_cols<NR, Z>(acc, e[u], ei[u], &vv[t + SWV * u][0]);
       }
       for (; t < nc; t += SWV) {
         const int c = cb + t;
-        const double e = TR ? b.get(c, i) : b.get(i, c);
-        const double ei = Z ? (TR ? -(&b.at(c, i))[b.zoff] : (&b.at(i, c))[b.zoff]) : 0.0;
+        const double e = TR ? b.get_nt(c, i) : b.get_nt(i, c);
+        const double ei = Z ? (TR ? -__builtin_nontemporal_load(&b.at(c, i) + b.zoff) : __builtin_nontemporal_load(&b.at(i, c) + b.zoff)) : 0.0;
         mac_cols<NR, Z>(acc, e, ei, &vv[t][0]);
       }
     }
@@ -1695,8 +1697,8 @@ __device__ __forceinline__ void gemv64(const Band &b, int rb, int cb, int nc, co
         for (int q = 0; q < RG; ++q) {
           const int i = rb + wave + SWV * (q0 + q);
           const bool in = t < nc && i >= 0 && i < b.n;
-          e[u][q] = in ? b.get(cb + t, i) : 0.0;
-          ei[u][q] = (Z && in) ? -(&b.at(cb + t, i))[b.zoff] : 0.0;
+          e[u][q] = in ? b.get_nt(cb + t, i) : 0.0;
+          ei[u][q] = (Z && in) ? -__builtin_nontemporal_load(&b.at(cb + t, i) + b.zoff) : 0.0;
         }
       }
 #pragma unroll

@@ -804,15 +804,15 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(c
       double e[8], ei[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        e[u] = row[(size_t)(k + GW * u) * ldu];
-        ei[u] = Z ? row[(size_t)(k + GW * u) * ldu + zo] : 0.0;
+        e[u] = __builtin_nontemporal_load(&row[(size_t)(k + GW * u) * ldu]);  // (a panel is read once per walk)
+        ei[u] = Z ? __builtin_nontemporal_load(&row[(size_t)(k + GW * u) * ldu + zo]) : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) mac_cols<NR, Z>(acc, e[u], ei[u], &xs[k + GW * u][0]);
     }
     for (; k < kn; k += GW) {
-      const double e = row[(size_t)k * ldu];
-      const double ei = Z ? row[(size_t)k * ldu + zo] : 0.0;
+      const double e = __builtin_nontemporal_load(&row[(size_t)k * ldu]);
+      const double ei = Z ? __builtin_nontemporal_load(&row[(size_t)k * ldu + zo]) : 0.0;
       mac_cols<NR, Z>(acc, e, ei, &xs[k][0]);
     }
   }
@@ -871,8 +871,8 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_t_kernel
       double e[RW], ei[RW];
 #pragma unroll
       for (int u = 0; u < RW; ++u) {
-        e[u] = col[u][kc];
-        ei[u] = Z ? -col[u][kc + b.pz] : 0.0;  // conjugate transpose
+        e[u] = __builtin_nontemporal_load(&col[u][kc]);
+        ei[u] = Z ? -__builtin_nontemporal_load(&col[u][kc + b.pz]) : 0.0;  // conjugate transpose
       }
       double xv[NR];
 #pragma unroll
