@@ -336,7 +336,7 @@ template <bool Z>
 __global__ __launch_bounds__(256) void mid_update_kernel(const int *__restrict__ list,
                                                          const int64_t *__restrict__ prefix, int count, int step,
                                                          TreeView t, double *__restrict__ invs,
-                                                         int *__restrict__ singular) {
+                                                         int *__restrict__ singular, int paired) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   const int64_t flat = prefix[0] + blockIdx.x;
   const int fi = item_of_tile(prefix, count, flat);
@@ -345,10 +345,30 @@ __global__ __launch_bounds__(256) void mid_update_kernel(const int *__restrict__
   const int np = t.np[f], j0 = step * NB, jb = min(NB, np - j0), origin = j0 + jb;
   const int ntile = (b.n - origin + 63) / 64;
   const int tile = (int)(flat - prefix[fi]);
-  const Region g{origin, b.n, origin, b.n, j0, jb, 0, ntile, np};
+  // Steps in pairs (round 4; `paired`): the counters showed these passes moving 86 GB per 100^3 factorisation at K = 64
+  // (8 flop per byte of window traffic).  An even step of a front that has another pivot block after it only brings
+  // that block's column and row up to date (L-shaped pass) and factors its diagonal block; the odd step that follows
+  // updates the rest of the window with both panels at once, K = 128: every second pass over the window is gone.
+  // A front whose next pivot block is missing or short takes the whole window at once, as before.
+  int kb = j0, klen = jb, lshape = 0, tx = tile % ntile, ty = tile / ntile;
+  // (only full blocks pair: the 64-wide tiles of an L-shaped pass over a shorter second block would reach into the window
+  // the odd step updates with both panels)
+  if (paired) {
+    if (step & 1) {
+      if (jb == NB) {
+        kb = j0 - NB;
+        klen = 2 * NB;
+      }
+    } else if (np >= origin + NB) {
+      lshape = 1;
+      tx = tile < ntile ? tile : 0;
+      ty = tile < ntile ? 0 : tile - ntile + 1;
+    }
+  }
+  const Region g{origin, b.n, origin, b.n, kb, klen, lshape, ntile, np};
   double *next = mid_slot(t, invs, f, origin);  // only written when origin is a pivot block
-  if (Z) update_tile_z<true>(b, g, tile % ntile, tile / ntile, singular, next, next + 2 * NB * NB, dsm);
-  else update_tile<true>(b, g, tile % ntile, tile / ntile, singular, next, next + NB * NB, dsm);
+  if (Z) update_tile_z<true>(b, g, tx, ty, singular, next, next + 2 * NB * NB, dsm);
+  else update_tile<true>(b, g, tx, ty, singular, next, next + NB * NB, dsm);
 }
 
 constexpr int kSmallFront = 128;   // fronts up to this size are factored by one workgroup each
@@ -1406,6 +1426,7 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
   // scatters the entries of A of level d - 1 into it: of the three parts of an assembly only the extend-add stays on
   // the chain of the levels (at 100^3: 12 of 27 ms).  SPL_MF_OVERLAP=0: everything on the main stream, as before.
   const bool overlap = !(getenv("SPL_MF_OVERLAP") && atoi(getenv("SPL_MF_OVERLAP")) == 0);
+  const bool mid_paired = !(getenv("SPL_MF_MIDPAIR") && atoi(getenv("SPL_MF_MIDPAIR")) == 0);  // 0: K = 64 every step (ablation)
   hipStream_t aux = side[2 * kStreams];
   struct Events {
     hipEvent_t taken = nullptr, prepared = nullptr;  // extend-add of a level queued; region of the next level ready
@@ -1522,6 +1543,7 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
                 const int64_t nt = (rest + 63) / 64;
                 tt = 2 * nt;
                 tu = nt * nt;
+                if (mid_paired && !(st & 1) && np >= j0 + jb + NB) tu = 2 * nt - 1;  // (the L-shaped pass of an even step)
               }
               pt[k + 1] = pt[k] + tt;
               pu[k + 1] = pu[k] + tu;
@@ -1547,7 +1569,8 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
             if (nu > 0)
               hipLaunchKernelGGL(mid_update_kernel<Z>, dim3((unsigned)nu), dim3(256),
                                  Z ? kDiagLdsZ : kTileBytes + 2 * NB * sizeof(double), s, dl,
-                                 dp + base + (size_t)(count + 1), count, st, F.view, F.invs.get(), singular.get());
+                                 dp + base + (size_t)(count + 1), count, st, F.view, F.invs.get(), singular.get(),
+                                 mid_paired ? 1 : 0);
           }
         }
       }

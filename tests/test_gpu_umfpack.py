@@ -394,6 +394,33 @@ def test_pair_chain_beside_the_bulk_pass_gives_the_same_solution(gpu, pkg, O, un
         assert np.max(np.abs(sols["1", mode] - xs) / xs) < 1e-11
 
 
+@pytest.mark.parametrize("kind,m", [("3d", 24), ("2d", 170), ("2d", 100)])
+def test_paired_steps_of_the_lockstep_fronts_give_the_same_solution(gpu, pkg, O, kind, m, monkeypatch):
+    """round 4, mid_update_kernel (csrc/multifrontal.hip): the medium fronts of a level advance in lockstep, and two
+    FULL pivot blocks in a row are taken as a pair — an L-shaped pass after the first, one pass over the rest of the
+    window with both panels (K = 128) after the second; a short second block does not pair (its L-shaped tiles would
+    reach into that window: the first version of this did, and solved nothing).  SPL_MF_MIDPAIR=0: one pass per block
+    as before.  Same products in other groupings: solutions agree to rounding level.  Limits lowered so that the top
+    separators of these small meshes (100 - 580 pivots: one to nine blocks, the last one short) are medium fronts."""
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    monkeypatch.setenv("SPL_MF_SMALL", "64")
+    monkeypatch.setenv("SPL_MF_MIDMAX", "4096")
+    n, A = _grid_matrix(pkg, O, kind, m)
+    S = csc_tuple_to_scipy(mat_to_tuple(A))
+    U = pkg.umfpack
+    xs = np.random.default_rng(m).uniform(0.5, 1.5, n)
+    b = np.asarray(S @ xs).ravel()
+    an = U.analyze(A)
+    sols = {}
+    for pair in ("1", "0"):
+        monkeypatch.setenv("SPL_MF_MIDPAIR", pair)
+        fact = U.factor(A, an)
+        sols[pair] = U.linearSolve_(fact, U.UmfpackNormal, A, b)
+        assert fact.solve_report["backward_error"] < 2.3e-16
+    assert np.max(np.abs(sols["1"] - sols["0"]) / np.abs(sols["0"])) < 1e-12
+    assert np.max(np.abs(sols["1"] - xs) / xs) < 1e-11
+
+
 @pytest.mark.parametrize("cut", [None, "2"])
 @pytest.mark.parametrize("kind,m", [("3d", 26), ("2d", 150)])
 def test_assembly_beside_the_factorisation_gives_the_same_factors(gpu, pkg, O, kind, m, cut, monkeypatch):
