@@ -338,8 +338,20 @@ __global__ __launch_bounds__(256) void mid_update_kernel(const int *__restrict__
                                                          TreeView t, double *__restrict__ invs,
                                                          int *__restrict__ singular, int paired) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
-  const int64_t flat = prefix[0] + blockIdx.x;
-  const int fi = item_of_tile(prefix, count, flat);
+  // The first `count` workgroups take tile (0,0) of one front each — the tile that goes on to factor the next diagonal
+  // block, 30 - 60 us of mostly one wavefront: started last, behind a front's other tiles, the thousand of them of a
+  // level were the tail of every launch.  The other workgroups take the tiles in order and skip that one.
+  int fi;
+  int64_t flat;
+  if ((int)blockIdx.x < count) {
+    fi = (int)blockIdx.x;
+    if (prefix[fi + 1] == prefix[fi]) return;  // this front is done with its pivots
+    flat = prefix[fi];
+  } else {
+    flat = prefix[0] + ((int64_t)blockIdx.x - count);
+    fi = item_of_tile(prefix, count, flat);
+    if (flat == prefix[fi]) return;
+  }
   const int f = list[fi];
   const Band b = mid_front(t, f);
   const int np = t.np[f], j0 = step * NB, jb = min(NB, np - j0), origin = j0 + jb;
@@ -1567,7 +1579,7 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
               hipLaunchKernelGGL(mid_trsm_kernel<Z>, dim3((unsigned)nt), dim3(256), Z ? kTrsmLdsZ : kTrsmLds, s, dl,
                                  dp + base, count, st, F.view, F.invs.get());
             if (nu > 0)
-              hipLaunchKernelGGL(mid_update_kernel<Z>, dim3((unsigned)nu), dim3(256),
+              hipLaunchKernelGGL(mid_update_kernel<Z>, dim3((unsigned)(nu + count)), dim3(256),
                                  Z ? kDiagLdsZ : kTileBytes + 2 * NB * sizeof(double), s, dl,
                                  dp + base + (size_t)(count + 1), count, st, F.view, F.invs.get(), singular.get(),
                                  mid_paired ? 1 : 0);
