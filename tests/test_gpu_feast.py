@@ -116,3 +116,30 @@ def test_feast_resident_factors_give_the_same_bits_as_refactoring(gpu, pkg, thre
     assert c1["iterations"] == c0["iterations"] >= 2
     assert c0["factorisations"] == 4 * c0["iterations"] and c0["factors_reused"] == 0
     assert c1["factorisations"] == 4 and c1["factors_reused"] == 4 * (c1["iterations"] - 1)
+
+
+def test_feast_keeps_only_the_factors_that_fit(gpu, pkg, monkeypatch):
+    """the factors of a contour point stay resident only while room remains for the points in flight (twice the resident
+    bytes of a factorisation each): with the device reporting less free memory than that, every point is refactored in
+    every iteration — the reference's way — and the eigenvalues are the same bits."""
+    import torch
+    monkeypatch.setenv("SPL_FEAST_THREADS", "2")
+    m = 12
+    H = pkg.DeviceMatrix.synthetic("poisson3d", m)
+    rp, ci, v = H.export_csr()
+    H.free()
+    n = m ** 3
+    A = pkg.Matrix(n, n, rp, ci, v)
+    ref = np.linalg.eigvalsh(pkg.pack(A))
+    uniq = np.unique(np.round(ref, 9))
+    lo, hi = 0.5 * (uniq[0] + uniq[1]), 0.5 * (uniq[2] + uniq[3])
+    params = pkg.feast.FeastParams(feastContourPoints=4)
+    lam1, X1 = pkg.feast.eigSHParams(params, 12, (lo, hi), A)
+    kept = dict(pkg.feast.geigSH_.last_clock)
+    real_info = torch.cuda.mem_get_info
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a, **k: (1024, real_info(*a, **k)[1]))
+    lam0, X0 = pkg.feast.eigSHParams(params, 12, (lo, hi), A)
+    none = dict(pkg.feast.geigSH_.last_clock)
+    assert np.array_equal(lam1, lam0) and np.array_equal(X1, X0)
+    assert kept["factors_reused"] > 0 and none["factors_reused"] == 0
+    assert none["factorisations"] == 4 * none["iterations"]
