@@ -197,10 +197,11 @@ def lu_zi(pkg, torch, m=100):
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     t = time.perf_counter()
-    U.linearSolve_(fa, U.UmfpackNormal, A, b)  # the same call again: the solve in its steady state
+    x2 = U.linearSolve_(fa, U.UmfpackNormal, A, b)  # the same call again: the solve in its steady state
     torch.cuda.synchronize()
     solve2 = time.perf_counter() - t
     rep = fa.solve_report
+    solve_dev, rep_dev, same_dev = _solve_in_hbm(pkg, torch, fa, A, b, x2)
     bh = np.asarray(S.conj().T @ xs).ravel()
     t3b = time.perf_counter()
     xh = U.linearSolve_(fa, U.UmfpackTrans, A, bh)
@@ -221,16 +222,17 @@ def lu_zi(pkg, torch, m=100):
            "value_is": "one shot in a fresh process: analyze + FIRST factorisation + first solve of A x = b",
            "steady_state_s": round((t1 - t0) + steady + solve2, 3),
            "analyze_s": round(t1 - t0, 3), "factor_s": round(steady, 3), "first_factor_s": round(t2 - t1, 3),
-           "first_solve_s": round(t3 - t2, 3), "solve_s": round(solve2, 3), "solve_conjugate_transposed_s": round(t4 - t3b, 3),
+           "first_solve_s": round(t3 - t2, 3), "solve_s": round(solve2, 3), "solve_in_hbm_s": round(solve_dev, 4), "solve_conjugate_transposed_s": round(t4 - t3b, 3),
            "factorisation": {"path": st["path"], "native_complex_fronts": bool(st["complex_fronts"]), "fronts": st["fronts"],
                              "device_GB": round(st["device_bytes"] * 1e-9, 2), "flops": st["flops"],
                              "TFLOP_per_s": round(rate, 2)},
            "roofline": {"bound": "mfma", "achieved": round(rate, 2), "peak": 78.6, "unit": "TFLOP/s",
                         "frac": round(rate / 78.6, 4), "traffic": None,
                         "note": "real flops executed (4 per complex multiply-add pair; L D L^T) over the whole numeric factorisation"},
-           "solve_roofline": _solve_roofline(rep, solve2, "second linearSolve_ call (steady state), complex panels in two planes"),
+           "solve_roofline": dict(_solve_roofline(rep_dev, solve_dev, "solve with b and x resident in HBM (spl_umfpack_zi_solve_many_dev, one column), complex panels in two planes"),
+                                  host_buffers=_solve_roofline(rep, solve2, "second linearSolve_ call: host buffers, b up and x down over PCIe inside the time")),
            "parity": {"max_rel_err_vs_manufactured": err, "conjugate_transposed_max_rel_err": errh,
-                      "within_1e-10": bool(err < 1e-10 and errh < 1e-10)},
+                      "within_1e-10": bool(err < 1e-10 and errh < 1e-10), "solve_in_hbm_bit_identical": same_dev},
            "cpu_baseline": None}
     del fa, an
     gc.collect()
@@ -248,8 +250,27 @@ def _solve_roofline(rep, seconds, what):
     return {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
             "traffic": None, "walks": rep["walks"], "bytes_per_walk": rep["walk_bytes"], "refinement_steps": rep["ir_attempted"],
             "backward_error": rep["backward_error"], "of": what,
-            "note": "bytes = walks x (8 per stored factor entry + 16 n); time = the whole solve call (upload of b, walks, "
-                    "residuals in twice the working precision, download of x)"}
+            "note": "bytes = walks x (8 per stored factor entry + 16 n); time = the whole solve call (walks, residuals in twice "
+                    "the working precision between them; the host-buffer form also the upload of b and the download of x)"}
+
+
+def _solve_in_hbm(pkg, torch, fa, A, b, x_host):
+    """the same solve with b and x resident in HBM (spl_umfpack_{di,zi}_solve_many_dev, one column): what the roofline of
+    the triangular solves is quoted on — the host-buffer call beside it moves b up and x down over PCIe inside its time.
+    -> (seconds, solve report, bits equal to the host-buffer call's solution)"""
+    import numpy as np
+    U = pkg.umfpack
+    dev = torch.device("cuda", torch.cuda.current_device())
+    Bd = torch.from_numpy(np.ascontiguousarray(b)).to(dev).reshape(1, -1)
+    Xd = U.linearSolveManyDevice_(fa, U.UmfpackNormal, A, Bd)  # (kernels of the device-pointer path loaded)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    Xd = U.linearSolveManyDevice_(fa, U.UmfpackNormal, A, Bd)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    rep = fa.solve_report
+    same = bool(np.array_equal(Xd[0].cpu().numpy(), x_host))
+    return dt, rep, same
 
 
 def lu_c5(pkg, torch, m=100, cpu_sample=0):
@@ -299,6 +320,7 @@ def lu_c5(pkg, torch, m=100, cpu_sample=0):
     fa = U.factor(A, an)
     torch.cuda.synchronize()
     steady = time.perf_counter() - t4
+    solve_dev, rep_dev, same_dev = _solve_in_hbm(pkg, torch, fa, A, b, x2)
     one_shot = t3 - t0
     total = (t1 - t0) + steady + solve2
     rate = st["flops"] / max(steady, 1e-9) * 1e-12
@@ -310,7 +332,7 @@ def lu_c5(pkg, torch, m=100, cpu_sample=0):
            "steady_state_is": "analyze + second factorisation with the same analysis (panels from the pool) + second solve",
            "analyze_s": round(t1 - t0, 3), "first_factor_s": round(t2 - t1, 3), "factor_s": round(steady, 3),
            "first_factor_hipmalloc_s": round(a2 - a1, 3), "analyze_hipmalloc_s": round(a1 - a0, 3),
-           "first_solve_s": round(t3 - t2, 3), "solve_s": round(solve2, 3),
+           "first_solve_s": round(t3 - t2, 3), "solve_s": round(solve2, 3), "solve_in_hbm_s": round(solve_dev, 4),
            "factorisation": {"path": st["path"], "fronts": st["fronts"], "device_GB": round(st["device_bytes"] * 1e-9, 2),
                              "flops": st["flops"], "TFLOP_per_s": round(rate, 2),
                              "note": "flops executed: a symmetric matrix is factored as L D L^T on the same fronts (half the update flops of LU)"},
@@ -318,9 +340,11 @@ def lu_c5(pkg, torch, m=100, cpu_sample=0):
                         "unit": "TFLOP/s", "frac": round(rate / 78.6, 4), "traffic": None,
                         "note": "whole numeric factorisation in its steady state (all launches) against the fp64 matrix-core peak; "
                                 "back-to-back v_mfma_f64_16x16x4 issue at 47 TFLOP/s on this part (profiles/r01_dense_lu_rate_probe.txt)"},
-           "solve_roofline": _solve_roofline(rep, solve2, "second linearSolve_ call (steady state)"),
+           "solve_roofline": dict(_solve_roofline(rep_dev, solve_dev, "solve with b and x resident in HBM (spl_umfpack_di_solve_many_dev, one column), steady state"),
+                                  host_buffers=_solve_roofline(rep, solve2, "second linearSolve_ call: host buffers, b up and x down over PCIe inside the time")),
            "parity": {"max_rel_err_vs_manufactured": err, "within_1e-10": bool(err < 1e-10), "scaled_residual": res,
-                      "componentwise_backward_error": rep1["backward_error"], "second_solve_bit_identical": same},
+                      "componentwise_backward_error": rep1["backward_error"], "second_solve_bit_identical": same,
+                      "solve_in_hbm_bit_identical": same_dev},
            "cpu_baseline": None}
     del fa, an
     gc.collect()
