@@ -40,6 +40,7 @@ struct DeviceTree {  // depends on the tree only (cached in mf::Tree::device_cac
   int device = 0;
   DBuf<int> p0, np, nb, ld, parent, front_of, bidx, rel, depth, ldp, ldu;
   DBuf<int64_t> bptr, ioff, woff, roff, poff, uoff;
+  std::shared_ptr<void> level_plan;  // mf::LevelPlan (below): the lists and grids of the levels, built by the first factorisation
 };
 
 struct TreeView {  // raw pointers for kernels
@@ -993,12 +994,12 @@ __global__ __launch_bounds__(256) void big_scatter_x_kernel(const int *__restric
 
 namespace mf {
 
-struct Factors {
-  std::shared_ptr<const Tree> tree;
-  std::shared_ptr<DeviceTree> D;     // the tree's own arrays and `rel`: shared by every factorisation of this tree
-  DBuf<int64_t> d_foff, d_cboff;     // where this factorisation's memory plan puts the fronts
-  TreeView view;
-  DBuf<double> arena, invs;  // factor panels, inverses of the diagonal blocks
+// Everything about the levels that depends on the tree and the size limits only — which fronts of a depth go to which
+// kernel, the prefix sums that turn a level into flat grids (factorisation and solves alike) —: built by the first
+// factorisation of a tree on a device and shared by all that follow (round 4; a refactorisation used to rebuild and
+// upload it: 1.8 ms of 134 at 100^3, 0.8 of 7 ms at 32^3, some 440 small copies).  Read-only once built.
+struct LevelPlan {
+  int small_limit = 0, mid_limit = 0, mid_paired = 0;  // what it was built for (with big_solve below)
   std::vector<DBuf<int>> level_lists;                // fronts of each depth
   std::vector<DBuf<int>> small_lists;                // ... those factored by one workgroup each
   std::vector<int> small_counts;
@@ -1012,8 +1013,6 @@ struct Factors {
   // U panels): the flat grids of extend-add and compaction
   std::vector<std::vector<int64_t>> h_ctile[2], h_ptile, h_utile, h_atile;  // h_atile: groups of 32 pivots (assembly)
   std::vector<DBuf<int64_t>> ctile[2], ptile, utile, atile;
-  int singular = 0;
-  int zm = 1;         // 2: complex fronts in two planes (TreeView::zm)
   int big_solve = 0;  // fronts above this size are solved by many workgroups (kBigSolve; SPL_MF_BIGSOLVE)
   int64_t gemv_scratch = 0;  // doubles per right-hand-side column the chunked boundary product of a level needs at most
   // those fronts, per depth, and the flat grids of their lockstep solve kernels: segments of
@@ -1041,6 +1040,27 @@ struct Factors {
     const int64_t *prefix(int kind, int k = 0) const { return d.get() + seg(kind, k); }
   };
   std::vector<BigLevel> big;
+  // the lockstep medium fronts of each depth (whole level) and the prefix arrays of their steps:
+  // [step][phase 0 = panel solves, 1 = update][count + 1]
+  struct Mid {
+    int count = 0, steps = 0;
+    DBuf<int> list;
+    std::vector<int64_t> h;
+    DBuf<int64_t> d;
+  };
+  std::vector<Mid> mid;
+};
+
+struct Factors {
+  std::shared_ptr<const Tree> tree;
+  std::shared_ptr<DeviceTree> D;     // the tree's own arrays and `rel`: shared by every factorisation of this tree
+  DBuf<int64_t> d_foff, d_cboff;     // where this factorisation's memory plan puts the fronts
+  TreeView view;
+  DBuf<double> arena, invs;  // factor panels, inverses of the diagonal blocks
+  std::shared_ptr<LevelPlan> lp;  // lists and grids of the levels (shared with the other factorisations of this tree)
+  using BigLevel = LevelPlan::BigLevel;
+  int singular = 0;
+  int zm = 1;         // 2: complex fronts in two planes (TreeView::zm)
   // independent large fronts of a level run on these (factorisation): one set per device and host
   // thread, created on first use and never destroyed (objects come and go by the thousand in a
   // contour integration; work of different objects on the same stream is merely ordered)
@@ -1170,9 +1190,14 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
   mf::Factors &F = *Fp;
   F.tree = tree;
   F.zm = ZM;
-  F.big_solve = getenv("SPL_MF_BIGSOLVE") ? std::max(64, atoi(getenv("SPL_MF_BIGSOLVE"))) : kBigSolve;
+  const int big_solve = getenv("SPL_MF_BIGSOLVE") ? std::max(64, atoi(getenv("SPL_MF_BIGSOLVE"))) : kBigSolve;
   const int nd = T.maxdepth + 1, nf = T.nfronts;
   const int small_limit = getenv("SPL_MF_SMALL") ? std::max(64, atoi(getenv("SPL_MF_SMALL"))) : kSmallFront;  // tuning knob
+  // medium fronts (kSmallFront < size <= mid_limit) go through the lockstep kernels; SPL_MF_MID=0
+  // sends them down the per-front pipeline instead (ablation)
+  const int mid_limit = (getenv("SPL_MF_MID") && atoi(getenv("SPL_MF_MID")) == 0) ? small_limit
+                        : std::max(getenv("SPL_MF_MIDMAX") ? atoi(getenv("SPL_MF_MIDMAX")) : kMidFront, small_limit);
+  const bool mid_paired = !(getenv("SPL_MF_MIDPAIR") && atoi(getenv("SPL_MF_MIDPAIR")) == 0);  // 0: K = 64 every step (ablation)
   // ---- memory plan: the smallest cut depth whose transient part fits next to the resident part
   Plan plan;
   {
@@ -1243,38 +1268,84 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
                     F.d_foff.get(), D.ioff.get(), D.woff.get(), D.roff.get(), D.poff.get(),  D.uoff.get(),
                     {region0.get(), region1.get()}, F.arena.get(), F.d_cboff.get(), cutbuf.get(), symmetric ? 1 : 0, ZM,
                     pivot ? 1 : diag_form_without_interchanges(), pivot ? d_rscale : nullptr};
-  F.level_lists.resize((size_t)nd);
-  F.small_lists.resize((size_t)nd);
-  F.small_counts.assign((size_t)nd, 0);
-  F.solve_lists.resize((size_t)nd);
-  F.big.resize((size_t)nd);
-  F.solve_counts.assign((size_t)nd, 0);
-  F.h_small.assign((size_t)nd, std::vector<int>());
-  for (int sl = 0; sl < 2; ++sl) {
-    F.child_lists[sl].resize((size_t)nd);
-    F.child_counts[sl].assign((size_t)nd, 0);
-    F.child_maxnb[sl].assign((size_t)nd, 0);
-    F.h_child[sl].assign((size_t)nd, std::vector<int>());
-  }
   std::vector<std::vector<int>> staged;  // host copies must outlive the asynchronous uploads
+  // the medium fronts among the fronts [b0, b1) of a level's list, the number of block steps of the longest and the
+  // prefix arrays of all steps: [step][phase 0 = panel solves, 1 = update][count + 1]
+  auto mid_fronts_of = [&](const std::vector<int> &fronts, int b0, int b1, std::vector<int> &mid, int &steps,
+                           std::vector<int64_t> &pre) {
+    mid.clear();
+    steps = 0;
+    for (int i = b0; i < b1; ++i) {
+      const int f = fronts[(size_t)i];
+      if (T.np[(size_t)f] == 0 || T.fs(f) <= small_limit || T.fs(f) > mid_limit) continue;
+      mid.push_back(f);
+      steps = std::max(steps, (T.np[(size_t)f] + NB - 1) / NB);
+    }
+    const int count = (int)mid.size();
+    pre.assign((size_t)steps * 2 * (size_t)(count + 1), 0);
+    for (int st = 0; st < steps; ++st) {
+      int64_t *pt = pre.data() + ((size_t)st * 2) * (size_t)(count + 1), *pu = pt + (count + 1);
+      for (int k = 0; k < count; ++k) {
+        const int f = mid[(size_t)k], np = T.np[(size_t)f], j0 = st * NB;
+        int64_t tt = 0, tu = 0;
+        if (j0 < np) {
+          const int jb = std::min(NB, np - j0), rest = T.fs(f) - (j0 + jb);
+          const int64_t nt = (rest + 63) / 64;
+          tt = 2 * nt;
+          tu = nt * nt;
+          if (mid_paired && !(st & 1) && np >= j0 + jb + NB) tu = 2 * nt - 1;  // (the L-shaped pass of an even step)
+        }
+        pt[k + 1] = pt[k] + tt;
+        pu[k + 1] = pu[k] + tu;
+      }
+    }
+  };
+  // the lists and grids of the levels: from the tree's cache, or built now (and kept there)
+  std::unique_lock<std::mutex> plan_lock(T.device_cache_mu);
+  {
+    std::shared_ptr<mf::LevelPlan> have = std::static_pointer_cast<mf::LevelPlan>(D.level_plan);
+    if (have && have->small_limit == small_limit && have->big_solve == big_solve && have->mid_limit == mid_limit &&
+        have->mid_paired == (mid_paired ? 1 : 0))
+      F.lp = have;
+  }
+  const bool build_plan = !F.lp;
+  if (build_plan) {
+  F.lp = std::make_shared<mf::LevelPlan>();
+  F.lp->small_limit = small_limit;
+  F.lp->big_solve = big_solve;
+  F.lp->mid_limit = mid_limit;
+  F.lp->mid_paired = mid_paired ? 1 : 0;
+  F.lp->level_lists.resize((size_t)nd);
+  F.lp->small_lists.resize((size_t)nd);
+  F.lp->small_counts.assign((size_t)nd, 0);
+  F.lp->solve_lists.resize((size_t)nd);
+  F.lp->big.resize((size_t)nd);
+  F.lp->solve_counts.assign((size_t)nd, 0);
+  F.lp->h_small.assign((size_t)nd, std::vector<int>());
+  for (int sl = 0; sl < 2; ++sl) {
+    F.lp->child_lists[sl].resize((size_t)nd);
+    F.lp->child_counts[sl].assign((size_t)nd, 0);
+    F.lp->child_maxnb[sl].assign((size_t)nd, 0);
+    F.lp->h_child[sl].assign((size_t)nd, std::vector<int>());
+  }
   staged.reserve((size_t)nd);
   for (int d = 0; d < nd; ++d) {
-    upload_vec(F.level_lists[(size_t)d], T.by_depth[(size_t)d], s);
+    upload_vec(F.lp->level_lists[(size_t)d], T.by_depth[(size_t)d], s);
     for (int f : T.by_depth[(size_t)d])
-      if (T.np[(size_t)f] > 0 && T.fs(f) <= small_limit) F.h_small[(size_t)d].push_back(f);
-    F.small_counts[(size_t)d] = (int)F.h_small[(size_t)d].size();
-    upload_vec(F.small_lists[(size_t)d], F.h_small[(size_t)d], s);
+      if (T.np[(size_t)f] > 0 && T.fs(f) <= small_limit) F.lp->h_small[(size_t)d].push_back(f);
+    F.lp->small_counts[(size_t)d] = (int)F.lp->h_small[(size_t)d].size();
+    upload_vec(F.lp->small_lists[(size_t)d], F.lp->h_small[(size_t)d], s);
     std::vector<int> one_wg;
     for (int f : T.by_depth[(size_t)d])
-      if (T.fs(f) <= F.big_solve) one_wg.push_back(f);
-    F.solve_counts[(size_t)d] = (int)one_wg.size();
+      if (T.fs(f) <= F.lp->big_solve) one_wg.push_back(f);
+    F.lp->solve_counts[(size_t)d] = (int)one_wg.size();
     staged.push_back(std::move(one_wg));
-    upload_vec(F.solve_lists[(size_t)d], staged.back(), s);
+    upload_vec(F.lp->solve_lists[(size_t)d], staged.back(), s);
     {
-      mf::Factors::BigLevel &B = F.big[(size_t)d];
+      mf::Factors::BigLevel &B = F.lp->big[(size_t)d];
       std::vector<int> large;
       for (int f : T.by_depth[(size_t)d])
-        if (T.fs(f) > F.big_solve && T.np[(size_t)f] > 0) large.push_back(f);
+        if (T.fs(f) > F.lp->big_solve && T.np[(size_t)f] > 0) large.push_back(f);
       B.count = (int)large.size();
       constexpr int span = SB * NB;
       for (int f : large) B.steps = std::max(B.steps, (T.np[(size_t)f] + span - 1) / span);
@@ -1331,40 +1402,40 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
         fill(7, 0, [&](int f) -> int64_t { return (int64_t)((T.np[(size_t)f] + 63) / 64) * chunks(f); });
         fill(8, 0, [&](int f) -> int64_t { return chunks(f) > 1 ? (T.np[(size_t)f] + 255) / 256 : 0; });
         fill(9, 0, [&](int f) -> int64_t { return chunks(f) > 1 ? chunks(f) * T.np[(size_t)f] : 0; });
-        F.gemv_scratch = std::max(F.gemv_scratch, B.h[B.seg(9) + (size_t)B.count]);
+        F.lp->gemv_scratch = std::max(F.lp->gemv_scratch, B.h[B.seg(9) + (size_t)B.count]);
         auto fchunks = [&](int f) -> int64_t { return (T.np[(size_t)f] + kGemvChunk - 1) / kGemvChunk; };
         fill(10, 0, [&](int f) -> int64_t { return (int64_t)((T.nb[(size_t)f] + (T.np[(size_t)f] & 15) + 63) / 64) * fchunks(f); });
         fill(11, 0, [&](int f) -> int64_t { return fchunks(f) > 1 ? (T.nb[(size_t)f] + 255) / 256 : 0; });
         fill(12, 0, [&](int f) -> int64_t { return fchunks(f) > 1 ? fchunks(f) * T.nb[(size_t)f] : 0; });
-        F.gemv_scratch = std::max(F.gemv_scratch, B.h[B.seg(12) + (size_t)B.count]);
+        F.lp->gemv_scratch = std::max(F.lp->gemv_scratch, B.h[B.seg(12) + (size_t)B.count]);
         staged.push_back(std::move(large));
         upload_vec(B.list, staged.back(), s);
         upload_vec(B.d, B.h, s);
       }
     }
     if (d + 1 < nd) {
-      for (int c : T.by_depth[(size_t)d + 1]) F.h_child[T.slot[(size_t)c]][(size_t)d].push_back(c);
+      for (int c : T.by_depth[(size_t)d + 1]) F.lp->h_child[T.slot[(size_t)c]][(size_t)d].push_back(c);
       for (int sl = 0; sl < 2; ++sl) {
-        F.child_counts[sl][(size_t)d] = (int)F.h_child[sl][(size_t)d].size();
-        for (int c : F.h_child[sl][(size_t)d]) F.child_maxnb[sl][(size_t)d] = std::max(F.child_maxnb[sl][(size_t)d], T.nb[(size_t)c]);
-        upload_vec(F.child_lists[sl][(size_t)d], F.h_child[sl][(size_t)d], s);
+        F.lp->child_counts[sl][(size_t)d] = (int)F.lp->h_child[sl][(size_t)d].size();
+        for (int c : F.lp->h_child[sl][(size_t)d]) F.lp->child_maxnb[sl][(size_t)d] = std::max(F.lp->child_maxnb[sl][(size_t)d], T.nb[(size_t)c]);
+        upload_vec(F.lp->child_lists[sl][(size_t)d], F.lp->h_child[sl][(size_t)d], s);
       }
     }
   }
   {
     auto tiles = [](int64_t rows, int64_t cols) { return ((rows + 63) / 64) * ((cols + kTileCols - 1) / kTileCols); };
-    F.h_ptile.assign((size_t)nd, std::vector<int64_t>());
-    F.h_utile.assign((size_t)nd, std::vector<int64_t>());
-    F.h_atile.assign((size_t)nd, std::vector<int64_t>());
-    F.ptile.resize((size_t)nd);
-    F.utile.resize((size_t)nd);
-    F.atile.resize((size_t)nd);
+    F.lp->h_ptile.assign((size_t)nd, std::vector<int64_t>());
+    F.lp->h_utile.assign((size_t)nd, std::vector<int64_t>());
+    F.lp->h_atile.assign((size_t)nd, std::vector<int64_t>());
+    F.lp->ptile.resize((size_t)nd);
+    F.lp->utile.resize((size_t)nd);
+    F.lp->atile.resize((size_t)nd);
     for (int sl = 0; sl < 2; ++sl) {
-      F.h_ctile[sl].assign((size_t)nd, std::vector<int64_t>());
-      F.ctile[sl].resize((size_t)nd);
+      F.lp->h_ctile[sl].assign((size_t)nd, std::vector<int64_t>());
+      F.lp->ctile[sl].resize((size_t)nd);
     }
     for (int d = 0; d < nd; ++d) {
-      std::vector<int64_t> &pp = F.h_ptile[(size_t)d], &uu = F.h_utile[(size_t)d], &aa = F.h_atile[(size_t)d];
+      std::vector<int64_t> &pp = F.lp->h_ptile[(size_t)d], &uu = F.lp->h_utile[(size_t)d], &aa = F.lp->h_atile[(size_t)d];
       pp.assign(1, 0);
       uu.assign(1, 0);
       aa.assign(1, 0);
@@ -1373,20 +1444,35 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
         uu.push_back(uu.back() + tiles(T.np[(size_t)f], T.nb[(size_t)f]));
         aa.push_back(aa.back() + (T.np[(size_t)f] + 31) / 32);
       }
-      upload_vec(F.ptile[(size_t)d], pp, s);
-      upload_vec(F.utile[(size_t)d], uu, s);
-      upload_vec(F.atile[(size_t)d], aa, s);
+      upload_vec(F.lp->ptile[(size_t)d], pp, s);
+      upload_vec(F.lp->utile[(size_t)d], uu, s);
+      upload_vec(F.lp->atile[(size_t)d], aa, s);
       for (int sl = 0; sl < 2; ++sl) {
-        std::vector<int64_t> &cc = F.h_ctile[sl][(size_t)d];
+        std::vector<int64_t> &cc = F.lp->h_ctile[sl][(size_t)d];
         cc.assign(1, 0);
-        for (int c : F.h_child[sl][(size_t)d]) cc.push_back(cc.back() + tiles(T.nb[(size_t)c], T.nb[(size_t)c]));
-        upload_vec(F.ctile[sl][(size_t)d], cc, s);
+        for (int c : F.lp->h_child[sl][(size_t)d]) cc.push_back(cc.back() + tiles(T.nb[(size_t)c], T.nb[(size_t)c]));
+        upload_vec(F.lp->ctile[sl][(size_t)d], cc, s);
       }
     }
   }
+  // the lockstep medium fronts of every (whole) level and the prefix arrays of their steps
+  F.lp->mid.resize((size_t)nd);
+  for (int d = 0; d < nd; ++d) {
+    mf::LevelPlan::Mid &M = F.lp->mid[(size_t)d];
+    std::vector<int> mid;
+    mid_fronts_of(T.by_depth[(size_t)d], 0, (int)T.by_depth[(size_t)d].size(), mid, M.steps, M.h);
+    M.count = (int)mid.size();
+    if (M.count == 0) continue;
+    upload_vec(M.list, mid, s);
+    upload_vec(M.d, M.h, s);
+    staged.push_back(std::move(mid));
+  }
   SPL_HIP(hipStreamSynchronize(s));
   staged.clear();
-  lap("level lists");
+  D.level_plan = F.lp;
+  }  // build_plan
+  plan_lock.unlock();
+  lap(build_plan ? "level lists (built)" : "level lists (from the tree's cache)");
   DBuf<int> singular(1);
   SPL_HIP(hipMemsetAsync(singular.get(), 0, sizeof(int), s));
   set_factor_attributes();
@@ -1407,11 +1493,7 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
   F.make_streams();
   hipStream_t *side = F.side;
   auto region_of = [&](int d) { return (d & 1) ? region1.get() : region0.get(); };
-  // medium fronts (kSmallFront < size <= mid_limit) go through the lockstep kernels; SPL_MF_MID=0
-  // sends them down the per-front pipeline instead (ablation)
-  const int mid_limit = (getenv("SPL_MF_MID") && atoi(getenv("SPL_MF_MID")) == 0) ? small_limit
-                        : std::max(getenv("SPL_MF_MIDMAX") ? atoi(getenv("SPL_MF_MIDMAX")) : kMidFront, small_limit);
-  std::vector<DBuf<int>> mid_lists;          // alive until the factorisation has run
+  std::vector<DBuf<int>> mid_lists;          // (subtrees of a cut tree: their lists are made on the way) alive until the factorisation has run
   std::vector<DBuf<int64_t>> mid_prefixes;
   std::vector<std::vector<int64_t>> staged64;
   // [begin, end) of the ids lo..hi inside an ascending list
@@ -1423,14 +1505,14 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
     int b0, b1;
     range_of(T.by_depth[(size_t)d], lo, hi, b0, b1);
     if (b1 == b0) return;
-    const int64_t tp = F.h_ptile[(size_t)d][(size_t)b1] - F.h_ptile[(size_t)d][(size_t)b0];
-    const int64_t tu = F.h_utile[(size_t)d][(size_t)b1] - F.h_utile[(size_t)d][(size_t)b0];
+    const int64_t tp = F.lp->h_ptile[(size_t)d][(size_t)b1] - F.lp->h_ptile[(size_t)d][(size_t)b0];
+    const int64_t tu = F.lp->h_utile[(size_t)d][(size_t)b1] - F.lp->h_utile[(size_t)d][(size_t)b0];
     if (tp > 0)
-      hipLaunchKernelGGL(compact_kernel<Z>, dim3((unsigned)tp), dim3(256), 0, q, F.level_lists[(size_t)d].get() + b0,
-                         F.ptile[(size_t)d].get() + b0, b1 - b0, F.view, 0);
+      hipLaunchKernelGGL(compact_kernel<Z>, dim3((unsigned)tp), dim3(256), 0, q, F.lp->level_lists[(size_t)d].get() + b0,
+                         F.lp->ptile[(size_t)d].get() + b0, b1 - b0, F.view, 0);
     if (tu > 0)
-      hipLaunchKernelGGL(compact_kernel<Z>, dim3((unsigned)tu), dim3(256), 0, q, F.level_lists[(size_t)d].get() + b0,
-                         F.utile[(size_t)d].get() + b0, b1 - b0, F.view, 1);
+      hipLaunchKernelGGL(compact_kernel<Z>, dim3((unsigned)tu), dim3(256), 0, q, F.lp->level_lists[(size_t)d].get() + b0,
+                         F.lp->utile[(size_t)d].get() + b0, b1 - b0, F.view, 1);
   };
   // Assembly beside the factorisation (round 4): the fronts of a level live in the region the level two below it
   // used, which is free as soon as the level between them has taken its children's Schur complements.  So while
@@ -1438,7 +1520,6 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
   // scatters the entries of A of level d - 1 into it: of the three parts of an assembly only the extend-add stays on
   // the chain of the levels (at 100^3: 12 of 27 ms).  SPL_MF_OVERLAP=0: everything on the main stream, as before.
   const bool overlap = !(getenv("SPL_MF_OVERLAP") && atoi(getenv("SPL_MF_OVERLAP")) == 0);
-  const bool mid_paired = !(getenv("SPL_MF_MIDPAIR") && atoi(getenv("SPL_MF_MIDPAIR")) == 0);  // 0: K = 64 every step (ablation)
   hipStream_t aux = side[2 * kStreams];
   struct Events {
     hipEvent_t taken = nullptr, prepared = nullptr;  // extend-add of a level queued; region of the next level ready
@@ -1460,10 +1541,10 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
       extent = std::max(extent, plan.foff[(size_t)f] + ((int64_t)T.ld[(size_t)f] * std::max(T.fs(f), 1) + 15) / 16 * 16);
     }
     SPL_HIP(hipMemsetAsync(region_of(d), 0, (size_t)ZM * (size_t)extent * sizeof(double), q));
-    const int64_t groups = F.h_atile[(size_t)d][(size_t)b1] - F.h_atile[(size_t)d][(size_t)b0];
+    const int64_t groups = F.lp->h_atile[(size_t)d][(size_t)b1] - F.lp->h_atile[(size_t)d][(size_t)b0];
     if (groups > 0)
-      hipLaunchKernelGGL(assemble_kernel<Z>, dim3((unsigned)groups), dim3(256), 0, q, F.level_lists[(size_t)d].get() + b0,
-                         F.atile[(size_t)d].get() + b0, b1 - b0, F.view, d_perm, d_inv, d_Ap, d_Ai, d_Ax, d_Rp, d_Rj, d_Rx);
+      hipLaunchKernelGGL(assemble_kernel<Z>, dim3((unsigned)groups), dim3(256), 0, q, F.lp->level_lists[(size_t)d].get() + b0,
+                         F.lp->atile[(size_t)d].get() + b0, b1 - b0, F.view, d_perm, d_inv, d_Ap, d_Ai, d_Ax, d_Rp, d_Rj, d_Rx);
     return extent;
   };
   // levels dbot .. dtop (bottom-up) of the fronts with ids lo..hi.  children_saved: the children of
@@ -1484,12 +1565,12 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
       if (d + 1 < nd) {
         for (int sl = 0; sl < 2; ++sl) {
           int c0, c1;
-          range_of(F.h_child[sl][(size_t)d], lo, hi, c0, c1);
+          range_of(F.lp->h_child[sl][(size_t)d], lo, hi, c0, c1);
           if (c1 == c0) continue;
-          const int64_t tc = F.h_ctile[sl][(size_t)d][(size_t)c1] - F.h_ctile[sl][(size_t)d][(size_t)c0];
+          const int64_t tc = F.lp->h_ctile[sl][(size_t)d][(size_t)c1] - F.lp->h_ctile[sl][(size_t)d][(size_t)c0];
           if (tc > 0)
             hipLaunchKernelGGL(extend_add_kernel<Z>, dim3((unsigned)tc), dim3(256), 0, s,
-                               F.child_lists[sl][(size_t)d].get() + c0, F.ctile[sl][(size_t)d].get() + c0, c1 - c0,
+                               F.lp->child_lists[sl][(size_t)d].get() + c0, F.lp->ctile[sl][(size_t)d].get() + c0, c1 - c0,
                                F.view);
         }
         // the children are done with: keep their panels, their region is free again (subtree
@@ -1513,9 +1594,9 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
         if (d + 1 < nd)
           for (int sl = 0; sl < 2; ++sl) {
             int c0, c1;
-            range_of(F.h_child[sl][(size_t)d], lo, hi, c0, c1);
+            range_of(F.lp->h_child[sl][(size_t)d], lo, hi, c0, c1);
             for (int i = c0; i < c1; ++i) {
-              const int c = F.h_child[sl][(size_t)d][(size_t)i];
+              const int c = F.lp->h_child[sl][(size_t)d][(size_t)i];
               const double q = T.nb[(size_t)c], pp = T.np[(size_t)c];
               ea += symmetric ? q * (q + 1) / 2 : q * q;
               cp += pp * (pp + 2 * q);
@@ -1527,49 +1608,42 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
         lap(what);
       }
       int s0, s1;
-      range_of(F.h_small[(size_t)d], lo, hi, s0, s1);
+      range_of(F.lp->h_small[(size_t)d], lo, hi, s0, s1);
       if (s1 > s0)
         hipLaunchKernelGGL(front_factor_kernel<Z>, dim3((unsigned)(s1 - s0)), dim3(256), Z ? kFrontLdsZ : 2 * kTileBytes, s,
-                           F.small_lists[(size_t)d].get() + s0, F.view, F.invs.get(), singular.get());
+                           F.lp->small_lists[(size_t)d].get() + s0, F.view, F.invs.get(), singular.get());
       // medium fronts: lockstep over block steps, one flat launch per phase and step
       {
-        std::vector<int> mid;
-        int steps = 0;
-        for (int i = b0; i < b1; ++i) {
-          const int f = T.by_depth[(size_t)d][(size_t)i];
-          if (T.np[(size_t)f] == 0 || T.fs(f) <= small_limit || T.fs(f) > mid_limit) continue;
-          mid.push_back(f);
-          steps = std::max(steps, (T.np[(size_t)f] + NB - 1) / NB);
-        }
-        if (!mid.empty()) {
-          const int count = (int)mid.size();
-          // prefix arrays of all steps: [step][phase 0 = panel solves, 1 = update][count + 1]
-          std::vector<int64_t> pre((size_t)steps * 2 * (size_t)(count + 1), 0);
-          for (int st = 0; st < steps; ++st) {
-            int64_t *pt = pre.data() + ((size_t)st * 2) * (size_t)(count + 1), *pu = pt + (count + 1);
-            for (int k = 0; k < count; ++k) {
-              const int f = mid[(size_t)k], np = T.np[(size_t)f], j0 = st * NB;
-              int64_t tt = 0, tu = 0;
-              if (j0 < np) {
-                const int jb = std::min(NB, np - j0), rest = T.fs(f) - (j0 + jb);
-                const int64_t nt = (rest + 63) / 64;
-                tt = 2 * nt;
-                tu = nt * nt;
-                if (mid_paired && !(st & 1) && np >= j0 + jb + NB) tu = 2 * nt - 1;  // (the L-shaped pass of an even step)
-              }
-              pt[k + 1] = pt[k] + tt;
-              pu[k + 1] = pu[k] + tu;
-            }
+        int count = 0, steps = 0;
+        const int *dl = nullptr;
+        const int64_t *dp = nullptr;
+        const std::vector<int64_t> *hpp = nullptr;
+        if (b0 == 0 && b1 == (int)T.by_depth[(size_t)d].size()) {  // the whole level: from the plan
+          const mf::LevelPlan::Mid &M = F.lp->mid[(size_t)d];
+          count = M.count;
+          steps = M.steps;
+          dl = M.list.get();
+          dp = M.d.get();
+          hpp = &M.h;
+        } else {  // a subtree of a cut tree
+          std::vector<int> mid;
+          std::vector<int64_t> pre;
+          mid_fronts_of(T.by_depth[(size_t)d], b0, b1, mid, steps, pre);
+          count = (int)mid.size();
+          if (count > 0) {
+            mid_lists.emplace_back();
+            mid_prefixes.emplace_back();
+            upload_vec(mid_lists.back(), mid, s);
+            upload_vec(mid_prefixes.back(), pre, s);
+            staged.push_back(std::move(mid));
+            staged64.push_back(std::move(pre));
+            dl = mid_lists.back().get();
+            dp = mid_prefixes.back().get();
+            hpp = &staged64.back();
           }
-          mid_lists.emplace_back();
-          mid_prefixes.emplace_back();
-          upload_vec(mid_lists.back(), mid, s);
-          upload_vec(mid_prefixes.back(), pre, s);
-          staged.push_back(std::move(mid));
-          staged64.push_back(std::move(pre));
-          const std::vector<int64_t> &hp = staged64.back();
-          const int *dl = mid_lists.back().get();
-          const int64_t *dp = mid_prefixes.back().get();
+        }
+        if (count > 0) {
+          const std::vector<int64_t> &hp = *hpp;
           hipLaunchKernelGGL(mid_diag_kernel<Z>, dim3((unsigned)count), dim3(256),
                              Z ? kDiagLdsZ : kTileBytes + 2 * NB * sizeof(double), s, dl, F.view, F.invs.get(), singular.get());
           for (int st = 0; st < steps; ++st) {
@@ -1708,15 +1782,15 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
     double bytes = 0.0;
     int maxnp = 0;
     for (int f : T.by_depth[(size_t)d]) {
-      const bool is_big = T.fs(f) > F.big_solve && T.np[(size_t)f] > 0;
+      const bool is_big = T.fs(f) > F.lp->big_solve && T.np[(size_t)f] > 0;
       if (is_big != large) continue;
       const double np = T.np[(size_t)f], nb = T.fs(f) - T.np[(size_t)f];
       bytes += (np * np * 0.5 + np * nb) * 8.0 * F.zm;
       maxnp = std::max(maxnp, T.np[(size_t)f]);
     }
     fprintf(stderr, "[mf_solve] %s level %2d: %4d large of %6zu fronts %8.2f ms  %8.1f MB %6.2f TB/s  steps %d max np %d\n", dir, d,
-            F.big[(size_t)d].count, T.by_depth[(size_t)d].size(), ms, bytes * 1e-6, ms > 0 ? bytes / ms * 1e-9 : 0.0,
-            large ? F.big[(size_t)d].steps : 0, maxnp);
+            F.lp->big[(size_t)d].count, T.by_depth[(size_t)d].size(), ms, bytes * 1e-6, ms > 0 ? bytes / ms * 1e-9 : 0.0,
+            large ? F.lp->big[(size_t)d].steps : 0, maxnp);
     t_last = now;
   };
   if (timing) (void)hipStreamSynchronize(s);
@@ -1726,17 +1800,17 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
   for (int d = nd - 1; d >= 0; --d) {
     if (d + 1 < nd)
       for (int sl = 0; sl < 2; ++sl)
-        if (F.child_counts[sl][(size_t)d] > 0) {
-          const int64_t most = (int64_t)F.child_maxnb[sl][(size_t)d] * NR;  // entries of the largest child
+        if (F.lp->child_counts[sl][(size_t)d] > 0) {
+          const int64_t most = (int64_t)F.lp->child_maxnb[sl][(size_t)d] * NR;  // entries of the largest child
           const unsigned share = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (most + 2047) / 2048));
-          hipLaunchKernelGGL(solve_gather_kernel<NR>, dim3((unsigned)F.child_counts[sl][(size_t)d], share), dim3(256), 0, s,
-                             F.child_lists[sl][(size_t)d].get(), F.view, work);
+          hipLaunchKernelGGL(solve_gather_kernel<NR>, dim3((unsigned)F.lp->child_counts[sl][(size_t)d], share), dim3(256), 0, s,
+                             F.lp->child_lists[sl][(size_t)d].get(), F.view, work);
         }
-    if (F.solve_counts[(size_t)d] > 0)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_forward_kernel<TRANS, NR, Z>), dim3((unsigned)F.solve_counts[(size_t)d]),
-                         dim3(solve_threads<NR>()), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work);
+    if (F.lp->solve_counts[(size_t)d] > 0)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_forward_kernel<TRANS, NR, Z>), dim3((unsigned)F.lp->solve_counts[(size_t)d]),
+                         dim3(solve_threads<NR>()), 0, s, F.lp->solve_lists[(size_t)d].get(), F.view, invs, work);
     lap("up small  ", d);
-    const mf::Factors::BigLevel &B = F.big[(size_t)d];
+    const mf::Factors::BigLevel &B = F.lp->big[(size_t)d];
     if (B.count > 0) {
       // untransposed: the boundary rows get their updates inside the pass over the pivot columns;
       // transposed: U11^T on the pivots, then the boundary with U12^T
@@ -1773,12 +1847,12 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
     lap("up large  ", d);
   }
   for (int d = 0; d < nd; ++d) {
-    if (F.solve_counts[(size_t)d] > 0)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_backward_kernel<TRANS, NR, Z>), dim3((unsigned)F.solve_counts[(size_t)d]),
-                         dim3(solve_threads<NR>()), 0, s, F.solve_lists[(size_t)d].get(), F.view, invs, work, c,
+    if (F.lp->solve_counts[(size_t)d] > 0)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_backward_kernel<TRANS, NR, Z>), dim3((unsigned)F.lp->solve_counts[(size_t)d]),
+                         dim3(solve_threads<NR>()), 0, s, F.lp->solve_lists[(size_t)d].get(), F.view, invs, work, c,
                          stride);
     lap("down small", d);
-    const mf::Factors::BigLevel &B = F.big[(size_t)d];
+    const mf::Factors::BigLevel &B = F.lp->big[(size_t)d];
     if (B.count > 0) {
       if (B.total(4) > 0) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gather_x_kernel<NR, Z>), dim3(B.total(4)), dim3(256), 0, s, B.list.get(),
@@ -1831,9 +1905,9 @@ void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride,
     // right-hand side is two real columns of the work matrices: one at a time, or four together
     constexpr int kGroupZ = 8;  // = kSolveGroup columns of the caller, each a packed complex vector: 16 real columns
     const int nrz = k == 1 ? 2 : 2 * kGroupZ;
-    DBuf<double> wz(((size_t)T.work_elems * 3 + (size_t)F.gemv_scratch) * nrz);  // work, z and carry matrices, scratch of the boundary products
+    DBuf<double> wz(((size_t)T.work_elems * 3 + (size_t)F.lp->gemv_scratch) * nrz);  // work, z and carry matrices, scratch of the boundary products
     double *wk = wz.get(), *zb = wz.get() + (size_t)T.work_elems * nrz, *gs = zb + (size_t)T.work_elems * nrz;
-    double *cb = gs + (size_t)F.gemv_scratch * nrz;
+    double *cb = gs + (size_t)F.lp->gemv_scratch * nrz;
     if (k == 1) {
       if (sys == 0) solve_columns_on_tree<false, 2, true>(F, d_c, stride, wk, zb, gs, cb, s);
       else solve_columns_on_tree<true, 2, true>(F, d_c, stride, wk, zb, gs, cb, s);
@@ -1848,12 +1922,12 @@ void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride,
     return;
   }
   const int nr = k == 1 ? 1 : kSolveGroup;
-  DBuf<double> both(((size_t)T.work_elems * 3 + (size_t)F.gemv_scratch) * nr);  // work, z and carry matrices of all fronts, scratch: one allocation
+  DBuf<double> both(((size_t)T.work_elems * 3 + (size_t)F.lp->gemv_scratch) * nr);  // work, z and carry matrices of all fronts, scratch: one allocation
   struct Span {
     double *p;
     double *get() const { return p; }
   } work{both.get()}, zbuf{both.get() + (size_t)T.work_elems * nr}, gscr{both.get() + (size_t)T.work_elems * nr * 2},
-      cbuf{both.get() + ((size_t)T.work_elems * 2 + (size_t)F.gemv_scratch) * nr};
+      cbuf{both.get() + ((size_t)T.work_elems * 2 + (size_t)F.lp->gemv_scratch) * nr};
   if (k == 1) {
     if (sys == 0) solve_columns_on_tree<false, 1>(F, d_c, stride, work.get(), zbuf.get(), gscr.get(), cbuf.get(), s);
     else solve_columns_on_tree<true, 1>(F, d_c, stride, work.get(), zbuf.get(), gscr.get(), cbuf.get(), s);
