@@ -37,10 +37,13 @@ __global__ __launch_bounds__(256) void nd_stamp_kernel(const int *__restrict__ v
 }
 
 // root of a traversal: level 0 = {root}
-__global__ void nd_root_kernel(int root, int *__restrict__ mark, int stamp, int *__restrict__ queue,
+__global__ void nd_root_kernel(const int64_t *__restrict__ xadj, int root, int *__restrict__ mark, int stamp,
+                               int *__restrict__ queue, int64_t *__restrict__ qbeg, int *__restrict__ qcnt,
                                int *__restrict__ levptr, int *__restrict__ tail, unsigned *__restrict__ blocks_done) {
   mark[root] = stamp;
   queue[0] = root;
+  qbeg[0] = xadj[root];
+  qcnt[0] = (int)(xadj[root + 1] - xadj[root]);
   levptr[0] = 0;
   levptr[1] = 1;
   *tail = 1;
@@ -49,9 +52,14 @@ __global__ void nd_root_kernel(int root, int *__restrict__ mark, int stamp, int 
 
 // level l: the frontier queue[levptr[l], levptr[l + 1]) claims its unreached neighbours (mark == accept -> stamp) and
 // appends them from *tail on; the last workgroup to finish writes levptr[l + 2]
+// (round 4: a level is a chain of dependent memory round trips — level pointers, frontier vertex, its adjacency range,
+// a neighbour, its mark, the claim, the slot, the append, the last workgroup's bookkeeping: ~10 us whatever the size of
+// the frontier.  Two of them are gone: the queue carries every vertex's adjacency range, fetched by whoever claimed it
+// beside the slot reservation, and a neighbour is claimed by the compare-and-swap alone, without reading its mark first.)
 __global__ __launch_bounds__(kBfsThreads) void nd_level_kernel(const int64_t *__restrict__ xadj,
                                                                const int *__restrict__ adj, int *__restrict__ mark,
                                                                int accept, int stamp, int *__restrict__ queue,
+                                                               int64_t *__restrict__ qbeg, int *__restrict__ qcnt,
                                                                int *__restrict__ levptr, int l, int *__restrict__ tail,
                                                                unsigned *__restrict__ blocks_done) {
   const int beg = levptr[l], end = levptr[l + 1];
@@ -66,23 +74,33 @@ __global__ __launch_bounds__(kBfsThreads) void nd_level_kernel(const int64_t *__
     const int i = base + lane / kBfsShare;
     int64_t p = 0, pe = 0;
     if (i < end) {
-      const int v = queue[i];
-      p = xadj[v] + lane % kBfsShare;
-      pe = xadj[v + 1];
+      const int64_t b = qbeg[i];
+      p = b + lane % kBfsShare;
+      pe = b + qcnt[i];
     }
     while (__any(p < pe)) {
       int u = -1;
       if (p < pe) {
         const int cand = adj[p];
         p += kBfsShare;
-        if (mark[cand] == accept && atomicCAS(&mark[cand], accept, stamp) == accept) u = cand;
+        if (atomicCAS(&mark[cand], accept, stamp) == accept) u = cand;
       }
       const unsigned long long won = __ballot(u >= 0);
       if (won) {
+        int64_t ub = 0, ue = 0;
+        if (u >= 0) {  // (requested before the slot: the two round trips overlap)
+          ub = xadj[u];
+          ue = xadj[u + 1];
+        }
         int slot = 0;
         if (lane == __ffsll((long long)won) - 1) slot = atomicAdd(tail, __popcll(won));
         slot = __shfl(slot, __ffsll((long long)won) - 1, 64);
-        if (u >= 0) queue[slot + __popcll(won & ((1ull << lane) - 1ull))] = u;
+        if (u >= 0) {
+          const int at = slot + __popcll(won & ((1ull << lane) - 1ull));
+          queue[at] = u;
+          qbeg[at] = ub;
+          qcnt[at] = (int)(ue - ub);
+        }
       }
     }
   }
@@ -124,6 +142,8 @@ __global__ __launch_bounds__(256) void nd_unkey_kernel(const unsigned long long 
 // every call uses stamps of its own.
 struct Slot {
   int *queue = nullptr, *verts = nullptr, *levptr = nullptr, *counters = nullptr;  // counters: [0] tail, [1] blocks_done
+  int64_t *qbeg = nullptr;  // adjacency range of queue[i]: adj[qbeg[i] .. qbeg[i] + qcnt[i])
+  int *qcnt = nullptr;
   unsigned long long *keys = nullptr, *keys_alt = nullptr;
   char *sort_temp = nullptr;
   std::vector<int> h_levptr;
@@ -197,7 +217,7 @@ struct GpuLevels : mf::LevelService {
     const size_t nnz = (size_t)h_xadj[n], N = (size_t)n;
     sort_temp_bytes = radix_sort_u64_temp_bytes(n);
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t per_slot = up(N * 4) * 2 + up((N + kBatch + 4) * 4) + up(16) + up(N * 8) * 2 + up(sort_temp_bytes ? sort_temp_bytes : 1);
+    const size_t per_slot = up(N * 4) * 3 + up((N + kBatch + 4) * 4) + up(16) + up(N * 8) * 3 + up(sort_temp_bytes ? sort_temp_bytes : 1);
     const size_t total = up((N + 1) * 8) + up((nnz ? nnz : 1) * 4) + up(N * 4) + kSlots * per_slot;
     slab.alloc(std::max<size_t>(total, (size_t)1 << 30));
     lap("slab");
@@ -209,6 +229,8 @@ struct GpuLevels : mf::LevelService {
     for (Slot &sl : slots) {
       sl.queue = reinterpret_cast<int *>(take(N * 4));
       sl.verts = reinterpret_cast<int *>(take(N * 4));
+      sl.qcnt = reinterpret_cast<int *>(take(N * 4));
+      sl.qbeg = reinterpret_cast<int64_t *>(take(N * 8));
       sl.levptr = reinterpret_cast<int *>(take((N + kBatch + 4) * 4));
       sl.counters = reinterpret_cast<int *>(take(16));
       sl.keys = reinterpret_cast<unsigned long long *>(take(N * 8));
@@ -261,7 +283,7 @@ struct GpuLevels : mf::LevelService {
     hipStream_t s = sl.s;
     std::vector<int> &h_levptr = sl.h_levptr;
     unsigned *blocks_done = reinterpret_cast<unsigned *>(sl.counters + 1);
-    hipLaunchKernelGGL(nd_root_kernel, dim3(1), dim3(1), 0, s, root, mark, st, sl.queue, sl.levptr,
+    hipLaunchKernelGGL(nd_root_kernel, dim3(1), dim3(1), 0, s, xadj, root, mark, st, sl.queue, sl.qbeg, sl.qcnt, sl.levptr,
                        sl.counters, blocks_done);
     h_levptr.assign(2, 0);
     h_levptr[1] = 1;
@@ -269,7 +291,7 @@ struct GpuLevels : mf::LevelService {
     for (;;) {
       for (int k = 0; k < kBatch; ++k)
         hipLaunchKernelGGL(nd_level_kernel, dim3(kBfsBlocks), dim3(kBfsThreads), 0, s, xadj, adj, mark,
-                           accept, st, sl.queue, sl.levptr, l + k, sl.counters, blocks_done);
+                           accept, st, sl.queue, sl.qbeg, sl.qcnt, sl.levptr, l + k, sl.counters, blocks_done);
       h_levptr.resize((size_t)l + kBatch + 2);
       SPL_HIP(hipMemcpyAsync(h_levptr.data() + l + 2, sl.levptr + l + 2, (size_t)kBatch * sizeof(int),
                              hipMemcpyDeviceToHost, s));
