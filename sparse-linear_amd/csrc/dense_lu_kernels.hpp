@@ -814,6 +814,19 @@ __device__ __forceinline__ void crecip_straight(double pr, double pi, double &qr
   qr = wide ? u : v;
   qi = wide ? -v : -u;
 }
+// conj(p) / |p|^2: ONE division on the chain of a pivot instead of Smith's two in a row (the reciprocal of the pivot is
+// the longest dependent stretch of a complex panel column: 68 -> 5x us per 64 x 64 block).  |p|^2 must neither overflow
+// nor lose its bits: outside 1e-280 .. 1e280 (pivots beyond 1e+-140) Smith's form takes over — a uniform branch.
+__device__ __forceinline__ void crecip_short(double pr, double pi, double &qr, double &qi) {
+  const double m2 = pr * pr + pi * pi;
+  if (m2 > 1e-280 && m2 < 1e280) {
+    const double inv = 1.0 / m2;
+    qr = pr * inv;
+    qi = -pi * inv;
+  } else {
+    crecip_straight(pr, pi, qr, qi);
+  }
+}
 
 // diag_block_factor in complex arithmetic: same register layout (lane = row, wave w owns the columns c = w mod 4),
 // same pivot loop, two registers per entry
@@ -1047,7 +1060,7 @@ __device__ __forceinline__ void diag_block_factor_blocked_z(const Band &b, int j
         const bool zero = pr == 0.0 && pi == 0.0;
         zero_pivot |= zero;
         double qr, qi;
-        crecip_straight(zero ? 1.0 : pr, pi, qr, qi);
+        crecip_short(zero ? 1.0 : pr, pi, qr, qi);
         const bool below = lane > k && !zero;
         const double tr_ = ar[kk] * qr - ai[kk] * qi, ti_ = ar[kk] * qi + ai[kk] * qr;
         ar[kk] = below ? tr_ : ar[kk];
