@@ -38,6 +38,11 @@ void device_free(void *p) noexcept;
 size_t device_free_bytes();      // free memory as the driver reports it + what the pool would give back
 size_t device_release_cached();  // returns the bytes given back to the driver
 double device_alloc_seconds();  // seconds spent inside hipMalloc so far (pool misses)
+// Non-blocking streams, kept for the life of the process (device_pool.hip): creating one costs 0.3 - 0.6 ms here and the
+// first of a process 15 ms; the analysis takes four for its level structures, a factorisation seventeen per host thread.
+hipStream_t pooled_stream_take(int device);            // an idle one of this device, or a new one (nullptr: creation failed)
+void pooled_stream_give(int device, hipStream_t s);    // back, once its work is complete
+void pooled_streams_prewarm(int device, int count);    // create streams until `count` are idle (another thread may take them meanwhile)
 
 // RAII device buffer, movable
 template <typename T>

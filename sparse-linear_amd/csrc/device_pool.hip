@@ -17,6 +17,7 @@
 #include <map>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "common.hpp"
 
@@ -154,6 +155,63 @@ size_t device_free_bytes() {
 }
 
 double device_alloc_seconds() { return (double)g_alloc_ns.load() * 1e-9; }
+
+namespace {
+struct StreamPool {
+  std::mutex mu;
+  std::vector<std::pair<int, hipStream_t>> idle;
+};
+StreamPool &stream_pool() {
+  static StreamPool *p = new StreamPool();  // never destroyed, like the streams in it
+  return *p;
+}
+}  // namespace
+
+hipStream_t pooled_stream_take(int device) {
+  StreamPool &P = stream_pool();
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (size_t i = 0; i < P.idle.size(); ++i)
+      if (P.idle[i].first == device) {
+        hipStream_t s = P.idle[i].second;
+        P.idle.erase(P.idle.begin() + (ptrdiff_t)i);
+        return s;
+      }
+  }
+  DeviceGuard g(device);
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return s;
+}
+
+void pooled_stream_give(int device, hipStream_t s) {
+  if (!s) return;
+  StreamPool &P = stream_pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  P.idle.emplace_back(device, s);
+}
+
+void pooled_streams_prewarm(int device, int count) {
+  StreamPool &P = stream_pool();
+  for (;;) {
+    {
+      std::lock_guard<std::mutex> lk(P.mu);
+      int have = 0;
+      for (const auto &e : P.idle) have += e.first == device;
+      if (have >= count) return;
+    }
+    DeviceGuard g(device);
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    pooled_stream_give(device, s);
+  }
+}
 
 size_t device_release_cached() {
   Pool &P = pool();

@@ -1079,7 +1079,10 @@ struct Factors {
       // kStreams for the fronts, kStreams beside them for the look-ahead tiles of their large windows, one for the
       // assembly work that runs beside the factorisation of a level (mf_factor_t)
       std::unique_ptr<hipStream_t[]> fresh(new hipStream_t[2 * kStreams + 1]);
-      for (int i = 0; i < 2 * kStreams + 1; ++i) SPL_HIP(hipStreamCreateWithFlags(&fresh[i], hipStreamNonBlocking));
+      for (int i = 0; i < 2 * kStreams + 1; ++i) {  // (from the pool the analysis filled beside its own work, or new)
+        fresh[i] = pooled_stream_take(device);
+        if (!fresh[i]) throw DeviceError{SPL_ERROR_internal};
+      }
       set = std::move(fresh);
     }
     side = set.get();

@@ -151,35 +151,6 @@ struct Slot {
   bool busy = false;
 };
 
-// Streams of finished analyses, per device, for the next one: creating one costs 0.3 - 0.6 ms here (2 ms per analysis, 19 ms
-// for the first of a process), destroying it again as much.  Never destroyed.
-struct StreamPool {
-  std::mutex mu;
-  std::vector<std::pair<int, hipStream_t>> idle;
-  hipStream_t take(int device) {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      for (size_t i = 0; i < idle.size(); ++i)
-        if (idle[i].first == device) {
-          hipStream_t s = idle[i].second;
-          idle.erase(idle.begin() + (ptrdiff_t)i);
-          return s;
-        }
-    }
-    hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    return s;
-  }
-  void give(int device, hipStream_t s) {
-    std::lock_guard<std::mutex> lk(mu);
-    idle.emplace_back(device, s);
-  }
-};
-StreamPool &stream_pool() {
-  static StreamPool *p = new StreamPool();
-  return *p;
-}
-
 struct GpuLevels : mf::LevelService {
   static constexpr int kSlots = 4;
   int device = 0;
@@ -200,7 +171,7 @@ struct GpuLevels : mf::LevelService {
     for (Slot &sl : slots)
       if (sl.s) {
         (void)hipStreamSynchronize(sl.s);
-        stream_pool().give(device, sl.s);
+        pooled_stream_give(device, sl.s);
       }
   }
 
@@ -236,10 +207,10 @@ struct GpuLevels : mf::LevelService {
       sl.keys = reinterpret_cast<unsigned long long *>(take(N * 8));
       sl.keys_alt = reinterpret_cast<unsigned long long *>(take(N * 8));
       sl.sort_temp = take(sort_temp_bytes ? sort_temp_bytes : 1);
-      sl.s = stream_pool().take(device);
+      sl.s = pooled_stream_take(device);
       if (!sl.s) {
         for (Slot &made : slots)
-          if (made.s) stream_pool().give(device, made.s);
+          if (made.s) pooled_stream_give(device, made.s);
         throw DeviceError{SPL_ERROR_internal};
       }
     }
@@ -253,7 +224,7 @@ struct GpuLevels : mf::LevelService {
       lap("copies");
     } catch (...) {  // (the destructor does not run for an object whose constructor throws)
       for (Slot &sl : slots)
-        if (sl.s) stream_pool().give(device, sl.s);
+        if (sl.s) pooled_stream_give(device, sl.s);
       throw;
     }
   }
