@@ -42,8 +42,13 @@
  * sizes are planned ahead), B is ordered, factored without interchanges and checked like any
  * speculation.  Only if that fails too: the band factorisation with partial pivoting (when its
  * band does not fit the HBM — a large mesh — solve returns UMFPACK_ERROR_out_of_memory and the
- * object keeps its previous factors).  SPL_LU_STATIC_PIVOT=0 skips the first stage.  SPL_LU_METHOD=band|mf forces the ordering.  Square matrices only (the reference's linearSolve_
- * assumes square, Umfpack.hs:93).
+ * object keeps its previous factors).  SPL_LU_STATIC_PIVOT=0 skips the first stage.  SPL_LU_METHOD=band|mf forces the ordering.
+ * RECTANGULAR matrices (n_row != n_col) are analysed and "factored" as far as the reference's binding can observe:
+ * symbolic records shape and pattern, numeric checks the pattern and returns UMFPACK_OK when min(n_row, n_col) non-zero
+ * pivots exist at all (the structural rank over the non-zero entries; UMFPACK counts the non-zero pivots it found) and
+ * UMFPACK_WARNING_singular_matrix otherwise, without factoring anything; every solve returns
+ * UMFPACK_ERROR_invalid_system, as UMFPACK's does ("the matrix is not square"; the reference's linearSolve_ assumes
+ * square, Umfpack.hs:93).
  * The complex (`zi`) entry points (Internal.hs:69-115): a Numeric object holds the real 2n x 2n
  * embedding with interleaved unknowns (csrc/umfpack_zi.hip) — packed complex arrays (imaginary
  * pointer NULL, the only form the reference uses, Internal.hs:124-132) ARE the real arrays of the

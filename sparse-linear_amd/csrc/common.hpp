@@ -220,6 +220,12 @@ double symbolic_tree_flops(void *Symbolic);  // LU flops of the multifrontal tre
 int numeric_of_embedding(const int *Ep, const int *Ei, const double *Ex, void *Symbolic, void **Numeric, int native = 0);
 bool symbolic_has_complex_tree(void *Symbolic);  // the analysis kept the tree of the complex pattern (native complex fronts possible)
 uint64_t pattern_hash(const int *Ai, int64_t nnz);
+// rectangular matrices (umfpack.hip, Symbolic::rectangular): analysed and "factored" as far as the reference's binding
+// can observe — statuses; solves return UMFPACK_ERROR_invalid_system as UMFPACK's do
+int symbolic_rectangular(int n_row, int n_col, const int *Ap, const int *Ai, void **Symbolic);
+bool symbolic_is_rectangular(void *Symbolic);
+int numeric_rectangular_of(void *Symbolic, const int *Ap, const int *Ai, const std::vector<char> &nonzero, void **Numeric);
+bool numeric_is_rectangular(void *Numeric);
 void finalize_matrix(Matrix *m, hipStream_t s);
 int spmv_cus(const Matrix *m);  // CUs the persistent SpMV images are laid out for: the device's minus the reserved ones
 void measure_locality(Matrix *m, hipStream_t s);  // fills new_line_fraction on first call

@@ -57,6 +57,15 @@ struct Symbolic {
   // (tree is its expansion): what the native complex fronts are built on
   std::shared_ptr<const mf::Tree> ztree;
   bool have_band = false;  // perm / inv / kl / ku are set (large matrices whose tree wins by a lower bound skip them)
+  // Rectangular matrices (round 4).  UMFPACK analyses and factors them and refuses to SOLVE with them
+  // (UMFPACK_ERROR_invalid_system: "the matrix is not square"); through the reference's binding nothing of such a
+  // factorisation is observable but the statuses (Umfpack.hs:60-102 binds symbolic, numeric, solve and the frees).
+  // Here: the analysis records the shape and the pattern, the numeric call checks the pattern and reports whether a
+  // full set of min(n_row, n_col) non-zero pivots exists at all — the structural rank over the non-zero entries, where
+  // UMFPACK counts the non-zero pivots it found (UMFPACK_WARNING_singular_matrix otherwise) — and holds no factors;
+  // the solve returns UMFPACK_ERROR_invalid_system as UMFPACK's does.
+  int n_row = 0, n_col = 0;
+  bool rectangular = false;
 };
 
 struct Numeric {
@@ -64,6 +73,7 @@ struct Numeric {
   int device = 0;
   int n = 0, kl = 0, ku = 0, ldab = 1;
   int singular = 0;
+  int rectangular = 0;  // 1: of a rectangular matrix (Symbolic::rectangular): no factors, solves return invalid_system
   int nopiv = 0;  // 1: blocked factorisation without interchanges
   int mf_sym = 0;  // 1: the multifrontal factors held are those of a symmetric matrix (L D L^T: half the update flops)
   // Native complex fronts (round 3).  This object holds the real embedding E of a complex matrix (umfpack_zi.hip) for
@@ -1080,6 +1090,123 @@ static int symbolic_common(int n, const int *Ap, const int *Ai, int mult, const 
   }
 }
 
+}  // extern "C"
+
+namespace spl {
+// analysis of a rectangular matrix: shape and pattern only (Symbolic::rectangular)
+int symbolic_rectangular(int n_row, int n_col, const int *Ap, const int *Ai, void **SymbolicOut) {
+  try {
+    std::unique_ptr<Symbolic> S(new Symbolic());
+    S->rectangular = true;
+    S->n_row = n_row;
+    S->n_col = n_col;
+    S->n = n_col;
+    S->nnz = Ap[n_col];
+    S->Ap.assign(Ap, Ap + n_col + 1);
+    S->ai_hash = hash_indices(Ai, S->nnz);
+    *SymbolicOut = S.release();
+    return UMFPACK_OK;
+  } catch (const std::bad_alloc &) {
+    return UMFPACK_ERROR_out_of_memory;
+  } catch (...) {
+    return UMFPACK_ERROR_internal_error;
+  }
+}
+// size of a maximum matching of the columns to the rows over the entries keep[p] != 0: augmenting paths by depth-first
+// search with a look-ahead for free rows (Duff's MC21), iterative; O(n_col nnz) at worst, near-linear on what occurs
+int structural_rank(int n_row, int n_col, const int *Ap, const int *Ai, const std::vector<char> &keep) {
+  std::vector<int> col_of_row((size_t)n_row, -1), look((size_t)n_col), seen((size_t)n_row, -1);
+  for (int j = 0; j < n_col; ++j) look[(size_t)j] = Ap[j];
+  std::vector<int> stack_col, stack_pos, row_of;
+  int rank = 0;
+  for (int j0 = 0; j0 < n_col; ++j0) {
+    stack_col.assign(1, j0);
+    stack_pos.assign(1, Ap[j0]);
+    row_of.assign(1, -1);  // the row through which a column on the stack was reached
+    bool found = false;
+    while (!stack_col.empty() && !found) {
+      const int j = stack_col.back();
+      int free_row = -1;
+      for (int &p = look[(size_t)j]; p < Ap[j + 1]; ++p)  // look-ahead: every entry of a column is tested once for a free row
+        if (keep[(size_t)p] && col_of_row[(size_t)Ai[p]] < 0) { free_row = Ai[p]; ++p; break; }
+      bool pushed = false;
+      if (free_row < 0)
+        for (int &p = stack_pos.back(); p < Ap[j + 1]; ++p) {
+          const int i = Ai[p];
+          if (!keep[(size_t)p] || seen[(size_t)i] == j0) continue;
+          seen[(size_t)i] = j0;
+          const int next_col = col_of_row[(size_t)i];
+          ++p;
+          if (next_col < 0) {  // (matched rows stay matched, so the look-ahead has seen every free one; kept for safety)
+            free_row = i;
+            break;
+          }
+          stack_col.push_back(next_col);
+          stack_pos.push_back(Ap[next_col]);
+          row_of.push_back(i);
+          pushed = true;
+          break;
+        }
+      if (free_row >= 0) {
+        // augment along the stack: the last column takes the free row, every column before it the row that led on from it
+        int r = free_row;
+        for (size_t k = stack_col.size(); k-- > 0;) {
+          col_of_row[(size_t)r] = stack_col[k];
+          r = row_of[k];
+        }
+        found = true;
+        break;
+      }
+      if (!pushed) {
+        stack_col.pop_back();
+        stack_pos.pop_back();
+        row_of.pop_back();
+      }
+    }
+    rank += found ? 1 : 0;
+  }
+  return rank;
+}
+// "factorisation" of a rectangular matrix: the pattern check and the status (Symbolic::rectangular)
+int numeric_rectangular(Symbolic *S, const int *Ap, const int *Ai, const std::vector<char> &nonzero, void **NumericOut) {
+  if (Ap[S->n_col] != S->nnz || !std::equal(S->Ap.begin(), S->Ap.end(), Ap) || hash_indices(Ai, S->nnz) != S->ai_hash)
+    return UMFPACK_ERROR_different_pattern;
+  try {
+    std::unique_ptr<Numeric> N(new Numeric());
+    N->rectangular = 1;
+    N->n = 0;
+    if (hipGetDevice(&N->device) != hipSuccess) {
+      (void)hipGetLastError();
+      N->device = 0;
+    }
+    const int rank = structural_rank(S->n_row, S->n_col, Ap, Ai, nonzero);
+    N->singular = rank < std::min(S->n_row, S->n_col) ? 1 : 0;
+    const int st = N->singular ? UMFPACK_WARNING_singular_matrix : UMFPACK_OK;
+    *NumericOut = N.release();
+    return st;
+  } catch (const std::bad_alloc &) {
+    return UMFPACK_ERROR_out_of_memory;
+  } catch (...) {
+    return UMFPACK_ERROR_internal_error;
+  }
+}
+bool symbolic_is_rectangular(void *SymbolicIn) {
+  Symbolic *S = as_symbolic(SymbolicIn);
+  return S && S->rectangular;
+}
+int numeric_rectangular_of(void *SymbolicIn, const int *Ap, const int *Ai, const std::vector<char> &nonzero, void **NumericOut) {
+  Symbolic *S = as_symbolic(SymbolicIn);
+  if (!S || !S->rectangular) return UMFPACK_ERROR_invalid_Symbolic_object;
+  return numeric_rectangular(S, Ap, Ai, nonzero, NumericOut);
+}
+bool numeric_is_rectangular(void *NumericIn) {
+  Numeric *N = as_numeric(NumericIn);
+  return N && N->rectangular;
+}
+}  // namespace spl
+
+extern "C" {
+
 int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], const double Ax[],
                         void **SymbolicOut, const double Control[], double Info[]) {
   (void)Ax; (void)Control; (void)Info;
@@ -1087,10 +1214,10 @@ int umfpack_di_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
   *SymbolicOut = nullptr;
   if (!Ap || (!Ai && n_col > 0 && Ap[n_col] > 0)) return UMFPACK_ERROR_argument_missing;
   if (n_row <= 0 || n_col <= 0) return UMFPACK_ERROR_n_nonpositive;
-  if (n_row != n_col) return UMFPACK_ERROR_invalid_system;  // square systems only (Umfpack.hs:93)
   if (Ap[n_col] < 0) return UMFPACK_ERROR_invalid_matrix;
   int st = validate_host_csc(n_row, n_col, Ap, Ai);
   if (st != UMFPACK_OK) return st;
+  if (n_row != n_col) return symbolic_rectangular(n_row, n_col, Ap, Ai, SymbolicOut);
   return symbolic_common(n_col, Ap, Ai, 1, Ap, Ai, SymbolicOut);
 }
 
@@ -1142,6 +1269,12 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
   Symbolic *S = as_symbolic(SymbolicIn);
   if (!S) return UMFPACK_ERROR_invalid_Symbolic_object;
   if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;
+  if (S->rectangular) {
+    if (Ap[S->n_col] != S->nnz) return UMFPACK_ERROR_different_pattern;
+    std::vector<char> nonzero((size_t)S->nnz);
+    for (int p = 0; p < S->nnz; ++p) nonzero[(size_t)p] = (Ax[p] != 0.0 && Ax[p] == Ax[p]) ? 1 : 0;  // (NaN: no pivot)
+    return numeric_rectangular(S, Ap, Ai, nonzero, NumericOut);
+  }
   const int n = S->n;
   // (the `zi` wrapper has compared the complex pattern — a quarter of the embedding's — and vouches for the rest)
   if (!t_pattern_vouched &&
@@ -1611,6 +1744,7 @@ int umfpack_di_solve(int sys, const int Ap[], const int Ai[], const double Ax[],
   (void)Control;
   Numeric *N = as_numeric(NumericIn);
   if (!N) return UMFPACK_ERROR_invalid_Numeric_object;
+  if (N->rectangular) return UMFPACK_ERROR_invalid_system;  // "the matrix is not square", as UMFPACK's solve
   if (!X || !B) return UMFPACK_ERROR_argument_missing;
   if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;  // UMFPACK needs A for refinement
   if (sys != UMFPACK_A && sys != UMFPACK_At) return UMFPACK_ERROR_invalid_system;
@@ -1622,6 +1756,7 @@ int spl_umfpack_di_solve_many(int sys, const int Ap[], const int Ai[], const dou
                               const double B[], void *NumericIn) {
   Numeric *N = as_numeric(NumericIn);
   if (!N) return UMFPACK_ERROR_invalid_Numeric_object;
+  if (N->rectangular) return UMFPACK_ERROR_invalid_system;
   if (nrhs < 0) return UMFPACK_ERROR_argument_missing;
   if (nrhs > 0 && N->n > 0 && (!X || !B)) return UMFPACK_ERROR_argument_missing;
   if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;
@@ -1634,6 +1769,7 @@ int spl_umfpack_di_solve_many_dev(int sys, const int Ap[], const int Ai[], const
                                   const double *d_B, void *NumericIn) {
   Numeric *N = as_numeric(NumericIn);
   if (!N) return UMFPACK_ERROR_invalid_Numeric_object;
+  if (N->rectangular) return UMFPACK_ERROR_invalid_system;
   if (nrhs < 0) return UMFPACK_ERROR_argument_missing;
   if (nrhs > 0 && N->n > 0 && (!d_X || !d_B)) return UMFPACK_ERROR_argument_missing;
   if (sys != UMFPACK_A && sys != UMFPACK_At) return UMFPACK_ERROR_invalid_system;

@@ -226,12 +226,23 @@ int umfpack_zi_symbolic(int n_row, int n_col, const int Ap[], const int Ai[], co
   *Symbolic = nullptr;
   if (!Ap) return UMFPACK_ERROR_argument_missing;
   if (n_row <= 0 || n_col <= 0) return UMFPACK_ERROR_n_nonpositive;
-  if (n_row != n_col) return UMFPACK_ERROR_invalid_system;
   if (Ap[0] != 0 || Ap[n_col] < 0 || (Ap[n_col] > 0 && !Ai)) return UMFPACK_ERROR_invalid_matrix;
   for (int j = 0; j < n_col; ++j) {
     if (Ap[j] > Ap[j + 1]) return UMFPACK_ERROR_invalid_matrix;
     for (int p = Ap[j]; p < Ap[j + 1]; ++p)
       if (Ai[p] < 0 || Ai[p] >= n_row || (p > Ap[j] && Ai[p] <= Ai[p - 1])) return UMFPACK_ERROR_invalid_matrix;
+  }
+  if (n_row != n_col) {  // rectangular: shape and pattern only (umfpack.hip, Symbolic::rectangular)
+    try {
+      ZiSymbolic *S = new ZiSymbolic();
+      S->n = n_col;
+      const int st = spl::symbolic_rectangular(n_row, n_col, Ap, Ai, &S->di);
+      if (st < 0) { delete S; return st; }
+      *Symbolic = S;
+      return st;
+    } catch (...) {
+      return UMFPACK_ERROR_out_of_memory;
+    }
   }
   try {
     Embedded E;
@@ -260,6 +271,20 @@ int umfpack_zi_numeric(const int Ap[], const int Ai[], const double Ax[], const 
   ZiSymbolic *S = static_cast<ZiSymbolic *>(Symbolic);
   if (!S || S->magic != 0x5A53594Du) return UMFPACK_ERROR_invalid_Symbolic_object;
   if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;
+  if (spl::symbolic_is_rectangular(S->di)) {
+    try {
+      const int nnz = Ap[S->n];
+      if (nnz < 0) return UMFPACK_ERROR_different_pattern;
+      std::vector<char> nonzero((size_t)nnz);
+      for (int p = 0; p < nnz; ++p) {
+        const double re = Az ? Ax[p] : Ax[2 * (size_t)p], im = Az ? Az[p] : Ax[2 * (size_t)p + 1];
+        nonzero[(size_t)p] = ((re != 0.0 || im != 0.0) && re == re && im == im) ? 1 : 0;
+      }
+      return spl::numeric_rectangular_of(S->di, Ap, Ai, nonzero, Numeric);
+    } catch (...) {
+      return UMFPACK_ERROR_out_of_memory;
+    }
+  }
   try {
     // Static pivoting inside the 2 x 2 blocks of the diagonal.  The scalar factorisation of the
     // embedding pivots on the REAL part of a complex diagonal entry first; where the imaginary part
@@ -347,6 +372,7 @@ int umfpack_zi_solve(int sys, const int Ap[], const int Ai[], const double Ax[],
                      double Xx[], double Xz[], const double Bx[], const double Bz[], void *Numeric,
                      const double Control[], double Info[]) {
   (void)Az;
+  if (spl::numeric_is_rectangular(Numeric)) return UMFPACK_ERROR_invalid_system;
   if (!Xx || !Bx) return UMFPACK_ERROR_argument_missing;
   if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;
   // the Numeric object holds device copies of E and E^T (residuals use those, like the `di` path)
@@ -388,6 +414,7 @@ int spl_umfpack_zi_solve_many(int sys, const int Ap[], const int Ai[], const dou
                               int nrhs, double Xx[], double Xz[], const double Bx[], const double Bz[],
                               void *Numeric) {
   (void)Az;
+  if (spl::numeric_is_rectangular(Numeric)) return UMFPACK_ERROR_invalid_system;
   if (nrhs < 0) return UMFPACK_ERROR_argument_missing;
   if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;
   const int n2 = spl_umfpack_dimension(Numeric);
@@ -428,6 +455,7 @@ int spl_umfpack_zi_solve_many(int sys, const int Ap[], const int Ai[], const dou
 // packed complex right-hand sides and solutions in device memory (see umfpack_hip.h)
 int spl_umfpack_zi_solve_many_dev(int sys, const int Ap[], const int Ai[], const double Ax[], int nrhs, double *d_X,
                                   const double *d_B, void *Numeric) {
+  if (spl::numeric_is_rectangular(Numeric)) return UMFPACK_ERROR_invalid_system;
   if (nrhs < 0) return UMFPACK_ERROR_argument_missing;
   const int n2 = spl_umfpack_dimension(Numeric);
   if (n2 < 0 || (n2 == 0 && !Numeric)) return UMFPACK_ERROR_invalid_Numeric_object;

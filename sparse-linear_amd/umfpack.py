@@ -21,6 +21,10 @@ UmfpackTrans = 1   # sys = UMFPACK_At
 class UmfpackError(RuntimeError):
     """negative status: the reference calls errorWithStackTrace (Umfpack.hs:67,81,101)"""
 
+    def __init__(self, message, status=None):
+        super().__init__(message)
+        self.status = status  # the UMFPACK status behind it (None: raised by a check of this mirror)
+
 
 def _declare():
     L = lib()
@@ -74,7 +78,7 @@ def _report(where, status):
     L = _declare()
     L.umfpack_di_report_status(None, status)  # umfpack_report_status mat nullPtr _stat
     if status < 0:
-        raise UmfpackError("%s failed (status %d)" % (where, status))
+        raise UmfpackError("%s failed (status %d)" % (where, status), status)
     return status
 
 

@@ -120,10 +120,7 @@ def test_status_codes(gpu, pkg):
     B = pkg.fromTriples(3, 3, [(0, 0, 1.0), (1, 1, 1.0), (2, 2, 1.0), (0, 2, 1.0)])
     with pytest.raises(pkg.umfpack.UmfpackError):
         pkg.umfpack.factor(B, an)
-    # non-square, bad handles
-    R = pkg.zeros(2, 3)
-    with pytest.raises(pkg.umfpack.UmfpackError):
-        pkg.umfpack.analyze(R)
+    # bad handles (rectangular matrices: test_rectangular_matrices_are_analysed_factored_and_refused_by_solve)
     x = np.zeros(3)
     ap = (C.c_int * 4)(0, 1, 2, 3)
     ai = (C.c_int * 3)(0, 1, 2)
@@ -132,6 +129,50 @@ def test_status_codes(gpu, pkg):
     h = C.c_void_p()
     L.umfpack_di_free_numeric(C.byref(h))  # NULL: no-op
     L.umfpack_di_free_symbolic(C.byref(h))
+
+
+def test_rectangular_matrices_are_analysed_factored_and_refused_by_solve(gpu, pkg):
+    """UMFPACK analyses and factors rectangular matrices and refuses to solve with them (UMFPACK_ERROR_invalid_system,
+    "the matrix is not square"); the reference's binding passes n_row and n_col through (Umfpack.hs:60-69) and throws
+    on negative statuses only.  Here the statuses follow UMFPACK's: symbolic 0, numeric 0 for full structural rank over
+    the non-zero entries and the singular-matrix warning (+1) otherwise, different_pattern as for square matrices, solve
+    -13 in every form; real and complex; nothing is factored (round 4; rounds 1 - 3 refused at the analysis)."""
+    import ctypes as C
+    U = pkg.umfpack
+    wide = pkg.fromTriples(2, 3, [(0, 0, 1.0), (1, 1, 2.0), (0, 2, 3.0)])          # rank 2 = min(2, 3)
+    tall = pkg.fromTriples(4, 2, [(0, 0, 1.0), (3, 0, 2.0), (3, 1, 3.0)])          # rank 2: column 1 must take row 3, column 0 row 0
+    short = pkg.fromTriples(3, 2, [(2, 0, 1.0), (2, 1, 1.0)])                      # both columns only reach row 2: rank 1
+    zeroed = pkg.fromTriples(2, 3, [(0, 0, 0.0), (1, 1, 2.0), (0, 2, 0.0)])        # stored zeros are no pivots: rank 1
+    for mat, want in ((wide, 0), (tall, 0), (short, 1), (zeroed, 1)):
+        an = U.analyze(mat)
+        f = U.factor(mat, an)
+        assert f.status == want
+        with pytest.raises(U.UmfpackError) as e:
+            U.linearSolve_(f, U.UmfpackNormal, mat, np.ones(mat.nrows))
+        assert e.value.status == -13
+        with pytest.raises(U.UmfpackError):
+            U.linearSolveMany_(f, U.UmfpackTrans, mat, [np.ones(mat.nrows)] * 2)
+    # the pattern is checked as for square matrices
+    other = pkg.fromTriples(2, 3, [(0, 0, 1.0), (1, 1, 2.0), (1, 2, 3.0)])
+    with pytest.raises(U.UmfpackError) as e:
+        U.factor(other, U.analyze(wide))
+    assert e.value.status == -11
+    # complex (umfpack_zi_*), a longer chain of augmenting paths: a 40 x 50 band whose columns j reach rows j - 1 and j
+    n_row, n_col = 40, 50
+    tri = [(max(j - 1, 0), j, 1.0 + 1.0j) for j in range(n_col) if max(j - 1, 0) < n_row]
+    tri += [(j, j, 2.0 - 1.0j) for j in range(min(n_row, n_col)) if j > 0]
+    Z = pkg.fromTriples(n_row, n_col, sorted(set(tri), key=lambda t: (t[1], t[0])))
+    assert Z.is_complex
+    fz = U.factor(Z, U.analyze(Z))
+    assert fz.status == 0  # rank 40 = min(40, 50)
+    with pytest.raises(U.UmfpackError) as e:
+        U.linearSolve_(fz, U.UmfpackNormal, Z, np.ones(n_row, dtype=complex))
+    assert e.value.status == -13
+    # the device-pointer form refuses as well
+    L = U._declare()
+    nr, nc, ap, ai, ax = wide._tuple32()
+    f = U.factor(wide, U.analyze(wide))
+    assert L.spl_umfpack_di_solve_many_dev(0, pkg._ffi.p_i32(ap), pkg._ffi.p_i32(ai), pkg._ffi.p_f64(ax), 1, None, None, f.value) == -13
 
 
 def test_nopiv_path_unsymmetric_dominant_and_transposed(gpu, pkg, O):
