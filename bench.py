@@ -429,9 +429,8 @@ def main():
         bad = O.count_not_close(y_gpu, y_cpu, 1e-10)
         out["cpu_baseline"] = {"value": round(B_total / t_cpu / 1e9, 3), "unit": "GB/s", "cores": 1,
                                "kind": "port",
-                               "sample": "whole %s matrix (nnz=%d), median of %d serial CSC-scatter mulV runs "
-                                         "(oracle restatement of Sparse.hs:433-471, 64-bit indices), %.2f s each"
-                                         % (args.matrix, nnz_total, len(times), t_cpu)}
+                               "sample": "whole matrix, median of %d serial CSC-scatter mulV runs (oracle, Sparse.hs:433-471, "
+                                         "64-bit indices), %.2f s each" % (len(times), t_cpu)}
         out["parity"] = {"checked": int(n), "not_close_1e-10": int(bad),
                          "bit_identical": bool(np.array_equal(y_gpu, y_cpu))}
         # a fair CPU (NOT the reference): OpenMP CSR gather on all host cores, arrays placed by parallel first
@@ -443,7 +442,7 @@ def main():
         if t_omp > 0:
             out["cpu_fair_openmp"] = {"value": round(B_total / t_omp / 1e9, 3), "unit": "GB/s",
                                       "cores": O.omp_threads(), "bit_identical_to_reference_order": bool(np.array_equal(yo, y_cpu)),
-                                      "note": "not the reference: OpenMP CSR gather, int32, NUMA first-touch placement, best of 5"}
+                                      "note": "not the reference: OpenMP CSR gather, int32, best of 5"}
 
     if exchange_failed:
         out["invalid"] = "the one-sided exchange of y timed out on at least one rank: y is incomplete, the figures mean nothing"
@@ -491,7 +490,13 @@ def main():
         out["secondary"] = secondary
 
     if rank == 0:
-        print(json.dumps(out))
+        # The driver keeps the last 8 KB of stdout: the line stays under 7 500 bytes (tests/test_gpu_bench_rehearsal.py
+        # asserts it on the full list of secondary items; round 4's 13.9 KB line lost three of them).  What every key
+        # means is DESIGN.md §7's legend, not prose in the line.
+        line = json.dumps(out, separators=(",", ":"))
+        if len(line) > 7500:
+            sys.stderr.write("bench.py: the result line has %d bytes (> 7500)\n" % len(line))
+        print(line)
     if exchange_failed:
         sys.exit(3)
     if N > 1:

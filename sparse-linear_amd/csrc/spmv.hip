@@ -408,46 +408,51 @@ bool panels_pay(const Matrix *m) {
   return per_line >= 0.3;
 }
 
-// Blocking pays when x does not fit the L2s and neighbouring rows do not share x lines
-// (measured: random 1e7 gathers move 10x the algorithmic bytes; banded rows reuse lines).
-// Shape: 16 panels per CU fill its LDS; the panel height is chosen so that the generations of
-// the persistent grid are full (n = 1e7 on 256 CUs: 2 generations of 4096 panels of 1221 rows).
+// Blocking pays when x does not fit ONE XCD's L2 (4 MiB: a CU gathers through the L2 of its own XCD) and
+// neighbouring rows do not share x lines (measured: random 1e7 gathers move 10x the algorithmic bytes; banded rows
+// reuse lines).  Shape (profiles/r05_blocked_threshold_sweep.txt: every n = 2^17 .. 2^23 with 4 / 8 / 16 wavefronts per
+// CU and x windows of 2^13 .. 2^18 columns, all 256 CUs busy): the kernel is fastest when a (panel, column block) SEGMENT
+// holds about ten 64-entry chunks — the depth of its register pipeline; longer segments fall into the un-pipelined tail
+// loop, shorter ones pay the fixed cost of a phase (barrier, segment pointers) per few entries — and, at equal segment
+// length, with more wavefronts per CU.  So: for nw = 16, 8, 4 wavefronts per CU take the panel height that fills the chip
+// (several full generations when the LDS is too small), then the widest x window <= 2 MiB whose segments stay within
+// ~11 chunks; accept the first nw whose segments are at least half a pipeline long (a rank's short row block of a wide
+// matrix ends at nw = 4: 1/8 of C2 0.197 ms with 4 x 1221 rows against 0.230 ms with 16 x 306).
+// Round 4 left everything below 12 MiB of x to the CSR-stream kernel on the strength of a sweep whose blocked image had
+// the default 16 x 1024-row shape (8 .. 128 of 256 CUs busy at n = 2^17 .. 2^21); shaped as above the blocked image wins
+// from 4 MiB of x on: n = 2^19 0.071 vs 0.077 ms, 2^20 0.131 vs 0.224, 2^21 0.247 vs 0.617, R-MAT scale 20 0.194 vs 0.365.
 void choose_blocking(const Matrix *m, int *rows_per_panel, int *w, int *waves) {
   *rows_per_panel = 0;
   *w = 0;
   *waves = 16;
   const int64_t x_bytes = m->ncols * 8;
-  // (round 4: the limit was 32 MiB, "x fits the aggregate L2" — but a CU gathers through the 4 MiB L2 of its OWN XCD.
-  // Measured on random n x n, 20 draws per row, reference order (tools/probe/panel_threshold_sweep.py): x = 16 MB
-  // stream 0.62 ms, blocked 0.52; 32 MB 1.41 vs 0.53; 8 MB 0.23 vs 0.53 — the blocked image has a floor of ~0.5 ms of
-  // phases, so it pays from about 12 MiB of x on.)
-  if (x_bytes <= (12LL << 20)) return;
+  if (x_bytes < (4LL << 20)) return;         // x fits one XCD's L2: the CSR-stream kernel (2 MiB: 0.037 vs 0.036 ms)
   if (m->new_line_fraction < 0.5) return;    // rows reuse their neighbours' lines (banded, stencil)
   if (m->nnz < 4 * m->nrows_local) return;   // too sparse for 64-entry chunks per segment
   const int cus = spmv_cus(m);
-  const int64_t rmax = (160 * 1024 / 8) / 16;  // 1280 rows of y per wavefront (16 wavefronts fill the LDS)
-  // Small row blocks (one rank of a multi-GPU run): fewer, fuller wavefronts per CU amortise the
-  // fixed cost of a phase better than 16 nearly empty ones (measured at 1/8 of C2: 0.197 ms with
-  // 4 x 1221 rows per CU vs 0.230 ms with 16 x 306).
-  int nw = 16;
+  const double avg = (double)m->nnz / (double)(m->nrows_local > 0 ? m->nrows_local : 1);
+  auto shape_for = [&](int nw, int64_t *R_out, int *w_out) -> double {  // -> entries per segment
+    const int64_t rmax = (160 * 1024 / 8) / nw;  // rows of y per wavefront: nw wavefronts fill the LDS
+    const int64_t slots = (int64_t)cus * nw;
+    const int64_t ngen = (m->nrows_local + slots * rmax - 1) / (slots * rmax);  // generations of full panels
+    int64_t R = (m->nrows_local + ngen * slots - 1) / (ngen * slots);
+    if (R < 64) R = 64;
+    int ww = 18;  // 2 MiB of x
+    auto seg = [&](int wv) { return avg * (double)R / (double)((m->ncols + (1LL << wv) - 1) >> wv); };
+    while (ww > 13 && seg(ww) > 700.0) --ww;
+    *R_out = R;
+    *w_out = ww;
+    return seg(ww);
+  };
   int64_t R = 0;
-  for (int cand : {4, 8, 16}) {
-    const int64_t r = (m->nrows_local + (int64_t)cus * cand - 1) / ((int64_t)cus * cand);
-    if (r <= rmax) { nw = cand; R = r; break; }
+  int ww = 18, nw = 16;
+  for (int cand : {16, 8, 4}) {
+    nw = cand;
+    const double seg = shape_for(cand, &R, &ww);
+    if (seg >= 320.0) break;
   }
-  if (R == 0) {  // several generations of 16 panels per CU, all full
-    const int64_t slots = (int64_t)cus * 16;
-    const int64_t ngen = (m->nrows_local + slots * rmax - 1) / (slots * rmax);
-    R = (m->nrows_local + ngen * slots - 1) / (ngen * slots);
-  }
-  if (R < 64) R = 64;
   *rows_per_panel = (int)R;
   *waves = nw;
-  // column block: 2 MiB of x unless segments would outgrow the 10-chunk register pipeline
-  const double avg = (double)m->nnz / (double)(m->nrows_local > 0 ? m->nrows_local : 1);
-  // (a segment longer than the register pipeline just takes the un-pipelined tail loop)
-  int ww = 18;
-  while (ww > 14 && avg * (double)R / (double)((m->ncols >> ww) + 1) > 1100.0) --ww;
   *w = ww;
 }
 

@@ -39,6 +39,31 @@ def _oops(fn, msg):
     raise SparseError("%s: %s" % (fn, msg))
 
 
+def _frozen(a):
+    """a read-only view of `a` (the caller's own array object keeps its flags); an array that is read-only already —
+    the field of another Matrix — is passed on as the object it is, so matrices built from the same pattern share it"""
+    if not a.flags.writeable:
+        return a
+    v = a.view()
+    v.setflags(write=False)
+    return v
+
+
+def _sample(a, k=2048):
+    n = len(a)
+    if n <= k:
+        return a.copy()
+    return a[np.linspace(0, n - 1, k).astype(np.int64)]
+
+
+def _pattern_fingerprint(pointers, indices):
+    return (len(pointers), len(indices), _sample(pointers), _sample(indices))
+
+
+def _same_fingerprint(a, b):
+    return a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+
+
 class Matrix(object):
     """Matrix in compressed sparse column (CSC) format (Sparse.hs:67-76)."""
 
@@ -47,8 +72,10 @@ class Matrix(object):
     def __init__(self, ncols, nrows, pointers, indices, values):
         self.ncols = int(ncols)
         self.nrows = int(nrows)
-        self.pointers = np.ascontiguousarray(pointers, dtype=I64)
-        self.indices = np.ascontiguousarray(indices, dtype=I64)
+        # read-only views: a Matrix is a value (the fields of the Haskell record cannot change), and the FFI seam keeps
+        # narrowed copies of the pattern (_tuple32) — an in-place edit through the Matrix raises instead of going unnoticed
+        self.pointers = _frozen(np.ascontiguousarray(pointers, dtype=I64))
+        self.indices = _frozen(np.ascontiguousarray(indices, dtype=I64))
         values = np.asarray(values)
         # Double, or Complex Double (the reference's two SPECIALIZE instances, Sparse.hs:456-457)
         self.values = np.ascontiguousarray(values, dtype=C128 if np.iscomplexobj(values) else F64)
@@ -113,11 +140,15 @@ class Matrix(object):
         # The reference narrows its 64-bit Int arrays on EVERY call (Foreign.hs:39-41: 2.4 GB of conversion per FFI call at
         # config C2).  A Matrix is a value — the fields of the Haskell record cannot change — so the
         # mirror narrows once and keeps the int32 copies while `pointers` and `indices` are the objects they were
-        # (round 4: at config C5 the copy was 30 ms of every 170 ms `linearSolve_`).  Arrays changed IN PLACE after a
-        # call are not noticed: build a new Matrix instead, as the reference's combinators do.
+        # (round 4: at config C5 the copy was 30 ms of every 170 ms `linearSolve_`).  The fields are read-only views, so
+        # an edit through the Matrix raises; an edit through another alias of the caller's buffer is looked for on every
+        # call by a fingerprint of the pattern (lengths, last pointer, ~4 000 evenly spaced entries: microseconds) — a
+        # mismatch narrows again.  (identity alone let a stale pattern through.)
         kept = getattr(self, "_narrowed", None)
-        if kept is None or kept[0] is not self.pointers or kept[1] is not self.indices:
-            kept = (self.pointers, self.indices, as_i32(self.pointers), as_i32(self.indices))
+        if (kept is None or kept[0] is not self.pointers or kept[1] is not self.indices
+                or not _same_fingerprint(kept[4], _pattern_fingerprint(self.pointers, self.indices))):
+            kept = (self.pointers, self.indices, as_i32(self.pointers), as_i32(self.indices),
+                    _pattern_fingerprint(self.pointers, self.indices))
             try:
                 self._narrowed = kept
             except AttributeError:  # (a subclass with __slots__)

@@ -142,7 +142,11 @@ def test_secondary_block_rides_on_the_headline_line(gpu):
            "--cpu-reps", "1", "--secondary", "c5:16:cpu8,banded,no-such-item,c4:12,zi:14,spmv:poisson3d:16,spmv:rmat:12,feast:10"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][0]
+    # the driver keeps 8 KB of stdout (round 4's 13.9 KB line lost three secondary entries): same number of items as the
+    # default list, every key present, and the whole stdout — not only the line — under 7 500 bytes
+    assert len(line) <= 7500 and r.stdout.rstrip().endswith(line), (len(line), len(r.stdout))
+    out = json.loads(line)
     assert out["metric"] == "fp64 CSR SpMV effective GB/s" and out["n_gpus"] == 1 and out["parity"]["not_close_1e-10"] == 0
     assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["kind"] == "port"
     sec = out["secondary"]
@@ -156,8 +160,9 @@ def test_secondary_block_rides_on_the_headline_line(gpu):
     assert lu["value"] >= lu["analyze_s"] + lu["first_factor_s"]  # the one-shot figure: analysis + FIRST factorisation + first solve
     sr = lu["solve_roofline"]
     assert sr["bound"] == "hbm" and sr["walks"] >= 1 and sr["bytes_per_walk"] > 16 * 4096 and 0 < sr["frac"] < 1
-    assert sr["walks"] == 1 + sr["refinement_steps"] and sr["backward_error"] < 2.3e-16
-    assert lu["cpu_baseline"]["same_workload"] is False
+    assert sr["backward_error"] < 2.3e-16 and 0 < sr["host_buffers"]["frac"] < 1 and sr["host_buffers"]["s"] > 0
+    assert lu["cpu_baseline"]["same_workload"] is False and isinstance(lu["memory_was_clean"], bool)
+    assert "traffic" in sr and "traffic" in lu["roofline"]
     assert sec["f3_zi_lu_shifted_poisson3d_14"]["solve_roofline"]["walks"] >= 1
     for k in ("spmv_poisson3d_16", "spmv_rmat_12"):
         assert sec[k]["parity"]["bit_identical"] and sec[k]["roofline"]["bound"] == "hbm" and sec[k]["unit"] == "GB/s"

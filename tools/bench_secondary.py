@@ -37,10 +37,22 @@ def _traffic(key):
     ent = json.load(open(tfile)).get(key)
     if not ent:
         return None
-    src = os.path.join(ROOT, ent["source"])
-    if not os.path.exists(src) or hashlib.sha1(open(src, "rb").read()).hexdigest() != ent["source_sha1"]:
+    h = hashlib.sha1()
+    for rel in ent["sources"] if "sources" in ent else [ent["source"]]:
+        src = os.path.join(ROOT, rel)
+        if not os.path.exists(src):
+            return None
+        h.update(open(src, "rb").read())
+    if h.hexdigest() != ent.get("sources_sha1", ent.get("source_sha1")):
         return None
     return ent["traffic_bytes"]
+
+
+def _sig(x, digits=3):
+    """a float rounded to `digits` significant digits (the driver keeps 8 KB of stdout: no 17-digit noise in the line)"""
+    if x is None or isinstance(x, (bool, int)) or x != x or x in (float("inf"), float("-inf")):
+        return x
+    return float("%.*g" % (digits, x))
 
 
 def banded_c2(pkg, torch, n=10_000_000, draws=20, steps=20, check=True):
@@ -65,24 +77,23 @@ def banded_c2(pkg, torch, n=10_000_000, draws=20, steps=20, check=True):
     B = 12 * nnz + 4 * (n + 1) + 8 * n + 8 * n
     kcode = H.spmv_kernel()
     kernel = {8: "spmv_blocked_lockstep", 15: "spmv_sell", 16: "spmv_panel"}.get(kcode, "spmv_stream")
-    out = {"workload": "banded CSR %dx%d, 20 diagonals within +-1000, nnz=%d, y=A*x fp64, int32 indices" % (n, n, nnz),
-           "value": round(B / ms / 1e6, 1), "unit": "GB/s", "ms_per_step": round(ms, 4), "steps": steps, "sum_order": "reference",
+    out = {"workload": "banded CSR n=%d, 20 diagonals within +-1000, nnz=%d" % (n, nnz),
+           "value": round(B / ms / 1e6, 1), "unit": "GB/s", "ms_per_step": round(ms, 4), "sum_order": "reference",
            "roofline": {"bound": "hbm", "achieved": round(B / ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(B / ms / 1e6 / HBM_PEAK_GBPS, 4), "traffic": _traffic("banded:%s" % kernel),
-                        "kernel": kernel, "kernel_ms": round(ms, 4), "bytes_per_launch": B}}
+                        "kernel": kernel, "bytes_per_launch": B}}
     if check:
         import numpy as np
         from oracle import oracle as O
         xh = x.cpu().numpy()
         rows, same = 0, True
-        for row0 in (0, 999, n // 2 - 1000, n - 2000):
+        for row0 in (0, 999, n // 2 - 1000, n - 2000):  # 4 windows of 2000 rows regenerated and multiplied by the oracle
             rp, ci, v = O.gen_banded_csr(n, row0=row0, row1=row0 + 2000)
             yo = np.zeros(2000)
             O.csr_gaxpy32(rp.astype(np.int32), ci, v, xh, yo)
             same = same and bool(np.array_equal(y[row0:row0 + 2000].cpu().numpy(), yo))
             rows += 2000
-        out["parity"] = {"rows_checked": rows, "bit_identical": same,
-                         "how": "4 windows of 2000 rows regenerated and multiplied by the oracle (reference order)"}
+        out["parity"] = {"rows_checked": rows, "bit_identical": same}
     H.free()
     del x, y
     return out
@@ -106,14 +117,12 @@ def spgemm_c4(pkg, torch, scale=20, edge_factor=32, abc=(0.25, 0.25, 0.25), reps
     tt = sorted(times[1:])[len(times[1:]) // 2]
     nnzC = HC.info()["nnz"]
     B = 12 * (nnzA + products + nnzC)
-    out = {"workload": "SpGEMM A*A, R-MAT scale %d, edge factor %d, (a,b,c)=%s: n=%d nnz(A)=%d products=%d nnz(C)=%d"
-                       % (scale, edge_factor, tuple(abc), n, nnzA, products, nnzC),
+    out = {"workload": "SpGEMM A*A, R-MAT scale %d, edge factor %d, (a,b,c)=%s: nnz(A)=%d products=%d nnz(C)=%d"
+                       % (scale, edge_factor, tuple(abc), nnzA, products, nnzC),
            "value": round(products / tt / 1e9, 3), "unit": "Gproducts/s", "seconds": round(tt, 5), "reps": reps,
-           "dtype": "f64",
            "roofline": {"bound": "hbm", "achieved": round(B / tt / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(B / tt / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
-                        "bytes_per_call": B, "timing": "wall clock around the whole spl_matrix_spgemm call "
-                                                       "(device-resident operands and result), median of %d" % reps}}
+                        "frac": round(B / tt / 1e9 / HBM_PEAK_GBPS, 4), "traffic": _traffic("c4_rmat%d:spgemm" % scale),
+                        "bytes_per_call": B}}
     if cpu_rows > 0:
         from oracle import oracle as O
         rp, ci, v = H.export_csr()
@@ -133,8 +142,7 @@ def spgemm_c4(pkg, torch, scale=20, edge_factor=32, abc=(0.25, 0.25, 0.25), reps
             prod_s += int(np.sum(lens[ci[a:b]]))
             rows += k // 2
         out["cpu_baseline"] = {"value": round(prod_s / t_cpu / 1e9, 4), "unit": "Gproducts/s", "cores": 1, "kind": "port",
-                               "sample": "%d rows of C (%d products), oracle touched-list mm (Sparse.hs:691-702, "
-                                         "ScatterGather.hs), %.2f s" % (rows, prod_s, t_cpu)}
+                               "sample": "%d rows of C (%d products), oracle mm, %.2f s" % (rows, prod_s, t_cpu)}
         out["parity"] = {"rows_checked": rows, "structure_and_values_bit_identical": ok}
     HC.free()
     H.free()
@@ -161,9 +169,9 @@ def _superlu_sample(pkg, ms=32):
     t = time.perf_counter()
     x = lu.solve(b)
     ts = time.perf_counter() - t
-    return {"value": round(tf + ts, 3), "unit": "s", "cores": 1, "kind": "stand-in: scipy SuperLU splu (no libumfpack in this pipeline)",
-            "sample": "%d^3 grid (n=%d): factor %.2f s, solve %.3f s, fill %d, max rel. error %.1e"
-                      % (ms, n, tf, ts, int(lu.L.nnz + lu.U.nnz), float(np.max(np.abs(x - xs) / np.abs(xs))))}
+    return {"value": round(tf + ts, 3), "unit": "s", "cores": 1, "kind": "stand-in: scipy SuperLU",
+            "sample": "%d^3 grid: factor %.2f s, solve %.3f s, max rel. error %.1e" % (ms, tf, ts, float(np.max(np.abs(x - xs) / np.abs(xs)))),
+            "same_workload": False}
 
 
 def lu_zi(pkg, torch, m=100):
@@ -216,22 +224,18 @@ def lu_zi(pkg, torch, m=100):
     err = float(np.max(np.abs(x - xs) / np.abs(xs)))
     errh = float(np.max(np.abs(xh - xs) / np.abs(xs)))
     rate = st["flops"] / max(steady, 1e-9) * 1e-12
-    out = {"workload": "complex sparse LU + solves (umfpack_zi_symbolic/numeric/solve), z I - A on the 3-D 7-point Laplacian %d^3, "
-                       "z = 3 + 0.5i: n=%d complex unknowns, nnz=%d" % (m, n, int(S.nnz)),
+    out = {"workload": "complex LU + solves (umfpack_zi_*), z I - A, 3-D 7-point Laplacian %d^3, z = 3 + 0.5i: n=%d nnz=%d" % (m, n, int(S.nnz)),
            "value": round(t3 - t0, 3), "unit": "s", "higher_is_better": False,
-           "value_is": "one shot in a fresh process: analyze + FIRST factorisation + first solve of A x = b",
            "steady_state_s": round((t1 - t0) + steady + solve2, 3),
            "analyze_s": round(t1 - t0, 3), "factor_s": round(steady, 3), "first_factor_s": round(t2 - t1, 3),
            "first_solve_s": round(t3 - t2, 3), "solve_s": round(solve2, 3), "solve_in_hbm_s": round(solve_dev, 4), "solve_conjugate_transposed_s": round(t4 - t3b, 3),
            "factorisation": {"path": st["path"], "native_complex_fronts": bool(st["complex_fronts"]), "fronts": st["fronts"],
-                             "device_GB": round(st["device_bytes"] * 1e-9, 2), "flops": st["flops"],
+                             "device_GB": round(st["device_bytes"] * 1e-9, 2), "flops": _sig(st["flops"], 5),
                              "TFLOP_per_s": round(rate, 2)},
            "roofline": {"bound": "mfma", "achieved": round(rate, 2), "peak": 78.6, "unit": "TFLOP/s",
-                        "frac": round(rate / 78.6, 4), "traffic": None,
-                        "note": "real flops executed (4 per complex multiply-add pair; L D L^T) over the whole numeric factorisation"},
-           "solve_roofline": dict(_solve_roofline(rep_dev, solve_dev, "solve with b and x resident in HBM (spl_umfpack_zi_solve_many_dev, one column), complex panels in two planes"),
-                                  host_buffers=_solve_roofline(rep, solve2, "second linearSolve_ call: host buffers, b up and x down over PCIe inside the time")),
-           "parity": {"max_rel_err_vs_manufactured": err, "conjugate_transposed_max_rel_err": errh,
+                        "frac": round(rate / 78.6, 4), "traffic": _traffic("zi_lu_%d:factor" % m)},
+           "solve_roofline": _solve_roofline(rep_dev, solve_dev, rep, solve2, _traffic("zi_lu_%d:solve" % m)),
+           "parity": {"max_rel_err_vs_manufactured": _sig(err), "conjugate_transposed_max_rel_err": _sig(errh),
                       "within_1e-10": bool(err < 1e-10 and errh < 1e-10), "solve_in_hbm_bit_identical": same_dev},
            "cpu_baseline": None}
     del fa, an
@@ -240,18 +244,23 @@ def lu_zi(pkg, torch, m=100):
     return out
 
 
-def _solve_roofline(rep, seconds, what):
-    """HBM roofline of the triangular solves of one `linearSolve_` call: every walk over the factors (forward and
-    backward substitution: the first solve and one per refinement step) reads each stored entry of L and U once —
-    8 bytes, dense panels without index arrays — plus the vectors (SURVEY.md §8d "SpTRSV"); the residuals between the
-    walks (an SpMV each) are in the time and not in the bytes."""
+def _solve_roofline(rep, seconds, host_rep=None, host_seconds=None, traffic=None):
+    """HBM roofline of the triangular solves of one `linearSolve_` call with b and x resident in HBM
+    (spl_umfpack_{di,zi}_solve_many_dev, one column; steady state): every walk over the factors (forward and backward
+    substitution: the first solve and one per refinement step) reads each stored entry of L and U once — 8 bytes, dense
+    panels without index arrays — plus the vectors (SURVEY.md §8d "SpTRSV"): bytes = walks x bytes_per_walk; the time is
+    the whole call, the residuals (in twice the working precision) between the walks included.  `host_buffers`: the same
+    solve through the host-buffer entry point (second linearSolve_ call), b up and x down over PCIe inside its time.
+    `traffic`: HBM bytes of one solve call from the committed PMC passes (profiles/traffic.json), else null."""
     B = rep["walks"] * rep["walk_bytes"]
     gbps = B / max(seconds, 1e-12) / 1e9
-    return {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
-            "traffic": None, "walks": rep["walks"], "bytes_per_walk": rep["walk_bytes"], "refinement_steps": rep["ir_attempted"],
-            "backward_error": rep["backward_error"], "of": what,
-            "note": "bytes = walks x (8 per stored factor entry + 16 n); time = the whole solve call (walks, residuals in twice "
-                    "the working precision between them; the host-buffer form also the upload of b and the download of x)"}
+    out = {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+           "traffic": traffic, "walks": rep["walks"], "bytes_per_walk": int(rep["walk_bytes"]),
+           "backward_error": _sig(rep["backward_error"])}
+    if host_rep is not None:
+        hb = host_rep["walks"] * host_rep["walk_bytes"] / max(host_seconds, 1e-12) / 1e9
+        out["host_buffers"] = {"frac": round(hb / HBM_PEAK_GBPS, 4), "s": round(host_seconds, 4)}
+    return out
 
 
 def _solve_in_hbm(pkg, torch, fa, A, b, x_host):
@@ -324,36 +333,33 @@ def lu_c5(pkg, torch, m=100, cpu_sample=0):
     one_shot = t3 - t0
     total = (t1 - t0) + steady + solve2
     rate = st["flops"] / max(steady, 1e-9) * 1e-12
-    out = {"workload": "sparse LU + triangular solves, 3-D 7-point Poisson %d^3: n=%d nnz=%d, umfpack_di_symbolic/numeric/solve"
-                       % (m, n, int(rp[-1])),
+    out = {"workload": "LU + triangular solves (umfpack_di_*), 3-D 7-point Poisson %d^3: n=%d nnz=%d" % (m, n, int(rp[-1])),
            "value": round(one_shot, 3), "unit": "s", "higher_is_better": False,
-           "value_is": "one shot in a fresh process: analyze + FIRST factorisation + first solve (what `linearSolve`, Umfpack.hs:38-46, pays)",
            "steady_state_s": round(total, 3),
-           "steady_state_is": "analyze + second factorisation with the same analysis (panels from the pool) + second solve",
            "analyze_s": round(t1 - t0, 3), "first_factor_s": round(t2 - t1, 3), "factor_s": round(steady, 3),
-           "first_factor_hipmalloc_s": round(a2 - a1, 3), "analyze_hipmalloc_s": round(a1 - a0, 3),
+           "first_factor_hipmalloc_s": round(a2 - a1, 3), "memory_was_clean": bool(a2 - a1 < 0.5),
            "first_solve_s": round(t3 - t2, 3), "solve_s": round(solve2, 3), "solve_in_hbm_s": round(solve_dev, 4),
            "factorisation": {"path": st["path"], "fronts": st["fronts"], "device_GB": round(st["device_bytes"] * 1e-9, 2),
-                             "flops": st["flops"], "TFLOP_per_s": round(rate, 2),
-                             "note": "flops executed: a symmetric matrix is factored as L D L^T on the same fronts (half the update flops of LU)"},
+                             "flops": _sig(st["flops"], 5), "TFLOP_per_s": round(rate, 2)},
            "roofline": {"bound": "mfma", "achieved": round(rate, 2), "peak": 78.6,
-                        "unit": "TFLOP/s", "frac": round(rate / 78.6, 4), "traffic": None,
-                        "note": "whole numeric factorisation in its steady state (all launches) against the fp64 matrix-core peak; "
-                                "back-to-back v_mfma_f64_16x16x4 issue at 47 TFLOP/s on this part (profiles/r01_dense_lu_rate_probe.txt)"},
-           "solve_roofline": dict(_solve_roofline(rep_dev, solve_dev, "solve with b and x resident in HBM (spl_umfpack_di_solve_many_dev, one column), steady state"),
-                                  host_buffers=_solve_roofline(rep, solve2, "second linearSolve_ call: host buffers, b up and x down over PCIe inside the time")),
-           "parity": {"max_rel_err_vs_manufactured": err, "within_1e-10": bool(err < 1e-10), "scaled_residual": res,
-                      "componentwise_backward_error": rep1["backward_error"], "second_solve_bit_identical": same,
-                      "solve_in_hbm_bit_identical": same_dev},
+                        "unit": "TFLOP/s", "frac": round(rate / 78.6, 4), "traffic": _traffic("lu_poisson3d_%d:factor" % m)},
+           "solve_roofline": _solve_roofline(rep_dev, solve_dev, rep, solve2, _traffic("lu_poisson3d_%d:solve" % m)),
+           "parity": {"max_rel_err_vs_manufactured": _sig(err), "within_1e-10": bool(err < 1e-10), "scaled_residual": _sig(res),
+                      "second_solve_bit_identical": same, "solve_in_hbm_bit_identical": same_dev},
            "cpu_baseline": None}
     del fa, an
     gc.collect()
     ffi.release_cached_memory()
     if cpu_sample:
-        out["cpu_baseline"] = _superlu_sample(pkg, cpu_sample)
-        out["cpu_baseline"]["same_workload"] = False
-        out["cpu_baseline"]["note"] = ("a DIFFERENT size (%d^3): SuperLU's fill makes the full grid take minutes to hours on one core; "
-                                       "there is no same-size CPU figure (profiles/r04_superlu_64.json: 64^3)" % cpu_sample)
+        out["cpu_baseline"] = _superlu_sample(pkg, cpu_sample)  # a DIFFERENT, smaller grid: SuperLU's fill makes m^3 take hours
+    else:
+        # no same-size CPU figure exists (no libumfpack in this pipeline; SuperLU needs 18 minutes at 64^3): the committed
+        # 64^3 measurement stands in, labelled as a different workload
+        f = os.path.join(ROOT, "profiles", "r04_superlu_64.json")
+        if os.path.exists(f):
+            r = json.load(open(f))
+            out["cpu_baseline"] = {"value": round(r["factor_s"] + r["solve_s"], 1), "unit": "s", "cores": 8, "kind": "stand-in: scipy SuperLU",
+                                   "sample": "%d^3 grid, measured once (profiles/r04_superlu_64.json)" % r["m"], "same_workload": False}
     return out
 
 
@@ -370,9 +376,8 @@ def spmv_other(pkg, torch, which, steps=20):
 
     def make():
         if kind == "poisson3d":
-            return pkg.DeviceMatrix.synthetic("poisson3d", int(arg)), "3-D 7-point Poisson %s^3 (config C5's matrix)" % arg
-        return (pkg.DeviceMatrix.rmat(int(arg), 32, (0.25, 0.25, 0.25)),
-                "R-MAT scale %s, edge factor 32, Erdos-Renyi quadrants (config C4's matrix)" % arg)
+            return pkg.DeviceMatrix.synthetic("poisson3d", int(arg)), "3-D 7-point Poisson %s^3 (C5's matrix)" % arg
+        return (pkg.DeviceMatrix.rmat(int(arg), 32, (0.25, 0.25, 0.25)), "R-MAT scale %s, edge factor 32, ER (C4's matrix)" % arg)
 
     runs, yo, t_cpu, name, n, nnz, B = {}, None, 0.0, "", 0, 0, 0
     for order in ("reference", "free"):
@@ -412,15 +417,16 @@ def spmv_other(pkg, torch, which, steps=20):
         del x, y
     best = min(runs, key=lambda k: runs[k]["ms_per_step"])
     r = runs[best]
-    return {"workload": "SpMV y = A x fp64, int32 indices: %s, n=%d nnz=%d" % (name, n, nnz),
-            "value": r["GB_per_s"], "unit": "GB/s", "ms_per_step": r["ms_per_step"], "steps": steps, "sum_order": best,
-            "roofline": {"bound": "hbm", "achieved": r["GB_per_s"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": r["frac"],
-                         "traffic": None, "kernel": r["kernel"], "kernel_ms": r["ms_per_step"], "bytes_per_launch": B},
+    gbs = r["GB_per_s"]
+    for r_ in runs.values():
+        del r_["GB_per_s"]
+    return {"workload": "SpMV: %s, n=%d nnz=%d" % (name, n, nnz),
+            "value": gbs, "unit": "GB/s", "ms_per_step": r["ms_per_step"], "sum_order": best,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": r["frac"],
+                         "traffic": _traffic("%s:%s" % (which, r["kernel"])), "kernel": r["kernel"], "bytes_per_launch": B},
             "by_sum_order": runs,
             "parity": {"rows_checked": int(n), "bit_identical": runs["reference"]["bit_identical"],
-                       "order_free_not_close_1e-10": runs["free"]["not_close_1e-10"],
-                       "how": "whole y against the oracle's CSR loop (reference order) on the exported arrays: the reference-order "
-                              "kernel bit for bit, the order-free one to 1e-10 relative"},
+                       "order_free_not_close_1e-10": runs["free"]["not_close_1e-10"]},
             "cpu_baseline": {"value": round(B / t_cpu / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
                              "sample": "the same matrix, one serial CSR pass of the oracle, %.3f s" % t_cpu}}
 
@@ -448,15 +454,15 @@ def feast_3d(pkg, torch, m=80, m0=16):
     lam = np.sort(np.asarray(lam))
     ok = len(lam) == len(inside)
     stages = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in pkg.feast.geigSH_.last_clock.items()}
-    return {"metric": "FEAST-style eigensolve seconds (3-D Laplacian %d^3, m0 = %d, 8 contour points)" % (m, m0),
-            "value": round(dt, 3), "unit": "s", "higher_is_better": False, "n": n,
+    # stage_seconds are thread seconds (contour points on SPL_FEAST_THREADS host threads), 'contour' the wall time of that
+    # stage; the factors of the contour points stay resident across the iterations (factors_reused); the reference
+    # refactors each time (Feast.hs:214-218)
+    return {"workload": "FEAST-style eigensolve, 3-D Laplacian %d^3, m0 = %d, 8 contour points" % (m, m0),
+            "value": round(dt, 3), "unit": "s", "higher_is_better": False,
             "eigenvalues_exact_in_window": int(len(inside)), "found": int(len(lam)),
-            "max_rel_error": float(np.max(np.abs(lam - inside) / inside)) if ok and len(lam) else None,
+            "max_rel_error": _sig(float(np.max(np.abs(lam - inside) / inside))) if ok and len(lam) else None,
             "within_1e-10": bool(ok and len(lam) and np.max(np.abs(lam - inside) / inside) < 1e-10),
-            "stage_seconds": stages,
-            "note": "stage_seconds are thread seconds (contour points on SPL_FEAST_THREADS host threads), 'contour' the wall "
-                    "time of that stage; the factors of the contour points stay resident across the iterations "
-                    "(factors_reused), the reference refactors each time (Feast.hs:214-218)"}
+            "stage_seconds": stages}
 
 
 def run_item(item, n=10_000_000, draws=20, steps=20):
