@@ -380,23 +380,24 @@ def main():
     if traffic_note:
         roofline["traffic_note"] = traffic_note
     if kcode == 8:
-        roofline["image"] = "column-blocked: %d rows/panel, 2^%d columns/block" % (info["blocked_rows"], info["blocked_cols_log2"])
+        roofline["image"] = "blocked %d rows x 2^%d cols" % (info["blocked_rows"], info["blocked_cols_log2"])
     elif kcode == 16:
-        roofline["image"] = "column-sorted panels: %d rows/workgroup, 2^%d columns/index block" % (info["blocked_rows"], info["blocked_cols_log2"])
+        roofline["image"] = "panels %d rows x 2^%d cols" % (info["blocked_rows"], info["blocked_cols_log2"])
 
     out = {
         "metric": "fp64 CSR SpMV effective GB/s", "value": round(value, 1), "unit": "GB/s",
         "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "%s CSR %dx%d, %d draws/row, nnz=%d, y=A*x fp64, int32 indices%s"
+        "config": {"workload": "%s CSR %dx%d, %d draws/row, nnz=%d%s"
                                % (args.matrix, n, n, args.draws, nnz_total,
                                   "" if N == 1 else ", %d row blocks, exchange of y: %s" % (N, exchange)),
                    "algorithmic_bytes": B_total, "hbm_frac_of_%dx8TBps" % N: round(value / (N * HBM_PEAK_GBPS), 4),
-                   "variant": args.variant, "blocked": args.blocked or "auto", "panel": args.panel or "auto",
                    "sum_order": args.order},
         "roofline": roofline,
     }
+    if args.variant or args.blocked or args.panel:  # forced kernel / image (ablations): said only when not the default choice
+        out["config"]["forced"] = {"variant": args.variant, "blocked": args.blocked, "panel": args.panel}
     # fingerprint of the whole y every rank holds after the last step: equal for every N and exchange
     import hashlib
     step()
@@ -404,7 +405,7 @@ def main():
     barrier()  # one-sided exchange: no rank may release its receive buffers while a peer is still storing
     yh = op.y_full.cpu().numpy()
     out["y_sha1"] = hashlib.sha1(yh.tobytes()).hexdigest()  # equal for every N under --order reference
-    out["y_sum"], out["y_norm2"] = float(yh.sum()), float(np.sqrt((yh * yh).sum()))  # equal to ~1e-15 under either order
+    out["y_sum"], out["y_norm2"] = float("%.13g" % yh.sum()), float("%.13g" % np.sqrt((yh * yh).sum()))  # equal to ~1e-15 under either order
     if tuning:
         out["config"]["exchange_ms_per_step_by_chunks"] = tuning  # measured before the timed region
     if fell_back:
@@ -429,8 +430,7 @@ def main():
         bad = O.count_not_close(y_gpu, y_cpu, 1e-10)
         out["cpu_baseline"] = {"value": round(B_total / t_cpu / 1e9, 3), "unit": "GB/s", "cores": 1,
                                "kind": "port",
-                               "sample": "whole matrix, median of %d serial CSC-scatter mulV runs (oracle, Sparse.hs:433-471, "
-                                         "64-bit indices), %.2f s each" % (len(times), t_cpu)}
+                               "sample": "whole matrix, median of %d serial CSC-scatter mulV runs of the oracle, %.2f s each" % (len(times), t_cpu)}
         out["parity"] = {"checked": int(n), "not_close_1e-10": int(bad),
                          "bit_identical": bool(np.array_equal(y_gpu, y_cpu))}
         # a fair CPU (NOT the reference): OpenMP CSR gather on all host cores, arrays placed by parallel first
@@ -442,7 +442,7 @@ def main():
         if t_omp > 0:
             out["cpu_fair_openmp"] = {"value": round(B_total / t_omp / 1e9, 3), "unit": "GB/s",
                                       "cores": O.omp_threads(), "bit_identical_to_reference_order": bool(np.array_equal(yo, y_cpu)),
-                                      "note": "not the reference: OpenMP CSR gather, int32, best of 5"}
+                                      "note": "not the reference: OpenMP CSR gather"}
 
     if exchange_failed:
         out["invalid"] = "the one-sided exchange of y timed out on at least one rank: y is incomplete, the figures mean nothing"

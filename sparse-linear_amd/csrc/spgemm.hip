@@ -52,6 +52,17 @@ constexpr int kLargeProducts = 4096, kLargeB = 2048;
 constexpr int kOrdCapSmall = 1536, kOrdPNbSmall = 96;
 constexpr int kOrdPBuckets = 512;
 constexpr int kOrdCapLarge = 2048, kOrdPNbLarge = 128;
+// Round 5: the image is a workspace + a RING of entry slots whose two ends hold the column being sorted and the pending
+// one (OrdPipeLds).  With 2 CAP slots the ends are round 4's two full buffers.  A NARROW ring (2 400 slots = 32 576 bytes,
+// five workgroups per CU: columns of C4 have 1 024 products on average) was built and measured (SPL_SPGEMM_RING=narrow):
+// 49 ms against 13.4 — when the two columns do not fit together (9 % of C4's pairs) the pending one must be finished
+// BEFORE the column in hand is sorted, i.e. while its ticket is held unpublished, and every such delay ages the look-back
+// of a thousand later columns: the chain tips over into a convoy (1.9 M sleeps against a hundred per million).  Even
+// with overflow ruled out (SPL_SPGEMM_ORD_CAP=1200) five workgroups per CU at 96 registers were slower than four at 109
+// (14.6 against 13.7 ms): the kernel no longer lives on occupancy.  Kept as an ablation, not used.
+constexpr int kOrdRingSmall = 2 * kOrdCapSmall, kOrdRingSmallNarrow = 2400, kOrdRingLarge = 2 * kOrdCapLarge;
+constexpr int kOrdAdmitSmall = kOrdCapSmall, kOrdAdmitLarge = kOrdCapLarge;
+static_assert(kOrdAdmitSmall <= 2 * kOrdRingSmallNarrow / 3, "the merge-tree fallback's second key buffer must fit the narrow ring");
 constexpr int kMaxPool = 2048;  // dense-accumulator slots = resident workgroups of spgemm_dense_kernel: eight per CU (it lives on latency overlap)
 
 inline unsigned blocks_for(int64_t n, int per_block) {
@@ -121,6 +132,41 @@ __global__ __launch_bounds__(256) void products_kernel(Csc A, Csc B, int64_t nco
     base[threadIdx.x] = atomicAdd(&list_counts[threadIdx.x], local_count[threadIdx.x]);
   __syncthreads();
   if (owner && bin >= 2) {
+    if (xback) {
+      xlarge_list[ncolsB - 1 - (base[3] + pos)] = j;
+    } else {
+      int64_t *list = bin == 2 ? medium_list : bin == 3 ? xlarge_list : dense_list;
+      list[base[bin - 2] + pos] = j;
+    }
+  }
+}
+
+// The bin lists of the ORDERED form from the per-column product counts the first pass left behind: no second walk
+// over the columns of B and the extents of A (round 4 ran products_kernel twice: 0.23 ms of C4's 16.7).
+__global__ __launch_bounds__(256) void relist_ordered_kernel(Csc B, int64_t ncolsB, const int64_t *__restrict__ nprod,
+                                                             int64_t *__restrict__ medium_list, int64_t *__restrict__ xlarge_list,
+                                                             int64_t *__restrict__ dense_list, int *__restrict__ list_counts,
+                                                             int ord_cap, int ord_nb, int x_heavy) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ int local_count[4], base[4];
+  if (threadIdx.x < 4) local_count[threadIdx.x] = 0;
+  __syncthreads();
+  int bin = 0, pos = 0;
+  bool xback = false;
+  if (j < ncolsB) {
+    const int64_t n = nprod[j];
+    const int nb = B.p[j + 1] - B.p[j];
+    bin = bin_of(n, nb);
+    if (x_heavy && bin == 3) bin = 4;
+    if (n > 0) bin = (n <= ord_cap && nb <= ord_nb) ? 1 : (bin < 2 ? 2 : bin);  // (as products_kernel with ordered = 1)
+    xback = bin == 3 && nb > kMediumB;
+    if (bin >= 2) pos = atomicAdd(&local_count[xback ? 3 : bin - 2], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && local_count[threadIdx.x] > 0)
+    base[threadIdx.x] = atomicAdd(&list_counts[threadIdx.x], local_count[threadIdx.x]);
+  __syncthreads();
+  if (bin >= 2) {
     if (xback) {
       xlarge_list[ncolsB - 1 - (base[3] + pos)] = j;
     } else {
@@ -902,37 +948,75 @@ __device__ inline void ord_publish(unsigned long long *__restrict__ status, int6
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ inline int64_t ord_lookback(unsigned long long *__restrict__ status, int64_t j, int64_t count) {
+// Look-back: kLookBlocks x 64 status words per dependent round trip (independent loads, nearest block first), evaluated
+// block by block.  Measured on C4 (SPL_SPGEMM_STAMPS=1, round 5): the pipelined path needs ONE round for 99.6 % of its
+// look-backs and sleeps for an unpublished predecessor about a hundred times in a million columns — the chain costs one
+// memory round trip per column (3 200 cycles under this kernel's load), not a walk and not a wait; eight blocks per
+// round were slower than two (the surplus loads queue in front of other wavefronts' gathers).
+constexpr int kLookBlocks = 2;
+
+__device__ inline int64_t ord_lookback(unsigned long long *__restrict__ status, int64_t j, int64_t count, bool polled = true,
+                                       unsigned long long *diag = nullptr) {
   const int lane = threadIdx.x & 63;
   if (j == 0) return 0;
+  const unsigned long long t_in = diag ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long rounds = 0, polls = 0, t_poll = 0;
   int64_t sum = 0;
   int64_t p = j - 1;  // nearest predecessor not yet accounted for
-  // The nearest predecessor took its ticket just before this column and is usually the last to publish: one
-  // lane polls it, asleep in between (64 lanes polling from a thousand waiting wavefronts take issue slots and
-  // L2 requests from the wavefronts they are waiting for); the wide look-back starts once it is there.
-  if (lane == 0) {
-    while ((__hip_atomic_load(status + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 62) == 0) __builtin_amdgcn_s_sleep(32);
-  }
-  __builtin_amdgcn_wave_barrier();
+  auto poll_nearest = [&]() {  // one lane polls, asleep in between (64 lanes polling from a thousand waiting wavefronts
+    if (lane == 0) {           // take issue slots and L2 requests from the wavefronts they are waiting for)
+      while ((__hip_atomic_load(status + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 62) == 0) __builtin_amdgcn_s_sleep(32);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  // `polled`: the paths that look back right after publishing wait for the nearest predecessor first — it took its
+  // ticket just before this column and is usually the last to publish.  The pipelined path looks back a whole column
+  // of work later: everything is there, and the poll would only be one more dependent round trip.
+  if (polled) poll_nearest();
   for (;;) {
-    const int64_t q = p - lane;
-    unsigned long long w = 0;
-    if (q >= 0) w = __hip_atomic_load(status + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned flag = (unsigned)(w >> 62);
-    const unsigned long long not_ready = __ballot(q >= 0 && flag == 0);
-    const unsigned long long is_prefix = __ballot(q >= 0 && flag == 2);
-    // lanes are ordered by distance: use everything up to the nearest prefix, provided nothing nearer is missing
-    const int first_missing = not_ready ? __builtin_ctzll(not_ready) : 64;
-    const int first_prefix = is_prefix ? __builtin_ctzll(is_prefix) : 64;
-    const int upto = first_prefix < first_missing ? first_prefix + 1 : first_missing;  // lanes [0, upto) are usable
-    long long part = (lane < upto && q >= 0) ? (long long)(w & kOrdValueMask) : 0;
+    unsigned long long w[kLookBlocks];
+#pragma unroll
+    for (int k = 0; k < kLookBlocks; ++k) {
+      const int64_t q = p - 64 * k - lane;
+      w[k] = q >= 0 ? __hip_atomic_load(status + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+    long long part = 0;
+    int consumed = 0;
+    bool done = false, stalled = false;
+    ++rounds;
+#pragma unroll
+    for (int k = 0; k < kLookBlocks; ++k) {
+      if (done || stalled) break;  // (wave-uniform)
+      const int64_t q = p - 64 * k - lane;
+      const unsigned flag = (unsigned)(w[k] >> 62);
+      const unsigned long long not_ready = __ballot(q >= 0 && flag == 0);
+      const unsigned long long is_prefix = __ballot(q >= 0 && flag == 2);
+      // lanes are ordered by distance: use everything up to the nearest prefix, provided nothing nearer is missing
+      const int first_missing = not_ready ? __builtin_ctzll(not_ready) : 64;
+      const int first_prefix = is_prefix ? __builtin_ctzll(is_prefix) : 64;
+      const int upto = first_prefix < first_missing ? first_prefix + 1 : first_missing;  // lanes [0, upto) are usable
+      if (lane < upto && q >= 0) part += (long long)(w[k] & kOrdValueMask);
+      consumed += upto;
+      if (first_prefix < first_missing) done = true;  // met a predecessor that knows everything before it
+      else if (first_missing < 64) stalled = true;    // a column in this block has not published yet
+    }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
     sum += part;
-    if (first_prefix < first_missing) break;               // met a predecessor that knows everything before it
-    if (p - upto < 0 && first_missing == 64) break;        // ran past column 0 (cannot happen: column 0 publishes a prefix)
-    p -= upto;
-    if (first_missing < 64 && upto == 0) __builtin_amdgcn_s_sleep(16);  // the nearest one is not there yet
+    if (done) break;
+    p -= consumed;
+    if (p < 0) break;  // ran past column 0 (cannot happen: column 0 publishes a prefix)
+    if (stalled) {
+      const unsigned long long tp = diag ? __builtin_amdgcn_s_memtime() : 0ull;
+      poll_nearest();
+      if (diag) { t_poll += __builtin_amdgcn_s_memtime() - tp; ++polls; }
+    }
+  }
+  if (diag) {  // SPL_SPGEMM_STAMPS=1: ticks inside the look-back, of them asleep waiting for a column that had not published, rounds, waits
+    diag[0] += __builtin_amdgcn_s_memtime() - t_in;
+    diag[1] += t_poll;
+    diag[2] += rounds;
+    diag[3] += polls;
   }
   if (lane == 0)
     __hip_atomic_store(status + j, kOrdFlagPrefix | (unsigned long long)(sum + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1244,68 +1328,73 @@ __device__ inline void ord_column(const Csc &A, const Csc &B, int64_t j, int np,
 // fold, write) after that — one whole column of work later, when its predecessors have long published.  A
 // workgroup still only ever waits for columns with smaller tickets.
 
-template <int CAP, int NBCAP>
-struct OrdPipeLds {  // workspace + two result buffers
+// Round 5: the two result buffers are the two ENDS of one ring of RING entry slots (a product column and a key column
+// side by side): the pending column lies at one end with exactly its np entries, the column being sorted goes to the
+// other end.  RING = 2 CAP: they always fit.  A narrower ring finishes the pending column first when they do not —
+// measured and ruinous, see kOrdRingSmallNarrow above.
+template <int CAP, int NBCAP, int RING>
+struct OrdPipeLds {  // workspace + the ring
+  static_assert(RING >= CAP, "a column must fit the ring by itself");
   static constexpr size_t kb_bytes = NBCAP * sizeof(double);
   static constexpr size_t start_bytes = NBCAP * sizeof(int);
   static constexpr size_t off_bytes = (NBCAP + 8) * sizeof(int);
   static constexpr size_t hist_bytes = (kOrdPBuckets + 8) * sizeof(int);
   static constexpr size_t scratch_bytes = 32 * sizeof(int);
   static constexpr size_t work_bytes = kb_bytes + start_bytes + off_bytes + hist_bytes + scratch_bytes;
-  static constexpr size_t vals_bytes = CAP * sizeof(double), keys_bytes = CAP * sizeof(unsigned);
-  static constexpr size_t total = work_bytes + 2 * (vals_bytes + keys_bytes);
+  static constexpr size_t vals_bytes = (size_t)RING * sizeof(double), keys_bytes = (size_t)RING * sizeof(unsigned);
+  static constexpr size_t total = work_bytes + vals_bytes + keys_bytes;
 };
 
 struct OrdPending {
   int64_t j = 0;
   int np = 0, count = 0;
-  int keys_in = 0, vals_in = 0;  // which key / value buffer holds the column
+  int before = 0;       // distinct rows in the parts of the sorted column that belong to earlier wavefronts
+  int end = 0;          // which end of the ring holds the column (0: slots [0, np), 1: slots [RING - np, RING))
   bool valid = false;
 };
+
+// The sorted column is dealt to the four wavefronts in contiguous parts of whole 64-entry chunks: wavefront w counts,
+// folds and writes positions [w L, (w + 1) L).  ordp_count leaves every wavefront the number of distinct rows before
+// its part, so the write loop of ordp_finish needs no workgroup barrier (round 4 crossed two per 256 entries: ~10 per
+// column) and every wavefront writes one contiguous stretch of Ci / Cx.
+__device__ inline int ordp_part(int np) { return (((np + 3) >> 2) + 63) & ~63; }
 
 // finish a column whose sorted keys and products wait in LDS: look-back, fold, write (scratch: 16 ints of its own)
 __device__ inline void ordp_finish(const OrdPending &P, const unsigned *skeys, const double *vals, int *scratch, int tid,
                                    unsigned long long *__restrict__ status, int64_t *__restrict__ Cp,
-                                   int *__restrict__ Ci, double *__restrict__ Cx) {
-  const int lane = tid & 63;
-  if ((tid >> 6) == 0) {
-    const int64_t e = ord_lookback(status, P.j, P.count);
+                                   int *__restrict__ Ci, double *__restrict__ Cx, unsigned long long *diag = nullptr) {
+  const int lane = tid & 63, wave = tid >> 6;
+  if (wave == 0) {
+    const int64_t e = ord_lookback(status, P.j, P.count, false, diag);
     if (lane == 0) { scratch[10] = (int)(e & 0xffffffffll); scratch[11] = (int)(e >> 32); }
   }
   __syncthreads();
   const int64_t base = ((int64_t)scratch[11] << 32) | (int64_t)(unsigned)scratch[10];
   if (tid == 0) Cp[P.j] = base;
-  const int np = P.np;
-  int running = 0;
-  for (int t0 = 0; t0 < np; t0 += 256) {
-    const int t = t0 + tid;
+  const int np = P.np, L = ordp_part(np);
+  const int t1 = min(np, (wave + 1) * L);
+  int64_t out = base + P.before;
+  for (int t0 = wave * L; t0 < t1; t0 += 64) {
+    const int t = t0 + lane;
     int row = 0;
     bool head = false;
-    if (t < np) {
+    if (t < t1) {
       row = (int)(skeys[t] >> kOrdTB);
       head = t == 0 || (int)(skeys[t - 1] >> kOrdTB) != row;
     }
     const unsigned long long m = __ballot(head);
-    int off = running + __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) scratch[tid >> 6] = __popcll(m);
-    __syncthreads();
-    int total = 0;
-    for (int wv = 0; wv < 4; ++wv) {
-      if (wv < (tid >> 6)) off += scratch[wv];
-      total += scratch[wv];
-    }
-    __syncthreads();
     if (head) {
+      const int64_t o = out + __popcll(m & ((1ull << lane) - 1ull));
       double acc = 0.0;  // SG.reset 0
-      for (int u = t; u < np; ++u) {
+      for (int u = t; u < np; ++u) {  // (a run may reach into the next wavefront's part: its entries are no heads there)
         const unsigned k = skeys[u];
         if ((int)(k >> kOrdTB) != row) break;
         acc = acc + vals[k & ((1u << kOrdTB) - 1u)];  // c + a * b in ascending k
       }
-      Ci[base + off] = row;
-      Cx[base + off] = acc;
+      Ci[o] = row;
+      Cx[o] = acc;
     }
-    running += total;
+    out += __popcll(m);
   }
 }
 
@@ -1330,7 +1419,13 @@ __global__ __launch_bounds__(256) void ord_bmeta_kernel(Csc A, Csc B, int64_t nn
   out[q] = m;
 }
 
-template <int CAP, int NBCAP>
+// PER = CAP / 256 slots per thread for the products it expands, ranks and scatters; the loops over them are fully
+// unrolled (the slots live in registers).  A column of 1 024 products needs four of the six slots of the small shape:
+// every unrolled loop leaves at the first slot beyond per = ceil(np / 256) — a wave-uniform scalar branch — instead of
+// running the surplus slots predicated off (half again the instructions of such a column).  (One instantiation per
+// value of `per` does the same and was measured SLOWER, 20.3 against 13.7 ms: 56 KB of code for sixteen wavefronts in
+// different phases against a 64 KB instruction cache.)
+template <int CAP, int NBCAP, int RING>
 __device__ inline int ordp_sort(const Csc &A, const OrdBMeta *__restrict__ bmeta, int qs, int nb, int np, int bucket_shift,
                                 unsigned char *work, unsigned *keys, double *vals, int tid,
                                 unsigned long long *stamps = nullptr) {
@@ -1342,8 +1437,8 @@ __device__ inline int ordp_sort(const Csc &A, const OrdBMeta *__restrict__ bmeta
       t_prev = now;
     }
   };
-  constexpr int NT = 256, NBK = kOrdPBuckets;
-  typedef OrdPipeLds<CAP, NBCAP> PL;
+  constexpr int NT = 256, NBK = kOrdPBuckets, PER = CAP / NT;
+  typedef OrdPipeLds<CAP, NBCAP, RING> PL;
   double *kb = reinterpret_cast<double *>(work);
   int *kstart = reinterpret_cast<int *>(work + PL::kb_bytes);
   int *koff = kstart + NBCAP;
@@ -1375,8 +1470,7 @@ __device__ inline int ordp_sort(const Csc &A, const OrdBMeta *__restrict__ bmeta
     __syncthreads();
   }
   stamp(1);
-  constexpr int PER = CAP / NT;
-  const int per = (np + NT - 1) / NT;
+  const int per = __builtin_amdgcn_readfirstlane((np + NT - 1) / NT);  // wave-uniform, in a scalar register
   unsigned myk[PER];
   int myrank[PER];
   {
@@ -1393,6 +1487,7 @@ __device__ inline int ordp_sort(const Csc &A, const OrdBMeta *__restrict__ bmeta
     int pp[PER], qq[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
+      if (u >= per) break;  // (wave-uniform)
       const int t = t0 + u;
       pp[u] = -1;
       qq[u] = 0;
@@ -1406,11 +1501,13 @@ __device__ inline int ordp_sort(const Csc &A, const OrdBMeta *__restrict__ bmeta
     double av[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
+      if (u >= per) break;
       rows[u] = pp[u] >= 0 ? A.i[pp[u]] : 0;
       av[u] = pp[u] >= 0 ? A.x[pp[u]] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
+      if (u >= per) break;
       myk[u] = 0xffffffffu;
       myrank[u] = 0;
       if (pp[u] >= 0) {
@@ -1448,8 +1545,10 @@ __device__ inline int ordp_sort(const Csc &A, const OrdBMeta *__restrict__ bmeta
   stamp(3);
   if (scratch[8] != 0) {  // a crowded bucket: hand the keys over in run order, the caller merges them
 #pragma unroll
-    for (int u = 0; u < PER; ++u)
+    for (int u = 0; u < PER; ++u) {
+      if (u >= per) break;
       if (myk[u] != 0xffffffffu) keys[myk[u] & ((1u << kOrdTB) - 1u)] = myk[u];
+    }
     __syncthreads();
     return -1;
   }
@@ -1461,6 +1560,7 @@ __device__ inline int ordp_sort(const Csc &A, const OrdBMeta *__restrict__ bmeta
   int bs[PER], be[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
+    if (u >= per) break;
     bs[u] = 0;
     be[u] = 0;
     if (myk[u] != 0xffffffffu) {
@@ -1474,35 +1574,41 @@ __device__ inline int ordp_sort(const Csc &A, const OrdBMeta *__restrict__ bmeta
   int rank[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
+    if (u >= per) break;
     rank[u] = 0;
     for (int i = bs[u]; i < be[u]; i += 4) {  // four independent loads per wait; the index is clamped, the test masks
-      const unsigned k0 = keys[i], k1 = keys[min(i + 1, CAP - 1)], k2 = keys[min(i + 2, CAP - 1)], k3 = keys[min(i + 3, CAP - 1)];
+      const unsigned k0 = keys[i], k1 = keys[min(i + 1, np - 1)], k2 = keys[min(i + 2, np - 1)], k3 = keys[min(i + 3, np - 1)];
       rank[u] += (k0 < myk[u] ? 1 : 0) + ((i + 1 < be[u] && k1 < myk[u]) ? 1 : 0) + ((i + 2 < be[u] && k2 < myk[u]) ? 1 : 0) +
                  ((i + 3 < be[u] && k3 < myk[u]) ? 1 : 0);
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < PER; ++u)
+  for (int u = 0; u < PER; ++u) {
+    if (u >= per) break;
     if (myk[u] != 0xffffffffu) keys[bs[u] + rank[u]] = myk[u];
+  }
   __syncthreads();
   stamp(4);
   return 0;
 }
 
-// distinct rows of a sorted column (workgroup-wide)
-__device__ inline int ordp_count(const unsigned *skeys, int np, int *scratch, int tid) {
+// distinct rows of a sorted column (workgroup-wide); *before = those in the parts of the wavefronts before this one
+__device__ inline int ordp_count(const unsigned *skeys, int np, int *scratch, int tid, int *before) {
+  const int lane = tid & 63, wave = tid >> 6, L = ordp_part(np);
+  const int t1 = min(np, (wave + 1) * L);
   int count = 0;
-  for (int t0 = 0; t0 < np; t0 += 256) {
-    const int t = t0 + tid;
-    const bool head = t < np && (t == 0 || (skeys[t] >> kOrdTB) != (skeys[t - 1] >> kOrdTB));
+  for (int t0 = wave * L; t0 < t1; t0 += 64) {
+    const int t = t0 + lane;
+    const bool head = t < t1 && (t == 0 || (skeys[t] >> kOrdTB) != (skeys[t - 1] >> kOrdTB));
     count += __popcll(__ballot(head));
   }
-  if ((tid & 63) == 0) scratch[4 + (tid >> 6)] = count;
+  if (lane == 0) scratch[4 + wave] = count;
   __syncthreads();
-  count = scratch[4] + scratch[5] + scratch[6] + scratch[7];
+  const int c0 = scratch[4], c1 = scratch[5], c2 = scratch[6], c3 = scratch[7];
   __syncthreads();
-  return count;
+  *before = wave == 0 ? 0 : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+  return c0 + c1 + c2 + c3;
 }
 
 // column classes of the ordered form
@@ -1557,8 +1663,8 @@ __global__ __launch_bounds__(256) void ord_task_fill_kernel(Csc B, int64_t ncols
   }
 }
 
-template <int CAP, int NBCAP>
-__global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64_t ncolsB, int bucket_shift_wave,
+template <int CAP, int NBCAP, int RING, int WGS>
+__global__ __launch_bounds__(256, WGS) void spgemm_ordered_kernel(Csc A, Csc B, int64_t ncolsB, int bucket_shift_wave,
                                                              int bucket_shift_group, const int64_t *__restrict__ nprod,
                                                              const unsigned char *__restrict__ cls,
                                                              const int64_t *__restrict__ heavy_slot,
@@ -1573,24 +1679,27 @@ __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ long long s_tile;
   __shared__ long long s_base;
+  __shared__ int4 s_rec;
   typedef OrdLds<kOrdWaveCap, kOrdWaveNb> LW;
-  typedef OrdPipeLds<CAP, NBCAP> PL;
+  typedef OrdPipeLds<CAP, NBCAP, RING> PL;
   constexpr size_t wave_bytes = (LW::total + 15) / 16 * 16;
+  static_assert(4 * wave_bytes <= PL::total, "the four one-wavefront images of a tile of light columns lie over the ring");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned long long acc_stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long acc_stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long *const local_stamps = stamps ? acc_stamps : nullptr;
-  // pipelined workgroup path: workspace, then the two (values, keys) result buffers
+  // pipelined workgroup path: workspace, then the ring (value column, key column)
   unsigned char *work = smem;
-  auto pvals = [&](int i) { return reinterpret_cast<double *>(smem + PL::work_bytes + (size_t)i * PL::vals_bytes); };
-  auto pkeys = [&](int i) {
-    return reinterpret_cast<unsigned *>(smem + PL::work_bytes + 2 * PL::vals_bytes + (size_t)i * PL::keys_bytes);
-  };
+  double *const ring_vals = reinterpret_cast<double *>(smem + PL::work_bytes);
+  unsigned *const ring_keys = reinterpret_cast<unsigned *>(smem + PL::work_bytes + PL::vals_bytes);
+  auto pvals = [&](int end, int np) { return end ? ring_vals + (RING - np) : ring_vals; };
+  auto pkeys = [&](int end, int np) { return end ? ring_keys + (RING - np) : ring_keys; };
   int *scratch_a = reinterpret_cast<int *>(smem + PL::work_bytes) - 32;  // the workspace's scratch: [0,16) sort, [16,32) finish
   int *scratch_b = scratch_a + 16;
   OrdPending pend;
   auto finish_pending = [&]() {
     if (pend.valid) {
-      ordp_finish(pend, pkeys(pend.keys_in), pvals(pend.vals_in), scratch_b, tid, status, Cp, Ci, Cx);
+      ordp_finish(pend, pkeys(pend.end, pend.np), pvals(pend.end, pend.np), scratch_b, tid, status, Cp, Ci, Cx,
+                  (stamps && tid == 0) ? acc_stamps + 8 : nullptr);
       pend.valid = false;
       __syncthreads();
     }
@@ -1603,18 +1712,31 @@ __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64
       t_mark = now;
     }
   };
+  // Thread 0 asks for the next ticket and its task record once the column in hand is sorted (two dependent round
+  // trips that travel while the column is counted and the pending one finished), so the top of the loop finds both
+  // in registers.  Taking the ticket EARLIER — when the column starts — was measured and is 45 % slower (20.2 against
+  // 13.9 ms on C4): a ticket held for a whole column before its column is even started ages every later column's
+  // look-back.  A workgroup only ever waits for columns with smaller tickets, all held by resident workgroups.
+  long long nxt_ticket = 0;
+  int4 nxt_rec = make_int4(0, 0, 0, 0);
+  auto request_next = [&]() {
+    if (tid == 0) {
+      nxt_ticket = (long long)atomicAdd(ticket, 1ull);
+      nxt_rec = tasks[nxt_ticket < ntasks ? nxt_ticket : ntasks - 1];
+    }
+  };
+  request_next();
   for (;;) {
     mark(7);  // (whatever is not covered below)
-    if (tid == 0) s_tile = (long long)atomicAdd(ticket, 1ull);
+    if (tid == 0) { s_tile = nxt_ticket; s_rec = nxt_rec; }
     __syncthreads();
     const int64_t tk = s_tile;
+    const int4 rec = s_rec;
     __syncthreads();
     if (tk >= ntasks) break;
-    int4 rec = tasks[tk];
-    if (stamps) rec.x = __builtin_amdgcn_readfirstlane(rec.x);  // wait for the record here, so that the stamp sees it
     mark(0);
     if (rec.x < 0) {  // four light columns: one wavefront each, no workgroup barrier inside
-      finish_pending();  // (their LDS image overlaps the result buffers)
+      finish_pending();  // (their LDS image overlaps the ring)
       const int64_t j = (int64_t)~rec.x + wave;
       const int cw = j < ncolsB ? (int)cls[j] : -1;
       if (cw == 0) {
@@ -1624,30 +1746,40 @@ __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64
         ord_column<64, kOrdWaveCap, kOrdWaveNb>(A, B, j, (int)nprod[j], bucket_shift_wave, smem + wave * wave_bytes, lane,
                                                 status, Cp, Ci, Cx, wave == 0 ? local_stamps : nullptr);
       }
+      request_next();
     } else {
       const int64_t j = rec.x;
       const int cw = rec.w >> 16, nbj = rec.w & 0xffff;
       if (cw == 1 || cw == 2) {
-        // sort this column into the buffers the pending one does not use, publish its length, THEN finish the
+        // sort this column into the end of the ring the pending one does not use, publish its length, THEN finish the
         // pending column: its look-back has had a whole column of work to become a formality
-        const int kin = pend.valid ? 1 - pend.keys_in : 0, vin = pend.valid ? 1 - pend.vals_in : 0;
         const int np = rec.y;
-        int keys_in = kin;
-        const int st = ordp_sort<CAP, NBCAP>(A, bmeta, rec.z, nbj, np, bucket_shift_group, work, pkeys(kin), pvals(vin), tid,
-                                 tid == 0 ? local_stamps : nullptr);
+        if (pend.valid && pend.np + np > RING) finish_pending();  // the two do not fit the ring together
+        const int end = pend.valid ? 1 - pend.end : 0;
+        unsigned *keys = pkeys(end, np);
+        double *vals = pvals(end, np);
+        const int st = ordp_sort<CAP, NBCAP, RING>(A, bmeta, rec.z, nbj, np, bucket_shift_group, work, keys, vals, tid,
+                                                   tid == 0 ? local_stamps : nullptr);
+        request_next();
         if (stamps) t_mark = __builtin_amdgcn_s_memtime();
-        if (st < 0) {  // crowded bucket: merge tree over the runs; needs the other key buffer, so finish what waits there
-          finish_pending();
+        if (st < 0) {  // crowded bucket: merge tree over the runs; its second key buffer is the other end of the ring when
+          finish_pending();  // two such columns fit, else the tail of the value column behind this column's products
+          unsigned *second = 2 * np <= RING ? pkeys(1 - end, np)
+                                            : reinterpret_cast<unsigned *>(end ? ring_vals : ring_vals + np);
           const int *koff = reinterpret_cast<const int *>(work + PL::kb_bytes + PL::start_bytes);
-          const unsigned *sorted = ord_merge_tree<256, CAP>(pkeys(kin), pkeys(1 - kin), koff, nbj, np, tid);
-          keys_in = sorted == pkeys(kin) ? kin : 1 - kin;
+          const unsigned *sorted = ord_merge_tree<256, CAP>(keys, second, koff, nbj, np, tid);
+          if (sorted != keys) {  // (the merge tree ends with a barrier)
+            for (int t = tid; t < np; t += 256) keys[t] = sorted[t];
+            __syncthreads();
+          }
         }
-        const int count = ordp_count(pkeys(keys_in), np, scratch_a, tid);
+        int before = 0;
+        const int count = ordp_count(keys, np, scratch_a, tid, &before);
         if (wave == 0) ord_publish(status, j, count);
         mark(5);
         finish_pending();
         mark(6);
-        pend.j = j; pend.np = np; pend.count = count; pend.keys_in = keys_in; pend.vals_in = vin; pend.valid = true;
+        pend.j = j; pend.np = np; pend.count = count; pend.before = before; pend.end = end; pend.valid = true;
       } else {  // empty, or computed beforehand into its scratch slot: publish the length, copy
         const int cnt = cw == 3 ? heavy_count[j] : 0;
         if (wave == 0) {
@@ -1664,33 +1796,42 @@ __global__ __launch_bounds__(256) void spgemm_ordered_kernel(Csc A, Csc B, int64
           }
         }
         __syncthreads();
+        request_next();
       }
     }
   }
   finish_pending();
   if (stamps && tid == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(stamps + i, acc_stamps[i]);
+    for (int i = 0; i < 12; ++i) atomicAdd(stamps + i, acc_stamps[i]);
 }
 
 // products in the columns where the ordered kernel's workgroup path pays: out[0] with the large shape
 // (513 ... 2048 products, <= 128 entries of B), out[1] with the small one (... 1536, <= 96)
 __global__ __launch_bounds__(256) void ord_share_kernel(Csc B, int64_t ncolsB, const int64_t *__restrict__ nprod,
                                                         unsigned long long *__restrict__ out) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // grid-stride over the columns, one pair of atomics per WORKGROUP: same-address atomics cost ~12 ns apiece on this part
+  // (round 4: one pair per wavefront of 64 columns, 32 768 of them = 0.42 ms of C4's 16.7)
   unsigned long long v = 0, w = 0;
-  if (j < ncolsB) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ncolsB; j += (int64_t)gridDim.x * blockDim.x) {
     const int64_t np = nprod[j];
     const int nb = B.p[j + 1] - B.p[j];
-    if (np > 2 * kOrdWaveCap && np <= kOrdCapLarge && nb <= kOrdPNbLarge) v = (unsigned long long)np;
-    if (np > 2 * kOrdWaveCap && np <= kOrdCapSmall && nb <= kOrdPNbSmall) w = (unsigned long long)np;
+    if (np > 2 * kOrdWaveCap && np <= kOrdAdmitLarge && nb <= kOrdPNbLarge) v += (unsigned long long)np;
+    if (np > 2 * kOrdWaveCap && np <= kOrdAdmitSmall && nb <= kOrdPNbSmall) w += (unsigned long long)np;
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
     v += __shfl_xor(v, d, 64);
     w += __shfl_xor(w, d, 64);
   }
-  if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
-  if ((threadIdx.x & 63) == 0 && w) atomicAdd(out + 1, w);
+  __shared__ unsigned long long sv[4], sw[4];
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; sw[threadIdx.x >> 6] = w; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    v = sv[0] + sv[1] + sv[2] + sv[3];
+    w = sw[0] + sw[1] + sw[2] + sw[3];
+    if (v) atomicAdd(out, v);
+    if (w) atomicAdd(out + 1, w);
+  }
 }
 
 // upper bound of a column's length in the result: exact for the columns computed beforehand, its products otherwise
@@ -1782,7 +1923,7 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
   if (ordered_possible && single_pass) {
     DBuf<unsigned long long> share(2);
     SPL_HIP(hipMemsetAsync(share.get(), 0, 2 * sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(ord_share_kernel, dim3(blocks_for(ncolsB, 256)), dim3(256), 0, s, B, ncolsB, nprod.get(), share.get());
+    hipLaunchKernelGGL(ord_share_kernel, dim3(std::min(blocks_for(ncolsB, 256), 256u)), dim3(256), 0, s, B, ncolsB, nprod.get(), share.get());
     unsigned long long h[2] = {0, 0};
     SPL_HIP(hipMemcpyAsync(h, share.get(), sizeof(h), hipMemcpyDeviceToHost, s));
     SPL_HIP(hipStreamSynchronize(s));
@@ -1790,12 +1931,17 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     large_shape = (double)(h[0] - h[1]) > 0.08 * (double)total_products;
     if (const char *e = getenv("SPL_SPGEMM_ORDERED_SHAPE")) large_shape = e[0] == 'l';
   }
-  const int ord_cap = large_shape ? kOrdCapLarge : kOrdCapSmall, ord_nb = large_shape ? kOrdPNbLarge : kOrdPNbSmall;
+  int ord_cap = large_shape ? kOrdAdmitLarge : kOrdAdmitSmall;
+  const int ord_nb = large_shape ? kOrdPNbLarge : kOrdPNbSmall;
+  if (const char *e = getenv("SPL_SPGEMM_ORD_CAP")) {  // ablation: admit fewer products per column to the ordered kernel's own path
+    const int v = atoi(e);
+    if (v >= 2 * kOrdWaveCap && v < ord_cap) ord_cap = v;
+  }
   lap("form chosen (share)");
   if (ordered) {  // the columns the ordered kernel handles itself leave the bin lists
     SPL_HIP(hipMemsetAsync(list_counts.get(), 0, 4 * sizeof(int), s));
-    hipLaunchKernelGGL(products_kernel, dim3(blocks_for(ncolsB, 32)), dim3(256), 0, s, A, B, ncolsB, nprod.get(),
-                       medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), 1, ord_cap, ord_nb, x_heavy);
+    hipLaunchKernelGGL(relist_ordered_kernel, dim3(blocks_for(ncolsB, 256)), dim3(256), 0, s, B, ncolsB, nprod.get(),
+                       medium_list.get(), xlarge_list.get(), dense_list.get(), list_counts.get(), ord_cap, ord_nb, x_heavy);
     SPL_HIP(hipMemcpyAsync(hc, list_counts.get(), 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     SPL_HIP(hipStreamSynchronize(s));
   }
@@ -2034,8 +2180,12 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     while ((1LL << rb) < nrowsA) ++rb;
     const int sh_wave = rb > 7 ? rb - 7 : 0, sh_group = rb > 9 ? rb - 9 : 0;  // 128 / 512 buckets
     typedef OrdLds<kOrdWaveCap, kOrdWaveNb> LW;
-    const size_t pipe_lds = large_shape ? (size_t)OrdPipeLds<kOrdCapLarge, kOrdPNbLarge>::total
-                                        : (size_t)OrdPipeLds<kOrdCapSmall, kOrdPNbSmall>::total;
+    // SPL_SPGEMM_RING=narrow (ablation): the small shape with 2 400 ring slots, five workgroups per CU (see kOrdRingSmallNarrow)
+    const char *ring_env = getenv("SPL_SPGEMM_RING");
+    const bool narrow_ring = !large_shape && ring_env && ring_env[0] == 'n';
+    const size_t pipe_lds = large_shape ? (size_t)OrdPipeLds<kOrdCapLarge, kOrdPNbLarge, kOrdRingLarge>::total
+                            : narrow_ring ? (size_t)OrdPipeLds<kOrdCapSmall, kOrdPNbSmall, kOrdRingSmallNarrow>::total
+                                          : (size_t)OrdPipeLds<kOrdCapSmall, kOrdPNbSmall, kOrdRingSmall>::total;
     const size_t lds = std::max((LW::total + 15) / 16 * 16 * 4, pipe_lds);
     int cus = 256;
     {
@@ -2068,21 +2218,23 @@ void spgemm_device(int64_t nrowsA, int64_t ncolsA, const int *Ap, const int *Ai,
     DBuf<unsigned long long> stamps;
     if (const char *ev = getenv("SPL_SPGEMM_STAMPS")) {
       if (ev[0] == '1') {
-        stamps.alloc(8);
-        SPL_HIP(hipMemsetAsync(stamps.get(), 0, 8 * sizeof(unsigned long long), s));
+        stamps.alloc(12);
+        SPL_HIP(hipMemsetAsync(stamps.get(), 0, 12 * sizeof(unsigned long long), s));
       }
     }
-    if (large_shape)
-      hipLaunchKernelGGL((spgemm_ordered_kernel<kOrdCapLarge, kOrdPNbLarge>), dim3((unsigned)grid), dim3(256), lds, s, A, B,
-                         ncolsB, sh_wave, sh_group, nprod.get(), cls.get(), heavy_slot.get(), counts.get(), Ti.get(), Tx.get(),
-                         status.get(), ticket, tasks.get(), ntasks, bmeta.get(), Cp.get(), Ci.get(), Cx.get(), stamps.get());
-    else
-      hipLaunchKernelGGL((spgemm_ordered_kernel<kOrdCapSmall, kOrdPNbSmall>), dim3((unsigned)grid), dim3(256), lds, s, A, B,
-                         ncolsB, sh_wave, sh_group, nprod.get(), cls.get(), heavy_slot.get(), counts.get(), Ti.get(), Tx.get(),
-                         status.get(), ticket, tasks.get(), ntasks, bmeta.get(), Cp.get(), Ci.get(), Cx.get(), stamps.get());
+#define SPL_ORD_LAUNCH(CAPV, NBV, RINGV, WGSV)                                                                          \
+  hipLaunchKernelGGL((spgemm_ordered_kernel<CAPV, NBV, RINGV, WGSV>), dim3((unsigned)grid), dim3(256), lds, s, A, B, ncolsB,  \
+                     sh_wave, sh_group, nprod.get(), cls.get(), heavy_slot.get(), counts.get(), Ti.get(), Tx.get(),            \
+                     status.get(), ticket, tasks.get(), ntasks, bmeta.get(), Cp.get(), Ci.get(), Cx.get(), stamps.get())
+    if (large_shape) SPL_ORD_LAUNCH(kOrdCapLarge, kOrdPNbLarge, kOrdRingLarge, 3);
+    else if (narrow_ring) SPL_ORD_LAUNCH(kOrdCapSmall, kOrdPNbSmall, kOrdRingSmallNarrow, 5);
+    else SPL_ORD_LAUNCH(kOrdCapSmall, kOrdPNbSmall, kOrdRingSmall, 4);
+#undef SPL_ORD_LAUNCH
     if (stamps.get()) {
-      unsigned long long h[8];
+      unsigned long long h[12];
       SPL_HIP(hipMemcpy(h, stamps.get(), sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[spgemm ordered] look-back inside the finish (wide form only): %llu ticks, of them %llu asleep for a column that had "
+              "not published; %llu rounds, %llu waits\n", h[8], h[9], h[10], h[11]);
       // (the wavefront path of light columns adds its own phases to slots 0-5: meaningful for one class at a time)
       fprintf(stderr, "[spgemm ordered] s_memtime ticks of thread 0 per phase, summed over %lld tasks: ticket+record %llu | "
               "stage+scan %llu | expand %llu | histogram scan %llu | scatter+bucket sort %llu | count+publish %llu | "
