@@ -59,6 +59,7 @@ struct TreeView {  // raw pointers for kernels
   int zm;
   int piv;  // 1: threshold pivoting inside the diagonal blocks (Band::piv)
   const double *rscale;  // ... with these row scales (per unknown of the tree, new ordering; nullptr: none)
+
   __device__ __forceinline__ double *front(int f) const { return region[depth[f] & 1] + (int64_t)zm * foff[f]; }
   __device__ __forceinline__ int64_t fplane(int f) const {  // doubles of one plane of the whole front (make_plan)
     const int64_t fs = np[f] + nb[f];
@@ -599,13 +600,10 @@ __global__ __launch_bounds__(256) void solve_gather_kernel(const int *__restrict
 }
 
 // forward elimination inside a front: y = M11^-1 W[0:np) block by block (stored inverses of the diagonal
-// blocks), every later entry of W loses its coupling with the block just solved
+// blocks), every later entry of W loses its coupling with the block just solved.  One workgroup; w, v: its LDS.
 template <bool TRANS, int NR, bool Z = false>
-__global__ __launch_bounds__(solve_threads<NR>()) void solve_forward_kernel(const int *__restrict__ list, TreeView t,
-                                                                      const double *__restrict__ invs,
-                                                                      double *__restrict__ work) {
-  __shared__ double w[NB][NR], v[NB][NR];
-  const int f = list[blockIdx.x];
+__device__ __forceinline__ void front_forward(const TreeView &t, int f, const double *__restrict__ invs,
+                                              double *__restrict__ work, double (*w)[NR], double (*v)[NR]) {
   const Panels fr = panels_of(t, f);
   const int np = fr.np, fs = fr.fs;
   double *W = work + (size_t)t.woff[f] * NR;
@@ -630,15 +628,20 @@ __global__ __launch_bounds__(solve_threads<NR>()) void solve_forward_kernel(cons
   }
 }
 
+template <bool TRANS, int NR, bool Z = false>
+__global__ __launch_bounds__(solve_threads<NR>()) void solve_forward_kernel(const int *__restrict__ list, TreeView t,
+                                                                      const double *__restrict__ invs,
+                                                                      double *__restrict__ work) {
+  __shared__ double w[NB][NR], v[NB][NR];
+  front_forward<TRANS, NR, Z>(t, list[blockIdx.x], invs, work, w, v);
+}
+
 // back substitution inside a front: x_piv = M11^-1 (y - M12 x_bnd), x_bnd read from the solution of
 // the ancestors; writes the pivots' part of the solution
 template <bool TRANS, int NR, bool Z = false>
-__global__ __launch_bounds__(solve_threads<NR>()) void solve_backward_kernel(const int *__restrict__ list, TreeView t,
-                                                                       const double *__restrict__ invs,
-                                                                       double *__restrict__ work,
-                                                                       double *__restrict__ x, size_t stride) {
-  __shared__ double w[NB][NR], v[NB][NR];
-  const int f = list[blockIdx.x];
+__device__ __forceinline__ void front_backward(const TreeView &t, int f, const double *__restrict__ invs,
+                                               double *__restrict__ work, double *__restrict__ x, size_t stride,
+                                               double (*w)[NR], double (*v)[NR]) {
   const Panels fr = panels_of(t, f);
   const int np = fr.np, nb = fr.nb, p0 = t.p0[f], fs = fr.fs;
   double *W = work + (size_t)t.woff[f] * NR;
@@ -675,6 +678,15 @@ __global__ __launch_bounds__(solve_threads<NR>()) void solve_backward_kernel(con
     couple_block<TRANS, NR, Z>(fr, 0, j0, j0, jb, v, W);
     __syncthreads();
   }
+}
+
+template <bool TRANS, int NR, bool Z = false>
+__global__ __launch_bounds__(solve_threads<NR>()) void solve_backward_kernel(const int *__restrict__ list, TreeView t,
+                                                                       const double *__restrict__ invs,
+                                                                       double *__restrict__ work,
+                                                                       double *__restrict__ x, size_t stride) {
+  __shared__ double w[NB][NR], v[NB][NR];
+  front_backward<TRANS, NR, Z>(t, list[blockIdx.x], invs, work, x, stride, w, v);
 }
 
 // ---- large fronts: the same steps spread over many workgroups, all large fronts of a level in
@@ -1057,6 +1069,7 @@ struct Factors {
   DBuf<int64_t> d_foff, d_cboff;     // where this factorisation's memory plan puts the fronts
   TreeView view;
   DBuf<double> arena, invs;  // factor panels, inverses of the diagonal blocks
+
   std::shared_ptr<LevelPlan> lp;  // lists and grids of the levels (shared with the other factorisations of this tree)
   using BigLevel = LevelPlan::BigLevel;
   int singular = 0;
@@ -1331,6 +1344,75 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
     F.lp->child_maxnb[sl].assign((size_t)nd, 0);
     F.lp->h_child[sl].assign((size_t)nd, std::vector<int>());
   }
+  // the flat grids of the lockstep solve kernels for the large fronts `large` of one depth
+  auto build_big = [&](mf::Factors::BigLevel &B, std::vector<int> large) {
+    B.count = (int)large.size();
+    constexpr int span = SB * NB;
+    for (int f : large) B.steps = std::max(B.steps, (T.np[(size_t)f] + span - 1) / span);
+    if (B.count > 0) {
+      // every workgroup of a step redoes the in-super-block solve: where the first step alone
+      // would launch thousands of workgroups, each takes kSolveRowBlocks blocks of rows instead
+      int64_t first_step = 0;
+      for (int f : large) first_step += (T.fs(f) + 63) / 64;
+      B.row_blocks = first_step >= 4096 ? kSolveRowBlocks : 1;
+      const int rbk = B.row_blocks;
+      B.h.assign((size_t)(3 * B.steps + 10 + 2 * (B.steps + 1)) * (size_t)(B.count + 1), 0);
+      auto fill = [&](int kind, int k, auto groups_of) {
+        int64_t *pre = B.h.data() + B.seg(kind, k);
+        for (int i = 0; i < B.count; ++i) pre[i + 1] = pre[i] + groups_of(large[(size_t)i]);
+      };
+      for (int k = 0; k < B.steps; ++k) {
+        auto fwd_rows = [&](int f, int n) -> int64_t {  // workgroups of forward step k of a pass over n rows
+          const int np = T.np[(size_t)f], j0 = k * span;
+          if (j0 >= np) return 0;
+          const int jbs = std::min(span, np - j0);
+          return std::max(1, ((n - (j0 + jbs) + 63) / 64 + rbk - 1) / rbk);
+        };
+        fill(0, k, [&](int f) { return fwd_rows(f, T.fs(f)); });
+        fill(1, k, [&](int f) { return fwd_rows(f, T.np[(size_t)f]); });
+        fill(2, k, [&](int f) -> int64_t {
+          const int np = T.np[(size_t)f], nsup = (np + span - 1) / span;
+          if (k >= nsup) return 0;
+          return std::max(1, (((nsup - 1 - k) * span + 63) / 64 + rbk - 1) / rbk);
+        });
+      }
+      for (int k = 0; k <= B.steps; ++k) {  // the pipelined passes: lead groups of step k + bulk groups of step k - 1
+        auto groups = [&](int f, bool forward) -> int64_t {
+          const int np = T.np[(size_t)f], nsup = (np + span - 1) / span;
+          auto beyond = [&](int st) {  // rows of the pivot block still to be updated by step st
+            const int j0 = (forward ? st : nsup - 1 - st) * span, jbs = std::min(span, np - j0);
+            return forward ? np - (j0 + jbs) : j0;
+          };
+          int64_t g = 0;
+          if (k < nsup) g += std::max(1, std::min(SB, (beyond(k) + 63) / 64));
+          if (k >= 1 && k - 1 < nsup) {
+            const int rest = beyond(k - 1) - span;
+            if (rest > 0) g += ((rest + 63) / 64 + rbk - 1) / rbk;
+          }
+          return g;
+        };
+        fill(13, k, [&](int f) { return groups(f, true); });
+        fill(14, k, [&](int f) { return groups(f, false); });
+      }
+      fill(3, 0, [&](int f) -> int64_t { return (T.nb[(size_t)f] + 3) / 4; });
+      fill(4, 0, [&](int f) -> int64_t { return (T.nb[(size_t)f] + 255) / 256; });
+      fill(5, 0, [&](int f) -> int64_t { return T.nb[(size_t)f] > 0 ? (T.np[(size_t)f] + 63) / 64 : 0; });
+      fill(6, 0, [&](int f) -> int64_t { return (T.np[(size_t)f] + 255) / 256; });
+      auto chunks = [&](int f) -> int64_t { return (T.nb[(size_t)f] + kGemvChunk - 1) / kGemvChunk; };
+      fill(7, 0, [&](int f) -> int64_t { return (int64_t)((T.np[(size_t)f] + 63) / 64) * chunks(f); });
+      fill(8, 0, [&](int f) -> int64_t { return chunks(f) > 1 ? (T.np[(size_t)f] + 255) / 256 : 0; });
+      fill(9, 0, [&](int f) -> int64_t { return chunks(f) > 1 ? chunks(f) * T.np[(size_t)f] : 0; });
+      F.lp->gemv_scratch = std::max(F.lp->gemv_scratch, B.h[B.seg(9) + (size_t)B.count]);
+      auto fchunks = [&](int f) -> int64_t { return (T.np[(size_t)f] + kGemvChunk - 1) / kGemvChunk; };
+      fill(10, 0, [&](int f) -> int64_t { return (int64_t)((T.nb[(size_t)f] + (T.np[(size_t)f] & 15) + 63) / 64) * fchunks(f); });
+      fill(11, 0, [&](int f) -> int64_t { return fchunks(f) > 1 ? (T.nb[(size_t)f] + 255) / 256 : 0; });
+      fill(12, 0, [&](int f) -> int64_t { return fchunks(f) > 1 ? fchunks(f) * T.nb[(size_t)f] : 0; });
+      F.lp->gemv_scratch = std::max(F.lp->gemv_scratch, B.h[B.seg(12) + (size_t)B.count]);
+      staged.push_back(std::move(large));
+      upload_vec(B.list, staged.back(), s);
+      upload_vec(B.d, B.h, s);
+    }
+      };
   staged.reserve((size_t)nd);
   for (int d = 0; d < nd; ++d) {
     upload_vec(F.lp->level_lists[(size_t)d], T.by_depth[(size_t)d], s);
@@ -1345,76 +1427,10 @@ mf::Factors *mf_factor_t(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, 
     staged.push_back(std::move(one_wg));
     upload_vec(F.lp->solve_lists[(size_t)d], staged.back(), s);
     {
-      mf::Factors::BigLevel &B = F.lp->big[(size_t)d];
       std::vector<int> large;
       for (int f : T.by_depth[(size_t)d])
         if (T.fs(f) > F.lp->big_solve && T.np[(size_t)f] > 0) large.push_back(f);
-      B.count = (int)large.size();
-      constexpr int span = SB * NB;
-      for (int f : large) B.steps = std::max(B.steps, (T.np[(size_t)f] + span - 1) / span);
-      if (B.count > 0) {
-        // every workgroup of a step redoes the in-super-block solve: where the first step alone
-        // would launch thousands of workgroups, each takes kSolveRowBlocks blocks of rows instead
-        int64_t first_step = 0;
-        for (int f : large) first_step += (T.fs(f) + 63) / 64;
-        B.row_blocks = first_step >= 4096 ? kSolveRowBlocks : 1;
-        const int rbk = B.row_blocks;
-        B.h.assign((size_t)(3 * B.steps + 10 + 2 * (B.steps + 1)) * (size_t)(B.count + 1), 0);
-        auto fill = [&](int kind, int k, auto groups_of) {
-          int64_t *pre = B.h.data() + B.seg(kind, k);
-          for (int i = 0; i < B.count; ++i) pre[i + 1] = pre[i] + groups_of(large[(size_t)i]);
-        };
-        for (int k = 0; k < B.steps; ++k) {
-          auto fwd_rows = [&](int f, int n) -> int64_t {  // workgroups of forward step k of a pass over n rows
-            const int np = T.np[(size_t)f], j0 = k * span;
-            if (j0 >= np) return 0;
-            const int jbs = std::min(span, np - j0);
-            return std::max(1, ((n - (j0 + jbs) + 63) / 64 + rbk - 1) / rbk);
-          };
-          fill(0, k, [&](int f) { return fwd_rows(f, T.fs(f)); });
-          fill(1, k, [&](int f) { return fwd_rows(f, T.np[(size_t)f]); });
-          fill(2, k, [&](int f) -> int64_t {
-            const int np = T.np[(size_t)f], nsup = (np + span - 1) / span;
-            if (k >= nsup) return 0;
-            return std::max(1, (((nsup - 1 - k) * span + 63) / 64 + rbk - 1) / rbk);
-          });
-        }
-        for (int k = 0; k <= B.steps; ++k) {  // the pipelined passes: lead groups of step k + bulk groups of step k - 1
-          auto groups = [&](int f, bool forward) -> int64_t {
-            const int np = T.np[(size_t)f], nsup = (np + span - 1) / span;
-            auto beyond = [&](int st) {  // rows of the pivot block still to be updated by step st
-              const int j0 = (forward ? st : nsup - 1 - st) * span, jbs = std::min(span, np - j0);
-              return forward ? np - (j0 + jbs) : j0;
-            };
-            int64_t g = 0;
-            if (k < nsup) g += std::max(1, std::min(SB, (beyond(k) + 63) / 64));
-            if (k >= 1 && k - 1 < nsup) {
-              const int rest = beyond(k - 1) - span;
-              if (rest > 0) g += ((rest + 63) / 64 + rbk - 1) / rbk;
-            }
-            return g;
-          };
-          fill(13, k, [&](int f) { return groups(f, true); });
-          fill(14, k, [&](int f) { return groups(f, false); });
-        }
-        fill(3, 0, [&](int f) -> int64_t { return (T.nb[(size_t)f] + 3) / 4; });
-        fill(4, 0, [&](int f) -> int64_t { return (T.nb[(size_t)f] + 255) / 256; });
-        fill(5, 0, [&](int f) -> int64_t { return T.nb[(size_t)f] > 0 ? (T.np[(size_t)f] + 63) / 64 : 0; });
-        fill(6, 0, [&](int f) -> int64_t { return (T.np[(size_t)f] + 255) / 256; });
-        auto chunks = [&](int f) -> int64_t { return (T.nb[(size_t)f] + kGemvChunk - 1) / kGemvChunk; };
-        fill(7, 0, [&](int f) -> int64_t { return (int64_t)((T.np[(size_t)f] + 63) / 64) * chunks(f); });
-        fill(8, 0, [&](int f) -> int64_t { return chunks(f) > 1 ? (T.np[(size_t)f] + 255) / 256 : 0; });
-        fill(9, 0, [&](int f) -> int64_t { return chunks(f) > 1 ? chunks(f) * T.np[(size_t)f] : 0; });
-        F.lp->gemv_scratch = std::max(F.lp->gemv_scratch, B.h[B.seg(9) + (size_t)B.count]);
-        auto fchunks = [&](int f) -> int64_t { return (T.np[(size_t)f] + kGemvChunk - 1) / kGemvChunk; };
-        fill(10, 0, [&](int f) -> int64_t { return (int64_t)((T.nb[(size_t)f] + (T.np[(size_t)f] & 15) + 63) / 64) * fchunks(f); });
-        fill(11, 0, [&](int f) -> int64_t { return fchunks(f) > 1 ? (T.nb[(size_t)f] + 255) / 256 : 0; });
-        fill(12, 0, [&](int f) -> int64_t { return fchunks(f) > 1 ? fchunks(f) * T.nb[(size_t)f] : 0; });
-        F.lp->gemv_scratch = std::max(F.lp->gemv_scratch, B.h[B.seg(12) + (size_t)B.count]);
-        staged.push_back(std::move(large));
-        upload_vec(B.list, staged.back(), s);
-        upload_vec(B.d, B.h, s);
-      }
+      build_big(F.lp->big[(size_t)d], std::move(large));
     }
     if (d + 1 < nd) {
       for (int c : T.by_depth[(size_t)d + 1]) F.lp->h_child[T.slot[(size_t)c]][(size_t)d].push_back(c);
@@ -1765,6 +1781,35 @@ static void launch_big_pipe(const mf::Factors &F, const mf::Factors::BigLevel &B
   }
 }
 
+// the solve lists of one depth
+struct SolveLevel {
+  const int *solve_list;
+  int solve_count;
+  const int *child_list[2];
+  int child_count[2], child_maxnb[2];
+  const mf::Factors::BigLevel *big;
+};
+static SolveLevel whole_level(const mf::LevelPlan &lp, int d, int nd) {
+  SolveLevel L;
+  L.solve_list = lp.solve_lists[(size_t)d].get();
+  L.solve_count = lp.solve_counts[(size_t)d];
+  for (int sl = 0; sl < 2; ++sl) {
+    L.child_list[sl] = d + 1 < nd ? lp.child_lists[sl][(size_t)d].get() : nullptr;
+    L.child_count[sl] = d + 1 < nd ? lp.child_counts[sl][(size_t)d] : 0;
+    L.child_maxnb[sl] = d + 1 < nd ? lp.child_maxnb[sl][(size_t)d] : 0;
+  }
+  L.big = &lp.big[(size_t)d];
+  return L;
+}
+// NR columns through the tree, up with L (or U^T) and down with U (or L^T), level by level on the caller's stream.
+// What bounds a walk at the FEAST sizes (kernel trace of a 100^3 solve, profiles/r05_solve_100_kernel_trace.txt): 931
+// kernels of 5 - 40 us in 16 ms, the GPU "busy" 97 % of the time, launch gaps 0.5 ms in all — the time is the fixed cost
+// and the inner latency chain of each kernel, not the gaps between them, so a captured graph buys nothing.  Two other
+// shapes of the walk were built and measured in round 5, both bit-identical to this one and both slower
+// (profiles/r05_solve_walk_experiments.txt): a whole subtree per workgroup below a cut depth (one launch per direction
+// for the deep levels; a front of 1 000 rows takes a single workgroup 100 us: 19.9 ms at depth 14, 15.4 at 18 against
+// 15.5), and the subtrees of the top nodes side by side on streams of their own (2 branches 16.1 ms, 4 branches 18.3:
+// kernels of different streams do not overlap their fixed costs here, the dispatcher takes them one at a time).
 template <bool TRANS, int NR, bool Z = false>
 static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride, double *work, double *zbuf,
                                   double *gscr, double *cbuf, hipStream_t s) {
@@ -1772,7 +1817,7 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
   const int nd = T.maxdepth + 1;
   double *invs = F.invs.get();
   constexpr int FWD = TRANS ? 2 : 0, BWD = TRANS ? 3 : 1;
-  const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // per-level times on stderr (diagnostic)
+  const bool timing = getenv("SPL_MF_TIMING") != nullptr;  // per-level times on stderr (diagnostic; the walk is then not split)
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char *dir, int d) {
     if (!timing) return;
@@ -1796,39 +1841,34 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
             large ? F.lp->big[(size_t)d].steps : 0, maxnp);
     t_last = now;
   };
-  if (timing) (void)hipStreamSynchronize(s);
-  t_last = std::chrono::steady_clock::now();
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_init_kernel<NR, Z>), dim3((unsigned)T.nfronts, 8), dim3(256), 0, s, F.view, c, stride,
-                     work);
-  for (int d = nd - 1; d >= 0; --d) {
-    if (d + 1 < nd)
-      for (int sl = 0; sl < 2; ++sl)
-        if (F.lp->child_counts[sl][(size_t)d] > 0) {
-          const int64_t most = (int64_t)F.lp->child_maxnb[sl][(size_t)d] * NR;  // entries of the largest child
-          const unsigned share = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (most + 2047) / 2048));
-          hipLaunchKernelGGL(solve_gather_kernel<NR>, dim3((unsigned)F.lp->child_counts[sl][(size_t)d], share), dim3(256), 0, s,
-                             F.lp->child_lists[sl][(size_t)d].get(), F.view, work);
-        }
-    if (F.lp->solve_counts[(size_t)d] > 0)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_forward_kernel<TRANS, NR, Z>), dim3((unsigned)F.lp->solve_counts[(size_t)d]),
-                         dim3(solve_threads<NR>()), 0, s, F.lp->solve_lists[(size_t)d].get(), F.view, invs, work);
-    lap("up small  ", d);
-    const mf::Factors::BigLevel &B = F.lp->big[(size_t)d];
+  // (split: SPL_MF_SPLIT_FWD=0 restores the steps over all fs rows of rounds 1 - 3; pipe: SPL_MF_PIPE=0 restores one
+  // launch per step with the whole chain in it: ablations, read once per walk)
+  const char *sf = getenv("SPL_MF_SPLIT_FWD"), *pe = getenv("SPL_MF_PIPE");
+  const bool split_fwd = !(sf && sf[0] == '0'), pipe_on = !(pe && pe[0] == '0');
+
+  // one level on the way up: children's boundaries into their parents, the one-workgroup fronts, the large ones in lockstep
+  auto up_level = [&](const SolveLevel &L, double *scr, hipStream_t q) {
+    for (int sl = 0; sl < 2; ++sl)
+      if (L.child_count[sl] > 0) {
+        const int64_t most = (int64_t)L.child_maxnb[sl] * NR;  // entries of the largest child
+        const unsigned share = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (most + 2047) / 2048));
+        hipLaunchKernelGGL(solve_gather_kernel<NR>, dim3((unsigned)L.child_count[sl], share), dim3(256), 0, q, L.child_list[sl],
+                           F.view, work);
+      }
+    if (L.solve_count > 0)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_forward_kernel<TRANS, NR, Z>), dim3((unsigned)L.solve_count),
+                         dim3(solve_threads<NR>()), 0, q, L.solve_list, F.view, invs, work);
+    const mf::Factors::BigLevel &B = *L.big;
     if (B.count > 0) {
-      // untransposed: the boundary rows get their updates inside the pass over the pivot columns;
-      // transposed: U11^T on the pivots, then the boundary with U12^T
-      // (split: SPL_MF_SPLIT_FWD=0 restores the steps over all fs rows of rounds 1 - 3, for ablation)
-      const char *sf = getenv("SPL_MF_SPLIT_FWD");
-      const bool split = !(sf && sf[0] == '0');
-      const bool pivots_only = !TRANS && split;
-      // (pipe: SPL_MF_PIPE=0 restores one launch per step with the whole chain in it, for ablation)
-      const char *pe = getenv("SPL_MF_PIPE");
-      // (one or two columns only: with 8 or 16 the in-super-block solve is instruction-bound, and the bulk groups'
-      // reload of the solved super block costs more than the overlap gains: FEAST 80^3 solve stage 2.95 -> 3.05 s)
-      const bool pipe = !(pe && pe[0] == '0') && (TRANS || pivots_only) && NR <= 2;
-      if (pipe) launch_big_pipe<FWD, NR, Z>(F, B, 13, work, zbuf, cbuf, s);
+      // untransposed: the boundary rows get their updates from a streaming product of their own once the pivots are
+      // solved; transposed: U11^T on the pivots, then the boundary with U12^T
+      const bool pivots_only = !TRANS && split_fwd;
+      // (pipelined steps with one or two columns only: with 8 or 16 the in-super-block solve is instruction-bound, and the
+      // bulk groups' reload of the solved super block costs more than the overlap gains: FEAST 80^3 solve stage 2.95 -> 3.05 s)
+      const bool pipe = pipe_on && (TRANS || pivots_only) && NR <= 2;
+      if (pipe) launch_big_pipe<FWD, NR, Z>(F, B, 13, work, zbuf, cbuf, q);
       else
-      for (int k = 0; k < B.steps; ++k) launch_big_super<FWD, NR, Z>(F, B, (TRANS || pivots_only) ? 1 : 0, k, work, zbuf, s, pivots_only ? 1 : 0);
+        for (int k = 0; k < B.steps; ++k) launch_big_super<FWD, NR, Z>(F, B, (TRANS || pivots_only) ? 1 : 0, k, work, zbuf, q, pivots_only ? 1 : 0);
       if (pivots_only && B.total(10) > 0) {
         constexpr size_t lds = (size_t)std::max(kGemvChunk, gemv_waves<NR>() * 64) * NR * sizeof(double);
         static std::atomic<uint64_t> attr_set{0};  // one mask per instantiation, one bit per device
@@ -1837,28 +1877,26 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           mark_used_on_this_device(attr_set);
         }
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_chunk_kernel<NR, Z, true>), dim3(B.total(10)), dim3(gemv_waves<NR>() * 64), lds, s,
-                           B.list.get(), B.prefix(10), B.count, F.view, work, zbuf, B.prefix(12), gscr);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_chunk_kernel<NR, Z, true>), dim3(B.total(10)), dim3(gemv_waves<NR>() * 64), lds, q,
+                           B.list.get(), B.prefix(10), B.count, F.view, work, zbuf, B.prefix(12), scr);
         if (B.total(11) > 0)
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_reduce_kernel<NR, true>), dim3(B.total(11)), dim3(256), 0, s, B.list.get(),
-                             B.prefix(11), B.count, F.view, work, zbuf, B.prefix(12), gscr);
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_reduce_kernel<NR, true>), dim3(B.total(11)), dim3(256), 0, q, B.list.get(),
+                             B.prefix(11), B.count, F.view, work, zbuf, B.prefix(12), scr);
       }
       if (TRANS && B.total(3) > 0)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_boundary_t_kernel<NR, Z>), dim3(B.total(3)), dim3(256), 0, s, B.list.get(),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_boundary_t_kernel<NR, Z>), dim3(B.total(3)), dim3(256), 0, q, B.list.get(),
                            B.prefix(3), B.count, F.view, work, zbuf);
     }
-    lap("up large  ", d);
-  }
-  for (int d = 0; d < nd; ++d) {
-    if (F.lp->solve_counts[(size_t)d] > 0)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_backward_kernel<TRANS, NR, Z>), dim3((unsigned)F.lp->solve_counts[(size_t)d]),
-                         dim3(solve_threads<NR>()), 0, s, F.lp->solve_lists[(size_t)d].get(), F.view, invs, work, c,
-                         stride);
-    lap("down small", d);
-    const mf::Factors::BigLevel &B = F.lp->big[(size_t)d];
+  };
+  // ... and on the way down
+  auto down_level = [&](const SolveLevel &L, double *scr, hipStream_t q) {
+    if (L.solve_count > 0)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_backward_kernel<TRANS, NR, Z>), dim3((unsigned)L.solve_count),
+                         dim3(solve_threads<NR>()), 0, q, L.solve_list, F.view, invs, work, c, stride);
+    const mf::Factors::BigLevel &B = *L.big;
     if (B.count > 0) {
       if (B.total(4) > 0) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gather_x_kernel<NR, Z>), dim3(B.total(4)), dim3(256), 0, s, B.list.get(),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gather_x_kernel<NR, Z>), dim3(B.total(4)), dim3(256), 0, q, B.list.get(),
                            B.prefix(4), B.count, F.view, c, stride, work, zbuf);
         {
           constexpr size_t lds = (size_t)(TRANS ? kGemvChunk : std::max(kGemvChunk, gemv_waves<NR>() * 64)) * NR * sizeof(double);
@@ -1874,25 +1912,52 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
           }
           if (TRANS)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_chunk_t_kernel<NR, Z>), dim3(B.total(7)), dim3(gemv_waves<NR>() * 64), lds,
-                               s, B.list.get(), B.prefix(7), B.count, F.view, work, zbuf, B.prefix(9), gscr);
+                               q, B.list.get(), B.prefix(7), B.count, F.view, work, zbuf, B.prefix(9), scr);
           else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_chunk_kernel<NR, Z>), dim3(B.total(7)), dim3(gemv_waves<NR>() * 64), lds, s,
-                               B.list.get(), B.prefix(7), B.count, F.view, work, zbuf, B.prefix(9), gscr);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_chunk_kernel<NR, Z>), dim3(B.total(7)), dim3(gemv_waves<NR>() * 64), lds, q,
+                               B.list.get(), B.prefix(7), B.count, F.view, work, zbuf, B.prefix(9), scr);
           if (B.total(8) > 0)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_reduce_kernel<NR>), dim3(B.total(8)), dim3(256), 0, s, B.list.get(),
-                               B.prefix(8), B.count, F.view, work, zbuf, B.prefix(9), gscr);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_reduce_kernel<NR>), dim3(B.total(8)), dim3(256), 0, q, B.list.get(),
+                               B.prefix(8), B.count, F.view, work, zbuf, B.prefix(9), scr);
         }
       }
       // the pivot block alone; columns of Z / W are fs apart
-      {
-        const char *pe = getenv("SPL_MF_PIPE");
-        if (!(pe && pe[0] == '0') && NR <= 2) launch_big_pipe<BWD, NR, Z>(F, B, 14, work, zbuf, cbuf, s);
-        else
-        for (int k = 0; k < B.steps; ++k) launch_big_super<BWD, NR, Z>(F, B, 2, k, work, zbuf, s);
-      }
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(big_scatter_x_kernel<NR, Z>), dim3(B.total(6)), dim3(256), 0, s, B.list.get(),
+      if (pipe_on && NR <= 2) launch_big_pipe<BWD, NR, Z>(F, B, 14, work, zbuf, cbuf, q);
+      else
+        for (int k = 0; k < B.steps; ++k) launch_big_super<BWD, NR, Z>(F, B, 2, k, work, zbuf, q);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(big_scatter_x_kernel<NR, Z>), dim3(B.total(6)), dim3(256), 0, q, B.list.get(),
                          B.prefix(6), B.count, F.view, work, zbuf, c, stride);
     }
+  };
+
+  if (timing) (void)hipStreamSynchronize(s);
+  t_last = std::chrono::steady_clock::now();
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_init_kernel<NR, Z>), dim3((unsigned)T.nfronts, 8), dim3(256), 0, s, F.view, c, stride,
+                     work);
+  for (int d = nd - 1; d >= 0; --d) {
+    const SolveLevel L = whole_level(*F.lp, d, nd);
+    if (!timing) { up_level(L, gscr, s); continue; }
+    // (timed: the one-workgroup fronts and the large ones apart, as the level table of profiles/ wants them)
+    SolveLevel small = L, large = L;
+    static const mf::Factors::BigLevel none;
+    small.big = &none;
+    large.solve_count = 0;
+    large.child_count[0] = large.child_count[1] = 0;
+    up_level(small, gscr, s);
+    lap("up small  ", d);
+    up_level(large, gscr, s);
+    lap("up large  ", d);
+  }
+  for (int d = 0; d < nd; ++d) {
+    const SolveLevel L = whole_level(*F.lp, d, nd);
+    if (!timing) { down_level(L, gscr, s); continue; }
+    SolveLevel small = L, large = L;
+    static const mf::Factors::BigLevel none;
+    small.big = &none;
+    large.solve_count = 0;
+    down_level(small, gscr, s);
+    lap("down small", d);
+    down_level(large, gscr, s);
     lap("down large", d);
   }
 }
@@ -1903,44 +1968,40 @@ void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride,
   const mf::Factors &F = *Fp;
   const mf::Tree &T = *F.tree;
   if (T.n == 0 || k == 0) return;
-  if (F.zm == 2) {
-    // complex fronts: the k columns are packed complex vectors of T.n entries (stride doubles apart); a complex
-    // right-hand side is two real columns of the work matrices: one at a time, or four together
-    constexpr int kGroupZ = 8;  // = kSolveGroup columns of the caller, each a packed complex vector: 16 real columns
-    const int nrz = k == 1 ? 2 : 2 * kGroupZ;
-    DBuf<double> wz(((size_t)T.work_elems * 3 + (size_t)F.lp->gemv_scratch) * nrz);  // work, z and carry matrices, scratch of the boundary products
-    double *wk = wz.get(), *zb = wz.get() + (size_t)T.work_elems * nrz, *gs = zb + (size_t)T.work_elems * nrz;
-    double *cb = gs + (size_t)F.lp->gemv_scratch * nrz;
-    if (k == 1) {
-      if (sys == 0) solve_columns_on_tree<false, 2, true>(F, d_c, stride, wk, zb, gs, cb, s);
-      else solve_columns_on_tree<true, 2, true>(F, d_c, stride, wk, zb, gs, cb, s);
+  const bool z = F.zm == 2;
+  // complex fronts: the k columns are packed complex vectors of T.n entries (stride doubles apart); a complex right-hand
+  // side is two real columns of the work matrices: one at a time, or eight together (= kSolveGroup columns of the caller)
+  constexpr int kGroupZ = 8;
+  const int nr = z ? (k == 1 ? 2 : 2 * kGroupZ) : (k == 1 ? 1 : kSolveGroup);
+  const size_t elems = ((size_t)T.work_elems * 3 + (size_t)F.lp->gemv_scratch) * (size_t)nr;  // work, z and carry matrices of all fronts, scratch
+  // every walk of this call on stream q, with the work matrices at `base`
+  auto run = [&](double *base, hipStream_t q) {
+    double *wk = base, *zb = base + (size_t)T.work_elems * nr, *gs = zb + (size_t)T.work_elems * nr;
+    double *cb = gs + (size_t)F.lp->gemv_scratch * nr;
+    if (z) {
+      if (k == 1) {
+        if (sys == 0) solve_columns_on_tree<false, 2, true>(F, d_c, stride, wk, zb, gs, cb, q);
+        else solve_columns_on_tree<true, 2, true>(F, d_c, stride, wk, zb, gs, cb, q);
+      } else {
+        for (int c0 = 0; c0 < k; c0 += kGroupZ) {  // (k is a multiple of kSolveGroup = 8 here: zero-padded by the caller)
+          double *c = d_c + (size_t)c0 * stride;
+          if (sys == 0) solve_columns_on_tree<false, 2 * kGroupZ, true>(F, c, stride, wk, zb, gs, cb, q);
+          else solve_columns_on_tree<true, 2 * kGroupZ, true>(F, c, stride, wk, zb, gs, cb, q);
+        }
+      }
+    } else if (k == 1) {
+      if (sys == 0) solve_columns_on_tree<false, 1>(F, d_c, stride, wk, zb, gs, cb, q);
+      else solve_columns_on_tree<true, 1>(F, d_c, stride, wk, zb, gs, cb, q);
     } else {
-      for (int c0 = 0; c0 < k; c0 += kGroupZ) {  // (k is a multiple of kSolveGroup = 8 here: zero-padded by the caller)
+      for (int c0 = 0; c0 < k; c0 += kSolveGroup) {
         double *c = d_c + (size_t)c0 * stride;
-        if (sys == 0) solve_columns_on_tree<false, 2 * kGroupZ, true>(F, c, stride, wk, zb, gs, cb, s);
-        else solve_columns_on_tree<true, 2 * kGroupZ, true>(F, c, stride, wk, zb, gs, cb, s);
+        if (sys == 0) solve_columns_on_tree<false, kSolveGroup>(F, c, stride, wk, zb, gs, cb, q);
+        else solve_columns_on_tree<true, kSolveGroup>(F, c, stride, wk, zb, gs, cb, q);
       }
     }
-    SPL_HIP(hipStreamSynchronize(s));
-    return;
-  }
-  const int nr = k == 1 ? 1 : kSolveGroup;
-  DBuf<double> both(((size_t)T.work_elems * 3 + (size_t)F.lp->gemv_scratch) * nr);  // work, z and carry matrices of all fronts, scratch: one allocation
-  struct Span {
-    double *p;
-    double *get() const { return p; }
-  } work{both.get()}, zbuf{both.get() + (size_t)T.work_elems * nr}, gscr{both.get() + (size_t)T.work_elems * nr * 2},
-      cbuf{both.get() + ((size_t)T.work_elems * 2 + (size_t)F.lp->gemv_scratch) * nr};
-  if (k == 1) {
-    if (sys == 0) solve_columns_on_tree<false, 1>(F, d_c, stride, work.get(), zbuf.get(), gscr.get(), cbuf.get(), s);
-    else solve_columns_on_tree<true, 1>(F, d_c, stride, work.get(), zbuf.get(), gscr.get(), cbuf.get(), s);
-  } else {
-    for (int c0 = 0; c0 < k; c0 += kSolveGroup) {
-      double *c = d_c + (size_t)c0 * stride;
-      if (sys == 0) solve_columns_on_tree<false, kSolveGroup>(F, c, stride, work.get(), zbuf.get(), gscr.get(), cbuf.get(), s);
-      else solve_columns_on_tree<true, kSolveGroup>(F, c, stride, work.get(), zbuf.get(), gscr.get(), cbuf.get(), s);
-    }
-  }
+  };
+  DBuf<double> both(elems);
+  run(both.get(), s);
   SPL_HIP(hipStreamSynchronize(s));  // the work matrices are freed on return
 }
 
