@@ -489,6 +489,13 @@ def main():
                 time.sleep(min(8.0, 1.0 + (time.perf_counter() - t_item) * 0.2))
         out["secondary"] = secondary
 
+    if rank == 0 and N > 1:
+        # the last line on stderr, <= 500 bytes: what a failed or odd-looking scaling run is diagnosed from
+        brief = {"n_gpus": N, "value": out["value"], "ms_per_step": out["ms_per_step"], "kernel_ms": roofline["kernel_ms"],
+                 "exchange": exchange[:120], "tournament": tuning, "fell_back": fell_back}
+        line = json.dumps(brief, separators=(",", ":"))
+        sys.stderr.write("\n" + (line if len(line) <= 500 else json.dumps({k: brief[k] for k in ("n_gpus", "value", "ms_per_step", "kernel_ms", "fell_back")})) + "\n")
+        sys.stderr.flush()
     if rank == 0:
         # The driver keeps the last 8 KB of stdout: the line stays under 7 500 bytes (tests/test_gpu_bench_rehearsal.py
         # asserts it on the full list of secondary items; round 4's 13.9 KB line lost three of them).  What every key

@@ -22,9 +22,11 @@ def _free_port():
     return p
 
 
-def _run(nproc, extra, chunks=None, exchange=None, plain=False, env_extra=None, want_stderr=False):
+def _run(nproc, extra, chunks=None, exchange=None, plain=False, env_extra=None, want_stderr=False, drop_env=()):
     env = dict(os.environ, SPL_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.update(env_extra or {})
+    for k in drop_env:
+        env.pop(k, None)
     if chunks is not None:
         env["SPL_BENCH_CHUNKS"] = str(chunks)
     if exchange is not None:
@@ -116,19 +118,34 @@ def test_plain_launch_starts_its_own_ranks(gpu):
     assert two["n_gpus"] == 2 and two["y_sha1"] == one["y_sha1"]
 
 
-@pytest.mark.skipif(os.environ.get("SPL_TEST_FOUR_RANKS") != "1",
-                    reason="4 ranks + launcher agent + this runner are exactly the 6 processes a one-GPU box admits: "
-                           "opt in with SPL_TEST_FOUR_RANKS=1 (passed on gfx950 in round 3); 3 ranks run by default")
 def test_four_ranks_all_schedules(gpu):
     """the widest rehearsal a one-GPU box admits (its process guard allows 6 processes on the card: this test
-    runner, the launcher's agent and 4 ranks): 3 IPC peers and 3 copy streams per rank, 4-way all-gather, all six
-    schedules measured and each equal to the single-rank y.  The 8-rank shape of config C3 is rehearsed on CPU
-    ranks (tests/test_dist_gloo.py)."""
-    args = ["--rows", "480000"]
+    runner and 4 ranks use it, the launcher's agent does not initialise it): 3 IPC peers and 3 copy streams per rank,
+    4-way all-gather, all six schedules measured and each equal to the single-rank y.  Unattended since round 5
+    (rounds 3 - 4: opt-in).  The 8-rank shape of config C3 is rehearsed on CPU ranks (tests/test_dist_gloo.py)."""
+    args = ["--rows", "240000"]
     one = _run(1, args)
-    four = _run(4, args)
+    four, err = _run(4, args, want_stderr=True)
     assert four["n_gpus"] == 4 and four["y_sha1"] == one["y_sha1"]
     assert set(four["config"]["exchange_ms_per_step_by_chunks"]) == {"rccl1", "rccl2", "rccl4", "peer1", "peer2", "peer4"}
+    # rank 0's last stderr line: a <= 500-byte summary a failed scaling run can be diagnosed from
+    last = [l for l in err.strip().splitlines() if l.startswith("{")][-1]
+    brief = json.loads(last)
+    assert len(last) <= 500 and brief["n_gpus"] == 4 and brief["value"] == four["value"] and set(brief["tournament"]) == set(four["config"]["exchange_ms_per_step_by_chunks"])
+
+
+@pytest.mark.parametrize("exchange", ["peer", "rccl"])
+def test_bench_sets_the_ipc_mode_itself(gpu, exchange):
+    """bench.py:88 `os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")`: this platform's host driver supports dmabuf
+    IPC only, and without the variable hipIpcGetMemHandle fails.  The pool's boxes export it; here it is REMOVED from the
+    ranks' environment, so the one-sided exchange (IPC handles of the peers' buffers) only works if bench.py put it back
+    before HIP initialised — what a bare 8-GPU box gets."""
+    args = ["--rows", "240000"]
+    one = _run(1, args)
+    two = _run(2, args, chunks=1, exchange=exchange, drop_env=("HSA_ENABLE_IPC_MODE_LEGACY",))
+    assert two["n_gpus"] == 2 and two["y_sha1"] == one["y_sha1"]
+    if exchange == "peer":
+        assert "one-sided peer stores" in two["config"]["workload"]
 
 
 def test_secondary_block_rides_on_the_headline_line(gpu):
