@@ -45,8 +45,11 @@
  * object keeps its previous factors).  SPL_LU_STATIC_PIVOT=0 skips the first stage.  SPL_LU_METHOD=band|mf forces the ordering.
  * RECTANGULAR matrices (n_row != n_col) are analysed and "factored" as far as the reference's binding can observe:
  * symbolic records shape and pattern, numeric checks the pattern and returns UMFPACK_OK when min(n_row, n_col) non-zero
- * pivots exist at all (the structural rank over the non-zero entries; UMFPACK counts the non-zero pivots it found) and
- * UMFPACK_WARNING_singular_matrix otherwise, without factoring anything; every solve returns
+ * pivots exist and UMFPACK_WARNING_singular_matrix otherwise, without keeping factors: the structural rank over the
+ * non-zero entries decides for large matrices, and a matrix with rows x columns x min(rows, columns) <= 4e8 that is
+ * structurally regular is eliminated on the host (row pivoting, a pivot counts unless exactly zero, as in UMFPACK), so
+ * the 3 x 2 matrix of ones is reported singular as UMFPACK reports it.  KNOWN DIVERGENCE: a large rectangular matrix
+ * that is structurally regular but numerically rank deficient gets UMFPACK_OK here.  Every solve returns
  * UMFPACK_ERROR_invalid_system, as UMFPACK's does ("the matrix is not square"; the reference's linearSolve_ assumes
  * square, Umfpack.hs:93).
  * The complex (`zi`) entry points (Internal.hs:69-115): a Numeric object holds the real 2n x 2n

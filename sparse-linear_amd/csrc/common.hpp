@@ -224,7 +224,8 @@ uint64_t pattern_hash(const int *Ai, int64_t nnz);
 // can observe — statuses; solves return UMFPACK_ERROR_invalid_system as UMFPACK's do
 int symbolic_rectangular(int n_row, int n_col, const int *Ap, const int *Ai, void **Symbolic);
 bool symbolic_is_rectangular(void *Symbolic);
-int numeric_rectangular_of(void *Symbolic, const int *Ap, const int *Ai, const std::vector<char> &nonzero, void **Numeric);
+int numeric_rectangular_of(void *Symbolic, const int *Ap, const int *Ai, const std::vector<char> &nonzero, void **Numeric,
+                           const double *re = nullptr, const double *im = nullptr, int vstride = 1);  // values: small matrices get their numerical rank
 bool numeric_is_rectangular(void *Numeric);
 void finalize_matrix(Matrix *m, hipStream_t s);
 int spmv_cus(const Matrix *m);  // CUs the persistent SpMV images are laid out for: the device's minus the reserved ones

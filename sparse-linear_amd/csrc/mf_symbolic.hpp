@@ -25,6 +25,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <exception>
 #include <vector>
 
 namespace spl {
@@ -75,6 +76,10 @@ struct Tree {
   // search has at most diameter + 1 levels and every ordering has bandwidth >= (n - 1) / diameter: a lower bound of
   // what a band factorisation of this pattern costs, without computing a band ordering (umfpack.hip)
   int root_levels = 0;
+  // a region without separators was left as ONE leaf after kMaxPeels unbalanced cuts (dissect): its front is not meant
+  // to be factored — a matrix that is not column dominant goes straight to static pivoting (umfpack.hip; ADVICE r4: this
+  // used to be inferred from the memory plan's allocation failure, after a dense front of up to 1e5 rows had been tried)
+  bool gave_up = false;
   int fs(int f) const { return np[(size_t)f] + nb[(size_t)f]; }
   // What a numeric factorisation derives from the tree alone — its arrays on the device, the positions of every
   // boundary index inside the parent's front — is built by the first factorisation and kept here for the later
@@ -91,7 +96,7 @@ struct Tree {
     ldp = o.ldp; ldu = o.ldu; ioff = o.ioff; woff = o.woff; roff = o.roff; level_elems = o.level_elems;
     region_elems[0] = o.region_elems[0]; region_elems[1] = o.region_elems[1];
     front_elems = o.front_elems; panel_elems = o.panel_elems; inv_elems = o.inv_elems; work_elems = o.work_elems;
-    rel_elems = o.rel_elems; flops = o.flops; by_depth = o.by_depth; root_levels = o.root_levels;
+    rel_elems = o.rel_elems; flops = o.flops; by_depth = o.by_depth; root_levels = o.root_levels; gave_up = o.gave_up;
     device_cache.reset();
     return *this;
   }
@@ -178,6 +183,7 @@ struct Shared {
   // cost the device more than the host's threads below 10^6 vertices: 3000^2 0.65 -> 0.91 s with this limit for all)
   int service_min_bulky = 150000;
   int root_levels = 0;  // levels of the root region's final level structure (written by the depth-0 call only)
+  std::atomic<int> gave_up{0};  // a region was left as one leaf because it has no separators (Tree::gave_up)
   std::atomic<int> stamp{0};
   Shared(int n_, const std::vector<int64_t> &xa, const std::vector<int> &ad, int leaf_)
       : n(n_), xadj(xa), adj(ad), leaf(leaf_), verts((size_t)n_), mark((size_t)n_, 0), level((size_t)n_, 0) {
@@ -454,8 +460,10 @@ struct Worker {
   std::vector<Node> dissect(int lo, int hi, int depth, int hint = -1, bool thin_parent = false, int peels = 0) {
     const int size = hi - lo;
     if (size <= S.leaf) return make_leaf(lo, hi);
-    if (peels >= kMaxPeels && peels < 1000 && size > 16 * S.leaf) return make_leaf(lo, hi);
-    if (peels >= 1000 + kMaxHubPeels && size > 16 * S.leaf) return make_leaf(lo, hi);
+    if ((peels >= kMaxPeels && peels < 1000 && size > 16 * S.leaf) || (peels >= 1000 + kMaxHubPeels && size > 16 * S.leaf)) {
+      S.gave_up.store(1, std::memory_order_relaxed);
+      return make_leaf(lo, hi);
+    }
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {  // SPL_MF_TIMING: the phases of the top regions
       if (!S.timing || depth > 2) return;
@@ -701,6 +709,7 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
     detail::Worker w(shared);
     nodes = w.dissect(0, n, 0);
     T.root_levels = shared.root_levels;
+    T.gave_up = shared.gave_up.load(std::memory_order_relaxed) != 0;
   }
   lap("dissection");
   // the node vector is a post-order: children before their parent
@@ -788,6 +797,20 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
         for (size_t k = i; k < std::min(i + chunk, L.size()); ++k) boundary_of(L[k]);
     };
     std::vector<std::thread> team;
+    // The team is stopped and joined on EVERY way out of this block (a bad_alloc in boundary_of on the main
+    // thread destroyed joinable threads -> std::terminate instead of UMFPACK_ERROR_out_of_memory); what a worker throws
+    // is kept and rethrown on the main thread after the level's barrier.
+    std::exception_ptr worker_error;
+    std::mutex worker_error_mu;
+    struct StopTeam {
+      std::atomic<int> &stop;
+      std::vector<std::thread> &team;
+      ~StopTeam() {
+        stop.store(1, std::memory_order_release);
+        for (std::thread &th : team)
+          if (th.joinable()) th.join();
+      }
+    } stop_team{stop, team};
     if (nthreads > 1 && nf >= 512)
       for (int w = 1; w < nthreads; ++w) {
         try {
@@ -800,7 +823,12 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
                 if (++spins > 200) { std::this_thread::yield(); spins = 0; }
               }
               seen = now;
-              take_chunks();
+              try {
+                take_chunks();
+              } catch (...) {
+                std::lock_guard<std::mutex> lk(worker_error_mu);
+                if (!worker_error) worker_error = std::current_exception();
+              }
               reported.fetch_add(1, std::memory_order_release);
             }
           });
@@ -822,10 +850,18 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
       next_item.store(0, std::memory_order_relaxed);
       reported.store(0, std::memory_order_relaxed);
       generation.fetch_add(1, std::memory_order_release);
-      take_chunks();
+      std::exception_ptr mine;
+      try {
+        take_chunks();
+      } catch (...) {
+        mine = std::current_exception();
+        next_item.store(L.size(), std::memory_order_relaxed);  // nothing more to hand out: the level ends at once
+      }
       while (reported.load(std::memory_order_acquire) < (int)team.size()) std::this_thread::yield();
+      if (mine) std::rethrow_exception(mine);
+      if (worker_error) std::rethrow_exception(worker_error);
     }
-    stop.store(1, std::memory_order_release);
+    stop.store(1, std::memory_order_release);  // (the guard above does the same on the exceptional ways out)
     for (std::thread &th : team) th.join();
     for (int f = 0; f < nf; ++f) {
       T.nb[(size_t)f] = (int)bnd[(size_t)f].size();

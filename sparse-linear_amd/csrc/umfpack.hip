@@ -30,6 +30,7 @@
 #include <mutex>
 #include <vector>
 
+#include <complex>
 #include "common.hpp"
 #include "mf_symbolic.hpp"
 #include "static_pivot.hpp"
@@ -1167,8 +1168,48 @@ int structural_rank(int n_row, int n_col, const int *Ap, const int *Ai, const st
   }
   return rank;
 }
+// Numerical rank of a SMALL rectangular matrix on the host (the structural rank over the non-zero entries
+// calls the 3 x 2 matrix of ones regular; UMFPACK meets an exactly zero pivot there and warns): Gaussian elimination
+// with row pivoting, column by column, a column without a non-zero candidate is dependent and skipped.  As in UMFPACK a
+// pivot counts unless it is exactly zero (or NaN).  Dense, so only where rows x columns x min(rows, columns) stays
+// below kDenseRankWork; -1: too large, the caller keeps the structural rank (documented in include/umfpack_hip.h).
+// re, im: the values (im may be null; packed complex: im = re + 1 with stride 2).
+constexpr double kDenseRankWork = 4e8;
+int dense_numeric_rank(int n_row, int n_col, const int *Ap, const int *Ai, const double *re, const double *im, int vstride) {
+  const double work = (double)n_row * (double)n_col * (double)std::min(n_row, n_col);
+  if (work > kDenseRankWork) return -1;
+  std::vector<std::complex<double>> a((size_t)n_row * (size_t)n_col);  // column-major
+  for (int j = 0; j < n_col; ++j)
+    for (int p = Ap[j]; p < Ap[j + 1]; ++p)
+      a[(size_t)Ai[p] + (size_t)j * (size_t)n_row] = std::complex<double>(re[(size_t)p * vstride], im ? im[(size_t)p * vstride] : 0.0);
+  std::vector<char> used((size_t)n_row, 0);
+  int rank = 0;
+  for (int j = 0; j < n_col && rank < n_row; ++j) {
+    std::complex<double> *cj = a.data() + (size_t)j * (size_t)n_row;
+    int piv = -1;
+    double best = 0.0;
+    for (int i = 0; i < n_row; ++i) {
+      if (used[(size_t)i]) continue;
+      const double mag = std::abs(cj[i]);
+      if (mag > best) { best = mag; piv = i; }  // (NaN never compares greater: no pivot)
+    }
+    if (piv < 0) continue;  // dependent on the columns before it
+    used[(size_t)piv] = 1;
+    ++rank;
+    for (int c = j + 1; c < n_col; ++c) {
+      std::complex<double> *cc = a.data() + (size_t)c * (size_t)n_row;
+      if (cc[piv] == std::complex<double>(0.0, 0.0)) continue;
+      const std::complex<double> f = cc[piv] / cj[piv];
+      for (int i = 0; i < n_row; ++i)
+        if (!used[(size_t)i]) cc[i] -= f * cj[i];
+    }
+  }
+  return rank;
+}
+
 // "factorisation" of a rectangular matrix: the pattern check and the status (Symbolic::rectangular)
-int numeric_rectangular(Symbolic *S, const int *Ap, const int *Ai, const std::vector<char> &nonzero, void **NumericOut) {
+int numeric_rectangular(Symbolic *S, const int *Ap, const int *Ai, const std::vector<char> &nonzero, void **NumericOut,
+                        const double *re = nullptr, const double *im = nullptr, int vstride = 1) {
   if (Ap[S->n_col] != S->nnz || !std::equal(S->Ap.begin(), S->Ap.end(), Ap) || hash_indices(Ai, S->nnz) != S->ai_hash)
     return UMFPACK_ERROR_different_pattern;
   try {
@@ -1179,7 +1220,11 @@ int numeric_rectangular(Symbolic *S, const int *Ap, const int *Ai, const std::ve
       (void)hipGetLastError();
       N->device = 0;
     }
-    const int rank = structural_rank(S->n_row, S->n_col, Ap, Ai, nonzero);
+    int rank = structural_rank(S->n_row, S->n_col, Ap, Ai, nonzero);
+    if (re && rank == std::min(S->n_row, S->n_col)) {  // structurally regular: small matrices are eliminated for real
+      const int numeric = dense_numeric_rank(S->n_row, S->n_col, Ap, Ai, re, im, vstride);
+      if (numeric >= 0) rank = numeric;
+    }
     N->singular = rank < std::min(S->n_row, S->n_col) ? 1 : 0;
     const int st = N->singular ? UMFPACK_WARNING_singular_matrix : UMFPACK_OK;
     *NumericOut = N.release();
@@ -1194,10 +1239,11 @@ bool symbolic_is_rectangular(void *SymbolicIn) {
   Symbolic *S = as_symbolic(SymbolicIn);
   return S && S->rectangular;
 }
-int numeric_rectangular_of(void *SymbolicIn, const int *Ap, const int *Ai, const std::vector<char> &nonzero, void **NumericOut) {
+int numeric_rectangular_of(void *SymbolicIn, const int *Ap, const int *Ai, const std::vector<char> &nonzero, void **NumericOut,
+                           const double *re, const double *im, int vstride) {
   Symbolic *S = as_symbolic(SymbolicIn);
   if (!S || !S->rectangular) return UMFPACK_ERROR_invalid_Symbolic_object;
-  return numeric_rectangular(S, Ap, Ai, nonzero, NumericOut);
+  return numeric_rectangular(S, Ap, Ai, nonzero, NumericOut, re, im, vstride);
 }
 bool numeric_is_rectangular(void *NumericIn) {
   Numeric *N = as_numeric(NumericIn);
@@ -1273,7 +1319,7 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
     if (Ap[S->n_col] != S->nnz) return UMFPACK_ERROR_different_pattern;
     std::vector<char> nonzero((size_t)S->nnz);
     for (int p = 0; p < S->nnz; ++p) nonzero[(size_t)p] = (Ax[p] != 0.0 && Ax[p] == Ax[p]) ? 1 : 0;  // (NaN: no pivot)
-    return numeric_rectangular(S, Ap, Ai, nonzero, NumericOut);
+    return numeric_rectangular(S, Ap, Ai, nonzero, NumericOut, Ax, nullptr, 1);
   }
   const int n = S->n;
   // (the `zi` wrapper has compared the complex pattern — a quarter of the embedding's — and vouches for the rest)
@@ -1360,6 +1406,9 @@ int umfpack_di_numeric(const int Ap[], const int Ai[], const double Ax[], void *
       bool fits = true;
       try {
         if (!dominant && getenv("SPL_LU_TEST_SPECULATION_OOM")) throw DeviceError{SPL_ERROR_out_of_memory};  // tests: as if it did not fit
+        // the analysis left a region without separators as one giant leaf (Tree::gave_up): that front is not for
+        // factoring — straight to static pivoting, whose transversal gives the matrix its mesh pattern back
+        if (!dominant && N->tree && N->tree->gave_up) throw DeviceError{SPL_ERROR_out_of_memory};
         if (N->tree) factor_multifrontal(N, s); else factor_band(N, true, s);
       } catch (const DeviceError &e) {
         // The speculation's own ordering does not fit the device: the pattern of A + A^T has no separators — e.g. a
@@ -1742,13 +1791,18 @@ static int solve_columns(Numeric *N, int sys, int k, double *X, const double *B,
 int umfpack_di_solve(int sys, const int Ap[], const int Ai[], const double Ax[], double X[],
                      const double B[], void *NumericIn, const double Control[], double Info[]) {
   (void)Control;
-  Numeric *N = as_numeric(NumericIn);
-  if (!N) return UMFPACK_ERROR_invalid_Numeric_object;
-  if (N->rectangular) return UMFPACK_ERROR_invalid_system;  // "the matrix is not square", as UMFPACK's solve
-  if (!X || !B) return UMFPACK_ERROR_argument_missing;
-  if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;  // UMFPACK needs A for refinement
-  if (sys != UMFPACK_A && sys != UMFPACK_At) return UMFPACK_ERROR_invalid_system;
-  return solve_columns(N, sys, 1, X, B, Ap, Ai, Ax, false, Info);
+  auto status = [&]() -> int {
+    Numeric *N = as_numeric(NumericIn);
+    if (!N) return UMFPACK_ERROR_invalid_Numeric_object;
+    if (N->rectangular) return UMFPACK_ERROR_invalid_system;  // "the matrix is not square", as UMFPACK's solve
+    if (!X || !B) return UMFPACK_ERROR_argument_missing;
+    if (!Ap || !Ai || !Ax) return UMFPACK_ERROR_argument_missing;  // UMFPACK needs A for refinement
+    if (sys != UMFPACK_A && sys != UMFPACK_At) return UMFPACK_ERROR_invalid_system;
+    return solve_columns(N, sys, 1, X, B, Ap, Ai, Ax, false, Info);
+  };
+  const int st = status();
+  if (Info && st < 0) Info[0] = st;  // Info[UMFPACK_STATUS] on the error returns as well
+  return st;
 }
 
 // batched linearSolve: nrhs right-hand sides in one call (see umfpack_hip.h)

@@ -280,7 +280,7 @@ int umfpack_zi_numeric(const int Ap[], const int Ai[], const double Ax[], const 
         const double re = Az ? Ax[p] : Ax[2 * (size_t)p], im = Az ? Az[p] : Ax[2 * (size_t)p + 1];
         nonzero[(size_t)p] = ((re != 0.0 || im != 0.0) && re == re && im == im) ? 1 : 0;
       }
-      return spl::numeric_rectangular_of(S->di, Ap, Ai, nonzero, Numeric);
+      return spl::numeric_rectangular_of(S->di, Ap, Ai, nonzero, Numeric, Ax, Az ? Az : Ax + 1, Az ? 1 : 2);
     } catch (...) {
       return UMFPACK_ERROR_out_of_memory;
     }
@@ -368,9 +368,21 @@ int umfpack_zi_numeric(const int Ap[], const int Ai[], const double Ax[], const 
   }
 }
 
+static int zi_solve(int sys, const int Ap[], const int Ai[], const double Ax[], const double Az[],
+                    double Xx[], double Xz[], const double Bx[], const double Bz[], void *Numeric,
+                    const double Control[], double Info[]);
+
 int umfpack_zi_solve(int sys, const int Ap[], const int Ai[], const double Ax[], const double Az[],
                      double Xx[], double Xz[], const double Bx[], const double Bz[], void *Numeric,
                      const double Control[], double Info[]) {
+  const int st = zi_solve(sys, Ap, Ai, Ax, Az, Xx, Xz, Bx, Bz, Numeric, Control, Info);
+  if (Info && st < 0) Info[0] = st;  // Info[UMFPACK_STATUS] on the error returns as well
+  return st;
+}
+
+static int zi_solve(int sys, const int Ap[], const int Ai[], const double Ax[], const double Az[],
+                    double Xx[], double Xz[], const double Bx[], const double Bz[], void *Numeric,
+                    const double Control[], double Info[]) {
   (void)Az;
   if (spl::numeric_is_rectangular(Numeric)) return UMFPACK_ERROR_invalid_system;
   if (!Xx || !Bx) return UMFPACK_ERROR_argument_missing;

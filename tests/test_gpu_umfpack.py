@@ -143,15 +143,19 @@ def test_rectangular_matrices_are_analysed_factored_and_refused_by_solve(gpu, pk
     tall = pkg.fromTriples(4, 2, [(0, 0, 1.0), (3, 0, 2.0), (3, 1, 3.0)])          # rank 2: column 1 must take row 3, column 0 row 0
     short = pkg.fromTriples(3, 2, [(2, 0, 1.0), (2, 1, 1.0)])                      # both columns only reach row 2: rank 1
     zeroed = pkg.fromTriples(2, 3, [(0, 0, 0.0), (1, 1, 2.0), (0, 2, 0.0)])        # stored zeros are no pivots: rank 1
-    for mat, want in ((wide, 0), (tall, 0), (short, 1), (zeroed, 1)):
+    # structurally regular, numerically rank 1 — UMFPACK meets an exactly zero pivot and warns; small matrices
+    # are eliminated on the host for their numerical rank (real and complex)
+    ones = pkg.fromTriples(3, 2, [(i, j, 1.0) for j in range(2) for i in range(3)])
+    zones = pkg.fromTriples(2, 3, [(i, j, (1.0 + 2.0j) * (j + 1)) for j in range(3) for i in range(2)])  # rows equal: rank 1
+    for mat, want in ((wide, 0), (tall, 0), (short, 1), (zeroed, 1), (ones, 1), (zones, 1)):
         an = U.analyze(mat)
         f = U.factor(mat, an)
         assert f.status == want
         with pytest.raises(U.UmfpackError) as e:
-            U.linearSolve_(f, U.UmfpackNormal, mat, np.ones(mat.nrows))
+            U.linearSolve_(f, U.UmfpackNormal, mat, np.ones(mat.nrows, dtype=complex if mat.is_complex else float))
         assert e.value.status == -13
         with pytest.raises(U.UmfpackError):
-            U.linearSolveMany_(f, U.UmfpackTrans, mat, [np.ones(mat.nrows)] * 2)
+            U.linearSolveMany_(f, U.UmfpackTrans, mat, [np.ones(mat.nrows, dtype=complex if mat.is_complex else float)] * 2)
     # the pattern is checked as for square matrices
     other = pkg.fromTriples(2, 3, [(0, 0, 1.0), (1, 1, 2.0), (1, 2, 3.0)])
     with pytest.raises(U.UmfpackError) as e:
@@ -173,6 +177,20 @@ def test_rectangular_matrices_are_analysed_factored_and_refused_by_solve(gpu, pk
     nr, nc, ap, ai, ax = wide._tuple32()
     f = U.factor(wide, U.analyze(wide))
     assert L.spl_umfpack_di_solve_many_dev(0, pkg._ffi.p_i32(ap), pkg._ffi.p_i32(ai), pkg._ffi.p_f64(ax), 1, None, None, f.value) == -13
+    # Info[UMFPACK_STATUS] carries the status on the error returns of the solves as well, real and complex
+    info = np.full(90, 7.0)
+    xb = np.ones(3)
+    assert L.umfpack_di_solve(0, pkg._ffi.p_i32(ap), pkg._ffi.p_i32(ai), pkg._ffi.p_f64(ax), pkg._ffi.p_f64(xb), pkg._ffi.p_f64(xb),
+                              f.value, None, pkg._ffi.p_f64(info)) == -13 and info[0] == -13.0
+    sq = pkg.fromTriples(2, 2, [(0, 0, 2.0), (1, 1, 4.0)])
+    fs = U.factor(sq, U.analyze(sq))
+    _nr, _nc, sp_, si_, sx_ = sq._tuple32()
+    info[:] = 7.0
+    assert L.umfpack_di_solve(5, pkg._ffi.p_i32(sp_), pkg._ffi.p_i32(si_), pkg._ffi.p_f64(sx_), pkg._ffi.p_f64(xb), pkg._ffi.p_f64(xb),
+                              fs.value, None, pkg._ffi.p_f64(info)) == -13 and info[0] == -13.0  # no such system
+    info[:] = 7.0
+    assert L.umfpack_di_solve(0, pkg._ffi.p_i32(sp_), pkg._ffi.p_i32(si_), pkg._ffi.p_f64(sx_), pkg._ffi.p_f64(xb), pkg._ffi.p_f64(np.array([2.0, 4.0, 0.0])),
+                              fs.value, None, pkg._ffi.p_f64(info)) == 0 and info[0] == 0.0 and xb[0] == 1.0 and xb[1] == 1.0
 
 
 def test_nopiv_path_unsymmetric_dominant_and_transposed(gpu, pkg, O):
