@@ -1,16 +1,16 @@
 #!/bin/bash
 # HBM-side traffic of the triangular solves from the PMC counters (separate passes, as the guide prescribes):
-#   bash tools/pmc_solve.sh [m]   -> gpurun_out/pmc_solve/summary.txt
+#   bash tools/pmc_solve.sh [m [z]]   -> gpurun_out/pmc_solve/summary.txt   (z: the complex shifted matrix, umfpack_zi_*)
 # Sums TCC_EA0_RDREQ (x 128 B, less 96 B per 32-B request) and WRITE_SIZE over the kernels of ONE linearSolve_ call and
 # sets them against walks x bytes per walk of spl_umfpack_solve_report.
 cd /tmp && export TMPDIR=/tmp
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out/pmc_solve
-m=${1:-128}
+m=${1:-128}; zflag=${2:-}
 rm -rf "$out"; mkdir -p "$out"
-timeout -k 10 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d "$out/rd" -- python3 "$repo/tools/pmc_solve_target.py" "$m" > "$out/rd.log" 2>&1
+timeout -k 10 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d "$out/rd" -- python3 "$repo/tools/pmc_solve_target.py" "$m" $zflag > "$out/rd.log" 2>&1
 echo "[pmc_solve] read pass rc=$?"
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/wr" -- python3 "$repo/tools/pmc_solve_target.py" "$m" > "$out/wr.log" 2>&1
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/wr" -- python3 "$repo/tools/pmc_solve_target.py" "$m" $zflag > "$out/wr.log" 2>&1
 echo "[pmc_solve] write pass rc=$?"
 python3 - "$out" "$m" <<'PY' | tee "$out/summary.txt"
 import csv, glob, re, sys, collections, ast
