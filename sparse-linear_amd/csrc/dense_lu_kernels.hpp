@@ -2085,6 +2085,20 @@ __device__ __forceinline__ void solve_super_block_in_lds(const Band &b, const do
   }
 }
 
+// Where a BACKWARD pass may put the solution of a super block besides `out` (round 5: the multifrontal walk wrote the
+// pivots' part of x with a launch of its own per level, big_scatter_x_kernel — a dependent kernel costs ~5 us whatever it
+// does).  x: the caller's solution array at this system's first unknown (complex: packed pairs, at 2 x that unknown);
+// column r of the work matrices is x + r * stride (complex: the real or imaginary parts of right-hand side r / 2).
+struct SolutionSink {
+  double *x = nullptr;
+  size_t stride = 0;
+};
+template <int NR, bool Z>
+__device__ __forceinline__ void sink_store(const SolutionSink &sk, int t, int r, double val) {
+  if (Z) sk.x[(size_t)(r >> 1) * sk.stride + 2 * (size_t)t + (r & 1)] = val;
+  else sk.x[(size_t)r * sk.stride + t] = val;
+}
+
 // NR right-hand sides at once: column r of in/out starts at r * stride
 // `tile`: which rows outside the super block this workgroup updates: `tiles` consecutive blocks of 64
 // rows starting at block tile * tiles (workgroup 0 also writes `out`).  Every workgroup redoes the
@@ -2092,7 +2106,7 @@ __device__ __forceinline__ void solve_super_block_in_lds(const Band &b, const do
 template <int MODE, int NR, bool Z = false>
 __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__restrict__ invs, int j0, int jbs,
                                                  double *in, double *__restrict__ out, size_t stride, int tile,
-                                                 double *dsm, int tiles = 1) {
+                                                 double *dsm, int tiles = 1, SolutionSink sink = SolutionSink()) {
   constexpr int SWV = solve_waves<NR>();
   double(*v)[NR] = reinterpret_cast<double(*)[NR]>(dsm);                          // [SB * NB]
   double(*w)[NR] = reinterpret_cast<double(*)[NR]>(dsm + SB * NB * NR);           // [NB]
@@ -2113,6 +2127,7 @@ __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__
     for (int o = tid; o < jbs * NR; o += SWV * 64) {
       const int t = o % jbs, r = o / jbs;
       out[(size_t)r * stride + j0 + t] = v[t][r];
+      if (sink.x) sink_store<NR, Z>(sink, j0 + t, r, v[t][r]);
     }
   // the rows of this workgroup outside the super block, 64 at a time
   for (int q = 0; q < tiles; ++q) {
@@ -2147,7 +2162,8 @@ __device__ __forceinline__ void solve_super_tile(const Band &b, const double *__
 template <int MODE, int NR, bool Z = false>
 __device__ __forceinline__ void solve_super_pipelined(const Band &b, const double *__restrict__ invs, int j0, int jbs,
                                                       double *in, double *out, double *carry, size_t stride, int role,
-                                                      int tile, bool first, double *dsm, int tiles) {
+                                                      int tile, bool first, double *dsm, int tiles,
+                                                      SolutionSink sink = SolutionSink()) {
   constexpr int SWV = solve_waves<NR>();
   double(*v)[NR] = reinterpret_cast<double(*)[NR]>(dsm);                          // [SB * NB]
   double(*w)[NR] = reinterpret_cast<double(*)[NR]>(dsm + SB * NB * NR);           // [NB]
@@ -2173,6 +2189,7 @@ __device__ __forceinline__ void solve_super_pipelined(const Band &b, const doubl
       for (int o = tid; o < jbs * NR; o += SWV * 64) {
         const int t = o % jbs, r = o / jbs;
         out[(size_t)r * stride + j0 + t] = v[t][r];
+        if (sink.x) sink_store<NR, Z>(sink, j0 + t, r, v[t][r]);
       }
     const int rb = fwd ? j0 + jbs + tile * 64 : j0 - (tile + 1) * 64;
     if (fwd ? rb >= b.n : rb + 64 <= 0) return;  // workgroup-uniform: no such rows (the last super block)

@@ -582,17 +582,19 @@ __global__ __launch_bounds__(256) void solve_init_kernel(TreeView t, const doubl
   }
 }
 
-// W(parent)[rel] += boundary part of W(child), for the listed children
+// W(parent)[rel] += boundary part of W(child), for the listed children: one launch per child slot (two children may add
+// into the same row of their parent, so the slots take turns).  Round 5 measured ONE launch for both slots — a workgroup
+// per parent and range of its rows, child 1 behind a barrier after child 0, same bits —: slower, 15.42 against 15.17 ms
+// per solve at 100^3 and 10.84 against 10.55 at complex 64^3 (same box, alternating runs).
 template <int NR>
 __global__ __launch_bounds__(256) void solve_gather_kernel(const int *__restrict__ children, TreeView t,
-                                                           double *__restrict__ work) {
+                                                                double *__restrict__ work) {
   const int c = children[blockIdx.x];
   const int p = t.parent[c], npc = t.np[c], nbc = t.nb[c];
   const int fsc = npc + nbc, fsp = t.np[p] + t.nb[p];
   const int *rel = t.rel + t.roff[c];
   const double *Wc = work + (size_t)t.woff[c] * NR;
   double *Wp = work + (size_t)t.woff[p] * NR;
-  // (gridDim.y workgroups share a child: the children of the top levels have boundaries of thousands of indices)
   for (int o = blockIdx.y * blockDim.x + threadIdx.x; o < nbc * NR; o += gridDim.y * blockDim.x) {
     const int k = o % nbc, r = o / nbc;
     Wp[(size_t)r * fsp + rel[k]] += Wc[(size_t)r * fsc + npc + k];
@@ -729,7 +731,8 @@ template <int MODE, int NR, bool Z = false>
 __global__ __launch_bounds__(solve_waves<NR>() * 64) void big_super_kernel(const int *__restrict__ list,
                                                             const int64_t *__restrict__ prefix, int count, int step,
                                                             TreeView t, const double *__restrict__ invs,
-                                                            double *work, double *zbuf, int row_blocks, int pivots_only) {
+                                                            double *work, double *zbuf, int row_blocks, int pivots_only,
+                                                            double *x, size_t xstride) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   constexpr bool fwd = (MODE == 0 || MODE == 2);
   const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
@@ -739,8 +742,10 @@ __global__ __launch_bounds__(solve_waves<NR>() * 64) void big_super_kernel(const
   // pivots_only, round 4 — from big_gemv_chunk_kernel<.., FWD> once the pivots are solved (see there)
   const int n = (MODE == 0 && !pivots_only) ? b.fs : b.np;
   const Band band{const_cast<double *>(b.P), n, n, n, b.ldp + 1, 0, 0, b.pz};
+  // backward passes: the solved pivots go straight to the solution as well (x: nullptr in the forward passes)
+  const SolutionSink sink{(!fwd && x) ? x + (size_t)(Z ? 2 : 1) * (size_t)t.p0[b.f] : nullptr, xstride};
   solve_super_tile<MODE, NR, Z>(band, invs + (Z ? 2 : 1) * t.ioff[b.f], j0, jbs, fwd ? b.W : b.Z, fwd ? b.Z : b.W,
-                                (size_t)b.fs, b.blk, dsm, row_blocks);
+                                (size_t)b.fs, b.blk, dsm, row_blocks, sink);
 }
 
 // The same pass as a software pipeline over launches (solve_super_pipelined, dense_lu_kernels.hpp): launch k carries,
@@ -752,7 +757,8 @@ template <int MODE, int NR, bool Z = false>
 __global__ __launch_bounds__(solve_waves<NR>() * 64) void big_super_pipe_kernel(const int *__restrict__ list,
                                                             const int64_t *__restrict__ prefix, int count, int launch,
                                                             TreeView t, const double *__restrict__ invs,
-                                                            double *work, double *zbuf, double *cbuf, int row_blocks) {
+                                                            double *work, double *zbuf, double *cbuf, int row_blocks,
+                                                            double *x, size_t xstride) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   constexpr bool fwd = (MODE == 0 || MODE == 2);
   const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
@@ -769,23 +775,9 @@ __global__ __launch_bounds__(solve_waves<NR>() * 64) void big_super_pipe_kernel(
   const int j0 = (fwd ? step : nsup - 1 - step) * span, jbs = min(span, n - j0);
   const Band band{const_cast<double *>(b.P), n, n, n, b.ldp + 1, 0, 0, b.pz};
   double *carry = cbuf + (size_t)t.woff[b.f] * NR;
+  const SolutionSink sink{(!fwd && x) ? x + (size_t)(Z ? 2 : 1) * (size_t)t.p0[b.f] : nullptr, xstride};
   solve_super_pipelined<MODE, NR, Z>(band, invs + (Z ? 2 : 1) * t.ioff[b.f], j0, jbs, fwd ? b.W : b.Z, fwd ? b.Z : b.W, carry,
-                                     (size_t)b.fs, role, role == 0 ? b.blk : b.blk - nlead, step == 0, dsm, row_blocks);
-}
-
-// boundary part of the solution into the front's work matrix: W[r * fs + np + k] = x[r * stride + bidx[k]]
-template <int NR, bool Z = false>
-__global__ __launch_bounds__(256) void big_gather_x_kernel(const int *__restrict__ list,
-                                                           const int64_t *__restrict__ prefix, int count, TreeView t,
-                                                           const double *__restrict__ x, size_t stride, double *work,
-                                                           double *zbuf) {
-  const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
-  const int k = b.blk * 256 + (int)threadIdx.x;
-  if (k >= b.nb) return;
-  const int g = t.bidx[t.bptr[b.f] + k];
-#pragma unroll
-  for (int r = 0; r < NR; ++r)
-    b.W[(size_t)r * b.fs + b.np + k] = Z ? x[(size_t)(r >> 1) * stride + 2 * (size_t)g + (r & 1)] : x[(size_t)r * stride + g];
+                                     (size_t)b.fs, role, role == 0 ? b.blk : b.blk - nlead, step == 0, dsm, row_blocks, sink);
 }
 
 // Z[i][:] -= sum_k M(i, np + k) W[np + k][:], i < np: the boundary's part in the back substitution of a large front.
@@ -815,7 +807,8 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(c
                                                                                const int64_t *__restrict__ prefix, int count,
                                                                                TreeView t, double *work, double *zbuf,
                                                                                const int64_t *__restrict__ pofs,
-                                                                               double *__restrict__ scratch) {
+                                                                               double *__restrict__ scratch,
+                                                                               const double *__restrict__ x = nullptr, size_t xstride = 0) {
   constexpr int GW = gemv_waves<NR>();
   extern __shared__ __attribute__((aligned(16))) double gsm[];
   double(*xs)[NR] = reinterpret_cast<double(*)[NR]>(gsm);  // [kGemvChunk]
@@ -830,10 +823,14 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(c
   // that row (`skew` rows of the first block belong to the pivot block and are masked), so every block is whole lines
   const int skew = FWD ? (b.np & 15) : 0;
   const int i0 = rb * 64 - skew, k0 = ch * kGemvChunk, kn = min(kGemvChunk, nb - k0);
+  // backward pass (x given): the boundary's part of the solution straight from x through the front's boundary indices
+  // (round 4 gathered it into W with a launch of its own per level, big_gather_x_kernel)
   const double *xb = FWD ? b.Z + k0 : b.W + b.np + k0;
+  const int *bi = t.bidx + t.bptr[b.f] + k0;
   for (int o = threadIdx.x; o < kn * NR; o += GW * 64) {
     const int kk = o % kn, r = o / kn;
-    xs[kk][r] = xb[(size_t)r * fs + kk];
+    if (!FWD && x) xs[kk][r] = Z ? x[(size_t)(r >> 1) * xstride + 2 * (size_t)bi[kk] + (r & 1)] : x[(size_t)r * xstride + bi[kk]];
+    else xs[kk][r] = xb[(size_t)r * fs + kk];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -883,7 +880,8 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_t_kernel
                                                                                  const int64_t *__restrict__ prefix, int count,
                                                                                  TreeView t, double *work, double *zbuf,
                                                                                  const int64_t *__restrict__ pofs,
-                                                                                 double *__restrict__ scratch) {
+                                                                                 double *__restrict__ scratch,
+                                                                                 const double *__restrict__ x = nullptr, size_t xstride = 0) {
   constexpr int GW = gemv_waves<NR>();
   extern __shared__ __attribute__((aligned(16))) double gsm[];
   double(*xs)[kGemvChunk] = reinterpret_cast<double(*)[kGemvChunk]>(gsm);  // [NR]
@@ -893,9 +891,12 @@ __global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_t_kernel
   const int rb = b.blk / nch, ch = b.blk - rb * nch;
   const int i0 = rb * 64, k0 = ch * kGemvChunk, kn = min(kGemvChunk, nb - k0);
   const double *xb = b.W + b.np + k0;
+  const int *bi = t.bidx + t.bptr[b.f] + k0;
   for (int o = threadIdx.x; o < kGemvChunk * NR; o += GW * 64) {
     const int kk = o % kGemvChunk, r = o / kGemvChunk;
-    xs[r][kk] = kk < kn ? xb[(size_t)r * fs + kk] : 0.0;  // (zeros past the chunk's end: the loads below are clamped, not masked)
+    double xv = 0.0;  // (zeros past the chunk's end: the loads below are clamped, not masked)
+    if (kk < kn) xv = x ? (Z ? x[(size_t)(r >> 1) * xstride + 2 * (size_t)bi[kk] + (r & 1)] : x[(size_t)r * xstride + bi[kk]]) : xb[(size_t)r * fs + kk];
+    xs[r][kk] = xv;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -983,23 +984,6 @@ __global__ __launch_bounds__(256) void big_boundary_t_kernel(const int *__restri
   }
   wave_reduce_scatter<NR>(acc);
   if (wave_reduce_owner<NR>(lane)) b.W[(size_t)wave_reduce_index<NR>(lane, 0) * b.fs + b.np + k] -= acc[0];
-}
-
-// the pivots' part of the solution of every listed front: x[p0 + i] = W[i]
-template <int NR, bool Z = false>
-__global__ __launch_bounds__(256) void big_scatter_x_kernel(const int *__restrict__ list,
-                                                            const int64_t *__restrict__ prefix, int count,
-                                                            TreeView t, double *work, double *zbuf,
-                                                            double *__restrict__ x, size_t stride) {
-  const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
-  const int i = b.blk * 256 + (int)threadIdx.x;
-  if (i >= b.np) return;
-  const int p0 = t.p0[b.f];
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    if (Z) x[(size_t)(r >> 1) * stride + 2 * (size_t)(p0 + i) + (r & 1)] = b.W[(size_t)r * b.fs + i];
-    else x[(size_t)r * stride + p0 + i] = b.W[(size_t)r * b.fs + i];
-  }
 }
 
 }  // namespace
@@ -1749,7 +1733,7 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
 // launch per super-block step over all of them (Factors::BigLevel).
 template <int MODE, int NR, bool Z = false>
 static void launch_big_super(const mf::Factors &F, const mf::Factors::BigLevel &B, int kind, int step, double *work,
-                             double *zbuf, hipStream_t s, int pivots_only = 0) {
+                             double *zbuf, hipStream_t s, int pivots_only = 0, double *x = nullptr, size_t xstride = 0) {
   constexpr size_t lds = (size_t)((SB + 2) * NB + solve_waves<NR>() * 64) * NR * sizeof(double);
   static std::atomic<uint64_t> attr_set{0};  // one mask per instantiation, one bit per device
   if (first_use_on_this_device(attr_set)) {
@@ -1760,12 +1744,12 @@ static void launch_big_super(const mf::Factors &F, const mf::Factors::BigLevel &
   const unsigned groups = B.total(kind, step);
   if (groups > 0)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(big_super_kernel<MODE, NR, Z>), dim3(groups), dim3(solve_waves<NR>() * 64), lds, s, B.list.get(),
-                       B.prefix(kind, step), B.count, step, F.view, F.invs.get(), work, zbuf, B.row_blocks, pivots_only);
+                       B.prefix(kind, step), B.count, step, F.view, F.invs.get(), work, zbuf, B.row_blocks, pivots_only, x, xstride);
 }
 
 template <int MODE, int NR, bool Z = false>
 static void launch_big_pipe(const mf::Factors &F, const mf::Factors::BigLevel &B, int kind, double *work, double *zbuf,
-                            double *cbuf, hipStream_t s) {
+                            double *cbuf, hipStream_t s, double *x = nullptr, size_t xstride = 0) {
   constexpr size_t lds = (size_t)((SB + 2) * NB + solve_waves<NR>() * 64) * NR * sizeof(double);
   static std::atomic<uint64_t> attr_set{0};  // one mask per instantiation, one bit per device
   if (first_use_on_this_device(attr_set)) {
@@ -1777,7 +1761,7 @@ static void launch_big_pipe(const mf::Factors &F, const mf::Factors::BigLevel &B
     const unsigned groups = B.total(kind, k);
     if (groups > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(big_super_pipe_kernel<MODE, NR, Z>), dim3(groups), dim3(solve_waves<NR>() * 64), lds, s,
-                         B.list.get(), B.prefix(kind, k), B.count, k, F.view, F.invs.get(), work, zbuf, cbuf, B.row_blocks);
+                         B.list.get(), B.prefix(kind, k), B.count, k, F.view, F.invs.get(), work, zbuf, cbuf, B.row_blocks, x, xstride);
   }
 }
 
@@ -1785,18 +1769,18 @@ static void launch_big_pipe(const mf::Factors &F, const mf::Factors::BigLevel &B
 struct SolveLevel {
   const int *solve_list;
   int solve_count;
-  const int *child_list[2];
-  int child_count[2], child_maxnb[2];
+  const int *child_list[2];  // the children (by slot) of the fronts of this depth, and the largest boundary among them
+  int child_count[2], child_maxnb;
   const mf::Factors::BigLevel *big;
 };
 static SolveLevel whole_level(const mf::LevelPlan &lp, int d, int nd) {
   SolveLevel L;
   L.solve_list = lp.solve_lists[(size_t)d].get();
   L.solve_count = lp.solve_counts[(size_t)d];
+  L.child_maxnb = d + 1 < nd ? std::max(lp.child_maxnb[0][(size_t)d], lp.child_maxnb[1][(size_t)d]) : 0;
   for (int sl = 0; sl < 2; ++sl) {
     L.child_list[sl] = d + 1 < nd ? lp.child_lists[sl][(size_t)d].get() : nullptr;
     L.child_count[sl] = d + 1 < nd ? lp.child_counts[sl][(size_t)d] : 0;
-    L.child_maxnb[sl] = d + 1 < nd ? lp.child_maxnb[sl][(size_t)d] : 0;
   }
   L.big = &lp.big[(size_t)d];
   return L;
@@ -1848,13 +1832,13 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
 
   // one level on the way up: children's boundaries into their parents, the one-workgroup fronts, the large ones in lockstep
   auto up_level = [&](const SolveLevel &L, double *scr, hipStream_t q) {
-    for (int sl = 0; sl < 2; ++sl)
-      if (L.child_count[sl] > 0) {
-        const int64_t most = (int64_t)L.child_maxnb[sl] * NR;  // entries of the largest child
-        const unsigned share = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (most + 2047) / 2048));
-        hipLaunchKernelGGL(solve_gather_kernel<NR>, dim3((unsigned)L.child_count[sl], share), dim3(256), 0, q, L.child_list[sl],
-                           F.view, work);
-      }
+    if (L.child_count[0] + L.child_count[1] > 0) {
+      const int64_t most = (int64_t)L.child_maxnb * NR;  // entries of the largest child
+      const unsigned share = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (most + 2047) / 2048));
+      for (int sl = 0; sl < 2; ++sl)
+        if (L.child_count[sl] > 0)
+          hipLaunchKernelGGL(solve_gather_kernel<NR>, dim3((unsigned)L.child_count[sl], share), dim3(256), 0, q, L.child_list[sl], F.view, work);
+    }
     if (L.solve_count > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(solve_forward_kernel<TRANS, NR, Z>), dim3((unsigned)L.solve_count),
                          dim3(solve_threads<NR>()), 0, q, L.solve_list, F.view, invs, work);
@@ -1895,9 +1879,7 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
                          dim3(solve_threads<NR>()), 0, q, L.solve_list, F.view, invs, work, c, stride);
     const mf::Factors::BigLevel &B = *L.big;
     if (B.count > 0) {
-      if (B.total(4) > 0) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gather_x_kernel<NR, Z>), dim3(B.total(4)), dim3(256), 0, q, B.list.get(),
-                           B.prefix(4), B.count, F.view, c, stride, work, zbuf);
+      if (B.total(4) > 0) {  // (fronts with a boundary; its part of the solution is read from x inside the product)
         {
           constexpr size_t lds = (size_t)(TRANS ? kGemvChunk : std::max(kGemvChunk, gemv_waves<NR>() * 64)) * NR * sizeof(double);
           static std::atomic<uint64_t> attr_set{0};  // one mask per instantiation, one bit per device
@@ -1912,21 +1894,20 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
           }
           if (TRANS)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_chunk_t_kernel<NR, Z>), dim3(B.total(7)), dim3(gemv_waves<NR>() * 64), lds,
-                               q, B.list.get(), B.prefix(7), B.count, F.view, work, zbuf, B.prefix(9), scr);
+                               q, B.list.get(), B.prefix(7), B.count, F.view, work, zbuf, B.prefix(9), scr, (const double *)c, stride);
           else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_chunk_kernel<NR, Z>), dim3(B.total(7)), dim3(gemv_waves<NR>() * 64), lds, q,
-                               B.list.get(), B.prefix(7), B.count, F.view, work, zbuf, B.prefix(9), scr);
+                               B.list.get(), B.prefix(7), B.count, F.view, work, zbuf, B.prefix(9), scr, (const double *)c, stride);
           if (B.total(8) > 0)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(big_gemv_reduce_kernel<NR>), dim3(B.total(8)), dim3(256), 0, q, B.list.get(),
                                B.prefix(8), B.count, F.view, work, zbuf, B.prefix(9), scr);
         }
       }
       // the pivot block alone; columns of Z / W are fs apart
-      if (pipe_on && NR <= 2) launch_big_pipe<BWD, NR, Z>(F, B, 14, work, zbuf, cbuf, q);
+      // (the solved pivots go to x from inside these steps: round 4 had a scatter launch per level behind them)
+      if (pipe_on && NR <= 2) launch_big_pipe<BWD, NR, Z>(F, B, 14, work, zbuf, cbuf, q, c, stride);
       else
-        for (int k = 0; k < B.steps; ++k) launch_big_super<BWD, NR, Z>(F, B, 2, k, work, zbuf, q);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(big_scatter_x_kernel<NR, Z>), dim3(B.total(6)), dim3(256), 0, q, B.list.get(),
-                         B.prefix(6), B.count, F.view, work, zbuf, c, stride);
+        for (int k = 0; k < B.steps; ++k) launch_big_super<BWD, NR, Z>(F, B, 2, k, work, zbuf, q, 0, c, stride);
     }
   };
 
