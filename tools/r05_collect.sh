@@ -3,7 +3,7 @@
 # (100^3, 200^3) and of the factorisation (100^3); the full bench line; three FEAST runs.  Everything lands under
 # gpurun_out/r05/ (the raw counter files of the LU passes are deleted once summarised: gpurun merges at most 64 MiB back);
 # the summaries worth keeping are copied to profiles/ by hand afterwards.
-#   bash tools/r05_collect.sh [steps...]     steps: spmv spgemm solve100 factor100 solve200 spmvother solvez100 factor200 bench feast
+#   bash tools/r05_collect.sh [steps...]     steps: spmv spgemm solve100 factor100 solve200 spmvother solvez100 factorz100 factor200 bench feast
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$repo" || exit 1
 mkdir -p gpurun_out/r05
@@ -23,7 +23,9 @@ for st in $steps; do
                bash tools/pmc_spmv_other.sh rmat:20 reference > gpurun_out/r05/pmc_spmv_rmat.log 2>&1 && bash tools/pmc_spmv_other.sh rmat:20 free >> gpurun_out/r05/pmc_spmv_rmat.log 2>&1 || { echo "pmc_spmv_other failed"; exit 1; } ;;
     solvez100) bash tools/pmc_solve.sh 100 z > gpurun_out/r05/pmc_solve_z100.log 2>&1 || { echo "pmc_solve z 100 failed"; exit 1; }
                cp gpurun_out/pmc_solve/summary.txt gpurun_out/r05/pmc_solve_z100.txt; rm -rf gpurun_out/pmc_solve ;;
-    factor200) bash tools/pmc_factor.sh 200 > gpurun_out/r05/pmc_factor_200.log 2>&1 || { echo "pmc_factor 200 failed"; exit 1; }
+    factorz100) bash tools/pmc_factor.sh 100 z > gpurun_out/r05/pmc_factor_z100.log 2>&1 || { echo "pmc_factor z 100 failed"; exit 1; }
+               cp gpurun_out/pmc_factor/summary.txt gpurun_out/r05/pmc_factor_z100.txt; rm -rf gpurun_out/pmc_factor ;;
+    factor200) FFP_REPS=1 bash tools/pmc_factor.sh 200 > gpurun_out/r05/pmc_factor_200.log 2>&1 || { echo "pmc_factor 200 failed"; exit 1; }
                cp gpurun_out/pmc_factor/summary.txt gpurun_out/r05/pmc_factor_200.txt; rm -rf gpurun_out/pmc_factor ;;
     bench)     timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 > gpurun_out/r05/bench.json 2> gpurun_out/r05/bench.err || { echo "bench failed"; exit 1; }
                wc -c gpurun_out/r05/bench.json ;;
