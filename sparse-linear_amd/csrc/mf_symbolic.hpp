@@ -16,20 +16,68 @@
 #pragma once
 
 #include <stdint.h>
+#include <sys/mman.h>
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <atomic>
 #include <future>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <exception>
+#include <stdexcept>
 #include <vector>
 
 namespace spl {
 namespace mf {
+
+// The per-vertex arrays of the analysis (adjacency, marks, levels, the vertex array: tens of megabytes at 10^6 unknowns,
+// read and written at random by the traversals) come from their own mappings with transparent huge pages asked for:
+// on 4 KB pages every access to them is a TLB miss as well as a cache miss (the GPU box runs THP in `madvise` mode,
+// which the C library's allocator never asks for), a fresh mapping costs a page fault per 4 KB the first time it is
+// touched (half of what a one-shot analysis pays over a repeated one), and where the C library happens to put the
+// arrays relative to each other moved the dissection by a quarter from one build to the next.
+template <typename T>
+struct HugeAlloc {
+  using value_type = T;
+  static constexpr size_t kHuge = (size_t)2 << 20, kFrom = (size_t)1 << 20;
+  HugeAlloc() = default;
+  template <typename U>
+  HugeAlloc(const HugeAlloc<U> &) {}
+  static size_t mapped_bytes(size_t bytes) { return (bytes + kHuge - 1) / kHuge * kHuge; }
+  T *allocate(size_t count) {
+    const size_t bytes = count * sizeof(T);
+    if (bytes < kFrom) {
+      void *p = malloc(bytes ? bytes : 1);
+      if (!p) throw std::bad_alloc();
+      return static_cast<T *>(p);
+    }
+    // (over-map by one huge page and give back the unaligned ends: the mapping then starts on a 2 MB boundary)
+    const size_t len = mapped_bytes(bytes), span = len + kHuge;
+    char *raw = static_cast<char *>(mmap(nullptr, span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+    if (raw == MAP_FAILED) throw std::bad_alloc();
+    char *at = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(raw) + kHuge - 1) / kHuge * kHuge);
+    if (at > raw) munmap(raw, (size_t)(at - raw));
+    if (at + len < raw + span) munmap(at + len, (size_t)(raw + span - (at + len)));
+    (void)madvise(at, len, MADV_HUGEPAGE);  // advisory: plain pages if the kernel declines
+    return reinterpret_cast<T *>(at);
+  }
+  void deallocate(T *p, size_t count) noexcept {
+    const size_t bytes = count * sizeof(T);
+    if (bytes < kFrom) free(p);
+    else munmap(p, mapped_bytes(bytes));
+  }
+  template <typename U>
+  bool operator==(const HugeAlloc<U> &) const { return true; }
+  template <typename U>
+  bool operator!=(const HugeAlloc<U> &) const { return false; }
+};
+template <typename T>
+using BigVec = std::vector<T, HugeAlloc<T>>;
 
 constexpr int kBlock = 64;  // pivot block of the dense kernels (NB of band_nopiv.hip)
 // regions up to this size start their level structure from the end vertex their parent hands down
@@ -108,10 +156,21 @@ struct Tree {
 // grouped by level, in a deterministic order inside a level) and `level_ptr`; returns the number of vertices reached
 // (< size: the region is disconnected and the outputs are not meaningful).  Thread-safe.
 // root >= 0: ONE traversal, from that vertex (a hint from the parent region).
+// boundaries(): the boundary lists of every front of the finished tree (T.nb, T.bptr, T.bidx from T.inv, T.front_of,
+// T.p0, T.np, T.parent, T.depth), exactly what build_tree's host code makes level by level; false: not done (too large
+// for the device's scheme, a tree it does not understand, any failure there) and the outputs are untouched.
 struct LevelService {
   virtual ~LevelService() {}
   virtual int levels(const int *region, int size, std::vector<int> &queue, std::vector<int64_t> &level_ptr, int root = -1) = 0;
+  virtual bool boundaries(Tree &) { return false; }
 };
+
+// SPL_MF_TIMING set: phase times of the analysis on stderr; any value but "phases" also the laps of the top regions,
+// which cost stream synchronisations inside the device's level structures (nd_levels.hip)
+inline bool detailed_timing() {
+  const char *e = getenv("SPL_MF_TIMING");
+  return e && strcmp(e, "phases") != 0;
+}
 
 namespace detail {
 
@@ -161,19 +220,20 @@ struct Node {
 // one atomic counter so that they are unique across workers.
 struct Shared {
   int n;
-  const std::vector<int64_t> &xadj;
-  const std::vector<int> &adj;
+  const BigVec<int64_t> &xadj;
+  const BigVec<int> &adj;
   int leaf;
   // mark[v] = stamp of the last thing that happened to v: put into a region (region stamp), or
   // reached by a BFS (that BFS's stamp).  One word per vertex answers "in my region and not yet
   // reached" during a traversal.
-  std::vector<int> verts, mark, level;
+  BigVec<int> verts, mark, level;
   // claim[u] = (stamp of a team traversal << 32) | ~position of the frontier vertex that takes u
   // (team_bfs); allocated only when the graph is large enough for a team
-  std::vector<uint64_t> claim;
+  BigVec<uint64_t> claim;
   int max_team = 1;
   int team_region = kTeamRegion, team_frontier = kTeamFrontier;  // SPL_ND_TEAM_REGION / _FRONTIER (experiments)
   bool timing = false;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();  // (timing: when the dissection began)
   LevelService *service = nullptr;  // level structures of regions of service_min vertices and more (nullptr: none)
   // The device serves one region at a time (siblings wait for each other) while the host dissects the regions of a
   // depth side by side: the GPU pays where regions are few and large — the top of the tree, the serial part.
@@ -185,12 +245,12 @@ struct Shared {
   int root_levels = 0;  // levels of the root region's final level structure (written by the depth-0 call only)
   std::atomic<int> gave_up{0};  // a region was left as one leaf because it has no separators (Tree::gave_up)
   std::atomic<int> stamp{0};
-  Shared(int n_, const std::vector<int64_t> &xa, const std::vector<int> &ad, int leaf_)
+  Shared(int n_, const BigVec<int64_t> &xa, const BigVec<int> &ad, int leaf_)
       : n(n_), xadj(xa), adj(ad), leaf(leaf_), verts((size_t)n_), mark((size_t)n_, 0), level((size_t)n_, 0) {
     for (int i = 0; i < n; ++i) verts[(size_t)i] = i;
     const unsigned hw = std::thread::hardware_concurrency();
     max_team = (int)std::min<unsigned>(hw ? hw : 1, kMaxTeam);
-    timing = getenv("SPL_MF_TIMING") != nullptr;
+    timing = detailed_timing();
     if (const char *e = getenv("SPL_ND_TEAM")) max_team = std::max(1, std::min(atoi(e), 64));
     if (const char *e = getenv("SPL_ND_TEAM_REGION")) team_region = std::max(1024, atoi(e));
     if (const char *e = getenv("SPL_ND_TEAM_FRONTIER")) team_frontier = std::max(64, atoi(e));
@@ -427,6 +487,9 @@ struct Worker {
       if (mid > lo) left = dissect(lo, mid, depth + 1, hint_l, thin, peels);
       if (hi > mid) right = dissect(mid, hi, depth + 1, hint_r, thin, peels);
     }
+    if (S.timing && depth <= 5)  // when the subtrees of the chain of large regions were complete
+      fprintf(stderr, "[dissect] depth %d, %9d vertices: closed at %8.1f ms\n", depth, hi - lo + (int)top.piv.size(),
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - S.t0).count());
     std::vector<Node> out;
     out.reserve(left.size() + right.size() + 1);
     const bool has_l = !left.empty(), has_r = !right.empty();
@@ -473,17 +536,32 @@ struct Worker {
       t_last = now;
     };
     region_stamp = ++S.stamp;
-    for (int i = lo; i < hi; ++i) S.mark[(size_t)S.verts[(size_t)i]] = region_stamp;
-    lap("region stamp");
+    auto stamp_region = [this, lo, hi] {
+      for (int i = lo; i < hi; ++i) S.mark[(size_t)S.verts[(size_t)i]] = region_stamp;
+    };
     int reached = -1;
     bool from_service = false;
-    const bool use_hint = hint >= 0 && (size <= kHintBelow || thin_parent) && S.mark[(size_t)hint] == region_stamp;
-    if (S.service && S.service_min > 0 && size >= (thin_parent || depth == 0 ? S.service_min : S.service_min_bulky)) {
+    const bool to_service = S.service && S.service_min > 0 && size >= (thin_parent || depth == 0 ? S.service_min : S.service_min_bulky);
+    const bool hint_wanted = hint >= 0 && (size <= kHintBelow || thin_parent);
+    bool use_hint = false;
+    if (to_service) {
+      // The host's marks of the region (what the host code needs if the device hands the region back, and what a
+      // child's hint is checked against) are written beside the device's traversals, not before them: a pass of random
+      // writes over the region, 0.5 - 1 ms per region on the chain of large regions down the tree at 10^6 unknowns.
+      // The device checks the hint against its own marks (nd_levels.hip: a root outside the region reaches nothing).
+      std::future<void> stamping;
       try {
-        reached = S.service->levels(S.verts.data() + lo, size, queue, level_ptr, use_hint ? hint : -1);
+        stamping = std::async(std::launch::async, stamp_region);
+      } catch (...) {
+        stamp_region();
+      }
+      try {
+        reached = S.service->levels(S.verts.data() + lo, size, queue, level_ptr, hint_wanted ? hint : -1);
       } catch (...) {  // no memory on the device, or any other failure there: the host code below takes the region
         reached = -1;
       }
+      if (stamping.valid()) stamping.get();
+      use_hint = hint_wanted && S.mark[(size_t)hint] == region_stamp;
       from_service = reached == size;
       if (from_service) {
         lap("level structure (GPU)");
@@ -492,6 +570,10 @@ struct Worker {
         // done for the candidates' successors lazily: see `touches`)
         bfs_stamp = ++S.stamp;
       }
+    } else {
+      stamp_region();
+      lap("region stamp");
+      use_hint = hint_wanted && S.mark[(size_t)hint] == region_stamp;
     }
     if (from_service) {
       // nothing else to do here
@@ -646,8 +728,8 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
   // both of its ends, so a symmetric pair appears twice: harmless for BFS, removed from the boundary lists by sort +
   // unique, but twice the edge work).
   const bool pattern_symmetric = pattern_symmetric_hint >= 0 ? pattern_symmetric_hint != 0 : detail::structurally_symmetric(n, Ap, Ai);
-  std::vector<int64_t> xadj((size_t)n + 1, 0);
-  std::vector<int> adj;
+  BigVec<int64_t> xadj((size_t)n + 1, 0);
+  BigVec<int> adj;
   if (pattern_symmetric) {
     // column ranges on threads: lengths, one sequential prefix sum, then the lists
     unsigned nt = std::thread::hardware_concurrency();
@@ -749,7 +831,7 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
   // level is shared out among threads; the lists are concatenated in front order afterwards.
   T.bptr.assign((size_t)nf + 1, 0);
   lap("permutation, levels");
-  {
+  auto host_boundaries = [&] {
     std::vector<std::vector<int>> bnd((size_t)nf);
     auto boundary_of = [&](int f) {
       const detail::Node &nd = nodes[(size_t)f];
@@ -869,6 +951,38 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
     }
     T.bidx.resize((size_t)T.bptr[(size_t)nf]);
     for (int f = 0; f < nf; ++f) std::copy(bnd[(size_t)f].begin(), bnd[(size_t)f].end(), T.bidx.begin() + T.bptr[(size_t)f]);
+  };
+  // On the device when the graph is there already (nd_levels.hip: a bitmap per front over its ancestors' pivots, own
+  // neighbours set by one pass over the edges, children merged by shifts level by level: 18 -> 4 ms at 10^6 unknowns,
+  // 146 ms at 8 10^6); SPL_ND_BOUNDARIES=host keeps it here, =check makes both and compares them (tests).
+  {
+    const char *mode = getenv("SPL_ND_BOUNDARIES");
+    const bool host_only = mode && strcmp(mode, "host") == 0, check = mode && strcmp(mode, "check") == 0;
+    bool done = false;
+    if (service && !host_only) {
+      try {
+        done = service->boundaries(T);
+      } catch (...) {
+        done = false;
+      }
+    }
+    if (done && check) {
+      std::vector<int> nb_d, bidx_d;
+      std::vector<int64_t> bptr_d;
+      nb_d.swap(T.nb);
+      bptr_d.swap(T.bptr);
+      bidx_d.swap(T.bidx);
+      T.nb.assign((size_t)nf, 0);
+      T.bptr.assign((size_t)nf + 1, 0);
+      host_boundaries();
+      if (nb_d != T.nb || bptr_d != T.bptr || bidx_d != T.bidx)
+        throw std::logic_error("mf::build_tree: the device's boundary lists differ from the host's");
+      if (timing) fprintf(stderr, "[build_tree] boundaries: device == host (%zu indices)\n", T.bidx.size());
+    } else if (!done) {
+      if (check && service) throw std::logic_error("mf::build_tree: SPL_ND_BOUNDARIES=check and the device made no boundary lists");
+      host_boundaries();
+    }
+    if (timing) fprintf(stderr, "[build_tree] boundaries made %s\n", done ? "on the device" : "on the host");
   }
   lap("boundaries");
   if (mult > 1) {

@@ -37,9 +37,18 @@ __global__ __launch_bounds__(256) void nd_stamp_kernel(const int *__restrict__ v
 }
 
 // root of a traversal: level 0 = {root}
-__global__ void nd_root_kernel(const int64_t *__restrict__ xadj, int root, int *__restrict__ mark, int stamp,
+// (a root that does not carry `accept` — a caller's hint from outside the region — leaves an empty level 0: the
+// traversal reaches nothing and the caller's host code takes the region)
+__global__ void nd_root_kernel(const int64_t *__restrict__ xadj, int root, int *__restrict__ mark, int accept, int stamp,
                                int *__restrict__ queue, int64_t *__restrict__ qbeg, int *__restrict__ qcnt,
                                int *__restrict__ levptr, int *__restrict__ tail, unsigned *__restrict__ blocks_done) {
+  *blocks_done = 0;
+  if (mark[root] != accept) {
+    levptr[0] = 0;
+    levptr[1] = 0;
+    *tail = 0;
+    return;
+  }
   mark[root] = stamp;
   queue[0] = root;
   qbeg[0] = xadj[root];
@@ -47,7 +56,6 @@ __global__ void nd_root_kernel(const int64_t *__restrict__ xadj, int root, int *
   levptr[0] = 0;
   levptr[1] = 1;
   *tail = 1;
-  *blocks_done = 0;
 }
 
 // level l: the frontier queue[levptr[l], levptr[l + 1]) claims its unreached neighbours (mark == accept -> stamp) and
@@ -134,6 +142,138 @@ __global__ __launch_bounds__(256) void nd_unkey_kernel(const unsigned long long 
                                                        int *__restrict__ queue) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < reached) queue[i] = (int)(unsigned)(keys[i] & ((1ull << vbits) - 1ull));
+}
+
+// ---- boundary lists of the finished tree ---------------------------------------------------------------------------
+// The boundary of front f lies in the separators above it.  Coordinates of f: its ancestors' pivots laid end to end,
+// parent first — up(f) = the number of pivots above f of them; position h of ancestor a has coordinate
+// up(f) - up(a) - np(a) + (h - p0(a)), and ascending coordinates are ascending positions (an ancestor further up comes
+// later in the post-order).  One bitmap of up(f) bits per front:
+//   * every edge (v, u) with u eliminated after v's front sets the bit of u in the bitmap of v's front (one pass over
+//     the adjacency, atomic OR);
+//   * a child's coordinates are its parent's shifted by np(parent): level by level from the bottom, a front ORs its
+//     children's bitmaps, shifted right by its own pivot count, into its own;
+//   * the set bits, counted and then written out in order, are the lists: sorted and free of duplicates by construction.
+// The host does the same with sorted lists merged level by level (mf_symbolic.hpp), bound there by the six random
+// reads of inv[] per vertex and the sorts; here it is a few hundred microseconds of kernels around the transfers.
+constexpr int kHeavyDegree = 32;  // vertices with more neighbours are taken by a whole wavefront each
+
+struct BndTree {  // per front, on the device
+  const int *p0, *np, *parent, *up, *sub0, *c0, *c1;
+  const int64_t *boff;  // first word of the front's bitmap
+};
+
+__device__ inline void bnd_set(const BndTree &t, int f, int lastf, int h, const int *__restrict__ front_of,
+                               unsigned long long *__restrict__ bits, int *__restrict__ error) {
+  const int a = front_of[h];
+  // a must be an ancestor of f: f's pivots inside a's subtree, before a's own
+  if (!(t.sub0[a] <= t.p0[f] && lastf <= t.p0[a])) { *error = 1; return; }
+  const int c = t.up[f] - t.up[a] - t.np[a] + (h - t.p0[a]);
+  if (c < 0 || c >= t.up[f]) { *error = 1; return; }
+  atomicOr(&bits[t.boff[f] + (c >> 6)], 1ull << (c & 63));
+}
+
+__global__ __launch_bounds__(256) void bnd_own_kernel(int n, const int64_t *__restrict__ xadj, const int *__restrict__ adj,
+                                                      const int *__restrict__ inv, const int *__restrict__ front_of,
+                                                      BndTree t, unsigned long long *__restrict__ bits,
+                                                      int *__restrict__ heavy, int *__restrict__ nheavy,
+                                                      int *__restrict__ error) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= n) return;
+  const int64_t b = xadj[v], e = xadj[v + 1];
+  if (e - b > kHeavyDegree) {
+    heavy[atomicAdd(nheavy, 1)] = v;
+    return;
+  }
+  const int f = front_of[inv[v]], lastf = t.p0[f] + t.np[f];
+  for (int64_t p = b; p < e; ++p) {
+    const int h = inv[adj[p]];
+    if (h >= lastf) bnd_set(t, f, lastf, h, front_of, bits, error);
+  }
+}
+
+__global__ __launch_bounds__(256) void bnd_own_heavy_kernel(const int64_t *__restrict__ xadj, const int *__restrict__ adj,
+                                                            const int *__restrict__ inv, const int *__restrict__ front_of,
+                                                            BndTree t, unsigned long long *__restrict__ bits,
+                                                            const int *__restrict__ heavy, const int *__restrict__ nheavy,
+                                                            int *__restrict__ error) {
+  const int lane = threadIdx.x & 63, nh = *nheavy;
+  for (int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < nh; k += gridDim.x * 4) {
+    const int v = heavy[k], f = front_of[inv[v]], lastf = t.p0[f] + t.np[f];
+    for (int64_t p = xadj[v] + lane; p < xadj[v + 1]; p += 64) {
+      const int h = inv[adj[p]];
+      if (h >= lastf) bnd_set(t, f, lastf, h, front_of, bits, error);
+    }
+  }
+}
+
+// fronts[0 .. count) of one tree level: bitmap |= each child's bitmap >> np(front)
+__global__ __launch_bounds__(256) void bnd_merge_kernel(const int *__restrict__ fronts, BndTree t,
+                                                        unsigned long long *__restrict__ bits) {
+  const int f = fronts[blockIdx.x];
+  const int nw = (t.up[f] + 63) >> 6;
+  if (nw == 0) return;
+  const int npf = t.np[f], s = npf >> 6, r = npf & 63;
+  unsigned long long *dst = bits + t.boff[f];
+  for (int which = 0; which < 2; ++which) {
+    const int ch = which ? t.c1[f] : t.c0[f];
+    if (ch < 0) continue;
+    const int cw = (t.up[ch] + 63) >> 6;
+    const unsigned long long *src = bits + t.boff[ch];
+    for (int i = threadIdx.x; i < nw; i += 256) {
+      const unsigned long long lo = i + s < cw ? src[i + s] : 0ull;
+      unsigned long long val = lo;
+      if (r) {
+        const unsigned long long hi = i + s + 1 < cw ? src[i + s + 1] : 0ull;
+        val = (lo >> r) | (hi << (64 - r));
+      }
+      if (val) dst[i] |= val;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bnd_count_kernel(int nf, BndTree t, const unsigned long long *__restrict__ bits,
+                                                        int *__restrict__ nb) {
+  const int lane = threadIdx.x & 63;
+  for (int f = blockIdx.x * 4 + (threadIdx.x >> 6); f < nf; f += gridDim.x * 4) {
+    const int nw = (t.up[f] + 63) >> 6;
+    const unsigned long long *w = bits + t.boff[f];
+    int cnt = 0;
+    for (int i = lane; i < nw; i += 64) cnt += __popcll(w[i]);
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) nb[f] = cnt;
+  }
+}
+
+__global__ __launch_bounds__(256) void bnd_emit_kernel(int nf, BndTree t, const unsigned long long *__restrict__ bits,
+                                                       const int64_t *__restrict__ bptr, int *__restrict__ bidx) {
+  const int lane = threadIdx.x & 63;
+  for (int f = blockIdx.x * 4 + (threadIdx.x >> 6); f < nf; f += gridDim.x * 4) {
+    const int upf = t.up[f], nw = (upf + 63) >> 6;
+    const unsigned long long *words = bits + t.boff[f];
+    int64_t out0 = bptr[f];
+    for (int i0 = 0; i0 < nw; i0 += 64) {  // (wave-uniform trip count)
+      const int i = i0 + lane;
+      unsigned long long w = i < nw ? words[i] : 0ull;
+      const int cnt = __popcll(w);
+      int pre = cnt;  // inclusive scan over the lanes
+      for (int off = 1; off < 64; off <<= 1) {
+        const int got = __shfl_up(pre, off, 64);
+        if (lane >= off) pre += got;
+      }
+      const int total = __shfl(pre, 63, 64);
+      int64_t out = out0 + (pre - cnt);
+      int a = t.parent[f];
+      while (w) {
+        const int c = (i << 6) + (__ffsll((long long)w) - 1);
+        w &= w - 1;
+        while (a >= 0 && c >= upf - t.up[a]) a = t.parent[a];  // the ancestor whose pivots hold coordinate c
+        if (a < 0) break;  // (cannot happen: c < up(f))
+        bidx[out++] = c - (upf - t.up[a] - t.np[a]) + t.p0[a];
+      }
+      out0 += total;
+    }
+  }
 }
 
 // Buffers of one traversal in flight.  The regions of a depth are dissected side by side by host threads; each call
@@ -254,10 +394,10 @@ struct GpuLevels : mf::LevelService {
     hipStream_t s = sl.s;
     std::vector<int> &h_levptr = sl.h_levptr;
     unsigned *blocks_done = reinterpret_cast<unsigned *>(sl.counters + 1);
-    hipLaunchKernelGGL(nd_root_kernel, dim3(1), dim3(1), 0, s, xadj, root, mark, st, sl.queue, sl.qbeg, sl.qcnt, sl.levptr,
-                       sl.counters, blocks_done);
+    hipLaunchKernelGGL(nd_root_kernel, dim3(1), dim3(1), 0, s, xadj, root, mark, accept, st, sl.queue, sl.qbeg, sl.qcnt,
+                       sl.levptr, sl.counters, blocks_done);
     h_levptr.assign(2, 0);
-    h_levptr[1] = 1;
+    h_levptr[1] = 1;  // (0 on the device if the root was refused: every later pointer is then 0 and the count below too)
     int l = 0;  // next level to expand
     for (;;) {
       for (int k = 0; k < kBatch; ++k)
@@ -276,6 +416,115 @@ struct GpuLevels : mf::LevelService {
     }
   }
 
+  // the boundary lists of the finished tree (kernels above); the traversals are over: slot 0's stream and buffers
+  bool boundaries(mf::Tree &T) override {
+    const int nf = T.nfronts;
+    if (nf <= 0 || T.n != n || (int)T.inv.size() != n || (int)T.front_of.size() != n) return false;
+    if (T.maxdepth > 2048) return false;  // (a launch per level: chains of hub peels stay on the host)
+    DeviceGuard g(device);
+    static const bool timing = getenv("SPL_MF_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    // per front: pivots above it, first position of its subtree, children, bitmap offsets
+    std::vector<int> up((size_t)nf, 0), sub0(T.p0), c0((size_t)nf, -1), c1((size_t)nf, -1);
+    std::vector<int64_t> boff((size_t)nf + 1, 0);
+    for (int f = nf - 1; f >= 0; --f) {
+      const int p = T.parent[(size_t)f];
+      if (p >= 0 && p <= f) return false;  // not a post-order
+      up[(size_t)f] = p < 0 ? 0 : up[(size_t)p] + T.np[(size_t)p];
+    }
+    for (int f = 0; f < nf; ++f) {
+      const int p = T.parent[(size_t)f];
+      if (p < 0) continue;
+      sub0[(size_t)p] = std::min(sub0[(size_t)p], sub0[(size_t)f]);
+      if (c0[(size_t)p] < 0) c0[(size_t)p] = f;
+      else if (c1[(size_t)p] < 0) c1[(size_t)p] = f;
+      else return false;  // more than two children
+    }
+    for (int f = 0; f < nf; ++f) boff[(size_t)f + 1] = boff[(size_t)f] + ((up[(size_t)f] + 63) >> 6);
+    const int64_t words = boff[(size_t)nf];
+    if (words > ((int64_t)1 << 29)) return false;  // 4 GiB of bitmaps: the host's lists then
+    std::vector<int> order;  // fronts by depth
+    std::vector<int> lev_ptr((size_t)T.maxdepth + 2, 0);
+    order.reserve((size_t)nf);
+    for (int d = 0; d <= T.maxdepth; ++d) {
+      lev_ptr[(size_t)d] = (int)order.size();
+      order.insert(order.end(), T.by_depth[(size_t)d].begin(), T.by_depth[(size_t)d].end());
+    }
+    lev_ptr[(size_t)T.maxdepth + 1] = (int)order.size();
+    if ((int)order.size() != nf) return false;
+    // one upload of everything per front: seven int arrays, the order, then the offsets
+    const size_t F = (size_t)nf;
+    std::vector<int> packed(8 * F);
+    std::copy(T.p0.begin(), T.p0.end(), packed.begin());
+    std::copy(T.np.begin(), T.np.end(), packed.begin() + F);
+    std::copy(T.parent.begin(), T.parent.end(), packed.begin() + 2 * F);
+    std::copy(up.begin(), up.end(), packed.begin() + 3 * F);
+    std::copy(sub0.begin(), sub0.end(), packed.begin() + 4 * F);
+    std::copy(c0.begin(), c0.end(), packed.begin() + 5 * F);
+    std::copy(c1.begin(), c1.end(), packed.begin() + 6 * F);
+    std::copy(order.begin(), order.end(), packed.begin() + 7 * F);
+    Slot &sl = slots[0];
+    hipStream_t s = sl.s;
+    DBuf<int> d_packed(8 * F), d_nb(F);
+    DBuf<int64_t> d_boff(F + 1), d_bptr(F + 1);
+    DBuf<unsigned long long> d_bits((size_t)std::max<int64_t>(words, 1));
+    int *d_inv = sl.queue, *d_front_of = sl.verts, *d_heavy = sl.qcnt;  // n ints each: idle now
+    int *d_flags = sl.counters;                                          // [0] heavy count, [1] error
+    SPL_HIP(hipMemcpyAsync(d_inv, T.inv.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    SPL_HIP(hipMemcpyAsync(d_front_of, T.front_of.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    SPL_HIP(hipMemcpyAsync(d_packed.get(), packed.data(), packed.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    SPL_HIP(hipMemcpyAsync(d_boff.get(), boff.data(), (F + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    SPL_HIP(hipMemsetAsync(d_bits.get(), 0, (size_t)std::max<int64_t>(words, 1) * sizeof(unsigned long long), s));
+    SPL_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), s));
+    BndTree t;
+    t.p0 = d_packed.get();
+    t.np = d_packed.get() + F;
+    t.parent = d_packed.get() + 2 * F;
+    t.up = d_packed.get() + 3 * F;
+    t.sub0 = d_packed.get() + 4 * F;
+    t.c0 = d_packed.get() + 5 * F;
+    t.c1 = d_packed.get() + 6 * F;
+    t.boff = d_boff.get();
+    const int *d_order = d_packed.get() + 7 * F;
+    hipLaunchKernelGGL(bnd_own_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, xadj, adj, d_inv, d_front_of, t,
+                       d_bits.get(), d_heavy, d_flags, d_flags + 1);
+    hipLaunchKernelGGL(bnd_own_heavy_kernel, dim3(256), dim3(256), 0, s, xadj, adj, d_inv, d_front_of, t, d_bits.get(),
+                       d_heavy, d_flags, d_flags + 1);
+    for (int d = T.maxdepth - 1; d >= 0; --d) {
+      const int count = lev_ptr[(size_t)d + 1] - lev_ptr[(size_t)d];
+      if (count > 0)
+        hipLaunchKernelGGL(bnd_merge_kernel, dim3((unsigned)count), dim3(256), 0, s, d_order + lev_ptr[(size_t)d], t, d_bits.get());
+    }
+    const unsigned per_front_grid = (unsigned)std::min<int64_t>(((int64_t)nf + 3) / 4, 4096);
+    hipLaunchKernelGGL(bnd_count_kernel, dim3(per_front_grid), dim3(256), 0, s, nf, t, d_bits.get(), d_nb.get());
+    std::vector<int> nb(F);
+    int flags[2] = {0, 0};
+    SPL_HIP(hipMemcpyAsync(nb.data(), d_nb.get(), F * sizeof(int), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipMemcpyAsync(flags, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipStreamSynchronize(s));
+    SPL_HIP(hipGetLastError());
+    if (flags[1]) return false;  // an edge to a front that is no ancestor: not a tree this scheme understands
+    std::vector<int64_t> bptr(F + 1, 0);
+    for (int f = 0; f < nf; ++f) bptr[(size_t)f + 1] = bptr[(size_t)f] + nb[(size_t)f];
+    const int64_t total = bptr[F];
+    std::vector<int> bidx((size_t)total);
+    if (total > 0) {
+      DBuf<int> d_bidx((size_t)total);
+      SPL_HIP(hipMemcpyAsync(d_bptr.get(), bptr.data(), (F + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(bnd_emit_kernel, dim3(per_front_grid), dim3(256), 0, s, nf, t, d_bits.get(), d_bptr.get(), d_bidx.get());
+      SPL_HIP(hipMemcpyAsync(bidx.data(), d_bidx.get(), (size_t)total * sizeof(int), hipMemcpyDeviceToHost, s));
+      SPL_HIP(hipStreamSynchronize(s));
+      SPL_HIP(hipGetLastError());
+    }
+    T.nb.swap(nb);
+    T.bptr.swap(bptr);
+    T.bidx.swap(bidx);
+    if (timing)
+      fprintf(stderr, "[nd_levels] boundaries: %d fronts, %.1f MB of bitmaps, %lld indices, %.2f ms\n", nf, (double)words * 8 / 1e6,
+              (long long)total, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    return true;
+  }
+
   int levels(const int *region, int size, std::vector<int> &out_queue, std::vector<int64_t> &out_level_ptr,
              int root) override {
     DeviceGuard g(device);
@@ -289,7 +538,7 @@ struct GpuLevels : mf::LevelService {
     std::vector<int> &h_levptr = sl.h_levptr;
     const int region_stamp = stamp.fetch_add(3) + 1, first = region_stamp + 1, second = region_stamp + 2;
     if (region_stamp > 0x7ffffff0) throw DeviceError{SPL_ERROR_internal};  // (never in practice: three stamps per call)
-    static const bool timing = getenv("SPL_MF_TIMING") != nullptr;
+    static const bool timing = mf::detailed_timing();
     auto t_last = std::chrono::steady_clock::now();
     double laps[5] = {0, 0, 0, 0, 0};
     auto lap = [&](int k) {

@@ -1032,7 +1032,10 @@ def test_level_structures_on_the_gpu(gpu, pkg, O, kind, monkeypatch):
     host = U.factor(A, U.analyze(A))
     monkeypatch.setenv("SPL_ND_GPU_MIN", "2000")
     results = []
-    for _ in range(2):
+    for rep in range(2):
+        # the boundary lists of the fronts are made on the device too (bitmaps over the ancestors' pivots): the first
+        # analysis makes them on both sides and fails unless they agree entry for entry
+        monkeypatch.setenv("SPL_ND_BOUNDARIES", "check" if rep == 0 else "")
         f = U.factor(A, U.analyze(A))
         assert f.path in (3, 4)
         sols = []
@@ -1045,6 +1048,50 @@ def test_level_structures_on_the_gpu(gpu, pkg, O, kind, monkeypatch):
     assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
     assert all(np.array_equal(p, q) for p, q in zip(results[0][2], results[1][2]))
     assert results[0][0] <= 1.25 * host.stats["flops"]
+
+
+@pytest.mark.parametrize("kind", ["arrow", "complex", "3d_host_lists"])
+def test_boundary_lists_on_the_gpu(gpu, pkg, O, kind, monkeypatch):
+    """csrc/nd_levels.hip, boundaries(): trees the mesh cases above do not make — hubs peeled one at a time (an arrow
+    matrix: a chain of one-pivot separators), the tree of a complex matrix (ordered on the small graph, expanded
+    afterwards) — with SPL_ND_BOUNDARIES=check: the analysis fails unless the device's lists equal the host's; and
+    SPL_ND_BOUNDARIES=host gives the same factorisation as the default."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    monkeypatch.setenv("SPL_ND_GPU_MIN", "2000")
+    rng = np.random.default_rng(15)
+    U = pkg.umfpack
+    if kind == "arrow":
+        m = 70
+        n0, A0 = _grid_matrix(pkg, O, "2d", m)
+        S0 = csc_tuple_to_scipy(mat_to_tuple(A0)).tolil()
+        for h in (0, 1, 2):  # three dense rows and columns
+            S0[h, :] = -0.01
+            S0[:, h] = -0.01
+            S0[h, h] = 2.0 * n0
+        S0 = sp.csc_matrix(S0)
+        S0.sort_indices()
+        A = pkg.Matrix(n0, n0, S0.indptr.astype(np.int32), S0.indices.astype(np.int32), S0.data)
+    elif kind == "complex":
+        n0, A0 = _grid_matrix(pkg, O, "3d", 22)
+        S0 = csc_tuple_to_scipy(mat_to_tuple(A0))
+        S0 = sp.csc_matrix((3.0 + 0.5j) * sp.identity(n0) - S0)
+        S0.sort_indices()
+        A = pkg.Matrix(n0, n0, S0.indptr.astype(np.int32), S0.indices.astype(np.int32), S0.data)
+    else:
+        n0, A = _grid_matrix(pkg, O, "3d", 30)
+        S0 = csc_tuple_to_scipy(mat_to_tuple(A))
+    xs = rng.uniform(0.5, 1.5, n0) + (1j * rng.uniform(0.5, 1.5, n0) if kind == "complex" else 0.0)
+    b = np.asarray(S0 @ xs).ravel()
+    monkeypatch.setenv("SPL_ND_BOUNDARIES", "check")
+    f = U.factor(A, U.analyze(A))
+    x = U.linearSolve_(f, U.UmfpackNormal, A, b)
+    assert _backward_error(S0, x, b) <= 1e-13
+    if kind == "3d_host_lists":
+        monkeypatch.setenv("SPL_ND_BOUNDARIES", "host")
+        g = U.factor(A, U.analyze(A))
+        assert g.stats["flops"] == f.stats["flops"] and g.stats["fronts"] == f.stats["fronts"]
+        assert np.array_equal(U.linearSolve_(g, U.UmfpackNormal, A, b), x)
 
 
 # ---- threshold pivoting inside the diagonal blocks of the fronts (csrc/dense_lu_kernels.hpp, Band::piv) ------------

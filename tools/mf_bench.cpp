@@ -35,8 +35,13 @@ int main(int argc, char **argv) {
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     int maxfs = 0;
     for (int f = 0; f < T.nfronts; ++f) maxfs = maxfs > T.fs(f) ? maxfs : T.fs(f);
-    printf("%d-D grid %d: n=%ld analyze %.3f s fronts=%d depth=%d maxfront=%d flops=%.4g panel_GB=%.2f\n", dim, m, n, dt,
-           T.nfronts, T.maxdepth, maxfs, T.flops, (double)T.panel_elems * 8 / 1e9);
+    // order-sensitive checksums of the permutation and of the boundary lists: two builds of the analysis agree on the tree
+    unsigned long long hp = 1469598103934665603ull, hb = hp;
+    for (int v : T.perm) hp = (hp ^ (unsigned)v) * 1099511628211ull;
+    for (int v : T.bidx) hb = (hb ^ (unsigned)v) * 1099511628211ull;
+    for (int f = 0; f < T.nfronts; ++f) hb = (hb ^ (unsigned)T.nb[(size_t)f]) * 1099511628211ull;
+    printf("%d-D grid %d: n=%ld analyze %.3f s fronts=%d depth=%d maxfront=%d flops=%.4g panel_GB=%.2f perm=%016llx bnd=%016llx (%zu)\n",
+           dim, m, n, dt, T.nfronts, T.maxdepth, maxfs, T.flops, (double)T.panel_elems * 8 / 1e9, hp, hb, T.bidx.size());
   }
   return 0;
 }
