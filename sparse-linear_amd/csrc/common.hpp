@@ -259,7 +259,7 @@ struct Factors;
 struct LevelService;
 }  // namespace mf
 // level structures of the nested dissection's large regions on the GPU (nd_levels.hip); nullptr: no usable device
-std::unique_ptr<mf::LevelService> make_gpu_level_service(int n, const int64_t *xadj, const int *adj);
+std::unique_ptr<mf::LevelService> make_gpu_level_service(int n, int64_t max_adj);
 size_t mf_device_bytes(const mf::Tree &T, int zm = 1);  // zm = 2: complex fronts (two planes)
 mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, const int *d_Ai, const double *d_Ax,
                        const int *d_Rp, const int *d_Rj, const double *d_Rx, const int *d_perm, const int *d_inv,

@@ -14,6 +14,7 @@
 // twenty work arrays of 1-500 MB per call — 3 ms of a 19 ms product on config C4 before this tier existed.
 #include <atomic>
 #include <chrono>
+#include <future>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -74,7 +75,12 @@ Pool &pool() {
 
 }  // namespace
 
+namespace {
+void warm_streams_once();  // (below, behind the stream pool it fills)
+}  // namespace
+
 void *device_alloc(size_t bytes) {
+  warm_streams_once();
   Pool &P = pool();
   void *p = nullptr;
   if (bytes < kSmallMin || !P.enabled) {
@@ -212,6 +218,51 @@ void pooled_streams_prewarm(int device, int count) {
     pooled_stream_give(device, s);
   }
 }
+
+namespace {
+// The first stream a process creates costs ~15 ms (every other one 0.3 - 0.6 ms), and an analysis needs four of them
+// 10 ms after it begins (nd_levels.hip), a factorisation seventeen: the streams of the pool are made by a thread of
+// their own from the first allocation a process makes on a device — a one-shot umfpack_di_symbolic that follows the
+// construction of its matrix finds them there (round 5: 17 - 20 ms of a first analysis at 10^6 unknowns were the wait
+// for them).  SPL_PREWARM_STREAMS=0: never.  The jobs are joined when the library is unloaded.
+struct StreamWarmers {
+  std::mutex mu;
+  std::vector<std::pair<int, std::future<void>>> jobs;
+  void start(int device) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto &j : jobs)
+      if (j.first == device) return;
+    const char *e = getenv("SPL_PREWARM_STREAMS");
+    std::future<void> job;
+    if (!(e && atoi(e) == 0)) {
+      try {
+        job = std::async(std::launch::async, [device] { pooled_streams_prewarm(device, 21); });
+      } catch (...) {  // no thread to be had: the streams are made where they are needed
+      }
+    }
+    jobs.emplace_back(device, std::move(job));
+  }
+  ~StreamWarmers() {
+    for (auto &j : jobs)
+      if (j.second.valid()) j.second.wait();
+  }
+};
+void warm_streams_once() {
+  (void)stream_pool();  // constructed before W, so destroyed after the jobs W joins
+  static StreamWarmers W;
+  static std::atomic<uint64_t> seen{0};  // one bit per device: the common case is a load and a test
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  const uint64_t bit = 1ull << (device & 63);
+  if (seen.load(std::memory_order_relaxed) & bit) return;
+  seen.fetch_or(bit, std::memory_order_relaxed);
+  W.start(device);
+}
+}  // namespace
+
 
 size_t device_release_cached() {
   Pool &P = pool();

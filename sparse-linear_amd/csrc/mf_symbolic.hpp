@@ -71,6 +71,12 @@ struct HugeAlloc {
     if (bytes < kFrom) free(p);
     else munmap(p, mapped_bytes(bytes));
   }
+  // resize(n) / vector(n) leave the elements uninitialised (they are plain integers, written before they are read):
+  // no pass of zeros over tens of megabytes, and the first touch of a page is its user's, often one of several threads
+  template <typename U>
+  void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+  template <typename U, typename... Args>
+  void construct(U *p, Args &&...args) { ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...); }
   template <typename U>
   bool operator==(const HugeAlloc<U> &) const { return true; }
   template <typename U>
@@ -159,8 +165,10 @@ struct Tree {
 // boundaries(): the boundary lists of every front of the finished tree (T.nb, T.bptr, T.bidx from T.inv, T.front_of,
 // T.p0, T.np, T.parent, T.depth), exactly what build_tree's host code makes level by level; false: not done (too large
 // for the device's scheme, a tree it does not understand, any failure there) and the outputs are untouched.
+// graph(): the adjacency the service was announced (ServiceFactory) — false: no service after all.
 struct LevelService {
   virtual ~LevelService() {}
+  virtual bool graph(const int64_t *xadj, const int *adj) = 0;
   virtual int levels(const int *region, int size, std::vector<int> &queue, std::vector<int64_t> &level_ptr, int root = -1) = 0;
   virtual bool boundaries(Tree &) { return false; }
 };
@@ -210,6 +218,12 @@ inline bool structurally_symmetric(int n, const int *Ap, const int *Ai) {
   return ok.load();
 }
 
+// vertices from which a graph's analysis gets a level service at all: SPL_ND_GPU_MIN (0: never), 10^6 by default
+inline int service_threshold() {
+  const char *e = getenv("SPL_ND_GPU_MIN");
+  return e ? atoi(e) : 1000000;
+}
+
 struct Node {
   int left = -1, right = -1;  // indices in the same vector (post-order: children before the parent)
   std::vector<int> piv;       // pivots (separator, or all vertices of a leaf), original numbering
@@ -254,7 +268,7 @@ struct Shared {
     if (const char *e = getenv("SPL_ND_TEAM")) max_team = std::max(1, std::min(atoi(e), 64));
     if (const char *e = getenv("SPL_ND_TEAM_REGION")) team_region = std::max(1024, atoi(e));
     if (const char *e = getenv("SPL_ND_TEAM_FRONTIER")) team_frontier = std::max(64, atoi(e));
-    if (const char *e = getenv("SPL_ND_GPU_MIN")) service_min = service_min_bulky = atoi(e);
+    if (getenv("SPL_ND_GPU_MIN")) service_min = service_min_bulky = service_threshold();
     if (n >= team_region && max_team > 1) claim.assign((size_t)n, 0);
   }
 };
@@ -708,8 +722,9 @@ inline void layout_tree(Tree &T);
 // unexpanded != nullptr (mult > 1): also receives the tree of the small graph itself, laid out for fronts of its own
 // n unknowns (native complex fronts, multifrontal.hip: one dissection serves both)
 // pattern_symmetric: 1 / 0 if the caller has already run detail::structurally_symmetric, -1: not known
-// make_service: called with the adjacency (n, xadj, adj) once it is built; may return nullptr
-using ServiceFactory = std::unique_ptr<LevelService> (*)(int, const int64_t *, const int *);
+// make_service: called when the analysis begins with n and an upper bound on the adjacency's length (the service gets
+// its memory and streams ready beside the construction of the adjacency, which it is handed by graph()); may return nullptr
+using ServiceFactory = std::unique_ptr<LevelService> (*)(int, int64_t);
 inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, int mult = 1, Tree *unexpanded = nullptr,
                        int pattern_symmetric_hint = -1, ServiceFactory make_service = nullptr) {
   T = Tree();
@@ -728,6 +743,11 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
   // both of its ends, so a symmetric pair appears twice: harmless for BFS, removed from the boundary lists by sort +
   // unique, but twice the edge work).
   const bool pattern_symmetric = pattern_symmetric_hint >= 0 ? pattern_symmetric_hint != 0 : detail::structurally_symmetric(n, Ap, Ai);
+  std::unique_ptr<LevelService> service;
+  {
+    const int service_min = detail::service_threshold();
+    if (make_service && service_min > 0 && n >= service_min) service = make_service(n, (int64_t)Ap[n] * (pattern_symmetric ? 1 : 2));
+  }
   BigVec<int64_t> xadj((size_t)n + 1, 0);
   BigVec<int> adj;
   if (pattern_symmetric) {
@@ -780,9 +800,8 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
   }
   lap(pattern_symmetric ? "adjacency (symmetric pattern)" : "adjacency of A + A^T");
   detail::Shared shared(n, xadj, adj, leaf);
-  std::unique_ptr<LevelService> service;
-  if (make_service && shared.service_min > 0 && n >= shared.service_min) {
-    service = make_service(n, xadj.data(), adj.data());
+  if (service) {
+    if (!service->graph(xadj.data(), adj.data())) service.reset();
     shared.service = service.get();
     lap(service ? "graph to the GPU" : "no GPU level service");
   }

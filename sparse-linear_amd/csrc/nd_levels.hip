@@ -17,6 +17,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <future>
 #include <mutex>
 
 #include "common.hpp"
@@ -308,6 +309,12 @@ struct GpuLevels : mf::LevelService {
   std::condition_variable freed;
 
   ~GpuLevels() override {
+    if (ready.valid()) {
+      try {
+        ready.get();
+      } catch (...) {
+      }
+    }
     for (Slot &sl : slots)
       if (sl.s) {
         (void)hipStreamSynchronize(sl.s);
@@ -315,8 +322,20 @@ struct GpuLevels : mf::LevelService {
       }
   }
 
-  GpuLevels(int n_, const int64_t *h_xadj, const int *h_adj) : n(n_) {
+  // Two steps (round 5): the slab and the streams are taken by a thread of their own from the moment the analysis
+  // begins — 5 + 4 ms the first time a process gets here, beside the construction of the adjacency on the host — and
+  // the graph follows when it exists (graph()).  max_adj: an upper bound on the adjacency's length.
+  std::future<void> ready;
+  size_t adj_capacity = 0;
+
+  GpuLevels(int n_, int64_t max_adj) : n(n_) {
     SPL_HIP(hipGetDevice(&device));
+    adj_capacity = (size_t)std::max<int64_t>(max_adj, 1);
+    ready = std::async(std::launch::async, [this] { prepare(); });
+  }
+
+  void prepare() {
+    DeviceGuard g(device);  // (HIP's current device belongs to the thread)
     const bool timing = getenv("SPL_MF_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -325,17 +344,17 @@ struct GpuLevels : mf::LevelService {
       fprintf(stderr, "[nd_levels] service: %-20s %6.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
       t_last = now;
     };
-    const size_t nnz = (size_t)h_xadj[n], N = (size_t)n;
+    const size_t N = (size_t)n;
     sort_temp_bytes = radix_sort_u64_temp_bytes(n);
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t per_slot = up(N * 4) * 3 + up((N + kBatch + 4) * 4) + up(16) + up(N * 8) * 3 + up(sort_temp_bytes ? sort_temp_bytes : 1);
-    const size_t total = up((N + 1) * 8) + up((nnz ? nnz : 1) * 4) + up(N * 4) + kSlots * per_slot;
+    const size_t total = up((N + 1) * 8) + up(adj_capacity * 4) + up(N * 4) + kSlots * per_slot;
     slab.alloc(std::max<size_t>(total, (size_t)1 << 30));
     lap("slab");
     char *at = slab.get();
     auto take = [&](size_t b) { char *p = at; at += up(b); return p; };
     xadj = reinterpret_cast<int64_t *>(take((N + 1) * 8));
-    adj = reinterpret_cast<int *>(take((nnz ? nnz : 1) * 4));
+    adj = reinterpret_cast<int *>(take(adj_capacity * 4));
     mark = reinterpret_cast<int *>(take(N * 4));
     for (Slot &sl : slots) {
       sl.queue = reinterpret_cast<int *>(take(N * 4));
@@ -348,24 +367,27 @@ struct GpuLevels : mf::LevelService {
       sl.keys_alt = reinterpret_cast<unsigned long long *>(take(N * 8));
       sl.sort_temp = take(sort_temp_bytes ? sort_temp_bytes : 1);
       sl.s = pooled_stream_take(device);
-      if (!sl.s) {
-        for (Slot &made : slots)
-          if (made.s) pooled_stream_give(device, made.s);
-        throw DeviceError{SPL_ERROR_internal};
-      }
+      if (!sl.s) throw DeviceError{SPL_ERROR_internal};  // (the destructor gives back the streams taken so far)
     }
+    SPL_HIP(hipMemsetAsync(mark, 0, N * sizeof(int), slots[0].s));
     lap("streams");
+  }
+
+  // the graph to the device; false: no service (the preparation failed, the graph is larger than announced, a copy
+  // failed): the caller drops the object
+  bool graph(const int64_t *h_xadj, const int *h_adj) override {
     try {
+      if (ready.valid()) ready.get();
+      DeviceGuard g(device);
+      const size_t nnz = (size_t)h_xadj[n], N = (size_t)n;
+      if (nnz > adj_capacity) return false;
       hipStream_t s = slots[0].s;
       SPL_HIP(hipMemcpyAsync(xadj, h_xadj, (N + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
       if (nnz) SPL_HIP(hipMemcpyAsync(adj, h_adj, nnz * sizeof(int), hipMemcpyHostToDevice, s));
-      SPL_HIP(hipMemsetAsync(mark, 0, N * sizeof(int), s));
       SPL_HIP(hipStreamSynchronize(s));
-      lap("copies");
-    } catch (...) {  // (the destructor does not run for an object whose constructor throws)
-      for (Slot &sl : slots)
-        if (sl.s) pooled_stream_give(device, sl.s);
-      throw;
+      return true;
+    } catch (...) {
+      return false;
     }
   }
 
@@ -596,11 +618,11 @@ struct GpuLevels : mf::LevelService {
 }  // namespace
 
 // nullptr when no device is usable (the analysis then runs on the host alone)
-std::unique_ptr<mf::LevelService> make_gpu_level_service(int n, const int64_t *xadj, const int *adj) {
+std::unique_ptr<mf::LevelService> make_gpu_level_service(int n, int64_t max_adj) {
   try {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return nullptr;
-    return std::unique_ptr<mf::LevelService>(new GpuLevels(n, xadj, adj));
+    return std::unique_ptr<mf::LevelService>(new GpuLevels(n, max_adj));
   } catch (...) {
     return nullptr;
   }
