@@ -223,6 +223,34 @@ inline int service_threshold() {
   const char *e = getenv("SPL_ND_GPU_MIN");
   return e ? atoi(e) : 1000000;
 }
+// ... from 200 000 if the graph is bulky (bulky_graph below): a 3-D mesh has a few hundred wide levels, which the device
+// walks at ~10 us each while the host pays per vertex (80^3: 0.064 -> 0.043 s, a third of the CPU time); the thousands
+// of narrow levels of a 2-D mesh of that size stay with the host's threads (800^2: 0.044 s there, 0.057 s here)
+constexpr int kServiceFromBulky = 200000;
+
+// Does the graph grow like a volume rather than like a surface?  Levels a breadth-first search from vertex 0 takes to
+// reach 4096 vertices: a 2-D mesh needs 45 from an interior vertex (90 from a corner), a 3-D mesh 15 (29 from a corner).
+template <typename XAdj, typename Adj>
+inline bool bulky_graph(int n, const XAdj &xadj, const Adj &adj) {
+  constexpr int kReach = 4096, kLevels = 36;
+  if (n < kReach) return false;
+  std::vector<char> seen((size_t)n, 0);
+  std::vector<int> frontier(1, 0), next;
+  seen[0] = 1;
+  int reached = 1, levels = 0;
+  while (!frontier.empty() && reached < kReach) {
+    next.clear();
+    for (int v : frontier)
+      for (int64_t p = xadj[(size_t)v]; p < xadj[(size_t)v + 1]; ++p) {
+        const int u = adj[(size_t)p];
+        if (!seen[(size_t)u]) { seen[(size_t)u] = 1; next.push_back(u); }
+      }
+    reached += (int)next.size();
+    frontier.swap(next);
+    if (++levels > kLevels) return false;
+  }
+  return reached >= kReach;
+}
 
 struct Node {
   int left = -1, right = -1;  // indices in the same vector (post-order: children before the parent)
@@ -256,6 +284,7 @@ struct Shared {
   // region — 100^3 analysis 0.133 -> 0.111 s, 160^3 0.485 -> 0.434 s; the thousands of narrow levels of a 2-D mesh
   // cost the device more than the host's threads below 10^6 vertices: 3000^2 0.65 -> 0.91 s with this limit for all)
   int service_min_bulky = 150000;
+  bool root_bulky = false;  // the whole graph is bulky (bulky_graph): its root region too goes to the device from service_min_bulky on
   int root_levels = 0;  // levels of the root region's final level structure (written by the depth-0 call only)
   std::atomic<int> gave_up{0};  // a region was left as one leaf because it has no separators (Tree::gave_up)
   std::atomic<int> stamp{0};
@@ -555,7 +584,7 @@ struct Worker {
     };
     int reached = -1;
     bool from_service = false;
-    const bool to_service = S.service && S.service_min > 0 && size >= (thin_parent || depth == 0 ? S.service_min : S.service_min_bulky);
+    const bool to_service = S.service && S.service_min > 0 && size >= (thin_parent || (depth == 0 && !S.root_bulky) ? S.service_min : S.service_min_bulky);
     const bool hint_wanted = hint >= 0 && (size <= kHintBelow || thin_parent);
     bool use_hint = false;
     if (to_service) {
@@ -746,7 +775,8 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
   std::unique_ptr<LevelService> service;
   {
     const int service_min = detail::service_threshold();
-    if (make_service && service_min > 0 && n >= service_min) service = make_service(n, (int64_t)Ap[n] * (pattern_symmetric ? 1 : 2));
+    const int from = getenv("SPL_ND_GPU_MIN") ? service_min : std::min(service_min, detail::kServiceFromBulky);
+    if (make_service && service_min > 0 && n >= from) service = make_service(n, (int64_t)Ap[n] * (pattern_symmetric ? 1 : 2));
   }
   BigVec<int64_t> xadj((size_t)n + 1, 0);
   BigVec<int> adj;
@@ -800,6 +830,10 @@ inline void build_tree(int n, const int *Ap, const int *Ai, int leaf, Tree &T, i
   }
   lap(pattern_symmetric ? "adjacency (symmetric pattern)" : "adjacency of A + A^T");
   detail::Shared shared(n, xadj, adj, leaf);
+  if (service && n < shared.service_min) {  // announced for a bulky graph only
+    shared.root_bulky = detail::bulky_graph(n, xadj, adj);
+    if (!shared.root_bulky) service.reset();
+  }
   if (service) {
     if (!service->graph(xadj.data(), adj.data())) service.reset();
     shared.service = service.get();
