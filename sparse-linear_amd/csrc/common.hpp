@@ -267,6 +267,9 @@ mf::Factors *mf_factor(std::shared_ptr<const mf::Tree> tree, const int *d_Ap, co
                        const double *d_rscale = nullptr);  // pivot: threshold pivoting inside the diagonal blocks, on
                                                            // candidates scaled by d_rscale (new ordering of `tree`)
 int mf_singular(const mf::Factors *F);
+// the chain matrices of the large fronts' pivot blocks (mf_chain.hpp): out[0] bytes of device memory, out[1] milliseconds
+// their construction took, out[2] pivots per block (0: no chains)
+void mf_chain_info(const mf::Factors *F, double out[3]);
 void mf_solve(const mf::Factors *F, int sys, double *d_c, int k, size_t stride, hipStream_t s);
 void mf_free(mf::Factors *F);
 

@@ -725,6 +725,8 @@ __device__ __forceinline__ BigFront big_front(const int *__restrict__ list, cons
   return b;
 }
 
+#include "mf_chain.hpp"
+
 // one super-block step (256 pivots) of the triangular pass MODE through the pivot columns of every
 // listed front that has a step `step`: forward passes take W -> Z, backward passes Z -> W
 template <int MODE, int NR, bool Z = false>
@@ -1058,6 +1060,32 @@ struct Factors {
   using BigLevel = LevelPlan::BigLevel;
   int singular = 0;
   int zm = 1;         // 2: complex fronts in two planes (TreeView::zm)
+  // the pivot blocks of the large fronts as chains of matrix-vector products (mf_chain.hpp): built by the first
+  // untransposed solve with one right-hand side, under `once`; ok = false: none (switched off, no memory, or an entry
+  // beyond chain::kLimit) — the walk then keeps its substitution steps
+  struct Chain {
+    std::once_flag once;
+    bool ok = false;
+    int span = 0;
+    int64_t elems = 0;      // doubles of one plane
+    DBuf<double> buf;
+    DBuf<int64_t> off;      // per front (see chain::View)
+    // the flat grids of the chain launches: per depth, [pass 0 = forward, 1 = backward][launch 0 .. steps][count + 1]
+    struct Level {
+      int steps = 0, count = 0;
+      int lead_rows = 0;  // rows of a block per lead workgroup (chain::kRows, or rows_wide() on the levels of small pivot blocks)
+      size_t base = 0;
+    };
+    std::vector<Level> levels;
+    std::vector<int64_t> h;
+    DBuf<int64_t> d;
+    size_t at(int depth, int pass, int launch) const {
+      const Level &L = levels[(size_t)depth];
+      return L.base + ((size_t)pass * (size_t)(L.steps + 1) + (size_t)launch) * (size_t)(L.count + 1);
+    }
+    double build_ms = 0.0;
+  };
+  mutable Chain chain;
   // independent large fronts of a level run on these (factorisation): one set per device and host
   // thread, created on first use and never destroyed (objects come and go by the thousand in a
   // contour integration; work of different objects on the same stream is merely ordered)
@@ -1092,6 +1120,13 @@ struct Factors {
 void mf_free(mf::Factors *F) { delete F; }
 
 int mf_singular(const mf::Factors *F) { return F->singular; }
+
+void mf_chain_info(const mf::Factors *F, double out[3]) {
+  const bool ok = F->chain.ok;
+  out[0] = ok ? (double)F->zm * (double)F->chain.elems * 8.0 : 0.0;
+  out[1] = ok ? F->chain.build_ms : 0.0;
+  out[2] = ok ? (double)F->chain.span : 0.0;
+}
 
 namespace {
 
@@ -1765,6 +1800,128 @@ static void launch_big_pipe(const mf::Factors &F, const mf::Factors::BigLevel &B
   }
 }
 
+// ---- chains (mf_chain.hpp): built once per factorisation, by its first untransposed solve with one right-hand side
+template <bool Z>
+static void build_chain_t(const mf::Factors &F, hipStream_t s) {
+  mf::Factors::Chain &Cn = F.chain;
+  const mf::Tree &T = *F.tree;
+  int S = 512;
+  if (const char *e = getenv("SPL_MF_CHAIN")) {  // 0: none (ablation); 256: shorter blocks
+    const int v = atoi(e);
+    if (v <= 0) return;
+    if (v == 256 || v == 512 || v == 1024) S = v;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  const int nd = T.maxdepth + 1;
+  std::vector<int64_t> off((size_t)T.nfronts, -1);
+  std::vector<int> item_f, item_k;
+  std::vector<int64_t> pre{0};
+  int64_t elems = 0;
+  Cn.levels.assign((size_t)nd, mf::Factors::Chain::Level());
+  Cn.h.clear();
+  for (int d = 0; d < nd; ++d) {
+    std::vector<int> large;  // (the order of LevelPlan::BigLevel::list)
+    for (int f : T.by_depth[(size_t)d])
+      if (T.fs(f) > F.lp->big_solve && T.np[(size_t)f] > 0) large.push_back(f);
+    mf::Factors::Chain::Level &L = Cn.levels[(size_t)d];
+    L.count = (int)large.size();
+    if (L.count == 0) continue;
+    for (int f : large) L.steps = std::max(L.steps, (T.np[(size_t)f] + S - 1) / S);
+    int maxnp = 0;
+    for (int f : large) maxnp = std::max(maxnp, T.np[(size_t)f]);
+    L.lead_rows = maxnp <= chain::kWidePivots ? chain::rows_wide(Z) : chain::kRows;
+    L.base = Cn.h.size();
+    Cn.h.resize(Cn.h.size() + (size_t)2 * (size_t)(L.steps + 1) * (size_t)(L.count + 1), 0);
+    const int rbk = F.lp->big[(size_t)d].row_blocks;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int l = 0; l <= L.steps; ++l) {
+        int64_t *p = Cn.h.data() + Cn.at(d, pass, l);
+        for (int i = 0; i < L.count; ++i) {
+          const int np = T.np[(size_t)large[(size_t)i]], K = (np + S - 1) / S;
+          int64_t g = 0;
+          if (l < K) {  // lead groups of block l of the pass
+            const int k = pass == 0 ? l : K - 1 - l;
+            g += (std::min(S, np - k * S) + L.lead_rows - 1) / L.lead_rows;
+          }
+          if (l >= 1 && l - 1 < K) {  // bulk groups of the block before: the rows beyond the next block
+            const int kb = pass == 0 ? l - 1 : K - l;
+            const int rest = pass == 0 ? np - (kb + 2) * S : (kb - 1) * S;
+            if (rest > 0) g += ((rest + 63) / 64 + rbk - 1) / rbk;
+          }
+          p[i + 1] = p[i] + g;
+        }
+      }
+    for (int f : large) {
+      const int np = T.np[(size_t)f], K = (np + S - 1) / S;
+      off[(size_t)f] = elems;
+      elems += (int64_t)2 * np * chain::ld_of(np, S);
+      for (int up = 0; up < 2; ++up)
+        for (int k = 0; k < K; ++k) {
+          const int jbs = std::min(S, np - k * S);
+          int tiles = (jbs + 63) / 64;
+          if (up == 0 && k > 0) tiles += S / 64;
+          if (up == 1 && k < K - 1) tiles += (std::min(S, np - (k + 1) * S) + 63) / 64;
+          item_f.push_back(f);
+          item_k.push_back(k | (up << 30));
+          pre.push_back(pre.back() + tiles);
+        }
+    }
+  }
+  if (item_f.empty()) return;
+  try {
+    constexpr int ZM = Z ? 2 : 1;
+    Cn.buf.alloc((size_t)ZM * (size_t)elems + 256);
+    SPL_HIP(hipMemsetAsync(Cn.buf.get(), 0, ((size_t)ZM * (size_t)elems + 256) * sizeof(double), s));
+    upload_vec(Cn.off, off, s);
+    upload_vec(Cn.d, Cn.h, s);
+    DBuf<int> d_f, d_k, bad(1);
+    DBuf<int64_t> d_pre;
+    upload_vec(d_f, item_f, s);
+    upload_vec(d_k, item_k, s);
+    upload_vec(d_pre, pre, s);
+    SPL_HIP(hipMemsetAsync(bad.get(), 0, sizeof(int), s));
+    const chain::View cv{Cn.buf.get(), Cn.off.get(), (size_t)elems, S};
+    hipLaunchKernelGGL(chain_build_kernel<Z>, dim3((unsigned)pre.back()), dim3(256), 0, s, d_f.get(), d_k.get(), d_pre.get(),
+                       (int)item_f.size(), F.view, F.invs.get(), cv, bad.get());
+    int hbad = 0;
+    SPL_HIP(hipMemcpyAsync(&hbad, bad.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+    SPL_HIP(hipStreamSynchronize(s));
+    SPL_HIP(hipGetLastError());
+    if (hbad) {  // an entry too large to trust (or not finite): keep the substitution steps
+      Cn.buf.release();
+      return;
+    }
+  } catch (const DeviceError &) {  // no memory for the chains: the walk does without
+    Cn.buf.release();
+    (void)hipGetLastError();
+    return;
+  }
+  Cn.span = S;
+  Cn.elems = elems;
+  Cn.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  Cn.ok = true;
+  if (getenv("SPL_MF_TIMING"))
+    fprintf(stderr, "[mf_solve] chains: span %d, %zu blocks, %.2f GB, built in %.2f ms\n", S, item_f.size(),
+            (Z ? 2 : 1) * elems * 8e-9, Cn.build_ms);
+}
+
+template <int MODE, int NR, bool Z = false>
+static void launch_big_chain(const mf::Factors &F, int depth, double *work, double *zbuf, hipStream_t s, double *x = nullptr,
+                             size_t xstride = 0) {
+  const mf::Factors::Chain &Cn = F.chain;
+  const mf::Factors::Chain::Level &L = Cn.levels[(size_t)depth];
+  const mf::Factors::BigLevel &B = F.lp->big[(size_t)depth];
+  const size_t lds = (size_t)(Cn.span + NB + solve_waves<NR>() * 64) * NR * sizeof(double);
+  const chain::View cv{Cn.buf.get(), Cn.off.get(), (size_t)Cn.elems, Cn.span};
+  for (int l = 0; l <= L.steps; ++l) {
+    const size_t at = Cn.at(depth, MODE, l);
+    const unsigned groups = (unsigned)Cn.h[at + (size_t)L.count];
+    if (groups > 0)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(big_chain_kernel<MODE, NR, Z>), dim3(groups), dim3(solve_waves<NR>() * 64), lds, s,
+                         B.list.get(), Cn.d.get() + at, B.count, l, F.view, cv, work, zbuf, B.row_blocks, L.lead_rows, x, xstride);
+  }
+}
+
 // the solve lists of one depth
 struct SolveLevel {
   const int *solve_list;
@@ -1772,9 +1929,11 @@ struct SolveLevel {
   const int *child_list[2];  // the children (by slot) of the fronts of this depth, and the largest boundary among them
   int child_count[2], child_maxnb;
   const mf::Factors::BigLevel *big;
+  int depth;
 };
 static SolveLevel whole_level(const mf::LevelPlan &lp, int d, int nd) {
   SolveLevel L;
+  L.depth = d;
   L.solve_list = lp.solve_lists[(size_t)d].get();
   L.solve_count = lp.solve_counts[(size_t)d];
   L.child_maxnb = d + 1 < nd ? std::max(lp.child_maxnb[0][(size_t)d], lp.child_maxnb[1][(size_t)d]) : 0;
@@ -1829,6 +1988,8 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
   // launch per step with the whole chain in it: ablations, read once per walk)
   const char *sf = getenv("SPL_MF_SPLIT_FWD"), *pe = getenv("SPL_MF_PIPE");
   const bool split_fwd = !(sf && sf[0] == '0'), pipe_on = !(pe && pe[0] == '0');
+  // the pivot blocks as chains of matrix-vector products (mf_chain.hpp): untransposed systems, one right-hand side
+  const bool chain_on = !TRANS && NR <= 2 && split_fwd && pipe_on && F.chain.ok;
 
   // one level on the way up: children's boundaries into their parents, the one-workgroup fronts, the large ones in lockstep
   auto up_level = [&](const SolveLevel &L, double *scr, hipStream_t q) {
@@ -1850,7 +2011,8 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
       // (pipelined steps with one or two columns only: with 8 or 16 the in-super-block solve is instruction-bound, and the
       // bulk groups' reload of the solved super block costs more than the overlap gains: FEAST 80^3 solve stage 2.95 -> 3.05 s)
       const bool pipe = pipe_on && (TRANS || pivots_only) && NR <= 2;
-      if (pipe) launch_big_pipe<FWD, NR, Z>(F, B, 13, work, zbuf, cbuf, q);
+      if (chain_on && pivots_only) launch_big_chain<0, (NR <= 2 ? NR : 1), (NR <= 2 ? Z : false)>(F, L.depth, work, zbuf, q);
+      else if (pipe) launch_big_pipe<FWD, NR, Z>(F, B, 13, work, zbuf, cbuf, q);
       else
         for (int k = 0; k < B.steps; ++k) launch_big_super<FWD, NR, Z>(F, B, (TRANS || pivots_only) ? 1 : 0, k, work, zbuf, q, pivots_only ? 1 : 0);
       if (pivots_only && B.total(10) > 0) {
@@ -1905,7 +2067,8 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
       }
       // the pivot block alone; columns of Z / W are fs apart
       // (the solved pivots go to x from inside these steps: round 4 had a scatter launch per level behind them)
-      if (pipe_on && NR <= 2) launch_big_pipe<BWD, NR, Z>(F, B, 14, work, zbuf, cbuf, q, c, stride);
+      if (chain_on) launch_big_chain<1, (NR <= 2 ? NR : 1), (NR <= 2 ? Z : false)>(F, L.depth, work, zbuf, q, c, stride);
+      else if (pipe_on && NR <= 2) launch_big_pipe<BWD, NR, Z>(F, B, 14, work, zbuf, cbuf, q, c, stride);
       else
         for (int k = 0; k < B.steps; ++k) launch_big_super<BWD, NR, Z>(F, B, 2, k, work, zbuf, q, 0, c, stride);
     }
@@ -1981,6 +2144,8 @@ void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride,
       }
     }
   };
+  if (sys == 0 && k == 1)
+    std::call_once(F.chain.once, [&] { z ? build_chain_t<true>(F, s) : build_chain_t<false>(F, s); });
   DBuf<double> both(elems);
   run(both.get(), s);
   SPL_HIP(hipStreamSynchronize(s));  // the work matrices are freed on return

@@ -138,7 +138,8 @@ class Factors(_Handle):
         if _declare().spl_umfpack_solve_report(self.value, buf) != 0:
             raise UmfpackError("spl_umfpack_solve_report: invalid Numeric object")
         return {"walks": int(buf[0]), "ir_taken": int(buf[1]), "ir_attempted": int(buf[2]),
-                "backward_error": float(buf[3]), "walk_bytes": float(buf[4])}
+                "backward_error": float(buf[3]), "walk_bytes": float(buf[4]),
+                "chain_bytes": float(buf[5]), "chain_build_ms": float(buf[6]), "chain_span": int(buf[7])}
 
 
 def analyze(mat):

@@ -382,6 +382,7 @@ def test_pipelined_steps_and_split_boundary_product_give_the_same_solution(gpu, 
     (both systems: the transposed kernels too); the solve report says two walks each."""
     import scipy.sparse as sp
     monkeypatch.setenv("SPL_MF_BIGSOLVE", "64")  # many-workgroup solves from 64 rows on: more fronts, more steps
+    monkeypatch.setenv("SPL_MF_CHAIN", "0")  # the substitution steps themselves (round 5: chains take their place by default)
     m = 30
     n, A = _grid_matrix(pkg, O, "3d", m)
     rng = np.random.default_rng(3)
@@ -412,6 +413,64 @@ def test_pipelined_steps_and_split_boundary_product_give_the_same_solution(gpu, 
         assert np.array_equal(x, x_plain)
         assert np.max(np.abs(x - x_old) / np.abs(x_old)) < 1e-13
         assert np.max(np.abs(x - xs) / xs) < 1e-12
+
+
+@pytest.mark.parametrize("kind", ["symmetric", "unsymmetric", "pivoted", "complex"])
+@pytest.mark.parametrize("span", ["512", "256"])
+def test_chains_of_matrix_vector_products_give_the_same_solution(gpu, pkg, O, kind, span, monkeypatch):
+    """round 5, csrc/mf_chain.hpp: the pivot blocks of the large fronts as chains of matrix-vector products (explicit
+    inverses T_k of blocks of 512 pivots and M_k = T_k L_{k,k-1}, built by the first solve of A x = b on the matrix cores)
+    against the substitution steps they replace (SPL_MF_CHAIN=0): the same solution to rounding level, backward errors
+    below eps, for L D L^T fronts, plain LU fronts, fronts with interchanges inside their 64 x 64 blocks and native
+    complex fronts; blocks of 256 pivots as well.  A 3-D mesh whose root front has 1 296 pivots (three blocks, the last
+    one partial) above levels of fronts with one block; the report says what the chains take."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    m = 36
+    n, A = _grid_matrix(pkg, O, "3d", m)
+    rng = np.random.default_rng(11)
+    S = csc_tuple_to_scipy(mat_to_tuple(A))
+    if kind in ("unsymmetric", "pivoted"):
+        S0 = S.tocoo()
+        v = S0.data * rng.uniform(0.8, 1.2, S0.nnz)
+        # dominant: plain LU without interchanges; "pivoted": a weak diagonal, threshold pivoting inside the blocks
+        v[S0.row == S0.col] = 7.0 if kind == "unsymmetric" else rng.uniform(0.5, 1.5, n)
+        S = sp.csc_matrix((v, (S0.row, S0.col)), shape=S0.shape)
+    elif kind == "complex":
+        monkeypatch.setenv("SPL_ZI_NATIVE", "1")
+        S = sp.csc_matrix((3.0 + 0.5j) * sp.identity(n) - S)
+    S.sort_indices()
+    A = pkg.Matrix(n, n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
+    U = pkg.umfpack
+    xs = rng.uniform(0.5, 1.5, n) + (1j * rng.uniform(-1, 1, n) if kind == "complex" else 0.0)
+    b = np.asarray(S @ xs).ravel()
+    an = U.analyze(A)
+    monkeypatch.setenv("SPL_MF_CHAIN", "0")
+    f0 = U.factor(A, an)
+    x0 = U.linearSolve_(f0, U.UmfpackNormal, A, b)
+    r0 = f0.solve_report
+    assert f0.path in (3, 4) and r0["chain_span"] == 0 and r0["chain_bytes"] == 0
+    monkeypatch.setenv("SPL_MF_CHAIN", span)
+    f1 = U.factor(A, an)
+    x1 = U.linearSolve_(f1, U.UmfpackNormal, A, b)
+    r1 = f1.solve_report
+    assert f1.path == f0.path and f1.stats == f0.stats
+    if kind == "complex":
+        assert f1.stats["complex_fronts"] == 1
+    assert r1["chain_span"] == int(span) and r1["chain_bytes"] > 0 and r1["chain_build_ms"] > 0
+    assert r1["walk_bytes"] == r0["walk_bytes"]
+    lim = 1e-13 if kind == "pivoted" else 2.3e-16  # (block pivoting is a speculation checked against 1e-13)
+    assert r0["backward_error"] <= lim and r1["backward_error"] <= lim
+    assert np.max(np.abs(x1 - x0)) <= 1e-12 * np.max(np.abs(x0))
+    assert np.max(np.abs(x1 - xs) / np.abs(xs)) < 1e-10
+    # the chains belong to the factors: a second solve reuses them, the transposed system keeps its substitution steps
+    x2 = U.linearSolve_(f1, U.UmfpackNormal, A, b)
+    assert np.array_equal(x1, x2) and f1.solve_report["chain_build_ms"] == r1["chain_build_ms"]
+    St = sp.csc_matrix(S.conj().T)
+    bt = np.asarray(St @ xs).ravel()
+    xt0 = U.linearSolve_(f0, U.UmfpackTrans, A, bt)
+    xt1 = U.linearSolve_(f1, U.UmfpackTrans, A, bt)
+    assert np.max(np.abs(xt1 - xt0)) <= 1e-12 * np.max(np.abs(xt0))
 
 
 @pytest.mark.parametrize("unsym", [False, True])

@@ -42,9 +42,9 @@ def child(m, cplx):
     t = time.perf_counter(); xt = U.linearSolve_(fa, U.UmfpackTrans, A, b); tt = time.perf_counter() - t
     xd = Xd[0].cpu().numpy()
     x8 = X8[3].cpu().numpy()
-    print("RESULT factor %.4f s | solve %.5f s (%s) | 8 columns %.5f s | transposed %.5f s | err %.2e err8 %.2e errT %.2e | walks %d bwd err %.2e | device GB %.2f | sha1 %s" % (
+    print("RESULT factor %.4f s | solve %.5f s (%s) | 8 columns %.5f s | transposed %.5f s | err %.2e err8 %.2e errT %.2e | walks %d bwd err %.2e | device GB %.2f | chain %.2f GB %.2f ms span %d | sha1 %s" % (
         tf, min(ts), " ".join("%.5f" % v for v in ts), t8, tt, float(np.max(np.abs(xd - xs) / np.abs(xs))), float(np.max(np.abs(x8 - xs) / np.abs(xs))),
-        float(np.max(np.abs(xt - xs) / np.abs(xs))), rep["walks"], rep["backward_error"], fa.stats["device_bytes"] * 1e-9,
+        float(np.max(np.abs(xt - xs) / np.abs(xs))), rep["walks"], rep["backward_error"], fa.stats["device_bytes"] * 1e-9, rep["chain_bytes"] * 1e-9, rep["chain_build_ms"], rep["chain_span"],
         hashlib.sha1(xd.tobytes()).hexdigest()[:10]), flush=True)
 
 
