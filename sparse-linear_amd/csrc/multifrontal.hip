@@ -396,7 +396,10 @@ constexpr int kSolveThreads = 1024;  // one workgroup per front, 16 wavefronts f
 template <int NR>
 constexpr int solve_threads() { return (NR >= 16 || NR <= 2) ? 512 : kSolveThreads; }  // ... 8 with 16 columns (256 registers per thread) and with one or two (levels of thousands of small fronts: four workgroups per CU instead of two)
 constexpr int kSolveRowBlocks = 4;   // blocks of 64 rows per workgroup in the lockstep solve steps
-constexpr int kBigSolve = 256;       // fronts above this size are solved by many workgroups, in lockstep
+// fronts above this size are solved by many workgroups, in lockstep (round 5: 256 -> 128 — with the pivot blocks as chains of
+// matrix-vector products the many-workgroup path is the faster one for all but the leaves: 100^3 11.4 -> 10.3 ms per solve,
+// 64^3 4.9 -> 4.1, 40^3 2.45 -> 2.06, complex 100^3 18.6 -> 17.6; 64 gives the same)
+constexpr int kBigSolve = 128;
 
 // The panels of a front as the solves see them.  M is the triangular system a front contributes:
 // M(i, j) = F(i, j), or F(j, i) for the transposed systems, where F(i, j) lives in P for j < np and in
