@@ -332,6 +332,127 @@ __device__ __forceinline__ void chain_lead(const BigFront &b, const chain::View 
   }
 }
 
+// The lead groups with 8 or 16 right-hand-side columns (NR real columns, or NR / 2 complex ones as (re, im) column
+// pairs): the same product, a pair of rows per wavefront at a time, u in LDS one segment of 512 columns at a time as
+// us[column r][t] (a lane reads its two t of a column as one 16-byte word, lanes side by side: no bank conflicts).
+// lead_rows / wavefronts rows per wavefront: one pair on the levels of large fronts, four on the levels of small pivot
+// blocks (whose rows fit one segment, loaded once).
+constexpr int kChainSeg = 512;
+template <int NR, bool Z>
+__device__ __forceinline__ void chain_lead_multi(const BigFront &b, const chain::View &cv, bool fwd, int k, int S, int group,
+                                                 int lead_rows, const double *in, const double *prev, double *out,
+                                                 const SolutionSink &sink, double *us) {
+  constexpr int SWV = solve_waves<NR>();
+  const int n = b.np, K = (n + S - 1) / S;
+  const int j0 = k * S, jbs = min(S, n - j0);
+  const int twf = chain::tw_of(n, S), ldc = chain::ld_of(n, S);
+  const bool hasm = fwd ? k > 0 : k < K - 1;
+  const int jn0 = fwd ? j0 - S : j0 + S, jnb = hasm ? min(S, n - jn0) : 0;
+  const double *C = cv.buf + cv.off[b.f] + (fwd ? 0 : (int64_t)n * ldc) + (int64_t)k * S * ldc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t fs = (size_t)b.fs;
+  const int rpw = lead_rows / SWV;  // rows per wavefront
+  const int nseg = (ldc + kChainSeg - 1) / kChainSeg;
+  // u[seg] -> LDS (all threads)
+  auto stage = [&](int seg) {
+    const int t0 = seg * kChainSeg, ulen = min(kChainSeg, (ldc - t0 + 127) & ~127);  // (whole chunks of the row)
+    for (int o = threadIdx.x; o < ulen * NR; o += SWV * 64) {
+      const int tt = t0 + o % ulen, r = o / ulen;
+      double val = 0.0;
+      if (tt < twf) {
+        if (tt < jbs) val = in[(size_t)r * fs + j0 + tt];
+      } else if (tt - twf < jnb) {
+        val = -prev[(size_t)r * fs + jn0 + tt - twf];
+      }
+      us[r * kChainSeg + (tt - t0)] = val;
+    }
+  };
+  if (nseg == 1) {
+    stage(0);
+    __syncthreads();
+  }
+#pragma unroll 1
+  for (int pr = 0; pr < rpw; pr += 2) {
+    const int il = group * lead_rows + wave * rpw + pr;  // rows il, il + 1 (the same 64 x 64 block row: rpw is even)
+    const bool active = il < jbs, two = il + 1 < jbs;
+    const int tlo = fwd ? 0 : (il & ~63), thi = fwd ? (il & ~63) + 64 : twf;
+    const double *row0 = C + (size_t)(active ? il : 0) * ldc + 2 * lane, *row1 = row0 + (two ? ldc : 0);
+    double acc[2 * NR];
+#pragma unroll
+    for (int o = 0; o < 2 * NR; ++o) acc[o] = 0.0;
+#pragma unroll 1
+    for (int seg = 0; seg < nseg; ++seg) {
+      if (nseg > 1) {
+        __syncthreads();  // (the segment before is done with)
+        stage(seg);
+        __syncthreads();
+      }
+      if (!active) continue;
+#pragma unroll 1
+      for (int q0 = 0; q0 < kChainSeg / 128; q0 += 2) {
+        double2v c0r[2], c1r[2], c0i[2], c1i[2];
+        bool need[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c0 = seg * kChainSeg + 128 * (q0 + j);
+          need[j] = c0 < ldc && ((c0 < thi && c0 + 128 > tlo && c0 < twf) || (hasm && c0 >= twf));
+          if (need[j]) {
+            c0r[j] = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(row0 + c0));
+            c1r[j] = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(row1 + c0));
+            if (Z) {
+              c0i[j] = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(row0 + c0 + cv.plane));
+              c1i[j] = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(row1 + c0 + cv.plane));
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (need[j]) {
+            const double *up = us + 128 * (q0 + j) + 2 * lane;
+            if (!Z) {
+#pragma unroll
+              for (int r = 0; r < NR; ++r) {
+                const double2v u = *reinterpret_cast<const double2v *>(up + r * kChainSeg);
+                acc[r] = __builtin_fma(c0r[j][0], u[0], acc[r]);
+                acc[NR + r] = __builtin_fma(c1r[j][0], u[0], acc[NR + r]);
+                acc[r] = __builtin_fma(c0r[j][1], u[1], acc[r]);
+                acc[NR + r] = __builtin_fma(c1r[j][1], u[1], acc[NR + r]);
+              }
+            } else {
+#pragma unroll
+              for (int q = 0; q < NR / 2; ++q) {
+                const double2v ur = *reinterpret_cast<const double2v *>(up + (2 * q) * kChainSeg);
+                const double2v ui = *reinterpret_cast<const double2v *>(up + (2 * q + 1) * kChainSeg);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                  acc[2 * q] = __builtin_fma(c0r[j][e], ur[e], acc[2 * q]);
+                  acc[2 * q + 1] = __builtin_fma(c0r[j][e], ui[e], acc[2 * q + 1]);
+                  acc[NR + 2 * q] = __builtin_fma(c1r[j][e], ur[e], acc[NR + 2 * q]);
+                  acc[NR + 2 * q + 1] = __builtin_fma(c1r[j][e], ui[e], acc[NR + 2 * q + 1]);
+                  acc[2 * q] = __builtin_fma(-c0i[j][e], ui[e], acc[2 * q]);
+                  acc[2 * q + 1] = __builtin_fma(c0i[j][e], ur[e], acc[2 * q + 1]);
+                  acc[NR + 2 * q] = __builtin_fma(-c1i[j][e], ui[e], acc[NR + 2 * q]);
+                  acc[NR + 2 * q + 1] = __builtin_fma(c1i[j][e], ur[e], acc[NR + 2 * q + 1]);
+                }
+              }
+            }
+          }
+      }
+    }
+    if (!active) continue;
+    wave_reduce_scatter<2 * NR>(acc);
+    if (wave_reduce_owner<2 * NR>(lane)) {
+      const int idx = wave_reduce_index<2 * NR>(lane, 0);
+      const int rowi = idx / NR, r = idx % NR;
+      if (rowi == 0 || two) {
+        const int t = j0 + il + rowi;
+        out[(size_t)r * fs + t] = acc[0];
+        if (sink.x) sink_store<NR, Z>(sink, t, r, acc[0]);
+      }
+    }
+  }
+}
+
 // res-free form of gemv64 for the bulk groups (untransposed systems, one right-hand side): rows [rb, rb + 64) of `in` lose
 // sum_{t < nc} F(i, cb + t) vv[t][:].  Lane = row, the wavefronts split the columns; UB loads in flight per lane (a step's
 // columns, 512 / 16 wavefronts, in one round trip where gemv64 takes four), the old values of `in` requested beside them.
@@ -382,7 +503,7 @@ __global__ __launch_bounds__(solve_waves<NR>() * 64) void big_chain_kernel(const
                                                                            int launch, TreeView t, chain::View cv,
                                                                            double *work, double *zbuf, int row_blocks,
                                                                            int lead_rows, double *x, size_t xstride) {
-  static_assert(MODE <= 1 && NR <= 2, "chains: untransposed systems, one right-hand side");
+  static_assert(MODE <= 1, "chains: untransposed systems");
   extern __shared__ __attribute__((aligned(16))) double dsm[];
   constexpr bool fwd = MODE == 0;
   constexpr int SWV = solve_waves<NR>();
@@ -396,15 +517,20 @@ __global__ __launch_bounds__(solve_waves<NR>() * 64) void big_chain_kernel(const
   double *in = fwd ? b.W : b.Z, *out = fwd ? b.Z : b.W;
   if (b.blk < nlead) {
     const SolutionSink sink{(!fwd && x) ? x + (size_t)(Z ? 2 : 1) * (size_t)t.p0[b.f] : nullptr, xstride};
-    if (lead_rows == chain::rows_wide(Z)) chain_lead<NR, Z, (Z ? 4 : 8)>(b, cv, fwd, fwd ? launch : K - 1 - launch, S, b.blk, in, out, out, sink, dsm);
-    else chain_lead<NR, Z, 2>(b, cv, fwd, fwd ? launch : K - 1 - launch, S, b.blk, in, out, out, sink, dsm);
+    if constexpr (NR > 2) {
+      chain_lead_multi<NR, Z>(b, cv, fwd, fwd ? launch : K - 1 - launch, S, b.blk, lead_rows, in, out, out, sink, dsm);
+    } else {
+      if (lead_rows == chain::rows_wide(Z)) chain_lead<NR, Z, (Z ? 4 : 8)>(b, cv, fwd, fwd ? launch : K - 1 - launch, S, b.blk, in, out, out, sink, dsm);
+      else chain_lead<NR, Z, 2>(b, cv, fwd, fwd ? launch : K - 1 - launch, S, b.blk, in, out, out, sink, dsm);
+    }
     return;
   }
   // bulk of the block solved by the launch before: rows beyond the NEXT block (that one has its update inside M)
   const int kb = fwd ? launch - 1 : K - launch;
   const int j0 = kb * S, jbs = min(S, n - j0), tile = b.blk - nlead;
-  double(*v)[NR] = reinterpret_cast<double(*)[NR]>(dsm);  // [S]
-  double *part = dsm + (size_t)S * NR;                    // [SWV][NR][64]
+  double(*v)[NR] = reinterpret_cast<double(*)[NR]>(dsm);                     // [S]
+  double(*res)[NR] = reinterpret_cast<double(*)[NR]>(dsm + (size_t)S * NR);  // [NB] (8 / 16 columns)
+  double *part = dsm + (size_t)(S + NB) * NR;                                // [SWV][NR][64]
   const Band band{const_cast<double *>(b.P), n, n, n, b.ldp + 1, 0, 0, b.pz};
   const int tid = threadIdx.x;
   const size_t stride = (size_t)b.fs;
@@ -417,6 +543,17 @@ __global__ __launch_bounds__(solve_waves<NR>() * 64) void big_chain_kernel(const
     const int blk = tile * row_blocks + q;
     const int rb = fwd ? j0 + 2 * S + blk * 64 : j0 - S - (blk + 1) * 64;
     if (fwd ? rb >= n : rb + 64 <= 0) break;  // workgroup-uniform
-    chain_bulk_rows<NR, Z, (Z ? 16 : 32)>(band, rb, j0, jbs, v, in, stride, fwd, part);
+    if constexpr (NR <= 2) {
+      chain_bulk_rows<NR, Z, (Z ? 16 : 32)>(band, rb, j0, jbs, v, in, stride, fwd, part);
+    } else {
+      gemv64<MODE, NR, Z>(band, rb, j0, jbs, v, res, part);
+      for (int o = tid; o < 64 * NR; o += SWV * 64) {
+        const int l = o % 64, r = o / 64;
+        const int i = rb + l;
+        const bool ok = fwd ? (i < n) : (i >= 0);
+        if (ok) in[(size_t)r * stride + i] -= res[l][r];
+      }
+      __syncthreads();  // res and part are reused by the next block
+    }
   }
 }

@@ -1076,12 +1076,15 @@ struct Factors {
     // the flat grids of the chain launches: per depth, [pass 0 = forward, 1 = backward][launch 0 .. steps][count + 1]
     struct Level {
       int steps = 0, count = 0;
-      int lead_rows = 0;  // rows of a block per lead workgroup (chain::kRows, or rows_wide() on the levels of small pivot blocks)
+      // rows of a block per lead workgroup: chain::kRows, or rows_wide() on the levels of small pivot blocks; [1]: with 16
+      // right-hand-side columns (workgroups of 8 wavefronts): half of that, and 64
+      int lead_rows[2] = {0, 0};
       size_t base = 0;
     };
     std::vector<Level> levels;
     std::vector<int64_t> h;
     DBuf<int64_t> d;
+    // (pass: 0 forward, 1 backward; + 2 for the grids of 16 columns)
     size_t at(int depth, int pass, int launch) const {
       const Level &L = levels[(size_t)depth];
       return L.base + ((size_t)pass * (size_t)(L.steps + 1) + (size_t)launch) * (size_t)(L.count + 1);
@@ -1832,19 +1835,21 @@ static void build_chain_t(const mf::Factors &F, hipStream_t s) {
     for (int f : large) L.steps = std::max(L.steps, (T.np[(size_t)f] + S - 1) / S);
     int maxnp = 0;
     for (int f : large) maxnp = std::max(maxnp, T.np[(size_t)f]);
-    L.lead_rows = maxnp <= chain::kWidePivots ? chain::rows_wide(Z) : chain::kRows;
+    L.lead_rows[0] = maxnp <= chain::kWidePivots ? chain::rows_wide(Z) : chain::kRows;
+    L.lead_rows[1] = maxnp <= chain::kWidePivots ? 64 : chain::kRows / 2;
     L.base = Cn.h.size();
-    Cn.h.resize(Cn.h.size() + (size_t)2 * (size_t)(L.steps + 1) * (size_t)(L.count + 1), 0);
+    Cn.h.resize(Cn.h.size() + (size_t)4 * (size_t)(L.steps + 1) * (size_t)(L.count + 1), 0);
     const int rbk = F.lp->big[(size_t)d].row_blocks;
-    for (int pass = 0; pass < 2; ++pass)
+    for (int pc = 0; pc < 4; ++pc)
       for (int l = 0; l <= L.steps; ++l) {
-        int64_t *p = Cn.h.data() + Cn.at(d, pass, l);
+        const int pass = pc & 1, lead_rows = L.lead_rows[pc >> 1];
+        int64_t *p = Cn.h.data() + Cn.at(d, pc, l);
         for (int i = 0; i < L.count; ++i) {
           const int np = T.np[(size_t)large[(size_t)i]], K = (np + S - 1) / S;
           int64_t g = 0;
           if (l < K) {  // lead groups of block l of the pass
             const int k = pass == 0 ? l : K - 1 - l;
-            g += (std::min(S, np - k * S) + L.lead_rows - 1) / L.lead_rows;
+            g += (std::min(S, np - k * S) + lead_rows - 1) / lead_rows;
           }
           if (l >= 1 && l - 1 < K) {  // bulk groups of the block before: the rows beyond the next block
             const int kb = pass == 0 ? l - 1 : K - l;
@@ -1914,14 +1919,25 @@ static void launch_big_chain(const mf::Factors &F, int depth, double *work, doub
   const mf::Factors::Chain &Cn = F.chain;
   const mf::Factors::Chain::Level &L = Cn.levels[(size_t)depth];
   const mf::Factors::BigLevel &B = F.lp->big[(size_t)depth];
-  const size_t lds = (size_t)(Cn.span + NB + solve_waves<NR>() * 64) * NR * sizeof(double);
+  constexpr int cls = NR >= 16 ? 1 : 0;  // (workgroups of 8 wavefronts: grids of their own)
+  // LDS: the bulk groups' v, res and partial sums; levels without bulk groups (one block per front): the lead groups' u
+  const size_t lds_bulk = (size_t)(Cn.span + NB + solve_waves<NR>() * 64) * NR * sizeof(double);
+  const size_t lds_lead = NR <= 2 ? (size_t)2 * Cn.span * NR * sizeof(double) : (size_t)kChainSeg * NR * sizeof(double);
+  const size_t lds = L.steps > 1 ? std::max(lds_bulk, lds_lead) : lds_lead;
+  static std::atomic<uint64_t> attr_set{0};  // one mask per instantiation, one bit per device
+  if (first_use_on_this_device(attr_set)) {
+    SPL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&big_chain_kernel<MODE, NR, Z>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)std::min<size_t>(160 * 1024, (size_t)(1024 + NB + solve_waves<NR>() * 64) * NR * sizeof(double))));
+    mark_used_on_this_device(attr_set);
+  }
   const chain::View cv{Cn.buf.get(), Cn.off.get(), (size_t)Cn.elems, Cn.span};
   for (int l = 0; l <= L.steps; ++l) {
-    const size_t at = Cn.at(depth, MODE, l);
+    const size_t at = Cn.at(depth, MODE + 2 * cls, l);
     const unsigned groups = (unsigned)Cn.h[at + (size_t)L.count];
     if (groups > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(big_chain_kernel<MODE, NR, Z>), dim3(groups), dim3(solve_waves<NR>() * 64), lds, s,
-                         B.list.get(), Cn.d.get() + at, B.count, l, F.view, cv, work, zbuf, B.row_blocks, L.lead_rows, x, xstride);
+                         B.list.get(), Cn.d.get() + at, B.count, l, F.view, cv, work, zbuf, B.row_blocks, L.lead_rows[cls], x, xstride);
   }
 }
 
@@ -1992,7 +2008,9 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
   const char *sf = getenv("SPL_MF_SPLIT_FWD"), *pe = getenv("SPL_MF_PIPE");
   const bool split_fwd = !(sf && sf[0] == '0'), pipe_on = !(pe && pe[0] == '0');
   // the pivot blocks as chains of matrix-vector products (mf_chain.hpp): untransposed systems, one right-hand side
-  const bool chain_on = !TRANS && NR <= 2 && split_fwd && pipe_on && F.chain.ok;
+  const char *cm = getenv("SPL_MF_CHAIN_MULTI");  // 0: chains for one right-hand side only (ablation)
+  // (8 / 16 columns: blocks of at most 512 pivots — the bulk groups' LDS)
+  const bool chain_on = !TRANS && split_fwd && pipe_on && F.chain.ok && (NR <= 2 || (F.chain.span <= 512 && !(cm && cm[0] == '0')));
 
   // one level on the way up: children's boundaries into their parents, the one-workgroup fronts, the large ones in lockstep
   auto up_level = [&](const SolveLevel &L, double *scr, hipStream_t q) {
@@ -2014,7 +2032,7 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
       // (pipelined steps with one or two columns only: with 8 or 16 the in-super-block solve is instruction-bound, and the
       // bulk groups' reload of the solved super block costs more than the overlap gains: FEAST 80^3 solve stage 2.95 -> 3.05 s)
       const bool pipe = pipe_on && (TRANS || pivots_only) && NR <= 2;
-      if (chain_on && pivots_only) launch_big_chain<0, (NR <= 2 ? NR : 1), (NR <= 2 ? Z : false)>(F, L.depth, work, zbuf, q);
+      if (chain_on && pivots_only) launch_big_chain<0, NR, Z>(F, L.depth, work, zbuf, q);
       else if (pipe) launch_big_pipe<FWD, NR, Z>(F, B, 13, work, zbuf, cbuf, q);
       else
         for (int k = 0; k < B.steps; ++k) launch_big_super<FWD, NR, Z>(F, B, (TRANS || pivots_only) ? 1 : 0, k, work, zbuf, q, pivots_only ? 1 : 0);
@@ -2070,7 +2088,7 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
       }
       // the pivot block alone; columns of Z / W are fs apart
       // (the solved pivots go to x from inside these steps: round 4 had a scatter launch per level behind them)
-      if (chain_on) launch_big_chain<1, (NR <= 2 ? NR : 1), (NR <= 2 ? Z : false)>(F, L.depth, work, zbuf, q, c, stride);
+      if (chain_on) launch_big_chain<1, NR, Z>(F, L.depth, work, zbuf, q, c, stride);
       else if (pipe_on && NR <= 2) launch_big_pipe<BWD, NR, Z>(F, B, 14, work, zbuf, cbuf, q, c, stride);
       else
         for (int k = 0; k < B.steps; ++k) launch_big_super<BWD, NR, Z>(F, B, 2, k, work, zbuf, q, 0, c, stride);
@@ -2147,7 +2165,7 @@ void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride,
       }
     }
   };
-  if (sys == 0 && k == 1)
+  if (sys == 0)
     std::call_once(F.chain.once, [&] { z ? build_chain_t<true>(F, s) : build_chain_t<false>(F, s); });
   DBuf<double> both(elems);
   run(both.get(), s);
