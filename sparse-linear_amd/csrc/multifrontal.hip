@@ -154,11 +154,26 @@ __global__ __launch_bounds__(256) void rel_kernel(int nfronts, TreeView t, int *
 
 // Tile-to-item lookup of the flat grids below: items [0, count) own the tiles
 // [prefix[i], prefix[i+1]); returns the item of tile `flat` (prefix[0] <= flat < prefix[count]).
+// Round 5: a level of the lower tree lists thousands of fronts, and a plain bisection is 10 - 12 DEPENDENT loads before a
+// workgroup knows which front it works for — a third of the lifetime of the short workgroups of the solves.  Here the 64
+// lanes of a wavefront probe 64 evenly spaced items at once and a ballot picks the bracket: two round trips for up to
+// 4 096 items (every wavefront of the workgroup searches for itself: no barrier).  Called by all lanes, at kernel entry.
 __device__ __forceinline__ int item_of_tile(const int64_t *__restrict__ prefix, int count, int64_t flat) {
-  int lo = 0, hi = count - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (prefix[mid] <= flat) lo = mid; else hi = mid - 1;
+  int lo = 0, hi = count;  // the answer is the largest i in [lo, hi) with prefix[i] <= flat
+  if (count > 16) {
+    const int lane = threadIdx.x & 63;
+    while (hi - lo > 4) {
+      const int step = (hi - lo + 63) >> 6;
+      const int idx = lo + lane * step;
+      const bool ok = idx < hi && prefix[idx] <= flat;  // (monotone over the lanes; lane 0 holds)
+      const int k = __popcll(__ballot(ok)) - 1;
+      lo += (k > 0 ? k : 0) * step;
+      hi = lo + step < hi ? lo + step : hi;
+    }
+  }
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= flat) lo = mid; else hi = mid;
   }
   return lo;
 }
