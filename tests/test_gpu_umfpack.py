@@ -416,13 +416,13 @@ def test_pipelined_steps_and_split_boundary_product_give_the_same_solution(gpu, 
 
 
 @pytest.mark.parametrize("kind", ["symmetric", "unsymmetric", "pivoted", "complex"])
-@pytest.mark.parametrize("span", ["512", "256"])
+@pytest.mark.parametrize("span", ["512", "256", "1024"])
 def test_chains_of_matrix_vector_products_give_the_same_solution(gpu, pkg, O, kind, span, monkeypatch):
     """round 5, csrc/mf_chain.hpp: the pivot blocks of the large fronts as chains of matrix-vector products (explicit
     inverses T_k of blocks of 512 pivots and M_k = T_k L_{k,k-1}, built by the first solve of A x = b on the matrix cores)
     against the substitution steps they replace (SPL_MF_CHAIN=0): the same solution to rounding level, backward errors
     below eps, for L D L^T fronts, plain LU fronts, fronts with interchanges inside their 64 x 64 blocks and native
-    complex fronts; blocks of 256 pivots as well.  A 3-D mesh whose root front has 1 296 pivots (three blocks, the last
+    complex fronts; blocks of 256 and of 1 024 pivots as well.  A 3-D mesh whose root front has 1 296 pivots (three blocks, the last
     one partial) above levels of fronts with one block; the report says what the chains take."""
     import scipy.sparse as sp
     monkeypatch.setenv("SPL_LU_METHOD", "mf")
@@ -471,6 +471,52 @@ def test_chains_of_matrix_vector_products_give_the_same_solution(gpu, pkg, O, ki
     xt0 = U.linearSolve_(f0, U.UmfpackTrans, A, bt)
     xt1 = U.linearSolve_(f1, U.UmfpackTrans, A, bt)
     assert np.max(np.abs(xt1 - xt0)) <= 1e-12 * np.max(np.abs(xt0))
+
+
+@pytest.mark.parametrize("kind", ["symmetric", "unsymmetric", "complex"])
+def test_chains_with_eight_and_sixteen_columns_give_the_same_solutions(gpu, pkg, O, kind, monkeypatch):
+    """round 5, chain_lead_multi (csrc/mf_chain.hpp): batched solves take 8 real columns (16 for 8 complex ones) through
+    the tree together; their pivot-block steps are the same matrix-vector products with u staged through LDS a segment
+    of 512 columns at a time.  SPL_MF_CHAIN_MULTI=0 keeps the substitution steps for them (the chains then serve single
+    right-hand sides only): the same solutions to rounding level, column by column, backward errors below eps; 11
+    columns (two groups, the second padded); host and device right-hand sides."""
+    import scipy.sparse as sp
+    import torch
+    monkeypatch.setenv("SPL_LU_METHOD", "mf")
+    m = 36
+    n, A = _grid_matrix(pkg, O, "3d", m)
+    rng = np.random.default_rng(13)
+    S = csc_tuple_to_scipy(mat_to_tuple(A))
+    if kind == "unsymmetric":
+        S0 = S.tocoo()
+        v = S0.data * rng.uniform(0.8, 1.2, S0.nnz)
+        v[S0.row == S0.col] = 7.0
+        S = sp.csc_matrix((v, (S0.row, S0.col)), shape=S0.shape)
+    elif kind == "complex":
+        monkeypatch.setenv("SPL_ZI_NATIVE", "1")
+        S = sp.csc_matrix((3.0 + 0.5j) * sp.identity(n) - S)
+    S.sort_indices()
+    A = pkg.Matrix(n, n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
+    U = pkg.umfpack
+    k = 11
+    xs = [rng.uniform(0.5, 1.5, n) + (1j * rng.uniform(-1, 1, n) if kind == "complex" else 0.0) for _ in range(k)]
+    bs = [np.asarray(S @ x).ravel() for x in xs]
+    an = U.analyze(A)
+    monkeypatch.setenv("SPL_MF_CHAIN_MULTI", "0")
+    f0 = U.factor(A, an)
+    X0 = U.linearSolveMany_(f0, U.UmfpackNormal, A, bs)
+    assert f0.solve_report["chain_span"] == 512 and f0.solve_report["backward_error"] <= 2.3e-16
+    monkeypatch.delenv("SPL_MF_CHAIN_MULTI")
+    f1 = U.factor(A, an)
+    X1 = U.linearSolveMany_(f1, U.UmfpackNormal, A, bs)
+    assert f1.solve_report["chain_span"] == 512 and f1.solve_report["backward_error"] <= 2.3e-16
+    Xd = U.linearSolveManyDevice_(f1, U.UmfpackNormal, A, torch.from_numpy(np.stack(bs)).cuda()).cpu().numpy()
+    one = U.linearSolve_(f1, U.UmfpackNormal, A, bs[3])
+    for j in range(k):
+        assert np.max(np.abs(X1[j] - X0[j])) <= 1e-12 * np.max(np.abs(X0[j]))
+        assert np.max(np.abs(X1[j] - xs[j]) / np.abs(xs[j])) < 1e-10
+        assert np.array_equal(Xd[j], X1[j])
+    assert np.max(np.abs(one - X1[3])) <= 1e-12 * np.max(np.abs(one))
 
 
 @pytest.mark.parametrize("unsym", [False, True])
