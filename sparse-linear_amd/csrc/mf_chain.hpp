@@ -19,7 +19,7 @@
 //
 // Numerics: an explicit inverse of a 512 x 512 triangular block of a front factored without interchanges (or with
 // interchanges inside its 64 x 64 blocks) — the entries are checked when they are built: a chain with an entry beyond
-// kChainLimit (or not finite) is dropped and the walk keeps its substitution steps (solve_super_pipelined).  The solves
+// chain::kLimit (or not finite) is dropped and the walk keeps its substitution steps (solve_super_pipelined).  The solves
 // are followed by the residual check of umfpack_*_solve either way.
 //
 // Only the untransposed systems (L z = c, U x = z) have chains: A^T x = b keeps the substitution steps.

@@ -1083,7 +1083,7 @@ struct Factors {
   // beyond chain::kLimit) — the walk then keeps its substitution steps
   struct Chain {
     std::once_flag once;
-    bool ok = false;
+    std::atomic<bool> ok{false};  // (written once, under `once`; read by any thread: the solves, mf_chain_info)
     int span = 0;
     int64_t elems = 0;      // doubles of one plane
     DBuf<double> buf;
@@ -1143,7 +1143,7 @@ void mf_free(mf::Factors *F) { delete F; }
 int mf_singular(const mf::Factors *F) { return F->singular; }
 
 void mf_chain_info(const mf::Factors *F, double out[3]) {
-  const bool ok = F->chain.ok;
+  const bool ok = F->chain.ok.load(std::memory_order_acquire);
   out[0] = ok ? (double)F->zm * (double)F->chain.elems * 8.0 : 0.0;
   out[1] = ok ? F->chain.build_ms : 0.0;
   out[2] = ok ? (double)F->chain.span : 0.0;
@@ -1922,7 +1922,7 @@ static void build_chain_t(const mf::Factors &F, hipStream_t s) {
   Cn.span = S;
   Cn.elems = elems;
   Cn.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  Cn.ok = true;
+  Cn.ok.store(true, std::memory_order_release);
   if (getenv("SPL_MF_TIMING"))
     fprintf(stderr, "[mf_solve] chains: span %d, %zu blocks, %.2f GB, built in %.2f ms\n", S, item_f.size(),
             (Z ? 2 : 1) * elems * 8e-9, Cn.build_ms);
