@@ -264,7 +264,7 @@ __device__ __forceinline__ void chain_mac(const ChainRegs<Z, RW, QN> &g, int q0,
 // travel together.  RW = 2: rows of up to 2 S entries in batches of eight chunks (complex: four); RW = 8: the levels
 // (complex: 4) whose fronts have at most 256 pivots (thousands of fronts, rows of at most two chunks) — a quarter of
 // the workgroups.
-template <int NR, bool Z, int RW>
+template <int NR, bool Z, int RW, int QB = (Z ? 8 : 16) / RW, int PASSES = 1>
 __device__ __forceinline__ void chain_lead(const BigFront &b, const chain::View &cv, bool fwd, int k, int S, int group,
                                            const double *in, const double *prev, double *out, const SolutionSink &sink,
                                            double *us) {
@@ -277,19 +277,22 @@ __device__ __forceinline__ void chain_lead(const BigFront &b, const chain::View 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t fs = (size_t)b.fs;
   const int S2 = 2 * S;
-  const int il = (group * (int)(blockDim.x >> 6) + wave) * RW;  // this wavefront's rows: il .. il + RW - 1
-  const bool active = il < jbs;
+  // this wavefront's rows: RW at a time, PASSES times (QB: chunks per batch — by default 32 double-pairs of entries in
+  // flight per lane; the kernel of the levels of small pivot blocks takes fewer at a time to halve its registers)
+  const int il0 = (group * (int)(blockDim.x >> 6) + wave) * RW * PASSES;
   ChainRow w;
-  w.base = C + (size_t)(active ? il : 0) * ldc;
-  w.rmax = active ? min(RW - 1, jbs - 1 - il) : 0;
   w.plane = cv.plane;
   w.ldc = ldc;
-  w.tlo = fwd ? 0 : (il & ~63);
-  w.thi = fwd ? (il & ~63) + 64 : twf;
   w.twf = twf;
   w.hasm = hasm;
-  w.active = active;
-  constexpr int QB = (Z ? 8 : 16) / RW;  // chunks per batch (32 double-pairs of entries in flight per lane)
+  auto rows_of = [&](int il) {
+    w.active = il < jbs;
+    w.base = C + (size_t)(w.active ? il : 0) * ldc;
+    w.rmax = w.active ? min(RW - 1, jbs - 1 - il) : 0;
+    w.tlo = fwd ? 0 : (il & ~63);
+    w.thi = fwd ? (il & ~63) + 64 : twf;
+  };
+  rows_of(il0);
   ChainRegs<Z, RW, QB> g;
   chain_load<Z, RW, QB>(w, 0, g);
   // u = [a_k ; -z of the block before] in LDS
@@ -309,25 +312,33 @@ __device__ __forceinline__ void chain_lead(const BigFront &b, const chain::View 
     if (Z) us[S2 + tt] = im;
   }
   __syncthreads();
-  if (!active) return;
-  constexpr int NV = (Z ? 2 : 1) * RW;
-  double acc[NV];
-#pragma unroll
-  for (int o = 0; o < NV; ++o) acc[o] = 0.0;
-  chain_mac<Z, RW, QB>(g, 0, us, S2, acc);
 #pragma unroll 1
-  for (int q0 = QB; 128 * q0 < ldc; q0 += QB) {
-    chain_load<Z, RW, QB>(w, q0, g);
-    chain_mac<Z, RW, QB>(g, q0, us, S2, acc);
-  }
-  wave_reduce_scatter<NV>(acc);
-  if (wave_reduce_owner<NV>(lane)) {
-    const int idx = wave_reduce_index<NV>(lane, 0);
-    const int rowi = Z ? idx >> 1 : idx, part = Z ? idx & 1 : 0;
-    if (il + rowi < jbs) {
-      const int t = j0 + il + rowi;
-      out[(size_t)part * fs + t] = acc[0];
-      if (sink.x) sink_store<NR, Z>(sink, t, part, acc[0]);
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int il = il0 + ps * RW;
+    if (ps > 0) {
+      rows_of(il);
+      chain_load<Z, RW, QB>(w, 0, g);
+    }
+    if (!w.active) return;  // (wavefront-uniform; the rows of the later passes lie further down)
+    constexpr int NV = (Z ? 2 : 1) * RW;
+    double acc[NV];
+#pragma unroll
+    for (int o = 0; o < NV; ++o) acc[o] = 0.0;
+    chain_mac<Z, RW, QB>(g, 0, us, S2, acc);
+#pragma unroll 1
+    for (int q0 = QB; 128 * q0 < ldc; q0 += QB) {
+      chain_load<Z, RW, QB>(w, q0, g);
+      chain_mac<Z, RW, QB>(g, q0, us, S2, acc);
+    }
+    wave_reduce_scatter<NV>(acc);
+    if (wave_reduce_owner<NV>(lane)) {
+      const int idx = wave_reduce_index<NV>(lane, 0);
+      const int rowi = Z ? idx >> 1 : idx, part = Z ? idx & 1 : 0;
+      if (il + rowi < jbs) {
+        const int t = j0 + il + rowi;
+        out[(size_t)part * fs + t] = acc[0];
+        if (sink.x) sink_store<NR, Z>(sink, t, part, acc[0]);
+      }
     }
   }
 }
@@ -520,8 +531,7 @@ __global__ __launch_bounds__(solve_waves<NR>() * 64) void big_chain_kernel(const
     if constexpr (NR > 2) {
       chain_lead_multi<NR, Z>(b, cv, fwd, fwd ? launch : K - 1 - launch, S, b.blk, lead_rows, in, out, out, sink, dsm);
     } else {
-      if (lead_rows == chain::rows_wide(Z)) chain_lead<NR, Z, (Z ? 4 : 8)>(b, cv, fwd, fwd ? launch : K - 1 - launch, S, b.blk, in, out, out, sink, dsm);
-      else chain_lead<NR, Z, 2>(b, cv, fwd, fwd ? launch : K - 1 - launch, S, b.blk, in, out, out, sink, dsm);
+      chain_lead<NR, Z, 2>(b, cv, fwd, fwd ? launch : K - 1 - launch, S, b.blk, in, out, out, sink, dsm);  // (wide levels: big_chain_wide_kernel)
     }
     return;
   }
@@ -556,4 +566,23 @@ __global__ __launch_bounds__(solve_waves<NR>() * 64) void big_chain_kernel(const
       __syncthreads();  // res and part are reused by the next block
     }
   }
+}
+
+// The levels whose fronts all have at most chain::kWidePivots pivots (one block per front, no bulk groups; thousands of
+// fronts): the lead groups alone, 8 rows per wavefront (complex: 4) in two passes, one chunk of a row in flight per row —
+// half the registers of big_chain_kernel, so that TWO workgroups share a CU: these workgroups live 7 us for 40 - 90 KB each,
+// and how many of them a CU holds is what the launch takes.
+template <int MODE, int NR, bool Z = false>
+__global__ __launch_bounds__(solve_waves<NR>() * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void big_chain_wide_kernel(const int *__restrict__ list,
+                                                                                   const int64_t *__restrict__ prefix,
+                                                                                   int count, TreeView t, chain::View cv,
+                                                                                   double *work, double *zbuf, double *x,
+                                                                                   size_t xstride) {
+  static_assert(MODE <= 1 && NR <= 2, "one right-hand side; the others: chain_lead_multi");
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  constexpr bool fwd = MODE == 0;
+  const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
+  double *in = fwd ? b.W : b.Z, *out = fwd ? b.Z : b.W;
+  const SolutionSink sink{(!fwd && x) ? x + (size_t)(Z ? 2 : 1) * (size_t)t.p0[b.f] : nullptr, xstride};
+  chain_lead<NR, Z, (Z ? 2 : 4), 1, 2>(b, cv, fwd, 0, cv.span, b.blk, in, out, out, sink, dsm);
 }

@@ -1947,6 +1947,16 @@ static void launch_big_chain(const mf::Factors &F, int depth, double *work, doub
     mark_used_on_this_device(attr_set);
   }
   const chain::View cv{Cn.buf.get(), Cn.off.get(), (size_t)Cn.elems, Cn.span};
+  if constexpr (NR <= 2) {
+    if (L.lead_rows[0] == chain::rows_wide(Z)) {  // a level of small pivot blocks: one launch of lead groups, two workgroups per CU
+      const size_t at = Cn.at(depth, MODE, 0);
+      const unsigned groups = (unsigned)Cn.h[at + (size_t)L.count];
+      if (groups > 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(big_chain_wide_kernel<MODE, NR, Z>), dim3(groups), dim3(solve_waves<NR>() * 64), lds_lead, s,
+                           B.list.get(), Cn.d.get() + at, B.count, F.view, cv, work, zbuf, x, xstride);
+      return;
+    }
+  }
   for (int l = 0; l <= L.steps; ++l) {
     const size_t at = Cn.at(depth, MODE + 2 * cls, l);
     const unsigned groups = (unsigned)Cn.h[at + (size_t)L.count];
