@@ -164,7 +164,8 @@ int spl_umfpack_stats(void *Numeric, double out[8]);
  * substitution: the first solve plus one per refinement step attempted), out[1] refinement steps kept, out[2]
  * attempted, out[3] largest componentwise backward error max_i |r_i| / (|A||x| + |b|)_i among the delivered columns,
  * out[4] bytes ONE walk reads: 8 per stored entry of L and U (dense panels, no index arrays) + 16 n for the vectors.
- * out[5 .. 7]: the chain matrices a multifrontal object builds at its first solve of A x = b with one right-hand side
+ * out[5 .. 7]: the chain matrices a multifrontal object builds at its first solve of A x = b (and, for unsymmetric
+ * factorisations, a second set at its first solve of A^T x = b)
  * (explicit inverses of 512 x 512 blocks of the large fronts' pivot blocks, so that a step of the triangular passes is one
  * matrix-vector product): bytes of device memory, milliseconds their construction took, pivots per block (0: none).
  * Returns 0, or -1 if the object is invalid. */

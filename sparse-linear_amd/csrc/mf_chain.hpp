@@ -22,7 +22,8 @@
 // chain::kLimit (or not finite) is dropped and the walk keeps its substitution steps (solve_super_pipelined).  The solves
 // are followed by the residual check of umfpack_*_solve either way.
 //
-// Only the untransposed systems (L z = c, U x = z) have chains: A^T x = b keeps the substitution steps.
+// The transposed systems (U^H z = c, L^H x = z) have chains of their own, from the same construction on G = U^H, L^H
+// (chain_build_kernel<Z, true>), built by the first solve of A^T x = b: as much memory again, only for callers who solve both.
 #pragma once
 
 namespace chain {
@@ -54,7 +55,7 @@ __host__ __device__ __forceinline__ int ld_of(int np, int S) { return tw_of(np, 
 // every sub-block: four 16 x 16 accumulators (v_mfma_f64_16x16x4: lane l supplies A[l % 16][k0 + l / 16] and
 // B[k0 + l / 16][l % 16], holds C[l / 16 + 4 r][l % 16] in element r).
 // items: (front, block k, factor) triples; prefix: column tiles before each item.
-template <bool Z>
+template <bool Z, bool TR = false>
 __global__ __launch_bounds__(256) void chain_build_kernel(const int *__restrict__ item_f, const int *__restrict__ item_k,
                                                           const int64_t *__restrict__ prefix, int count, TreeView t,
                                                           const double *__restrict__ invs, chain::View cv,
@@ -76,7 +77,9 @@ __global__ __launch_bounds__(256) void chain_build_kernel(const int *__restrict_
   const size_t pz = Z ? (size_t)ldp * (size_t)np : 0;
   double *C = cv.buf + cv.off[f] + (up ? (int64_t)np * ldc : 0) + (int64_t)k * S * ldc;
   constexpr size_t iblk = Z ? (size_t)kInvBlockZ : (size_t)(2 * NB * NB);
-  const double *inv = invs + (Z ? 2 : 1) * t.ioff[f] + (size_t)(j0 / NB) * iblk + (up ? iblk / 2 : 0);
+  // TR: the chains of the TRANSPOSED systems (U^H z = c forward, L^H x = z backward): the same substitution with
+  // G = U^H (lower) resp. L^H (unit upper) — entries G(i, j) = conj(F(j, i)), diagonal blocks' inverses transposed
+  const double *inv = invs + (Z ? 2 : 1) * t.ioff[f] + (size_t)(j0 / NB) * iblk + ((up != 0) != TR ? iblk / 2 : 0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
   // T part: column tile ct of the identity — sub-blocks before (L) / after (U) its diagonal one are zero
   const int s_first = mpart ? (up ? nsub - 1 : 0) : tile;
@@ -98,8 +101,9 @@ __global__ __launch_bounds__(256) void chain_build_kernel(const int *__restrict_
         } else {
           const int gr = r0 + row, gc = jn0 + col;
           if (gr < np && gc < np) {
-            re = P[(size_t)gr + (size_t)gc * ldp];
-            if (Z) im = P[(size_t)gr + (size_t)gc * ldp + pz];
+            const size_t at = TR ? (size_t)gc + (size_t)gr * ldp : (size_t)gr + (size_t)gc * ldp;
+            re = P[at];
+            if (Z) im = TR ? -P[at + pz] : P[at + pz];
           }
         }
         acc[nt][r] = re;
@@ -115,10 +119,10 @@ __global__ __launch_bounds__(256) void chain_build_kernel(const int *__restrict_
       for (int k0 = 0; k0 < 64; k0 += 4) {
         const int gr = r0 + 16 * wave + li, gc = c0 + k0 + kq;
         const bool in = gr < np && gc < np;
-        const double *pa = in ? P + (size_t)gr + (size_t)gc * ldp : P;
+        const double *pa = in ? P + (TR ? (size_t)gc + (size_t)gr * ldp : (size_t)gr + (size_t)gc * ldp) : P;
         double a = *pa, ai = Z ? pa[pz] : 0.0;
         a = in ? -a : 0.0;
-        ai = in ? -ai : 0.0;
+        ai = in ? (TR ? ai : -ai) : 0.0;  // (minus the coupling; TR: of its conjugate)
         const int xr = 64 * tt + k0 + kq;
         const bool xin = xr < jbs;
         const double *px = C + (size_t)(xin ? xr : 0) * ldc + colbase + li;
@@ -156,9 +160,10 @@ __global__ __launch_bounds__(256) void chain_build_kernel(const int *__restrict_
 #pragma unroll 4
     for (int k0 = 0; k0 < 64; k0 += 4) {
       const int kc = k0 + kq;
-      double a = ig[(16 * wave + li) + kc * NB], ai = Z ? ig[NB * NB + (16 * wave + li) + kc * NB] : 0.0;
+      const int ia = TR ? kc + (16 * wave + li) * NB : (16 * wave + li) + kc * NB;
+      double a = ig[ia], ai = Z ? ig[NB * NB + ia] : 0.0;
       a = kc < jb ? a : 0.0;
-      ai = kc < jb ? ai : 0.0;
+      ai = kc < jb ? (TR ? -ai : ai) : 0.0;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const double b = Xs[0][kc][nt * 16 + li], bi = Z ? Xs[Z ? 1 : 0][kc][nt * 16 + li] : 0.0;
@@ -514,9 +519,8 @@ __global__ __launch_bounds__(solve_waves<NR>() * 64) void big_chain_kernel(const
                                                                            int launch, TreeView t, chain::View cv,
                                                                            double *work, double *zbuf, int row_blocks,
                                                                            int lead_rows, double *x, size_t xstride) {
-  static_assert(MODE <= 1, "chains: untransposed systems");
   extern __shared__ __attribute__((aligned(16))) double dsm[];
-  constexpr bool fwd = MODE == 0;
+  constexpr bool fwd = MODE == 0 || MODE == 2;  // (MODE 2, 3: the transposed systems, cv = their chains)
   constexpr int SWV = solve_waves<NR>();
   const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
   const int S = cv.span, n = b.np, K = (n + S - 1) / S;
@@ -553,17 +557,21 @@ __global__ __launch_bounds__(solve_waves<NR>() * 64) void big_chain_kernel(const
     const int blk = tile * row_blocks + q;
     const int rb = fwd ? j0 + 2 * S + blk * 64 : j0 - S - (blk + 1) * 64;
     if (fwd ? rb >= n : rb + 64 <= 0) break;  // workgroup-uniform
-    if constexpr (NR <= 2) {
+    if constexpr (NR <= 2 && MODE <= 1) {
       chain_bulk_rows<NR, Z, (Z ? 16 : 32)>(band, rb, j0, jbs, v, in, stride, fwd, part);
     } else {
-      gemv64<MODE, NR, Z>(band, rb, j0, jbs, v, res, part);
-      for (int o = tid; o < 64 * NR; o += SWV * 64) {
-        const int l = o % 64, r = o / 64;
-        const int i = rb + l;
-        const bool ok = fwd ? (i < n) : (i >= 0);
-        if (ok) in[(size_t)r * stride + i] -= res[l][r];
+      // (the transposed products of gemv64 take at most SB * NB = 256 columns at a time with fewer than 16 columns of right-hand sides)
+      constexpr int kMost = (MODE >= 2 && !tile_rows_on_lanes<NR>()) ? SB * NB : 1 << 30;
+      for (int c0 = 0; c0 < jbs; c0 += kMost) {
+        gemv64<MODE, NR, Z>(band, rb, j0 + c0, min(kMost, jbs - c0), v + c0, res, part);
+        for (int o = tid; o < 64 * NR; o += SWV * 64) {
+          const int l = o % 64, r = o / 64;
+          const int i = rb + l;
+          const bool ok = fwd ? (i < n) : (i >= 0);
+          if (ok) in[(size_t)r * stride + i] -= res[l][r];
+        }
+        __syncthreads();  // res and part are reused by the next block
       }
-      __syncthreads();  // res and part are reused by the next block
     }
   }
 }
@@ -578,9 +586,9 @@ __global__ __launch_bounds__(solve_waves<NR>() * 64) __attribute__((amdgpu_waves
                                                                                    int count, TreeView t, chain::View cv,
                                                                                    double *work, double *zbuf, double *x,
                                                                                    size_t xstride) {
-  static_assert(MODE <= 1 && NR <= 2, "one right-hand side; the others: chain_lead_multi");
+  static_assert(NR <= 2, "one right-hand side; the others: chain_lead_multi");
   extern __shared__ __attribute__((aligned(16))) double dsm[];
-  constexpr bool fwd = MODE == 0;
+  constexpr bool fwd = MODE == 0 || MODE == 2;
   const BigFront b = big_front<NR>(list, prefix, count, t, work, zbuf);
   double *in = fwd ? b.W : b.Z, *out = fwd ? b.Z : b.W;
   const SolutionSink sink{(!fwd && x) ? x + (size_t)(Z ? 2 : 1) * (size_t)t.p0[b.f] : nullptr, xstride};

@@ -1106,7 +1106,7 @@ struct Factors {
     }
     double build_ms = 0.0;
   };
-  mutable Chain chain;
+  mutable Chain chain, chain_t;  // A x = b; A^T x = b (A^H for complex fronts)
   // independent large fronts of a level run on these (factorisation): one set per device and host
   // thread, created on first use and never destroyed (objects come and go by the thousand in a
   // contour integration; work of different objects on the same stream is merely ordered)
@@ -1143,10 +1143,13 @@ void mf_free(mf::Factors *F) { delete F; }
 int mf_singular(const mf::Factors *F) { return F->singular; }
 
 void mf_chain_info(const mf::Factors *F, double out[3]) {
-  const bool ok = F->chain.ok.load(std::memory_order_acquire);
-  out[0] = ok ? (double)F->zm * (double)F->chain.elems * 8.0 : 0.0;
-  out[1] = ok ? F->chain.build_ms : 0.0;
-  out[2] = ok ? (double)F->chain.span : 0.0;
+  out[0] = out[1] = out[2] = 0.0;
+  for (const mf::Factors::Chain *c : {&F->chain, &F->chain_t})  // (both sets, where both systems have been solved)
+    if (c->ok.load(std::memory_order_acquire)) {
+      out[0] += (double)F->zm * (double)c->elems * 8.0;
+      out[1] += c->build_ms;
+      out[2] = (double)c->span;
+    }
 }
 
 namespace {
@@ -1822,9 +1825,9 @@ static void launch_big_pipe(const mf::Factors &F, const mf::Factors::BigLevel &B
 }
 
 // ---- chains (mf_chain.hpp): built once per factorisation, by its first untransposed solve with one right-hand side
-template <bool Z>
+template <bool Z, bool TR>
 static void build_chain_t(const mf::Factors &F, hipStream_t s) {
-  mf::Factors::Chain &Cn = F.chain;
+  mf::Factors::Chain &Cn = TR ? F.chain_t : F.chain;
   const mf::Tree &T = *F.tree;
   int S = 512;
   if (const char *e = getenv("SPL_MF_CHAIN")) {  // 0: none (ablation); 256: shorter blocks
@@ -1904,7 +1907,7 @@ static void build_chain_t(const mf::Factors &F, hipStream_t s) {
     upload_vec(d_pre, pre, s);
     SPL_HIP(hipMemsetAsync(bad.get(), 0, sizeof(int), s));
     const chain::View cv{Cn.buf.get(), Cn.off.get(), (size_t)elems, S};
-    hipLaunchKernelGGL(chain_build_kernel<Z>, dim3((unsigned)pre.back()), dim3(256), 0, s, d_f.get(), d_k.get(), d_pre.get(),
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(chain_build_kernel<Z, TR>), dim3((unsigned)pre.back()), dim3(256), 0, s, d_f.get(), d_k.get(), d_pre.get(),
                        (int)item_f.size(), F.view, F.invs.get(), cv, bad.get());
     int hbad = 0;
     SPL_HIP(hipMemcpyAsync(&hbad, bad.get(), sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1924,14 +1927,14 @@ static void build_chain_t(const mf::Factors &F, hipStream_t s) {
   Cn.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   Cn.ok.store(true, std::memory_order_release);
   if (getenv("SPL_MF_TIMING"))
-    fprintf(stderr, "[mf_solve] chains: span %d, %zu blocks, %.2f GB, built in %.2f ms\n", S, item_f.size(),
+    fprintf(stderr, "[mf_solve] chains%s: span %d, %zu blocks, %.2f GB, built in %.2f ms\n", TR ? " (transposed systems)" : "", S, item_f.size(),
             (Z ? 2 : 1) * elems * 8e-9, Cn.build_ms);
 }
 
 template <int MODE, int NR, bool Z = false>
 static void launch_big_chain(const mf::Factors &F, int depth, double *work, double *zbuf, hipStream_t s, double *x = nullptr,
                              size_t xstride = 0) {
-  const mf::Factors::Chain &Cn = F.chain;
+  const mf::Factors::Chain &Cn = MODE >= 2 ? F.chain_t : F.chain;
   const mf::Factors::Chain::Level &L = Cn.levels[(size_t)depth];
   const mf::Factors::BigLevel &B = F.lp->big[(size_t)depth];
   constexpr int cls = NR >= 16 ? 1 : 0;  // (workgroups of 8 wavefronts: grids of their own)
@@ -1949,7 +1952,7 @@ static void launch_big_chain(const mf::Factors &F, int depth, double *work, doub
   const chain::View cv{Cn.buf.get(), Cn.off.get(), (size_t)Cn.elems, Cn.span};
   if constexpr (NR <= 2) {
     if (L.lead_rows[0] == chain::rows_wide(Z)) {  // a level of small pivot blocks: one launch of lead groups, two workgroups per CU
-      const size_t at = Cn.at(depth, MODE, 0);
+      const size_t at = Cn.at(depth, MODE & 1, 0);
       const unsigned groups = (unsigned)Cn.h[at + (size_t)L.count];
       if (groups > 0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(big_chain_wide_kernel<MODE, NR, Z>), dim3(groups), dim3(solve_waves<NR>() * 64), lds_lead, s,
@@ -1958,7 +1961,7 @@ static void launch_big_chain(const mf::Factors &F, int depth, double *work, doub
     }
   }
   for (int l = 0; l <= L.steps; ++l) {
-    const size_t at = Cn.at(depth, MODE + 2 * cls, l);
+    const size_t at = Cn.at(depth, (MODE & 1) + 2 * cls, l);
     const unsigned groups = (unsigned)Cn.h[at + (size_t)L.count];
     if (groups > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(big_chain_kernel<MODE, NR, Z>), dim3(groups), dim3(solve_waves<NR>() * 64), lds, s,
@@ -2032,10 +2035,11 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
   // launch per step with the whole chain in it: ablations, read once per walk)
   const char *sf = getenv("SPL_MF_SPLIT_FWD"), *pe = getenv("SPL_MF_PIPE");
   const bool split_fwd = !(sf && sf[0] == '0'), pipe_on = !(pe && pe[0] == '0');
-  // the pivot blocks as chains of matrix-vector products (mf_chain.hpp): untransposed systems, one right-hand side
+  // the pivot blocks as chains of matrix-vector products (mf_chain.hpp); the transposed systems have a set of their own
   const char *cm = getenv("SPL_MF_CHAIN_MULTI");  // 0: chains for one right-hand side only (ablation)
   // (8 / 16 columns: blocks of at most 512 pivots — the bulk groups' LDS)
-  const bool chain_on = !TRANS && split_fwd && pipe_on && F.chain.ok && (NR <= 2 || (F.chain.span <= 512 && !(cm && cm[0] == '0')));
+  const mf::Factors::Chain &Ch = TRANS ? F.chain_t : F.chain;
+  const bool chain_on = (TRANS || split_fwd) && pipe_on && Ch.ok && (NR <= 2 || (Ch.span <= 512 && !(cm && cm[0] == '0')));
 
   // one level on the way up: children's boundaries into their parents, the one-workgroup fronts, the large ones in lockstep
   auto up_level = [&](const SolveLevel &L, double *scr, hipStream_t q) {
@@ -2057,7 +2061,7 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
       // (pipelined steps with one or two columns only: with 8 or 16 the in-super-block solve is instruction-bound, and the
       // bulk groups' reload of the solved super block costs more than the overlap gains: FEAST 80^3 solve stage 2.95 -> 3.05 s)
       const bool pipe = pipe_on && (TRANS || pivots_only) && NR <= 2;
-      if (chain_on && pivots_only) launch_big_chain<0, NR, Z>(F, L.depth, work, zbuf, q);
+      if (chain_on && (TRANS || pivots_only)) launch_big_chain<FWD, NR, Z>(F, L.depth, work, zbuf, q);
       else if (pipe) launch_big_pipe<FWD, NR, Z>(F, B, 13, work, zbuf, cbuf, q);
       else
         for (int k = 0; k < B.steps; ++k) launch_big_super<FWD, NR, Z>(F, B, (TRANS || pivots_only) ? 1 : 0, k, work, zbuf, q, pivots_only ? 1 : 0);
@@ -2113,7 +2117,7 @@ static void solve_columns_on_tree(const mf::Factors &F, double *c, size_t stride
       }
       // the pivot block alone; columns of Z / W are fs apart
       // (the solved pivots go to x from inside these steps: round 4 had a scatter launch per level behind them)
-      if (chain_on) launch_big_chain<1, NR, Z>(F, L.depth, work, zbuf, q, c, stride);
+      if (chain_on) launch_big_chain<BWD, NR, Z>(F, L.depth, work, zbuf, q, c, stride);
       else if (pipe_on && NR <= 2) launch_big_pipe<BWD, NR, Z>(F, B, 14, work, zbuf, cbuf, q, c, stride);
       else
         for (int k = 0; k < B.steps; ++k) launch_big_super<BWD, NR, Z>(F, B, 2, k, work, zbuf, q, 0, c, stride);
@@ -2190,8 +2194,8 @@ void mf_solve(const mf::Factors *Fp, int sys, double *d_c, int k, size_t stride,
       }
     }
   };
-  if (sys == 0)
-    std::call_once(F.chain.once, [&] { z ? build_chain_t<true>(F, s) : build_chain_t<false>(F, s); });
+  if (sys == 0) std::call_once(F.chain.once, [&] { z ? build_chain_t<true, false>(F, s) : build_chain_t<false, false>(F, s); });
+  else std::call_once(F.chain_t.once, [&] { z ? build_chain_t<true, true>(F, s) : build_chain_t<false, true>(F, s); });
   DBuf<double> both(elems);
   run(both.get(), s);
   SPL_HIP(hipStreamSynchronize(s));  // the work matrices are freed on return

@@ -450,6 +450,10 @@ def test_chains_of_matrix_vector_products_give_the_same_solution(gpu, pkg, O, ki
     x0 = U.linearSolve_(f0, U.UmfpackNormal, A, b)
     r0 = f0.solve_report
     assert f0.path in (3, 4) and r0["chain_span"] == 0 and r0["chain_bytes"] == 0
+    St = sp.csc_matrix(S.conj().T)
+    bt = np.asarray(St @ xs).ravel()
+    xt0 = U.linearSolve_(f0, U.UmfpackTrans, A, bt)  # (the switch is read when a set of chains would be built)
+    assert f0.solve_report["chain_bytes"] == 0
     monkeypatch.setenv("SPL_MF_CHAIN", span)
     f1 = U.factor(A, an)
     x1 = U.linearSolve_(f1, U.UmfpackNormal, A, b)
@@ -463,14 +467,17 @@ def test_chains_of_matrix_vector_products_give_the_same_solution(gpu, pkg, O, ki
     assert r0["backward_error"] <= lim and r1["backward_error"] <= lim
     assert np.max(np.abs(x1 - x0)) <= 1e-12 * np.max(np.abs(x0))
     assert np.max(np.abs(x1 - xs) / np.abs(xs)) < 1e-10
-    # the chains belong to the factors: a second solve reuses them, the transposed system keeps its substitution steps
+    # the chains belong to the factors: a second solve reuses them; the transposed system (A^H x = b for complex
+    # matrices) builds a set of its own at its first solve — the same construction on U^H and L^H
     x2 = U.linearSolve_(f1, U.UmfpackNormal, A, b)
     assert np.array_equal(x1, x2) and f1.solve_report["chain_build_ms"] == r1["chain_build_ms"]
-    St = sp.csc_matrix(S.conj().T)
-    bt = np.asarray(St @ xs).ravel()
-    xt0 = U.linearSolve_(f0, U.UmfpackTrans, A, bt)
     xt1 = U.linearSolve_(f1, U.UmfpackTrans, A, bt)
+    rt = f1.solve_report
+    assert rt["backward_error"] <= lim
     assert np.max(np.abs(xt1 - xt0)) <= 1e-12 * np.max(np.abs(xt0))
+    assert np.max(np.abs(xt1 - xs) / np.abs(xs)) < 1e-10
+    if kind in ("unsymmetric", "pivoted"):  # (symmetric factors serve A^T x = b with the untransposed kernels)
+        assert rt["chain_bytes"] == 2 * r1["chain_bytes"] and rt["chain_build_ms"] > r1["chain_build_ms"]
 
 
 @pytest.mark.parametrize("kind", ["symmetric", "unsymmetric", "complex"])
@@ -506,6 +513,9 @@ def test_chains_with_eight_and_sixteen_columns_give_the_same_solutions(gpu, pkg,
     f0 = U.factor(A, an)
     X0 = U.linearSolveMany_(f0, U.UmfpackNormal, A, bs)
     assert f0.solve_report["chain_span"] == 512 and f0.solve_report["backward_error"] <= 2.3e-16
+    St = sp.csc_matrix(S.conj().T)
+    bts = [np.asarray(St @ x).ravel() for x in xs]
+    T0 = U.linearSolveMany_(f0, U.UmfpackTrans, A, bts)
     monkeypatch.delenv("SPL_MF_CHAIN_MULTI")
     f1 = U.factor(A, an)
     X1 = U.linearSolveMany_(f1, U.UmfpackNormal, A, bs)
@@ -517,6 +527,12 @@ def test_chains_with_eight_and_sixteen_columns_give_the_same_solutions(gpu, pkg,
         assert np.max(np.abs(X1[j] - xs[j]) / np.abs(xs[j])) < 1e-10
         assert np.array_equal(Xd[j], X1[j])
     assert np.max(np.abs(one - X1[3])) <= 1e-12 * np.max(np.abs(one))
+    # ... and the transposed systems (their own chains, the transposed products of the bulk groups 256 columns at a time)
+    T1 = U.linearSolveMany_(f1, U.UmfpackTrans, A, bts)
+    assert f1.solve_report["backward_error"] <= 2.3e-16
+    for j in range(k):
+        assert np.max(np.abs(T1[j] - T0[j])) <= 1e-12 * np.max(np.abs(T0[j]))
+        assert np.max(np.abs(T1[j] - xs[j]) / np.abs(xs[j])) < 1e-10
 
 
 @pytest.mark.parametrize("unsym", [False, True])
