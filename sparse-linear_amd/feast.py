@@ -253,7 +253,8 @@ def geigSH_(params, m0, interval, matA, matB=None, guess=None):
             # the first point of the run alone: what a factorisation holds decides how many fit side by side (panels +
             # transient fronts + the work of the solves: taken as twice the resident bytes, against 80 % of the device)
             first = contour_point_on_this_stream(0)
-            fit = int(0.8 * torch.cuda.get_device_properties(dev).total_memory // max(2.0 * held[0], 1.0))
+            # (mem_get_info: one runtime call; get_device_properties initialises the SMI library first, 27 ms)
+            fit = int(0.8 * torch.cuda.mem_get_info(dev)[1] // max(2.0 * held[0], 1.0))
             if fit < 2:
                 pool = None
             else:
