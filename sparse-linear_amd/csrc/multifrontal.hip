@@ -1090,7 +1090,7 @@ struct Factors {
     DBuf<int64_t> off;      // per front (see chain::View)
     // the flat grids of the chain launches: per depth, [pass 0 = forward, 1 = backward][launch 0 .. steps][count + 1]
     struct Level {
-      int steps = 0, count = 0;
+      int steps = 0, count = 0, row_blocks = 1;
       // rows of a block per lead workgroup: chain::kRows, or rows_wide() on the levels of small pivot blocks; [1]: with 16
       // right-hand-side columns (workgroups of 8 wavefronts): half of that, and 64
       int lead_rows[2] = {0, 0};
@@ -1857,7 +1857,11 @@ static void build_chain_t(const mf::Factors &F, hipStream_t s) {
     L.lead_rows[1] = maxnp <= chain::kWidePivots ? 64 : chain::kRows / 2;
     L.base = Cn.h.size();
     Cn.h.resize(Cn.h.size() + (size_t)4 * (size_t)(L.steps + 1) * (size_t)(L.count + 1), 0);
-    const int rbk = F.lp->big[(size_t)d].row_blocks;
+    // blocks of 64 rows per bulk workgroup: ONE (the substitution steps take four on the levels that fill the chip, because
+    // every workgroup of theirs redoes the solve inside the super block first; a bulk group of a chain only loads the
+    // solved block — and the root front of config C5 has a hundred groups of four blocks per launch for 256 CUs)
+    const int rbk = getenv("SPL_MF_CHAIN_RB") ? std::max(1, atoi(getenv("SPL_MF_CHAIN_RB"))) : 1;
+    L.row_blocks = rbk;
     for (int pc = 0; pc < 4; ++pc)
       for (int l = 0; l <= L.steps; ++l) {
         const int pass = pc & 1, lead_rows = L.lead_rows[pc >> 1];
@@ -1965,7 +1969,7 @@ static void launch_big_chain(const mf::Factors &F, int depth, double *work, doub
     const unsigned groups = (unsigned)Cn.h[at + (size_t)L.count];
     if (groups > 0)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(big_chain_kernel<MODE, NR, Z>), dim3(groups), dim3(solve_waves<NR>() * 64), lds, s,
-                         B.list.get(), Cn.d.get() + at, B.count, l, F.view, cv, work, zbuf, B.row_blocks, L.lead_rows[cls], x, xstride);
+                         B.list.get(), Cn.d.get() + at, B.count, l, F.view, cv, work, zbuf, L.row_blocks, L.lead_rows[cls], x, xstride);
   }
 }
 
