@@ -514,7 +514,7 @@ __device__ __forceinline__ void chain_bulk_rows(const Band &b, int rb, int cb, i
 }
 
 template <int MODE, int NR, bool Z = false>
-__global__ __launch_bounds__(solve_waves<NR>() * 64) void big_chain_kernel(const int *__restrict__ list,
+__global__ __launch_bounds__(solve_waves<NR>() * 64) __attribute__((amdgpu_waves_per_eu((NR == 1 && MODE <= 1) ? 8 : 4, 8))) void big_chain_kernel(const int *__restrict__ list,
                                                                            const int64_t *__restrict__ prefix, int count,
                                                                            int launch, TreeView t, chain::View cv,
                                                                            double *work, double *zbuf, int row_blocks,
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(solve_waves<NR>() * 64) void big_chain_kernel(const
     if constexpr (NR > 2) {
       chain_lead_multi<NR, Z>(b, cv, fwd, fwd ? launch : K - 1 - launch, S, b.blk, lead_rows, in, out, out, sink, dsm);
     } else {
-      chain_lead<NR, Z, 2>(b, cv, fwd, fwd ? launch : K - 1 - launch, S, b.blk, in, out, out, sink, dsm);  // (wide levels: big_chain_wide_kernel)
+      chain_lead<NR, Z, 2, 4>(b, cv, fwd, fwd ? launch : K - 1 - launch, S, b.blk, in, out, out, sink, dsm);  // (wide levels: big_chain_wide_kernel)
     }
     return;
   }
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(solve_waves<NR>() * 64) void big_chain_kernel(const
     const int rb = fwd ? j0 + 2 * S + blk * 64 : j0 - S - (blk + 1) * 64;
     if (fwd ? rb >= n : rb + 64 <= 0) break;  // workgroup-uniform
     if constexpr (NR <= 2 && MODE <= 1) {
-      chain_bulk_rows<NR, Z, (Z ? 16 : 32)>(band, rb, j0, jbs, v, in, stride, fwd, part);
+      chain_bulk_rows<NR, Z, 16>(band, rb, j0, jbs, v, in, stride, fwd, part);
     } else {
       // (the transposed products of gemv64 take at most SB * NB = 256 columns at a time with fewer than 16 columns of right-hand sides)
       constexpr int kMost = (MODE >= 2 && !tile_rows_on_lanes<NR>()) ? SB * NB : 1 << 30;
