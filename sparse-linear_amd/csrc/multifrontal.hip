@@ -823,7 +823,10 @@ constexpr int kGemvChunk = 512;
 // config C5 where the backward pass, whose boundary product always was a kernel of its own, reaches 3.2 - 3.9.  Now the
 // steps stay inside the pivot block and the nb x np panel below it is streamed once, by this kernel, with every CU on it.
 template <int NR, bool Z = false, bool FWD = false>
-__global__ __launch_bounds__(gemv_waves<NR>() * 64) void big_gemv_chunk_kernel(const int *__restrict__ list,
+// (up to eight columns: at most 64 registers, so that two workgroups of 16 wavefronts share a CU — the complex backward
+// product took 66, the products with eight columns 66 - 68)
+__global__ __launch_bounds__(gemv_waves<NR>() * 64) __attribute__((amdgpu_waves_per_eu(NR <= 8 ? 8 : 2, 8)))
+void big_gemv_chunk_kernel(const int *__restrict__ list,
                                                                                const int64_t *__restrict__ prefix, int count,
                                                                                TreeView t, double *work, double *zbuf,
                                                                                const int64_t *__restrict__ pofs,
