@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void mid_trsm_kernel(const int *__restrict__ l
 }
 
 template <bool Z>
-__global__ __launch_bounds__(256) void mid_update_kernel(const int *__restrict__ list,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Z ? 1 : 3, 8))) void mid_update_kernel(const int *__restrict__ list,
                                                          const int64_t *__restrict__ prefix, int count, int step,
                                                          TreeView t, double *__restrict__ invs,
                                                          int *__restrict__ singular, int paired) {
